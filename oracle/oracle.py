@@ -1,0 +1,271 @@
+"""NumPy front-end to the CPU oracle (oracle/fi_oracle.c) plus restatements of the
+Python-level wrappers of the reference hot path.
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg.  The product package never imports this module.
+
+Reference citations are relative to the reference checkout (lib/...).
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libfi_oracle.so")
+_lib = None
+
+_f32p = ctypes.POINTER(ctypes.c_float)
+_i32p = ctypes.POINTER(ctypes.c_int32)
+_i64p = ctypes.POINTER(ctypes.c_int64)
+
+
+def build(force=False):
+    """Compile oracle/fi_oracle.c with gcc (see oracle/Makefile)."""
+    src = os.path.join(_HERE, "fi_oracle.c")
+    if force or (not os.path.exists(_LIB_PATH)) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B"])
+    return _LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = ctypes.CDLL(_LIB_PATH)
+        L.orc_crop_and_resize_forward.restype = ctypes.c_int
+        L.orc_crop_and_resize_backward.restype = ctypes.c_int
+        L.orc_crop_taps.restype = ctypes.c_int
+        L.orc_roi_pool_forward.restype = ctypes.c_int
+        L.orc_roi_pool_backward.restype = ctypes.c_int
+        L.orc_nms.restype = ctypes.c_long
+        L.orc_sinkhorn.restype = ctypes.c_float
+        L.orc_class_mean.restype = ctypes.c_int
+        L.orc_num_threads.restype = ctypes.c_int
+        _lib = L
+    return _lib
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _p(a, t):
+    return a.ctypes.data_as(t)
+
+
+def num_threads():
+    return int(lib().orc_num_threads())
+
+
+# ----------------------------------------------------------------------------
+# crop_and_resize (lib/roi_align/src/crop_and_resize.c)
+# ----------------------------------------------------------------------------
+def crop_and_resize_forward(image, boxes, box_ind, crop_h, crop_w, extrapolation_value=0.0):
+    image, boxes, box_ind = _f32(image), _f32(boxes), _i32(box_ind)
+    B, C, H, W = image.shape
+    N = boxes.shape[0]
+    crops = np.empty((N, C, crop_h, crop_w), np.float32)
+    rc = lib().orc_crop_and_resize_forward(
+        _p(image, _f32p), B, C, H, W, _p(boxes, _f32p), _p(box_ind, _i32p), N,
+        int(crop_h), int(crop_w), ctypes.c_float(extrapolation_value), _p(crops, _f32p))
+    if rc != 0:
+        raise RuntimeError("oracle crop_and_resize_forward: status %d" % rc)
+    return crops
+
+
+def crop_and_resize_backward(grads, boxes, box_ind, image_shape):
+    grads, boxes, box_ind = _f32(grads), _f32(boxes), _i32(box_ind)
+    B, C, H, W = image_shape
+    N, C2, ch, cw = grads.shape
+    assert C2 == C
+    out = np.empty((B, C, H, W), np.float32)
+    rc = lib().orc_crop_and_resize_backward(
+        _p(grads, _f32p), _p(boxes, _f32p), _p(box_ind, _i32p), N, B, C, H, W, ch, cw,
+        _p(out, _f32p))
+    if rc != 0:
+        raise RuntimeError("oracle crop_and_resize_backward: status %d" % rc)
+    return out
+
+
+def crop_taps(boxes, H, W, crop_h, crop_w):
+    """Bin assignment only: dict of [N,crop] arrays per axis."""
+    boxes = _f32(boxes)
+    N = boxes.shape[0]
+    yv, y0, y1 = (np.empty((N, crop_h), np.int32) for _ in range(3))
+    xv, x0, x1 = (np.empty((N, crop_w), np.int32) for _ in range(3))
+    yf = np.empty((N, crop_h), np.float32)
+    xf = np.empty((N, crop_w), np.float32)
+    rc = lib().orc_crop_taps(_p(boxes, _f32p), N, H, W, crop_h, crop_w,
+                             _p(yv, _i32p), _p(y0, _i32p), _p(y1, _i32p), _p(yf, _f32p),
+                             _p(xv, _i32p), _p(x0, _i32p), _p(x1, _i32p), _p(xf, _f32p))
+    assert rc == 0
+    return dict(y_valid=yv, y0=y0, y1=y1, y_frac=yf, x_valid=xv, x0=x0, x1=x1, x_frac=xf)
+
+
+def roi_align_boxes(boxes_xyxy, H, W, crop_h, crop_w, transform_fpcoor=True):
+    """Pixel (x1,y1,x2,y2) -> normalised (y1,x1,y2,x2) exactly as RoIAlign.forward,
+    lib/roi_align/roi_align.py:26-45 (fp32 elementwise arithmetic in that order)."""
+    b = _f32(boxes_xyxy)
+    x1, y1, x2, y2 = (b[:, i:i + 1] for i in range(4))
+    f = np.float32
+    if transform_fpcoor:
+        sw = (x2 - x1) / f(crop_w)
+        sh = (y2 - y1) / f(crop_h)
+        nx0 = (x1 + sw / f(2) - f(0.5)) / f(W - 1)
+        ny0 = (y1 + sh / f(2) - f(0.5)) / f(H - 1)
+        nw = sw * f(crop_w - 1) / f(W - 1)
+        nh = sh * f(crop_h - 1) / f(H - 1)
+        out = np.concatenate((ny0, nx0, ny0 + nh, nx0 + nw), 1)
+    else:
+        out = np.concatenate((y1 / f(H - 1), x1 / f(W - 1), y2 / f(H - 1), x2 / f(W - 1)), 1)
+    return out.astype(np.float32)
+
+
+# ----------------------------------------------------------------------------
+# RoIPool (lib/roi_pooling/src/roi_pooling_kernel.cu)
+# ----------------------------------------------------------------------------
+def roi_pool_forward(features, rois, ph, pw, scale):
+    features, rois = _f32(features), _f32(rois)
+    B, C, H, W = features.shape
+    N = rois.shape[0]
+    assert rois.shape[1] == 5
+    out = np.empty((N, C, ph, pw), np.float32)
+    arg = np.empty((N, C, ph, pw), np.int32)
+    rc = lib().orc_roi_pool_forward(_p(features, _f32p), B, C, H, W, _p(rois, _f32p), N,
+                                    ph, pw, ctypes.c_float(scale), _p(out, _f32p), _p(arg, _i32p))
+    assert rc == 0
+    return out, arg
+
+
+def roi_pool_backward(top_grad, argmax, rois, feature_shape, scale):
+    top_grad, rois, argmax = _f32(top_grad), _f32(rois), _i32(argmax)
+    B, C, H, W = feature_shape
+    N, _, ph, pw = top_grad.shape
+    out = np.empty((B, C, H, W), np.float32)
+    rc = lib().orc_roi_pool_backward(_p(top_grad, _f32p), _p(argmax, _i32p), _p(rois, _f32p), N,
+                                     B, C, H, W, ph, pw, ctypes.c_float(scale), _p(out, _f32p))
+    assert rc == 0
+    return out
+
+
+# ----------------------------------------------------------------------------
+# NMS (lib/nms/src/nms.c, lib/nms/pth_nms.py, lib/nms/nms_wrapper.py)
+# ----------------------------------------------------------------------------
+def nms_core(boxes, order, areas, thresh, strict=False):
+    boxes = _f32(boxes)
+    order = np.ascontiguousarray(order, dtype=np.int64)
+    areas = _f32(areas)
+    N, dim = boxes.shape
+    keep = np.empty((N,), np.int64)
+    n = lib().orc_nms(_p(boxes, _f32p), N, dim, _p(order, _i64p), _p(areas, _f32p),
+                      ctypes.c_float(thresh), int(bool(strict)), _p(keep, _i64p))
+    return keep[:n].copy()
+
+
+def pth_nms(dets, thresh, strict=False):
+    """dets [N,5] = (y1,x1,y2,x2,score): lib/nms/pth_nms.py:5-19 (CPU branch): areas
+    in fp32 with the +1 convention, order = scores sorted descending, then cpu_nms.
+    A stable descending sort is used; both reference call sites pass unique,
+    pre-sorted scores (lib/layers.py:103-105, 690-691)."""
+    dets = _f32(dets)
+    x1, y1, x2, y2 = dets[:, 1], dets[:, 0], dets[:, 3], dets[:, 2]
+    one = np.float32(1)
+    areas = (x2 - x1 + one) * (y2 - y1 + one)
+    order = np.argsort(-dets[:, 4], kind="stable")
+    return nms_core(dets, order, areas, thresh, strict)
+
+
+def nms(dets, thresh, strict=False):
+    """Batched wrapper, lib/nms/nms_wrapper.py:14-34: per image, truncate every
+    image to the shortest keep list, int32 [bs, min_keep]."""
+    keeps = [pth_nms(d, thresh, strict) for d in dets]
+    m = min(len(k) for k in keeps) if keeps else 0
+    out = np.zeros((len(keeps), m), np.int32)
+    for i, k in enumerate(keeps):
+        out[i] = k[:m]
+    return out
+
+
+# ----------------------------------------------------------------------------
+# OT intertwiner loss (lib/OT_module.py)
+# ----------------------------------------------------------------------------
+def sinkhorn(x, y, eps_inv=1.0, L=5, c_form="cosine", return_plan=False):
+    x, y = _f32(x), _f32(y)
+    S, D = x.shape
+    assert y.shape == (S, D)
+    plan = np.empty((S, S), np.float32) if return_plan else None
+    v = lib().orc_sinkhorn(_p(x, _f32p), _p(y, _f32p), S, D, ctypes.c_float(eps_inv), int(L),
+                           1 if c_form == "l2" else 0,
+                           _p(plan, _f32p) if return_plan else None)
+    return (np.float32(v), plan) if return_plan else np.float32(v)
+
+
+def conv1d_same_k3(x, weight, bias):
+    """nn.Conv1d(k=3, padding=1, stride=1) on x [n, Cin, Lx] (lib/OT_module.py:37-41,
+    58-63).  float64 accumulation, fp32 result."""
+    x = _f32(x)
+    n, cin, lx = x.shape
+    xp = np.zeros((n, cin, lx + 2), np.float64)
+    xp[:, :, 1:-1] = x
+    w = weight.astype(np.float64)
+    out = np.zeros((n, w.shape[0], lx), np.float64)
+    for k in range(3):
+        out += np.einsum("oc,ncl->nol", w[:, :, k], xp[:, :, k:k + lx])
+    out += bias.astype(np.float64)[None, :, None]
+    return out.astype(np.float32)
+
+
+def opttrans_1d_forward(x, y, g_w, g_b, c_w, c_b, epsilon=1.0, L=5, c_form="cosine",
+                        remove_bias=False, return_terms=False):
+    """OptTrans.forward for the 1-D ('conv') form, lib/OT_module.py:67-102:
+    x_up = relu(G_net(x)); T(p,q) = [sinkhorn(critic(p)[i], critic(q)[i]) for i];
+    loss = 2 T(x_up,y) - T(x_up,x_up) - T(y,y)  (or T(x_up,y) if remove_bias)."""
+    relu = lambda t: np.maximum(t, np.float32(0))
+    x_up = relu(conv1d_same_k3(x, g_w, g_b))
+
+    def term(p, q):
+        cp = relu(conv1d_same_k3(p, c_w, c_b))   # [n, ch/4, L]  -> samples = channels
+        cq = relu(conv1d_same_k3(q, c_w, c_b))
+        return np.array([sinkhorn(cp[i], cq[i], 1.0 / epsilon, L, c_form) for i in range(cp.shape[0])],
+                        np.float32)
+
+    t_xy = term(x_up, y)
+    if remove_bias:
+        return (t_xy, (t_xy,)) if return_terms else t_xy
+    t_xx = term(x_up, x_up)
+    t_yy = term(_f32(y), _f32(y))
+    loss = np.float32(2) * t_xy - t_xx - t_yy
+    return (loss, (t_xy, t_xx, t_yy)) if return_terms else loss
+
+
+def class_mean(features, gt, num_classes):
+    features, gt = _f32(features), _i32(gt)
+    N, F = features.shape
+    feat = np.empty((F, num_classes), np.float32)
+    cnt = np.empty((num_classes,), np.float32)
+    rc = lib().orc_class_mean(_p(features, _f32p), _p(gt, _i32p), N, F, num_classes,
+                              _p(feat, _f32p), _p(cnt, _f32p))
+    assert rc == 0
+    return feat, cnt.reshape(1, num_classes)
+
+
+def roi_level(rois, image_area, base=224.0):
+    """Pyramid level assignment, lib/sub_module.py:396-410 == lib/layers.py:168-181:
+    clamp(round(4 + log2(sqrt(h*w) / (base / sqrt(image_area)))), 2, 5) in fp32.
+    torch.round is round-half-to-even (as np.rint)."""
+    r = _f32(rois)
+    h = r[..., 2] - r[..., 0]
+    w = r[..., 3] - r[..., 1]
+    f = np.float32
+    ratio = np.sqrt(h * w) / (f(base) / np.sqrt(f(image_area)))
+    with np.errstate(divide="ignore"):
+        lvl = f(4) + (np.log(ratio) / np.log(f(2))).astype(np.float32)
+    lvl = np.rint(lvl)
+    lvl = np.where(np.isfinite(lvl), lvl, -1e9)
+    return np.clip(lvl, 2, 5).astype(np.int32)
