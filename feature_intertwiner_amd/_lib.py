@@ -1,0 +1,124 @@
+"""ctypes binding of libfi_hip.so (the C ABI declared in include/fi_capi.h).
+
+The product path has NO fallback: if the shared library is missing or fails to
+load, importing any operator raises.  torch is imported first on purpose so that
+the HIP runtime already resident in the process (torch's bundled libamdhip64,
+soname libamdhip64.so.7) is the one our library binds to -- device pointers and
+streams are then shared between torch and the kernels.
+"""
+import ctypes
+import os
+
+import torch  # noqa: F401  (must precede the CDLL below, see module docstring)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfi_hip.so")
+
+c_int = ctypes.c_int
+c_float = ctypes.c_float
+c_void_p = ctypes.c_void_p
+c_size_t = ctypes.c_size_t
+c_char_p = ctypes.c_char_p
+_pp = ctypes.POINTER(ctypes.c_void_p)
+_ip = ctypes.POINTER(ctypes.c_int)
+
+# name -> (restype, argtypes); mirrors include/fi_capi.h one to one
+SIGNATURES = {
+    "fi_version": (c_char_p, []),
+    "fi_last_error": (c_char_p, []),
+    "fi_crop_and_resize_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                           c_int, c_int, c_int, c_float, c_void_p, c_void_p,
+                                           c_void_p]),
+    "fi_crop_and_resize_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                            c_int, c_int, c_int, c_void_p, c_void_p]),
+    "fi_crop_and_resize_taps": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int] +
+                                [c_void_p] * 8 + [c_void_p]),
+    "fi_pyramid_crop_forward": (c_int, [_pp, _ip, _ip, c_int, c_void_p, c_void_p, c_void_p, c_int,
+                                        c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p]),
+    "fi_pyramid_crop_backward": (c_int, [c_void_p, _pp, _ip, _ip, c_int, c_void_p, c_void_p,
+                                         c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "fi_roi_pool_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
+                                    c_int, c_float, c_void_p, c_void_p, c_void_p]),
+    "fi_roi_pool_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                     c_int, c_int, c_float, c_void_p, c_void_p]),
+    "fi_nms_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "fi_nms_sorted": (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_int, c_int, c_void_p,
+                              c_void_p, c_void_p, c_void_p]),
+    "fi_sinkhorn_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_int, c_int,
+                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "fi_class_mean_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,
+                                      c_void_p]),
+    "fi_class_mean_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p,
+                                       c_void_p]),
+    "fi_prof_enable": (None, [c_int]),
+    "fi_prof_reset": (None, []),
+    "fi_prof_get": (c_int, [c_int, _ip, ctypes.POINTER(c_float)]),
+    "fi_prof_kernel_name": (c_char_p, [c_int]),
+}
+
+KERNEL_IDS = {
+    "crop_fwd": 0, "crop_bwd": 1, "roipool_fwd": 2, "roipool_bwd": 3, "nms_mask": 4,
+    "nms_scan": 5, "sinkhorn": 6, "class_mean": 7, "pyramid_crop_fwd": 8, "pyramid_crop_bwd": 9,
+}
+
+_lib = None
+
+
+class FiError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libfi_hip.so and attach the signatures.  Raises if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FiError(
+            "libfi_hip.so not found at %s -- build it with "
+            "`python -m feature_intertwiner_amd.build` (there is no CPU/PyTorch fallback)" % LIB_PATH)
+    L = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(L, name)  # AttributeError if the library lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().fi_last_error().decode("utf-8", "replace")
+        raise FiError("%s failed (status %d): %s" % (what, rc, msg))
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def current_stream():
+    """hipStream_t of torch's current stream on the current device."""
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise FiError("feature_intertwiner_amd operators run on the GPU only "
+                          "(got a %s tensor); there is no CPU fallback" % t.device)
+
+
+def prof_enable(on=True):
+    load().fi_prof_enable(1 if on else 0)
+
+
+def prof_reset():
+    load().fi_prof_reset()
+
+
+def prof_get(name):
+    n = ctypes.c_int(0)
+    ms = ctypes.c_float(0.0)
+    check(load().fi_prof_get(KERNEL_IDS[name], ctypes.byref(n), ctypes.byref(ms)), "fi_prof_get")
+    return n.value, ms.value

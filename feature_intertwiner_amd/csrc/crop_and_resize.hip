@@ -1,0 +1,449 @@
+// crop_and_resize.hip -- RoIAlign (single bilinear tap per bin), forward/backward,
+// single-level and pyramid (all FPN levels in one launch) forms, for gfx950.
+//
+// Arithmetic specification: lib/roi_align/src/crop_and_resize.c:31-110 (forward)
+// and :190-251 (backward) of the reference -- see oracle/fi_oracle.c, which this
+// file is tested against bit for bit (bin assignment) / exactly (forward values).
+//
+// Design (not a translation of the reference's one-thread-per-output kernel):
+//   * one 256-thread workgroup = one RoI x one channel chunk; the RoI's sampling
+//     table (tap rows/cols, lerp weights, in-range flags) is computed ONCE per
+//     workgroup by crop_h + crop_w lanes and parked in LDS, instead of being
+//     re-derived (2 divisions, 10 flops) for each of the C*ch*cw outputs;
+//   * channel chunks are the fast grid index and their count is a multiple of 8
+//     where possible, so that (with the observed block -> XCD = block % 8
+//     round-robin) each XCD's private L2 only ever sees one slice of the channel
+//     planes, and all RoIs that overlap in space share those lines in one L2;
+//   * output addresses are contiguous in the flat (channel, y, x) index, so every
+//     wavefront store is a fully coalesced 256-byte write; the 4 gathers per output
+//     are issued for 4 outputs at a time (16 loads in flight per lane);
+//   * crop sizes 7, 14, 28 (every size the model uses) are compile-time so the
+//     flat-index -> (c, y, x) split is multiply-shift, not integer division;
+//   * every output element is written (zeros / extrapolation value included), so
+//     the reference's separate 25..100 MB zero-fill pass disappears.
+#include "fi_common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kMaxCrop = 64;   // LDS table entries per axis
+constexpr int kMaxLevels = 8;
+
+struct Tap {
+    int i0;      // floorf(coord)
+    int i1;      // ceilf(coord)
+    float frac;  // coord - i0
+    int valid;   // 0 when coord is outside [0, extent-1]
+};
+
+struct LevelSet {
+    const float *img[kMaxLevels];
+    int H[kMaxLevels];
+    int W[kMaxLevels];
+    int n;
+};
+
+struct LevelSetMut {
+    float *img[kMaxLevels];
+    int H[kMaxLevels];
+    int W[kMaxLevels];
+    int n;
+};
+
+// Sampling coordinate k of one axis.  Mirrors the operation order of the
+// reference exactly (each * / + rounded to fp32; the crop == 1 case goes through
+// double because of the 0.5 literal) -- oracle: orc_axis_taps().
+__device__ __forceinline__ Tap make_tap(float lo, float hi, int extent, int crop, int k)
+{
+    const float span = (float)(extent - 1);
+    float c;
+    if (crop > 1) {
+        const float d = hi - lo;
+        const float m = d * span;
+        const float step = m / (float)(crop - 1);
+        const float base = lo * span;
+        const float off = (float)k * step;
+        c = base + off;
+    } else {
+        const float s = lo + hi;
+        const double dc = 0.5 * (double)s * (double)(extent - 1);
+        c = (float)dc;
+    }
+    Tap t;
+    if (c < 0.0f || c > span) {
+        t.valid = 0;
+        t.i0 = 0;
+        t.i1 = 0;
+        t.frac = 0.0f;
+    } else {
+        t.valid = 1;
+        t.i0 = (int)floorf(c);
+        t.i1 = (int)ceilf(c);
+        t.frac = c - (float)t.i0;  // via the int, as the reference: keeps -0.0 - 0 == -0.0
+    }
+    return t;
+}
+
+// Resolve the (uniform) per-workgroup box header.  Returns false when the box has
+// no valid source (bad image index or level): the caller writes zeros.
+struct BoxHeader {
+    int lvl, H, W, img;
+    float y1, x1, y2, x2;
+};
+
+template <typename LS>
+__device__ __forceinline__ bool load_box(const LS &ls, const float *__restrict__ boxes,
+                                         const int *__restrict__ box_ind,
+                                         const int *__restrict__ level, int box, int batch,
+                                         BoxHeader &h)
+{
+    h.lvl = level ? (level[box] - 2) : 0;
+    h.img = box_ind[box];
+    const bool ok = (h.lvl >= 0) && (h.lvl < ls.n) && (h.img >= 0) && (h.img < batch);
+    if (!ok) return false;
+    h.H = ls.H[h.lvl];
+    h.W = ls.W[h.lvl];
+    const float *b = boxes + 4 * (size_t)box;  // scalar loads: no alignment demand on callers
+    h.y1 = b[0];
+    h.x1 = b[1];
+    h.y2 = b[2];
+    h.x2 = b[3];
+    return true;
+}
+
+template <int CH, int CW>
+__global__ __launch_bounds__(kThreads) void crop_fwd_kernel(
+    LevelSet ls, const float *__restrict__ boxes, const int *__restrict__ box_ind,
+    const int *__restrict__ level, int num_boxes, int batch, int depth, int crop_h_rt,
+    int crop_w_rt, float extrap, int chan_per_block, int chunks, float *__restrict__ crops,
+    int *__restrict__ status)
+{
+    const int crop_h = CH ? CH : crop_h_rt;
+    const int crop_w = CW ? CW : crop_w_rt;
+    const int bins = crop_h * crop_w;
+    __shared__ Tap s_ty[kMaxCrop];
+    __shared__ Tap s_tx[kMaxCrop];
+
+    const int tid = threadIdx.x;
+    const int box = blockIdx.x / chunks;
+    const int chunk = blockIdx.x - box * chunks;
+    const int c_begin = chunk * chan_per_block;
+    const int c_count = min(chan_per_block, depth - c_begin);
+    const int total = c_count * bins;
+    float *__restrict__ out = crops + ((size_t)box * depth + c_begin) * bins;
+
+    BoxHeader h;
+    if (!load_box(ls, boxes, box_ind, level, box, batch, h)) {
+        for (int i = tid; i < total; i += kThreads) out[i] = 0.0f;
+        if (status && tid == 0 && chunk == 0) atomicOr(status, 1);
+        return;
+    }
+    if (tid < crop_h) s_ty[tid] = make_tap(h.y1, h.y2, h.H, crop_h, tid);
+    if (tid >= 64 && tid < 64 + crop_w) s_tx[tid - 64] = make_tap(h.x1, h.x2, h.W, crop_w, tid - 64);
+    __syncthreads();
+
+    const size_t plane = (size_t)h.H * (size_t)h.W;
+    const float *__restrict__ src = ls.img[h.lvl] + ((size_t)h.img * depth + c_begin) * plane;
+    const int W = h.W;
+
+    constexpr int UNROLL = 4;
+    for (int base = tid; base < total; base += kThreads * UNROLL) {
+        float tl[UNROLL], tr[UNROLL], bl[UNROLL], br[UNROLL], fx[UNROLL], fy[UNROLL];
+        int ok[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const int idx = base + u * kThreads;
+            ok[u] = 0;
+            tl[u] = tr[u] = bl[u] = br[u] = 0.0f;
+            fx[u] = fy[u] = 0.0f;
+            if (idx < total) {
+                const int c = idx / bins;
+                const int bin = idx - c * bins;
+                const int y = bin / crop_w;
+                const int x = bin - y * crop_w;
+                const Tap ty = s_ty[y];
+                const Tap tx = s_tx[x];
+                ok[u] = (ty.valid & tx.valid) ? 1 : 2;
+                if (ok[u] == 1) {
+                    const float *__restrict__ p = src + (size_t)c * plane;
+                    const int r0 = ty.i0 * W, r1 = ty.i1 * W;
+                    tl[u] = p[r0 + tx.i0];
+                    tr[u] = p[r0 + tx.i1];
+                    bl[u] = p[r1 + tx.i0];
+                    br[u] = p[r1 + tx.i1];
+                    fx[u] = tx.frac;
+                    fy[u] = ty.frac;
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const int idx = base + u * kThreads;
+            if (ok[u] == 1) {
+                const float dt = tr[u] - tl[u];
+                const float top = tl[u] + dt * fx[u];
+                const float db = br[u] - bl[u];
+                const float bot = bl[u] + db * fx[u];
+                const float dv = bot - top;
+                out[idx] = top + dv * fy[u];
+            } else if (ok[u] == 2) {
+                out[idx] = extrap;
+            }
+        }
+    }
+}
+
+template <int CH, int CW>
+__global__ __launch_bounds__(kThreads) void crop_bwd_kernel(
+    LevelSetMut ls, const float *__restrict__ grads, const float *__restrict__ boxes,
+    const int *__restrict__ box_ind, const int *__restrict__ level, int num_boxes, int batch,
+    int depth, int crop_h_rt, int crop_w_rt, int chan_per_block, int chunks)
+{
+    const int crop_h = CH ? CH : crop_h_rt;
+    const int crop_w = CW ? CW : crop_w_rt;
+    const int bins = crop_h * crop_w;
+    __shared__ Tap s_ty[kMaxCrop];
+    __shared__ Tap s_tx[kMaxCrop];
+
+    const int tid = threadIdx.x;
+    const int box = blockIdx.x / chunks;
+    const int chunk = blockIdx.x - box * chunks;
+    const int c_begin = chunk * chan_per_block;
+    const int c_count = min(chan_per_block, depth - c_begin);
+    const int total = c_count * bins;
+
+    BoxHeader h;
+    if (!load_box(ls, boxes, box_ind, level, box, batch, h)) return;
+    if (tid < crop_h) s_ty[tid] = make_tap(h.y1, h.y2, h.H, crop_h, tid);
+    if (tid >= 64 && tid < 64 + crop_w) s_tx[tid - 64] = make_tap(h.x1, h.x2, h.W, crop_w, tid - 64);
+    __syncthreads();
+
+    const size_t plane = (size_t)h.H * (size_t)h.W;
+    float *__restrict__ dst = ls.img[h.lvl] + ((size_t)h.img * depth + c_begin) * plane;
+    const float *__restrict__ g = grads + ((size_t)box * depth + c_begin) * bins;
+    const int W = h.W;
+
+    for (int idx = tid; idx < total; idx += kThreads) {
+        const int c = idx / bins;
+        const int bin = idx - c * bins;
+        const int y = bin / crop_w;
+        const int x = bin - y * crop_w;
+        const Tap ty = s_ty[y];
+        const Tap tx = s_tx[x];
+        if (!(ty.valid & tx.valid)) continue;
+        const float gv = g[idx];
+        float *__restrict__ p = dst + (size_t)c * plane;
+        // reference order: dtop = (1-ly)*g; TL += (1-lx)*dtop; TR += lx*dtop;
+        //                  dbot = ly*g;     BL += (1-lx)*dbot; BR += lx*dbot
+        const float wy0 = 1.0f - ty.frac;
+        const float wx0 = 1.0f - tx.frac;
+        const float gtop = wy0 * gv;
+        const float gbot = ty.frac * gv;
+        const int r0 = ty.i0 * W, r1 = ty.i1 * W;
+        atomicAdd(p + r0 + tx.i0, wx0 * gtop);
+        atomicAdd(p + r0 + tx.i1, tx.frac * gtop);
+        atomicAdd(p + r1 + tx.i0, wx0 * gbot);
+        atomicAdd(p + r1 + tx.i1, tx.frac * gbot);
+    }
+}
+
+__global__ void crop_taps_kernel(const float *__restrict__ boxes, int num_boxes, int H, int W,
+                                 int crop_h, int crop_w, int *y_valid, int *y0, int *y1,
+                                 float *y_frac, int *x_valid, int *x0, int *x1, float *x_frac)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int per_box = crop_h + crop_w;
+    if (i >= num_boxes * per_box) return;
+    const int box = i / per_box;
+    const int k = i - box * per_box;
+    const float *b = boxes + 4 * (size_t)box;
+    if (k < crop_h) {
+        const Tap t = make_tap(b[0], b[2], H, crop_h, k);
+        y_valid[box * crop_h + k] = t.valid;
+        y0[box * crop_h + k] = t.i0;
+        y1[box * crop_h + k] = t.i1;
+        y_frac[box * crop_h + k] = t.frac;
+    } else {
+        const int kx = k - crop_h;
+        const Tap t = make_tap(b[1], b[3], W, crop_w, kx);
+        x_valid[box * crop_w + kx] = t.valid;
+        x0[box * crop_w + kx] = t.i0;
+        x1[box * crop_w + kx] = t.i1;
+        x_frac[box * crop_w + kx] = t.frac;
+    }
+}
+
+// Channel chunking: prefer 8 chunks (one per XCD) of >= 8 channels; shrink the
+// chunk while the grid would not fill the chip (256 CUs x 8 workgroups).
+void pick_chunks(int num_boxes, int depth, int *chan_per_block, int *chunks)
+{
+    int cpb = fi::ceil_div(depth, 8);
+    if (cpb < 1) cpb = 1;
+    while (cpb > 8 && (long)num_boxes * fi::ceil_div(depth, cpb) < 2048) cpb = fi::ceil_div(cpb, 2);
+    *chan_per_block = cpb;
+    *chunks = fi::ceil_div(depth, cpb);
+}
+
+template <typename K, typename... Args>
+int launch_sized(int crop_h, int crop_w, K k77, K k1414, K k2828, K kgen, dim3 grid,
+                 hipStream_t st, Args... args)
+{
+    K k = kgen;
+    if (crop_h == 7 && crop_w == 7) k = k77;
+    else if (crop_h == 14 && crop_w == 14) k = k1414;
+    else if (crop_h == 28 && crop_w == 28) k = k2828;
+    hipLaunchKernelGGL(k, grid, dim3(kThreads), 0, st, args...);
+    FI_HIP_CHECK(hipGetLastError());
+    return FI_OK;
+}
+
+int check_common(int num_boxes, int batch, int depth, int crop_h, int crop_w)
+{
+    FI_REQUIRE(num_boxes >= 0 && batch > 0 && depth > 0, "sizes must be positive");
+    FI_REQUIRE(crop_h >= 1 && crop_w >= 1, "crop size must be >= 1");
+    if (crop_h > kMaxCrop || crop_w > kMaxCrop) {
+        fi::set_error("crop size %dx%d exceeds the supported maximum %d", crop_h, crop_w, kMaxCrop);
+        return FI_ERR_UNSUPPORTED;
+    }
+    return FI_OK;
+}
+
+int forward_impl(const LevelSet &ls, const float *boxes, const int32_t *box_ind,
+                 const int32_t *level, int num_boxes, int batch, int depth, int crop_h, int crop_w,
+                 float extrap, float *crops, int32_t *status, hipStream_t st, int prof_id)
+{
+    if (num_boxes == 0) return FI_OK;
+    int cpb, chunks;
+    pick_chunks(num_boxes, depth, &cpb, &chunks);
+    const long nblk = (long)num_boxes * chunks;
+    FI_REQUIRE(nblk < 2147483647L, "grid too large");
+    fi::ProfScope prof(prof_id, st);
+    return launch_sized(crop_h, crop_w, crop_fwd_kernel<7, 7>, crop_fwd_kernel<14, 14>,
+                        crop_fwd_kernel<28, 28>, crop_fwd_kernel<0, 0>, dim3((unsigned)nblk), st, ls,
+                        boxes, box_ind, level, num_boxes, batch, depth, crop_h, crop_w, extrap, cpb,
+                        chunks, crops, status);
+}
+
+int backward_impl(const LevelSetMut &ls, const float *grads, const float *boxes,
+                  const int32_t *box_ind, const int32_t *level, int num_boxes, int batch, int depth,
+                  int crop_h, int crop_w, hipStream_t st, int prof_id)
+{
+    for (int l = 0; l < ls.n; ++l) {
+        const size_t bytes = sizeof(float) * (size_t)batch * depth * ls.H[l] * ls.W[l];
+        FI_HIP_CHECK(hipMemsetAsync(ls.img[l], 0, bytes, st));
+    }
+    if (num_boxes == 0) return FI_OK;
+    int cpb, chunks;
+    pick_chunks(num_boxes, depth, &cpb, &chunks);
+    const long nblk = (long)num_boxes * chunks;
+    FI_REQUIRE(nblk < 2147483647L, "grid too large");
+    fi::ProfScope prof(prof_id, st);
+    return launch_sized(crop_h, crop_w, crop_bwd_kernel<7, 7>, crop_bwd_kernel<14, 14>,
+                        crop_bwd_kernel<28, 28>, crop_bwd_kernel<0, 0>, dim3((unsigned)nblk), st, ls,
+                        grads, boxes, box_ind, level, num_boxes, batch, depth, crop_h, crop_w, cpb,
+                        chunks);
+}
+
+}  // namespace
+
+extern "C" {
+
+int fi_crop_and_resize_forward(const float *image, const float *boxes, const int32_t *box_ind,
+                               int num_boxes, int batch, int depth, int image_h, int image_w,
+                               int crop_h, int crop_w, float extrapolation_value, float *crops,
+                               int32_t *dev_status, fi_stream_t stream)
+{
+    int rc = check_common(num_boxes, batch, depth, crop_h, crop_w);
+    if (rc != FI_OK) return rc;
+    FI_REQUIRE(image_h >= 1 && image_w >= 1, "image size must be positive");
+    FI_REQUIRE(num_boxes == 0 || (image && boxes && box_ind && crops), "null pointer");
+    LevelSet ls = {};
+    ls.img[0] = image;
+    ls.H[0] = image_h;
+    ls.W[0] = image_w;
+    ls.n = 1;
+    return forward_impl(ls, boxes, box_ind, nullptr, num_boxes, batch, depth, crop_h, crop_w,
+                        extrapolation_value, crops, dev_status, (hipStream_t)stream, FI_K_CROP_FWD);
+}
+
+int fi_crop_and_resize_backward(const float *grads, const float *boxes, const int32_t *box_ind,
+                                int num_boxes, int batch, int depth, int image_h, int image_w,
+                                int crop_h, int crop_w, float *grads_image, fi_stream_t stream)
+{
+    int rc = check_common(num_boxes, batch, depth, crop_h, crop_w);
+    if (rc != FI_OK) return rc;
+    FI_REQUIRE(image_h >= 1 && image_w >= 1, "image size must be positive");
+    FI_REQUIRE(grads_image != nullptr, "null grads_image");
+    FI_REQUIRE(num_boxes == 0 || (grads && boxes && box_ind), "null pointer");
+    LevelSetMut ls = {};
+    ls.img[0] = grads_image;
+    ls.H[0] = image_h;
+    ls.W[0] = image_w;
+    ls.n = 1;
+    return backward_impl(ls, grads, boxes, box_ind, nullptr, num_boxes, batch, depth, crop_h, crop_w,
+                         (hipStream_t)stream, FI_K_CROP_BWD);
+}
+
+int fi_crop_and_resize_taps(const float *boxes, int num_boxes, int image_h, int image_w, int crop_h,
+                            int crop_w, int32_t *y_valid, int32_t *y0, int32_t *y1, float *y_frac,
+                            int32_t *x_valid, int32_t *x0, int32_t *x1, float *x_frac,
+                            fi_stream_t stream)
+{
+    FI_REQUIRE(num_boxes >= 0 && crop_h >= 1 && crop_w >= 1, "bad sizes");
+    if (num_boxes == 0) return FI_OK;
+    const int total = num_boxes * (crop_h + crop_w);
+    hipLaunchKernelGGL(crop_taps_kernel, dim3(fi::ceil_div(total, 256)), dim3(256), 0,
+                       (hipStream_t)stream, boxes, num_boxes, image_h, image_w, crop_h, crop_w,
+                       y_valid, y0, y1, y_frac, x_valid, x0, x1, x_frac);
+    FI_HIP_CHECK(hipGetLastError());
+    return FI_OK;
+}
+
+int fi_pyramid_crop_forward(const float *const *level_images_host, const int *level_h_host,
+                            const int *level_w_host, int num_levels, const float *boxes,
+                            const int32_t *box_ind, const int32_t *level, int num_boxes, int batch,
+                            int depth, int crop_h, int crop_w, float extrapolation_value,
+                            float *crops, fi_stream_t stream)
+{
+    int rc = check_common(num_boxes, batch, depth, crop_h, crop_w);
+    if (rc != FI_OK) return rc;
+    FI_REQUIRE(num_levels >= 1 && num_levels <= kMaxLevels, "1 <= num_levels <= 8");
+    FI_REQUIRE(level_images_host && level_h_host && level_w_host, "null level arrays");
+    FI_REQUIRE(num_boxes == 0 || (boxes && box_ind && level && crops), "null pointer");
+    LevelSet ls = {};
+    ls.n = num_levels;
+    for (int l = 0; l < num_levels; ++l) {
+        ls.img[l] = level_images_host[l];
+        ls.H[l] = level_h_host[l];
+        ls.W[l] = level_w_host[l];
+        FI_REQUIRE(ls.img[l] && ls.H[l] >= 1 && ls.W[l] >= 1, "bad level entry");
+    }
+    return forward_impl(ls, boxes, box_ind, level, num_boxes, batch, depth, crop_h, crop_w,
+                        extrapolation_value, crops, nullptr, (hipStream_t)stream,
+                        FI_K_PYRAMID_CROP_FWD);
+}
+
+int fi_pyramid_crop_backward(const float *grads, float *const *level_grads_host,
+                             const int *level_h_host, const int *level_w_host, int num_levels,
+                             const float *boxes, const int32_t *box_ind, const int32_t *level,
+                             int num_boxes, int batch, int depth, int crop_h, int crop_w,
+                             fi_stream_t stream)
+{
+    int rc = check_common(num_boxes, batch, depth, crop_h, crop_w);
+    if (rc != FI_OK) return rc;
+    FI_REQUIRE(num_levels >= 1 && num_levels <= kMaxLevels, "1 <= num_levels <= 8");
+    FI_REQUIRE(level_grads_host && level_h_host && level_w_host, "null level arrays");
+    FI_REQUIRE(num_boxes == 0 || (grads && boxes && box_ind && level), "null pointer");
+    LevelSetMut ls = {};
+    ls.n = num_levels;
+    for (int l = 0; l < num_levels; ++l) {
+        ls.img[l] = level_grads_host[l];
+        ls.H[l] = level_h_host[l];
+        ls.W[l] = level_w_host[l];
+        FI_REQUIRE(ls.img[l] && ls.H[l] >= 1 && ls.W[l] >= 1, "bad level entry");
+    }
+    return backward_impl(ls, grads, boxes, box_ind, level, num_boxes, batch, depth, crop_h, crop_w,
+                         (hipStream_t)stream, FI_K_PYRAMID_CROP_BWD);
+}
+
+}  // extern "C"

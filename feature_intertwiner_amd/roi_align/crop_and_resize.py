@@ -1,0 +1,120 @@
+"""Drop-in for lib/roi_align/crop_and_resize.py:14-54 of the reference.
+
+`CropAndResizeFunction(crop_height, crop_width, extrapolation_value=0)(image, boxes,
+box_ind)` keeps the reference's call shape (an instance that is then called); the
+autograd part is a new-style torch.autograd.Function because old-style instance
+Functions no longer exist.  Gradients flow to `image` only (reference :54).
+"""
+import torch
+
+from .. import _lib
+
+
+class _CropAndResize(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, image, boxes, box_ind, crop_height, crop_width, extrapolation_value):
+        _lib.require_cuda(image, boxes, box_ind)
+        L = _lib.load()
+        image = image.contiguous().float()
+        boxes_c = boxes.detach().contiguous().float()
+        ind_c = box_ind.detach().contiguous().to(torch.int32)
+        B, C, H, W = image.shape
+        N = boxes_c.shape[0]
+        crops = torch.empty((N, C, crop_height, crop_width), device=image.device, dtype=torch.float32)
+        with torch.cuda.device(image.device):
+            _lib.check(L.fi_crop_and_resize_forward(
+                _lib.ptr(image), _lib.ptr(boxes_c), _lib.ptr(ind_c), N, B, C, H, W,
+                int(crop_height), int(crop_width), float(extrapolation_value), _lib.ptr(crops),
+                None, _lib.current_stream()), "fi_crop_and_resize_forward")
+        ctx.im_size = (B, C, H, W)
+        ctx.crop = (int(crop_height), int(crop_width))
+        ctx.save_for_backward(boxes_c, ind_c)
+        return crops
+
+    @staticmethod
+    def backward(ctx, grad_outputs):
+        boxes_c, ind_c = ctx.saved_tensors
+        L = _lib.load()
+        g = grad_outputs.contiguous().float()
+        B, C, H, W = ctx.im_size
+        grad_image = torch.empty((B, C, H, W), device=g.device, dtype=torch.float32)
+        with torch.cuda.device(g.device):
+            _lib.check(L.fi_crop_and_resize_backward(
+                _lib.ptr(g), _lib.ptr(boxes_c), _lib.ptr(ind_c), boxes_c.shape[0], B, C, H, W,
+                ctx.crop[0], ctx.crop[1], _lib.ptr(grad_image), _lib.current_stream()),
+                "fi_crop_and_resize_backward")
+        return grad_image, None, None, None, None, None
+
+
+class CropAndResizeFunction(object):
+    """Single-tap bilinear crop (tf.image.crop_and_resize semantics)."""
+
+    def __init__(self, crop_height, crop_width, extrapolation_value=0):
+        self.crop_height = crop_height
+        self.crop_width = crop_width
+        self.extrapolation_value = extrapolation_value
+
+    def __call__(self, image, boxes, box_ind):
+        return _CropAndResize.apply(image, boxes, box_ind, self.crop_height, self.crop_width,
+                                    self.extrapolation_value)
+
+    forward = __call__
+
+
+class _PyramidCrop(torch.autograd.Function):
+    """All FPN levels in one launch (the callers' per-level loops, lib/layers.py:183-216 and
+    lib/sub_module.py:429-662, collapse into a precomputed `level` vector)."""
+
+    @staticmethod
+    def forward(ctx, boxes, box_ind, level, crop_height, crop_width, extrapolation_value, *maps):
+        import ctypes
+        _lib.require_cuda(boxes, box_ind, level, *maps)
+        L = _lib.load()
+        maps = [m.contiguous().float() for m in maps]
+        nl = len(maps)
+        B, C = maps[0].shape[:2]
+        boxes_c = boxes.detach().contiguous().float()
+        ind_c = box_ind.detach().contiguous().to(torch.int32)
+        lvl_c = level.detach().contiguous().to(torch.int32)
+        N = boxes_c.shape[0]
+        crops = torch.empty((N, C, crop_height, crop_width), device=boxes_c.device,
+                            dtype=torch.float32)
+        ptrs = (ctypes.c_void_p * nl)(*[m.data_ptr() for m in maps])
+        hs = (ctypes.c_int * nl)(*[m.shape[2] for m in maps])
+        ws = (ctypes.c_int * nl)(*[m.shape[3] for m in maps])
+        with torch.cuda.device(boxes_c.device):
+            _lib.check(L.fi_pyramid_crop_forward(
+                ptrs, hs, ws, nl, _lib.ptr(boxes_c), _lib.ptr(ind_c), _lib.ptr(lvl_c), N, B, C,
+                int(crop_height), int(crop_width), float(extrapolation_value), _lib.ptr(crops),
+                _lib.current_stream()), "fi_pyramid_crop_forward")
+        ctx.shapes = [tuple(m.shape) for m in maps]
+        ctx.crop = (int(crop_height), int(crop_width))
+        ctx.save_for_backward(boxes_c, ind_c, lvl_c)
+        return crops
+
+    @staticmethod
+    def backward(ctx, grad_outputs):
+        import ctypes
+        boxes_c, ind_c, lvl_c = ctx.saved_tensors
+        L = _lib.load()
+        g = grad_outputs.contiguous().float()
+        nl = len(ctx.shapes)
+        B, C = ctx.shapes[0][:2]
+        grads = [torch.empty(s, device=g.device, dtype=torch.float32) for s in ctx.shapes]
+        ptrs = (ctypes.c_void_p * nl)(*[t.data_ptr() for t in grads])
+        hs = (ctypes.c_int * nl)(*[s[2] for s in ctx.shapes])
+        ws = (ctypes.c_int * nl)(*[s[3] for s in ctx.shapes])
+        with torch.cuda.device(g.device):
+            _lib.check(L.fi_pyramid_crop_backward(
+                _lib.ptr(g), ptrs, hs, ws, nl, _lib.ptr(boxes_c), _lib.ptr(ind_c), _lib.ptr(lvl_c),
+                boxes_c.shape[0], B, C, ctx.crop[0], ctx.crop[1], _lib.current_stream()),
+                "fi_pyramid_crop_backward")
+        return (None, None, None, None, None, None) + tuple(grads)
+
+
+def pyramid_crop_and_resize(feature_maps, boxes, box_ind, level, crop_height, crop_width,
+                            extrapolation_value=0.0):
+    """crops[i] = crop of box i from feature_maps[level[i] - 2]; rows with a level
+    outside the pyramid are zero.  Output rows are in the order of `boxes`."""
+    return _PyramidCrop.apply(boxes, box_ind, level, crop_height, crop_width, extrapolation_value,
+                              *feature_maps)

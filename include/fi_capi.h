@@ -1,0 +1,228 @@
+/*
+ * fi_capi.h -- C ABI of libfi_hip.so, the MI355X (gfx950) implementation of the
+ * Feature Intertwiner hot-path operators.
+ *
+ * This is the drop-in boundary: plain device pointers, sizes and a HIP stream
+ * handle; no framework types.  Each entry point names the reference interface it
+ * replaces (paths relative to the reference checkout).  The reference built three
+ * torch.utils.ffi (cffi) extensions whose inner launchers already took raw device
+ * pointers + ints + a stream; those launchers are the level mirrored here.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in _host;
+ *   - tensors are fp32, contiguous, NCHW, exactly as in the reference;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream);
+ *     calls enqueue work and return without synchronising (the reference's NMS
+ *     performed a blocking D2H copy, lib/nms/src/nms_cuda.c:33-34 -- removed);
+ *   - the callee owns no persistent device memory: outputs and workspaces are
+ *     caller-allocated (sizes via the *_workspace_bytes helpers);
+ *   - return value: FI_OK (0) or a negative FI_ERR_* code; the library never
+ *     calls exit() (the reference launchers did: crop_and_resize_kernel.cu:186-191,
+ *     roi_pooling_kernel.cu:117-122).  fi_last_error() gives a thread-local
+ *     message for the last failing call;
+ *   - functions are re-entrant and device-agnostic: they launch on the device
+ *     that is current for the calling thread (as the reference did under
+ *     nn.DataParallel's one-thread-per-GPU model).
+ */
+#ifndef FI_CAPI_H_
+#define FI_CAPI_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FI_OK 0
+#define FI_ERR_INVALID_ARG (-1)
+#define FI_ERR_HIP (-2)          /* a HIP runtime call / launch failed          */
+#define FI_ERR_UNSUPPORTED (-3)  /* size outside what the kernels implement     */
+
+typedef void *fi_stream_t;
+
+/* Library identification: "fi_hip <version> gfx950". */
+const char *fi_version(void);
+/* Message for the most recent failing call on this thread ("" if none). */
+const char *fi_last_error(void);
+
+/* ------------------------------------------------------------------------
+ * crop_and_resize  (RoIAlign, one bilinear tap per bin)
+ * Replaces: crop_and_resize_gpu_forward   lib/roi_align/src/crop_and_resize_gpu.c:7-37
+ *           CropAndResizeLaucher          lib/roi_align/src/cuda/crop_and_resize_kernel.cu:168-193
+ *           (CPU twin crop_and_resize_forward, lib/roi_align/src/crop_and_resize.c:115-154,
+ *            defines the arithmetic: separately rounded fp32 mul/add, floorf/ceilf taps).
+ * image  [batch, depth, image_h, image_w]
+ * boxes  [num_boxes, 4] = (y1, x1, y2, x2), normalised: 0 -> row 0, 1 -> row H-1
+ * box_ind[num_boxes]   int32 image index of each box
+ * crops  [num_boxes, depth, crop_h, crop_w]  -- every element is written (the
+ *        reference zero-fills first, crop_and_resize_gpu.c:24-25; here the kernel
+ *        writes the zeros/extrapolation value itself).
+ * A box whose box_ind is outside [0, batch) produces zeros (GPU reference
+ * behaviour, crop_and_resize_kernel.cu:35-38) and, if dev_status != NULL, sets
+ * bit 0 of *dev_status (the CPU reference aborted: crop_and_resize.c:39-42).
+ * ---------------------------------------------------------------------- */
+int fi_crop_and_resize_forward(const float *image, const float *boxes,
+                               const int32_t *box_ind, int num_boxes, int batch,
+                               int depth, int image_h, int image_w, int crop_h,
+                               int crop_w, float extrapolation_value, float *crops,
+                               int32_t *dev_status, fi_stream_t stream);
+
+/* Replaces: crop_and_resize_gpu_backward  lib/roi_align/src/crop_and_resize_gpu.c:40-69
+ *           CropAndResizeBackpropImageLaucher  .../crop_and_resize_kernel.cu:196-221
+ * grads [num_boxes, depth, crop_h, crop_w] -> grads_image [batch, depth, H, W].
+ * grads_image is zero-filled by the call (crop_and_resize_gpu.c:57) and then
+ * accumulated with hardware fp32 atomics (summation order is not deterministic,
+ * as in the reference's atomicAdd kernel). */
+int fi_crop_and_resize_backward(const float *grads, const float *boxes,
+                                const int32_t *box_ind, int num_boxes, int batch,
+                                int depth, int image_h, int image_w, int crop_h,
+                                int crop_w, float *grads_image, fi_stream_t stream);
+
+/* Test hook: the bin assignment alone (tap rows/cols, lerp weights, in-range
+ * flags), so parity tests can require it bit-exact.  Outputs [num_boxes, crop]. */
+int fi_crop_and_resize_taps(const float *boxes, int num_boxes, int image_h,
+                            int image_w, int crop_h, int crop_w, int32_t *y_valid,
+                            int32_t *y0, int32_t *y1, float *y_frac,
+                            int32_t *x_valid, int32_t *x0, int32_t *x1,
+                            float *x_frac, fi_stream_t stream);
+
+/* Pyramid form: one launch over all FPN levels.  Replaces the per-level
+ * nonzero/gather/crop/cat/scatter loops of pyramid_roi_align (lib/layers.py:145-218)
+ * and Dev.forward + _reshape_result (lib/sub_module.py:429-662): box i is cropped
+ * from level_images_host[level[i] - 2] and written to row i of crops (original
+ * RoI order, so no scatter-back is needed).  level[i] outside [2, 2+num_levels)
+ * or a bad box_ind yields a zero row (the reference leaves unassigned rows zero).
+ * level_images_host / level_h_host / level_w_host are HOST arrays of num_levels
+ * entries (num_levels <= 8). */
+int fi_pyramid_crop_forward(const float *const *level_images_host,
+                            const int *level_h_host, const int *level_w_host,
+                            int num_levels, const float *boxes,
+                            const int32_t *box_ind, const int32_t *level,
+                            int num_boxes, int batch, int depth, int crop_h,
+                            int crop_w, float extrapolation_value, float *crops,
+                            fi_stream_t stream);
+
+/* Backward of the pyramid form; every level's gradient map is zero-filled first. */
+int fi_pyramid_crop_backward(const float *grads, float *const *level_grads_host,
+                             const int *level_h_host, const int *level_w_host,
+                             int num_levels, const float *boxes,
+                             const int32_t *box_ind, const int32_t *level,
+                             int num_boxes, int batch, int depth, int crop_h,
+                             int crop_w, fi_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * RoIPool (Caffe max pooling)
+ * Replaces: roi_pooling_forward_cuda   lib/roi_pooling/src/roi_pooling_cuda.c:7-47
+ *           ROIPoolForwardLaucher      lib/roi_pooling/src/roi_pooling_kernel.cu:95-125
+ * features [batch, channels, height, width]
+ * rois     [num_rois, 5] = (batch index, x1, y1, x2, y2) in pixels
+ * output, argmax [num_rois, channels, pooled_h, pooled_w]; argmax is the flat index
+ * into the whole features tensor, -1 for an empty bin (kernel.cu:73-86).
+ * ---------------------------------------------------------------------- */
+int fi_roi_pool_forward(const float *features, const float *rois, int num_rois,
+                        int batch, int channels, int height, int width,
+                        int pooled_h, int pooled_w, float spatial_scale,
+                        float *output, int32_t *argmax, fi_stream_t stream);
+
+/* Replaces: roi_pooling_backward_cuda  lib/roi_pooling/src/roi_pooling_cuda.c:49-88
+ *           ROIPoolBackwardLaucher     lib/roi_pooling/src/roi_pooling_kernel.cu:205-234
+ * bottom_grad [batch, channels, height, width] is zero-filled by the call, then
+ * every pooled cell scatters its gradient to its argmax (fp32 atomics) under the
+ * same feasibility conditions as the reference's gather (kernel.cu:147-190). */
+int fi_roi_pool_backward(const float *top_grad, const float *rois,
+                         const int32_t *argmax, int num_rois, int batch,
+                         int channels, int height, int width, int pooled_h,
+                         int pooled_w, float spatial_scale, float *bottom_grad,
+                         fi_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Greedy NMS on score-sorted boxes
+ * Replaces: gpu_nms  lib/nms/src/nms_cuda.c:17-67  +  _nms  lib/nms/src/cuda/nms_kernel.cu:73-83
+ *           cpu_nms  lib/nms/src/nms.c:4-69 (defines the `>=` comparison used when strict == 0)
+ * boxes   [batch, num_boxes, box_stride] fp32, rows sorted by DESCENDING score
+ *         (both reference callers pre-sort: lib/layers.py:103-105, 690-691);
+ *         columns 0..3 are the two corner points (x1,y1,x2,y2) or (y1,x1,y2,x2) --
+ *         IoU with the +1 pixel convention is symmetric in that choice;
+ *         box_stride >= 4 (5 for the reference's [.., score] rows).
+ * strict  0: suppress when IoU >= thresh (CPU reference, the parity spec);
+ *         1: suppress when IoU >  thresh (CUDA reference, nms_kernel.cu:63).
+ * max_keep  <= 0: keep everything; > 0: stop after max_keep survivors per image
+ *         (the caller truncates to proposal_count anyway, lib/layers.py:130).
+ * keep_out [batch, num_boxes] int64 indices into the sorted rows, in visit order;
+ *          entries past num_out[b] are left untouched.
+ * num_out  [batch] int32.
+ * workspace: fi_nms_workspace_bytes(batch, num_boxes) bytes (the suppression
+ *          bit-matrix; the reference allocated/freed it per call, nms_cuda.c:28-35).
+ * No host synchronisation: the greedy scan runs on the GPU.
+ * ---------------------------------------------------------------------- */
+size_t fi_nms_workspace_bytes(int batch, int num_boxes);
+int fi_nms_sorted(const float *boxes, int batch, int num_boxes, int box_stride,
+                  float thresh, int strict, int max_keep, int64_t *keep_out,
+                  int32_t *num_out, void *workspace, fi_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Sinkhorn term of the OT intertwiner loss (no native counterpart in the
+ * reference: lib/OT_module.py:104-135 runs 2L+6 small torch kernels per problem
+ * inside a Python loop over the batch, :100-101).
+ * x, y   [num_problems, S, D] fp32 (rows = samples, e.g. the 256 critic channels)
+ * cost_mode 0: cosine cost, rows normalised by (||row||_2 + 1e-20) inside (:110-113);
+ *         1: C_ij = ||x_i - y_j||_2 (:106-109);
+ *         2: C = 1 - x y^T on rows the caller already normalised (lets an autograd
+ *            wrapper own the normalisation and its backward)
+ * eps_inv = 1/epsilon (the module stores the inverse, :13), L iterations.
+ * loss   [num_problems]   <P, C> with P = a K b^T
+ * plan   [num_problems, S, S] or NULL: the transport plan P (treated as a
+ *        constant by the reference when no_bp_P_L, :129-131)
+ * xn_out, yn_out [num_problems, S, D] or NULL: when both non-NULL (cost_mode 0 only)
+ *        receive the normalised rows x^, y^ used for C.
+ * Supported: 1 <= S <= 256, D >= 1.
+ * ---------------------------------------------------------------------- */
+int fi_sinkhorn_forward(const float *x, const float *y, int num_problems, int S,
+                        int D, float eps_inv, int L, int cost_mode, float *loss,
+                        float *plan, float *xn_out, float *yn_out,
+                        fi_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Per-class feature mean of the intertwiner statistics.
+ * Replaces: Dev._assign_feat2cls  lib/sub_module.py:664-684 (Python loop over classes).
+ * features [N, F]; gt [N] int32 class ids (0 = background, skipped);
+ * feat [F, num_classes] (column c = mean of rows with class c, 0 if absent);
+ * cnt  [num_classes] fp32 counts.
+ * ---------------------------------------------------------------------- */
+int fi_class_mean_forward(const float *features, const int32_t *gt, int N, int F,
+                          int num_classes, float *feat, float *cnt,
+                          fi_stream_t stream);
+/* grad_features[n, f] = grad_feat[f, gt[n]] / cnt[gt[n]] for foreground rows, else 0. */
+int fi_class_mean_backward(const float *grad_feat, const int32_t *gt,
+                           const float *cnt, int N, int F, int num_classes,
+                           float *grad_features, fi_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * In-library kernel timing (HIP events recorded on the launch stream around
+ * each kernel launch while enabled).  Used by bench.py for the roofline object;
+ * off by default, zero cost when off.
+ * ---------------------------------------------------------------------- */
+enum {
+    FI_K_CROP_FWD = 0,
+    FI_K_CROP_BWD = 1,
+    FI_K_ROIPOOL_FWD = 2,
+    FI_K_ROIPOOL_BWD = 3,
+    FI_K_NMS_MASK = 4,
+    FI_K_NMS_SCAN = 5,
+    FI_K_SINKHORN = 6,
+    FI_K_CLASS_MEAN = 7,
+    FI_K_PYRAMID_CROP_FWD = 8,
+    FI_K_PYRAMID_CROP_BWD = 9,
+    FI_K_COUNT = 10
+};
+void fi_prof_enable(int on);
+void fi_prof_reset(void);
+/* Synchronises the recorded events, then returns launches and summed ms. */
+int fi_prof_get(int kernel_id, int *launches, float *total_ms);
+const char *fi_prof_kernel_name(int kernel_id);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FI_CAPI_H_ */

@@ -1,0 +1,89 @@
+"""Seeded synthetic inputs shared by the tests, smoke() and bench.py."""
+import numpy as np
+
+
+def adversarial_boxes(rs, n, H, W):
+    """Normalised (y1,x1,y2,x2) boxes that stress the bin assignment: inside, partly and
+    fully outside, degenerate, flipped, grid-aligned, touching the last row/column."""
+    f = np.float32
+    boxes = []
+    for i in range(n):
+        k = i % 8
+        if k == 0:      # ordinary box
+            y1, x1 = rs.uniform(0, 0.8, 2)
+            h, w = rs.uniform(0.02, 0.2, 2)
+            b = [y1, x1, y1 + h, x1 + w]
+        elif k == 1:    # straddles the border
+            y1, x1 = rs.uniform(-0.2, 0.95, 2)
+            b = [y1, x1, y1 + rs.uniform(0.1, 0.5), x1 + rs.uniform(0.1, 0.5)]
+        elif k == 2:    # exactly on the pixel grid
+            r0, c0 = rs.randint(0, H - 8), rs.randint(0, W - 8)
+            r1, c1 = r0 + rs.randint(1, 8), c0 + rs.randint(1, 8)
+            b = [r0 / (H - 1), c0 / (W - 1), r1 / (H - 1), c1 / (W - 1)]
+        elif k == 3:    # touches the last row / column (in == H-1)
+            b = [rs.uniform(0.5, 0.9), rs.uniform(0.5, 0.9), 1.0, 1.0]
+        elif k == 4:    # degenerate (zero area)
+            y, x = rs.uniform(0, 1, 2)
+            b = [y, x, y, x]
+        elif k == 5:    # flipped
+            y1, x1 = rs.uniform(0.3, 0.9, 2)
+            b = [y1, x1, y1 - rs.uniform(0.05, 0.3), x1 - rs.uniform(0.05, 0.3)]
+        elif k == 6:    # completely outside
+            b = [1.2, 1.3, 1.6, 1.7] if i % 16 == 6 else [-0.7, -0.6, -0.2, -0.1]
+        else:           # whole image
+            b = [0.0, 0.0, 1.0, 1.0]
+        boxes.append(b)
+    return np.asarray(boxes, f)
+
+
+def clustered_dets(rs, n, size, n_clusters=20, pixel_round=False):
+    """[n,5] = (y1,x1,y2,x2,score) proposals: jittered copies of a few 'objects' plus
+    background, clipped to [0,size], unique scores sorted descending."""
+    f = np.float32
+    cy, cx = rs.uniform(0.1 * size, 0.9 * size, (2, n_clusters))
+    side = np.exp(rs.uniform(np.log(16), np.log(size / 2), n_clusters))
+    asp = np.exp(rs.uniform(np.log(0.5), np.log(2.0), n_clusters))
+    n_fg = int(0.7 * n)
+    which = rs.randint(0, n_clusters, n_fg)
+    h = side[which] / np.sqrt(asp[which]) * np.exp(rs.normal(0, 0.15, n_fg))
+    w = side[which] * np.sqrt(asp[which]) * np.exp(rs.normal(0, 0.15, n_fg))
+    y = cy[which] + rs.normal(0, 0.1, n_fg) * h
+    x = cx[which] + rs.normal(0, 0.1, n_fg) * w
+    fg = np.stack([y - h / 2, x - w / 2, y + h / 2, x + w / 2], 1)
+    n_bg = n - n_fg
+    y1, x1 = rs.uniform(0, size * 0.9, (2, n_bg))
+    hh, ww = np.exp(rs.uniform(np.log(8), np.log(size / 2), (2, n_bg)))
+    bg = np.stack([y1, x1, y1 + hh, x1 + ww], 1)
+    boxes = np.clip(np.concatenate([fg, bg], 0), 0, size)
+    if pixel_round:
+        boxes = np.round(boxes)
+    scores = rs.permutation(n).astype(np.float64) / n + rs.uniform(0, 0.1 / n, n)
+    order = np.argsort(-scores, kind="stable")
+    dets = np.concatenate([boxes, scores[:, None]], 1)[order]
+    return dets.astype(f)
+
+
+def training_rois(rs, batch, per_image, n_gt=20):
+    """Normalised (y1,x1,y2,x2) RoIs per image: half jittered GT copies, half background."""
+    f = np.float32
+    out = np.zeros((batch, per_image, 4), f)
+    for b in range(batch):
+        side = np.exp(rs.uniform(np.log(16 / 1024), np.log(0.5), n_gt))
+        asp = np.exp(rs.uniform(np.log(0.5), np.log(2.0), n_gt))
+        gh, gw = side / np.sqrt(asp), side * np.sqrt(asp)
+        gy, gx = rs.uniform(0, 1 - gh), rs.uniform(0, 1 - gw)
+        k = per_image // 2
+        w = rs.randint(0, n_gt, k)
+        jy = gy[w] + rs.uniform(-0.2, 0.2, k) * gh[w]
+        jx = gx[w] + rs.uniform(-0.2, 0.2, k) * gw[w]
+        jh = gh[w] * rs.uniform(0.8, 1.2, k)
+        jw = gw[w] * rs.uniform(0.8, 1.2, k)
+        fg = np.stack([jy, jx, jy + jh, jx + jw], 1)
+        m = per_image - k
+        s2 = np.exp(rs.uniform(np.log(16 / 1024), np.log(0.6), m))
+        a2 = np.exp(rs.uniform(np.log(0.5), np.log(2.0), m))
+        bh, bw = s2 / np.sqrt(a2), s2 * np.sqrt(a2)
+        by, bx = rs.uniform(0, 1, m) * (1 - np.minimum(bh, 1)), rs.uniform(0, 1, m) * (1 - np.minimum(bw, 1))
+        bg = np.stack([by, bx, by + bh, bx + bw], 1)
+        out[b] = np.clip(np.concatenate([fg, bg], 0), 0, 1)
+    return out

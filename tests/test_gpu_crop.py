@@ -1,0 +1,213 @@
+"""HIP crop_and_resize (RoIAlign) vs the CPU oracle -- through the C ABI and through
+the reference-shaped Python operator.  Bar: bin assignment and forward values
+BIT-EXACT; backward (fp32 atomics, order not fixed) within a stated tolerance."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import adversarial_boxes, training_rois
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def _fwd(image, boxes, ind, ch, cw, extrap=0.0):
+    from feature_intertwiner_amd.roi_align.crop_and_resize import CropAndResizeFunction
+    out = CropAndResizeFunction(ch, cw, extrap)(
+        torch.from_numpy(image).to(DEV), torch.from_numpy(boxes).to(DEV), torch.from_numpy(ind).to(DEV))
+    torch.cuda.synchronize()
+    return out.cpu().numpy()
+
+
+@pytest.mark.parametrize("crop", [(7, 7), (14, 14), (28, 28), (1, 1), (5, 3), (1, 9), (64, 64)])
+def test_taps_bit_exact(oracle, crop):
+    from feature_intertwiner_amd import _lib
+    L = _lib.load()
+    ch, cw = crop
+    rs = np.random.RandomState(3)
+    for (H, W) in ((64, 64), (37, 91), (256, 256), (2, 2), (1, 5)):
+        boxes = adversarial_boxes(rs, 400, max(H, 9), max(W, 9))
+        exp = oracle.crop_taps(boxes, H, W, ch, cw)
+        tb = torch.from_numpy(boxes).to(DEV)
+        N = boxes.shape[0]
+        o = {k: torch.empty((N, ch if k[0] == "y" else cw), device=DEV,
+                            dtype=torch.float32 if k.endswith("frac") else torch.int32)
+             for k in ("y_valid", "y0", "y1", "y_frac", "x_valid", "x0", "x1", "x_frac")}
+        _lib.check(L.fi_crop_and_resize_taps(_lib.ptr(tb), N, H, W, ch, cw, _lib.ptr(o["y_valid"]),
+                                             _lib.ptr(o["y0"]), _lib.ptr(o["y1"]), _lib.ptr(o["y_frac"]),
+                                             _lib.ptr(o["x_valid"]), _lib.ptr(o["x0"]), _lib.ptr(o["x1"]),
+                                             _lib.ptr(o["x_frac"]), _lib.current_stream()), "taps")
+        torch.cuda.synchronize()
+        for k, v in o.items():
+            got = v.cpu().numpy()
+            if k.endswith("frac"):
+                assert np.array_equal(_bits(got), _bits(exp[k])), (k, H, W)
+            else:
+                assert np.array_equal(got, exp[k]), (k, H, W)
+
+
+@pytest.mark.parametrize("crop", [(7, 7), (14, 14), (28, 28), (1, 1), (5, 3), (3, 11)])
+@pytest.mark.parametrize("shape", [(2, 8, 64, 64), (3, 5, 37, 91), (1, 70, 16, 16)])
+def test_forward_bit_exact_adversarial(oracle, crop, shape):
+    rs = np.random.RandomState(11)
+    B, C, H, W = shape
+    image = rs.standard_normal(shape).astype(np.float32)
+    boxes = adversarial_boxes(rs, 203, H, W)
+    ind = rs.randint(0, B, boxes.shape[0]).astype(np.int32)
+    for extrap in (0.0, -3.5):
+        exp = oracle.crop_and_resize_forward(image, boxes, ind, crop[0], crop[1], extrap)
+        got = _fwd(image, boxes, ind, crop[0], crop[1], extrap)
+        assert got.shape == exp.shape
+        assert np.array_equal(_bits(got), _bits(exp))
+
+
+def test_forward_full_size_bit_exact(oracle):
+    """north-star shape: 512 RoIs x 256 ch x 7x7 (and 14x14) from a [2,256,256,256] map."""
+    rs = np.random.RandomState(2000)
+    image = rs.standard_normal((2, 256, 256, 256)).astype(np.float32)
+    rois = training_rois(rs, 2, 256).reshape(-1, 4)
+    ind = np.repeat(np.arange(2, dtype=np.int32), 256)
+    for crop in (7, 14):
+        exp = oracle.crop_and_resize_forward(image, rois, ind, crop, crop, 0.0)
+        got = _fwd(image, rois, ind, crop, crop)
+        assert np.array_equal(_bits(got), _bits(exp))
+
+
+def test_identity_crop_property():
+    """size-independent property: the box (0,0,1,1) with crop == map size is the identity."""
+    rs = np.random.RandomState(5)
+    image = rs.standard_normal((3, 40, 64, 48)).astype(np.float32)
+    boxes = np.tile(np.array([[0, 0, 1, 1]], np.float32), (3, 1))
+    ind = np.arange(3, dtype=np.int32)
+    got = _fwd(image, boxes, ind, 64, 48)
+    assert np.array_equal(_bits(got), _bits(image))
+
+
+def test_bad_box_index_gives_zeros_and_status():
+    from feature_intertwiner_amd import _lib
+    L = _lib.load()
+    rs = np.random.RandomState(1)
+    image = torch.from_numpy(rs.standard_normal((2, 4, 16, 16)).astype(np.float32)).to(DEV)
+    boxes = torch.tensor([[0.1, 0.1, 0.5, 0.5]] * 3, device=DEV)
+    ind = torch.tensor([0, 7, -1], device=DEV, dtype=torch.int32)
+    crops = torch.full((3, 4, 7, 7), 9.0, device=DEV)
+    status = torch.zeros(1, device=DEV, dtype=torch.int32)
+    _lib.check(L.fi_crop_and_resize_forward(_lib.ptr(image), _lib.ptr(boxes), _lib.ptr(ind), 3, 2, 4, 16, 16,
+                                            7, 7, 0.0, _lib.ptr(crops), _lib.ptr(status),
+                                            _lib.current_stream()), "fwd")
+    torch.cuda.synchronize()
+    assert status.item() == 1
+    assert crops[1].abs().max().item() == 0 and crops[2].abs().max().item() == 0
+    assert crops[0].abs().max().item() > 0
+
+
+def test_empty_and_invalid_args():
+    from feature_intertwiner_amd import _lib
+    from feature_intertwiner_amd.roi_align.crop_and_resize import CropAndResizeFunction
+    image = torch.randn(1, 3, 8, 8, device=DEV)
+    out = CropAndResizeFunction(7, 7)(image, torch.zeros(0, 4, device=DEV),
+                                      torch.zeros(0, dtype=torch.int32, device=DEV))
+    assert out.shape == (0, 3, 7, 7)
+    with pytest.raises(_lib.FiError):
+        CropAndResizeFunction(65, 7)(image, torch.zeros(1, 4, device=DEV),
+                                     torch.zeros(1, dtype=torch.int32, device=DEV))
+    with pytest.raises(_lib.FiError):   # no CPU fallback
+        CropAndResizeFunction(7, 7)(image.cpu(), torch.zeros(1, 4), torch.zeros(1, dtype=torch.int32))
+
+
+@pytest.mark.parametrize("crop", [(7, 7), (14, 14), (4, 9), (1, 1)])
+def test_backward_vs_oracle(oracle, crop):
+    from feature_intertwiner_amd.roi_align.crop_and_resize import CropAndResizeFunction
+    rs = np.random.RandomState(23)
+    shape = (2, 6, 33, 47)
+    B, C, H, W = shape
+    boxes = adversarial_boxes(rs, 150, H, W)
+    ind = rs.randint(0, B, boxes.shape[0]).astype(np.int32)
+    grads = rs.standard_normal((boxes.shape[0], C, crop[0], crop[1])).astype(np.float32)
+    exp = oracle.crop_and_resize_backward(grads, boxes, ind, shape)
+    image = torch.zeros(shape, device=DEV, requires_grad=True)
+    out = CropAndResizeFunction(crop[0], crop[1])(image, torch.from_numpy(boxes).to(DEV),
+                                                  torch.from_numpy(ind).to(DEV))
+    out.backward(torch.from_numpy(grads).to(DEV))
+    got = image.grad.cpu().numpy()
+    # tolerance: fp32 sums of <= ~150*crop terms in a different order
+    scale = np.abs(exp).max() + 1e-6
+    assert np.max(np.abs(got - exp)) <= 2e-5 * scale
+    # run twice: atomics may reorder, result must stay within the same tolerance
+    image.grad = None
+    out2 = CropAndResizeFunction(crop[0], crop[1])(image, torch.from_numpy(boxes).to(DEV),
+                                                   torch.from_numpy(ind).to(DEV))
+    out2.backward(torch.from_numpy(grads).to(DEV))
+    assert np.max(np.abs(image.grad.cpu().numpy() - exp)) <= 2e-5 * scale
+
+
+def test_backward_adjoint_property_full_size():
+    """<crop(I), G> == <I, crop^T(G)> at the north-star size (size-independent property)."""
+    from feature_intertwiner_amd.roi_align.crop_and_resize import CropAndResizeFunction
+    g = torch.Generator(device="cpu").manual_seed(7)
+    image = torch.randn(2, 256, 128, 128, generator=g).to(DEV).requires_grad_(True)
+    rs = np.random.RandomState(9)
+    rois = torch.from_numpy(training_rois(rs, 2, 256).reshape(-1, 4)).to(DEV)
+    ind = torch.arange(2, dtype=torch.int32, device=DEV).repeat_interleave(256)
+    out = CropAndResizeFunction(7, 7)(image, rois, ind)
+    G = torch.randn(out.shape, generator=g).to(DEV)
+    lhs = (out.double() * G.double()).sum()
+    out.backward(G)
+    rhs = (image.detach().double() * image.grad.double()).sum()
+    assert abs(lhs.item() - rhs.item()) <= 1e-5 * max(1.0, abs(lhs.item()))
+
+
+def test_pyramid_matches_per_level_oracle(oracle):
+    from feature_intertwiner_amd.roi_align.crop_and_resize import pyramid_crop_and_resize
+    rs = np.random.RandomState(31)
+    B, C = 2, 16
+    maps = [rs.standard_normal((B, C, s, s)).astype(np.float32) for s in (64, 32, 16, 8)]
+    N = 300
+    boxes = adversarial_boxes(rs, N, 64, 64)
+    ind = rs.randint(0, B, N).astype(np.int32)
+    level = rs.randint(1, 7, N).astype(np.int32)   # includes out-of-pyramid levels 1 and 6
+    tm = [torch.from_numpy(m).to(DEV).requires_grad_(True) for m in maps]
+    for crop in (7, 14):
+        out = pyramid_crop_and_resize(tm, torch.from_numpy(boxes).to(DEV), torch.from_numpy(ind).to(DEV),
+                                      torch.from_numpy(level).to(DEV), crop, crop)
+        got = out.detach().cpu().numpy()
+        exp = np.zeros_like(got)
+        for l in range(2, 6):
+            sel = np.nonzero(level == l)[0]
+            if len(sel):
+                exp[sel] = oracle.crop_and_resize_forward(maps[l - 2], boxes[sel], ind[sel], crop, crop, 0.0)
+        assert np.array_equal(_bits(got), _bits(exp))
+        # backward: per-level oracle on the selected rows
+        G = rs.standard_normal(got.shape).astype(np.float32)
+        for t in tm:
+            t.grad = None
+        out.backward(torch.from_numpy(G).to(DEV))
+        for l in range(2, 6):
+            sel = np.nonzero(level == l)[0]
+            e = oracle.crop_and_resize_backward(G[sel], boxes[sel], ind[sel], maps[l - 2].shape)
+            g = tm[l - 2].grad.cpu().numpy()
+            assert np.max(np.abs(g - e)) <= 2e-5 * (np.abs(e).max() + 1e-6)
+
+
+def test_roi_align_module_matches_oracle(oracle):
+    from feature_intertwiner_amd.roi_align.roi_align import RoIAlign
+    rs = np.random.RandomState(4)
+    fm = rs.standard_normal((2, 8, 40, 56)).astype(np.float32)
+    xy = rs.uniform(0, 30, (50, 2)).astype(np.float32)
+    wh = rs.uniform(1, 25, (50, 2)).astype(np.float32)
+    boxes = np.concatenate([xy, xy + wh], 1).astype(np.float32)   # x1,y1,x2,y2 pixels
+    ind = rs.randint(0, 2, 50).astype(np.int32)
+    for tf in (True, False):
+        nb = oracle.roi_align_boxes(boxes, 40, 56, 7, 7, tf)
+        exp = oracle.crop_and_resize_forward(fm, nb, ind, 7, 7, 0.0)
+        got = RoIAlign(7, 7, 0, tf)(torch.from_numpy(fm).to(DEV), torch.from_numpy(boxes).to(DEV),
+                                    torch.from_numpy(ind).to(DEV)).cpu().numpy()
+        # the box transform runs in torch fp32 on the GPU: division may differ by 1 ulp from
+        # numpy, so compare values with a tolerance here (bin assignment itself is tested above)
+        assert np.allclose(got, exp, rtol=1e-4, atol=1e-4)
