@@ -21,6 +21,8 @@
 //     flat-index -> (c, y, x) split is multiply-shift, not integer division;
 //   * every output element is written (zeros / extrapolation value included), so
 //     the reference's separate 25..100 MB zero-fill pass disappears.
+#include <stdlib.h>
+
 #include "fi_common.h"
 
 namespace {
@@ -28,6 +30,10 @@ namespace {
 constexpr int kThreads = 256;
 constexpr int kMaxCrop = 64;   // LDS table entries per axis
 constexpr int kMaxLevels = 8;
+
+// <2 x float> that may sit at any 4-byte boundary: lowers to one global_load_dwordx2
+typedef float pair_f32 __attribute__((ext_vector_type(2)));
+typedef pair_f32 pair_f32_a4 __attribute__((aligned(4)));
 
 struct Tap {
     int i0;      // floorf(coord)
@@ -146,15 +152,24 @@ __global__ __launch_bounds__(kThreads) void crop_fwd_kernel(
     const float *__restrict__ src = ls.img[h.lvl] + ((size_t)h.img * depth + c_begin) * plane;
     const int W = h.W;
 
+    // The left/right taps of a bin are adjacent floats (x1 == x0 or x0 + 1), so each row is
+    // fetched with ONE 8-byte load at column min(x0, W-2) instead of two 4-byte gathers: the
+    // kernel is bound by L1 line look-ups per wavefront instruction, not by bytes, and this
+    // halves them.  (W == 1 maps use the scalar path.)
+    const bool pair_ok = (W >= 2);
     constexpr int UNROLL = 4;
     for (int base = tid; base < total; base += kThreads * UNROLL) {
-        float tl[UNROLL], tr[UNROLL], bl[UNROLL], br[UNROLL], fx[UNROLL], fy[UNROLL];
+        float2 top2[UNROLL], bot2[UNROLL];
+        float fx[UNROLL], fy[UNROLL];
+        int sel[UNROLL];   // bit0: left tap is .y, bit1: right tap is .y
         int ok[UNROLL];
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
             const int idx = base + u * kThreads;
             ok[u] = 0;
-            tl[u] = tr[u] = bl[u] = br[u] = 0.0f;
+            sel[u] = 0;
+            top2[u] = make_float2(0.0f, 0.0f);
+            bot2[u] = make_float2(0.0f, 0.0f);
             fx[u] = fy[u] = 0.0f;
             if (idx < total) {
                 const int c = idx / bins;
@@ -167,10 +182,23 @@ __global__ __launch_bounds__(kThreads) void crop_fwd_kernel(
                 if (ok[u] == 1) {
                     const float *__restrict__ p = src + (size_t)c * plane;
                     const int r0 = ty.i0 * W, r1 = ty.i1 * W;
-                    tl[u] = p[r0 + tx.i0];
-                    tr[u] = p[r0 + tx.i1];
-                    bl[u] = p[r1 + tx.i0];
-                    br[u] = p[r1 + tx.i1];
+                    if (pair_ok) {
+                        const int xb = min(tx.i0, W - 2);
+                        sel[u] = (tx.i0 != xb ? 1 : 0) | (tx.i1 != xb ? 2 : 0);
+                        const float *pt = p + r0 + xb;
+                        const float *pb = p + r1 + xb;
+                        // 4-byte aligned 8-byte loads (global memory allows unaligned dwordx2)
+                        const pair_f32 vt = *reinterpret_cast<const pair_f32_a4 *>(pt);
+                        const pair_f32 vb = *reinterpret_cast<const pair_f32_a4 *>(pb);
+                        top2[u] = make_float2(vt.x, vt.y);
+                        bot2[u] = make_float2(vb.x, vb.y);
+                    } else {
+                        top2[u].x = p[r0 + tx.i0];
+                        top2[u].y = p[r0 + tx.i1];
+                        bot2[u].x = p[r1 + tx.i0];
+                        bot2[u].y = p[r1 + tx.i1];
+                        sel[u] = 2;
+                    }
                     fx[u] = tx.frac;
                     fy[u] = ty.frac;
                 }
@@ -180,10 +208,14 @@ __global__ __launch_bounds__(kThreads) void crop_fwd_kernel(
         for (int u = 0; u < UNROLL; ++u) {
             const int idx = base + u * kThreads;
             if (ok[u] == 1) {
-                const float dt = tr[u] - tl[u];
-                const float top = tl[u] + dt * fx[u];
-                const float db = br[u] - bl[u];
-                const float bot = bl[u] + db * fx[u];
+                const float tl = (sel[u] & 1) ? top2[u].y : top2[u].x;
+                const float tr = (sel[u] & 2) ? top2[u].y : top2[u].x;
+                const float bl = (sel[u] & 1) ? bot2[u].y : bot2[u].x;
+                const float br = (sel[u] & 2) ? bot2[u].y : bot2[u].x;
+                const float dt = tr - tl;
+                const float top = tl + dt * fx[u];
+                const float db = br - bl;
+                const float bot = bl + db * fx[u];
                 const float dv = bot - top;
                 out[idx] = top + dv * fy[u];
             } else if (ok[u] == 2) {
@@ -277,6 +309,12 @@ __global__ void crop_taps_kernel(const float *__restrict__ boxes, int num_boxes,
 // chunk while the grid would not fill the chip (256 CUs x 8 workgroups).
 void pick_chunks(int num_boxes, int depth, int *chan_per_block, int *chunks)
 {
+    static const int forced = getenv("FI_CROP_CPB") ? atoi(getenv("FI_CROP_CPB")) : 0;  // tuning knob
+    if (forced > 0) {
+        *chan_per_block = forced;
+        *chunks = fi::ceil_div(depth, forced);
+        return;
+    }
     int cpb = fi::ceil_div(depth, 8);
     if (cpb < 1) cpb = 1;
     while (cpb > 8 && (long)num_boxes * fi::ceil_div(depth, cpb) < 2048) cpb = fi::ceil_div(cpb, 2);

@@ -19,10 +19,16 @@ DEV = "cuda:0"
 HBM_PEAK = 8.0e12
 
 
-def timeit(fn, iters=50, warm=10):
+def timeit(fn, iters=50, warm=10, kernel=None):
+    """median/best wall time per call (HIP events around the Python call) and, when `kernel`
+    names a library kernel, its mean duration from the in-library event pairs."""
+    from feature_intertwiner_amd import _lib
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
+    if kernel:
+        _lib.prof_reset()
+        _lib.prof_enable(True)
     ts = []
     for _ in range(iters):
         a = torch.cuda.Event(enable_timing=True)
@@ -33,7 +39,14 @@ def timeit(fn, iters=50, warm=10):
         b.synchronize()
         ts.append(a.elapsed_time(b) * 1e-3)
     ts.sort()
+    if kernel:
+        _lib.prof_enable(False)
+        n, ms = _lib.prof_get(kernel)
+        KERNEL_US[0] = ms * 1e3 / max(n, 1)
     return ts[len(ts) // 2], ts[0]
+
+
+KERNEL_US = [0.0]
 
 
 def unique_taps_bytes(oracle_taps, C):
@@ -76,18 +89,20 @@ def main():
             b_min = out_bytes + unique_taps_bytes(taps, C) + 20 * N
             b_max = out_bytes * 5
             if "crop" in ops:
-                med, best = timeit(lambda: fn(image, rois, ind), args.iters)
+                med, best = timeit(lambda: fn(image, rois, ind), args.iters, kernel="crop_fwd")
+                k = KERNEL_US[0] * 1e-6
                 print(json.dumps({"op": "crop_and_resize_fwd", "shape": [N, C, crop, crop], "map": [B, C, S, S],
-                                  "us_median": med * 1e6, "us_best": best * 1e6, "B_min_MB": b_min / 1e6,
-                                  "B_max_MB": b_max / 1e6, "GBps_Bmin": b_min / med / 1e9,
-                                  "frac_hbm_Bmin": b_min / med / HBM_PEAK, "frac_hbm_Bmax": b_max / med / HBM_PEAK}))
+                                  "us_median": med * 1e6, "us_best": best * 1e6, "kernel_us": k * 1e6,
+                                  "B_min_MB": b_min / 1e6, "B_max_MB": b_max / 1e6, "GBps_Bmin": b_min / k / 1e9,
+                                  "frac_hbm_Bmin": b_min / k / HBM_PEAK, "frac_hbm_Bmax": b_max / k / HBM_PEAK}))
             if "cropbwd" in ops:
                 img = image.clone().requires_grad_(True)
                 out = fn(img, rois, ind)
                 g = torch.randn_like(out)
-                med, best = timeit(lambda: torch.autograd.grad(out, img, g, retain_graph=True), args.iters)
+                med, best = timeit(lambda: torch.autograd.grad(out, img, g, retain_graph=True), args.iters,
+                                   kernel="crop_bwd")
                 print(json.dumps({"op": "crop_and_resize_bwd(+memset)", "shape": [N, C, crop, crop],
-                                  "us_median": med * 1e6, "us_best": best * 1e6}))
+                                  "us_median": med * 1e6, "us_best": best * 1e6, "kernel_us": KERNEL_US[0]}))
 
     if "pyramid" in ops:
         maps = [torch.randn(4, 256, s, s, device=DEV) for s in (256, 128, 64, 32)]
@@ -95,8 +110,10 @@ def main():
         i4 = torch.arange(4, dtype=torch.int32, device=DEV).repeat_interleave(512)
         lv = roi_level(r4, 1024 * 1024)
         for crop in (7, 14):
-            med, best = timeit(lambda: pyramid_crop_and_resize(maps, r4, i4, lv, crop, crop), args.iters)
+            med, best = timeit(lambda: pyramid_crop_and_resize(maps, r4, i4, lv, crop, crop), args.iters,
+                               kernel="pyramid_crop_fwd")
             print(json.dumps({"op": "pyramid_crop_fwd", "shape": [r4.shape[0], 256, crop, crop],
+                              "kernel_us": KERNEL_US[0],
                               "levels": np.bincount(lv.cpu().numpy(), minlength=6)[2:].tolist(),
                               "us_median": med * 1e6, "us_best": best * 1e6,
                               "GBps_write_only": 4 * r4.shape[0] * 256 * crop * crop / med / 1e9}))
