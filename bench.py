@@ -1,0 +1,256 @@
+"""Headline benchmark: images/sec of the full Feature-Intertwiner train step
+(BASELINE.json: ResNet-101-FPN, 1024x1024, 512 RoIs/image, OT intertwiner on, Sinkhorn
+L=50, 80 classes) on N MI355X GPUs of one node.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One process per GPU; weak scaling (4 images per GPU at every N); rank 0 prints ONE JSON
+line.  A step = forward + intertwiner (OT) loss + backward + gradient all-reduce + clip
++ SGD update on one synthetic COCO-shaped batch already resident in HBM (synthetic.py).
+All arithmetic is fp32, as in the reference.
+
+Extra objects on the JSON line
+  roofline      for crop_fwd_kernel<7, 7> (RoIAlign 7x7, the north-star kernel): algorithmic
+                bytes (SURVEY 8d's B_min = output + unique taps per RoI + box records) of its
+                launch in the step / its mean duration, measured with HIP events recorded on
+                the launch stream by the library (fi_prof_*) during the timed steps.
+  cpu_baseline  the CPU oracle (oracle/, kind "port") timed on this host for the hot-path
+                OPERATORS of one step -- see cpu_baseline() for the exact sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def crop_algorithmic_bytes(log_entry):
+    """B_min of one pyramid RoIAlign launch: 4*N*C*ch*cw (write) + 4*C*sum_r U_r (U_r = distinct
+    (row, col) taps of RoI r on its level) + 24*N (box, image index, level records)."""
+    from feature_intertwiner_amd import _lib
+    L = _lib.load()
+    boxes, level, shapes, crop, C = (log_entry[k] for k in ("boxes", "level", "shapes", "crop", "depth"))
+    N = boxes.size(0)
+    dev = boxes.device
+    total_u = 0
+    for li, (H, W) in enumerate(shapes):
+        sel = torch.nonzero(level == li + 2).view(-1)
+        n = sel.numel()
+        if n == 0:
+            continue
+        b = boxes[sel].contiguous()
+        o = {k: torch.empty((n, crop), device=dev, dtype=torch.float32 if k.endswith("frac") else torch.int32)
+             for k in ("y_valid", "y0", "y1", "y_frac", "x_valid", "x0", "x1", "x_frac")}
+        _lib.check(L.fi_crop_and_resize_taps(_lib.ptr(b), n, H, W, crop, crop, _lib.ptr(o["y_valid"]),
+                                             _lib.ptr(o["y0"]), _lib.ptr(o["y1"]), _lib.ptr(o["y_frac"]),
+                                             _lib.ptr(o["x_valid"]), _lib.ptr(o["x0"]), _lib.ptr(o["x1"]),
+                                             _lib.ptr(o["x_frac"]), _lib.current_stream()), "taps")
+
+        def distinct(i0, i1, valid):
+            v = torch.cat([torch.where(valid > 0, i0, torch.full_like(i0, -1)),
+                           torch.where(valid > 0, i1, torch.full_like(i1, -1))], 1)
+            v = torch.sort(v, dim=1)[0]
+            new = torch.cat([torch.ones_like(v[:, :1], dtype=torch.bool), v[:, 1:] != v[:, :-1]], 1)
+            return (new & (v >= 0)).sum(1)
+
+        total_u += int((distinct(o["y0"], o["y1"], o["y_valid"]) * distinct(o["x0"], o["x1"], o["x_valid"])).sum())
+    return 4 * N * C * crop * crop + 4 * C * total_u + 24 * N
+
+
+def cpu_baseline(model, batch, log_entries):
+    """Hot-path operators of ONE step on the CPU oracle (all host cores for RoIAlign forward,
+    one thread for backward / NMS / Sinkhorn, as the reference's C and Python do): the step's
+    RoIAlign 7x7 and 14x14 forward on the real RoIs and feature-map sizes, their backward, NMS
+    of 4 x 6000 clustered proposals, and 240 Sinkhorn problems (256 samples, L=50).  The dense
+    conv stack is NOT included (it has no hand-written CPU twin here); the value is therefore
+    images/s of the operator part only and is an upper bound on a full CPU step."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle import oracle as O
+    from helpers import clustered_dets
+    O.build()
+    rs = np.random.RandomState(2000)
+    t_total = 0.0
+    detail = {}
+    bs = batch[0].size(0)
+    for e in log_entries:
+        crop, C = e["crop"], e["depth"]
+        boxes = e["boxes"].cpu().numpy()
+        level = e["level"].cpu().numpy()
+        ind = e["box_ind"].cpu().numpy()
+        t_f = t_b = 0.0
+        for li, (H, W) in enumerate(e["shapes"]):
+            sel = np.nonzero(level == li + 2)[0]
+            if len(sel) == 0:
+                continue
+            fmap = rs.standard_normal((bs, C, H, W)).astype(np.float32)
+            t = time.time()
+            out = O.crop_and_resize_forward(fmap, boxes[sel], ind[sel], crop, crop)
+            t_f += time.time() - t
+            t = time.time()
+            O.crop_and_resize_backward(out, boxes[sel], ind[sel], fmap.shape)
+            t_b += time.time() - t
+        detail["roialign_%dx%d_fwd_ms" % (crop, crop)] = t_f * 1e3
+        detail["roialign_%dx%d_bwd_ms" % (crop, crop)] = t_b * 1e3
+        t_total += t_f + t_b
+    dets = [clustered_dets(rs, 6000, 1024) for _ in range(bs)]
+    t = time.time()
+    for d in dets:
+        O.pth_nms(d, 0.7)
+    detail["nms_ms"] = (time.time() - t) * 1e3
+    t_total += time.time() - t
+    x = np.maximum(rs.standard_normal((240, 256, 1)), 0).astype(np.float32)
+    y = np.maximum(rs.standard_normal((240, 256, 1)), 0).astype(np.float32)
+    t = time.time()
+    n_sk = 24                      # bounded sample: 24 of the 240 problems, scaled
+    for p in range(n_sk):
+        O.sinkhorn(x[p], y[p], 1.0, 50)
+    sk = (time.time() - t) * (240.0 / n_sk)
+    detail["sinkhorn_240_ms"] = sk * 1e3
+    t_total += sk
+    return {"value": bs / t_total, "unit": "images/sec (hot-path operators only, conv stack excluded)",
+            "cores": O.num_threads(), "kind": "port",
+            "sample": "one step's operator work on the CPU oracle: RoIAlign 7x7+14x14 fwd (OpenMP, %d threads) "
+                      "and bwd (serial) on the step's %d RoIs, NMS 4x6000 @0.7 (serial), Sinkhorn 240x256x256 "
+                      "L=50 (serial, 24 problems timed and scaled x10)" % (O.num_threads(), log_entries[0]["boxes"].size(0)),
+            "detail_ms": {k: round(v, 1) for k, v in detail.items()}, "host_cpus": os.cpu_count()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--backbone", default="resnet101")
+    ap.add_argument("--image-size", type=int, default=1024)
+    ap.add_argument("--batch-per-gpu", type=int, default=4)
+    ap.add_argument("--rois", type=int, default=512)
+    ap.add_argument("--ot-L", type=int, default=50)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from feature_intertwiner_amd import _lib
+    from feature_intertwiner_amd.config import make_config
+    from feature_intertwiner_amd.data_parallel import GradientBuckets, all_reduce_statistics, broadcast_parameters
+    from feature_intertwiner_amd.model import MaskRCNN
+    from feature_intertwiner_amd.roi_align import crop_and_resize as car
+    from feature_intertwiner_amd.synthetic import SyntheticProposals, synthetic_batch
+    from feature_intertwiner_amd.workflow import set_optimizer, train_step
+    _lib.load()
+
+    torch.manual_seed(2000)
+    cfg = make_config(args.backbone, args.image_size, args.batch_per_gpu, args.rois, dev_switch=True,
+                      loss_choice="ot", ot_L=args.ot_L, gpu_count=world)
+    model = MaskRCNN(cfg).to(dev)
+    broadcast_parameters(model)
+    opt = set_optimizer(model, cfg.TRAIN)
+    sync = GradientBuckets(model) if world > 1 else None
+    reduce_fn = all_reduce_statistics if world > 1 else None
+    batch = synthetic_batch(args.batch_per_gpu, args.image_size, device=dev, seed=2000 + rank)
+    model.proposal_hook = SyntheticProposals(batch[2], args.image_size, seed=7 + rank)
+    model.generator = torch.Generator(device=dev).manual_seed(11 + rank)
+
+    def step():
+        return train_step(model, opt, list(batch), do_meta=True, grad_sync=sync, world_size=world,
+                          reduce_fn=reduce_fn)
+
+    for _ in range(args.warmup):
+        terms = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    _lib.prof_reset()
+    _lib.prof_enable(True)
+    car.LAUNCH_LOG = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        terms = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    _lib.prof_enable(False)
+    log = car.LAUNCH_LOG
+    car.LAUNCH_LOG = None
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        global_batch = args.batch_per_gpu * world
+        ms_per_step = elapsed / args.steps * 1e3
+        value = global_batch * args.steps / elapsed
+        # ---- roofline of the RoIAlign 7x7 forward kernel ---------------------------------
+        n7, ms7 = _lib.prof_get("crop_fwd_7x7")
+        fwd7 = [e for e in log if e["crop"] == 7 and e["pyramid"]]
+        roof = None
+        if n7 and fwd7:
+            e = fwd7[-1]
+            b_alg = crop_algorithmic_bytes(e)
+            dur = ms7 / n7 * 1e-3
+            ach = b_alg / dur / 1e9
+            roof = {"kernel": "crop_fwd_kernel<7, 7>", "bound": "hbm", "achieved": round(ach, 1),
+                    "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4),
+                    "traffic": None, "algorithmic_bytes_per_launch": int(b_alg),
+                    "avg_launch_us": round(dur * 1e6, 2), "launches_timed": n7,
+                    "rois_per_launch": int(e["boxes"].size(0)), "bytes_model": "B_min (SURVEY 8d)"}
+        kern = {}
+        for k in _lib.KERNEL_IDS:
+            n, ms = _lib.prof_get(k)
+            if n:
+                kern[k] = {"launches": n, "avg_us": round(ms / n * 1e3, 2)}
+        out = {
+            "metric": "images/sec (train step, ResNet-101-FPN 1024^2, 512 RoIs)", "value": round(value, 4),
+            "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic (seeded N(0,1)*64 images, 20 GT boxes/img, random-init weights, "
+                    "GT-jittered proposals planted among RPN candidates before NMS)",
+            "config": {"workload": "BASELINE configs[2]: %s-FPN, %dx%d, %d images/GPU, %d RoIs/image, OT intertwiner "
+                                   "on (Sinkhorn L=%d, 256 samples, 80 classes), full train step fwd+loss+bwd+clip+SGD"
+                                   % (args.backbone, args.image_size, args.image_size, args.batch_per_gpu, args.rois,
+                                      args.ot_L),
+                       "global_batch": global_batch, "parallelism": "dp%d" % world,
+                       "conv_stack": "MIOpen fp32 via torch (MFMA conv kernels not yet hand-written)"},
+            "losses": {k: round(float(v), 5) for k, v in terms.items()},
+            "roofline": roof, "kernels": kern,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                entries = [e for e in log if e["pyramid"] and e["crop"] in (7, 14) and e["boxes"].size(0) ==
+                           args.batch_per_gpu * args.rois][-2:]
+                out["cpu_baseline"] = cpu_baseline(model, batch, entries)
+            except Exception as ex:   # the baseline must never take the headline down
+                out["cpu_baseline"] = {"error": repr(ex)}
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -57,8 +57,10 @@ SIGNATURES = {
 }
 
 KERNEL_IDS = {
-    "crop_fwd": 0, "crop_bwd": 1, "roipool_fwd": 2, "roipool_bwd": 3, "nms_mask": 4,
-    "nms_scan": 5, "sinkhorn": 6, "class_mean": 7, "pyramid_crop_fwd": 8, "pyramid_crop_bwd": 9,
+    "crop_fwd_7x7": 0, "crop_fwd_14x14": 1, "crop_fwd_28x28": 2, "crop_fwd_generic": 3,
+    "crop_bwd_7x7": 4, "crop_bwd_14x14": 5, "crop_bwd_28x28": 6, "crop_bwd_generic": 7,
+    "roipool_fwd": 8, "roipool_bwd": 9, "nms_mask": 10, "nms_scan": 11, "sinkhorn": 12,
+    "class_mean": 13,
 }
 
 _lib = None

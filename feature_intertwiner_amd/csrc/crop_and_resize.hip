@@ -335,6 +335,14 @@ int launch_sized(int crop_h, int crop_w, K k77, K k1414, K k2828, K kgen, dim3 g
     return FI_OK;
 }
 
+int size_class(int crop_h, int crop_w)
+{
+    if (crop_h == 7 && crop_w == 7) return 0;
+    if (crop_h == 14 && crop_w == 14) return 1;
+    if (crop_h == 28 && crop_w == 28) return 2;
+    return 3;
+}
+
 int check_common(int num_boxes, int batch, int depth, int crop_h, int crop_w)
 {
     FI_REQUIRE(num_boxes >= 0 && batch > 0 && depth > 0, "sizes must be positive");
@@ -348,14 +356,14 @@ int check_common(int num_boxes, int batch, int depth, int crop_h, int crop_w)
 
 int forward_impl(const LevelSet &ls, const float *boxes, const int32_t *box_ind,
                  const int32_t *level, int num_boxes, int batch, int depth, int crop_h, int crop_w,
-                 float extrap, float *crops, int32_t *status, hipStream_t st, int prof_id)
+                 float extrap, float *crops, int32_t *status, hipStream_t st)
 {
     if (num_boxes == 0) return FI_OK;
     int cpb, chunks;
     pick_chunks(num_boxes, depth, &cpb, &chunks);
     const long nblk = (long)num_boxes * chunks;
     FI_REQUIRE(nblk < 2147483647L, "grid too large");
-    fi::ProfScope prof(prof_id, st);
+    fi::ProfScope prof(FI_K_CROP_FWD_7X7 + size_class(crop_h, crop_w), st);
     return launch_sized(crop_h, crop_w, crop_fwd_kernel<7, 7>, crop_fwd_kernel<14, 14>,
                         crop_fwd_kernel<28, 28>, crop_fwd_kernel<0, 0>, dim3((unsigned)nblk), st, ls,
                         boxes, box_ind, level, num_boxes, batch, depth, crop_h, crop_w, extrap, cpb,
@@ -364,7 +372,7 @@ int forward_impl(const LevelSet &ls, const float *boxes, const int32_t *box_ind,
 
 int backward_impl(const LevelSetMut &ls, const float *grads, const float *boxes,
                   const int32_t *box_ind, const int32_t *level, int num_boxes, int batch, int depth,
-                  int crop_h, int crop_w, hipStream_t st, int prof_id)
+                  int crop_h, int crop_w, hipStream_t st)
 {
     for (int l = 0; l < ls.n; ++l) {
         const size_t bytes = sizeof(float) * (size_t)batch * depth * ls.H[l] * ls.W[l];
@@ -375,7 +383,7 @@ int backward_impl(const LevelSetMut &ls, const float *grads, const float *boxes,
     pick_chunks(num_boxes, depth, &cpb, &chunks);
     const long nblk = (long)num_boxes * chunks;
     FI_REQUIRE(nblk < 2147483647L, "grid too large");
-    fi::ProfScope prof(prof_id, st);
+    fi::ProfScope prof(FI_K_CROP_BWD_7X7 + size_class(crop_h, crop_w), st);
     return launch_sized(crop_h, crop_w, crop_bwd_kernel<7, 7>, crop_bwd_kernel<14, 14>,
                         crop_bwd_kernel<28, 28>, crop_bwd_kernel<0, 0>, dim3((unsigned)nblk), st, ls,
                         grads, boxes, box_ind, level, num_boxes, batch, depth, crop_h, crop_w, cpb,
@@ -401,7 +409,7 @@ int fi_crop_and_resize_forward(const float *image, const float *boxes, const int
     ls.W[0] = image_w;
     ls.n = 1;
     return forward_impl(ls, boxes, box_ind, nullptr, num_boxes, batch, depth, crop_h, crop_w,
-                        extrapolation_value, crops, dev_status, (hipStream_t)stream, FI_K_CROP_FWD);
+                        extrapolation_value, crops, dev_status, (hipStream_t)stream);
 }
 
 int fi_crop_and_resize_backward(const float *grads, const float *boxes, const int32_t *box_ind,
@@ -419,7 +427,7 @@ int fi_crop_and_resize_backward(const float *grads, const float *boxes, const in
     ls.W[0] = image_w;
     ls.n = 1;
     return backward_impl(ls, grads, boxes, box_ind, nullptr, num_boxes, batch, depth, crop_h, crop_w,
-                         (hipStream_t)stream, FI_K_CROP_BWD);
+                         (hipStream_t)stream);
 }
 
 int fi_crop_and_resize_taps(const float *boxes, int num_boxes, int image_h, int image_w, int crop_h,
@@ -457,8 +465,7 @@ int fi_pyramid_crop_forward(const float *const *level_images_host, const int *le
         FI_REQUIRE(ls.img[l] && ls.H[l] >= 1 && ls.W[l] >= 1, "bad level entry");
     }
     return forward_impl(ls, boxes, box_ind, level, num_boxes, batch, depth, crop_h, crop_w,
-                        extrapolation_value, crops, nullptr, (hipStream_t)stream,
-                        FI_K_PYRAMID_CROP_FWD);
+                        extrapolation_value, crops, nullptr, (hipStream_t)stream);
 }
 
 int fi_pyramid_crop_backward(const float *grads, float *const *level_grads_host,
@@ -481,7 +488,7 @@ int fi_pyramid_crop_backward(const float *grads, float *const *level_grads_host,
         FI_REQUIRE(ls.img[l] && ls.H[l] >= 1 && ls.W[l] >= 1, "bad level entry");
     }
     return backward_impl(ls, grads, boxes, box_ind, level, num_boxes, batch, depth, crop_h, crop_w,
-                         (hipStream_t)stream, FI_K_PYRAMID_CROP_BWD);
+                         (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -118,9 +118,11 @@ int fi_prof_get(int kernel_id, int *launches, float *total_ms)
 const char *fi_prof_kernel_name(int kernel_id)
 {
     static const char *names[FI_K_COUNT] = {
-        "fi_crop_fwd",     "fi_crop_bwd",  "fi_roipool_fwd",      "fi_roipool_bwd",
-        "fi_nms_mask",     "fi_nms_scan",  "fi_sinkhorn",         "fi_class_mean",
-        "fi_pyramid_crop_fwd", "fi_pyramid_crop_bwd"};
+        "crop_fwd_kernel<7, 7>",   "crop_fwd_kernel<14, 14>", "crop_fwd_kernel<28, 28>",
+        "crop_fwd_kernel<0, 0>",   "crop_bwd_kernel<7, 7>",   "crop_bwd_kernel<14, 14>",
+        "crop_bwd_kernel<28, 28>", "crop_bwd_kernel<0, 0>",   "roi_pool_fwd_kernel",
+        "roi_pool_bwd_kernel",     "nms_mask_kernel",         "nms_scan_kernel",
+        "sinkhorn_kernel",         "class_mean_fwd_kernel"};
     if (kernel_id < 0 || kernel_id >= FI_K_COUNT) return "?";
     return names[kernel_id];
 }

@@ -1,0 +1,303 @@
+"""The callers either side of the hot-path operators: anchors, the proposal layer around
+NMS, RPN / detection target generation and the five detector losses.  Counterpart of
+lib/layers.py and tools/box_utils.py of the reference.
+
+Same arithmetic, different execution: everything is batched over the minibatch with
+static shapes and validity masks on the GPU -- no per-image Python loops, no per-positive
+loops (lib/layers.py:599-604, 892-895, 923-926), no host round trips (the reference reads
+counts back with .data[0] / .cpu().numpy() at lib/layers.py:453, 505-507, 866 and
+lib/nms/nms_wrapper.py:33).  Random sub-sampling uses the device generator instead of
+np.random / torch.randperm on the host (statistically equivalent, not stream-identical).
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from .nms.pth_nms import nms_sorted
+from .roi_align.crop_and_resize import CropAndResizeFunction
+
+EPS_IOU = 10e-20     # tools/box_utils.py:4
+
+
+# --------------------------------------------------------------------------------------
+# anchors (lib/layers.py:9-65) -- executed once, on the host
+# --------------------------------------------------------------------------------------
+def generate_priors(scales, ratios, shape, feature_stride, anchor_stride):
+    scales, ratios = np.meshgrid(np.array(scales), np.array(ratios))
+    scales, ratios = scales.flatten(), ratios.flatten()
+    heights = scales / np.sqrt(ratios)
+    widths = scales * np.sqrt(ratios)
+    shifts_y = np.arange(0, shape[0], anchor_stride) * feature_stride
+    shifts_x = np.arange(0, shape[1], anchor_stride) * feature_stride
+    shifts_x, shifts_y = np.meshgrid(shifts_x, shifts_y)
+    box_widths, box_centers_x = np.meshgrid(widths, shifts_x)
+    box_heights, box_centers_y = np.meshgrid(heights, shifts_y)
+    box_centers = np.stack([box_centers_y, box_centers_x], axis=2).reshape([-1, 2])
+    box_sizes = np.stack([box_heights, box_widths], axis=2).reshape([-1, 2])
+    return np.concatenate([box_centers - 0.5 * box_sizes, box_centers + 0.5 * box_sizes], axis=1)
+
+
+def generate_pyramid_priors(scales, ratios, feature_shapes, feature_strides, anchor_stride):
+    """[N, (y1, x1, y2, x2)] pixel anchors, level-major (261 888 x 4 at 1024^2)."""
+    return np.concatenate([generate_priors(scales[i], ratios, feature_shapes[i], feature_strides[i],
+                                           anchor_stride) for i in range(len(scales))], axis=0)
+
+
+# --------------------------------------------------------------------------------------
+# box arithmetic (tools/box_utils.py:7-60, 89-140)
+# --------------------------------------------------------------------------------------
+def apply_box_deltas(boxes, deltas):
+    height = boxes[..., 2] - boxes[..., 0]
+    width = boxes[..., 3] - boxes[..., 1]
+    center_y = boxes[..., 0] + 0.5 * height
+    center_x = boxes[..., 1] + 0.5 * width
+    center_y = center_y + deltas[..., 0] * height
+    center_x = center_x + deltas[..., 1] * width
+    height = height * torch.exp(deltas[..., 2])
+    width = width * torch.exp(deltas[..., 3])
+    y1 = center_y - 0.5 * height
+    x1 = center_x - 0.5 * width
+    return torch.stack([y1, x1, y1 + height, x1 + width], dim=-1)
+
+
+def clip_boxes(boxes, window):
+    """window = (y1, x1, y2, x2) python floats."""
+    return torch.stack([boxes[..., 0].clamp(window[0], window[2]), boxes[..., 1].clamp(window[1], window[3]),
+                        boxes[..., 2].clamp(window[0], window[2]), boxes[..., 3].clamp(window[1], window[3])], -1)
+
+
+def box_refinement(box, gt_box):
+    height = box[..., 2] - box[..., 0]
+    width = box[..., 3] - box[..., 1]
+    center_y = box[..., 0] + 0.5 * height
+    center_x = box[..., 1] + 0.5 * width
+    gt_height = gt_box[..., 2] - gt_box[..., 0]
+    gt_width = gt_box[..., 3] - gt_box[..., 1]
+    gt_center_y = gt_box[..., 0] + 0.5 * gt_height
+    gt_center_x = gt_box[..., 1] + 0.5 * gt_width
+    dy = (gt_center_y - center_y) / height
+    dx = (gt_center_x - center_x) / width
+    dh = torch.log(gt_height / height)
+    dw = torch.log(gt_width / width)
+    return torch.stack([dy, dx, dh, dw], dim=-1)
+
+
+def bbox_overlaps(boxes1, boxes2):
+    """IoU [.., N, M] of boxes1 [.., N, 4] vs boxes2 [.., M, 4] (no +1; union + 1e-19)."""
+    b1 = boxes1.unsqueeze(-2)
+    b2 = boxes2.unsqueeze(-3)
+    y1 = torch.maximum(b1[..., 0], b2[..., 0])
+    x1 = torch.maximum(b1[..., 1], b2[..., 1])
+    y2 = torch.minimum(b1[..., 2], b2[..., 2])
+    x2 = torch.minimum(b1[..., 3], b2[..., 3])
+    inter = (x2 - x1).clamp(min=0) * (y2 - y1).clamp(min=0)
+    a1 = (b1[..., 2] - b1[..., 0]) * (b1[..., 3] - b1[..., 1])
+    a2 = (b2[..., 2] - b2[..., 0]) * (b2[..., 3] - b2[..., 1])
+    return inter / (a1 + a2 - inter + EPS_IOU)
+
+
+# --------------------------------------------------------------------------------------
+# proposal layer (lib/layers.py:71-139)
+# --------------------------------------------------------------------------------------
+def proposal_layer(inputs, proposal_count, nms_threshold, priors, config, proposal_hook=None):
+    """rpn_probs [b, A, 2], rpn_bbox [b, A, 4] -> normalised proposals [b, proposal_count, 4]
+    (zero rows past each image's count) and the per-image counts [b] (int32, on the GPU).
+
+    The reference truncates every image to the shortest keep list, which needs the counts on
+    the host (lib/nms/nms_wrapper.py:29-33); here shapes are static and the count
+    travels with the tensor.  `proposal_hook(boxes, scores) -> (boxes, scores)` (pixel boxes
+    [b, pre_nms, 4], scores sorted descending) lets the synthetic benchmark plant
+    object-like proposals among the random-weight RPN output; it must keep scores sorted.
+    """
+    scores = inputs[0][:, :, 1]
+    deltas = inputs[1] * torch.as_tensor(config.DATA.BBOX_STD_DEV, device=scores.device).view(1, 1, 4)
+    anchors = priors.to(scores.device)
+    pre_nms_limit = min(config.RPN.PRE_NMS_LIMIT, anchors.size(0))
+    scores, order = torch.topk(scores, pre_nms_limit, dim=1, sorted=True)
+    deltas_trim = torch.gather(deltas, 1, order.unsqueeze(2).expand(-1, -1, 4))
+    anchors_trim = anchors[order]
+    boxes = apply_box_deltas(anchors_trim, deltas_trim)
+    height, width = float(config.DATA.IMAGE_SHAPE[0]), float(config.DATA.IMAGE_SHAPE[1])
+    boxes = clip_boxes(boxes, (0.0, 0.0, height, width))
+    if proposal_hook is not None:
+        boxes, scores = proposal_hook(boxes, scores)
+    dets = torch.cat((boxes, scores.unsqueeze(2)), 2).detach()
+    keep, num = nms_sorted(dets, nms_threshold, max_keep=proposal_count)
+    keep = keep[:, :proposal_count]
+    valid = torch.arange(keep.size(1), device=keep.device).unsqueeze(0) < num.unsqueeze(1)
+    boxes_keep = torch.gather(boxes, 1, keep.unsqueeze(2).expand(-1, -1, 4)) * valid.unsqueeze(2).float()
+    norm = torch.tensor([height, width, height, width], device=boxes.device)
+    return boxes_keep / norm, num
+
+
+# --------------------------------------------------------------------------------------
+# RPN targets (lib/layers.py:439-658), batched
+# --------------------------------------------------------------------------------------
+def _random_subset(mask, limit, kmax, generator=None):
+    """Keep at most limit[b] of the True entries of mask [b, n], uniformly at random.
+    limit: python int or int tensor [b]; kmax: static upper bound of limit."""
+    b, n = mask.shape
+    key = torch.rand(mask.shape, device=mask.device, generator=generator) + 1.0
+    key = torch.where(mask, key, torch.zeros_like(key))
+    k = min(n, int(kmax))
+    top, idx = torch.topk(key, k, dim=1, sorted=True)
+    lim = limit if torch.is_tensor(limit) else torch.full((b,), int(limit), device=mask.device)
+    take = (torch.arange(k, device=mask.device).unsqueeze(0) < lim.unsqueeze(1)) & (top > 0)
+    out = torch.zeros_like(mask)
+    out.scatter_(1, idx, take)
+    return out
+
+
+def prepare_rpn_target(anchors, gt_class_ids, gt_boxes, config, generator=None):
+    """anchors [A,4] pixels; gt_class_ids [b,G] (0 = padding, <0 = crowd); gt_boxes [b,G,4]
+    pixels.  Returns target_rpn_match [b,A] in {1,-1,0} and target_rpn_deltas [b,A,4] (the
+    refinement of every anchor towards its best GT, already divided by BBOX_STD_DEV; only
+    rows with match == 1 are used).  The reference packs the positives' deltas into
+    [b, 256, 4] in anchor order (:599-604) and the loss re-aligns them (:854-861); keeping
+    them per anchor is the same pairing without the packing."""
+    anchors = anchors.to(gt_boxes.device)
+    b, G = gt_class_ids.shape
+    A = anchors.size(0)
+    valid_gt = gt_class_ids > 0
+    crowd = gt_class_ids < 0
+    overlaps = bbox_overlaps(anchors.unsqueeze(0), gt_boxes)                 # [b, A, G]
+    ov_gt = torch.where(valid_gt.unsqueeze(1), overlaps, torch.zeros_like(overlaps))
+    no_crowd = torch.where(crowd.unsqueeze(1), overlaps, torch.zeros_like(overlaps)).amax(2) < 0.001
+    iou_max, iou_argmax = ov_gt.max(dim=2)
+    match = torch.zeros(b, A, device=gt_boxes.device)
+    match = torch.where((iou_max < config.RPN.TARGET_NEG_THRES) & no_crowd, -torch.ones_like(match), match)
+    # every valid GT claims its best anchor (:495-497)
+    gt_best = ov_gt.argmax(dim=1)                                             # [b, G]
+    claim = torch.zeros(b, A, device=gt_boxes.device, dtype=torch.int32)
+    claim.scatter_add_(1, gt_best, valid_gt.to(torch.int32))      # padded GTs add 0
+    claim = claim > 0
+    match = torch.where(claim, torch.ones_like(match), match)
+    match = torch.where(iou_max >= config.RPN.TARGET_POS_THRES, torch.ones_like(match), match)
+    # balance: at most half positives, negatives fill the rest (:512-548)
+    n_total = config.RPN.TRAIN_ANCHORS_PER_IMAGE
+    pos = _random_subset(match == 1, n_total // 2, n_total // 2, generator)
+    n_pos = pos.sum(1)
+    neg = _random_subset(match == -1, (n_total - n_pos).clamp(min=0), n_total, generator)
+    match = pos.float() - neg.float()
+    gt_for_anchor = torch.gather(gt_boxes, 1, iou_argmax.unsqueeze(2).expand(-1, -1, 4))
+    deltas = box_refinement(anchors.unsqueeze(0).expand(b, -1, -1), gt_for_anchor)
+    deltas = deltas / torch.as_tensor(config.DATA.BBOX_STD_DEV, device=deltas.device)
+    deltas = torch.where(pos.unsqueeze(2), deltas, torch.zeros_like(deltas))
+    return match, deltas
+
+
+# --------------------------------------------------------------------------------------
+# detection targets (lib/layers.py:224-433), batched
+# --------------------------------------------------------------------------------------
+def prepare_det_target(proposals, num_proposals, gt_class_ids, gt_boxes, gt_masks, config, generator=None):
+    """proposals [b,P,4] normalised (zero rows past num_proposals[b]); gt_* zero padded,
+    gt_boxes normalised, gt_masks [b,G,56,56] mini-masks.
+    Returns rois [b,R,4], target_class_ids [b,R] int32, target_deltas [b,R,4],
+    target_mask [b,R,28,28] -- positives first, then negatives, then zero padding."""
+    b, P, _ = proposals.shape
+    G = gt_class_ids.size(1)
+    dev = proposals.device
+    R = config.ROIS.TRAIN_ROIS_PER_IMAGE
+    mh, mw = config.MRCNN.MASK_SHAPE
+    valid_prop = torch.arange(P, device=dev).unsqueeze(0) < num_proposals.unsqueeze(1)
+    valid_gt = gt_class_ids > 0
+    crowd = gt_class_ids < 0
+    overlaps = bbox_overlaps(proposals, gt_boxes)                              # [b, P, G]
+    ov_gt = torch.where(valid_gt.unsqueeze(1), overlaps, torch.zeros_like(overlaps))
+    no_crowd = torch.where(crowd.unsqueeze(1), overlaps, torch.zeros_like(overlaps)).amax(2) < 0.001
+    roi_iou_max, assign = ov_gt.max(dim=2)
+    pos_bool = (roi_iou_max >= 0.5) & valid_prop
+    neg_bool = (roi_iou_max < 0.5) & no_crowd & valid_prop
+
+    pos_cap = int(R * config.ROIS.ROI_POSITIVE_RATIO)
+    ratio = 1.0 / config.ROIS.ROI_POSITIVE_RATIO
+
+    def ranked(mask, k):
+        key = torch.rand(mask.shape, device=dev, generator=generator) + 1.0
+        key = torch.where(mask, key, torch.zeros_like(key))
+        top, idx = torch.topk(key, min(k, P), dim=1, sorted=True)
+        return idx, (top > 0).sum(1)
+
+    pos_idx, n_pos_avail = ranked(pos_bool, pos_cap)
+    pos_cnt = n_pos_avail.clamp(max=pos_cap)
+    neg_want = torch.floor(ratio * pos_cnt.double() - pos_cnt.double()).long()     # int(r*pos - pos)
+    neg_idx, n_neg_avail = ranked(neg_bool, R)
+    neg_cnt = torch.minimum(neg_want, n_neg_avail).clamp(max=R)
+    neg_cnt = torch.minimum(neg_cnt, (R - pos_cnt))
+
+    slot = torch.arange(R, device=dev).unsqueeze(0)
+    is_pos = slot < pos_cnt.unsqueeze(1)
+    is_neg = (~is_pos) & (slot < (pos_cnt + neg_cnt).unsqueeze(1))
+    pi = torch.gather(pos_idx, 1, slot.clamp(max=pos_idx.size(1) - 1))
+    ni = torch.gather(neg_idx, 1, (slot - pos_cnt.unsqueeze(1)).clamp(min=0, max=neg_idx.size(1) - 1))
+    sel = torch.where(is_pos, pi, ni)
+    used = (is_pos | is_neg)
+    rois = torch.gather(proposals, 1, sel.unsqueeze(2).expand(-1, -1, 4)) * used.unsqueeze(2).float()
+
+    roi_assign = torch.gather(assign, 1, sel)
+    roi_gt_boxes = torch.gather(gt_boxes, 1, roi_assign.unsqueeze(2).expand(-1, -1, 4))
+    cls = torch.gather(gt_class_ids, 1, roi_assign)
+    target_class_ids = torch.where(is_pos, cls, torch.zeros_like(cls)).to(torch.int32)
+    deltas = box_refinement(rois, roi_gt_boxes) / torch.as_tensor(config.DATA.BBOX_STD_DEV, device=dev)
+    target_deltas = torch.where(is_pos.unsqueeze(2), deltas, torch.zeros_like(deltas))
+
+    # mask targets: crop the GT mini-mask with the RoI expressed in mini-mask space (:301-322)
+    boxes = rois
+    if config.MRCNN.USE_MINI_MASK:
+        gh = (roi_gt_boxes[..., 2] - roi_gt_boxes[..., 0])
+        gw = (roi_gt_boxes[..., 3] - roi_gt_boxes[..., 1])
+        boxes = torch.stack([(rois[..., 0] - roi_gt_boxes[..., 0]) / gh, (rois[..., 1] - roi_gt_boxes[..., 1]) / gw,
+                             (rois[..., 2] - roi_gt_boxes[..., 0]) / gh, (rois[..., 3] - roi_gt_boxes[..., 1]) / gw], -1)
+    boxes = torch.where(is_pos.unsqueeze(2), boxes, torch.zeros_like(boxes))
+    box_ids = (roi_assign + torch.arange(b, device=dev).unsqueeze(1) * G).to(torch.int32)
+    masks = CropAndResizeFunction(mh, mw)(gt_masks.reshape(b * G, 1, gt_masks.size(2), gt_masks.size(3)).float(),
+                                          boxes.reshape(-1, 4), box_ids.reshape(-1))
+    masks = torch.round(masks.view(b, R, mh, mw))
+    target_mask = torch.where(is_pos.view(b, R, 1, 1), masks, torch.zeros_like(masks))
+    return rois.detach(), target_class_ids, target_deltas.detach(), target_mask.detach()
+
+
+# --------------------------------------------------------------------------------------
+# losses (lib/layers.py:808-934) -- masked means instead of nonzero() gathers
+# --------------------------------------------------------------------------------------
+def _masked_mean(values, mask, per_item=1):
+    n = mask.sum()
+    return (values * mask).sum() / (n * per_item).clamp(min=1)
+
+
+def compute_rpn_class_loss(target_rpn_match, rpn_class_logits):
+    anchor_class = (target_rpn_match == 1).long()
+    ce = F.cross_entropy(rpn_class_logits.reshape(-1, 2), anchor_class.reshape(-1), reduction='none')
+    return _masked_mean(ce, (target_rpn_match != 0).reshape(-1).float())
+
+
+def compute_rpn_bbox_loss(target_rpn_deltas, target_rpn_match, rpn_bbox):
+    pos = (target_rpn_match == 1).float().unsqueeze(2)
+    l = F.smooth_l1_loss(rpn_bbox, target_rpn_deltas, reduction='none')
+    return (l * pos).sum() / (pos.sum() * 4).clamp(min=1)
+
+
+def compute_mrcnn_class_loss(target_class_ids, pred_class_logits):
+    has_fg = (target_class_ids.sum() != 0).float()
+    loss = F.cross_entropy(pred_class_logits.reshape(-1, pred_class_logits.size(-1)),
+                           target_class_ids.long().reshape(-1))
+    return loss * has_fg
+
+
+def compute_mrcnn_bbox_loss(target_bbox, target_class_ids, pred_bbox):
+    """pred_bbox [b, R, num_classes, 4]: positives only, class-specific row."""
+    cls = target_class_ids.long()
+    pos = (cls > 0).float().unsqueeze(2)
+    pred = torch.gather(pred_bbox, 2, cls.view(cls.size(0), cls.size(1), 1, 1).expand(-1, -1, 1, 4)).squeeze(2)
+    l = F.smooth_l1_loss(pred, target_bbox, reduction='none')
+    return (l * pos).sum() / (pos.sum() * 4).clamp(min=1)
+
+
+def compute_mrcnn_mask_loss(target_masks, target_class_ids, pred_masks):
+    """pred_masks [b, R, num_classes, h, w] probabilities: positives only, class-specific mask."""
+    cls = target_class_ids.long()
+    b, R, _, h, w = pred_masks.shape
+    pos = (cls > 0).float().view(b, R, 1, 1)
+    pred = torch.gather(pred_masks, 2, cls.view(b, R, 1, 1, 1).expand(-1, -1, 1, h, w)).squeeze(2)
+    l = F.binary_cross_entropy(pred, target_masks, reduction='none')
+    return (l * pos).sum() / (pos.sum() * h * w).clamp(min=1)

@@ -1,0 +1,167 @@
+"""MaskRCNN with the feature intertwiner: the caller of every hot-path operator.
+Counterpart of lib/model.py of the reference (train path; same sub-module names, so
+state dicts line up: fpn.*, rpn.*, dev_roi.*, ot_loss.*, classifier.*, mask.*).
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .intertwiner import FeatureBuffer, merge_feat_vec
+from .layers import (compute_mrcnn_bbox_loss, compute_mrcnn_class_loss, compute_mrcnn_mask_loss,
+                     compute_rpn_bbox_loss, compute_rpn_class_loss, generate_pyramid_priors,
+                     prepare_det_target, prepare_rpn_target, proposal_layer)
+from .OT_module import OptTrans
+from .sub_module import FPN, RPN, Classifier, Dev, Mask, ResNet
+
+EPS = 1e-20
+
+
+class MaskRCNN(nn.Module):
+    def __init__(self, config):
+        super(MaskRCNN, self).__init__()
+        self.config = config
+        self._build(config)
+        self._initialize_weights()
+        self.feature_buffer = None
+        self.proposal_hook = None     # synthetic-benchmark hook, see layers.proposal_layer
+        self.generator = None         # optional torch.Generator for target sub-sampling
+
+    def _build(self, config):
+        resnet = ResNet(config.MODEL.BACKBONE, stage5=True)
+        C1, C2, C3, C4, C5 = resnet.stages()
+        self.fpn = FPN(config, C1, C2, C3, C4, C5, out_channels=256)
+        priors = generate_pyramid_priors(config.RPN.ANCHOR_SCALES, config.RPN.ANCHOR_RATIOS,
+                                         config.MODEL.BACKBONE_SHAPES, config.MODEL.BACKBONE_STRIDES,
+                                         config.RPN.ANCHOR_STRIDE)
+        self.register_buffer("priors", torch.from_numpy(priors).float(), persistent=False)
+        self.rpn = RPN(len(config.RPN.ANCHOR_RATIOS), config.RPN.ANCHOR_STRIDE, input_ch=256)
+        self.dev_roi = Dev(config, depth=256)
+        if config.DEV.SWITCH and config.DEV.LOSS_CHOICE == 'ot':
+            self.ot_loss = OptTrans(config, ch_x=1024, epsilon=config.DEV.OT_EPSILON, L=config.DEV.OT_L)
+        self.classifier = Classifier(depth=256, num_classes=config.DATASET.NUM_CLASSES,
+                                     pool_size=config.MRCNN.POOL_SIZE, config=config)
+        self.mask = Mask(depth=256, num_classes=config.DATASET.NUM_CLASSES)
+
+    def _initialize_weights(self):
+        """lib/model.py:84-103."""
+        for m in self.modules():
+            if isinstance(m, (nn.Conv2d, nn.Conv1d)):
+                nn.init.xavier_uniform_(m.weight)
+                if m.bias is not None:
+                    m.bias.data.zero_()
+            elif isinstance(m, (nn.ConvTranspose2d, nn.ConvTranspose1d)):
+                nn.init.xavier_normal_(m.weight)
+                if m.bias is not None:
+                    m.bias.data.zero_()
+            elif isinstance(m, (nn.BatchNorm2d, nn.BatchNorm1d)):
+                m.weight.data.fill_(1)
+                m.bias.data.zero_()
+            elif isinstance(m, nn.Linear):
+                m.weight.data.normal_(0, 0.01)
+                m.bias.data.zero_()
+
+    def initialize_buffer(self, device=None):
+        device = device or next(self.parameters()).device
+        self.feature_buffer = FeatureBuffer(self.config.DEV.BUFFER_SIZE, 1024, self.config.DATASET.NUM_CLASSES,
+                                            device)
+
+    # ------------------------------------------------------------------ forward (train)
+    def forward(self, input, mode='train'):
+        """input = [images [b,3,S,S], gt_class_ids [b,G], gt_boxes [b,G,4] pixels, gt_masks [b,G,56,56]].
+        Returns (loss_merge [1,5], big_feat, big_cnt, small_feat, small_cnt, big_loss,
+        small_output_all, small_gt_all, fpn_ot_loss) as lib/model.py:466-469."""
+        if mode != 'train':
+            raise NotImplementedError("the MI355X build covers the training hot path (SURVEY 8a)")
+        cfg = self.config
+        images, gt_class_ids, gt_boxes, gt_masks = input[0], input[1], input[2], input[3]
+        bs = images.size(0)
+        self.eval()   # the reference always runs BN (and everything else) in eval mode
+        proposal_cnt = cfg.RPN.POST_NMS_ROIS_INFERENCE   # also Q1
+
+        p2, p3, p4, p5, p6, fpn_ot_loss = self.fpn(images, mode=mode)
+        rpn_maps = [p2, p3, p4, p5, p6]
+        mrcnn_maps = [p2, p3, p4, p5]
+        outs = [self.rpn(p) for p in rpn_maps]
+        rpn_logits, rpn_probs, rpn_bbox = [torch.cat(list(o), dim=1) for o in zip(*outs)]
+
+        with torch.no_grad():
+            proposals, num_prop = proposal_layer([rpn_probs, rpn_bbox], proposal_cnt, cfg.RPN.NMS_THRESHOLD,
+                                                 self.priors, cfg, self.proposal_hook)
+            h, w = float(cfg.DATA.IMAGE_SHAPE[0]), float(cfg.DATA.IMAGE_SHAPE[1])
+            scale = torch.tensor([h, w, h, w], device=images.device)
+            target_rpn_match, target_rpn_deltas = prepare_rpn_target(self.priors, gt_class_ids, gt_boxes, cfg,
+                                                                     self.generator)
+            rois, target_class_ids, target_deltas, target_mask = prepare_det_target(
+                proposals, num_prop, gt_class_ids, gt_boxes / scale, gt_masks, cfg, self.generator)
+
+        K = cfg.DATASET.NUM_CLASSES
+        pooled_cls, pooled_mask, feat_out = self.dev_roi(mrcnn_maps, rois, target_class_ids)
+        scale_num = 3
+        if cfg.DEV.SWITCH and not cfg.DEV.BASELINE:
+            big_feat, big_cnt, small_feat, small_cnt, big_loss, small_output_all, small_gt_all = feat_out
+        else:
+            z = images.new_zeros
+            big_feat, small_feat = z(1, scale_num, 1024, K), z(1, scale_num, 1024, K)
+            big_cnt, small_cnt = z(1, scale_num, 1, K), z(1, scale_num, 1, K)
+            big_loss, small_output_all, small_gt_all = z(1, scale_num, 1), z(1, 1024), z(1)
+
+        mrcnn_class_logits, _, mrcnn_bbox = self.classifier(pooled_cls, small_output_all, small_gt_all)
+        mrcnn_mask = self.mask(pooled_mask)
+        mrcnn_class_logits = mrcnn_class_logits.view(bs, -1, mrcnn_class_logits.size(1))
+        mrcnn_bbox = mrcnn_bbox.view(bs, -1, mrcnn_bbox.size(1), mrcnn_bbox.size(2))
+        mrcnn_mask = mrcnn_mask.view(bs, -1, mrcnn_mask.size(1), mrcnn_mask.size(2), mrcnn_mask.size(3))
+
+        losses = torch.stack((
+            compute_rpn_class_loss(target_rpn_match, rpn_logits),
+            compute_rpn_bbox_loss(target_rpn_deltas, target_rpn_match, rpn_bbox),
+            compute_mrcnn_class_loss(target_class_ids, mrcnn_class_logits),
+            compute_mrcnn_bbox_loss(target_deltas, target_class_ids, mrcnn_bbox),
+            compute_mrcnn_mask_loss(target_mask, target_class_ids, mrcnn_mask))).view(1, 5)
+        return (losses, big_feat, big_cnt, small_feat, small_cnt, big_loss, small_output_all, small_gt_all,
+                fpn_ot_loss)
+
+    # ------------------------------------------------------------------ meta loss
+    def meta_loss(self, feat_input, reduce_fn=None):
+        """lib/model.py:143-210 for DEV.INST_LOSS == False.
+
+        big_*/small_* are [G, S, ...] stacks over (gpu, scale).  `reduce_fn(sum_feat, sum_cnt)`
+        -- used by the data-parallel path -- all-reduces the count-weighted sums across ranks,
+        which is algebraically the reference's gather-to-GPU-0 + _merge_feat_vec.
+        Static shapes: the loss is evaluated for every foreground class and averaged over the
+        classes present in both the current small statistics and the buffer; the reference
+        selects those classes with nonzero() and leaves the OT loss as a per-class vector that
+        `loss.backward()` could not reduce -- mean is used here, as for
+        its l1/l2 choices."""
+        cfg = self.config
+        big_feat, big_cnt, small_feat, small_cnt = feat_input[:4]
+        if self.feature_buffer is None:
+            self.initialize_buffer(big_feat.device)
+
+        def merged(feat, cnt):
+            s = (feat * cnt).sum(0).sum(0)
+            c = cnt.sum(0).sum(0)
+            if reduce_fn is not None:
+                s, c = reduce_fn(s, c)
+            return s / (c + EPS), c
+
+        b_feat, b_cnt = merged(big_feat.detach(), big_cnt.detach())
+        final_big = self.feature_buffer.update(b_feat, b_cnt)                  # [1024, K]
+        s_feat, s_cnt = merged(small_feat, small_cnt.detach())
+        s_cnt = s_cnt.clone()
+        s_cnt[0, 0] = 0                                                       # no background class
+        buf_cnt = self.feature_buffer.buffer_cnt.sum(0)                       # [1, K]
+        sel = ((s_cnt > 0) & (buf_cnt > 0)).view(-1)[1:].float()              # foreground classes
+        SMALL = s_feat[:, 1:].t()                                             # [K-1, 1024]
+        BIG = final_big[:, 1:].t().detach()
+        choice = cfg.DEV.LOSS_CHOICE
+        if choice == 'ot':
+            per_cls = self.ot_loss(SMALL.unsqueeze(-1), BIG.unsqueeze(-1).contiguous())
+        elif choice == 'l2':
+            per_cls = ((SMALL - BIG) ** 2).mean(1)
+        elif choice == 'l1':
+            per_cls = (SMALL - BIG).abs().mean(1)
+        elif choice == 'kl':
+            per_cls = (BIG * (torch.log(BIG.clamp_min(1e-38)) - torch.log(SMALL))).mean(1)
+        else:
+            raise ValueError(choice)
+        return (per_cls * sel).sum() / sel.sum().clamp(min=1)

@@ -9,6 +9,10 @@ import torch
 
 from .. import _lib
 
+# bench.py sets this to a list to record, per forward launch, what is needed to compute the
+# launch's algorithmic bytes (references only; no copies, no synchronisation).
+LAUNCH_LOG = None
+
 
 class _CropAndResize(torch.autograd.Function):
     @staticmethod
@@ -87,6 +91,9 @@ class _PyramidCrop(torch.autograd.Function):
                 ptrs, hs, ws, nl, _lib.ptr(boxes_c), _lib.ptr(ind_c), _lib.ptr(lvl_c), N, B, C,
                 int(crop_height), int(crop_width), float(extrapolation_value), _lib.ptr(crops),
                 _lib.current_stream()), "fi_pyramid_crop_forward")
+        if LAUNCH_LOG is not None:
+            LAUNCH_LOG.append({"pyramid": True, "crop": int(crop_height), "depth": int(C), "boxes": boxes_c,
+                               "level": lvl_c, "box_ind": ind_c, "shapes": [(m.shape[2], m.shape[3]) for m in maps]})
         ctx.shapes = [tuple(m.shape) for m in maps]
         ctx.crop = (int(crop_height), int(crop_width))
         ctx.save_for_backward(boxes_c, ind_c, lvl_c)

@@ -1,0 +1,407 @@
+"""Network modules around the hot-path operators: ResNet-FPN backbone, RPN, the Dev
+(intertwiner RoI) stage, classifier and mask heads.  Counterpart of lib/sub_module.py
+of the reference, with identical parameter names (state-dict compatible) and the same
+layer arithmetic; the RoI stage is re-designed around the one-launch pyramid RoIAlign
+kernel instead of per-level nonzero / gather / crop / cat / scatter loops.
+
+Dense convolutions currently run on MIOpen through torch (fp32); the MFMA conv path is
+the next step of the build plan.  BatchNorm is always evaluated with running
+statistics, as in the reference where `if mode == 'inference' or 'visualize'` is always
+true (lib/model.py:265-267).
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .intertwiner import class_mean, roi_level
+from .roi_align.crop_and_resize import CropAndResizeFunction, pyramid_crop_and_resize
+from .roi_pooling.functions.roi_pool import RoIPoolFunction
+
+
+class SamePad2d(nn.Module):
+    """TensorFlow 'SAME' padding (lib/sub_module.py:9-33).  `folded=True` means the following
+    convolution carries the (symmetric) padding itself, so no padded copy is materialised."""
+
+    def __init__(self, kernel_size, stride, folded=False):
+        super(SamePad2d, self).__init__()
+        self.kernel_size = nn.modules.utils._pair(kernel_size)
+        self.stride = nn.modules.utils._pair(stride)
+        self.folded = folded
+
+    def pads(self, in_h, in_w):
+        out_h = math.ceil(float(in_h) / float(self.stride[0]))
+        out_w = math.ceil(float(in_w) / float(self.stride[1]))
+        pad_h = max((out_h - 1) * self.stride[0] + self.kernel_size[0] - in_h, 0)
+        pad_w = max((out_w - 1) * self.stride[1] + self.kernel_size[1] - in_w, 0)
+        return pad_w // 2, pad_w - pad_w // 2, pad_h // 2, pad_h - pad_h // 2
+
+    def forward(self, x):
+        if self.folded:
+            return x
+        l, r, t, b = self.pads(x.size(2), x.size(3))
+        return F.pad(x, (l, r, t, b), 'constant', 0)
+
+    def __repr__(self):
+        return self.__class__.__name__
+
+
+def _bn(ch, eps=0.001, momentum=0.01):
+    return nn.BatchNorm2d(ch, eps=eps, momentum=momentum)
+
+
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super(Bottleneck, self).__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, kernel_size=1, stride=stride)
+        self.bn1 = _bn(planes)
+        self.padding2 = SamePad2d(kernel_size=3, stride=1, folded=True)
+        self.conv2 = nn.Conv2d(planes, planes, kernel_size=3, padding=1)
+        self.bn2 = _bn(planes)
+        self.conv3 = nn.Conv2d(planes, planes * 4, kernel_size=1)
+        self.bn3 = _bn(planes * 4)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+        self.stride = stride
+
+    def forward(self, x):
+        residual = x
+        out = self.relu(self.bn1(self.conv1(x)))
+        out = self.relu(self.bn2(self.conv2(out)))
+        out = self.bn3(self.conv3(out))
+        if self.downsample is not None:
+            residual = self.downsample(x)
+        out = out + residual
+        return self.relu(out)
+
+
+class ResNet(nn.Module):
+    def __init__(self, architecture, stage5=False):
+        super(ResNet, self).__init__()
+        assert architecture in ["resnet50", "resnet101"]
+        self.inplanes = 64
+        self.layers = [3, 4, {"resnet50": 6, "resnet101": 23}[architecture], 3]
+        self.block = Bottleneck
+        self.stage5 = stage5
+        self.C1 = nn.Sequential(
+            nn.Conv2d(3, 64, kernel_size=7, stride=2, padding=3),
+            _bn(64),
+            nn.ReLU(inplace=True),
+            SamePad2d(kernel_size=3, stride=2),
+            nn.MaxPool2d(kernel_size=3, stride=2),
+        )
+        self.C2 = self.make_layer(self.block, 64, self.layers[0])
+        self.C3 = self.make_layer(self.block, 128, self.layers[1], stride=2)
+        self.C4 = self.make_layer(self.block, 256, self.layers[2], stride=2)
+        self.C5 = self.make_layer(self.block, 512, self.layers[3], stride=2) if self.stage5 else None
+
+    def stages(self):
+        return [self.C1, self.C2, self.C3, self.C4, self.C5]
+
+    def make_layer(self, block, planes, blocks, stride=1):
+        downsample = None
+        if stride != 1 or self.inplanes != planes * block.expansion:
+            downsample = nn.Sequential(
+                nn.Conv2d(self.inplanes, planes * block.expansion, kernel_size=1, stride=stride),
+                _bn(planes * block.expansion),
+            )
+        layers = [block(self.inplanes, planes, stride, downsample)]
+        self.inplanes = planes * block.expansion
+        for _ in range(1, blocks):
+            layers.append(block(self.inplanes, planes))
+        return nn.Sequential(*layers)
+
+
+class FPN(nn.Module):
+    def __init__(self, config, C1, C2, C3, C4, C5, out_channels):
+        super(FPN, self).__init__()
+        self.config = config
+        self.out_channels = out_channels
+        self.C1, self.C2, self.C3, self.C4, self.C5 = C1, C2, C3, C4, C5
+        self.P6 = nn.MaxPool2d(kernel_size=1, stride=2)
+        oc = out_channels
+
+        def smooth():
+            return nn.Sequential(SamePad2d(kernel_size=3, stride=1, folded=True),
+                                 nn.Conv2d(oc, oc, kernel_size=3, stride=1, padding=1))
+
+        self.P5_conv1 = nn.Conv2d(2048, oc, kernel_size=1, stride=1)
+        self.P5_conv2 = smooth()
+        self.P4_conv1 = nn.Conv2d(1024, oc, kernel_size=1, stride=1)
+        self.P4_conv2 = smooth()
+        self.P3_conv1 = nn.Conv2d(512, oc, kernel_size=1, stride=1)
+        self.P3_conv2 = smooth()
+        self.P2_conv1 = nn.Conv2d(256, oc, kernel_size=1, stride=1)
+        self.P2_conv2 = smooth()
+        self.ot = False
+        if getattr(config.TRAIN, "FPN_OT_LOSS", False):
+            from .OT_module import OptTrans
+            self.ot = True
+            base = int(config.DATA.IMAGE_SHAPE[0] / 4)
+            self.p2_ot = OptTrans(config, ch_x=256, spatial_x=base / 2, spatial_y=base)
+            self.p3_ot = OptTrans(config, ch_x=256, spatial_x=base / 4, spatial_y=base / 2)
+            self.p4_ot = OptTrans(config, ch_x=256, spatial_x=base / 8, spatial_y=base / 4)
+
+    def forward(self, x, mode='train'):
+        bs = x.size(0)
+        ot_loss = x.new_zeros(bs, 3)
+        x = self.C1(x)
+        c2 = self.C2(x)
+        c3 = self.C3(c2)
+        c4 = self.C4(c3)
+        c5 = self.C5(c4)
+        p5 = self.P5_conv1(c5)
+        up = lambda t: F.interpolate(t, scale_factor=2, mode='nearest')
+        if self.ot and mode == 'train':
+            t4 = self.P4_conv1(c4)
+            l0 = self.p4_ot(p5, t4)
+            p4 = t4 + up(p5)
+            t3 = self.P3_conv1(c3)
+            l1 = self.p3_ot(p4, t3)
+            p3 = t3 + up(p4)
+            t2 = self.P2_conv1(c2)
+            l2 = self.p2_ot(p3, t2)
+            p2 = t2 + up(p3)
+            ot_loss = torch.stack((l0, l1, l2), 1)
+        else:
+            p4 = self.P4_conv1(c4) + up(p5)
+            p3 = self.P3_conv1(c3) + up(p4)
+            p2 = self.P2_conv1(c2) + up(p3)
+        p5 = self.P5_conv2(p5)
+        p4 = self.P4_conv2(p4)
+        p3 = self.P3_conv2(p3)
+        p2 = self.P2_conv2(p2)
+        p6 = self.P6(p5)
+        return [p2, p3, p4, p5, p6, ot_loss]
+
+
+class RPN(nn.Module):
+    """Returns [rpn_class_logits [b, anchors, 2], rpn_probs, rpn_bbox [b, anchors, 4]]."""
+
+    def __init__(self, anchors_per_location, anchor_stride, input_ch):
+        super(RPN, self).__init__()
+        self.anchor_stride = anchor_stride
+        self.input_ch = input_ch
+        self.padding = SamePad2d(kernel_size=3, stride=anchor_stride, folded=(anchor_stride == 1))
+        self.conv_shared = nn.Conv2d(input_ch, 512, kernel_size=3, stride=anchor_stride,
+                                     padding=1 if anchor_stride == 1 else 0)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv_class = nn.Conv2d(512, 2 * anchors_per_location, kernel_size=1, stride=1)
+        self.softmax = nn.Softmax(dim=2)
+        self.conv_bbox = nn.Conv2d(512, 4 * anchors_per_location, kernel_size=1, stride=1)
+
+    def forward(self, x):
+        x = self.relu(self.conv_shared(self.padding(x)))
+        logits = self.conv_class(x).permute(0, 2, 3, 1).contiguous().view(x.size(0), -1, 2)
+        probs = self.softmax(logits)
+        bbox = self.conv_bbox(x).permute(0, 2, 3, 1).contiguous().view(x.size(0), -1, 4)
+        return [logits, probs, bbox]
+
+
+class Dev(nn.Module):
+    """The intertwiner RoI stage (lib/sub_module.py:286-692), 'beta' structure.
+
+    forward(x, rois, roi_cls_gt) -> pooled [bs*R,256,7,7], mask [bs*R,256,14,14], feat_out.
+    One pyramid launch per crop size replaces the per-level loops; outputs are in the
+    original RoI order by construction (the reference scatters them back, :644-662).
+    """
+
+    def __init__(self, config, depth):
+        super(Dev, self).__init__()
+        self.depth = depth
+        self.use_dev = config.DEV.SWITCH
+        self.pool_size = config.MRCNN.POOL_SIZE
+        self.mask_pool_size = config.MRCNN.MASK_POOL_SIZE
+        self.image_shape = config.DATA.IMAGE_SHAPE
+        self.num_classs = config.DATASET.NUM_CLASSES
+        self.config = config
+        self.structure = config.DEV.STRUCTURE
+        self.roi_type = config.ROIS.METHOD
+        self.roi_spatial_scale = [1. / 4, 1. / 8, 1. / 16, 1. / 32]
+        if self.use_dev:
+            self.feat_pool_size = config.DEV.FEAT_BRANCH_POOL_SIZE
+            assert self.feat_pool_size % 2 == 0, 'pool size of feature branch has to be even'
+            if not config.DEV.DIS_UPSAMPLER:
+                if config.DEV.UPSAMPLE_FAC == 1.:
+                    conv_opt = nn.Conv2d(depth, depth, kernel_size=3, padding=1)
+                elif config.DEV.UPSAMPLE_FAC == 2.:
+                    conv_opt = nn.ConvTranspose2d(depth, depth, kernel_size=3, stride=2, padding=1,
+                                                  output_padding=1)
+                n_up = 4 if config.DEV.MULTI_UPSAMPLER else 1
+                self.upsample = nn.ModuleList()
+                for _ in range(n_up):
+                    self.upsample.append(nn.Sequential(conv_opt, nn.BatchNorm2d(depth), nn.ReLU(inplace=True)))
+            if not config.DEV.BASELINE:
+                k = int(self.feat_pool_size / 2)
+                self.feat_extract = nn.Sequential(
+                    nn.Conv2d(depth, 512, kernel_size=3, padding=1, stride=2), nn.BatchNorm2d(512),
+                    nn.ReLU(inplace=True),
+                    nn.Conv2d(512, 1024, kernel_size=k, stride=1), nn.BatchNorm2d(1024), nn.ReLU(inplace=True),
+                    nn.Conv2d(1024, 1024, kernel_size=1, stride=1), nn.BatchNorm2d(1024), nn.ReLU(inplace=True),
+                )
+                if config.DEV.LOSS_CHOICE in ('l2', 'l1'):
+                    self.last_op = nn.Sigmoid()
+                elif config.DEV.LOSS_CHOICE == 'kl':
+                    self.last_op = nn.Softmax(dim=1)
+
+    @staticmethod
+    def _find_big_box2(level, roi_lvl):
+        """RoIs that act as 'big' supervision at pyramid level `level` (:366-378)."""
+        return roi_lvl > level if level < 5 else torch.zeros_like(roi_lvl, dtype=torch.bool)
+
+    def _crop(self, maps, boxes, box_ind, level, size):
+        if self.roi_type == 'roi_align':
+            return pyramid_crop_and_resize(maps, boxes, box_ind, level, size, size)
+        # roi_pool: per level (the RoIPool kernel takes pixel boxes and a per-level scale)
+        out = boxes.new_zeros(boxes.size(0), maps[0].size(1), size, size)
+        pix = self._make_roi_pool_box_input(boxes, box_ind)
+        for i, lvl in enumerate(range(2, 6)):
+            sel = torch.nonzero(level == lvl).view(-1)
+            if sel.numel():
+                out[sel] = RoIPoolFunction(size, size, self.roi_spatial_scale[i])(maps[i], pix[sel])
+        return out
+
+    def _make_roi_pool_box_input(self, boxes, box_ind):
+        b = boxes * float(self.image_shape[0])      # square images only
+        return torch.stack([box_ind.float(), b[:, 1], b[:, 0], b[:, 3], b[:, 2]], dim=1)
+
+    def forward(self, x, rois, roi_cls_gt=None):
+        cfg = self.config
+        base = cfg.ROIS.ASSIGN_ANCHOR_BASE
+        bs, R = rois.size(0), rois.size(1)
+        boxes = rois.reshape(-1, 4)
+        box_ind = torch.arange(bs, device=rois.device, dtype=torch.int32).repeat_interleave(R)
+        level = roi_level(boxes, float(self.image_shape[0] * self.image_shape[1]), base)
+
+        if not self.use_dev:
+            pooled = self._crop(x, boxes, box_ind, level, self.pool_size)
+            mask = self._crop(x, boxes, box_ind, level, self.mask_pool_size)
+            return pooled, mask, None
+        if self.structure != 'beta':
+            raise NotImplementedError("only DEV.STRUCTURE='beta' executes in the reference (SURVEY Q9)")
+
+        train_phase = roi_cls_gt is not None
+        # make-up layer on every level, then ONE launch per crop size over all levels
+        up_maps = [self.upsample[i if cfg.DEV.MULTI_UPSAMPLER else 0](m) for i, m in enumerate(x)]
+        pooled = self._crop(up_maps, boxes, box_ind, level, self.pool_size)
+        mask_and_feat = self._crop(up_maps, boxes, box_ind, level, self.mask_pool_size)
+        if cfg.DEV.BASELINE:
+            return pooled, mask_and_feat, []
+
+        # 'small' features of the RoIs on levels 2..4 (levels with meta loss, :434-435), written
+        # level-major like the reference's small_output_all / small_gt_all (:583-598)
+        meta_lvl = level <= 4
+        small_rows = torch.nonzero(meta_lvl).view(-1)
+        order = small_rows[torch.sort(level[small_rows], stable=True)[1]]
+        small_output = self.feat_extract(mask_and_feat[order])
+        if cfg.DEV.LOSS_CHOICE != 'ot':
+            small_output = self.last_op(small_output)
+        small_output = small_output.view(order.numel(), -1)
+        total_box = bs * R
+        small_output_all = small_output.new_zeros(total_box, small_output.size(1))
+        small_output_all[:order.numel()] = small_output
+        small_gt_all = small_output.new_zeros(total_box)
+        if not train_phase:
+            small_gt_all[:order.numel()] = 1
+            return pooled, mask_and_feat, [small_output_all, small_gt_all]
+
+        gt = roi_cls_gt.reshape(-1).to(torch.int32)
+        small_gt_all[:order.numel()] = gt[order].float()
+        lvl_o = level[order]
+        gt_o = gt[order]
+        K = self.num_classs
+        small_feat, small_cnt, big_feat, big_cnt = [], [], [], []
+        for lvl in (2, 3, 4):
+            f, c = class_mean(small_output, torch.where(lvl_o == lvl, gt_o, torch.zeros_like(gt_o)), K)
+            small_feat.append(f)
+            small_cnt.append(c)
+        # 'big' boxes: RoIs of higher levels pooled 14x14 from the RAW level map (:498-507)
+        big_sel, big_lvl = [], []
+        for lvl in (2, 3, 4):
+            idx = torch.nonzero(self._find_big_box2(lvl, level)).view(-1)
+            big_sel.append(idx)
+            big_lvl.append(torch.full_like(idx, lvl, dtype=torch.int32))
+        big_idx = torch.cat(big_sel)
+        big_level = torch.cat(big_lvl)
+        with torch.set_grad_enabled(not cfg.DEV.BIG_FEAT_DETACH):
+            if big_idx.numel():
+                big_pooled = self._crop(x, boxes[big_idx], box_ind[big_idx], big_level, self.feat_pool_size)
+                big_out = self.feat_extract(big_pooled)
+                if cfg.DEV.LOSS_CHOICE != 'ot':
+                    big_out = self.last_op(big_out)
+                big_out = big_out.view(big_idx.numel(), -1)
+            else:
+                big_out = small_output.new_zeros(0, small_output.size(1))
+            big_gt = gt[big_idx]
+            for i, lvl in enumerate((2, 3, 4)):
+                # a level without small boxes contributes no big statistics either (:456-467)
+                has_small = (level == lvl).any().to(big_gt.dtype)
+                g = torch.where(big_level == lvl, big_gt, torch.zeros_like(big_gt)) * has_small
+                f, c = class_mean(big_out, g, K)
+                big_feat.append(f)
+                big_cnt.append(c)
+        bf = torch.stack(big_feat).unsqueeze(0)
+        if cfg.DEV.BIG_FEAT_DETACH:
+            bf = bf.detach()
+        feat_out = [bf, torch.stack(big_cnt).unsqueeze(0),
+                    torch.stack(small_feat).unsqueeze(0), torch.stack(small_cnt).unsqueeze(0),
+                    small_output.new_zeros(1, 3, 1), small_output_all, small_gt_all]
+        return pooled, mask_and_feat, feat_out
+
+
+class Classifier(nn.Module):
+    def __init__(self, depth, num_classes, pool_size, config):
+        super(Classifier, self).__init__()
+        self.depth = depth
+        self.pool_size = pool_size
+        self.num_classes = num_classes
+        self.config = config
+        self.conv1 = nn.Conv2d(depth, 1024, kernel_size=pool_size, stride=1)
+        self.bn1 = _bn(1024)
+        self.conv2 = nn.Conv2d(1024, 1024, kernel_size=1, stride=1)
+        self.bn2 = _bn(1024)
+        self.relu = nn.ReLU(inplace=True)
+        self.linear_class = nn.Linear(1024, num_classes)
+        self.softmax = nn.Softmax(dim=1)
+        self.linear_bbox = nn.Linear(1024, num_classes * 4)
+
+    def forward(self, x, small_feat_input=None, small_gt_index=None, mode='train'):
+        x = self.relu(self.bn1(self.conv1(x)))
+        x = self.relu(self.bn2(self.conv2(x)))
+        x = x.view(-1, 1024)
+        logits = self.linear_class(x)
+        probs = self.softmax(logits)
+        bbox = self.linear_bbox(x)
+        bbox = bbox.view(bbox.size(0), -1, 4)
+        return [logits, probs, bbox]
+
+
+class Mask(nn.Module):
+    def __init__(self, depth, num_classes):
+        super(Mask, self).__init__()
+        self.depth = depth
+        self.num_classes = num_classes
+        self.padding = SamePad2d(kernel_size=3, stride=1, folded=True)
+        self.conv1 = nn.Conv2d(depth, 256, kernel_size=3, stride=1, padding=1)
+        self.bn1 = nn.BatchNorm2d(256, eps=0.001)
+        self.conv2 = nn.Conv2d(256, 256, kernel_size=3, stride=1, padding=1)
+        self.bn2 = nn.BatchNorm2d(256, eps=0.001)
+        self.conv3 = nn.Conv2d(256, 256, kernel_size=3, stride=1, padding=1)
+        self.bn3 = nn.BatchNorm2d(256, eps=0.001)
+        self.conv4 = nn.Conv2d(256, 256, kernel_size=3, stride=1, padding=1)
+        self.bn4 = nn.BatchNorm2d(256, eps=0.001)
+        self.deconv = nn.ConvTranspose2d(256, 256, kernel_size=2, stride=2)
+        self.conv5 = nn.Conv2d(256, num_classes, kernel_size=1, stride=1)
+        self.sigmoid = nn.Sigmoid()
+        self.relu = nn.ReLU(inplace=True)
+
+    def forward(self, x):
+        x = self.relu(self.bn1(self.conv1(x)))
+        x = self.relu(self.bn2(self.conv2(x)))
+        x = self.relu(self.bn3(self.conv3(x)))
+        x = self.relu(self.bn4(self.conv4(x)))
+        x = self.relu(self.deconv(x))
+        return self.sigmoid(self.conv5(x))

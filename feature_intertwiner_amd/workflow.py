@@ -1,0 +1,57 @@
+"""One training iteration -- the loop body of train_epoch (lib/workflow.py:152-230 of the
+reference): forward, meta (intertwiner) loss, loss composition, backward, gradient
+clipping, SGD step.  The reference's epoch/stage loops, logging, visdom and checkpointing
+are out of scope."""
+import torch
+
+
+def set_optimizer(net, opt):
+    """tools/utils.py:474-501: SGD, weight decay on everything except BatchNorm affine
+    parameters (names containing 'bn')."""
+    wo_bn = [p for n, p in net.named_parameters() if p.requires_grad and 'bn' not in n]
+    only_bn = [p for n, p in net.named_parameters() if p.requires_grad and 'bn' in n]
+    return torch.optim.SGD([{'params': wo_bn, 'weight_decay': opt.WEIGHT_DECAY}, {'params': only_bn}],
+                           lr=opt.INIT_LR, momentum=opt.MOMENTUM)
+
+
+def compute_loss(model, inputs, do_meta=True, world_size=1, reduce_fn=None):
+    """Returns (loss to back-propagate, detached dict of its terms).
+
+    Data parallel: the reference total is mean_g(L_det,g) + meta(global statistics)
+    (lib/workflow.py:180, 221).  With one process per GPU and gradients AVERAGED over ranks, the
+    meta term -- evaluated identically on every rank from all-reduced statistics, but reaching
+    the parameters only through the local small features -- is scaled by world_size so that the
+    averaged gradient equals the reference's."""
+    cfg = model.config
+    (merged_loss, big_feat, big_cnt, small_feat, small_cnt, big_loss, small_output_all, small_gt_all,
+     fpn_ot_loss) = model(inputs, 'train')
+    detailed = merged_loss.mean(0)
+    if cfg.DEV.SWITCH and not cfg.DEV.BASELINE:
+        meta = model.meta_loss([big_feat, big_cnt, small_feat, small_cnt, small_output_all, small_gt_all],
+                               reduce_fn=reduce_fn)
+        meta = torch.where(meta < 0, torch.zeros_like(meta), meta)       # workflow.py:196-200
+        meta = meta * cfg.DEV.LOSS_FAC if do_meta else torch.zeros_like(meta)
+    else:
+        meta = detailed.new_zeros(())
+    fpn_ot = cfg.TRAIN.FPN_OT_LOSS_FAC * fpn_ot_loss.mean()
+    loss = detailed.sum() + meta * float(world_size) + fpn_ot
+    terms = {"rpn_cls": detailed[0], "rpn_bbox": detailed[1], "mrcnn_cls": detailed[2],
+             "mrcnn_bbox": detailed[3], "mrcnn_mask": detailed[4], "meta": meta, "total": detailed.sum() + meta}
+    return loss, {k: v.detach() for k, v in terms.items()}
+
+
+def train_step(model, optimizer, inputs, do_meta=True, grad_sync=None, world_size=1, reduce_fn=None):
+    """zero_grad / backward / clip_grad_norm(MAX_GRAD_NORM) / step (lib/workflow.py:226-230).
+    `grad_sync` (data parallel) is called after backward and must leave the rank-averaged
+    gradients in place BEFORE clipping -- the reference clips the reduced gradient."""
+    cfg = model.config
+    optimizer.zero_grad(set_to_none=True)
+    loss, terms = compute_loss(model, inputs, do_meta, world_size, reduce_fn)
+    loss.backward()
+    if grad_sync is not None:
+        grad_sync()
+    if cfg.TRAIN.CLIP_GRAD:
+        torch.nn.utils.clip_grad_norm_([p for p in model.parameters() if p.grad is not None],
+                                       cfg.TRAIN.MAX_GRAD_NORM)
+    optimizer.step()
+    return terms

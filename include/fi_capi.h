@@ -204,17 +204,23 @@ int fi_class_mean_backward(const float *grad_feat, const int32_t *gt,
  * off by default, zero cost when off.
  * ---------------------------------------------------------------------- */
 enum {
-    FI_K_CROP_FWD = 0,
-    FI_K_CROP_BWD = 1,
-    FI_K_ROIPOOL_FWD = 2,
-    FI_K_ROIPOOL_BWD = 3,
-    FI_K_NMS_MASK = 4,
-    FI_K_NMS_SCAN = 5,
-    FI_K_SINKHORN = 6,
-    FI_K_CLASS_MEAN = 7,
-    FI_K_PYRAMID_CROP_FWD = 8,
-    FI_K_PYRAMID_CROP_BWD = 9,
-    FI_K_COUNT = 10
+    /* ids follow the device kernels (one template instance per common crop size); the
+     * single-level and pyramid entry points launch the same kernels */
+    FI_K_CROP_FWD_7X7 = 0,
+    FI_K_CROP_FWD_14X14 = 1,
+    FI_K_CROP_FWD_28X28 = 2,
+    FI_K_CROP_FWD_GENERIC = 3,
+    FI_K_CROP_BWD_7X7 = 4,
+    FI_K_CROP_BWD_14X14 = 5,
+    FI_K_CROP_BWD_28X28 = 6,
+    FI_K_CROP_BWD_GENERIC = 7,
+    FI_K_ROIPOOL_FWD = 8,
+    FI_K_ROIPOOL_BWD = 9,
+    FI_K_NMS_MASK = 10,
+    FI_K_NMS_SCAN = 11,
+    FI_K_SINKHORN = 12,
+    FI_K_CLASS_MEAN = 13,
+    FI_K_COUNT = 14
 };
 void fi_prof_enable(int on);
 void fi_prof_reset(void);

@@ -89,7 +89,7 @@ def main():
             b_min = out_bytes + unique_taps_bytes(taps, C) + 20 * N
             b_max = out_bytes * 5
             if "crop" in ops:
-                med, best = timeit(lambda: fn(image, rois, ind), args.iters, kernel="crop_fwd")
+                med, best = timeit(lambda: fn(image, rois, ind), args.iters, kernel="crop_fwd_%dx%d" % (crop, crop))
                 k = KERNEL_US[0] * 1e-6
                 print(json.dumps({"op": "crop_and_resize_fwd", "shape": [N, C, crop, crop], "map": [B, C, S, S],
                                   "us_median": med * 1e6, "us_best": best * 1e6, "kernel_us": k * 1e6,
@@ -100,7 +100,7 @@ def main():
                 out = fn(img, rois, ind)
                 g = torch.randn_like(out)
                 med, best = timeit(lambda: torch.autograd.grad(out, img, g, retain_graph=True), args.iters,
-                                   kernel="crop_bwd")
+                                   kernel="crop_bwd_%dx%d" % (crop, crop))
                 print(json.dumps({"op": "crop_and_resize_bwd(+memset)", "shape": [N, C, crop, crop],
                                   "us_median": med * 1e6, "us_best": best * 1e6, "kernel_us": KERNEL_US[0]}))
 
@@ -111,7 +111,7 @@ def main():
         lv = roi_level(r4, 1024 * 1024)
         for crop in (7, 14):
             med, best = timeit(lambda: pyramid_crop_and_resize(maps, r4, i4, lv, crop, crop), args.iters,
-                               kernel="pyramid_crop_fwd")
+                               kernel="crop_fwd_%dx%d" % (crop, crop))
             print(json.dumps({"op": "pyramid_crop_fwd", "shape": [r4.shape[0], 256, crop, crop],
                               "kernel_us": KERNEL_US[0],
                               "levels": np.bincount(lv.cpu().numpy(), minlength=6)[2:].tolist(),
