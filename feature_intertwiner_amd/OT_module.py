@@ -19,6 +19,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
+from .conv import Conv1d, Conv2d
 
 EPS = 1e-20
 
@@ -105,7 +106,7 @@ class OptTrans(nn.Module):
             )
         else:
             self.G_net = nn.Sequential(
-                nn.Conv1d(ch_x, ch_y, kernel_size=3, padding=1, stride=1),
+                Conv1d(ch_x, ch_y, kernel_size=3, padding=1, stride=1),
                 nn.ReLU(),
             )
 
@@ -113,10 +114,10 @@ class OptTrans(nn.Module):
         if not self.skip_critic:
             if self.two_dim:
                 self.critic = nn.Sequential(
-                    nn.Conv2d(ch_y, int(ch_y / 2), kernel_size=3, padding=1, stride=2),
+                    Conv2d(ch_y, int(ch_y / 2), kernel_size=3, padding=1, stride=2),
                     nn.BatchNorm2d(int(ch_y / 2)),
                     nn.ReLU(),
-                    nn.Conv2d(int(ch_y / 2), int(ch_y / 4), kernel_size=3, padding=1, stride=2),
+                    Conv2d(int(ch_y / 2), int(ch_y / 4), kernel_size=3, padding=1, stride=2),
                     nn.BatchNorm2d(int(ch_y / 4)),
                     nn.ReLU(),
                 )
@@ -124,7 +125,7 @@ class OptTrans(nn.Module):
                 form = getattr(getattr(config, "DEV", None), "OT_ONE_DIM_FORM", "conv")
                 if form == 'conv':
                     self.critic = nn.Sequential(
-                        nn.Conv1d(ch_y, int(ch_y / 4), kernel_size=3, padding=1, stride=1),
+                        Conv1d(ch_y, int(ch_y / 4), kernel_size=3, padding=1, stride=1),
                         nn.ReLU(),
                     )
                 elif form == 'fc':

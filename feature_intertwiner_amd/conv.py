@@ -1,0 +1,123 @@
+"""Dense convolution layers of the detector on the MI355X matrix cores.
+
+`Conv2d`, `ConvTranspose2x2` and `Conv1d` are drop-in subclasses of the torch modules
+(same constructor, same parameter names and shapes -> state dicts of the reference load
+unchanged) whose forward/backward run the hand-written fp32 MFMA implicit-GEMM kernels of
+csrc/conv_igemm.hip:
+    forward        fi_conv2d_forward
+    grad input     fi_conv2d_forward on dY with the flipped/transposed weight (stride 1), or
+                   on a zero-stuffed dY (stride > 1)
+    grad weight    fi_conv2d_weight_grad
+    grad bias      a plain reduction
+"Full-window" convolutions whose kernel covers the whole input (the 7x7 classifier conv on
+7x7 crops, lib/sub_module.py:707; the 7x7 conv of feat_extract on 7x7 maps, :333) are
+plain matrix products and go to the library GEMM.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _lib
+
+
+def _conv_fwd(x, w, b, stride, padding, relu=False):
+    L = _lib.load()
+    N, Cin, H, W = x.shape
+    Cout, _, R, S = w.shape
+    OH = (H + 2 * padding[0] - R) // stride[0] + 1
+    OW = (W + 2 * padding[1] - S) // stride[1] + 1
+    y = torch.empty((N, Cout, OH, OW), device=x.device, dtype=torch.float32)
+    with torch.cuda.device(x.device):
+        _lib.check(L.fi_conv2d_forward(_lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(y), N, Cin, H, W, Cout,
+                                       R, S, stride[0], stride[1], padding[0], padding[1], 1 if relu else 0,
+                                       _lib.current_stream()), "fi_conv2d_forward")
+    return y
+
+
+class _Conv2dFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, stride, padding):
+        _lib.require_cuda(x, w)
+        x = x.contiguous().float()
+        w = w.contiguous().float()
+        bc = b.contiguous().float() if b is not None else None
+        ctx.save_for_backward(x, w)
+        ctx.conf = (tuple(stride), tuple(padding), b is not None)
+        return _conv_fwd(x, w, bc, stride, padding)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        stride, padding, has_bias = ctx.conf
+        L = _lib.load()
+        dy = dy.contiguous().float()
+        N, Cin, H, W = x.shape
+        Cout, _, R, S = w.shape
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            wt = w.flip(2, 3).transpose(0, 1).contiguous()          # [Cin, Cout, R, S]
+            if stride == (1, 1):
+                dx = _conv_fwd(dy, wt, None, (1, 1), (R - 1 - padding[0], S - 1 - padding[1]))
+            else:
+                OH, OW = dy.shape[2], dy.shape[3]
+                rem_h = (H + 2 * padding[0] - R) % stride[0]
+                rem_w = (W + 2 * padding[1] - S) % stride[1]
+                up = dy.new_zeros(N, Cout, (OH - 1) * stride[0] + 1 + rem_h, (OW - 1) * stride[1] + 1 + rem_w)
+                up[:, :, :(OH - 1) * stride[0] + 1:stride[0], :(OW - 1) * stride[1] + 1:stride[1]] = dy
+                dx = _conv_fwd(up, wt, None, (1, 1), (R - 1 - padding[0], S - 1 - padding[1]))
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(w)
+            with torch.cuda.device(x.device):
+                _lib.check(L.fi_conv2d_weight_grad(_lib.ptr(x), _lib.ptr(dy), _lib.ptr(dw), N, Cin, H, W, Cout,
+                                                   R, S, stride[0], stride[1], padding[0], padding[1],
+                                                   _lib.current_stream()), "fi_conv2d_weight_grad")
+        if has_bias and ctx.needs_input_grad[2]:
+            db = dy.sum((0, 2, 3))
+        return dx, dw, db, None, None
+
+
+def conv2d(x, weight, bias=None, stride=(1, 1), padding=(0, 0)):
+    """Functional form.  Full-window kernels become one library GEMM."""
+    R, S = weight.shape[2], weight.shape[3]
+    if (x.shape[2], x.shape[3]) == (R, S) and tuple(padding) == (0, 0) and R * S > 1:
+        y = F.linear(x.reshape(x.shape[0], -1), weight.reshape(weight.shape[0], -1), bias)
+        return y.view(x.shape[0], weight.shape[0], 1, 1)
+    if x.shape[2] * x.shape[3] == 1 and R * S == 1:
+        y = F.linear(x.reshape(x.shape[0], -1), weight.reshape(weight.shape[0], -1), bias)
+        return y.view(x.shape[0], weight.shape[0], 1, 1)
+    return _Conv2dFn.apply(x, weight, bias, tuple(stride), tuple(padding))
+
+
+class Conv2d(nn.Conv2d):
+    """nn.Conv2d (groups=1, dilation=1, zero padding) on the MFMA implicit-GEMM kernels."""
+
+    def forward(self, x):
+        if self.groups != 1 or self.dilation != (1, 1) or self.padding_mode != 'zeros' or \
+                isinstance(self.padding, str):
+            raise NotImplementedError("fi Conv2d supports groups=1, dilation=1, numeric zero padding")
+        return conv2d(x, self.weight, self.bias, self.stride, self.padding)
+
+
+class ConvTranspose2x2(nn.ConvTranspose2d):
+    """ConvTranspose2d(kernel_size=2, stride=2) (the mask head's deconv, lib/sub_module.py:763):
+    a 1x1 convolution to 4*Cout channels followed by a pixel shuffle."""
+
+    def forward(self, x):
+        assert self.kernel_size == (2, 2) and self.stride == (2, 2) and self.padding == (0, 0) and \
+            self.output_padding == (0, 0) and self.groups == 1
+        cin, cout = self.weight.shape[0], self.weight.shape[1]
+        w = self.weight.permute(1, 2, 3, 0).reshape(cout * 4, cin, 1, 1)
+        b = self.bias.repeat_interleave(4) if self.bias is not None else None
+        return F.pixel_shuffle(conv2d(x, w, b), 2)
+
+
+class Conv1d(nn.Conv1d):
+    """The OT module's Conv1d(k=3, padding=1) layers (lib/OT_module.py:37-41, 58-63).  On the
+    length-1 inputs the intertwiner feeds them only the centre tap contributes, which is a
+    library GEMM; other lengths fall through to the stock implementation."""
+
+    def forward(self, x):
+        if x.size(2) == 1 and self.kernel_size == (3,) and self.padding == (1,) and self.stride == (1,) \
+                and self.dilation == (1,) and self.groups == 1:
+            return F.linear(x[:, :, 0], self.weight[:, :, 1], self.bias).unsqueeze(2)
+        return super(Conv1d, self).forward(x)

@@ -1,0 +1,431 @@
+// conv_igemm.hip -- fp32 implicit-GEMM convolution on the CDNA4 matrix cores (gfx950):
+// forward / data-gradient (one kernel) and weight-gradient, NCHW, arbitrary R x S,
+// stride and zero padding.  This is the MFMA path for the dense 1x1/3x3/7x7 convolutions
+// of the ResNet-FPN backbone, RPN, Dev make-up layer and mask head
+// (lib/sub_module.py:38-128, 147-228, 234-280, 308-345, 750-787 of the reference, which
+// ran them through cuDNN).
+//
+// Arithmetic: exact fp32 -- v_mfma_f32_32x32x2_f32 is bit-for-bit an fp32 fma chain, so no
+// precision is given up against the reference's fp32 convolutions (there is no TF32-like
+// mode on gfx950).  Peak for this instruction is the fp32 vector peak, 157 TFLOP/s.
+//
+// GEMM view of the forward pass   Y[m][p] = sum_k A[m][k] * B[k][p]
+//   m = output channel, p = (image, oh, ow) flattened, k = (ci, r, s)
+//   A = the weight tensor as stored ([Cout][Cin*R*S], k contiguous),
+//   B = the im2col matrix, NEVER materialised: each workgroup gathers its
+//       [BK x BN] slice straight from the NCHW input (for a fixed k, consecutive p are
+//       consecutive pixels of one input row -> coalesced), zero-filling the halo.
+// Tile: BM x 128 x 16 per 256-thread workgroup (BM = 128 or 64), 4 wavefronts as 2 x 2,
+// each owning a (BM/2) x 64 accumulator block of 32x32 MFMA tiles.  LDS tiles are stored
+// k-major ([BK][BM+4], [BK][BN+4]) so that an MFMA operand read is 32 consecutive floats
+// per half-wavefront (conflict-free ds_read_b32).  Global loads for K-step t+1 are issued
+// into registers before the MFMAs of step t and written to the other LDS buffer afterwards:
+// one barrier per K-step, HBM/L2 latency hidden behind 16..32 MFMAs (64 cycles each).
+// The epilogue adds the bias, optionally applies ReLU, and stores rows of 32 consecutive
+// pixels (128-byte segments).
+//
+// The data gradient of a stride-1 convolution is the same kernel run on dY with the
+// flipped, transposed weights and padding R-1-pad.  The weight gradient is a second GEMM
+// with the reduction over pixels (split across workgroups, fp32 atomics into dW).
+#include "fi_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kThreads = 256;
+constexpr int BN = 128;
+constexpr int BK = 16;
+constexpr int PAD = 4;
+
+struct ConvGeom {
+    int N, Cin, H, W, Cout, R, S, sh, sw, ph, pw, OH, OW;
+    int K;        // Cin*R*S
+    int P;        // N*OH*OW
+};
+
+// -------------------------------------------------------------------------------------
+// forward / dgrad
+// -------------------------------------------------------------------------------------
+template <int BM, int TR, int TS>
+__global__ __launch_bounds__(kThreads) void conv_fwd_kernel(const float *__restrict__ x,
+                                                            const float *__restrict__ w,
+                                                            const float *__restrict__ bias,
+                                                            float *__restrict__ y, ConvGeom g,
+                                                            int relu)
+{
+    constexpr int MT = BM / 64;                 // 32-row MFMA tiles per wave along M
+    __shared__ float As[2][BK][BM + PAD];
+    __shared__ float Bs[2][BK][BN + PAD];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int R = TR ? TR : g.R, S = TS ? TS : g.S;
+    const int RS = R * S;
+    const int K = g.K;
+    const int m0 = blockIdx.y * BM;
+    const int p0 = blockIdx.x * BN;
+    const int OHW = g.OH * g.OW;
+    const int HW = g.H * g.W;
+
+    // ---- per-thread constants of the B (im2col) gather: one pixel column, 8 k rows ----
+    const int bj = tid & (BN - 1);
+    const int bk0 = tid >> 7;                   // 0 or 1; rows bk0, bk0+2, ... (wave-uniform)
+    const int p = p0 + bj;
+    const bool p_ok = p < g.P;
+    int n = 0, oh = 0, ow = 0;
+    if (p_ok) {
+        n = p / OHW;
+        const int q = p - n * OHW;
+        oh = q / g.OW;
+        ow = q - oh * g.OW;
+    }
+    const int ih0 = oh * g.sh - g.ph;
+    const int iw0 = ow * g.sw - g.pw;
+    const float *__restrict__ xn = x + (size_t)n * g.Cin * HW;
+
+    // ---- A (weights) loader: 4 consecutive k of one output channel per load -----------
+    constexpr int A_LOADS = BM * BK / 4 / kThreads;     // float4 loads per thread (2 or 1)
+    const int ak4 = (tid & 3) * 4;
+    const int am = tid >> 2;                            // 0..63 (+64 for the second load)
+    const bool k_vec = (K & 3) == 0;
+
+    float a_reg[A_LOADS][4];
+    float b_reg[BK / 2];
+
+    auto load_tiles = [&](int kt) {
+        const int kbase = kt * BK;
+#pragma unroll
+        for (int i = 0; i < A_LOADS; ++i) {
+            const int m = m0 + am + i * 64;
+            const int k = kbase + ak4;
+            if (m < g.Cout && k_vec && k + 3 < K) {
+                const float4 v = *reinterpret_cast<const float4 *>(w + (size_t)m * K + k);
+                a_reg[i][0] = v.x; a_reg[i][1] = v.y; a_reg[i][2] = v.z; a_reg[i][3] = v.w;
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    a_reg[i][q] = (m < g.Cout && k + q < K) ? w[(size_t)m * K + k + q] : 0.0f;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < BK / 2; ++i) {
+            const int k = __builtin_amdgcn_readfirstlane(kbase + bk0 + 2 * i);
+            float v = 0.0f;
+            if (k < K) {
+                const int ci = k / RS;
+                const int rs = k - ci * RS;
+                const int r = rs / S;
+                const int s = rs - r * S;
+                const int ih = ih0 + r, iw = iw0 + s;
+                if (p_ok && ih >= 0 && ih < g.H && iw >= 0 && iw < g.W)
+                    v = xn[(size_t)ci * HW + ih * g.W + iw];
+            }
+            b_reg[i] = v;
+        }
+    };
+    auto store_tiles = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < A_LOADS; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) As[buf][ak4 + q][am + i * 64] = a_reg[i][q];
+#pragma unroll
+        for (int i = 0; i < BK / 2; ++i) Bs[buf][bk0 + 2 * i][bj] = b_reg[i];
+    };
+
+    f32x16 acc[MT][2];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+    const int nk = (K + BK - 1) / BK;
+    load_tiles(0);
+    store_tiles(0);
+    __syncthreads();
+
+    const int l31 = lane & 31;
+    const int khalf = lane >> 5;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) load_tiles(kt + 1);
+#pragma unroll
+        for (int kk = 0; kk < BK / 2; ++kk) {
+            const int kr = kk * 2 + khalf;
+            float af[MT], bf[2];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) af[i] = As[buf][kr][wm * (BM / 2) + i * 32 + l31];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bf[j] = Bs[buf][kr][wn * 64 + j * 32 + l31];
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nk) store_tiles(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: C/D layout col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5) ------
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int pp = p0 + wn * 64 + j * 32 + l31;
+        if (pp >= g.P) continue;
+        const int on = pp / OHW;
+        const int oq = pp - on * OHW;
+        float *__restrict__ yb = y + (size_t)on * g.Cout * OHW + oq;
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + wm * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * khalf;
+                if (m < g.Cout) {
+                    float v = acc[i][j][e];
+                    if (bias) v += bias[m];
+                    if (relu) v = fmaxf(v, 0.0f);
+                    yb[(size_t)m * OHW] = v;
+                }
+            }
+    }
+}
+
+// -------------------------------------------------------------------------------------
+// weight gradient:  dW[m][k] = sum_p dY[m][p] * Xcol[k][p]
+//   GEMM rows m = output channel, columns k = (ci, r, s), reduction over pixels p.
+//   blockIdx.z splits the pixel range; partial sums are added with fp32 atomics.
+// -------------------------------------------------------------------------------------
+template <int BM, int TR, int TS>
+__global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(const float *__restrict__ x,
+                                                              const float *__restrict__ dy,
+                                                              float *__restrict__ dw, ConvGeom g,
+                                                              int p_per_split)
+{
+    constexpr int MT = BM / 64;
+    __shared__ float As[2][BK][BM + PAD];       // dY tile  [p][m]
+    __shared__ float Bs[2][BK][BN + PAD];       // Xcol tile [p][k]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int R = TR ? TR : g.R, S = TS ? TS : g.S;
+    const int RS = R * S;
+    const int K = g.K;
+    const int m0 = blockIdx.y * BM;
+    const int k0 = blockIdx.x * BN;
+    const int OHW = g.OH * g.OW;
+    const int HW = g.H * g.W;
+    const int p_begin = blockIdx.z * p_per_split;
+    const int p_end = min(g.P, p_begin + p_per_split);
+    if (p_begin >= p_end) return;
+
+    // A loader (dY): lane -> pixel (contiguous in memory), 16 pixels x BM channels per step
+    constexpr int A_LOADS = BM * BK / kThreads;   // 8 or 4 scalar loads per thread
+    const int ap = tid & 15;
+    const int am = tid >> 4;                      // 0..15 (+16*i)
+    // B loader (input patches): lane -> pixel, column k = (ci,r,s) fixed per thread
+    constexpr int B_LOADS = BN * BK / kThreads;   // 8
+    const int bp = tid & 15;
+    const int bk = tid >> 4;                      // 0..15 (+16*i)
+    int b_ci[B_LOADS], b_r[B_LOADS], b_s[B_LOADS];
+    bool b_ok[B_LOADS];
+#pragma unroll
+    for (int i = 0; i < B_LOADS; ++i) {
+        const int k = k0 + bk + 16 * i;
+        b_ok[i] = k < K;
+        const int kc = b_ok[i] ? k : 0;
+        b_ci[i] = kc / RS;
+        const int rs = kc - b_ci[i] * RS;
+        b_r[i] = rs / S;
+        b_s[i] = rs - b_r[i] * S;
+    }
+
+    float a_reg[A_LOADS], b_reg[B_LOADS];
+    auto load_tiles = [&](int pt) {
+        // pixel handled by this thread in this step (same for the A and B loaders: ap == bp)
+        const int p = pt + ap;
+        const bool ok = p < p_end;
+        int n = 0, oh = 0, ow = 0, q = 0;
+        if (ok) {
+            n = p / OHW;
+            q = p - n * OHW;
+            oh = q / g.OW;
+            ow = q - oh * g.OW;
+        }
+        const float *__restrict__ dyn = dy + (size_t)n * g.Cout * OHW + q;
+#pragma unroll
+        for (int i = 0; i < A_LOADS; ++i) {
+            const int m = m0 + am + 16 * i;
+            a_reg[i] = (ok && m < g.Cout) ? dyn[(size_t)m * OHW] : 0.0f;
+        }
+        const int ih0 = oh * g.sh - g.ph, iw0 = ow * g.sw - g.pw;
+        const float *__restrict__ xn = x + (size_t)n * g.Cin * HW;
+#pragma unroll
+        for (int i = 0; i < B_LOADS; ++i) {
+            const int ih = ih0 + b_r[i], iw = iw0 + b_s[i];
+            float v = 0.0f;
+            if (ok && b_ok[i] && ih >= 0 && ih < g.H && iw >= 0 && iw < g.W)
+                v = xn[(size_t)b_ci[i] * HW + ih * g.W + iw];
+            b_reg[i] = v;
+        }
+    };
+    auto store_tiles = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < A_LOADS; ++i) As[buf][ap][am + 16 * i] = a_reg[i];
+#pragma unroll
+        for (int i = 0; i < B_LOADS; ++i) Bs[buf][bp][bk + 16 * i] = b_reg[i];
+    };
+
+    f32x16 acc[MT][2];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+    const int steps = (p_end - p_begin + BK - 1) / BK;
+    load_tiles(p_begin);
+    store_tiles(0);
+    __syncthreads();
+    const int l31 = lane & 31;
+    const int khalf = lane >> 5;
+    for (int st = 0; st < steps; ++st) {
+        const int buf = st & 1;
+        if (st + 1 < steps) load_tiles(p_begin + (st + 1) * BK);
+#pragma unroll
+        for (int kk = 0; kk < BK / 2; ++kk) {
+            const int kr = kk * 2 + khalf;
+            float af[MT], bf[2];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) af[i] = As[buf][kr][wm * (BM / 2) + i * 32 + l31];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bf[j] = Bs[buf][kr][wn * 64 + j * 32 + l31];
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        if (st + 1 < steps) store_tiles(buf ^ 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int k = k0 + wn * 64 + j * 32 + l31;
+        if (k >= K) continue;
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + wm * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * khalf;
+                if (m < g.Cout) atomicAdd(dw + (size_t)m * K + k, acc[i][j][e]);
+            }
+    }
+}
+
+int make_geom(ConvGeom &g, int N, int Cin, int H, int W, int Cout, int R, int S, int sh, int sw,
+              int ph, int pw)
+{
+    FI_REQUIRE(N >= 1 && Cin >= 1 && H >= 1 && W >= 1 && Cout >= 1, "sizes must be positive");
+    FI_REQUIRE(R >= 1 && S >= 1 && sh >= 1 && sw >= 1 && ph >= 0 && pw >= 0, "bad window");
+    g.N = N; g.Cin = Cin; g.H = H; g.W = W; g.Cout = Cout; g.R = R; g.S = S;
+    g.sh = sh; g.sw = sw; g.ph = ph; g.pw = pw;
+    g.OH = (H + 2 * ph - R) / sh + 1;
+    g.OW = (W + 2 * pw - S) / sw + 1;
+    FI_REQUIRE(g.OH >= 1 && g.OW >= 1, "empty output");
+    const long K = (long)Cin * R * S, P = (long)N * g.OH * g.OW;
+    FI_REQUIRE(K < 2147483647L && P < 2147483647L, "problem too large for int32 indexing");
+    FI_REQUIRE((long)N * Cin * H * W < 2147483647L * 2 && (long)Cout * K < 2147483647L, "tensor too large");
+    g.K = (int)K;
+    g.P = (int)P;
+    return FI_OK;
+}
+
+template <int BM>
+void launch_fwd(const ConvGeom &g, const float *x, const float *w, const float *b, float *y, int relu,
+                hipStream_t st)
+{
+    dim3 grid(fi::ceil_div(g.P, BN), fi::ceil_div(g.Cout, BM));
+    if (g.R == 3 && g.S == 3)
+        hipLaunchKernelGGL((conv_fwd_kernel<BM, 3, 3>), grid, dim3(kThreads), 0, st, x, w, b, y, g, relu);
+    else if (g.R == 1 && g.S == 1)
+        hipLaunchKernelGGL((conv_fwd_kernel<BM, 1, 1>), grid, dim3(kThreads), 0, st, x, w, b, y, g, relu);
+    else if (g.R == 7 && g.S == 7)
+        hipLaunchKernelGGL((conv_fwd_kernel<BM, 7, 7>), grid, dim3(kThreads), 0, st, x, w, b, y, g, relu);
+    else
+        hipLaunchKernelGGL((conv_fwd_kernel<BM, 0, 0>), grid, dim3(kThreads), 0, st, x, w, b, y, g, relu);
+}
+
+template <int BM>
+void launch_wgrad(const ConvGeom &g, const float *x, const float *dy, float *dw, int splits,
+                  int p_per_split, hipStream_t st)
+{
+    dim3 grid(fi::ceil_div(g.K, BN), fi::ceil_div(g.Cout, BM), splits);
+    if (g.R == 3 && g.S == 3)
+        hipLaunchKernelGGL((conv_wgrad_kernel<BM, 3, 3>), grid, dim3(kThreads), 0, st, x, dy, dw, g, p_per_split);
+    else if (g.R == 1 && g.S == 1)
+        hipLaunchKernelGGL((conv_wgrad_kernel<BM, 1, 1>), grid, dim3(kThreads), 0, st, x, dy, dw, g, p_per_split);
+    else if (g.R == 7 && g.S == 7)
+        hipLaunchKernelGGL((conv_wgrad_kernel<BM, 7, 7>), grid, dim3(kThreads), 0, st, x, dy, dw, g, p_per_split);
+    else
+        hipLaunchKernelGGL((conv_wgrad_kernel<BM, 0, 0>), grid, dim3(kThreads), 0, st, x, dy, dw, g, p_per_split);
+}
+
+}  // namespace
+
+extern "C" {
+
+int fi_conv2d_forward(const float *x, const float *weight, const float *bias, float *y, int N,
+                      int Cin, int H, int W, int Cout, int R, int S, int stride_h, int stride_w,
+                      int pad_h, int pad_w, int relu, fi_stream_t stream)
+{
+    ConvGeom g;
+    int rc = make_geom(g, N, Cin, H, W, Cout, R, S, stride_h, stride_w, pad_h, pad_w);
+    if (rc != FI_OK) return rc;
+    FI_REQUIRE(x && weight && y, "null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    fi::ProfScope prof(FI_K_CONV_FWD, st);
+    if (Cout <= 64)
+        launch_fwd<64>(g, x, weight, bias, y, relu, st);
+    else
+        launch_fwd<128>(g, x, weight, bias, y, relu, st);
+    FI_HIP_CHECK(hipGetLastError());
+    return FI_OK;
+}
+
+int fi_conv2d_weight_grad(const float *x, const float *dy, float *dweight, int N, int Cin, int H,
+                          int W, int Cout, int R, int S, int stride_h, int stride_w, int pad_h,
+                          int pad_w, fi_stream_t stream)
+{
+    ConvGeom g;
+    int rc = make_geom(g, N, Cin, H, W, Cout, R, S, stride_h, stride_w, pad_h, pad_w);
+    if (rc != FI_OK) return rc;
+    FI_REQUIRE(x && dy && dweight, "null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    FI_HIP_CHECK(hipMemsetAsync(dweight, 0, sizeof(float) * (size_t)Cout * g.K, st));
+    const int BMsel = Cout <= 64 ? 64 : 128;
+    const long tiles = (long)fi::ceil_div(g.K, BN) * fi::ceil_div(Cout, BMsel);
+    // enough workgroups to fill 256 CUs x 2, but at least 512 pixels per split
+    long want = (1024 + tiles - 1) / tiles;
+    long max_splits = (g.P + 511) / 512;
+    int splits = (int)(want < 1 ? 1 : (want > max_splits ? max_splits : want));
+    if (splits < 1) splits = 1;
+    int pps = fi::ceil_div(g.P, splits);
+    pps = fi::ceil_div(pps, BK) * BK;
+    splits = fi::ceil_div(g.P, pps);
+    fi::ProfScope prof(FI_K_CONV_WGRAD, st);
+    if (BMsel == 64)
+        launch_wgrad<64>(g, x, dy, dweight, splits, pps, st);
+    else
+        launch_wgrad<128>(g, x, dy, dweight, splits, pps, st);
+    FI_HIP_CHECK(hipGetLastError());
+    return FI_OK;
+}
+
+}  // extern "C"

@@ -15,6 +15,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .conv import Conv2d, ConvTranspose2x2
 from .intertwiner import class_mean, roi_level
 from .roi_align.crop_and_resize import CropAndResizeFunction, pyramid_crop_and_resize
 from .roi_pooling.functions.roi_pool import RoIPoolFunction
@@ -56,12 +57,12 @@ class Bottleneck(nn.Module):
 
     def __init__(self, inplanes, planes, stride=1, downsample=None):
         super(Bottleneck, self).__init__()
-        self.conv1 = nn.Conv2d(inplanes, planes, kernel_size=1, stride=stride)
+        self.conv1 = Conv2d(inplanes, planes, kernel_size=1, stride=stride)
         self.bn1 = _bn(planes)
         self.padding2 = SamePad2d(kernel_size=3, stride=1, folded=True)
-        self.conv2 = nn.Conv2d(planes, planes, kernel_size=3, padding=1)
+        self.conv2 = Conv2d(planes, planes, kernel_size=3, padding=1)
         self.bn2 = _bn(planes)
-        self.conv3 = nn.Conv2d(planes, planes * 4, kernel_size=1)
+        self.conv3 = Conv2d(planes, planes * 4, kernel_size=1)
         self.bn3 = _bn(planes * 4)
         self.relu = nn.ReLU(inplace=True)
         self.downsample = downsample
@@ -87,7 +88,7 @@ class ResNet(nn.Module):
         self.block = Bottleneck
         self.stage5 = stage5
         self.C1 = nn.Sequential(
-            nn.Conv2d(3, 64, kernel_size=7, stride=2, padding=3),
+            Conv2d(3, 64, kernel_size=7, stride=2, padding=3),
             _bn(64),
             nn.ReLU(inplace=True),
             SamePad2d(kernel_size=3, stride=2),
@@ -105,7 +106,7 @@ class ResNet(nn.Module):
         downsample = None
         if stride != 1 or self.inplanes != planes * block.expansion:
             downsample = nn.Sequential(
-                nn.Conv2d(self.inplanes, planes * block.expansion, kernel_size=1, stride=stride),
+                Conv2d(self.inplanes, planes * block.expansion, kernel_size=1, stride=stride),
                 _bn(planes * block.expansion),
             )
         layers = [block(self.inplanes, planes, stride, downsample)]
@@ -126,15 +127,15 @@ class FPN(nn.Module):
 
         def smooth():
             return nn.Sequential(SamePad2d(kernel_size=3, stride=1, folded=True),
-                                 nn.Conv2d(oc, oc, kernel_size=3, stride=1, padding=1))
+                                 Conv2d(oc, oc, kernel_size=3, stride=1, padding=1))
 
-        self.P5_conv1 = nn.Conv2d(2048, oc, kernel_size=1, stride=1)
+        self.P5_conv1 = Conv2d(2048, oc, kernel_size=1, stride=1)
         self.P5_conv2 = smooth()
-        self.P4_conv1 = nn.Conv2d(1024, oc, kernel_size=1, stride=1)
+        self.P4_conv1 = Conv2d(1024, oc, kernel_size=1, stride=1)
         self.P4_conv2 = smooth()
-        self.P3_conv1 = nn.Conv2d(512, oc, kernel_size=1, stride=1)
+        self.P3_conv1 = Conv2d(512, oc, kernel_size=1, stride=1)
         self.P3_conv2 = smooth()
-        self.P2_conv1 = nn.Conv2d(256, oc, kernel_size=1, stride=1)
+        self.P2_conv1 = Conv2d(256, oc, kernel_size=1, stride=1)
         self.P2_conv2 = smooth()
         self.ot = False
         if getattr(config.TRAIN, "FPN_OT_LOSS", False):
@@ -186,12 +187,12 @@ class RPN(nn.Module):
         self.anchor_stride = anchor_stride
         self.input_ch = input_ch
         self.padding = SamePad2d(kernel_size=3, stride=anchor_stride, folded=(anchor_stride == 1))
-        self.conv_shared = nn.Conv2d(input_ch, 512, kernel_size=3, stride=anchor_stride,
+        self.conv_shared = Conv2d(input_ch, 512, kernel_size=3, stride=anchor_stride,
                                      padding=1 if anchor_stride == 1 else 0)
         self.relu = nn.ReLU(inplace=True)
-        self.conv_class = nn.Conv2d(512, 2 * anchors_per_location, kernel_size=1, stride=1)
+        self.conv_class = Conv2d(512, 2 * anchors_per_location, kernel_size=1, stride=1)
         self.softmax = nn.Softmax(dim=2)
-        self.conv_bbox = nn.Conv2d(512, 4 * anchors_per_location, kernel_size=1, stride=1)
+        self.conv_bbox = Conv2d(512, 4 * anchors_per_location, kernel_size=1, stride=1)
 
     def forward(self, x):
         x = self.relu(self.conv_shared(self.padding(x)))
@@ -226,7 +227,7 @@ class Dev(nn.Module):
             assert self.feat_pool_size % 2 == 0, 'pool size of feature branch has to be even'
             if not config.DEV.DIS_UPSAMPLER:
                 if config.DEV.UPSAMPLE_FAC == 1.:
-                    conv_opt = nn.Conv2d(depth, depth, kernel_size=3, padding=1)
+                    conv_opt = Conv2d(depth, depth, kernel_size=3, padding=1)
                 elif config.DEV.UPSAMPLE_FAC == 2.:
                     conv_opt = nn.ConvTranspose2d(depth, depth, kernel_size=3, stride=2, padding=1,
                                                   output_padding=1)
@@ -237,10 +238,10 @@ class Dev(nn.Module):
             if not config.DEV.BASELINE:
                 k = int(self.feat_pool_size / 2)
                 self.feat_extract = nn.Sequential(
-                    nn.Conv2d(depth, 512, kernel_size=3, padding=1, stride=2), nn.BatchNorm2d(512),
+                    Conv2d(depth, 512, kernel_size=3, padding=1, stride=2), nn.BatchNorm2d(512),
                     nn.ReLU(inplace=True),
-                    nn.Conv2d(512, 1024, kernel_size=k, stride=1), nn.BatchNorm2d(1024), nn.ReLU(inplace=True),
-                    nn.Conv2d(1024, 1024, kernel_size=1, stride=1), nn.BatchNorm2d(1024), nn.ReLU(inplace=True),
+                    Conv2d(512, 1024, kernel_size=k, stride=1), nn.BatchNorm2d(1024), nn.ReLU(inplace=True),
+                    Conv2d(1024, 1024, kernel_size=1, stride=1), nn.BatchNorm2d(1024), nn.ReLU(inplace=True),
                 )
                 if config.DEV.LOSS_CHOICE in ('l2', 'l1'):
                     self.last_op = nn.Sigmoid()
@@ -359,9 +360,9 @@ class Classifier(nn.Module):
         self.pool_size = pool_size
         self.num_classes = num_classes
         self.config = config
-        self.conv1 = nn.Conv2d(depth, 1024, kernel_size=pool_size, stride=1)
+        self.conv1 = Conv2d(depth, 1024, kernel_size=pool_size, stride=1)
         self.bn1 = _bn(1024)
-        self.conv2 = nn.Conv2d(1024, 1024, kernel_size=1, stride=1)
+        self.conv2 = Conv2d(1024, 1024, kernel_size=1, stride=1)
         self.bn2 = _bn(1024)
         self.relu = nn.ReLU(inplace=True)
         self.linear_class = nn.Linear(1024, num_classes)
@@ -385,16 +386,16 @@ class Mask(nn.Module):
         self.depth = depth
         self.num_classes = num_classes
         self.padding = SamePad2d(kernel_size=3, stride=1, folded=True)
-        self.conv1 = nn.Conv2d(depth, 256, kernel_size=3, stride=1, padding=1)
+        self.conv1 = Conv2d(depth, 256, kernel_size=3, stride=1, padding=1)
         self.bn1 = nn.BatchNorm2d(256, eps=0.001)
-        self.conv2 = nn.Conv2d(256, 256, kernel_size=3, stride=1, padding=1)
+        self.conv2 = Conv2d(256, 256, kernel_size=3, stride=1, padding=1)
         self.bn2 = nn.BatchNorm2d(256, eps=0.001)
-        self.conv3 = nn.Conv2d(256, 256, kernel_size=3, stride=1, padding=1)
+        self.conv3 = Conv2d(256, 256, kernel_size=3, stride=1, padding=1)
         self.bn3 = nn.BatchNorm2d(256, eps=0.001)
-        self.conv4 = nn.Conv2d(256, 256, kernel_size=3, stride=1, padding=1)
+        self.conv4 = Conv2d(256, 256, kernel_size=3, stride=1, padding=1)
         self.bn4 = nn.BatchNorm2d(256, eps=0.001)
-        self.deconv = nn.ConvTranspose2d(256, 256, kernel_size=2, stride=2)
-        self.conv5 = nn.Conv2d(256, num_classes, kernel_size=1, stride=1)
+        self.deconv = ConvTranspose2x2(256, 256, kernel_size=2, stride=2)
+        self.conv5 = Conv2d(256, num_classes, kernel_size=1, stride=1)
         self.sigmoid = nn.Sigmoid()
         self.relu = nn.ReLU(inplace=True)
 

@@ -199,6 +199,26 @@ int fi_class_mean_backward(const float *grad_feat, const int32_t *gt,
                            float *grad_features, fi_stream_t stream);
 
 /* ------------------------------------------------------------------------
+ * Dense convolution on the matrix cores (fp32 MFMA implicit GEMM), NCHW.
+ * Replaces: the cuDNN convolutions behind every nn.Conv2d of the backbone / FPN / RPN /
+ * Dev make-up layer / mask head (lib/sub_module.py:38-128, 147-228, 234-280, 308-345,
+ * 750-787); the reference has no native code of its own for them.
+ * x [N,Cin,H,W], weight [Cout,Cin,R,S], bias [Cout] or NULL, y [N,Cout,OH,OW] with
+ * OH = (H + 2*pad_h - R)/stride_h + 1.  relu != 0 fuses max(.,0) into the epilogue.
+ * The data gradient of a stride-1 convolution is this same call on dY with the flipped,
+ * transposed weight [Cin,Cout,R,S] and padding R-1-pad.
+ * fi_conv2d_weight_grad: dweight [Cout,Cin,R,S] = sum over images and pixels of
+ * dy (x) patches(x); zero-filled by the call, accumulated with fp32 atomics over a split
+ * of the pixel range.
+ * ---------------------------------------------------------------------- */
+int fi_conv2d_forward(const float *x, const float *weight, const float *bias, float *y,
+                      int N, int Cin, int H, int W, int Cout, int R, int S, int stride_h,
+                      int stride_w, int pad_h, int pad_w, int relu, fi_stream_t stream);
+int fi_conv2d_weight_grad(const float *x, const float *dy, float *dweight, int N, int Cin,
+                          int H, int W, int Cout, int R, int S, int stride_h, int stride_w,
+                          int pad_h, int pad_w, fi_stream_t stream);
+
+/* ------------------------------------------------------------------------
  * In-library kernel timing (HIP events recorded on the launch stream around
  * each kernel launch while enabled).  Used by bench.py for the roofline object;
  * off by default, zero cost when off.
@@ -220,7 +240,9 @@ enum {
     FI_K_NMS_SCAN = 11,
     FI_K_SINKHORN = 12,
     FI_K_CLASS_MEAN = 13,
-    FI_K_COUNT = 14
+    FI_K_CONV_FWD = 14,      /* conv_fwd_kernel (forward and stride-1 data gradient) */
+    FI_K_CONV_WGRAD = 15,
+    FI_K_COUNT = 16
 };
 void fi_prof_enable(int on);
 void fi_prof_reset(void);

@@ -20,8 +20,10 @@ ap.add_argument("--rois", type=int, default=64)
 ap.add_argument("--steps", type=int, default=3)
 ap.add_argument("--L", type=int, default=5)
 ap.add_argument("--dev", type=int, default=1)
+ap.add_argument("--find", type=int, default=0)
 a = ap.parse_args()
 torch.manual_seed(2000)
+torch.backends.cudnn.benchmark = bool(a.find)
 cfg = make_config(a.backbone, a.size, a.batch, a.rois, dev_switch=bool(a.dev), ot_L=a.L)
 model = MaskRCNN(cfg).cuda()
 print("params", sum(p.numel() for p in model.parameters()) / 1e6, "M")

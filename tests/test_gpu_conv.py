@@ -1,0 +1,97 @@
+"""fp32 MFMA implicit-GEMM convolution vs a float64 torch reference of the same op
+(forward, input gradient, weight gradient, bias gradient).  Tolerance: fp32 round-off of
+a K-term dot product, |d| <= 2e-5 * sqrt(K) * max|ref| (the MFMA path is an exact fp32 fma
+chain; only the summation order differs from the reference)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+CASES = [
+    # N, Cin, H, W, Cout, R, S, stride, pad
+    (2, 64, 20, 24, 64, 1, 1, 1, 0),
+    (2, 256, 13, 17, 128, 1, 1, 2, 0),
+    (3, 64, 19, 23, 64, 3, 3, 1, 1),
+    (2, 70, 16, 16, 200, 3, 3, 1, 1),
+    (2, 256, 14, 14, 512, 3, 3, 2, 1),
+    (2, 3, 64, 64, 64, 7, 7, 2, 3),
+    (1, 5, 11, 9, 7, 5, 3, 1, 2),
+    (2, 8, 15, 15, 130, 3, 3, 2, 0),
+    (4, 256, 7, 7, 1024, 7, 7, 1, 0),      # full-window -> GEMM path
+    (1, 1024, 8, 8, 2048, 1, 1, 1, 0),
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_conv_forward_backward(case):
+    from feature_intertwiner_amd.conv import conv2d
+    N, Cin, H, W, Cout, R, S, st, pd = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, R, S, generator=g) / math.sqrt(Cin * R * S)
+    b = torch.randn(Cout, generator=g)
+    xd, wd, bd = (t.double().requires_grad_(True) for t in (x, w, b))
+    yd = F.conv2d(xd, wd, bd, stride=st, padding=pd)
+    gy = torch.randn(yd.shape, generator=g)
+    yd.backward(gy.double())
+    xg, wg, bg = (t.to(DEV).requires_grad_(True) for t in (x, w, b))
+    y = conv2d(xg, wg, bg, (st, st), (pd, pd))
+    assert y.shape == yd.shape
+    y.backward(gy.to(DEV))
+    K = Cin * R * S
+    tol = lambda ref, k: 2e-5 * math.sqrt(k) * (ref.abs().max().item() + 1e-6)
+    assert (y.detach().cpu().double() - yd.detach()).abs().max().item() <= tol(yd.detach(), K)
+    assert (xg.grad.cpu().double() - xd.grad).abs().max().item() <= tol(xd.grad, Cout * R * S)
+    assert (wg.grad.cpu().double() - wd.grad).abs().max().item() <= tol(wd.grad, N * yd.shape[2] * yd.shape[3])
+    assert (bg.grad.cpu().double() - bd.grad).abs().max().item() <= tol(bd.grad, N * yd.shape[2] * yd.shape[3])
+
+
+def test_modules_match_torch_modules():
+    from feature_intertwiner_amd.conv import Conv1d, Conv2d, ConvTranspose2x2
+    torch.manual_seed(0)
+    ref = torch.nn.Conv2d(32, 48, 3, stride=1, padding=1)
+    m = Conv2d(32, 48, 3, stride=1, padding=1)
+    m.load_state_dict(ref.state_dict())
+    x = torch.randn(2, 32, 10, 12)
+    assert torch.allclose(m.to(DEV)(x.to(DEV)).cpu(), ref(x), rtol=1e-4, atol=1e-4)
+    rt = torch.nn.ConvTranspose2d(16, 24, kernel_size=2, stride=2)
+    mt = ConvTranspose2x2(16, 24, kernel_size=2, stride=2)
+    mt.load_state_dict(rt.state_dict())
+    x = torch.randn(3, 16, 7, 5)
+    xg = x.to(DEV).requires_grad_(True)
+    xr = x.clone().requires_grad_(True)
+    out = mt.to(DEV)(xg)
+    outr = rt(xr)
+    assert torch.allclose(out.cpu(), outr, rtol=1e-4, atol=1e-4)
+    gy = torch.randn_like(outr)
+    out.backward(gy.to(DEV))
+    outr.backward(gy)
+    assert torch.allclose(xg.grad.cpu(), xr.grad, rtol=1e-4, atol=1e-4)
+    assert torch.allclose(mt.weight.grad.cpu(), rt.weight.grad, rtol=1e-4, atol=1e-4)
+    assert torch.allclose(mt.bias.grad.cpu(), rt.bias.grad, rtol=1e-4, atol=1e-4)
+    r1 = torch.nn.Conv1d(20, 12, 3, padding=1)
+    m1 = Conv1d(20, 12, 3, padding=1)
+    m1.load_state_dict(r1.state_dict())
+    for L in (1, 6):
+        x = torch.randn(4, 20, L)
+        assert torch.allclose(m1.to(DEV)(x.to(DEV)).cpu(), r1(x), rtol=1e-4, atol=1e-5)
+
+
+def test_relu_epilogue_and_large_shape_property():
+    """fused ReLU == relu(conv); a P2-sized 3x3 conv is linear in its input (size-independent)."""
+    from feature_intertwiner_amd.conv import _conv_fwd
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(1, 256, 128, 128, generator=g).to(DEV)
+    x2 = torch.randn(1, 256, 128, 128, generator=g).to(DEV)
+    w = (torch.randn(256, 256, 3, 3, generator=g) / 48).to(DEV)
+    b = torch.randn(256, generator=g).to(DEV)
+    y = _conv_fwd(x, w, b, (1, 1), (1, 1))
+    yr = _conv_fwd(x, w, b, (1, 1), (1, 1), relu=True)
+    assert torch.equal(yr, torch.relu(y))
+    y2 = _conv_fwd(x2, w, None, (1, 1), (1, 1))
+    y12 = _conv_fwd(x + x2, w, b, (1, 1), (1, 1))
+    assert torch.allclose(y12, y + y2, rtol=1e-4, atol=1e-3)
