@@ -45,7 +45,7 @@ class MaskRCNN(nn.Module):
     def _initialize_weights(self):
         """lib/model.py:84-103."""
         for m in self.modules():
-            if isinstance(m, (nn.Conv2d, nn.Conv1d))  # fi Conv2d/Conv1d subclass these:
+            if isinstance(m, (nn.Conv2d, nn.Conv1d)):   # conv.Conv2d / conv.Conv1d subclass these
                 nn.init.xavier_uniform_(m.weight)
                 if m.bias is not None:
                     m.bias.data.zero_()
