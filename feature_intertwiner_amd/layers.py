@@ -225,7 +225,7 @@ def prepare_det_target(proposals, num_proposals, gt_class_ids, gt_boxes, gt_mask
     neg_cnt = torch.minimum(neg_want, n_neg_avail).clamp(max=R)
     neg_cnt = torch.minimum(neg_cnt, (R - pos_cnt))
 
-    slot = torch.arange(R, device=dev).unsqueeze(0)
+    slot = torch.arange(R, device=dev).unsqueeze(0).expand(b, R)
     is_pos = slot < pos_cnt.unsqueeze(1)
     is_neg = (~is_pos) & (slot < (pos_cnt + neg_cnt).unsqueeze(1))
     pi = torch.gather(pos_idx, 1, slot.clamp(max=pos_idx.size(1) - 1))

@@ -1,0 +1,139 @@
+"""GPU: the callers wired to the HIP operators -- proposal layer (NMS), detection targets
+(RoIAlign on GT masks), the Dev pyramid stage vs a per-level restatement on the oracle,
+and one full train step."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import training_rois
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _cfg(**kw):
+    from feature_intertwiner_amd.config import make_config
+    return make_config(**kw)
+
+
+def test_det_targets_invariants():
+    from feature_intertwiner_amd import layers as L
+    from feature_intertwiner_amd.synthetic import synthetic_batch
+    cfg = _cfg(backbone="resnet50", image_size=512, batch_size=3, train_rois_per_image=128)
+    _, gt_cls, gt_boxes, gt_masks = synthetic_batch(3, 512, device=DEV)
+    gt_cls[1, 15:] = 0
+    gt_boxes[1, 15:] = 0
+    gen = torch.Generator(device=DEV).manual_seed(1)
+    scale = torch.tensor([512.0] * 4, device=DEV)
+    # proposals: jittered GT copies + random boxes, image 2 has only 300 valid rows
+    jit = gt_boxes.repeat(1, 20, 1) * (1 + 0.1 * (torch.rand(3, 400, 4, device=DEV, generator=gen) - 0.5))
+    rnd = torch.rand(3, 600, 2, device=DEV, generator=gen) * 400
+    rnd = torch.cat([rnd, rnd + 8 + torch.rand(3, 600, 2, device=DEV, generator=gen) * 100], 2)
+    perm = torch.randperm(1000, device=DEV, generator=gen)
+    props = (torch.cat([jit, rnd], 1)[:, perm] / scale).clamp(0, 1)
+    num = torch.tensor([1000, 1000, 300], device=DEV, dtype=torch.int32)
+    props[2, 300:] = 0
+    rois, cls, deltas, masks = L.prepare_det_target(props, num, gt_cls, gt_boxes / scale, gt_masks, cfg, gen)
+    assert rois.shape == (3, 128, 4) and cls.dtype == torch.int32 and masks.shape == (3, 128, 28, 28)
+    assert torch.isfinite(deltas).all()
+    gtn = gt_boxes / scale
+    for b in range(3):
+        n_pos = int((cls[b] > 0).sum())
+        used = int((rois[b].abs().sum(1) > 0).sum())
+        assert 0 < n_pos <= int(128 * 0.33)
+        assert torch.all(cls[b, :n_pos] > 0) and torch.all(cls[b, n_pos:] == 0)        # positives first
+        assert used - n_pos <= int(n_pos / 0.33 - n_pos)                               # reference ratio rule
+        valid_gt = gt_cls[b] > 0
+        iou = L.bbox_overlaps(rois[b], gtn[b][valid_gt])
+        best, arg = iou.max(1)
+        assert torch.all(best[:n_pos] >= 0.5) and torch.all(best[n_pos:used] < 0.5)
+        assert torch.equal(cls[b, :n_pos].long(), gt_cls[b][valid_gt][arg[:n_pos]])
+        exp = L.box_refinement(rois[b, :n_pos], gtn[b][valid_gt][arg[:n_pos]]) / torch.tensor(
+            cfg.DATA.BBOX_STD_DEV, device=DEV)
+        assert torch.allclose(deltas[b, :n_pos], exp, rtol=1e-4, atol=1e-4)
+        assert torch.all(deltas[b, n_pos:] == 0) and torch.all(rois[b, used:] == 0)
+        assert torch.all((masks[b] == 0) | (masks[b] == 1)) and torch.all(masks[b, n_pos:] == 0)
+        assert masks[b, :n_pos].sum() > 0
+        # every RoI is one of the valid proposals of its own image
+        d = (rois[b, :used, None, :] - props[b, None, :int(num[b]), :]).abs().sum(2).min(1)[0]
+        assert torch.all(d == 0)
+
+
+def test_proposal_layer_matches_oracle_nms(oracle):
+    from feature_intertwiner_amd import layers as L
+    cfg = _cfg(backbone="resnet50", image_size=256)
+    pri = torch.from_numpy(L.generate_pyramid_priors(cfg.RPN.ANCHOR_SCALES, cfg.RPN.ANCHOR_RATIOS,
+                                                     cfg.MODEL.BACKBONE_SHAPES, cfg.MODEL.BACKBONE_STRIDES, 1)).float().to(DEV)
+    g = torch.Generator(device=DEV).manual_seed(2)
+    A = pri.size(0)
+    probs = torch.rand(2, A, 2, device=DEV, generator=g)
+    bbox = torch.randn(2, A, 4, device=DEV, generator=g) * 0.5
+    props, num = L.proposal_layer([probs, bbox], 1000, 0.7, pri, cfg)
+    assert props.shape == (2, 1000, 4)
+    for b in range(2):
+        sc, order = torch.sort(probs[b, :, 1], descending=True, stable=True)
+        k = min(6000, A)
+        boxes = L.clip_boxes(L.apply_box_deltas(pri[order[:k]], bbox[b, order[:k]] * torch.tensor(
+            cfg.DATA.BBOX_STD_DEV, device=DEV)), (0.0, 0.0, 256.0, 256.0))
+        dets = torch.cat([boxes, sc[:k, None]], 1).cpu().numpy()
+        keep = oracle.pth_nms(dets, 0.7)[:1000]
+        n = int(num[b])
+        assert n == len(keep)
+        assert np.allclose(props[b, :n].cpu().numpy(), dets[keep, :4] / 256.0, atol=1e-6)
+        assert torch.all(props[b, n:] == 0)
+
+
+def test_dev_stage_matches_per_level_restatement(oracle):
+    """Dev.forward (one pyramid launch per crop size) vs the reference's per-level procedure
+    (lib/sub_module.py:429-662) restated on the CPU oracle: pooled 7x7 / 14x14 outputs."""
+    from feature_intertwiner_amd.sub_module import Dev
+    cfg = _cfg(backbone="resnet50", image_size=256, batch_size=2, train_rois_per_image=64, dev_switch=True)
+    torch.manual_seed(0)
+    dev = Dev(cfg, 256).to(DEV).eval()
+    maps = [torch.randn(2, 256, s, s, device=DEV) for s in (64, 32, 16, 8)]
+    rs = np.random.RandomState(1)
+    rois_np = training_rois(rs, 2, 64)
+    rois_np[1, 60:] = 0                                   # zero-padded rows
+    rois = torch.from_numpy(rois_np).to(DEV)
+    cls = torch.randint(0, 81, (2, 64), device=DEV, dtype=torch.int32)
+    with torch.no_grad():
+        pooled, mask, feat_out = dev(maps, rois, cls)
+        up = [dev.upsample[0](m).cpu().numpy() for m in maps]
+    level = oracle.roi_level(rois_np.reshape(-1, 4), 256 * 256)
+    ind = np.repeat(np.arange(2, dtype=np.int32), 64)
+    for size, got in ((7, pooled), (14, mask)):
+        exp = np.zeros((128, 256, size, size), np.float32)
+        for l in range(2, 6):
+            sel = np.nonzero(level == l)[0]
+            if len(sel):
+                exp[sel] = oracle.crop_and_resize_forward(up[l - 2], rois_np.reshape(-1, 4)[sel], ind[sel], size, size)
+        assert np.array_equal(got.cpu().numpy().view(np.uint32), exp.view(np.uint32))
+    big_feat, big_cnt, small_feat, small_cnt = feat_out[:4]
+    assert big_feat.shape == (1, 3, 1024, 81) and small_cnt.shape == (1, 3, 1, 81)
+    cls_np = cls.cpu().numpy().reshape(-1)
+    for i, l in enumerate((2, 3, 4)):
+        exp_cnt = np.bincount(cls_np[(level == l) & (cls_np > 0)], minlength=81)
+        assert np.array_equal(small_cnt[0, i, 0].cpu().numpy(), exp_cnt.astype(np.float32))
+        exp_big = np.bincount(cls_np[(level > l) & (cls_np > 0)], minlength=81) * float((level == l).any())
+        assert np.array_equal(big_cnt[0, i, 0].cpu().numpy(), exp_big.astype(np.float32))
+    assert not big_feat.requires_grad
+
+
+def test_train_step_runs_and_learns():
+    from feature_intertwiner_amd.model import MaskRCNN
+    from feature_intertwiner_amd.synthetic import SyntheticProposals, synthetic_batch
+    from feature_intertwiner_amd.workflow import set_optimizer, train_step
+    torch.manual_seed(2000)
+    cfg = _cfg(backbone="resnet50", image_size=256, batch_size=2, train_rois_per_image=64, ot_L=5)
+    model = MaskRCNN(cfg).to(DEV)
+    opt = set_optimizer(model, cfg.TRAIN)
+    batch = synthetic_batch(2, 256, device=DEV)
+    model.proposal_hook = SyntheticProposals(batch[2], 256)
+    model.generator = torch.Generator(device=DEV).manual_seed(3)
+    hist = []
+    for _ in range(6):
+        t = train_step(model, opt, list(batch))
+        assert all(torch.isfinite(v) for v in t.values()), t
+        hist.append(float(t["total"]))
+    assert hist[-1] < hist[0]
+    assert all(p.grad is not None for n, p in model.named_parameters() if not n.startswith("ot_loss"))
