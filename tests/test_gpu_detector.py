@@ -31,6 +31,8 @@ def test_det_targets_invariants():
     rnd = torch.cat([rnd, rnd + 8 + torch.rand(3, 600, 2, device=DEV, generator=gen) * 100], 2)
     perm = torch.randperm(1000, device=DEV, generator=gen)
     props = (torch.cat([jit, rnd], 1)[:, perm] / scale).clamp(0, 1)
+    zero_rows = props.abs().sum(2) == 0          # copies of the zero-padded GT rows of image 1
+    props[zero_rows] = torch.tensor([0.9, 0.9, 0.95, 0.95], device=DEV)
     num = torch.tensor([1000, 1000, 300], device=DEV, dtype=torch.int32)
     props[2, 300:] = 0
     rois, cls, deltas, masks = L.prepare_det_target(props, num, gt_cls, gt_boxes / scale, gt_masks, cfg, gen)
