@@ -32,6 +32,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 = fp32 vector peak
 
 
 def crop_algorithmic_bytes(log_entry):
@@ -156,6 +157,7 @@ def main():
     from feature_intertwiner_amd.data_parallel import GradientBuckets, all_reduce_statistics, broadcast_parameters
     from feature_intertwiner_amd.model import MaskRCNN
     from feature_intertwiner_amd.roi_align import crop_and_resize as car
+    from feature_intertwiner_amd import conv as ficonv
     from feature_intertwiner_amd.synthetic import SyntheticProposals, synthetic_batch
     from feature_intertwiner_amd.workflow import set_optimizer, train_step
     _lib.load()
@@ -185,6 +187,7 @@ def main():
     _lib.prof_reset()
     _lib.prof_enable(True)
     car.LAUNCH_LOG = []
+    ficonv.FLOP_LOG = {}
     t0 = time.perf_counter()
     for _ in range(args.steps):
         terms = step()
@@ -196,6 +199,8 @@ def main():
     _lib.prof_enable(False)
     log = car.LAUNCH_LOG
     car.LAUNCH_LOG = None
+    flop_log = ficonv.FLOP_LOG
+    ficonv.FLOP_LOG = None
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -208,13 +213,13 @@ def main():
         # ---- roofline of the RoIAlign 7x7 forward kernel ---------------------------------
         n7, ms7 = _lib.prof_get("crop_fwd_7x7")
         fwd7 = [e for e in log if e["crop"] == 7 and e["pyramid"]]
-        roof = None
+        roof_roi = None
         if n7 and fwd7:
             e = fwd7[-1]
             b_alg = crop_algorithmic_bytes(e)
             dur = ms7 / n7 * 1e-3
             ach = b_alg / dur / 1e9
-            roof = {"kernel": "crop_fwd_kernel<7, 7>", "bound": "hbm", "achieved": round(ach, 1),
+            roof_roi = {"kernel": "crop_fwd_kernel<7, 7>", "bound": "hbm", "achieved": round(ach, 1),
                     "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4),
                     "traffic": None, "algorithmic_bytes_per_launch": int(b_alg),
                     "avg_launch_us": round(dur * 1e6, 2), "launches_timed": n7,
@@ -223,7 +228,25 @@ def main():
         for k in _lib.KERNEL_IDS:
             n, ms = _lib.prof_get(k)
             if n:
-                kern[k] = {"launches": n, "avg_us": round(ms / n * 1e3, 2)}
+                kern[_lib.kernel_name(k)] = {"launches": n, "avg_us": round(ms / n * 1e3, 2),
+                                             "ms_per_step": round(ms / args.steps, 3), "_key": k}
+        # ---- roofline of the DOMINANT kernel (largest share of the step) ------------------------
+        dom = max(kern.items(), key=lambda kv: kv[1]["ms_per_step"]) if kern else None
+        roof = None
+        if dom is not None and dom[1]["_key"] in flop_log:
+            launches, flops = flop_log[dom[1]["_key"]]
+            n, ms = _lib.prof_get(dom[1]["_key"])
+            ach = flops / (ms * 1e-3) / 1e12
+            roof = {"kernel": dom[0], "bound": "mfma", "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                    "algorithmic_flops_per_launch": int(flops / max(launches, 1)),
+                    "avg_launch_us": round(ms / n * 1e3, 2), "launches_timed": n,
+                    "share_of_step": round(dom[1]["ms_per_step"] / ms_per_step, 4),
+                    "flops_model": "2*N*Cout*OH*OW*Cin*R*S per launch (fp32, exact MFMA)"}
+        elif roof_roi is not None:
+            roof = roof_roi
+        for v in kern.values():
+            v.pop("_key", None)
         out = {
             "metric": "images/sec (train step, ResNet-101-FPN 1024^2, 512 RoIs)", "value": round(value, 4),
             "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -236,9 +259,10 @@ def main():
                                    % (args.backbone, args.image_size, args.image_size, args.batch_per_gpu, args.rois,
                                       args.ot_L),
                        "global_batch": global_batch, "parallelism": "dp%d" % world,
-                       "conv_stack": "MIOpen fp32 via torch (MFMA conv kernels not yet hand-written)"},
+                       "conv_stack": "hand-written fp32 MFMA implicit-GEMM kernels (csrc/conv_igemm.hip); "
+                                     "full-window convs and nn.Linear on the library GEMM"},
             "losses": {k: round(float(v), 5) for k, v in terms.items()},
-            "roofline": roof, "kernels": kern,
+            "roofline": roof, "roofline_roialign": roof_roi, "kernels": kern,
         }
         if world == 1 and not args.no_cpu_baseline:
             try:

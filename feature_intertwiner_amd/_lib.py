@@ -62,8 +62,22 @@ KERNEL_IDS = {
     "crop_fwd_7x7": 0, "crop_fwd_14x14": 1, "crop_fwd_28x28": 2, "crop_fwd_generic": 3,
     "crop_bwd_7x7": 4, "crop_bwd_14x14": 5, "crop_bwd_28x28": 6, "crop_bwd_generic": 7,
     "roipool_fwd": 8, "roipool_bwd": 9, "nms_mask": 10, "nms_scan": 11, "sinkhorn": 12,
-    "class_mean": 13, "conv_fwd": 14, "conv_wgrad": 15,
+    "class_mean": 13,
 }
+for _i, _bm in enumerate((64, 128)):
+    for _j, _w in enumerate(("1x1", "3x3", "7x7", "other")):
+        KERNEL_IDS["conv_fwd_bm%d_%s" % (_bm, _w)] = 14 + 4 * _i + _j
+        KERNEL_IDS["conv_wgrad_bm%d_%s" % (_bm, _w)] = 22 + 4 * _i + _j
+
+
+def conv_kernel_key(kind, cout, R, S):
+    """Name (KERNEL_IDS key) of the device kernel instance a convolution launch uses."""
+    w = {(1, 1): "1x1", (3, 3): "3x3", (7, 7): "7x7"}.get((R, S), "other")
+    return "conv_%s_bm%d_%s" % (kind, 64 if cout <= 64 else 128, w)
+
+
+def kernel_name(key):
+    return load().fi_prof_kernel_name(KERNEL_IDS[key]).decode()
 
 _lib = None
 

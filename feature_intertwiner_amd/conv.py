@@ -19,6 +19,18 @@ import torch.nn.functional as F
 
 from . import _lib
 
+# bench.py sets this to a dict to accumulate the algorithmic flops (2*N*Cout*OH*OW*Cin*R*S) of
+# every launch, keyed by the device kernel instance (see _lib.conv_kernel_key).
+FLOP_LOG = None
+
+
+def _log_flops(kind, cout, R, S, flops):
+    if FLOP_LOG is not None:
+        k = _lib.conv_kernel_key(kind, cout, R, S)
+        e = FLOP_LOG.setdefault(k, [0, 0])
+        e[0] += 1
+        e[1] += flops
+
 
 def _conv_fwd(x, w, b, stride, padding, relu=False):
     L = _lib.load()
@@ -26,6 +38,7 @@ def _conv_fwd(x, w, b, stride, padding, relu=False):
     Cout, _, R, S = w.shape
     OH = (H + 2 * padding[0] - R) // stride[0] + 1
     OW = (W + 2 * padding[1] - S) // stride[1] + 1
+    _log_flops("fwd", Cout, R, S, 2 * N * Cout * OH * OW * Cin * R * S)
     y = torch.empty((N, Cout, OH, OW), device=x.device, dtype=torch.float32)
     with torch.cuda.device(x.device):
         _lib.check(L.fi_conv2d_forward(_lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(y), N, Cin, H, W, Cout,
@@ -67,6 +80,7 @@ class _Conv2dFn(torch.autograd.Function):
                 dx = _conv_fwd(up, wt, None, (1, 1), (R - 1 - padding[0], S - 1 - padding[1]))
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(w)
+            _log_flops("wgrad", Cout, R, S, 2 * N * Cout * dy.shape[2] * dy.shape[3] * Cin * R * S)
             with torch.cuda.device(x.device):
                 _lib.check(L.fi_conv2d_weight_grad(_lib.ptr(x), _lib.ptr(dy), _lib.ptr(dw), N, Cin, H, W, Cout,
                                                    R, S, stride[0], stride[1], padding[0], padding[1],

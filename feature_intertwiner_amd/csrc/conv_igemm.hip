@@ -329,6 +329,14 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(const float *__res
     }
 }
 
+int window_class(int R, int S)
+{
+    if (R == 1 && S == 1) return 0;
+    if (R == 3 && S == 3) return 1;
+    if (R == 7 && S == 7) return 2;
+    return 3;
+}
+
 int make_geom(ConvGeom &g, int N, int Cin, int H, int W, int Cout, int R, int S, int sh, int sw,
               int ph, int pw)
 {
@@ -390,7 +398,7 @@ int fi_conv2d_forward(const float *x, const float *weight, const float *bias, fl
     if (rc != FI_OK) return rc;
     FI_REQUIRE(x && weight && y, "null pointer");
     hipStream_t st = (hipStream_t)stream;
-    fi::ProfScope prof(FI_K_CONV_FWD, st);
+    fi::ProfScope prof(FI_K_CONV_FWD + (Cout <= 64 ? 0 : 4) + window_class(R, S), st);
     if (Cout <= 64)
         launch_fwd<64>(g, x, weight, bias, y, relu, st);
     else
@@ -419,7 +427,7 @@ int fi_conv2d_weight_grad(const float *x, const float *dy, float *dweight, int N
     int pps = fi::ceil_div(g.P, splits);
     pps = fi::ceil_div(pps, BK) * BK;
     splits = fi::ceil_div(g.P, pps);
-    fi::ProfScope prof(FI_K_CONV_WGRAD, st);
+    fi::ProfScope prof(FI_K_CONV_WGRAD + (BMsel == 64 ? 0 : 4) + window_class(R, S), st);
     if (BMsel == 64)
         launch_wgrad<64>(g, x, dy, dweight, splits, pps, st);
     else

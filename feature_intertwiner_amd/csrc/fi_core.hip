@@ -122,8 +122,13 @@ const char *fi_prof_kernel_name(int kernel_id)
         "crop_fwd_kernel<0, 0>",   "crop_bwd_kernel<7, 7>",   "crop_bwd_kernel<14, 14>",
         "crop_bwd_kernel<28, 28>", "crop_bwd_kernel<0, 0>",   "roi_pool_fwd_kernel",
         "roi_pool_bwd_kernel",     "nms_mask_kernel",         "nms_scan_kernel",
-        "sinkhorn_kernel",         "class_mean_fwd_kernel",   "conv_fwd_kernel",
-        "conv_wgrad_kernel"};
+        "sinkhorn_kernel",         "class_mean_fwd_kernel",
+        "conv_fwd_kernel<64, 1, 1>",    "conv_fwd_kernel<64, 3, 3>",    "conv_fwd_kernel<64, 7, 7>",
+        "conv_fwd_kernel<64, 0, 0>",    "conv_fwd_kernel<128, 1, 1>",   "conv_fwd_kernel<128, 3, 3>",
+        "conv_fwd_kernel<128, 7, 7>",   "conv_fwd_kernel<128, 0, 0>",   "conv_wgrad_kernel<64, 1, 1>",
+        "conv_wgrad_kernel<64, 3, 3>",  "conv_wgrad_kernel<64, 7, 7>",  "conv_wgrad_kernel<64, 0, 0>",
+        "conv_wgrad_kernel<128, 1, 1>", "conv_wgrad_kernel<128, 3, 3>", "conv_wgrad_kernel<128, 7, 7>",
+        "conv_wgrad_kernel<128, 0, 0>"};
     if (kernel_id < 0 || kernel_id >= FI_K_COUNT) return "?";
     return names[kernel_id];
 }

@@ -240,9 +240,11 @@ enum {
     FI_K_NMS_SCAN = 11,
     FI_K_SINKHORN = 12,
     FI_K_CLASS_MEAN = 13,
-    FI_K_CONV_FWD = 14,      /* conv_fwd_kernel (forward and stride-1 data gradient) */
-    FI_K_CONV_WGRAD = 15,
-    FI_K_COUNT = 16
+    /* conv kernels: id = base + 4*(BM == 128) + window class (0: 1x1, 1: 3x3, 2: 7x7, 3: other);
+     * conv_fwd_kernel serves the forward pass and the stride-1 data gradient */
+    FI_K_CONV_FWD = 14,      /* .. 21 */
+    FI_K_CONV_WGRAD = 22,    /* .. 29 */
+    FI_K_COUNT = 30
 };
 void fi_prof_enable(int on);
 void fi_prof_reset(void);
