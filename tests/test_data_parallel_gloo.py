@@ -1,0 +1,100 @@
+"""CPU, world_size 2, gloo: the data-parallel engine (feature_intertwiner_amd/data_parallel.py)
+reproduces the reference update rule  d/dtheta [ mean_g L_det,g + M(sum_g s_g) ]
+(lib/workflow.py:180, 221) from per-rank backward + bucketed gradient averaging,
+and the intertwiner statistics all-reduce equals gather + _merge_feat_vec."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn as nn
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _net():
+    torch.manual_seed(0)
+    return nn.Sequential(nn.Linear(6, 16), nn.Tanh(), nn.Linear(16, 16), nn.Tanh(), nn.Linear(16, 5))
+
+
+def _meta(stat_sum):
+    return (stat_sum ** 2).sum() * 0.1 + stat_sum.sin().sum()
+
+
+def _worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from feature_intertwiner_amd.data_parallel import GradientBuckets, all_reduce_statistics, broadcast_parameters
+    net = _net()
+    if rank == 1:
+        for p in net.parameters():
+            p.data.add_(1.0)            # replicas must be re-synchronised from rank 0
+    broadcast_parameters(net)
+    sync = GradientBuckets(net, bucket_bytes=300)      # tiny buckets: several collectives
+    assert len(sync.buckets) > 2
+    g = torch.Generator().manual_seed(100)
+    x_all = torch.randn(world * 3, 6, generator=g)
+    x = x_all[rank * 3:(rank + 1) * 3]                  # this rank's shard of the minibatch
+    for it in range(2):                                 # twice: state must reset between steps
+        net.zero_grad(set_to_none=True)
+        y = net(x)
+        det = (y ** 2).mean()
+        s_local = y.sum(0)                              # "count-weighted feature sums" of this rank
+        cnt_local = torch.full((1, 5), float(rank + 1))
+        s_sum, c_sum = all_reduce_statistics(s_local, cnt_local)
+        loss = det + float(world) * _meta(s_sum)
+        loss.backward()
+        sync()
+    out[rank] = {"grads": [p.grad.detach().numpy().copy() for p in net.parameters()],
+                 "s_sum": s_sum.detach().numpy().copy(), "c_sum": c_sum.detach().numpy().copy(),
+                 "params": [p.data.numpy().copy() for p in net.parameters()]}
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_update_equals_reference_rule():
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    # single-process statement of the reference: mean over replicas of the detector loss + ONE
+    # meta loss on the merged statistics
+    net = _net()
+    g = torch.Generator().manual_seed(100)
+    x_all = torch.randn(world * 3, 6, generator=g)
+    ys = [net(x_all[r * 3:(r + 1) * 3]) for r in range(world)]
+    det = torch.stack([(y ** 2).mean() for y in ys]).mean()
+    s_sum = sum(y.sum(0) for y in ys)
+    (det + _meta(s_sum)).backward()
+    ref = [p.grad for p in net.parameters()]
+    import numpy as np
+    for r in range(world):
+        assert np.allclose(out[r]["s_sum"], s_sum.detach().numpy(), rtol=1e-6, atol=1e-6)
+        assert np.array_equal(out[r]["c_sum"], np.full((1, 5), 3.0, np.float32))
+        for a, b in zip(out[r]["grads"], ref):
+            assert np.allclose(a, b.numpy(), rtol=1e-5, atol=1e-6)
+        for a, b in zip(out[r]["params"], net.parameters()):
+            assert np.array_equal(a, b.data.numpy())    # broadcast made the replicas identical
+    for a, b in zip(out[0]["grads"], out[1]["grads"]):
+        assert np.array_equal(a, b)                     # every rank holds the same averaged gradient
+
+
+def test_single_process_is_a_no_op():
+    from feature_intertwiner_amd.data_parallel import GradientBuckets, all_reduce_statistics
+    net = _net()
+    sync = GradientBuckets(net)
+    net(torch.randn(2, 6)).sum().backward()
+    before = [p.grad.clone() for p in net.parameters()]
+    sync()
+    assert all(torch.equal(a, p.grad) for a, p in zip(before, net.parameters()))
+    a, b = torch.randn(4, 3), torch.ones(1, 3)
+    a2, b2 = all_reduce_statistics(a, b)
+    assert a2 is a and b2 is b
