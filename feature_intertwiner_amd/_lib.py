@@ -12,7 +12,7 @@ import os
 import torch  # noqa: F401  (must precede the CDLL below, see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfi_hip.so")
+LIB_PATH = os.environ.get("FI_LIB_PATH", os.path.join(_HERE, "libfi_hip.so"))   # override: kernel A/B builds
 
 c_int = ctypes.c_int
 c_float = ctypes.c_float
@@ -50,8 +50,8 @@ SIGNATURES = {
                                       c_void_p]),
     "fi_class_mean_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p,
                                        c_void_p]),
-    "fi_conv2d_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 12 + [c_void_p]),
-    "fi_conv2d_weight_grad": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 11 + [c_void_p]),
+    "fi_conv2d_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 13 + [c_void_p]),
+    "fi_conv2d_weight_grad": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 12 + [c_void_p]),
     "fi_prof_enable": (None, [c_int]),
     "fi_prof_reset": (None, []),
     "fi_prof_get": (c_int, [c_int, _ip, ctypes.POINTER(c_float)]),

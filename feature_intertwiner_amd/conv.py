@@ -33,9 +33,16 @@ def _log_flops(kind, cout, R, S, flops):
 
 
 def _conv_fwd(x, w, b, stride, padding, relu=False):
+    """w is [Cout, Cin, R, S].  When Cin % 16 == 0 the kernel's tap-major fast path is used: the
+    weight is handed over channels-last ([Cout, R, S, Cin]; a copy of at most a few MB)."""
     L = _lib.load()
     N, Cin, H, W = x.shape
     Cout, _, R, S = w.shape
+    layout = 0
+    if Cin % 16 == 0 and R * S <= 64:
+        layout = 1
+        if R * S > 1:
+            w = w.permute(0, 2, 3, 1).contiguous()
     OH = (H + 2 * padding[0] - R) // stride[0] + 1
     OW = (W + 2 * padding[1] - S) // stride[1] + 1
     _log_flops("fwd", Cout, R, S, 2 * N * Cout * OH * OW * Cin * R * S)
@@ -43,7 +50,7 @@ def _conv_fwd(x, w, b, stride, padding, relu=False):
     with torch.cuda.device(x.device):
         _lib.check(L.fi_conv2d_forward(_lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(y), N, Cin, H, W, Cout,
                                        R, S, stride[0], stride[1], padding[0], padding[1], 1 if relu else 0,
-                                       _lib.current_stream()), "fi_conv2d_forward")
+                                       layout, _lib.current_stream()), "fi_conv2d_forward")
     return y
 
 
@@ -79,12 +86,16 @@ class _Conv2dFn(torch.autograd.Function):
                 up[:, :, :(OH - 1) * stride[0] + 1:stride[0], :(OW - 1) * stride[1] + 1:stride[1]] = dy
                 dx = _conv_fwd(up, wt, None, (1, 1), (R - 1 - padding[0], S - 1 - padding[1]))
         if ctx.needs_input_grad[1]:
-            dw = torch.empty_like(w)
+            hwc = 1 if (Cin % 128 == 0) else 0         # tap-major fast path of the kernel
+            dw = torch.empty((Cout, R, S, Cin) if (hwc and R * S > 1) else (Cout, Cin, R, S), device=x.device,
+                             dtype=torch.float32)
             _log_flops("wgrad", Cout, R, S, 2 * N * Cout * dy.shape[2] * dy.shape[3] * Cin * R * S)
             with torch.cuda.device(x.device):
                 _lib.check(L.fi_conv2d_weight_grad(_lib.ptr(x), _lib.ptr(dy), _lib.ptr(dw), N, Cin, H, W, Cout,
-                                                   R, S, stride[0], stride[1], padding[0], padding[1],
+                                                   R, S, stride[0], stride[1], padding[0], padding[1], hwc,
                                                    _lib.current_stream()), "fi_conv2d_weight_grad")
+            if hwc and R * S > 1:
+                dw = dw.permute(0, 3, 1, 2)
         if has_bias and ctx.needs_input_grad[2]:
             db = dy.sum((0, 2, 3))
         return dx, dw, db, None, None

@@ -35,19 +35,65 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kThreads = 256;
 constexpr int BN = 128;
-constexpr int BK = 16;
+#ifndef FI_CONV_BK
+#define FI_CONV_BK 16
+#endif
+constexpr int BK = FI_CONV_BK;
 constexpr int PAD = 4;
 
 struct ConvGeom {
     int N, Cin, H, W, Cout, R, S, sh, sw, ph, pw, OH, OW;
     int K;        // Cin*R*S
     int P;        // N*OH*OW
+    unsigned mul_ohw, sft_ohw, mul_ow, sft_ow;   // magic numbers: n / d == umulhi(n, mul) >> sft
 };
+
+// exact for 0 <= n < 2^31 (mul = ceil(2^(32+sft) / d), 32 + sft = 31 + ceil(log2 d))
+__device__ __forceinline__ int fast_div(int n, unsigned mul, unsigned sft)
+{
+    return mul ? (int)(__umulhi((unsigned)n, mul) >> sft) : n;   // mul == 0 encodes d == 1
+}
+
+// One K-step of MFMAs on a staged [BK][BM+PAD] x [BK][BN+PAD] tile pair.  The operand
+// fragments of sub-step kk+1 are read from LDS while the MFMAs of sub-step kk issue
+// (two register sets, statically indexed), so LDS latency is not exposed per sub-step.
+template <int BM>
+__device__ __forceinline__ void mma_tile(const float (*__restrict__ As)[BM + PAD],
+                                         const float (*__restrict__ Bs)[BN + PAD], int a_col, int b_col,
+                                         int khalf, f32x16 (&acc)[BM / 64][2])
+{
+    constexpr int MT = BM / 64;
+    float af[2][MT], bf[2][2];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) af[0][i] = As[khalf][a_col + i * 32];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) bf[0][j] = Bs[khalf][b_col + j * 32];
+#pragma unroll
+    for (int kk = 0; kk < BK / 2; ++kk) {
+        const int cur = kk & 1, nxt = cur ^ 1;
+        if (kk + 1 < BK / 2) {
+            const int kr = (kk + 1) * 2 + khalf;
+#pragma unroll
+            for (int i = 0; i < MT; ++i) af[nxt][i] = As[kr][a_col + i * 32];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bf[nxt][j] = Bs[kr][b_col + j * 32];
+        }
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i], bf[cur][j], acc[i][j], 0, 0, 0);
+    }
+}
 
 // -------------------------------------------------------------------------------------
 // forward / dgrad
 // -------------------------------------------------------------------------------------
-template <int BM, int TR, int TS>
+// HWC = true: the reduction index runs tap-major, k = (r*S + s)*Cin + ci, over weights stored
+// [Cout][R][S][Cin] (requires Cin % BK == 0).  A K-step then has ONE tap and BK consecutive
+// channels, so the halo test is a bit test of a per-thread tap mask and the gather address is
+// base + i*2*H*W: ~3 instructions per load instead of ~35 for the (ci, r, s) order.
+template <int BM, int TR, int TS, bool HWC>
 __global__ __launch_bounds__(kThreads) void conv_fwd_kernel(const float *__restrict__ x,
                                                             const float *__restrict__ w,
                                                             const float *__restrict__ bias,
@@ -77,29 +123,43 @@ __global__ __launch_bounds__(kThreads) void conv_fwd_kernel(const float *__restr
     const bool p_ok = p < g.P;
     int n = 0, oh = 0, ow = 0;
     if (p_ok) {
-        n = p / OHW;
+        n = fast_div(p, g.mul_ohw, g.sft_ohw);
         const int q = p - n * OHW;
-        oh = q / g.OW;
+        oh = fast_div(q, g.mul_ow, g.sft_ow);
         ow = q - oh * g.OW;
     }
     const int ih0 = oh * g.sh - g.ph;
     const int iw0 = ow * g.sw - g.pw;
     const float *__restrict__ xn = x + (size_t)n * g.Cin * HW;
+    const int pix_off = ih0 * g.W + iw0;        // may be negative; only used when in range
 
     // ---- A (weights) loader: 4 consecutive k of one output channel per load -----------
-    constexpr int A_LOADS = BM * BK / 4 / kThreads;     // float4 loads per thread (2 or 1)
-    const int ak4 = (tid & 3) * 4;
-    const int am = tid >> 2;                            // 0..63 (+64 for the second load)
+    constexpr int A_TPR = BK / 4;                       // threads per weight row (float4 each)
+    constexpr int A_ROWS = kThreads / A_TPR;            // rows covered per pass
+    constexpr int A_LOADS = BM / A_ROWS;                // float4 loads per thread
+    const int ak4 = (tid % A_TPR) * 4;
+    const int am = tid / A_TPR;                         // + A_ROWS per further load
     const bool k_vec = (K & 3) == 0;
 
     float a_reg[A_LOADS][4];
     float b_reg[BK / 2];
 
+    // HWC state: tap and channel base of the NEXT K-step to be loaded (calls are sequential)
+    int cur_rs = 0, cur_ci0 = 0;
+    unsigned long long tap_mask = 0;
+    if (HWC) {
+        for (int rs = 0; rs < RS; ++rs) {
+            const int r = rs / S, s = rs - (rs / S) * S;
+            if (p_ok && ((unsigned)(ih0 + r) < (unsigned)g.H) && ((unsigned)(iw0 + s) < (unsigned)g.W))
+                tap_mask |= 1ULL << rs;
+        }
+    }
+
     auto load_tiles = [&](int kt) {
         const int kbase = kt * BK;
 #pragma unroll
         for (int i = 0; i < A_LOADS; ++i) {
-            const int m = m0 + am + i * 64;
+            const int m = m0 + am + i * A_ROWS;
             const int k = kbase + ak4;
             if (m < g.Cout && k_vec && k + 3 < K) {
                 const float4 v = *reinterpret_cast<const float4 *>(w + (size_t)m * K + k);
@@ -110,27 +170,47 @@ __global__ __launch_bounds__(kThreads) void conv_fwd_kernel(const float *__restr
                     a_reg[i][q] = (m < g.Cout && k + q < K) ? w[(size_t)m * K + k + q] : 0.0f;
             }
         }
+        if (HWC) {
+            const int rs = cur_rs;
+            const int r = rs / S, s = rs - (rs / S) * S;
+            const bool ok = (tap_mask >> rs) & 1ULL;
+            const int off0 = pix_off + r * g.W + s + (cur_ci0 + bk0) * HW;
+            const int base = ok ? off0 : 0;
+            const int stride = ok ? 2 * HW : 0;
+#pragma unroll
+            for (int i = 0; i < BK / 2; ++i) {
+                const float t = xn[base + i * stride];
+                b_reg[i] = ok ? t : 0.0f;
+            }
+            cur_ci0 += BK;
+            if (cur_ci0 >= g.Cin) {
+                cur_ci0 = 0;
+                ++cur_rs;
+            }
+            return;
+        }
+        // branch-free gather: out-of-range taps read element 0 of the image and are zeroed by a
+        // select, so the 8 loads of a K-step issue back to back (no exec-mask regions)
 #pragma unroll
         for (int i = 0; i < BK / 2; ++i) {
             const int k = __builtin_amdgcn_readfirstlane(kbase + bk0 + 2 * i);
-            float v = 0.0f;
-            if (k < K) {
-                const int ci = k / RS;
-                const int rs = k - ci * RS;
-                const int r = rs / S;
-                const int s = rs - r * S;
-                const int ih = ih0 + r, iw = iw0 + s;
-                if (p_ok && ih >= 0 && ih < g.H && iw >= 0 && iw < g.W)
-                    v = xn[(size_t)ci * HW + ih * g.W + iw];
-            }
-            b_reg[i] = v;
+            const int kc = min(k, K - 1);
+            const int ci = kc / RS;
+            const int rs = kc - ci * RS;
+            const int r = rs / S;
+            const int s = rs - r * S;
+            const int koff = ci * HW + r * g.W + s;              // scalar
+            const bool ok = p_ok && (k < K) && ((unsigned)(ih0 + r) < (unsigned)g.H) &&
+                            ((unsigned)(iw0 + s) < (unsigned)g.W);
+            const float t = xn[ok ? (pix_off + koff) : 0];
+            b_reg[i] = ok ? t : 0.0f;
         }
     };
     auto store_tiles = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < A_LOADS; ++i)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) As[buf][ak4 + q][am + i * 64] = a_reg[i][q];
+            for (int q = 0; q < 4; ++q) As[buf][ak4 + q][am + i * A_ROWS] = a_reg[i][q];
 #pragma unroll
         for (int i = 0; i < BK / 2; ++i) Bs[buf][bk0 + 2 * i][bj] = b_reg[i];
     };
@@ -153,20 +233,7 @@ __global__ __launch_bounds__(kThreads) void conv_fwd_kernel(const float *__restr
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
         if (kt + 1 < nk) load_tiles(kt + 1);
-#pragma unroll
-        for (int kk = 0; kk < BK / 2; ++kk) {
-            const int kr = kk * 2 + khalf;
-            float af[MT], bf[2];
-#pragma unroll
-            for (int i = 0; i < MT; ++i) af[i] = As[buf][kr][wm * (BM / 2) + i * 32 + l31];
-#pragma unroll
-            for (int j = 0; j < 2; ++j) bf[j] = Bs[buf][kr][wn * 64 + j * 32 + l31];
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
-        }
+        mma_tile<BM>(As[buf], Bs[buf], wm * (BM / 2) + l31, wn * 64 + l31, khalf, acc);
         if (kt + 1 < nk) store_tiles(buf ^ 1);
         __syncthreads();
     }
@@ -199,7 +266,10 @@ __global__ __launch_bounds__(kThreads) void conv_fwd_kernel(const float *__restr
 //   GEMM rows m = output channel, columns k = (ci, r, s), reduction over pixels p.
 //   blockIdx.z splits the pixel range; partial sums are added with fp32 atomics.
 // -------------------------------------------------------------------------------------
-template <int BM, int TR, int TS>
+// HWC = true: dW columns run tap-major (k = (r*S+s)*Cin + ci, dW stored [Cout][R][S][Cin]) and
+// Cin % 128 == 0, so a workgroup's 128 columns share one tap: one halo test per pixel and
+// constant-stride channel gathers.
+template <int BM, int TR, int TS, bool HWC>
 __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(const float *__restrict__ x,
                                                               const float *__restrict__ dy,
                                                               float *__restrict__ dw, ConvGeom g,
@@ -225,60 +295,76 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(const float *__res
     if (p_begin >= p_end) return;
 
     // A loader (dY): lane -> pixel (contiguous in memory), 16 pixels x BM channels per step
-    constexpr int A_LOADS = BM * BK / kThreads;   // 8 or 4 scalar loads per thread
-    const int ap = tid & 15;
-    const int am = tid >> 4;                      // 0..15 (+16*i)
+    constexpr int W_COLS = kThreads / BK;         // channels / k-columns covered per pass
+    constexpr int A_LOADS = BM / W_COLS;          // scalar loads per thread
+    const int ap = tid % BK;
+    const int am = tid / BK;                      // + W_COLS per further load
     // B loader (input patches): lane -> pixel, column k = (ci,r,s) fixed per thread
-    constexpr int B_LOADS = BN * BK / kThreads;   // 8
-    const int bp = tid & 15;
-    const int bk = tid >> 4;                      // 0..15 (+16*i)
-    int b_ci[B_LOADS], b_r[B_LOADS], b_s[B_LOADS];
+    constexpr int B_LOADS = BN / W_COLS;
+    const int bp = tid % BK;
+    const int bk = tid / BK;                      // + W_COLS per further load
+    int b_off[B_LOADS], b_r[B_LOADS], b_s[B_LOADS];
     bool b_ok[B_LOADS];
 #pragma unroll
     for (int i = 0; i < B_LOADS; ++i) {
-        const int k = k0 + bk + 16 * i;
+        const int k = k0 + bk + W_COLS * i;
         b_ok[i] = k < K;
         const int kc = b_ok[i] ? k : 0;
-        b_ci[i] = kc / RS;
-        const int rs = kc - b_ci[i] * RS;
+        const int ci = HWC ? (kc % g.Cin) : (kc / RS);
+        const int rs = HWC ? (kc / g.Cin) : (kc - ci * RS);
         b_r[i] = rs / S;
         b_s[i] = rs - b_r[i] * S;
+        b_off[i] = ci * HW + b_r[i] * g.W + b_s[i];
     }
+    // HWC: every column of this workgroup has the same tap; channels step by W_COLS
+    const int h_r = b_r[0], h_s = b_s[0];
+    const int h_stride = W_COLS * HW;
 
     float a_reg[A_LOADS], b_reg[B_LOADS];
     auto load_tiles = [&](int pt) {
         // pixel handled by this thread in this step (same for the A and B loaders: ap == bp)
         const int p = pt + ap;
         const bool ok = p < p_end;
-        int n = 0, oh = 0, ow = 0, q = 0;
-        if (ok) {
-            n = p / OHW;
-            q = p - n * OHW;
-            oh = q / g.OW;
-            ow = q - oh * g.OW;
-        }
+        const int pc = ok ? p : p_begin;
+        const int n = fast_div(pc, g.mul_ohw, g.sft_ohw);
+        const int q = pc - n * OHW;
+        const int oh = fast_div(q, g.mul_ow, g.sft_ow);
+        const int ow = q - oh * g.OW;
         const float *__restrict__ dyn = dy + (size_t)n * g.Cout * OHW + q;
 #pragma unroll
         for (int i = 0; i < A_LOADS; ++i) {
-            const int m = m0 + am + 16 * i;
-            a_reg[i] = (ok && m < g.Cout) ? dyn[(size_t)m * OHW] : 0.0f;
+            const int m = m0 + am + W_COLS * i;
+            const bool inm = ok && m < g.Cout;
+            const float t = dyn[inm ? m * OHW : 0];
+            a_reg[i] = inm ? t : 0.0f;
         }
         const int ih0 = oh * g.sh - g.ph, iw0 = ow * g.sw - g.pw;
         const float *__restrict__ xn = x + (size_t)n * g.Cin * HW;
+        const int pix_off = ih0 * g.W + iw0;
+        if (HWC) {
+            const bool inb = ok && ((unsigned)(ih0 + h_r) < (unsigned)g.H) && ((unsigned)(iw0 + h_s) < (unsigned)g.W);
+            const int base = inb ? (pix_off + b_off[0]) : 0;
+            const int stride = inb ? h_stride : 0;
+#pragma unroll
+            for (int i = 0; i < B_LOADS; ++i) {
+                const float t = xn[base + i * stride];
+                b_reg[i] = inb ? t : 0.0f;
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < B_LOADS; ++i) {
-            const int ih = ih0 + b_r[i], iw = iw0 + b_s[i];
-            float v = 0.0f;
-            if (ok && b_ok[i] && ih >= 0 && ih < g.H && iw >= 0 && iw < g.W)
-                v = xn[(size_t)b_ci[i] * HW + ih * g.W + iw];
-            b_reg[i] = v;
+            const bool inb = ok && b_ok[i] && ((unsigned)(ih0 + b_r[i]) < (unsigned)g.H) &&
+                             ((unsigned)(iw0 + b_s[i]) < (unsigned)g.W);
+            const float t = xn[inb ? (pix_off + b_off[i]) : 0];
+            b_reg[i] = inb ? t : 0.0f;
         }
     };
     auto store_tiles = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < A_LOADS; ++i) As[buf][ap][am + 16 * i] = a_reg[i];
+        for (int i = 0; i < A_LOADS; ++i) As[buf][ap][am + W_COLS * i] = a_reg[i];
 #pragma unroll
-        for (int i = 0; i < B_LOADS; ++i) Bs[buf][bp][bk + 16 * i] = b_reg[i];
+        for (int i = 0; i < B_LOADS; ++i) Bs[buf][bp][bk + W_COLS * i] = b_reg[i];
     };
 
     f32x16 acc[MT][2];
@@ -298,20 +384,7 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(const float *__res
     for (int st = 0; st < steps; ++st) {
         const int buf = st & 1;
         if (st + 1 < steps) load_tiles(p_begin + (st + 1) * BK);
-#pragma unroll
-        for (int kk = 0; kk < BK / 2; ++kk) {
-            const int kr = kk * 2 + khalf;
-            float af[MT], bf[2];
-#pragma unroll
-            for (int i = 0; i < MT; ++i) af[i] = As[buf][kr][wm * (BM / 2) + i * 32 + l31];
-#pragma unroll
-            for (int j = 0; j < 2; ++j) bf[j] = Bs[buf][kr][wn * 64 + j * 32 + l31];
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
-        }
+        mma_tile<BM>(As[buf], Bs[buf], wm * (BM / 2) + l31, wn * 64 + l31, khalf, acc);
         if (st + 1 < steps) store_tiles(buf ^ 1);
         __syncthreads();
     }
@@ -352,37 +425,68 @@ int make_geom(ConvGeom &g, int N, int Cin, int H, int W, int Cout, int R, int S,
     FI_REQUIRE((long)N * Cin * H * W < 2147483647L * 2 && (long)Cout * K < 2147483647L, "tensor too large");
     g.K = (int)K;
     g.P = (int)P;
+    auto magic = [](unsigned d, unsigned &mul, unsigned &sft) {
+        if (d <= 1) {
+            mul = 0;
+            sft = 0;
+            return;
+        }
+        unsigned L = 0;
+        while ((1ull << L) < d) ++L;                   // ceil(log2 d)
+        const unsigned total = 31 + L;                 // 2^total / d < 2^32
+        const unsigned long long num = 1ull << total;
+        mul = (unsigned)((num + d - 1) / d);
+        sft = total - 32;                              // L >= 1 for d >= 2
+    };
+    magic((unsigned)(g.OH * g.OW), g.mul_ohw, g.sft_ohw);
+    magic((unsigned)g.OW, g.mul_ow, g.sft_ow);
     return FI_OK;
 }
 
 template <int BM>
 void launch_fwd(const ConvGeom &g, const float *x, const float *w, const float *b, float *y, int relu,
-                hipStream_t st)
+                bool hwc, hipStream_t st)
 {
     dim3 grid(fi::ceil_div(g.P, BN), fi::ceil_div(g.Cout, BM));
+    if (hwc) {
+        if (g.R == 3 && g.S == 3)
+            hipLaunchKernelGGL((conv_fwd_kernel<BM, 3, 3, true>), grid, dim3(kThreads), 0, st, x, w, b, y, g, relu);
+        else if (g.R == 1 && g.S == 1)
+            hipLaunchKernelGGL((conv_fwd_kernel<BM, 1, 1, true>), grid, dim3(kThreads), 0, st, x, w, b, y, g, relu);
+        else
+            hipLaunchKernelGGL((conv_fwd_kernel<BM, 0, 0, true>), grid, dim3(kThreads), 0, st, x, w, b, y, g, relu);
+        return;
+    }
     if (g.R == 3 && g.S == 3)
-        hipLaunchKernelGGL((conv_fwd_kernel<BM, 3, 3>), grid, dim3(kThreads), 0, st, x, w, b, y, g, relu);
-    else if (g.R == 1 && g.S == 1)
-        hipLaunchKernelGGL((conv_fwd_kernel<BM, 1, 1>), grid, dim3(kThreads), 0, st, x, w, b, y, g, relu);
+        hipLaunchKernelGGL((conv_fwd_kernel<BM, 3, 3, false>), grid, dim3(kThreads), 0, st, x, w, b, y, g, relu);
     else if (g.R == 7 && g.S == 7)
-        hipLaunchKernelGGL((conv_fwd_kernel<BM, 7, 7>), grid, dim3(kThreads), 0, st, x, w, b, y, g, relu);
+        hipLaunchKernelGGL((conv_fwd_kernel<BM, 7, 7, false>), grid, dim3(kThreads), 0, st, x, w, b, y, g, relu);
     else
-        hipLaunchKernelGGL((conv_fwd_kernel<BM, 0, 0>), grid, dim3(kThreads), 0, st, x, w, b, y, g, relu);
+        hipLaunchKernelGGL((conv_fwd_kernel<BM, 0, 0, false>), grid, dim3(kThreads), 0, st, x, w, b, y, g, relu);
 }
 
 template <int BM>
 void launch_wgrad(const ConvGeom &g, const float *x, const float *dy, float *dw, int splits,
-                  int p_per_split, hipStream_t st)
+                  int p_per_split, bool hwc, hipStream_t st)
 {
     dim3 grid(fi::ceil_div(g.K, BN), fi::ceil_div(g.Cout, BM), splits);
+    if (hwc) {
+        if (g.R == 3 && g.S == 3)
+            hipLaunchKernelGGL((conv_wgrad_kernel<BM, 3, 3, true>), grid, dim3(kThreads), 0, st, x, dy, dw, g, p_per_split);
+        else if (g.R == 1 && g.S == 1)
+            hipLaunchKernelGGL((conv_wgrad_kernel<BM, 1, 1, true>), grid, dim3(kThreads), 0, st, x, dy, dw, g, p_per_split);
+        else
+            hipLaunchKernelGGL((conv_wgrad_kernel<BM, 0, 0, true>), grid, dim3(kThreads), 0, st, x, dy, dw, g, p_per_split);
+        return;
+    }
     if (g.R == 3 && g.S == 3)
-        hipLaunchKernelGGL((conv_wgrad_kernel<BM, 3, 3>), grid, dim3(kThreads), 0, st, x, dy, dw, g, p_per_split);
+        hipLaunchKernelGGL((conv_wgrad_kernel<BM, 3, 3, false>), grid, dim3(kThreads), 0, st, x, dy, dw, g, p_per_split);
     else if (g.R == 1 && g.S == 1)
-        hipLaunchKernelGGL((conv_wgrad_kernel<BM, 1, 1>), grid, dim3(kThreads), 0, st, x, dy, dw, g, p_per_split);
+        hipLaunchKernelGGL((conv_wgrad_kernel<BM, 1, 1, false>), grid, dim3(kThreads), 0, st, x, dy, dw, g, p_per_split);
     else if (g.R == 7 && g.S == 7)
-        hipLaunchKernelGGL((conv_wgrad_kernel<BM, 7, 7>), grid, dim3(kThreads), 0, st, x, dy, dw, g, p_per_split);
+        hipLaunchKernelGGL((conv_wgrad_kernel<BM, 7, 7, false>), grid, dim3(kThreads), 0, st, x, dy, dw, g, p_per_split);
     else
-        hipLaunchKernelGGL((conv_wgrad_kernel<BM, 0, 0>), grid, dim3(kThreads), 0, st, x, dy, dw, g, p_per_split);
+        hipLaunchKernelGGL((conv_wgrad_kernel<BM, 0, 0, false>), grid, dim3(kThreads), 0, st, x, dy, dw, g, p_per_split);
 }
 
 }  // namespace
@@ -391,30 +495,37 @@ extern "C" {
 
 int fi_conv2d_forward(const float *x, const float *weight, const float *bias, float *y, int N,
                       int Cin, int H, int W, int Cout, int R, int S, int stride_h, int stride_w,
-                      int pad_h, int pad_w, int relu, fi_stream_t stream)
+                      int pad_h, int pad_w, int relu, int weight_layout, fi_stream_t stream)
 {
     ConvGeom g;
     int rc = make_geom(g, N, Cin, H, W, Cout, R, S, stride_h, stride_w, pad_h, pad_w);
     if (rc != FI_OK) return rc;
     FI_REQUIRE(x && weight && y, "null pointer");
+    FI_REQUIRE(weight_layout == 0 || weight_layout == 1, "weight_layout: 0 = [Cout][Cin][R][S], 1 = [Cout][R][S][Cin]");
+    // tap-major fast path: channels-last weights (any 1x1 weight is both layouts at once)
+    const bool hwc = (Cin % BK == 0) && (R * S <= 64) && (weight_layout == 1 || R * S == 1);
+    FI_REQUIRE(hwc || weight_layout == 0, "weight_layout 1 needs Cin % 16 == 0 and R*S <= 64");
     hipStream_t st = (hipStream_t)stream;
     fi::ProfScope prof(FI_K_CONV_FWD + (Cout <= 64 ? 0 : 4) + window_class(R, S), st);
     if (Cout <= 64)
-        launch_fwd<64>(g, x, weight, bias, y, relu, st);
+        launch_fwd<64>(g, x, weight, bias, y, relu, hwc, st);
     else
-        launch_fwd<128>(g, x, weight, bias, y, relu, st);
+        launch_fwd<128>(g, x, weight, bias, y, relu, hwc, st);
     FI_HIP_CHECK(hipGetLastError());
     return FI_OK;
 }
 
 int fi_conv2d_weight_grad(const float *x, const float *dy, float *dweight, int N, int Cin, int H,
                           int W, int Cout, int R, int S, int stride_h, int stride_w, int pad_h,
-                          int pad_w, fi_stream_t stream)
+                          int pad_w, int weight_layout, fi_stream_t stream)
 {
     ConvGeom g;
     int rc = make_geom(g, N, Cin, H, W, Cout, R, S, stride_h, stride_w, pad_h, pad_w);
     if (rc != FI_OK) return rc;
     FI_REQUIRE(x && dy && dweight, "null pointer");
+    FI_REQUIRE(weight_layout == 0 || weight_layout == 1, "weight_layout: 0 = [Cout][Cin][R][S], 1 = [Cout][R][S][Cin]");
+    const bool hwc = (Cin % BN == 0) && (weight_layout == 1 || R * S == 1);
+    FI_REQUIRE(hwc || weight_layout == 0 , "weight_layout 1 needs Cin % 128 == 0");
     hipStream_t st = (hipStream_t)stream;
     FI_HIP_CHECK(hipMemsetAsync(dweight, 0, sizeof(float) * (size_t)Cout * g.K, st));
     const int BMsel = Cout <= 64 ? 64 : 128;
@@ -429,9 +540,9 @@ int fi_conv2d_weight_grad(const float *x, const float *dy, float *dweight, int N
     splits = fi::ceil_div(g.P, pps);
     fi::ProfScope prof(FI_K_CONV_WGRAD + (BMsel == 64 ? 0 : 4) + window_class(R, S), st);
     if (BMsel == 64)
-        launch_wgrad<64>(g, x, dy, dweight, splits, pps, st);
+        launch_wgrad<64>(g, x, dy, dweight, splits, pps, hwc, st);
     else
-        launch_wgrad<128>(g, x, dy, dweight, splits, pps, st);
+        launch_wgrad<128>(g, x, dy, dweight, splits, pps, hwc, st);
     FI_HIP_CHECK(hipGetLastError());
     return FI_OK;
 }

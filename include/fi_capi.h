@@ -205,18 +205,21 @@ int fi_class_mean_backward(const float *grad_feat, const int32_t *gt,
  * 750-787); the reference has no native code of its own for them.
  * x [N,Cin,H,W], weight [Cout,Cin,R,S], bias [Cout] or NULL, y [N,Cout,OH,OW] with
  * OH = (H + 2*pad_h - R)/stride_h + 1.  relu != 0 fuses max(.,0) into the epilogue.
+ * weight_layout 0: weight is [Cout,Cin,R,S] (as stored by the model); 1: [Cout,R,S,Cin]
+ * (tap-major / channels-last; needs Cin % 16 == 0) -- selects the fast gather path.
  * The data gradient of a stride-1 convolution is this same call on dY with the flipped,
  * transposed weight [Cin,Cout,R,S] and padding R-1-pad.
  * fi_conv2d_weight_grad: dweight [Cout,Cin,R,S] = sum over images and pixels of
  * dy (x) patches(x); zero-filled by the call, accumulated with fp32 atomics over a split
- * of the pixel range.
+ * of the pixel range.  weight_layout 1 writes dweight as [Cout,R,S,Cin] (needs Cin % 128 == 0).
  * ---------------------------------------------------------------------- */
 int fi_conv2d_forward(const float *x, const float *weight, const float *bias, float *y,
                       int N, int Cin, int H, int W, int Cout, int R, int S, int stride_h,
-                      int stride_w, int pad_h, int pad_w, int relu, fi_stream_t stream);
+                      int stride_w, int pad_h, int pad_w, int relu, int weight_layout,
+                      fi_stream_t stream);
 int fi_conv2d_weight_grad(const float *x, const float *dy, float *dweight, int N, int Cin,
                           int H, int W, int Cout, int R, int S, int stride_h, int stride_w,
-                          int pad_h, int pad_w, fi_stream_t stream);
+                          int pad_h, int pad_w, int weight_layout, fi_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * In-library kernel timing (HIP events recorded on the launch stream around
