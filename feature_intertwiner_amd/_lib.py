@@ -50,7 +50,8 @@ SIGNATURES = {
                                       c_void_p]),
     "fi_class_mean_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p,
                                        c_void_p]),
-    "fi_conv2d_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 13 + [c_void_p]),
+    "fi_conv2d_forward": (c_int, [c_void_p] * 6 + [c_int] * 13 + [c_void_p]),
+    "fi_bn_act_backward": (c_int, [c_void_p] * 6 + [c_int] * 4 + [c_void_p] * 5),
     "fi_conv2d_weight_grad": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 12 + [c_void_p]),
     "fi_prof_enable": (None, [c_int]),
     "fi_prof_reset": (None, []),
@@ -62,7 +63,7 @@ KERNEL_IDS = {
     "crop_fwd_7x7": 0, "crop_fwd_14x14": 1, "crop_fwd_28x28": 2, "crop_fwd_generic": 3,
     "crop_bwd_7x7": 4, "crop_bwd_14x14": 5, "crop_bwd_28x28": 6, "crop_bwd_generic": 7,
     "roipool_fwd": 8, "roipool_bwd": 9, "nms_mask": 10, "nms_scan": 11, "sinkhorn": 12,
-    "class_mean": 13,
+    "class_mean": 13, "bn_act_bwd": 30,
 }
 for _i, _bm in enumerate((64, 128)):
     for _j, _w in enumerate(("1x1", "3x3", "7x7", "other")):

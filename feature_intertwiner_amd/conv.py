@@ -32,7 +32,7 @@ def _log_flops(kind, cout, R, S, flops):
         e[1] += flops
 
 
-def _conv_fwd(x, w, b, stride, padding, relu=False):
+def _conv_fwd(x, w, b, stride, padding, relu=False, scale=None, residual=None):
     """w is [Cout, Cin, R, S].  When Cin % 16 == 0 the kernel's tap-major fast path is used: the
     weight is handed over channels-last ([Cout, R, S, Cin]; a copy of at most a few MB)."""
     L = _lib.load()
@@ -48,7 +48,8 @@ def _conv_fwd(x, w, b, stride, padding, relu=False):
     _log_flops("fwd", Cout, R, S, 2 * N * Cout * OH * OW * Cin * R * S)
     y = torch.empty((N, Cout, OH, OW), device=x.device, dtype=torch.float32)
     with torch.cuda.device(x.device):
-        _lib.check(L.fi_conv2d_forward(_lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(y), N, Cin, H, W, Cout,
+        _lib.check(L.fi_conv2d_forward(_lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(scale), _lib.ptr(residual),
+                                       _lib.ptr(y), N, Cin, H, W, Cout,
                                        R, S, stride[0], stride[1], padding[0], padding[1], 1 if relu else 0,
                                        layout, _lib.current_stream()), "fi_conv2d_forward")
     return y
@@ -69,36 +70,98 @@ class _Conv2dFn(torch.autograd.Function):
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
         stride, padding, has_bias = ctx.conf
+        dy = dy.contiguous().float()
+        dx, dw = _conv_backward(ctx.needs_input_grad, x, w, dy, stride, padding)
+        db = dy.sum((0, 2, 3)) if (has_bias and ctx.needs_input_grad[2]) else None
+        return dx, dw, db, None, None
+
+
+def _conv_backward(ctx_needs, x, w, dz, stride, padding):
+    """dX and dW of z = conv(x, w) given dz (shared by the plain and the fused functions)."""
+    L = _lib.load()
+    N, Cin, H, W = x.shape
+    Cout, _, R, S = w.shape
+    dx = dw = None
+    if ctx_needs[0]:
+        wt = w.flip(2, 3).transpose(0, 1).contiguous()          # [Cin, Cout, R, S]
+        if stride == (1, 1):
+            dx = _conv_fwd(dz, wt, None, (1, 1), (R - 1 - padding[0], S - 1 - padding[1]))
+        else:
+            OH, OW = dz.shape[2], dz.shape[3]
+            rem_h = (H + 2 * padding[0] - R) % stride[0]
+            rem_w = (W + 2 * padding[1] - S) % stride[1]
+            up = dz.new_zeros(N, Cout, (OH - 1) * stride[0] + 1 + rem_h, (OW - 1) * stride[1] + 1 + rem_w)
+            up[:, :, :(OH - 1) * stride[0] + 1:stride[0], :(OW - 1) * stride[1] + 1:stride[1]] = dz
+            dx = _conv_fwd(up, wt, None, (1, 1), (R - 1 - padding[0], S - 1 - padding[1]))
+    if ctx_needs[1]:
+        hwc = 1 if (Cin % 128 == 0) else 0         # tap-major fast path of the kernel
+        dw = torch.empty((Cout, R, S, Cin) if (hwc and R * S > 1) else (Cout, Cin, R, S), device=x.device,
+                         dtype=torch.float32)
+        _log_flops("wgrad", Cout, R, S, 2 * N * Cout * dz.shape[2] * dz.shape[3] * Cin * R * S)
+        with torch.cuda.device(x.device):
+            _lib.check(L.fi_conv2d_weight_grad(_lib.ptr(x), _lib.ptr(dz), _lib.ptr(dw), N, Cin, H, W, Cout,
+                                               R, S, stride[0], stride[1], padding[0], padding[1], hwc,
+                                               _lib.current_stream()), "fi_conv2d_weight_grad")
+        if hwc and R * S > 1:
+            dw = dw.permute(0, 3, 1, 2)
+    return dx, dw
+
+
+class _ConvBnActFn(torch.autograd.Function):
+    """y = act(BN_eval(conv(x)) [+ residual]) in ONE kernel launch; backward = one fused
+    elementwise/reduction pass (fi_bn_act_backward) + the conv dgrad/wgrad kernels."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, gamma, beta, mean, var, eps, residual, relu, stride, padding):
+        _lib.require_cuda(x, w)
+        x = x.contiguous().float()
+        w = w.contiguous().float()
+        scale = gamma * torch.rsqrt(var + eps)
+        shift = beta - mean * scale
+        if b is not None:
+            shift = shift + b * scale
+        res = residual.contiguous().float() if residual is not None else None
+        y = _conv_fwd(x, w, shift.contiguous(), stride, padding, relu=relu, scale=scale.contiguous(), residual=res)
+        ctx.save_for_backward(x, w, y, scale, gamma, beta, res)
+        ctx.conf = (tuple(stride), tuple(padding), b is not None, bool(relu), residual is not None, eps, mean, var)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y, scale, gamma, beta, res = ctx.saved_tensors
+        stride, padding, has_bias, relu, has_res, eps, mean, var = ctx.conf
         L = _lib.load()
         dy = dy.contiguous().float()
-        N, Cin, H, W = x.shape
-        Cout, _, R, S = w.shape
-        dx = dw = db = None
-        if ctx.needs_input_grad[0]:
-            wt = w.flip(2, 3).transpose(0, 1).contiguous()          # [Cin, Cout, R, S]
-            if stride == (1, 1):
-                dx = _conv_fwd(dy, wt, None, (1, 1), (R - 1 - padding[0], S - 1 - padding[1]))
-            else:
-                OH, OW = dy.shape[2], dy.shape[3]
-                rem_h = (H + 2 * padding[0] - R) % stride[0]
-                rem_w = (W + 2 * padding[1] - S) % stride[1]
-                up = dy.new_zeros(N, Cout, (OH - 1) * stride[0] + 1 + rem_h, (OW - 1) * stride[1] + 1 + rem_w)
-                up[:, :, :(OH - 1) * stride[0] + 1:stride[0], :(OW - 1) * stride[1] + 1:stride[1]] = dy
-                dx = _conv_fwd(up, wt, None, (1, 1), (R - 1 - padding[0], S - 1 - padding[1]))
-        if ctx.needs_input_grad[1]:
-            hwc = 1 if (Cin % 128 == 0) else 0         # tap-major fast path of the kernel
-            dw = torch.empty((Cout, R, S, Cin) if (hwc and R * S > 1) else (Cout, Cin, R, S), device=x.device,
-                             dtype=torch.float32)
-            _log_flops("wgrad", Cout, R, S, 2 * N * Cout * dy.shape[2] * dy.shape[3] * Cin * R * S)
-            with torch.cuda.device(x.device):
-                _lib.check(L.fi_conv2d_weight_grad(_lib.ptr(x), _lib.ptr(dy), _lib.ptr(dw), N, Cin, H, W, Cout,
-                                                   R, S, stride[0], stride[1], padding[0], padding[1], hwc,
-                                                   _lib.current_stream()), "fi_conv2d_weight_grad")
-            if hwc and R * S > 1:
-                dw = dw.permute(0, 3, 1, 2)
-        if has_bias and ctx.needs_input_grad[2]:
-            db = dy.sum((0, 2, 3))
-        return dx, dw, db, None, None
+        N, C, OH, OW = y.shape
+        dz = torch.empty_like(y)
+        g_res = torch.empty_like(y) if (has_res and ctx.needs_input_grad[8]) else None
+        dshift = torch.empty(C, device=y.device, dtype=torch.float32)
+        dgamma = torch.empty(C, device=y.device, dtype=torch.float32) if ctx.needs_input_grad[3] else None
+        with torch.cuda.device(y.device):
+            _lib.check(L.fi_bn_act_backward(_lib.ptr(dy), _lib.ptr(y), _lib.ptr(scale), _lib.ptr(gamma),
+                                            _lib.ptr(beta), _lib.ptr(res), N, C, OH * OW, 1 if relu else 0,
+                                            _lib.ptr(dz),
+                                            _lib.ptr(g_res), _lib.ptr(dshift), _lib.ptr(dgamma),
+                                            _lib.current_stream()), "fi_bn_act_backward")
+        dx, dw = _conv_backward(ctx.needs_input_grad, x, w, dz, stride, padding)
+        db = dshift * scale if (has_bias and ctx.needs_input_grad[2]) else None
+        dbeta = dshift if ctx.needs_input_grad[4] else None
+        return dx, dw, db, dgamma, dbeta, None, None, None, g_res, None, None, None
+
+
+def conv_bn_act(x, conv, bn, relu=True, residual=None):
+    """act(bn(conv(x)) [+ residual]) for an eval-mode BatchNorm2d (the reference always evaluates
+    BN with running statistics, lib/model.py:265-267).  Falls back to separate ops for a BN in
+    training mode or a full-window (GEMM) convolution."""
+    R, S = conv.weight.shape[2], conv.weight.shape[3]
+    gemm_path = ((x.shape[2], x.shape[3]) == (R, S) and tuple(conv.padding) == (0, 0)) or x.shape[2] * x.shape[3] == 1
+    if bn.training or gemm_path or not bn.track_running_stats:
+        y = bn(conv(x))
+        if residual is not None:
+            y = y + residual
+        return F.relu(y) if relu else y
+    return _ConvBnActFn.apply(x, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                              bn.eps, residual, relu, tuple(conv.stride), tuple(conv.padding))
 
 
 def conv2d(x, weight, bias=None, stride=(1, 1), padding=(0, 0)):

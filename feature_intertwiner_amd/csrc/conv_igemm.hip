@@ -41,6 +41,15 @@ constexpr int BN = 128;
 constexpr int BK = FI_CONV_BK;
 constexpr int PAD = 4;
 
+// epilogue: y = acc * scale[m] + bias[m] (+ residual) (ReLU) -- scale/bias carry an eval-mode
+// BatchNorm folded by the caller, residual the bottleneck shortcut
+struct Epilogue {
+    const float *bias;
+    const float *scale;
+    const float *residual;
+    int relu;
+};
+
 struct ConvGeom {
     int N, Cin, H, W, Cout, R, S, sh, sw, ph, pw, OH, OW;
     int K;        // Cin*R*S
@@ -96,9 +105,8 @@ __device__ __forceinline__ void mma_tile(const float (*__restrict__ As)[BM + PAD
 template <int BM, int TR, int TS, bool HWC>
 __global__ __launch_bounds__(kThreads) void conv_fwd_kernel(const float *__restrict__ x,
                                                             const float *__restrict__ w,
-                                                            const float *__restrict__ bias,
-                                                            float *__restrict__ y, ConvGeom g,
-                                                            int relu)
+                                                            Epilogue ep,
+                                                            float *__restrict__ y, ConvGeom g)
 {
     constexpr int MT = BM / 64;                 // 32-row MFMA tiles per wave along M
     __shared__ float As[2][BK][BM + PAD];
@@ -253,8 +261,10 @@ __global__ __launch_bounds__(kThreads) void conv_fwd_kernel(const float *__restr
                 const int m = m0 + wm * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * khalf;
                 if (m < g.Cout) {
                     float v = acc[i][j][e];
-                    if (bias) v += bias[m];
-                    if (relu) v = fmaxf(v, 0.0f);
+                    if (ep.scale) v = v * ep.scale[m];
+                    if (ep.bias) v += ep.bias[m];
+                    if (ep.residual) v += ep.residual[(size_t)on * g.Cout * OHW + oq + (size_t)m * OHW];
+                    if (ep.relu) v = fmaxf(v, 0.0f);
                     yb[(size_t)m * OHW] = v;
                 }
             }
@@ -444,25 +454,25 @@ int make_geom(ConvGeom &g, int N, int Cin, int H, int W, int Cout, int R, int S,
 }
 
 template <int BM>
-void launch_fwd(const ConvGeom &g, const float *x, const float *w, const float *b, float *y, int relu,
+void launch_fwd(const ConvGeom &g, const float *x, const float *w, const Epilogue &ep, float *y,
                 bool hwc, hipStream_t st)
 {
     dim3 grid(fi::ceil_div(g.P, BN), fi::ceil_div(g.Cout, BM));
     if (hwc) {
         if (g.R == 3 && g.S == 3)
-            hipLaunchKernelGGL((conv_fwd_kernel<BM, 3, 3, true>), grid, dim3(kThreads), 0, st, x, w, b, y, g, relu);
+            hipLaunchKernelGGL((conv_fwd_kernel<BM, 3, 3, true>), grid, dim3(kThreads), 0, st, x, w, ep, y, g);
         else if (g.R == 1 && g.S == 1)
-            hipLaunchKernelGGL((conv_fwd_kernel<BM, 1, 1, true>), grid, dim3(kThreads), 0, st, x, w, b, y, g, relu);
+            hipLaunchKernelGGL((conv_fwd_kernel<BM, 1, 1, true>), grid, dim3(kThreads), 0, st, x, w, ep, y, g);
         else
-            hipLaunchKernelGGL((conv_fwd_kernel<BM, 0, 0, true>), grid, dim3(kThreads), 0, st, x, w, b, y, g, relu);
+            hipLaunchKernelGGL((conv_fwd_kernel<BM, 0, 0, true>), grid, dim3(kThreads), 0, st, x, w, ep, y, g);
         return;
     }
     if (g.R == 3 && g.S == 3)
-        hipLaunchKernelGGL((conv_fwd_kernel<BM, 3, 3, false>), grid, dim3(kThreads), 0, st, x, w, b, y, g, relu);
+        hipLaunchKernelGGL((conv_fwd_kernel<BM, 3, 3, false>), grid, dim3(kThreads), 0, st, x, w, ep, y, g);
     else if (g.R == 7 && g.S == 7)
-        hipLaunchKernelGGL((conv_fwd_kernel<BM, 7, 7, false>), grid, dim3(kThreads), 0, st, x, w, b, y, g, relu);
+        hipLaunchKernelGGL((conv_fwd_kernel<BM, 7, 7, false>), grid, dim3(kThreads), 0, st, x, w, ep, y, g);
     else
-        hipLaunchKernelGGL((conv_fwd_kernel<BM, 0, 0, false>), grid, dim3(kThreads), 0, st, x, w, b, y, g, relu);
+        hipLaunchKernelGGL((conv_fwd_kernel<BM, 0, 0, false>), grid, dim3(kThreads), 0, st, x, w, ep, y, g);
 }
 
 template <int BM>
@@ -489,13 +499,97 @@ void launch_wgrad(const ConvGeom &g, const float *x, const float *dy, float *dw,
         hipLaunchKernelGGL((conv_wgrad_kernel<BM, 0, 0, false>), grid, dim3(kThreads), 0, st, x, dy, dw, g, p_per_split);
 }
 
+// -------------------------------------------------------------------------------------
+// Backward of the fused epilogue  y = act(z*scale + shift [+ residual]),  z = conv output:
+//   g  = dy * (y > 0)            (relu)   or dy
+//   dz = g * scale[c]            -> feeds dgrad / wgrad
+//   dshift[c] = sum g            (= d beta; the conv-bias gradient is dshift*scale)
+//   dgamma[c] = sum g * (y - beta[c]) / gamma[c]      (x_hat recovered from y where g != 0)
+// One pass over dy and y; one workgroup per (channel, image chunk); fp32 atomics for the sums.
+// -------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bn_act_bwd_kernel(const float *__restrict__ dy,
+                                                         const float *__restrict__ y,
+                                                         const float *__restrict__ scale,
+                                                         const float *__restrict__ gamma,
+                                                         const float *__restrict__ beta,
+                                                         const float *__restrict__ residual, int N, int C,
+                                                         int HW, int relu,
+                                                         float *__restrict__ dz, float *__restrict__ g_out,
+                                                         float *__restrict__ dshift,
+                                                         float *__restrict__ dgamma, int imgs_per_block)
+{
+    __shared__ float s_a[4], s_b[4];
+    const int c = blockIdx.x;
+    const int n0 = blockIdx.y * imgs_per_block;
+    const int n1 = min(N, n0 + imgs_per_block);
+    const float sc = scale[c];
+    const float be = beta ? beta[c] : 0.0f;
+    float sum_g = 0.0f, sum_gy = 0.0f;
+    const bool vec = (HW & 3) == 0;
+    for (int n = n0; n < n1; ++n) {
+        const size_t base = ((size_t)n * C + c) * HW;
+        if (vec) {
+            for (int i = threadIdx.x * 4; i < HW; i += 1024) {
+                const float4 d = *reinterpret_cast<const float4 *>(dy + base + i);
+                float4 v = *reinterpret_cast<const float4 *>(y + base + i);
+                float4 g;
+                g.x = (!relu || v.x > 0.0f) ? d.x : 0.0f;
+                g.y = (!relu || v.y > 0.0f) ? d.y : 0.0f;
+                g.z = (!relu || v.z > 0.0f) ? d.z : 0.0f;
+                g.w = (!relu || v.w > 0.0f) ? d.w : 0.0f;
+                if (residual) {   // BN output = y - shortcut wherever the gradient is non-zero
+                    const float4 r = *reinterpret_cast<const float4 *>(residual + base + i);
+                    v.x -= r.x; v.y -= r.y; v.z -= r.z; v.w -= r.w;
+                }
+                sum_g += (g.x + g.y) + (g.z + g.w);
+                sum_gy += (g.x * (v.x - be) + g.y * (v.y - be)) + (g.z * (v.z - be) + g.w * (v.w - be));
+                if (g_out) *reinterpret_cast<float4 *>(g_out + base + i) = g;
+                float4 o;
+                o.x = g.x * sc; o.y = g.y * sc; o.z = g.z * sc; o.w = g.w * sc;
+                *reinterpret_cast<float4 *>(dz + base + i) = o;
+            }
+        } else {
+            for (int i = threadIdx.x; i < HW; i += 256) {
+                const float d = dy[base + i], v = y[base + i];
+                const float g = (!relu || v > 0.0f) ? d : 0.0f;
+                const float vb = residual ? (v - residual[base + i]) : v;
+                sum_g += g;
+                sum_gy += g * (vb - be);
+                if (g_out) g_out[base + i] = g;
+                dz[base + i] = g * sc;
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        sum_g += __shfl_xor(sum_g, off, 64);
+        sum_gy += __shfl_xor(sum_gy, off, 64);
+    }
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        s_a[wave] = sum_g;
+        s_b[wave] = sum_gy;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float a = (s_a[0] + s_a[1]) + (s_a[2] + s_a[3]);
+        const float b = (s_b[0] + s_b[1]) + (s_b[2] + s_b[3]);
+        atomicAdd(dshift + c, a);
+        if (dgamma) {
+            const float ga = gamma[c];
+            atomicAdd(dgamma + c, ga != 0.0f ? b / ga : 0.0f);
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" {
 
-int fi_conv2d_forward(const float *x, const float *weight, const float *bias, float *y, int N,
-                      int Cin, int H, int W, int Cout, int R, int S, int stride_h, int stride_w,
-                      int pad_h, int pad_w, int relu, int weight_layout, fi_stream_t stream)
+int fi_conv2d_forward(const float *x, const float *weight, const float *bias, const float *scale,
+                      const float *residual, float *y, int N, int Cin, int H, int W, int Cout, int R,
+                      int S, int stride_h, int stride_w, int pad_h, int pad_w, int relu,
+                      int weight_layout, fi_stream_t stream)
 {
     ConvGeom g;
     int rc = make_geom(g, N, Cin, H, W, Cout, R, S, stride_h, stride_w, pad_h, pad_w);
@@ -506,11 +600,35 @@ int fi_conv2d_forward(const float *x, const float *weight, const float *bias, fl
     const bool hwc = (Cin % BK == 0) && (R * S <= 64) && (weight_layout == 1 || R * S == 1);
     FI_REQUIRE(hwc || weight_layout == 0, "weight_layout 1 needs Cin % 16 == 0 and R*S <= 64");
     hipStream_t st = (hipStream_t)stream;
+    const Epilogue ep = {bias, scale, residual, relu};
     fi::ProfScope prof(FI_K_CONV_FWD + (Cout <= 64 ? 0 : 4) + window_class(R, S), st);
     if (Cout <= 64)
-        launch_fwd<64>(g, x, weight, bias, y, relu, hwc, st);
+        launch_fwd<64>(g, x, weight, ep, y, hwc, st);
     else
-        launch_fwd<128>(g, x, weight, bias, y, relu, hwc, st);
+        launch_fwd<128>(g, x, weight, ep, y, hwc, st);
+    FI_HIP_CHECK(hipGetLastError());
+    return FI_OK;
+}
+
+int fi_bn_act_backward(const float *dy, const float *y, const float *scale, const float *gamma,
+                       const float *beta, const float *residual, int N, int C, int HW, int relu,
+                       float *dz, float *g_out, float *dshift, float *dgamma, fi_stream_t stream)
+{
+    FI_REQUIRE(N >= 1 && C >= 1 && HW >= 1, "sizes must be positive");
+    FI_REQUIRE(dy && y && scale && dz && dshift, "null pointer");
+    FI_REQUIRE(!dgamma || gamma, "dgamma needs gamma");
+    hipStream_t st = (hipStream_t)stream;
+    FI_HIP_CHECK(hipMemsetAsync(dshift, 0, sizeof(float) * C, st));
+    if (dgamma) FI_HIP_CHECK(hipMemsetAsync(dgamma, 0, sizeof(float) * C, st));
+    // enough workgroups to fill the chip: C * chunks >= ~2048
+    int chunks = fi::ceil_div(2048, C);
+    if (chunks > N) chunks = N;
+    if (chunks < 1) chunks = 1;
+    const int ipb = fi::ceil_div(N, chunks);
+    chunks = fi::ceil_div(N, ipb);
+    fi::ProfScope prof(FI_K_BN_ACT_BWD, st);
+    hipLaunchKernelGGL(bn_act_bwd_kernel, dim3(C, chunks), dim3(256), 0, st, dy, y, scale, gamma, beta, residual,
+                       N, C, HW, relu, dz, g_out, dshift, dgamma, ipb);
     FI_HIP_CHECK(hipGetLastError());
     return FI_OK;
 }

@@ -15,7 +15,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .conv import Conv2d, ConvTranspose2x2
+from .conv import Conv2d, ConvTranspose2x2, conv_bn_act
 from .intertwiner import class_mean, roi_level
 from .roi_align.crop_and_resize import CropAndResizeFunction, pyramid_crop_and_resize
 from .roi_pooling.functions.roi_pool import RoIPoolFunction
@@ -69,14 +69,13 @@ class Bottleneck(nn.Module):
         self.stride = stride
 
     def forward(self, x):
+        # conv + eval-BN (+ shortcut) + ReLU are one kernel launch each (conv.conv_bn_act)
+        out = conv_bn_act(x, self.conv1, self.bn1, relu=True)
+        out = conv_bn_act(out, self.conv2, self.bn2, relu=True)
         residual = x
-        out = self.relu(self.bn1(self.conv1(x)))
-        out = self.relu(self.bn2(self.conv2(out)))
-        out = self.bn3(self.conv3(out))
         if self.downsample is not None:
-            residual = self.downsample(x)
-        out = out + residual
-        return self.relu(out)
+            residual = conv_bn_act(x, self.downsample[0], self.downsample[1], relu=False)
+        return conv_bn_act(out, self.conv3, self.bn3, relu=True, residual=residual)
 
 
 class ResNet(nn.Module):
@@ -149,7 +148,8 @@ class FPN(nn.Module):
     def forward(self, x, mode='train'):
         bs = x.size(0)
         ot_loss = x.new_zeros(bs, 3)
-        x = self.C1(x)
+        x = conv_bn_act(x, self.C1[0], self.C1[1], relu=True)       # C1 = conv, bn, relu, pad, maxpool
+        x = self.C1[4](self.C1[3](x))
         c2 = self.C2(x)
         c3 = self.C3(c2)
         c4 = self.C4(c3)
@@ -248,6 +248,13 @@ class Dev(nn.Module):
                 elif config.DEV.LOSS_CHOICE == 'kl':
                     self.last_op = nn.Softmax(dim=1)
 
+    def _feat_extract(self, v):
+        fe = self.feat_extract
+        v = conv_bn_act(v, fe[0], fe[1], relu=True)
+        for i in range(3, len(fe)):
+            v = fe[i](v)
+        return v
+
     @staticmethod
     def _find_big_box2(level, roi_lvl):
         """RoIs that act as 'big' supervision at pyramid level `level` (:366-378)."""
@@ -286,7 +293,12 @@ class Dev(nn.Module):
 
         train_phase = roi_cls_gt is not None
         # make-up layer on every level, then ONE launch per crop size over all levels
-        up_maps = [self.upsample[i if cfg.DEV.MULTI_UPSAMPLER else 0](m) for i, m in enumerate(x)]
+        def make_up(i, m):
+            seq = self.upsample[i if cfg.DEV.MULTI_UPSAMPLER else 0]
+            if isinstance(seq[0], Conv2d):
+                return conv_bn_act(m, seq[0], seq[1], relu=True)
+            return seq(m)
+        up_maps = [make_up(i, m) for i, m in enumerate(x)]
         pooled = self._crop(up_maps, boxes, box_ind, level, self.pool_size)
         mask_and_feat = self._crop(up_maps, boxes, box_ind, level, self.mask_pool_size)
         if cfg.DEV.BASELINE:
@@ -297,7 +309,7 @@ class Dev(nn.Module):
         meta_lvl = level <= 4
         small_rows = torch.nonzero(meta_lvl).view(-1)
         order = small_rows[torch.sort(level[small_rows], stable=True)[1]]
-        small_output = self.feat_extract(mask_and_feat[order])
+        small_output = self._feat_extract(mask_and_feat[order])
         if cfg.DEV.LOSS_CHOICE != 'ot':
             small_output = self.last_op(small_output)
         small_output = small_output.view(order.numel(), -1)
@@ -330,7 +342,7 @@ class Dev(nn.Module):
         with torch.set_grad_enabled(not cfg.DEV.BIG_FEAT_DETACH):
             if big_idx.numel():
                 big_pooled = self._crop(x, boxes[big_idx], box_ind[big_idx], big_level, self.feat_pool_size)
-                big_out = self.feat_extract(big_pooled)
+                big_out = self._feat_extract(big_pooled)
                 if cfg.DEV.LOSS_CHOICE != 'ot':
                     big_out = self.last_op(big_out)
                 big_out = big_out.view(big_idx.numel(), -1)
@@ -400,9 +412,9 @@ class Mask(nn.Module):
         self.relu = nn.ReLU(inplace=True)
 
     def forward(self, x):
-        x = self.relu(self.bn1(self.conv1(x)))
-        x = self.relu(self.bn2(self.conv2(x)))
-        x = self.relu(self.bn3(self.conv3(x)))
-        x = self.relu(self.bn4(self.conv4(x)))
+        x = conv_bn_act(x, self.conv1, self.bn1, relu=True)
+        x = conv_bn_act(x, self.conv2, self.bn2, relu=True)
+        x = conv_bn_act(x, self.conv3, self.bn3, relu=True)
+        x = conv_bn_act(x, self.conv4, self.bn4, relu=True)
         x = self.relu(self.deconv(x))
         return self.sigmoid(self.conv5(x))

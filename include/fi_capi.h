@@ -204,7 +204,10 @@ int fi_class_mean_backward(const float *grad_feat, const int32_t *gt,
  * Dev make-up layer / mask head (lib/sub_module.py:38-128, 147-228, 234-280, 308-345,
  * 750-787); the reference has no native code of its own for them.
  * x [N,Cin,H,W], weight [Cout,Cin,R,S], bias [Cout] or NULL, y [N,Cout,OH,OW] with
- * OH = (H + 2*pad_h - R)/stride_h + 1.  relu != 0 fuses max(.,0) into the epilogue.
+ * OH = (H + 2*pad_h - R)/stride_h + 1.  Epilogue: y = acc*scale[c] + bias[c] (+ residual) then
+ * max(.,0) if relu; scale [Cout] and residual [N,Cout,OH,OW] may be NULL.  With scale = gamma /
+ * sqrt(var+eps) and bias = beta + (conv_bias - mean)*scale this is conv + eval-mode BatchNorm
+ * (the reference always evaluates BN with running statistics) + shortcut + ReLU.
  * weight_layout 0: weight is [Cout,Cin,R,S] (as stored by the model); 1: [Cout,R,S,Cin]
  * (tap-major / channels-last; needs Cin % 16 == 0) -- selects the fast gather path.
  * The data gradient of a stride-1 convolution is this same call on dY with the flipped,
@@ -213,10 +216,17 @@ int fi_class_mean_backward(const float *grad_feat, const int32_t *gt,
  * dy (x) patches(x); zero-filled by the call, accumulated with fp32 atomics over a split
  * of the pixel range.  weight_layout 1 writes dweight as [Cout,R,S,Cin] (needs Cin % 128 == 0).
  * ---------------------------------------------------------------------- */
-int fi_conv2d_forward(const float *x, const float *weight, const float *bias, float *y,
-                      int N, int Cin, int H, int W, int Cout, int R, int S, int stride_h,
-                      int stride_w, int pad_h, int pad_w, int relu, int weight_layout,
-                      fi_stream_t stream);
+int fi_conv2d_forward(const float *x, const float *weight, const float *bias,
+                      const float *scale, const float *residual, float *y, int N, int Cin,
+                      int H, int W, int Cout, int R, int S, int stride_h, int stride_w,
+                      int pad_h, int pad_w, int relu, int weight_layout, fi_stream_t stream);
+/* Backward of that fused epilogue (eval-mode BatchNorm folded into scale/shift, optional ReLU):
+ * g = dy * (y > 0 | 1); dz = g * scale[c]; dshift[c] = sum g; dgamma[c] = sum g*(y-beta[c])/gamma[c].
+ * dy, y, dz, g_out are [N,C,HW]; g_out (optional) receives g (the gradient of a fused residual);
+ * residual (optional) is the shortcut that was added in the epilogue (y - residual = BN output). */
+int fi_bn_act_backward(const float *dy, const float *y, const float *scale, const float *gamma,
+                       const float *beta, const float *residual, int N, int C, int HW, int relu,
+                       float *dz, float *g_out, float *dshift, float *dgamma, fi_stream_t stream);
 int fi_conv2d_weight_grad(const float *x, const float *dy, float *dweight, int N, int Cin,
                           int H, int W, int Cout, int R, int S, int stride_h, int stride_w,
                           int pad_h, int pad_w, int weight_layout, fi_stream_t stream);
@@ -247,7 +257,8 @@ enum {
      * conv_fwd_kernel serves the forward pass and the stride-1 data gradient */
     FI_K_CONV_FWD = 14,      /* .. 21 */
     FI_K_CONV_WGRAD = 22,    /* .. 29 */
-    FI_K_COUNT = 30
+    FI_K_BN_ACT_BWD = 30,
+    FI_K_COUNT = 31
 };
 void fi_prof_enable(int on);
 void fi_prof_reset(void);

@@ -95,3 +95,41 @@ def test_relu_epilogue_and_large_shape_property():
     y2 = _conv_fwd(x2, w, None, (1, 1), (1, 1))
     y12 = _conv_fwd(x + x2, w, b, (1, 1), (1, 1))
     assert torch.allclose(y12, y + y2, rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize("relu,res", [(True, False), (False, False), (True, True)])
+def test_fused_conv_bn_act_matches_separate_ops(relu, res):
+    """conv_bn_act (one launch: conv + eval-BN + shortcut + ReLU, fused backward) vs torch modules."""
+    from feature_intertwiner_amd.conv import Conv2d, conv_bn_act
+    torch.manual_seed(3)
+    conv = Conv2d(32, 48, 3, stride=1, padding=1).to(DEV)
+    bn = torch.nn.BatchNorm2d(48, eps=0.001).to(DEV).eval()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5); bn.bias.normal_(0, 0.3)
+        bn.running_mean.normal_(0, 0.2); bn.running_var.uniform_(0.5, 2.0)
+    rconv = torch.nn.Conv2d(32, 48, 3, stride=1, padding=1).double()
+    rbn = torch.nn.BatchNorm2d(48, eps=0.001).double().eval()
+    rconv.load_state_dict({k: v.cpu().double() for k, v in conv.state_dict().items()})
+    rbn.load_state_dict({k: v.cpu().double() if v.dtype.is_floating_point else v.cpu() for k, v in bn.state_dict().items()})
+    x = torch.randn(3, 32, 12, 10)
+    r = torch.randn(3, 48, 12, 10)
+    xg = x.to(DEV).requires_grad_(True)
+    rg = r.to(DEV).requires_grad_(True) if res else None
+    y = conv_bn_act(xg, conv, bn, relu=relu, residual=rg)
+    xd = x.double().requires_grad_(True)
+    rd = r.double().requires_grad_(True) if res else None
+    yd = rbn(rconv(xd))
+    if res:
+        yd = yd + rd
+    if relu:
+        yd = torch.relu(yd)
+    assert torch.allclose(y.detach().cpu().double(), yd.detach(), rtol=1e-4, atol=1e-4)
+    gy = torch.randn(yd.shape)
+    y.backward(gy.to(DEV))
+    yd.backward(gy.double())
+    pairs = [(xg.grad, xd.grad), (conv.weight.grad, rconv.weight.grad), (conv.bias.grad, rconv.bias.grad),
+             (bn.weight.grad, rbn.weight.grad), (bn.bias.grad, rbn.bias.grad)]
+    if res:
+        pairs.append((rg.grad, rd.grad))
+    for a, b in pairs:
+        assert torch.allclose(a.cpu().double(), b, rtol=2e-4, atol=2e-4), (a.shape,)

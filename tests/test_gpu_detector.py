@@ -100,7 +100,8 @@ def test_dev_stage_matches_per_level_restatement(oracle):
     cls = torch.randint(0, 81, (2, 64), device=DEV, dtype=torch.int32)
     with torch.no_grad():
         pooled, mask, feat_out = dev(maps, rois, cls)
-        up = [dev.upsample[0](m).cpu().numpy() for m in maps]
+        from feature_intertwiner_amd.conv import conv_bn_act
+        up = [conv_bn_act(m, dev.upsample[0][0], dev.upsample[0][1], relu=True).cpu().numpy() for m in maps]
     level = oracle.roi_level(rois_np.reshape(-1, 4), 256 * 256)
     ind = np.repeat(np.arange(2, dtype=np.int32), 64)
     for size, got in ((7, pooled), (14, mask)):
