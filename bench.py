@@ -146,11 +146,19 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    # FI_BENCH_SHARE_GPU=1 (testing only): all ranks share cuda:0 over the gloo backend, to exercise
+    # the multi-process code path on a single-GPU box; the real launch is one rank per GPU over RCCL
+    share = os.environ.get("FI_BENCH_SHARE_GPU") == "1"
+    if share:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if share:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from feature_intertwiner_amd import _lib
     from feature_intertwiner_amd.config import make_config

@@ -30,6 +30,7 @@ namespace {
 constexpr int kThreads = 256;
 constexpr int kMaxCrop = 64;   // LDS table entries per axis
 constexpr int kMaxLevels = 8;
+constexpr int kTileFloats = 8192;   // 32 KB LDS accumulation tile of the backward kernel
 
 // <2 x float> that may sit at any 4-byte boundary: lowers to one global_load_dwordx2
 typedef float pair_f32 __attribute__((ext_vector_type(2)));
@@ -254,6 +255,66 @@ __global__ __launch_bounds__(kThreads) void crop_bwd_kernel(
     float *__restrict__ dst = ls.img[h.lvl] + ((size_t)h.img * depth + c_begin) * plane;
     const float *__restrict__ g = grads + ((size_t)box * depth + c_begin) * bins;
     const int W = h.W;
+
+    // ---- LDS path: when the RoI's footprint on the map is small, the 4*bins scattered adds of a
+    // channel are first combined in an LDS tile (ds_add_f32) and each touched cell is then sent to
+    // memory ONCE, as row-contiguous atomics (a few L2 line operations per row instead of one per
+    // tap).  Falls through to direct global atomics for large footprints.
+    __shared__ float s_tile[kTileFloats];
+    int ymin = 1 << 30, ymax = -1, xmin = 1 << 30, xmax = -1;
+    for (int i = 0; i < crop_h; ++i) {
+        const Tap t = s_ty[i];
+        if (t.valid) { ymin = min(ymin, t.i0); ymax = max(ymax, t.i1); }
+    }
+    for (int i = 0; i < crop_w; ++i) {
+        const Tap t = s_tx[i];
+        if (t.valid) { xmin = min(xmin, t.i0); xmax = max(xmax, t.i1); }
+    }
+    if (ymax < 0 || xmax < 0) return;                 // nothing of this RoI is inside the map
+    const int fh = ymax - ymin + 1, fw = xmax - xmin + 1;
+    const int cells = fh * fw;
+    if (cells <= kTileFloats && cells * 2 < 4 * bins) {
+        const int G = min(c_count, kTileFloats / cells);   // channels per LDS pass
+        for (int cg = 0; cg < c_count; cg += G) {
+            const int gc = min(G, c_count - cg);
+            for (int i = tid; i < gc * cells; i += kThreads) s_tile[i] = 0.0f;
+            __syncthreads();
+            for (int idx = tid; idx < gc * bins; idx += kThreads) {
+                const int c = idx / bins;
+                const int bin = idx - c * bins;
+                const int y = bin / crop_w;
+                const int x = bin - y * crop_w;
+                const Tap ty = s_ty[y];
+                const Tap tx = s_tx[x];
+                if (!(ty.valid & tx.valid)) continue;
+                const float gv = g[(size_t)(cg + c) * bins + bin];
+                float *t = s_tile + c * cells;
+                const float wy0 = 1.0f - ty.frac;
+                const float wx0 = 1.0f - tx.frac;
+                const float gtop = wy0 * gv;
+                const float gbot = ty.frac * gv;
+                const int r0 = (ty.i0 - ymin) * fw, r1 = (ty.i1 - ymin) * fw;
+                const int c0 = tx.i0 - xmin, c1 = tx.i1 - xmin;
+                atomicAdd(t + r0 + c0, wx0 * gtop);
+                atomicAdd(t + r0 + c1, tx.frac * gtop);
+                atomicAdd(t + r1 + c0, wx0 * gbot);
+                atomicAdd(t + r1 + c1, tx.frac * gbot);
+            }
+            __syncthreads();
+            for (int i = tid; i < gc * cells; i += kThreads) {
+                const float v = s_tile[i];
+                if (v != 0.0f) {
+                    const int c = i / cells;
+                    const int rem = i - c * cells;
+                    const int r = rem / fw;
+                    const int col = rem - r * fw;
+                    atomicAdd(dst + (size_t)(cg + c) * plane + (size_t)(ymin + r) * W + (xmin + col), v);
+                }
+            }
+            __syncthreads();
+        }
+        return;
+    }
 
     for (int idx = tid; idx < total; idx += kThreads) {
         const int c = idx / bins;
