@@ -32,7 +32,7 @@ def _log_flops(kind, cout, R, S, flops):
         e[1] += flops
 
 
-def _conv_fwd(x, w, b, stride, padding, relu=False, scale=None, residual=None):
+def _conv_fwd(x, w, b, stride, padding, relu=False, scale=None, residual=None, out_hw=None):
     """w is [Cout, Cin, R, S].  When Cin % 16 == 0 the kernel's tap-major fast path is used: the
     weight is handed over channels-last ([Cout, R, S, Cin]; a copy of at most a few MB)."""
     L = _lib.load()
@@ -45,13 +45,16 @@ def _conv_fwd(x, w, b, stride, padding, relu=False, scale=None, residual=None):
             w = w.permute(0, 2, 3, 1).contiguous()
     OH = (H + 2 * padding[0] - R) // stride[0] + 1
     OW = (W + 2 * padding[1] - S) // stride[1] + 1
+    if out_hw is not None:
+        OH, OW = out_hw
     _log_flops("fwd", Cout, R, S, 2 * N * Cout * OH * OW * Cin * R * S)
     y = torch.empty((N, Cout, OH, OW), device=x.device, dtype=torch.float32)
     with torch.cuda.device(x.device):
         _lib.check(L.fi_conv2d_forward(_lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(scale), _lib.ptr(residual),
                                        _lib.ptr(y), N, Cin, H, W, Cout,
                                        R, S, stride[0], stride[1], padding[0], padding[1], 1 if relu else 0,
-                                       layout, _lib.current_stream()), "fi_conv2d_forward")
+                                       layout, OH if out_hw is not None else 0, OW if out_hw is not None else 0,
+                                       _lib.current_stream()), "fi_conv2d_forward")
     return y
 
 
@@ -76,6 +79,42 @@ class _Conv2dFn(torch.autograd.Function):
         return dx, dw, db, None, None
 
 
+def _class_taps(a, size_k, s, p):
+    """Taps of a stride-s convolution that reach input positions ih = s*q + a:
+    r = r0 + s*t (t < T); the output index is q + c0 - t."""
+    r0 = (a + p) % s
+    T = 0 if r0 >= size_k else (size_k - r0 + s - 1) // s
+    c0 = (a + p - r0) // s
+    return r0, T, c0
+
+
+def _strided_dgrad(dz, w, in_hw, stride, padding):
+    """Data gradient of a strided convolution WITHOUT zero-stuffing: the input positions split into
+    stride_h*stride_w residue classes; each class is a stride-1 correlation of dz with the sub-kernel
+    of the taps that reach it (e.g. 3x3/stride 2/pad 1: 1, 2, 2 and 4 taps instead of 9 everywhere)."""
+    N, Cout = dz.shape[0], dz.shape[1]
+    Cin, R, S = w.shape[1], w.shape[2], w.shape[3]
+    H, W = in_hw
+    sh, sw = stride
+    dx = dz.new_zeros(N, Cin, H, W)
+    for a in range(min(sh, H)):
+        r0, Th, ch0 = _class_taps(a, R, sh, padding[0])
+        qa = (H - a + sh - 1) // sh
+        for b in range(min(sw, W)):
+            s0, Tw, cw0 = _class_taps(b, S, sw, padding[1])
+            qb = (W - b + sw - 1) // sw
+            if Th == 0 or Tw == 0:
+                continue
+            pad_h, pad_w = Th - 1 - ch0, Tw - 1 - cw0
+            assert pad_h >= 0 and pad_w >= 0, "unsupported stride/padding combination"
+            rows = [r0 + sh * (Th - 1 - u) for u in range(Th)]
+            cols = [s0 + sw * (Tw - 1 - u) for u in range(Tw)]
+            k = w[:, :, rows][:, :, :, cols].transpose(0, 1).contiguous()      # [Cin, Cout, Th, Tw]
+            out = _conv_fwd(dz, k, None, (1, 1), (pad_h, pad_w), out_hw=(qa, qb))
+            dx[:, :, a::sh, b::sw] = out
+    return dx
+
+
 def _conv_backward(ctx_needs, x, w, dz, stride, padding):
     """dX and dW of z = conv(x, w) given dz (shared by the plain and the fused functions)."""
     L = _lib.load()
@@ -87,12 +126,7 @@ def _conv_backward(ctx_needs, x, w, dz, stride, padding):
         if stride == (1, 1):
             dx = _conv_fwd(dz, wt, None, (1, 1), (R - 1 - padding[0], S - 1 - padding[1]))
         else:
-            OH, OW = dz.shape[2], dz.shape[3]
-            rem_h = (H + 2 * padding[0] - R) % stride[0]
-            rem_w = (W + 2 * padding[1] - S) % stride[1]
-            up = dz.new_zeros(N, Cout, (OH - 1) * stride[0] + 1 + rem_h, (OW - 1) * stride[1] + 1 + rem_w)
-            up[:, :, :(OH - 1) * stride[0] + 1:stride[0], :(OW - 1) * stride[1] + 1:stride[1]] = dz
-            dx = _conv_fwd(up, wt, None, (1, 1), (R - 1 - padding[0], S - 1 - padding[1]))
+            dx = _strided_dgrad(dz, w, (H, W), stride, padding)
     if ctx_needs[1]:
         hwc = 1 if (Cin % 128 == 0) else 0         # tap-major fast path of the kernel
         dw = torch.empty((Cout, R, S, Cin) if (hwc and R * S > 1) else (Cout, Cin, R, S), device=x.device,

@@ -421,14 +421,14 @@ int window_class(int R, int S)
 }
 
 int make_geom(ConvGeom &g, int N, int Cin, int H, int W, int Cout, int R, int S, int sh, int sw,
-              int ph, int pw)
+              int ph, int pw, int out_h = 0, int out_w = 0)
 {
     FI_REQUIRE(N >= 1 && Cin >= 1 && H >= 1 && W >= 1 && Cout >= 1, "sizes must be positive");
     FI_REQUIRE(R >= 1 && S >= 1 && sh >= 1 && sw >= 1 && ph >= 0 && pw >= 0, "bad window");
     g.N = N; g.Cin = Cin; g.H = H; g.W = W; g.Cout = Cout; g.R = R; g.S = S;
     g.sh = sh; g.sw = sw; g.ph = ph; g.pw = pw;
-    g.OH = (H + 2 * ph - R) / sh + 1;
-    g.OW = (W + 2 * pw - S) / sw + 1;
+    g.OH = out_h > 0 ? out_h : (H + 2 * ph - R) / sh + 1;   // explicit size: taps past the input read zeros
+    g.OW = out_w > 0 ? out_w : (W + 2 * pw - S) / sw + 1;
     FI_REQUIRE(g.OH >= 1 && g.OW >= 1, "empty output");
     const long K = (long)Cin * R * S, P = (long)N * g.OH * g.OW;
     FI_REQUIRE(K < 2147483647L && P < 2147483647L, "problem too large for int32 indexing");
@@ -589,10 +589,10 @@ extern "C" {
 int fi_conv2d_forward(const float *x, const float *weight, const float *bias, const float *scale,
                       const float *residual, float *y, int N, int Cin, int H, int W, int Cout, int R,
                       int S, int stride_h, int stride_w, int pad_h, int pad_w, int relu,
-                      int weight_layout, fi_stream_t stream)
+                      int weight_layout, int out_h, int out_w, fi_stream_t stream)
 {
     ConvGeom g;
-    int rc = make_geom(g, N, Cin, H, W, Cout, R, S, stride_h, stride_w, pad_h, pad_w);
+    int rc = make_geom(g, N, Cin, H, W, Cout, R, S, stride_h, stride_w, pad_h, pad_w, out_h, out_w);
     if (rc != FI_OK) return rc;
     FI_REQUIRE(x && weight && y, "null pointer");
     FI_REQUIRE(weight_layout == 0 || weight_layout == 1, "weight_layout: 0 = [Cout][Cin][R][S], 1 = [Cout][R][S][Cin]");

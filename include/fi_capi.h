@@ -208,6 +208,8 @@ int fi_class_mean_backward(const float *grad_feat, const int32_t *gt,
  * max(.,0) if relu; scale [Cout] and residual [N,Cout,OH,OW] may be NULL.  With scale = gamma /
  * sqrt(var+eps) and bias = beta + (conv_bias - mean)*scale this is conv + eval-mode BatchNorm
  * (the reference always evaluates BN with running statistics) + shortcut + ReLU.
+ * out_h/out_w > 0 override the output size (window taps that fall outside the input read
+ * zeros) -- used by the strided data gradient, which is a set of stride-1 correlations.
  * weight_layout 0: weight is [Cout,Cin,R,S] (as stored by the model); 1: [Cout,R,S,Cin]
  * (tap-major / channels-last; needs Cin % 16 == 0) -- selects the fast gather path.
  * The data gradient of a stride-1 convolution is this same call on dY with the flipped,
@@ -219,7 +221,8 @@ int fi_class_mean_backward(const float *grad_feat, const int32_t *gt,
 int fi_conv2d_forward(const float *x, const float *weight, const float *bias,
                       const float *scale, const float *residual, float *y, int N, int Cin,
                       int H, int W, int Cout, int R, int S, int stride_h, int stride_w,
-                      int pad_h, int pad_w, int relu, int weight_layout, fi_stream_t stream);
+                      int pad_h, int pad_w, int relu, int weight_layout, int out_h, int out_w,
+                      fi_stream_t stream);
 /* Backward of that fused epilogue (eval-mode BatchNorm folded into scale/shift, optional ReLU):
  * g = dy * (y > 0 | 1); dz = g * scale[c]; dshift[c] = sum g; dgamma[c] = sum g*(y-beta[c])/gamma[c].
  * dy, y, dz, g_out are [N,C,HW]; g_out (optional) receives g (the gradient of a fused residual);
