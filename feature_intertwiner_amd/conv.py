@@ -24,9 +24,9 @@ from . import _lib
 FLOP_LOG = None
 
 
-def _log_flops(kind, cout, R, S, flops):
+def _log_flops(kind, cout, R, S, flops, pixels=None):
     if FLOP_LOG is not None:
-        k = _lib.conv_kernel_key(kind, cout, R, S)
+        k = _lib.conv_kernel_key(kind, cout, R, S, pixels)
         e = FLOP_LOG.setdefault(k, [0, 0])
         e[0] += 1
         e[1] += flops
@@ -47,7 +47,7 @@ def _conv_fwd(x, w, b, stride, padding, relu=False, scale=None, residual=None, o
     OW = (W + 2 * padding[1] - S) // stride[1] + 1
     if out_hw is not None:
         OH, OW = out_hw
-    _log_flops("fwd", Cout, R, S, 2 * N * Cout * OH * OW * Cin * R * S)
+    _log_flops("fwd", Cout, R, S, 2 * N * Cout * OH * OW * Cin * R * S, N * OH * OW)
     y = torch.empty((N, Cout, OH, OW), device=x.device, dtype=torch.float32)
     with torch.cuda.device(x.device):
         _lib.check(L.fi_conv2d_forward(_lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(scale), _lib.ptr(residual),

@@ -412,6 +412,15 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(const float *__res
     }
 }
 
+// 64-row tiles for narrow layers, and for grids that would leave the chip under-filled with
+// 128-row tiles (fewer than 2 workgroups per CU): C4/C5 of the backbone at batch 4.
+bool use_bm64(int Cout, int P)
+{
+    if (Cout <= 64) return true;
+    const long tiles128 = (long)fi::ceil_div(P, BN) * fi::ceil_div(Cout, 128);
+    return tiles128 < 512;
+}
+
 int window_class(int R, int S)
 {
     if (R == 1 && S == 1) return 0;
@@ -601,8 +610,9 @@ int fi_conv2d_forward(const float *x, const float *weight, const float *bias, co
     FI_REQUIRE(hwc || weight_layout == 0, "weight_layout 1 needs Cin % 16 == 0 and R*S <= 64");
     hipStream_t st = (hipStream_t)stream;
     const Epilogue ep = {bias, scale, residual, relu};
-    fi::ProfScope prof(FI_K_CONV_FWD + (Cout <= 64 ? 0 : 4) + window_class(R, S), st);
-    if (Cout <= 64)
+    const bool bm64 = use_bm64(Cout, g.P);
+    fi::ProfScope prof(FI_K_CONV_FWD + (bm64 ? 0 : 4) + window_class(R, S), st);
+    if (bm64)
         launch_fwd<64>(g, x, weight, ep, y, hwc, st);
     else
         launch_fwd<128>(g, x, weight, ep, y, hwc, st);
