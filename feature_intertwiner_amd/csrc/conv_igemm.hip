@@ -508,7 +508,9 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(const float *__res
     const int h_r = b_r[0], h_s = b_s[0];
     const int h_stride = W_COLS * HW;
 
+    // as in the forward kernel: loaded values stay untouched until store_tiles(); zeroing is a mask
     float a_reg[A_LOADS], b_reg[B_LOADS];
+    unsigned a_mask = 0, b_mask = 0;
     auto load_tiles = [&](int pt) {
         // pixel handled by this thread in this step (same for the A and B loaders: ap == bp)
         const int p = pt + ap;
@@ -523,8 +525,8 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(const float *__res
         for (int i = 0; i < A_LOADS; ++i) {
             const int m = m0 + am + W_COLS * i;
             const bool inm = ok && m < g.Cout;
-            const float t = dyn[inm ? m * OHW : 0];
-            a_reg[i] = inm ? t : 0.0f;
+            a_reg[i] = dyn[inm ? m * OHW : 0];
+            a_mask = (i == 0 ? 0u : a_mask) | (inm ? (1u << i) : 0u);
         }
         const int ih0 = oh * g.sh - g.ph, iw0 = ow * g.sw - g.pw;
         const float *__restrict__ xn = x + (size_t)n * g.Cin * HW;
@@ -534,25 +536,24 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(const float *__res
             const int base = inb ? (pix_off + b_off[0]) : 0;
             const int stride = inb ? h_stride : 0;
 #pragma unroll
-            for (int i = 0; i < B_LOADS; ++i) {
-                const float t = xn[base + i * stride];
-                b_reg[i] = inb ? t : 0.0f;
-            }
+            for (int i = 0; i < B_LOADS; ++i) b_reg[i] = xn[base + i * stride];
+            b_mask = inb ? 0xffffffffu : 0u;
             return;
         }
+        b_mask = 0;
 #pragma unroll
         for (int i = 0; i < B_LOADS; ++i) {
             const bool inb = ok && b_ok[i] && ((unsigned)(ih0 + b_r[i]) < (unsigned)g.H) &&
                              ((unsigned)(iw0 + b_s[i]) < (unsigned)g.W);
-            const float t = xn[inb ? (pix_off + b_off[i]) : 0];
-            b_reg[i] = inb ? t : 0.0f;
+            b_reg[i] = xn[inb ? (pix_off + b_off[i]) : 0];
+            b_mask |= inb ? (1u << i) : 0u;
         }
     };
     auto store_tiles = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < A_LOADS; ++i) As[buf][ap][am + W_COLS * i] = a_reg[i];
+        for (int i = 0; i < A_LOADS; ++i) As[buf][ap][am + W_COLS * i] = ((a_mask >> i) & 1u) ? a_reg[i] : 0.0f;
 #pragma unroll
-        for (int i = 0; i < B_LOADS; ++i) Bs[buf][bp][bk + W_COLS * i] = b_reg[i];
+        for (int i = 0; i < B_LOADS; ++i) Bs[buf][bp][bk + W_COLS * i] = ((b_mask >> i) & 1u) ? b_reg[i] : 0.0f;
     };
 
     f32x16 acc[MT][2];
