@@ -87,3 +87,64 @@ def training_rois(rs, batch, per_image, n_gt=20):
         bg = np.stack([by, bx, by + bh, bx + bw], 1)
         out[b] = np.clip(np.concatenate([fg, bg], 0), 0, 1)
     return out
+
+
+def filled_state(named_shapes, seed):
+    """Deterministic values for a state dict, by position: numpy legacy generator (stable across
+    versions).  Weights ~ N(0, 1/fan_in), biases small, BN statistics positive."""
+    out = {}
+    for i, (name, shape) in enumerate(named_shapes):
+        rs = np.random.RandomState(seed + i)
+        leaf = name.rsplit(".", 1)[-1]
+        if leaf == "num_batches_tracked":
+            out[name] = np.zeros(shape, np.int64)
+        elif leaf == "running_var":
+            out[name] = (1.0 + 0.2 * np.abs(rs.standard_normal(shape))).astype(np.float32)
+        elif leaf == "running_mean":
+            out[name] = (0.1 * rs.standard_normal(shape)).astype(np.float32)
+        elif len(shape) == 1 and leaf == "weight":                       # BN gamma
+            out[name] = (1.0 + 0.1 * rs.standard_normal(shape)).astype(np.float32)
+        elif leaf == "bias":
+            out[name] = (0.05 * rs.standard_normal(shape)).astype(np.float32)
+        else:
+            fan_in = int(np.prod(shape[1:])) if len(shape) > 1 else int(shape[0])
+            out[name] = (rs.standard_normal(shape) * np.sqrt(2.0 / fan_in)).astype(np.float32)
+    return out
+
+
+
+def golden_loss_inputs(seed=13):
+    """Seeded inputs for the five detector losses (shared by oracle/gen_golden_layers.py and the
+    tests, so the fixture only stores the reference's outputs)."""
+    rs = np.random.RandomState(seed)
+    B, A, R, NC = 2, 300, 24, 81
+    match = rs.choice([-1, 0, 1], size=(B, A), p=[0.3, 0.5, 0.2]).astype(np.int64)
+    rpn_logits = rs.standard_normal((B, A, 2)).astype(np.float32)
+    rpn_bbox = rs.standard_normal((B, A, 4)).astype(np.float32)
+    tgt_rpn_bbox = np.zeros((B, 256, 4), np.float32)
+    for b in range(B):
+        n = int((match[b] == 1).sum())
+        tgt_rpn_bbox[b, :n] = rs.standard_normal((n, 4))
+    cls_ids = np.zeros((B, R), np.int64)
+    cls_ids[0, :7] = rs.randint(1, NC, 7)
+    cls_ids[1, :3] = rs.randint(1, NC, 3)
+    cls_logits = rs.standard_normal((B, R, NC)).astype(np.float32)
+    tgt_bbox = (rs.standard_normal((B, R, 4)) * (cls_ids > 0)[..., None]).astype(np.float32)
+    pred_bbox = rs.standard_normal((B, R, NC, 4)).astype(np.float32)
+    tgt_masks = ((rs.uniform(size=(B, R, 28, 28)) > 0.5) * (cls_ids > 0)[..., None, None]).astype(np.float32)
+    pred_masks = rs.uniform(0.02, 0.98, (B, R, NC, 28, 28)).astype(np.float32)
+    return dict(rpn_match=match, rpn_logits=rpn_logits, rpn_bbox_pred=rpn_bbox, rpn_bbox_target=tgt_rpn_bbox,
+                cls_ids=cls_ids, cls_logits=cls_logits, bbox_target=tgt_bbox, bbox_pred=pred_bbox,
+                mask_target=tgt_masks, mask_pred=pred_masks)
+
+
+def golden_module_inputs(seed=7):
+    """Inputs of tests/golden/modules_r50_128.npz: image, 7x7 pooled RoIs, 14x14 pooled RoIs."""
+    rs = np.random.RandomState(seed)
+    image = rs.standard_normal((1, 3, 128, 128)).astype(np.float32)
+    pooled = np.maximum(rs.standard_normal((6, 256, 7, 7)), 0).astype(np.float32)
+    pooled14 = np.maximum(rs.standard_normal((3, 256, 14, 14)), 0).astype(np.float32)
+    return image, pooled, pooled14
+
+
+GOLDEN_MODULE_SEEDS = dict(fpn=100, rpn=2000, classifier=3000, mask=4000, dev=5000)
