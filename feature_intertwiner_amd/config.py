@@ -38,6 +38,8 @@ def make_config(backbone="resnet101", image_size=1024, batch_size=4, train_rois_
                BASELINE=False, BIG_SUPERVISE=False, STRUCTURE="beta", DIS_UPSAMPLER=False,
                BIG_FEAT_DETACH=True, CLS_MERGE_FEAT=False)
     c.MISC = NS(SEED=2000, GPU_COUNT=gpu_count)
+    c.TEST = NS(DET_MAX_INSTANCES=100, DET_MIN_CONFIDENCE=0, DET_NMS_THRESHOLD=0.3)      # lib/config.py:150-157
+    c.CTRL = NS(PHASE='train')
     if image_size % 64 != 0:
         raise ValueError("Image size must be dividable by 2 at least 6 times (lib/model.py:43-47)")
     c.MODEL.BACKBONE_SHAPES = np.array([[int(math.ceil(image_size / s)), int(math.ceil(image_size / s))]

@@ -131,6 +131,72 @@ def proposal_layer(inputs, proposal_count, nms_threshold, priors, config, propos
 
 
 # --------------------------------------------------------------------------------------
+# Detection layer, inference (lib/layers.py:664-802), batched, static shapes
+# --------------------------------------------------------------------------------------
+_CLASS_STRIDE = 8192.0      # > any pixel coordinate + 1; class*stride and the sums stay exact in fp32
+
+
+def detection_layer(rois, probs, deltas, windows, config, feature=None):
+    """rois [bs, N, 4] normalised, probs [bs*N, K], deltas [bs*N, K, 4], windows [bs, 4] (pixels)
+    -> detections [bs, DET_MAX_INSTANCES, (y1, x1, y2, x2, class_id, score)] in pixels, zero
+    padded, sorted by descending score (and the matching rows of `feature` if given).
+
+    The reference loops over images and over the classes present, sorting and calling NMS per
+    class (conduct_nms, :664-718).  Here every image is ONE sorted NMS launch: boxes are rounded
+    pixel integers (:765), so shifting a box by class_id * 8192 along x keeps every coordinate,
+    area and intersection exact in fp32 -- IoUs inside a class are unchanged and IoUs across
+    classes are 0, which is precisely per-class NMS.  Rows failing the filter (:768-769) are
+    sorted last and collapse onto one dummy box.  No host synchronisation."""
+    bs, N = rois.size(0), rois.size(1)
+    max_det = int(config.TEST.DET_MAX_INSTANCES)
+    class_scores, class_ids = torch.max(probs, dim=1)
+    idx = torch.arange(class_ids.size(0), device=probs.device)
+    std = torch.as_tensor(config.DATA.BBOX_STD_DEV, device=probs.device, dtype=probs.dtype).view(1, 4)
+    deltas_specific = deltas[idx, class_ids] * std
+    refined = apply_box_deltas(rois.reshape(1, -1, 4), deltas_specific.unsqueeze(0)).view(bs, N, 4)
+    h, w = float(config.DATA.IMAGE_SHAPE[0]), float(config.DATA.IMAGE_SHAPE[1])
+    refined = refined * torch.tensor([h, w, h, w], device=probs.device)
+    win = windows.to(refined.dtype).view(bs, 1, 4)
+    refined = torch.stack([torch.maximum(torch.minimum(refined[..., 0], win[..., 2]), win[..., 0]),
+                           torch.maximum(torch.minimum(refined[..., 1], win[..., 3]), win[..., 1]),
+                           torch.maximum(torch.minimum(refined[..., 2], win[..., 2]), win[..., 0]),
+                           torch.maximum(torch.minimum(refined[..., 3], win[..., 3]), win[..., 1])], 2)
+    refined = torch.round(refined)
+    class_ids = class_ids.view(bs, N)
+    class_scores = class_scores.view(bs, N)
+    area = (refined[..., 0] - refined[..., 2]) * (refined[..., 1] - refined[..., 3])
+    ok = (class_ids > 0) & (class_scores >= config.TEST.DET_MIN_CONFIDENCE) & (area > 0)
+    n_ok = ok.sum(1)
+    key = torch.where(ok, class_scores, torch.full_like(class_scores, -1.0))
+    key, order = torch.sort(key, dim=1, descending=True, stable=True)
+    g = lambda t: torch.gather(t, 1, order)
+    ok_s, cls_s = g(ok), g(class_ids)
+    box_s = torch.gather(refined, 1, order.unsqueeze(2).expand(-1, -1, 4))
+    shift = torch.where(ok_s, cls_s.to(box_s.dtype) * _CLASS_STRIDE, torch.zeros_like(key))
+    dummy = torch.tensor([0.0, 0.0, 1.0, 1.0], device=probs.device)     # class-0 slot: no real box lives there
+    nms_in = torch.where(ok_s.unsqueeze(2), box_s, dummy.expand_as(box_s)).clone()
+    nms_in[..., 1] += shift
+    nms_in[..., 3] += shift
+    dets = torch.cat((nms_in, key.unsqueeze(2)), 2)
+    keep, num = nms_sorted(dets, config.TEST.DET_NMS_THRESHOLD, max_keep=max_det + 1)
+    keep = keep[:, :max_det]
+    if keep.size(1) < max_det:
+        keep = F.pad(keep, (0, max_det - keep.size(1)))
+    slot = torch.arange(max_det, device=keep.device).unsqueeze(0)
+    valid = (slot < num.unsqueeze(1)) & (keep < n_ok.unsqueeze(1))
+    keep = torch.where(valid, keep, torch.zeros_like(keep))
+    out_box = torch.gather(box_s, 1, keep.unsqueeze(2).expand(-1, -1, 4))
+    out = torch.cat((out_box, torch.gather(cls_s, 1, keep).unsqueeze(2).to(out_box.dtype),
+                     torch.gather(key, 1, keep).unsqueeze(2)), 2) * valid.unsqueeze(2).to(out_box.dtype)
+    if feature is None:
+        return out
+    src = torch.gather(order, 1, keep)                                   # row of the RoI inside its image
+    feat = feature.view(bs, N, -1)
+    out_feat = torch.gather(feat, 1, src.unsqueeze(2).expand(-1, -1, feat.size(2))) * valid.unsqueeze(2).to(feat.dtype)
+    return out, out_feat
+
+
+# --------------------------------------------------------------------------------------
 # RPN targets (lib/layers.py:439-658), batched
 # --------------------------------------------------------------------------------------
 def _random_subset(mask, limit, kmax, generator=None):

@@ -8,7 +8,7 @@ import torch.nn as nn
 
 from .intertwiner import FeatureBuffer, merge_feat_vec
 from .layers import (compute_mrcnn_bbox_loss, compute_mrcnn_class_loss, compute_mrcnn_mask_loss,
-                     compute_rpn_bbox_loss, compute_rpn_class_loss, generate_pyramid_priors,
+                     compute_rpn_bbox_loss, compute_rpn_class_loss, detection_layer, generate_pyramid_priors,
                      prepare_det_target, prepare_rpn_target, proposal_layer)
 from .OT_module import OptTrans
 from .sub_module import FPN, RPN, Classifier, Dev, Mask, ResNet
@@ -70,11 +70,14 @@ class MaskRCNN(nn.Module):
         """input = [images [b,3,S,S], gt_class_ids [b,G], gt_boxes [b,G,4] pixels, gt_masks [b,G,56,56]].
         Returns (loss_merge [1,5], big_feat, big_cnt, small_feat, small_cnt, big_loss,
         small_output_all, small_gt_all, fpn_ot_loss) as lib/model.py:466-469."""
-        if mode != 'train':
-            raise NotImplementedError("the MI355X build covers the training hot path (SURVEY 8a)")
+        if mode not in ('train', 'inference'):
+            raise NotImplementedError("modes: 'train' (SURVEY 8a) and 'inference' (8f-3); 'visualize' is out of scope")
         cfg = self.config
-        images, gt_class_ids, gt_boxes, gt_masks = input[0], input[1], input[2], input[3]
+        images = input[0]
         bs = images.size(0)
+        if mode == 'inference':
+            return self._inference(images, input[1])
+        gt_class_ids, gt_boxes, gt_masks = input[1], input[2], input[3]
         self.eval()   # SURVEY Q1: the reference always runs BN (and everything else) in eval mode
         proposal_cnt = cfg.RPN.POST_NMS_ROIS_INFERENCE   # also Q1
 
@@ -119,6 +122,34 @@ class MaskRCNN(nn.Module):
             compute_mrcnn_mask_loss(target_mask, target_class_ids, mrcnn_mask))).view(1, 5)
         return (losses, big_feat, big_cnt, small_feat, small_cnt, big_loss, small_output_all, small_gt_all,
                 fpn_ot_loss)
+
+    # ------------------------------------------------------------------ inference
+    @torch.no_grad()
+    def _inference(self, images, image_metas):
+        """lib/model.py:265-345, mode == 'inference': [detections [bs, 100, 6] (pixels, class, score),
+        mrcnn_mask [bs, 100, K, 28, 28]].  `image_metas` is the reference's [bs, 8+K+1] meta array
+        (window in columns 4:8, tools/image_utils.py:31-40) or just the windows [bs, 4]."""
+        cfg = self.config
+        bs = images.size(0)
+        self.eval()
+        p2, p3, p4, p5, p6, _ = self.fpn(images, mode='inference')
+        mrcnn_maps = [p2, p3, p4, p5]
+        outs = [self.rpn(p) for p in (p2, p3, p4, p5, p6)]
+        _, rpn_probs, rpn_bbox = [torch.cat(list(o), dim=1) for o in zip(*outs)]
+        proposals, _ = proposal_layer([rpn_probs, rpn_bbox], cfg.RPN.POST_NMS_ROIS_INFERENCE,
+                                      cfg.RPN.NMS_THRESHOLD, self.priors, cfg, self.proposal_hook)
+        pooled_cls, _, feat_out = self.dev_roi(mrcnn_maps, proposals)
+        small_output_all, small_gt_all = feat_out if feat_out else (None, None)
+        _, mrcnn_class, mrcnn_bbox = self.classifier(pooled_cls, small_output_all, small_gt_all)
+        meta = torch.as_tensor(image_metas, device=images.device, dtype=torch.float32)
+        windows = meta if meta.size(1) == 4 else meta[:, 4:8]
+        detections = detection_layer(proposals, mrcnn_class, mrcnn_bbox, windows, cfg)
+        h, w = float(cfg.DATA.IMAGE_SHAPE[0]), float(cfg.DATA.IMAGE_SHAPE[1])
+        scale = torch.tensor([h, w, h, w], device=images.device)
+        _, pooled_mask, _ = self.dev_roi(mrcnn_maps, detections[:, :, :4] / scale)
+        mrcnn_mask = self.mask(pooled_mask)
+        mrcnn_mask = mrcnn_mask.view(bs, -1, mrcnn_mask.size(1), mrcnn_mask.size(2), mrcnn_mask.size(3))
+        return [detections, mrcnn_mask]
 
     # ------------------------------------------------------------------ meta loss
     def meta_loss(self, feat_input, reduce_fn=None):

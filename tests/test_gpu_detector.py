@@ -140,3 +140,103 @@ def test_train_step_runs_and_learns():
         hist.append(float(t["total"]))
     assert hist[-1] < hist[0]
     assert all(p.grad is not None for n, p in model.named_parameters() if not n.startswith("ot_loss"))
+
+
+def _detection_layer_restated(rois, probs, deltas, windows, cfg, oracle):
+    """lib/layers.py:664-802 step by step on the host: per image, per class present, sort by
+    score, NMS (oracle, `>=`), union, top DET_MAX_INSTANCES by score."""
+    bs, N = rois.shape[:2]
+    K = probs.shape[1]
+    out = np.zeros((bs, cfg.TEST.DET_MAX_INSTANCES, 6), np.float32)
+    ids = probs.argmax(1)
+    sc = probs.max(1)
+    d = deltas[np.arange(bs * N), ids] * np.asarray(cfg.DATA.BBOX_STD_DEV, np.float32)
+    b = rois.reshape(-1, 4)
+    hgt, wid = b[:, 2] - b[:, 0], b[:, 3] - b[:, 1]
+    cy, cx = b[:, 0] + np.float32(0.5) * hgt, b[:, 1] + np.float32(0.5) * wid
+    cy, cx = cy + d[:, 0] * hgt, cx + d[:, 1] * wid
+    hgt, wid = hgt * np.exp(d[:, 2]), wid * np.exp(d[:, 3])
+    y1, x1 = cy - np.float32(0.5) * hgt, cx - np.float32(0.5) * wid
+    ref = np.stack([y1, x1, y1 + hgt, x1 + wid], 1) * np.float32(cfg.DATA.IMAGE_SHAPE[0])
+    for i in range(bs):
+        w = windows[i]
+        r = ref[i * N:(i + 1) * N]
+        r = np.round(np.stack([r[:, 0].clip(w[0], w[2]), r[:, 1].clip(w[1], w[3]),
+                               r[:, 2].clip(w[0], w[2]), r[:, 3].clip(w[1], w[3])], 1))
+        cid, s = ids[i * N:(i + 1) * N], sc[i * N:(i + 1) * N]
+        ok = (cid > 0) & (s >= cfg.TEST.DET_MIN_CONFIDENCE) & ((r[:, 0] - r[:, 2]) * (r[:, 1] - r[:, 3]) > 0)
+        kept = []
+        for c in np.unique(cid[ok]):
+            ix = np.nonzero(ok & (cid == c))[0]
+            ix = ix[np.argsort(-s[ix], kind="stable")]
+            dets = np.concatenate([r[ix], s[ix, None]], 1).astype(np.float32)
+            kept.extend(ix[oracle.pth_nms(dets, cfg.TEST.DET_NMS_THRESHOLD)].tolist())
+        kept = np.array(sorted(kept), np.int64)
+        top = kept[np.argsort(-s[kept], kind="stable")][:cfg.TEST.DET_MAX_INSTANCES]
+        out[i, :len(top)] = np.concatenate([r[top], cid[top, None].astype(np.float32), s[top, None]], 1)
+    return out
+
+
+@pytest.mark.parametrize("min_conf", [0.0, 0.5])
+def test_detection_layer_matches_per_class_restatement(oracle, min_conf):
+    from feature_intertwiner_amd import layers as L
+    cfg = _cfg(backbone="resnet50", image_size=512)
+    cfg.TEST.DET_MIN_CONFIDENCE = min_conf
+    rs = np.random.RandomState(5)
+    bs, N, K = 3, 400, 81
+    # clustered proposals so that NMS has work: 12 centres, jittered copies; a few degenerate rows
+    ctr = rs.uniform(0.15, 0.85, (bs, 12, 2))
+    sz = rs.uniform(0.05, 0.3, (bs, 12, 2))
+    pick = rs.randint(0, 12, (bs, N))
+    c = np.take_along_axis(ctr, pick[..., None], 1) + rs.normal(0, 0.01, (bs, N, 2))
+    s = np.take_along_axis(sz, pick[..., None], 1) * rs.uniform(0.9, 1.1, (bs, N, 2))
+    rois = np.concatenate([c - s / 2, c + s / 2], 2).clip(0, 1).astype(np.float32)
+    rois[1, 390:] = 0
+    logits = rs.standard_normal((bs * N, K)).astype(np.float32)
+    cls_of_cluster = rs.randint(0, 6, (bs, 12))            # few classes (incl. background 0) => same-class clusters
+    fav = np.take_along_axis(cls_of_cluster, pick, 1).reshape(-1)
+    logits[np.arange(bs * N), fav] += rs.uniform(2, 6, bs * N).astype(np.float32)
+    probs = torch.softmax(torch.from_numpy(logits), 1).numpy()
+    deltas = (rs.standard_normal((bs * N, K, 4)) * 0.5).astype(np.float32)
+    windows = np.array([[0, 0, 512, 512], [32, 0, 480, 512], [0, 64, 512, 448]], np.float32)
+    T = lambda a: torch.from_numpy(a).to(DEV)
+    feat = rs.standard_normal((bs * N, 16)).astype(np.float32)
+    got, got_feat = L.detection_layer(T(rois), T(probs), T(deltas), T(windows), cfg, T(feat))
+    exp = _detection_layer_restated(rois, probs, deltas, windows, cfg, oracle)
+    got = got.cpu().numpy()
+    n_exp = (exp[:, :, 4] > 0).sum(1)
+    assert np.array_equal((got[:, :, 4] > 0).sum(1), n_exp) and n_exp.min() > 5
+    assert np.array_equal(got[:, :, 4], exp[:, :, 4])                         # classes, in score order
+    assert np.array_equal(got[:, :, 5], exp[:, :, 5])                         # scores: same elements of `probs`
+    assert np.abs(got[:, :, :4] - exp[:, :, :4]).max() <= 1.0                 # rounded pixels; exp() differs by ulps host/device
+    assert (np.abs(got[:, :, :4] - exp[:, :, :4]) > 0).mean() < 0.01
+    # feature rows follow their detections
+    ids = probs.argmax(1).reshape(bs, N)
+    sc = probs.max(1).reshape(bs, N)
+    for i in range(bs):
+        for j in range(int(n_exp[i])):
+            src = np.nonzero((sc[i] == got[i, j, 5]) & (ids[i] == got[i, j, 4]))[0]
+            assert len(src) == 1 and np.array_equal(got_feat[i, j].cpu().numpy(), feat[i * N + src[0]])
+    assert torch.all(got_feat[0, int(n_exp[0]):] == 0)
+
+
+def test_inference_path_runs():
+    from feature_intertwiner_amd.model import MaskRCNN
+    from feature_intertwiner_amd.synthetic import SyntheticProposals, synthetic_batch
+    torch.manual_seed(1)
+    cfg = _cfg(backbone="resnet50", image_size=256, batch_size=2)
+    model = MaskRCNN(cfg).to(DEV)
+    batch = synthetic_batch(2, 256, device=DEV)
+    model.proposal_hook = SyntheticProposals(batch[2], 256)
+    windows = torch.tensor([[0, 0, 256, 256], [0, 16, 256, 240]], dtype=torch.float32)
+    det, masks = model([batch[0], windows], mode='inference')
+    assert det.shape == (2, 100, 6) and masks.shape == (2, 100, 81, 28, 28)
+    n = (det[:, :, 4] > 0).sum(1)
+    assert torch.all(n > 0)
+    for b in range(2):
+        d = det[b, :int(n[b])]
+        assert torch.all(d[:-1, 5] >= d[1:, 5])                                # descending score
+        assert torch.all((d[:, 0] >= windows[b, 0]) & (d[:, 2] <= windows[b, 2]) &
+                         (d[:, 1] >= windows[b, 1]) & (d[:, 3] <= windows[b, 3]))
+        assert torch.all(det[b, int(n[b]):] == 0)
+    assert torch.isfinite(masks).all() and masks.min() >= 0 and masks.max() <= 1
