@@ -1,0 +1,46 @@
+"""Checkpoint file of the reference (tools/utils.py:567-586 save_model, :323-345 resume):
+
+    {'state_dict', 'epoch', 'iter', 'buffer', 'buffer_cnt', 'loss_data'}
+
+`buffer`/`buffer_cnt` are the intertwiner's history of big-object class features as numpy
+arrays ([] when the intertwiner is off).  Module names and parameter shapes are the
+reference's (tests/golden/state_dict_keys.json pins them), so the authors' `.pth` files load
+by name; like the reference, loading is non-strict and also accepts a bare state dict (its
+"legacy / pretrain" case).  The Keras-h5 converter (tools/convert_from_keras.py) needs h5py,
+which this image does not have, and is out of scope.
+"""
+import numpy as np
+import torch
+
+from .intertwiner import FeatureBuffer
+
+
+def save_model(model, path, epoch, iter, loss_data=None):
+    cfg = model.config
+    if cfg.DEV.SWITCH and not cfg.DEV.BASELINE and model.feature_buffer is not None:
+        buffer = model.feature_buffer.buffer.cpu().numpy()
+        buffer_cnt = model.feature_buffer.buffer_cnt.cpu().numpy()
+    else:
+        buffer, buffer_cnt = [], []
+    torch.save({'state_dict': model.state_dict(), 'epoch': int(epoch), 'iter': int(iter),
+                'buffer': buffer, 'buffer_cnt': buffer_cnt,
+                'loss_data': [] if loss_data is None else loss_data}, path)
+
+
+def load_model(model, path, map_location=None):
+    """Returns (start_epoch, start_iter, loss_data, missing_keys, unexpected_keys).  A resumed
+    model continues at iter+1 (epoch roll-over needs the dataset size and is left to the caller,
+    tools/utils.py:333-339); a bare state dict is a pretrain model and starts at (1, 1)."""
+    ckpt = torch.load(path, map_location=map_location, weights_only=False)
+    state = ckpt['state_dict'] if isinstance(ckpt, dict) and 'state_dict' in ckpt else ckpt
+    result = model.load_state_dict(state, strict=False)
+    if not (isinstance(ckpt, dict) and 'epoch' in ckpt and 'iter' in ckpt):
+        return 1, 1, [], result.missing_keys, result.unexpected_keys
+    buf = ckpt.get('buffer', [])
+    if isinstance(buf, np.ndarray) and buf.size:
+        dev = next(model.parameters()).device
+        fb = FeatureBuffer(buf.shape[0], buf.shape[1], buf.shape[2], dev)
+        fb.buffer = torch.from_numpy(buf).to(dev)
+        fb.buffer_cnt = torch.from_numpy(np.asarray(ckpt['buffer_cnt'])).to(dev)
+        model.feature_buffer = fb
+    return int(ckpt['epoch']), int(ckpt['iter']) + 1, ckpt.get('loss_data', []), result.missing_keys, result.unexpected_keys

@@ -126,3 +126,34 @@ def test_level_assignment_matches_oracle(oracle):
     m, cs = merge_feat_vec(f, c)
     assert torch.allclose(cs, c.sum((0, 1)))
     assert torch.allclose(m, (f * c).sum((0, 1)) / (cs + 1e-20))
+
+
+def test_checkpoint_file_round_trip(tmp_path):
+    """tools/utils.py:567-586 file layout; resume restores weights, counters and the history buffer."""
+    import numpy as np
+    import torch
+    from feature_intertwiner_amd.checkpoint import load_model, save_model
+    from feature_intertwiner_amd.config import make_config
+    from feature_intertwiner_amd.model import MaskRCNN
+    cfg = make_config(backbone="resnet50", image_size=128, batch_size=1, train_rois_per_image=16)
+    torch.manual_seed(0)
+    a = MaskRCNN(cfg)
+    a.initialize_buffer(torch.device("cpu"))
+    a.feature_buffer.buffer.normal_()
+    a.feature_buffer.buffer_cnt.fill_(3)
+    path = str(tmp_path / "mask_rcnn_ep_0002_iter_000123.pth")
+    save_model(a, path, epoch=2, iter=123, loss_data={"x": [1.0]})
+    raw = torch.load(path, weights_only=False)
+    assert sorted(raw) == ['buffer', 'buffer_cnt', 'epoch', 'iter', 'loss_data', 'state_dict']
+    assert isinstance(raw['buffer'], np.ndarray) and raw['buffer'].shape == (1, 1024, 81)
+    torch.manual_seed(1)
+    b = MaskRCNN(cfg)
+    ep, it, loss_data, missing, unexpected = load_model(b, path)
+    assert (ep, it) == (2, 124) and loss_data == {"x": [1.0]} and not missing and not unexpected
+    for (k, v), (k2, v2) in zip(a.state_dict().items(), b.state_dict().items()):
+        assert k == k2 and torch.equal(v, v2)
+    assert torch.equal(a.feature_buffer.buffer, b.feature_buffer.buffer)
+    assert torch.equal(a.feature_buffer.buffer_cnt, b.feature_buffer.buffer_cnt)
+    # bare state dict == pretrain model
+    torch.save(a.state_dict(), path)
+    assert load_model(MaskRCNN(cfg), path)[:2] == (1, 1)
