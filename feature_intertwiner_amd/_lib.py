@@ -37,6 +37,10 @@ SIGNATURES = {
                                         c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p]),
     "fi_pyramid_crop_backward": (c_int, [c_void_p, _pp, _ip, _ip, c_int, c_void_p, c_void_p,
                                          c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "fi_pyramid_crop_forward_nhwc": (c_int, [_pp, _ip, _ip, c_int, c_void_p, c_void_p, c_void_p, c_int,
+                                             c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p]),
+    "fi_pyramid_crop_backward_nhwc": (c_int, [c_void_p, _pp, _ip, _ip, c_int, c_void_p, c_void_p,
+                                              c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "fi_roi_pool_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                                     c_int, c_float, c_void_p, c_void_p, c_void_p]),
     "fi_roi_pool_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
@@ -64,6 +68,8 @@ KERNEL_IDS = {
     "crop_bwd_7x7": 4, "crop_bwd_14x14": 5, "crop_bwd_28x28": 6, "crop_bwd_generic": 7,
     "roipool_fwd": 8, "roipool_bwd": 9, "nms_mask": 10, "nms_scan": 11, "sinkhorn": 12,
     "class_mean": 13, "bn_act_bwd": 30,
+    "crop_fwd_nhwc_7x7": 31, "crop_fwd_nhwc_14x14": 32, "crop_fwd_nhwc_generic": 33,
+    "crop_bwd_nhwc_7x7": 34, "crop_bwd_nhwc_14x14": 35, "crop_bwd_nhwc_generic": 36,
 }
 for _i, _bm in enumerate((64, 128)):
     for _j, _w in enumerate(("1x1", "3x3", "7x7", "other")):

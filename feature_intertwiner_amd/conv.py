@@ -190,7 +190,12 @@ def conv_bn_act(x, conv, bn, relu=True, residual=None):
     R, S = conv.weight.shape[2], conv.weight.shape[3]
     gemm_path = ((x.shape[2], x.shape[3]) == (R, S) and tuple(conv.padding) == (0, 0)) or x.shape[2] * x.shape[3] == 1
     if bn.training or gemm_path or not bn.track_running_stats:
-        y = bn(conv(x))
+        if gemm_path and not bn.training and bn.track_running_stats:
+            # [N,C,1,1]: MIOpen's spatial inference BN takes ~0.4 ms on 8 MB here; the affine form is ~10 us
+            scale = bn.weight * torch.rsqrt(bn.running_var + bn.eps)
+            y = conv(x) * scale.view(1, -1, 1, 1) + (bn.bias - bn.running_mean * scale).view(1, -1, 1, 1)
+        else:
+            y = bn(conv(x))
         if residual is not None:
             y = y + residual
         return F.relu(y) if relu else y

@@ -21,6 +21,7 @@
 //     flat-index -> (c, y, x) split is multiply-shift, not integer division;
 //   * every output element is written (zeros / extrapolation value included), so
 //     the reference's separate 25..100 MB zero-fill pass disappears.
+#include <stdint.h>
 #include <stdlib.h>
 
 #include "fi_common.h"
@@ -340,6 +341,178 @@ __global__ __launch_bounds__(kThreads) void crop_bwd_kernel(
     }
 }
 
+// -------------------------------------------------------------------------------------
+// Channels-last maps ([batch][H][W][depth]).  In NCHW every (bin, channel) sample lives in its own
+// cache line, so the gather is bound by L1 line look-ups and outstanding misses (PMC: 64-byte
+// sectors fetched for 8 useful bytes).  With the channel axis innermost, the `depth` values of one
+// tap are contiguous: a wavefront instruction reads 64 channels of one tap = 256 contiguous bytes,
+// every fetched line is fully used, and the backward pass's atomics become line-wide as well.
+// The crop output stays [num_boxes][depth][ch][cw] (what the heads consume): lanes run over
+// channels, results are transposed through an LDS tile [channels][bins] (odd pitch: conflict
+// free) and written back as one contiguous block.  Arithmetic is identical to the NCHW kernels.
+// -------------------------------------------------------------------------------------
+template <int V> struct VecF;
+template <> struct VecF<1> { typedef float type; };
+template <> struct VecF<4> { typedef float4 type; };
+__device__ __forceinline__ float vget(const float &v, int) { return v; }
+__device__ __forceinline__ float vget(const float4 &v, int q) { return q == 0 ? v.x : q == 1 ? v.y : q == 2 ? v.z : v.w; }
+
+// V = channels per lane: 4 (16-byte loads; depth % 4 == 0 and 16-byte aligned maps) or 1.  A lane
+// keeps UNROLL bins x 4 taps in flight; with V = 4 that is 256 bytes per lane, which is what the
+// gather needs to cover the L2/HBM latency at the 3..6 workgroups per CU the LDS tile allows.
+template <int CH, int CW, int V>
+__global__ __launch_bounds__(kThreads) void crop_fwd_cl_kernel(
+    LevelSet ls, const float *__restrict__ boxes, const int *__restrict__ box_ind,
+    const int *__restrict__ level, int num_boxes, int batch, int depth, int crop_h_rt,
+    int crop_w_rt, float extrap, int cpb, int chunks, float *__restrict__ crops)
+{
+    typedef typename VecF<V>::type vec_t;
+    const int crop_h = CH ? CH : crop_h_rt;
+    const int crop_w = CW ? CW : crop_w_rt;
+    const int bins = crop_h * crop_w;
+    const int pitch = bins | 1;
+    extern __shared__ float s_dyn[];          // [cpb][pitch]
+    __shared__ Tap s_ty[kMaxCrop];
+    __shared__ Tap s_tx[kMaxCrop];
+
+    const int tid = threadIdx.x;
+    const int box = blockIdx.x / chunks;
+    const int chunk = blockIdx.x - box * chunks;
+    const int c_begin = chunk * cpb;
+    const int c_count = min(cpb, depth - c_begin);
+    const int total = c_count * bins;
+    float *__restrict__ out = crops + ((size_t)box * depth + c_begin) * bins;
+
+    BoxHeader h;
+    if (!load_box(ls, boxes, box_ind, level, box, batch, h)) {
+        for (int i = tid; i < total; i += kThreads) out[i] = 0.0f;
+        return;
+    }
+    if (tid < crop_h) s_ty[tid] = make_tap(h.y1, h.y2, h.H, crop_h, tid);
+    if (tid >= 64 && tid < 64 + crop_w) s_tx[tid - 64] = make_tap(h.x1, h.x2, h.W, crop_w, tid - 64);
+    __syncthreads();
+
+    const int lanes = cpb / V;                 // lanes per bin (consecutive lanes: consecutive channels)
+    const int c = (tid % lanes) * V;           // first channel of this lane
+    const int g = tid / lanes;                 // bin group
+    const int ng = kThreads / lanes;
+    const float *__restrict__ src =
+        ls.img[h.lvl] + (size_t)h.img * h.H * h.W * depth + c_begin + c;
+    const int W = h.W;
+    if (c < c_count) {
+        constexpr int UNROLL = 4;
+        for (int b0 = g; b0 < bins; b0 += ng * UNROLL) {
+            vec_t tl[UNROLL], tr[UNROLL], bl[UNROLL], br[UNROLL];
+            float fx[UNROLL], fy[UNROLL];
+            int ok[UNROLL];
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
+                const int b = b0 + u * ng;
+                ok[u] = 0;
+                fx[u] = fy[u] = 0.0f;
+                if (b < bins) {
+                    const int y = b / crop_w;
+                    const int x = b - y * crop_w;
+                    const Tap ty = s_ty[y];
+                    const Tap tx = s_tx[x];
+                    ok[u] = (ty.valid & tx.valid) ? 1 : 2;
+                    if (ok[u] == 1) {
+                        const size_t r0 = (size_t)ty.i0 * W, r1 = (size_t)ty.i1 * W;
+                        tl[u] = *reinterpret_cast<const vec_t *>(src + (r0 + tx.i0) * depth);
+                        tr[u] = *reinterpret_cast<const vec_t *>(src + (r0 + tx.i1) * depth);
+                        bl[u] = *reinterpret_cast<const vec_t *>(src + (r1 + tx.i0) * depth);
+                        br[u] = *reinterpret_cast<const vec_t *>(src + (r1 + tx.i1) * depth);
+                        fx[u] = tx.frac;
+                        fy[u] = ty.frac;
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
+                const int b = b0 + u * ng;
+                if (ok[u] == 1) {
+#pragma unroll
+                    for (int q = 0; q < V; ++q) {
+                        const float vtl = vget(tl[u], q), vtr = vget(tr[u], q);
+                        const float vbl = vget(bl[u], q), vbr = vget(br[u], q);
+                        const float dt = vtr - vtl;
+                        const float top = vtl + dt * fx[u];
+                        const float db = vbr - vbl;
+                        const float bot = vbl + db * fx[u];
+                        const float dv = bot - top;
+                        s_dyn[(c + q) * pitch + b] = top + dv * fy[u];
+                    }
+                } else if (ok[u] == 2) {
+#pragma unroll
+                    for (int q = 0; q < V; ++q) s_dyn[(c + q) * pitch + b] = extrap;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < total; i += kThreads) {
+        const int cc = i / bins;
+        out[i] = s_dyn[cc * pitch + (i - cc * bins)];
+    }
+}
+
+template <int CH, int CW>
+__global__ __launch_bounds__(kThreads) void crop_bwd_cl_kernel(
+    LevelSetMut ls, const float *__restrict__ grads, const float *__restrict__ boxes,
+    const int *__restrict__ box_ind, const int *__restrict__ level, int num_boxes, int batch,
+    int depth, int crop_h_rt, int crop_w_rt, int cpb, int chunks)
+{
+    const int crop_h = CH ? CH : crop_h_rt;
+    const int crop_w = CW ? CW : crop_w_rt;
+    const int bins = crop_h * crop_w;
+    const int pitch = bins | 1;
+    extern __shared__ float s_dyn[];          // [cpb][pitch]: the box's gradient block, transposed on read
+    __shared__ Tap s_ty[kMaxCrop];
+    __shared__ Tap s_tx[kMaxCrop];
+
+    const int tid = threadIdx.x;
+    const int box = blockIdx.x / chunks;
+    const int chunk = blockIdx.x - box * chunks;
+    const int c_begin = chunk * cpb;
+    const int c_count = min(cpb, depth - c_begin);
+    const int total = c_count * bins;
+
+    BoxHeader h;
+    if (!load_box(ls, boxes, box_ind, level, box, batch, h)) return;
+    if (tid < crop_h) s_ty[tid] = make_tap(h.y1, h.y2, h.H, crop_h, tid);
+    if (tid >= 64 && tid < 64 + crop_w) s_tx[tid - 64] = make_tap(h.x1, h.x2, h.W, crop_w, tid - 64);
+    const float *__restrict__ gsrc = grads + ((size_t)box * depth + c_begin) * bins;
+    for (int i = tid; i < total; i += kThreads) {
+        const int cc = i / bins;
+        s_dyn[cc * pitch + (i - cc * bins)] = gsrc[i];
+    }
+    __syncthreads();
+
+    const int c = tid % cpb;
+    const int g = tid / cpb;
+    const int ng = kThreads / cpb;
+    if (c >= c_count) return;
+    float *__restrict__ dst = ls.img[h.lvl] + (size_t)h.img * h.H * h.W * depth + c_begin + c;
+    const int W = h.W;
+    for (int b = g; b < bins; b += ng) {
+        const int y = b / crop_w;
+        const int x = b - y * crop_w;
+        const Tap ty = s_ty[y];
+        const Tap tx = s_tx[x];
+        if (!(ty.valid & tx.valid)) continue;
+        const float gv = s_dyn[c * pitch + b];
+        const float wy0 = 1.0f - ty.frac;
+        const float wx0 = 1.0f - tx.frac;
+        const float gtop = wy0 * gv;
+        const float gbot = ty.frac * gv;
+        const size_t r0 = (size_t)ty.i0 * W, r1 = (size_t)ty.i1 * W;
+        atomicAdd(dst + (r0 + tx.i0) * depth, wx0 * gtop);
+        atomicAdd(dst + (r0 + tx.i1) * depth, tx.frac * gtop);
+        atomicAdd(dst + (r1 + tx.i0) * depth, wx0 * gbot);
+        atomicAdd(dst + (r1 + tx.i1) * depth, tx.frac * gbot);
+    }
+}
+
 __global__ void crop_taps_kernel(const float *__restrict__ boxes, int num_boxes, int H, int W,
                                  int crop_h, int crop_w, int *y_valid, int *y0, int *y1,
                                  float *y_frac, int *x_valid, int *x0, int *x1, float *x_frac)
@@ -451,6 +624,93 @@ int backward_impl(const LevelSetMut &ls, const float *grads, const float *boxes,
                         chunks);
 }
 
+// channels-last launch geometry: channels per workgroup (multiple of 64 so that a wavefront shares
+// one bin) sized to keep the LDS tile <= 50 KB; returns 0 when the crop is too large for the tile
+int pick_cl_chunk(int depth, int bins)
+{
+    const int pitch = bins | 1;
+    int cpb = 256;
+    while (cpb > 64 && ((long)cpb * pitch * 4 > 28 * 1024 || cpb / 2 >= depth)) cpb /= 2;
+    if ((long)cpb * pitch * 4 > 56 * 1024) return 0;
+    return cpb;
+}
+
+int cl_size_class(int crop_h, int crop_w)
+{
+    if (crop_h == 7 && crop_w == 7) return 0;
+    if (crop_h == 14 && crop_w == 14) return 1;
+    return 2;
+}
+
+int forward_cl_impl(const LevelSet &ls, const float *boxes, const int32_t *box_ind,
+                    const int32_t *level, int num_boxes, int batch, int depth, int crop_h, int crop_w,
+                    float extrap, float *crops, hipStream_t st)
+{
+    if (num_boxes == 0) return FI_OK;
+    const int bins = crop_h * crop_w;
+    const int cpb = pick_cl_chunk(depth, bins);
+    if (cpb == 0) {
+        fi::set_error("channels-last crop supports crop_h*crop_w <= 220 (got %dx%d)", crop_h, crop_w);
+        return FI_ERR_UNSUPPORTED;
+    }
+    const int chunks = fi::ceil_div(depth, cpb);
+    const long nblk = (long)num_boxes * chunks;
+    FI_REQUIRE(nblk < 2147483647L, "grid too large");
+    const size_t lds = sizeof(float) * (size_t)cpb * (bins | 1);
+    const int cls = cl_size_class(crop_h, crop_w);
+    fi::ProfScope prof(FI_K_CROP_FWD_NHWC_7X7 + cls, st);
+    bool vec4 = (depth % 4 == 0);
+    for (int l = 0; l < ls.n; ++l) vec4 = vec4 && ((uintptr_t)ls.img[l] % 16 == 0);
+    auto k = vec4 ? (cls == 0 ? crop_fwd_cl_kernel<7, 7, 4> : cls == 1 ? crop_fwd_cl_kernel<14, 14, 4> : crop_fwd_cl_kernel<0, 0, 4>)
+                  : (cls == 0 ? crop_fwd_cl_kernel<7, 7, 1> : cls == 1 ? crop_fwd_cl_kernel<14, 14, 1> : crop_fwd_cl_kernel<0, 0, 1>);
+    hipLaunchKernelGGL(k, dim3((unsigned)nblk), dim3(kThreads), lds, st, ls, boxes, box_ind, level, num_boxes,
+                       batch, depth, crop_h, crop_w, extrap, cpb, chunks, crops);
+    FI_HIP_CHECK(hipGetLastError());
+    return FI_OK;
+}
+
+int backward_cl_impl(const LevelSetMut &ls, const float *grads, const float *boxes,
+                     const int32_t *box_ind, const int32_t *level, int num_boxes, int batch, int depth,
+                     int crop_h, int crop_w, hipStream_t st)
+{
+    for (int l = 0; l < ls.n; ++l) {
+        const size_t bytes = sizeof(float) * (size_t)batch * depth * ls.H[l] * ls.W[l];
+        FI_HIP_CHECK(hipMemsetAsync(ls.img[l], 0, bytes, st));
+    }
+    if (num_boxes == 0) return FI_OK;
+    const int bins = crop_h * crop_w;
+    const int cpb = pick_cl_chunk(depth, bins);
+    if (cpb == 0) {
+        fi::set_error("channels-last crop supports crop_h*crop_w <= 220 (got %dx%d)", crop_h, crop_w);
+        return FI_ERR_UNSUPPORTED;
+    }
+    const int chunks = fi::ceil_div(depth, cpb);
+    const long nblk = (long)num_boxes * chunks;
+    FI_REQUIRE(nblk < 2147483647L, "grid too large");
+    const size_t lds = sizeof(float) * (size_t)cpb * (bins | 1);
+    const int cls = cl_size_class(crop_h, crop_w);
+    fi::ProfScope prof(FI_K_CROP_BWD_NHWC_7X7 + cls, st);
+    auto k = cls == 0 ? crop_bwd_cl_kernel<7, 7> : cls == 1 ? crop_bwd_cl_kernel<14, 14> : crop_bwd_cl_kernel<0, 0>;
+    hipLaunchKernelGGL(k, dim3((unsigned)nblk), dim3(kThreads), lds, st, ls, grads, boxes, box_ind, level,
+                       num_boxes, batch, depth, crop_h, crop_w, cpb, chunks);
+    FI_HIP_CHECK(hipGetLastError());
+    return FI_OK;
+}
+
+int fill_levels(LevelSet &ls, const float *const *img, const int *hh, const int *ww, int n)
+{
+    FI_REQUIRE(n >= 1 && n <= kMaxLevels, "1 <= num_levels <= 8");
+    FI_REQUIRE(img && hh && ww, "null level arrays");
+    ls.n = n;
+    for (int l = 0; l < n; ++l) {
+        ls.img[l] = img[l];
+        ls.H[l] = hh[l];
+        ls.W[l] = ww[l];
+        FI_REQUIRE(ls.img[l] && ls.H[l] >= 1 && ls.W[l] >= 1, "bad level entry");
+    }
+    return FI_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -550,6 +810,47 @@ int fi_pyramid_crop_backward(const float *grads, float *const *level_grads_host,
     }
     return backward_impl(ls, grads, boxes, box_ind, level, num_boxes, batch, depth, crop_h, crop_w,
                          (hipStream_t)stream);
+}
+
+int fi_pyramid_crop_forward_nhwc(const float *const *level_images_host, const int *level_h_host,
+                                 const int *level_w_host, int num_levels, const float *boxes,
+                                 const int32_t *box_ind, const int32_t *level, int num_boxes,
+                                 int batch, int depth, int crop_h, int crop_w,
+                                 float extrapolation_value, float *crops, fi_stream_t stream)
+{
+    int rc = check_common(num_boxes, batch, depth, crop_h, crop_w);
+    if (rc != FI_OK) return rc;
+    FI_REQUIRE(num_boxes == 0 || (boxes && box_ind && crops), "null pointer");
+    LevelSet ls = {};
+    rc = fill_levels(ls, level_images_host, level_h_host, level_w_host, num_levels);
+    if (rc != FI_OK) return rc;
+    FI_REQUIRE(level != nullptr || num_levels == 1, "level[] is required with more than one map");
+    return forward_cl_impl(ls, boxes, box_ind, level, num_boxes, batch, depth, crop_h, crop_w,
+                           extrapolation_value, crops, (hipStream_t)stream);
+}
+
+int fi_pyramid_crop_backward_nhwc(const float *grads, float *const *level_grads_host,
+                                  const int *level_h_host, const int *level_w_host, int num_levels,
+                                  const float *boxes, const int32_t *box_ind, const int32_t *level,
+                                  int num_boxes, int batch, int depth, int crop_h, int crop_w,
+                                  fi_stream_t stream)
+{
+    int rc = check_common(num_boxes, batch, depth, crop_h, crop_w);
+    if (rc != FI_OK) return rc;
+    FI_REQUIRE(num_boxes == 0 || (grads && boxes && box_ind), "null pointer");
+    LevelSet lsc = {};
+    rc = fill_levels(lsc, level_grads_host, level_h_host, level_w_host, num_levels);
+    if (rc != FI_OK) return rc;
+    FI_REQUIRE(level != nullptr || num_levels == 1, "level[] is required with more than one map");
+    LevelSetMut ls = {};
+    ls.n = lsc.n;
+    for (int l = 0; l < lsc.n; ++l) {
+        ls.img[l] = level_grads_host[l];
+        ls.H[l] = lsc.H[l];
+        ls.W[l] = lsc.W[l];
+    }
+    return backward_cl_impl(ls, grads, boxes, box_ind, level, num_boxes, batch, depth, crop_h, crop_w,
+                            (hipStream_t)stream);
 }
 
 }  // extern "C"

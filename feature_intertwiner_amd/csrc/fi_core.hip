@@ -128,7 +128,9 @@ const char *fi_prof_kernel_name(int kernel_id)
         "conv_fwd_kernel<128, 7, 7>",   "conv_fwd_kernel<128, 0, 0>",   "conv_wgrad_kernel<64, 1, 1>",
         "conv_wgrad_kernel<64, 3, 3>",  "conv_wgrad_kernel<64, 7, 7>",  "conv_wgrad_kernel<64, 0, 0>",
         "conv_wgrad_kernel<128, 1, 1>", "conv_wgrad_kernel<128, 3, 3>", "conv_wgrad_kernel<128, 7, 7>",
-        "conv_wgrad_kernel<128, 0, 0>", "bn_act_bwd_kernel"};
+        "conv_wgrad_kernel<128, 0, 0>", "bn_act_bwd_kernel",
+        "crop_fwd_cl_kernel<7, 7>", "crop_fwd_cl_kernel<14, 14>", "crop_fwd_cl_kernel<0, 0>",
+        "crop_bwd_cl_kernel<7, 7>", "crop_bwd_cl_kernel<14, 14>", "crop_bwd_cl_kernel<0, 0>"};
     if (kernel_id < 0 || kernel_id >= FI_K_COUNT) return "?";
     return names[kernel_id];
 }

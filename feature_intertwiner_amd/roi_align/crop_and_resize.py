@@ -65,6 +65,11 @@ class CropAndResizeFunction(object):
     forward = __call__
 
 
+def _is_channels_last(t):
+    """[B,C,H,W] tensor whose memory is [B,H,W,C] (and not also plain-contiguous, as when C or H*W is 1)."""
+    return t.dim() == 4 and not t.is_contiguous() and t.is_contiguous(memory_format=torch.channels_last)
+
+
 class _PyramidCrop(torch.autograd.Function):
     """All FPN levels in one launch (the callers' per-level loops, lib/layers.py:183-216 and
     lib/sub_module.py:429-662, collapse into a precomputed `level` vector)."""
@@ -74,7 +79,9 @@ class _PyramidCrop(torch.autograd.Function):
         import ctypes
         _lib.require_cuda(boxes, box_ind, level, *maps)
         L = _lib.load()
-        maps = [m.contiguous().float() for m in maps]
+        # maps in torch.channels_last memory format ([B,H,W,C] in memory) take the channels-last kernels
+        cl = all(_is_channels_last(m) for m in maps)
+        maps = [m.float() if cl else m.contiguous().float() for m in maps]
         nl = len(maps)
         B, C = maps[0].shape[:2]
         boxes_c = boxes.detach().contiguous().float()
@@ -86,13 +93,15 @@ class _PyramidCrop(torch.autograd.Function):
         ptrs = (ctypes.c_void_p * nl)(*[m.data_ptr() for m in maps])
         hs = (ctypes.c_int * nl)(*[m.shape[2] for m in maps])
         ws = (ctypes.c_int * nl)(*[m.shape[3] for m in maps])
+        fn = L.fi_pyramid_crop_forward_nhwc if cl else L.fi_pyramid_crop_forward
         with torch.cuda.device(boxes_c.device):
-            _lib.check(L.fi_pyramid_crop_forward(
+            _lib.check(fn(
                 ptrs, hs, ws, nl, _lib.ptr(boxes_c), _lib.ptr(ind_c), _lib.ptr(lvl_c), N, B, C,
                 int(crop_height), int(crop_width), float(extrapolation_value), _lib.ptr(crops),
                 _lib.current_stream()), "fi_pyramid_crop_forward")
+        ctx.channels_last = cl
         if LAUNCH_LOG is not None:
-            LAUNCH_LOG.append({"pyramid": True, "crop": int(crop_height), "depth": int(C), "boxes": boxes_c,
+            LAUNCH_LOG.append({"pyramid": True, "nhwc": cl, "crop": int(crop_height), "depth": int(C), "boxes": boxes_c,
                                "level": lvl_c, "box_ind": ind_c, "shapes": [(m.shape[2], m.shape[3]) for m in maps]})
         ctx.shapes = [tuple(m.shape) for m in maps]
         ctx.crop = (int(crop_height), int(crop_width))
@@ -107,12 +116,14 @@ class _PyramidCrop(torch.autograd.Function):
         g = grad_outputs.contiguous().float()
         nl = len(ctx.shapes)
         B, C = ctx.shapes[0][:2]
-        grads = [torch.empty(s, device=g.device, dtype=torch.float32) for s in ctx.shapes]
+        fmt = torch.channels_last if ctx.channels_last else torch.contiguous_format
+        grads = [torch.empty(s, device=g.device, dtype=torch.float32, memory_format=fmt) for s in ctx.shapes]
         ptrs = (ctypes.c_void_p * nl)(*[t.data_ptr() for t in grads])
         hs = (ctypes.c_int * nl)(*[s[2] for s in ctx.shapes])
         ws = (ctypes.c_int * nl)(*[s[3] for s in ctx.shapes])
+        fn = L.fi_pyramid_crop_backward_nhwc if ctx.channels_last else L.fi_pyramid_crop_backward
         with torch.cuda.device(g.device):
-            _lib.check(L.fi_pyramid_crop_backward(
+            _lib.check(fn(
                 _lib.ptr(g), ptrs, hs, ws, nl, _lib.ptr(boxes_c), _lib.ptr(ind_c), _lib.ptr(lvl_c),
                 boxes_c.shape[0], B, C, ctx.crop[0], ctx.crop[1], _lib.current_stream()),
                 "fi_pyramid_crop_backward")

@@ -4,9 +4,9 @@ of the reference, with identical parameter names (state-dict compatible) and the
 layer arithmetic; the RoI stage is re-designed around the one-launch pyramid RoIAlign
 kernel instead of per-level nonzero / gather / crop / cat / scatter loops.
 
-Dense convolutions currently run on MIOpen through torch (fp32); the MFMA conv path is
-the next step of the build plan.  BatchNorm is always evaluated with running
-statistics, as in the reference where `if mode == 'inference' or 'visualize'` is always
+Dense convolutions run on the fp32 MFMA implicit-GEMM kernels (conv.py / csrc/conv_igemm.hip)
+with eval-BN, shortcut and ReLU folded into the epilogue.  BatchNorm is always evaluated with
+running statistics, as in the reference where `if mode == 'inference' or 'visualize'` is always
 true (lib/model.py:265-267).
 """
 import math
@@ -251,9 +251,8 @@ class Dev(nn.Module):
     def _feat_extract(self, v):
         fe = self.feat_extract
         v = conv_bn_act(v, fe[0], fe[1], relu=True)
-        for i in range(3, len(fe)):
-            v = fe[i](v)
-        return v
+        v = conv_bn_act(v, fe[3], fe[4], relu=True)      # full-window conv: library GEMM + affine BN
+        return conv_bn_act(v, fe[6], fe[7], relu=True)
 
     @staticmethod
     def _find_big_box2(level, roi_lvl):
@@ -382,8 +381,8 @@ class Classifier(nn.Module):
         self.linear_bbox = nn.Linear(1024, num_classes * 4)
 
     def forward(self, x, small_feat_input=None, small_gt_index=None, mode='train'):
-        x = self.relu(self.bn1(self.conv1(x)))
-        x = self.relu(self.bn2(self.conv2(x)))
+        x = conv_bn_act(x, self.conv1, self.bn1, relu=True)
+        x = conv_bn_act(x, self.conv2, self.bn2, relu=True)
         x = x.view(-1, 1024)
         logits = self.linear_class(x)
         probs = self.softmax(logits)

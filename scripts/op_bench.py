@@ -62,7 +62,7 @@ def unique_taps_bytes(oracle_taps, C):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--ops", default="crop,cropbwd,pyramid,roipool,nms,sinkhorn,classmean")
+    ap.add_argument("--ops", default="crop,cropbwd,pyramid,nhwc,roipool,nms,sinkhorn,classmean")
     ap.add_argument("--iters", type=int, default=50)
     args = ap.parse_args()
     ops = args.ops.split(",")
@@ -117,6 +117,45 @@ def main():
                               "levels": np.bincount(lv.cpu().numpy(), minlength=6)[2:].tolist(),
                               "us_median": med * 1e6, "us_best": best * 1e6,
                               "GBps_write_only": 4 * r4.shape[0] * 256 * crop * crop / med / 1e9}))
+
+    if "nhwc" in ops:
+        # channels-last maps: north-star shape on ONE map (B_min from the oracle's tap table) and the
+        # step's pyramid launch, forward and backward
+        image_cl = image.contiguous(memory_format=torch.channels_last)
+        lv1 = torch.full((N,), 2, device=DEV, dtype=torch.int32)
+        for crop in (7, 14):
+            out_bytes = 4 * N * C * crop * crop
+            taps = O.crop_taps(rois_np, S, S, crop, crop)
+            b_min = out_bytes + unique_taps_bytes(taps, C) + 20 * N
+            med, best = timeit(lambda: pyramid_crop_and_resize([image_cl], rois, ind, lv1, crop, crop), args.iters,
+                               kernel="crop_fwd_nhwc_%dx%d" % (crop, crop))
+            k = KERNEL_US[0] * 1e-6
+            print(json.dumps({"op": "crop_and_resize_fwd_nhwc", "shape": [N, C, crop, crop], "map": [B, S, S, C],
+                              "us_median": med * 1e6, "kernel_us": k * 1e6, "B_min_MB": b_min / 1e6,
+                              "GBps_Bmin": b_min / k / 1e9, "frac_hbm_Bmin": b_min / k / HBM_PEAK}))
+            img = image_cl.clone(memory_format=torch.channels_last).requires_grad_(True)
+            out = pyramid_crop_and_resize([img], rois, ind, lv1, crop, crop)
+            g = torch.randn_like(out)
+            med, best = timeit(lambda: torch.autograd.grad(out, img, g, retain_graph=True), args.iters,
+                               kernel="crop_bwd_nhwc_%dx%d" % (crop, crop))
+            print(json.dumps({"op": "crop_and_resize_bwd_nhwc(+memset)", "shape": [N, C, crop, crop],
+                              "us_median": med * 1e6, "kernel_us": KERNEL_US[0]}))
+        maps = [torch.randn(4, 256, s, s, device=DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+                for s in (256, 128, 64, 32)]
+        r4 = torch.from_numpy(training_rois(rs, 4, 512).reshape(-1, 4)).to(DEV)
+        i4 = torch.arange(4, dtype=torch.int32, device=DEV).repeat_interleave(512)
+        lv = roi_level(r4, 1024 * 1024)
+        for crop in (7, 14):
+            med, best = timeit(lambda: pyramid_crop_and_resize(maps, r4, i4, lv, crop, crop), args.iters,
+                               kernel="crop_fwd_nhwc_%dx%d" % (crop, crop))
+            kf = KERNEL_US[0]
+            out = pyramid_crop_and_resize(maps, r4, i4, lv, crop, crop)
+            g = torch.randn_like(out)
+            medb, _ = timeit(lambda: torch.autograd.grad(out, maps, g, retain_graph=True), args.iters,
+                             kernel="crop_bwd_nhwc_%dx%d" % (crop, crop))
+            print(json.dumps({"op": "pyramid_crop_nhwc", "shape": [r4.shape[0], 256, crop, crop],
+                              "fwd_kernel_us": kf, "fwd_us_median": med * 1e6,
+                              "bwd_kernel_us": KERNEL_US[0], "bwd_us_median(+memset)": medb * 1e6}))
 
     if "roipool" in ops:
         pix = torch.cat([ind.float().view(-1, 1), rois[:, [1, 0, 3, 2]] * 1024.0], 1).contiguous()

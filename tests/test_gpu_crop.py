@@ -195,6 +195,67 @@ def test_pyramid_matches_per_level_oracle(oracle):
             assert np.max(np.abs(g - e)) <= 2e-5 * (np.abs(e).max() + 1e-6)
 
 
+@pytest.mark.parametrize("C,crops", [(16, (7, 14)), (256, (7, 14)), (200, (7, 5)), (64, (1, 12))])
+def test_pyramid_channels_last_matches_per_level_oracle(oracle, C, crops):
+    """Maps in torch.channels_last memory format ([B,H,W,C]) take fi_pyramid_crop_*_nhwc: forward
+    BIT-EXACT vs the oracle (and hence vs the NCHW kernels), backward within the atomics tolerance,
+    gradients returned in channels_last."""
+    from feature_intertwiner_amd.roi_align.crop_and_resize import LAUNCH_LOG, pyramid_crop_and_resize
+    import feature_intertwiner_amd.roi_align.crop_and_resize as mod
+    rs = np.random.RandomState(32 + C)
+    B = 2
+    maps = [rs.standard_normal((B, C, s, s)).astype(np.float32) for s in (64, 32, 16, 8)]
+    N = 200
+    boxes = adversarial_boxes(rs, N, 64, 64)
+    ind = rs.randint(0, B, N).astype(np.int32)
+    ind[5] = B + 3                                  # bad image index -> zero row
+    level = rs.randint(1, 7, N).astype(np.int32)    # includes out-of-pyramid levels 1 and 6
+    tm = [torch.from_numpy(m).to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True) for m in maps]
+    assert not tm[0].is_contiguous()
+    for crop in crops:
+        mod.LAUNCH_LOG = []
+        out = pyramid_crop_and_resize(tm, torch.from_numpy(boxes).to(DEV), torch.from_numpy(ind).to(DEV),
+                                      torch.from_numpy(level).to(DEV), crop, crop)
+        assert mod.LAUNCH_LOG[-1]["nhwc"] is True
+        mod.LAUNCH_LOG = None
+        assert out.is_contiguous() and out.shape == (N, C, crop, crop)
+        got = out.detach().cpu().numpy()
+        exp = np.zeros_like(got)
+        good = (ind >= 0) & (ind < B)
+        for l in range(2, 6):
+            sel = np.nonzero((level == l) & good)[0]
+            if len(sel):
+                exp[sel] = oracle.crop_and_resize_forward(maps[l - 2], boxes[sel], ind[sel], crop, crop, 0.0)
+        assert np.array_equal(_bits(got), _bits(exp))
+        G = rs.standard_normal(got.shape).astype(np.float32)
+        for t in tm:
+            t.grad = None
+        out.backward(torch.from_numpy(G).to(DEV))
+        for l in range(2, 6):
+            sel = np.nonzero((level == l) & good)[0]
+            e = oracle.crop_and_resize_backward(G[sel], boxes[sel], ind[sel], maps[l - 2].shape)
+            assert tm[l - 2].grad.is_contiguous(memory_format=torch.channels_last)
+            g = tm[l - 2].grad.cpu().numpy()
+            assert np.max(np.abs(g - e)) <= 2e-5 * (np.abs(e).max() + 1e-6)
+
+
+def test_channels_last_full_size_equals_nchw_bitwise():
+    """North-star shape 512 x 256 x 7 x 7 (and 14 x 14): the two layouts give identical bits."""
+    from feature_intertwiner_amd.roi_align.crop_and_resize import pyramid_crop_and_resize
+    rs = np.random.RandomState(9)
+    B, C = 2, 256
+    maps = [torch.randn(B, C, s, s, device=DEV) for s in (128, 64, 32, 16)]
+    maps_cl = [m.contiguous(memory_format=torch.channels_last) for m in maps]
+    rois = torch.from_numpy(training_rois(rs, B, 256).reshape(-1, 4)).to(DEV)
+    ind = torch.arange(B, device=DEV, dtype=torch.int32).repeat_interleave(256)
+    from feature_intertwiner_amd.intertwiner import roi_level
+    level = roi_level(rois, 512.0 * 512.0)
+    for crop in (7, 14):
+        a = pyramid_crop_and_resize(maps, rois, ind, level, crop, crop)
+        b = pyramid_crop_and_resize(maps_cl, rois, ind, level, crop, crop)
+        assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+
+
 def test_roi_align_module_matches_oracle(oracle):
     from feature_intertwiner_amd.roi_align.roi_align import RoIAlign
     rs = np.random.RandomState(4)
