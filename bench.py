@@ -219,15 +219,22 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         value = global_batch * args.steps / elapsed
         # ---- roofline of the RoIAlign 7x7 forward kernel ---------------------------------
-        n7, ms7 = _lib.prof_get("crop_fwd_7x7")
-        fwd7 = [e for e in log if e["crop"] == 7 and e["pyramid"]]
+        # (the Dev stage's maps are channels-last: crop_fwd_cl_kernel<7, 7>; NCHW kernel otherwise)
+        n7, ms7 = _lib.prof_get("crop_fwd_nhwc_7x7")
+        fwd7 = [e for e in log if e["crop"] == 7 and e["pyramid"] and e.get("nhwc")]
+        roi_kernel = "crop_fwd_nhwc_7x7"
+        if not (n7 and fwd7):
+            n7, ms7 = _lib.prof_get("crop_fwd_7x7")
+            fwd7 = [e for e in log if e["crop"] == 7 and e["pyramid"] and not e.get("nhwc")]
+            roi_kernel = "crop_fwd_7x7"
         roof_roi = None
         if n7 and fwd7:
             e = fwd7[-1]
             b_alg = crop_algorithmic_bytes(e)
             dur = ms7 / n7 * 1e-3
             ach = b_alg / dur / 1e9
-            roof_roi = {"kernel": "crop_fwd_kernel<7, 7>", "bound": "hbm", "achieved": round(ach, 1),
+            roof_roi = {"kernel": _lib.kernel_name(roi_kernel), "map_layout": "NHWC" if e.get("nhwc") else "NCHW",
+                    "bound": "hbm", "achieved": round(ach, 1),
                     "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4),
                     "traffic": None, "algorithmic_bytes_per_launch": int(b_alg),
                     "avg_launch_us": round(dur * 1e6, 2), "launches_timed": n7,

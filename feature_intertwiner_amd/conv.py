@@ -32,9 +32,12 @@ def _log_flops(kind, cout, R, S, flops, pixels=None):
         e[1] += flops
 
 
-def _conv_fwd(x, w, b, stride, padding, relu=False, scale=None, residual=None, out_hw=None):
+def _conv_fwd(x, w, b, stride, padding, relu=False, scale=None, residual=None, out_hw=None,
+              out_channels_last=False):
     """w is [Cout, Cin, R, S].  When Cin % 16 == 0 the kernel's tap-major fast path is used: the
-    weight is handed over channels-last ([Cout, R, S, Cin]; a copy of at most a few MB)."""
+    weight is handed over channels-last ([Cout, R, S, Cin]; a copy of at most a few MB).
+    out_channels_last: y is returned in torch.channels_last memory format ([N,OH,OW,Cout] in
+    memory, written that way by the kernel epilogue)."""
     L = _lib.load()
     N, Cin, H, W = x.shape
     Cout, _, R, S = w.shape
@@ -48,12 +51,14 @@ def _conv_fwd(x, w, b, stride, padding, relu=False, scale=None, residual=None, o
     if out_hw is not None:
         OH, OW = out_hw
     _log_flops("fwd", Cout, R, S, 2 * N * Cout * OH * OW * Cin * R * S, N * OH * OW)
-    y = torch.empty((N, Cout, OH, OW), device=x.device, dtype=torch.float32)
+    y = torch.empty((N, Cout, OH, OW), device=x.device, dtype=torch.float32,
+                    memory_format=torch.channels_last if out_channels_last else torch.contiguous_format)
     with torch.cuda.device(x.device):
         _lib.check(L.fi_conv2d_forward(_lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(scale), _lib.ptr(residual),
                                        _lib.ptr(y), N, Cin, H, W, Cout,
                                        R, S, stride[0], stride[1], padding[0], padding[1], 1 if relu else 0,
                                        layout, OH if out_hw is not None else 0, OW if out_hw is not None else 0,
+                                       1 if out_channels_last else 0,
                                        _lib.current_stream()), "fi_conv2d_forward")
     return y
 
@@ -146,7 +151,7 @@ class _ConvBnActFn(torch.autograd.Function):
     elementwise/reduction pass (fi_bn_act_backward) + the conv dgrad/wgrad kernels."""
 
     @staticmethod
-    def forward(ctx, x, w, b, gamma, beta, mean, var, eps, residual, relu, stride, padding):
+    def forward(ctx, x, w, b, gamma, beta, mean, var, eps, residual, relu, stride, padding, out_cl=False):
         _lib.require_cuda(x, w)
         x = x.contiguous().float()
         w = w.contiguous().float()
@@ -155,7 +160,9 @@ class _ConvBnActFn(torch.autograd.Function):
         if b is not None:
             shift = shift + b * scale
         res = residual.contiguous().float() if residual is not None else None
-        y = _conv_fwd(x, w, shift.contiguous(), stride, padding, relu=relu, scale=scale.contiguous(), residual=res)
+        y = _conv_fwd(x, w, shift.contiguous(), stride, padding, relu=relu, scale=scale.contiguous(), residual=res,
+                      out_channels_last=out_cl)
+        ctx.out_cl = bool(out_cl)
         ctx.save_for_backward(x, w, y, scale, gamma, beta, res)
         ctx.conf = (tuple(stride), tuple(padding), b is not None, bool(relu), residual is not None, eps, mean, var)
         return y
@@ -165,9 +172,11 @@ class _ConvBnActFn(torch.autograd.Function):
         x, w, y, scale, gamma, beta, res = ctx.saved_tensors
         stride, padding, has_bias, relu, has_res, eps, mean, var = ctx.conf
         L = _lib.load()
-        dy = dy.contiguous().float()
+        # channels-last output: the gradient comes back channels-last from the RoIAlign backward and is
+        # transposed to NCHW inside the fused pass (dz feeds the NCHW dgrad / wgrad kernels)
+        dy = dy.float().contiguous(memory_format=torch.channels_last) if ctx.out_cl else dy.contiguous().float()
         N, C, OH, OW = y.shape
-        dz = torch.empty_like(y)
+        dz = torch.empty(y.shape, device=y.device, dtype=torch.float32)
         g_res = torch.empty_like(y) if (has_res and ctx.needs_input_grad[8]) else None
         dshift = torch.empty(C, device=y.device, dtype=torch.float32)
         dgamma = torch.empty(C, device=y.device, dtype=torch.float32) if ctx.needs_input_grad[3] else None
@@ -176,17 +185,19 @@ class _ConvBnActFn(torch.autograd.Function):
                                             _lib.ptr(beta), _lib.ptr(res), N, C, OH * OW, 1 if relu else 0,
                                             _lib.ptr(dz),
                                             _lib.ptr(g_res), _lib.ptr(dshift), _lib.ptr(dgamma),
+                                            1 if ctx.out_cl else 0,
                                             _lib.current_stream()), "fi_bn_act_backward")
         dx, dw = _conv_backward(ctx.needs_input_grad, x, w, dz, stride, padding)
         db = dshift * scale if (has_bias and ctx.needs_input_grad[2]) else None
         dbeta = dshift if ctx.needs_input_grad[4] else None
-        return dx, dw, db, dgamma, dbeta, None, None, None, g_res, None, None, None
+        return dx, dw, db, dgamma, dbeta, None, None, None, g_res, None, None, None, None
 
 
-def conv_bn_act(x, conv, bn, relu=True, residual=None):
+def conv_bn_act(x, conv, bn, relu=True, residual=None, channels_last_out=False):
     """act(bn(conv(x)) [+ residual]) for an eval-mode BatchNorm2d (the reference always evaluates
     BN with running statistics, lib/model.py:265-267).  Falls back to separate ops for a BN in
-    training mode or a full-window (GEMM) convolution."""
+    training mode or a full-window (GEMM) convolution.  channels_last_out: return the result in
+    torch.channels_last memory format (for maps that only the channels-last RoIAlign reads)."""
     R, S = conv.weight.shape[2], conv.weight.shape[3]
     gemm_path = ((x.shape[2], x.shape[3]) == (R, S) and tuple(conv.padding) == (0, 0)) or x.shape[2] * x.shape[3] == 1
     if bn.training or gemm_path or not bn.track_running_stats:
@@ -198,9 +209,12 @@ def conv_bn_act(x, conv, bn, relu=True, residual=None):
             y = bn(conv(x))
         if residual is not None:
             y = y + residual
-        return F.relu(y) if relu else y
-    return _ConvBnActFn.apply(x, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                              bn.eps, residual, relu, tuple(conv.stride), tuple(conv.padding))
+        y = F.relu(y) if relu else y
+        return y.contiguous(memory_format=torch.channels_last) if channels_last_out else y
+    out_cl = bool(channels_last_out) and residual is None and conv.weight.shape[0] % 4 == 0
+    y = _ConvBnActFn.apply(x, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                           bn.eps, residual, relu, tuple(conv.stride), tuple(conv.padding), out_cl)
+    return y.contiguous(memory_format=torch.channels_last) if (channels_last_out and not out_cl) else y
 
 
 def conv2d(x, weight, bias=None, stride=(1, 1), padding=(0, 0)):

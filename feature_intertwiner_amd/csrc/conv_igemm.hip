@@ -27,6 +27,7 @@
 // The data gradient of a stride-1 convolution is the same kernel run on dY with the
 // flipped, transposed weights and padding R-1-pad.  The weight gradient is a second GEMM
 // with the reduction over pixels (split across workgroups, fp32 atomics into dW).
+#include <stdint.h>
 #include <stdlib.h>
 
 #include "fi_common.h"
@@ -56,6 +57,7 @@ struct ConvGeom {
     int N, Cin, H, W, Cout, R, S, sh, sw, ph, pw, OH, OW;
     int K;        // Cin*R*S
     int P;        // N*OH*OW
+    int out_nhwc; // 1: y is [N][OH][OW][Cout] (channels-last), else [N][Cout][OH][OW]
     unsigned mul_ohw, sft_ohw, mul_ow, sft_ow;   // magic numbers: n / d == umulhi(n, mul) >> sft
 };
 
@@ -110,7 +112,7 @@ __device__ __forceinline__ void mma_tile(const float (*__restrict__ As)[BM + PAD
 // [Cout][R][S][Cin] (requires Cin % BK == 0).  A K-step then has ONE tap and BK consecutive
 // channels, so the halo test is a bit test of a per-thread tap mask and the gather address is
 // base + i*2*H*W: ~3 instructions per load instead of ~35 for the (ci, r, s) order.
-template <int BM, int TR, int TS, bool HWC>
+template <int BM, int TR, int TS, bool HWC, bool ONHWC = false>
 __global__ __launch_bounds__(kThreads) void conv_fwd_kernel(const float *__restrict__ x,
                                                             const float *__restrict__ w,
                                                             Epilogue ep,
@@ -258,6 +260,36 @@ __global__ __launch_bounds__(kThreads) void conv_fwd_kernel(const float *__restr
     }
 
     // ---- epilogue: C/D layout col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5) ------
+    if (ONHWC) {     // a separate instantiation: the wider stores must not raise the NCHW kernel's VGPR count
+        // channels-last output: a lane owns 4 consecutive channels (e & 3) of its pixel -> one 16-byte
+        // store; lanes l and l+32 are adjacent (32 bytes), the 4 e-groups x MT tiles complete the
+        // 128..256-byte channel run of the pixel within this wavefront (merged in L2).
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int pp = p0 + wn * 64 + j * 32 + l31;
+            if (pp >= g.P) continue;
+            float *__restrict__ yb = y + (size_t)pp * g.Cout;
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int eg = 0; eg < 4; ++eg) {
+                    const int m = m0 + wm * (BM / 2) + i * 32 + 8 * eg + 4 * khalf;
+                    if (m < g.Cout) {            // Cout % 4 == 0 (checked by the launcher)
+                        float v[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            v[q] = acc[i][j][eg * 4 + q];
+                            if (ep.scale) v[q] = v[q] * ep.scale[m + q];
+                            if (ep.bias) v[q] += ep.bias[m + q];
+                            if (ep.relu) v[q] = fmaxf(v[q], 0.0f);
+                        }
+                        *reinterpret_cast<float4 *>(yb + m) = make_float4(v[0], v[1], v[2], v[3]);
+                        __builtin_amdgcn_sched_barrier(0);     // one group at a time: keeps the accumulators in AGPRs
+                    }
+                }
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int pp = p0 + wn * 64 + j * 32 + l31;
@@ -615,6 +647,7 @@ int make_geom(ConvGeom &g, int N, int Cin, int H, int W, int Cout, int R, int S,
     FI_REQUIRE(R >= 1 && S >= 1 && sh >= 1 && sw >= 1 && ph >= 0 && pw >= 0, "bad window");
     g.N = N; g.Cin = Cin; g.H = H; g.W = W; g.Cout = Cout; g.R = R; g.S = S;
     g.sh = sh; g.sw = sw; g.ph = ph; g.pw = pw;
+    g.out_nhwc = 0;
     g.OH = out_h > 0 ? out_h : (H + 2 * ph - R) / sh + 1;   // explicit size: taps past the input read zeros
     g.OW = out_w > 0 ? out_w : (W + 2 * pw - S) / sw + 1;
     FI_REQUIRE(g.OH >= 1 && g.OW >= 1, "empty output");
@@ -647,13 +680,22 @@ void launch_fwd(const ConvGeom &g, const float *x, const float *w, const Epilogu
 {
     dim3 grid(fi::ceil_div(g.P, BN), fi::ceil_div(g.Cout, BM));
     static const int wave_mode = getenv("FI_CONV_WAVE") ? atoi(getenv("FI_CONV_WAVE")) : 0;
-    if (hwc && wave_mode) {
+    if (hwc && wave_mode && !g.out_nhwc) {
         if (g.R == 3 && g.S == 3)
             hipLaunchKernelGGL((conv_fwd_wave_kernel<BM / 2, 3, 3>), grid, dim3(kThreads), 0, st, x, w, ep, y, g);
         else if (g.R == 1 && g.S == 1)
             hipLaunchKernelGGL((conv_fwd_wave_kernel<BM / 2, 1, 1>), grid, dim3(kThreads), 0, st, x, w, ep, y, g);
         else
             hipLaunchKernelGGL((conv_fwd_wave_kernel<BM / 2, 0, 0>), grid, dim3(kThreads), 0, st, x, w, ep, y, g);
+        return;
+    }
+    if (hwc && g.out_nhwc) {
+        if (g.R == 3 && g.S == 3)
+            hipLaunchKernelGGL((conv_fwd_kernel<BM, 3, 3, true, true>), grid, dim3(kThreads), 0, st, x, w, ep, y, g);
+        else if (g.R == 1 && g.S == 1)
+            hipLaunchKernelGGL((conv_fwd_kernel<BM, 1, 1, true, true>), grid, dim3(kThreads), 0, st, x, w, ep, y, g);
+        else
+            hipLaunchKernelGGL((conv_fwd_kernel<BM, 0, 0, true, true>), grid, dim3(kThreads), 0, st, x, w, ep, y, g);
         return;
     }
     if (hwc) {
@@ -780,6 +822,75 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const float *__restrict
     }
 }
 
+// Channels-last variant: dy and y are [N*HW][C] (the gradient arrives from the channels-last
+// RoIAlign backward, y was written channels-last by the conv epilogue); dz leaves as [N][C][HW]
+// for the dgrad / wgrad kernels.  64 pixels x 64 channels are transposed through LDS per step:
+// reads run along channels, writes along pixels, both as 256-byte wavefront accesses.
+__global__ __launch_bounds__(256) void bn_act_bwd_cl_kernel(const float *__restrict__ dy,
+                                                            const float *__restrict__ y,
+                                                            const float *__restrict__ scale,
+                                                            const float *__restrict__ gamma,
+                                                            const float *__restrict__ beta, int P, int C,
+                                                            int HW, int relu, float *__restrict__ dz,
+                                                            float *__restrict__ dshift,
+                                                            float *__restrict__ dgamma, int tiles_per_block)
+{
+    __shared__ float s_t[64][65];
+    __shared__ float s_a[4][64], s_b[4][64];
+    const int c0 = blockIdx.x * 64;
+    const int lane = threadIdx.x & 63;
+    const int row = threadIdx.x >> 6;          // 0..3
+    const int c = c0 + lane;
+    const bool c_ok = c < C;
+    const float sc = c_ok ? scale[c] : 0.0f;
+    const float be = (c_ok && beta) ? beta[c] : 0.0f;
+    float sum_g = 0.0f, sum_gy = 0.0f;
+    const int t0 = blockIdx.y * tiles_per_block;
+    for (int t = t0; t < t0 + tiles_per_block; ++t) {
+        const int pbase = t * 64;
+        if (pbase >= P) break;
+#pragma unroll 4
+        for (int i = 0; i < 16; ++i) {
+            const int pl = row + 4 * i;
+            const int pix = pbase + pl;
+            float o = 0.0f;
+            if (c_ok && pix < P) {
+                const float d = dy[(size_t)pix * C + c];
+                const float v = y[(size_t)pix * C + c];
+                const float gq = (!relu || v > 0.0f) ? d : 0.0f;
+                sum_g += gq;
+                sum_gy += gq * (v - be);
+                o = gq * sc;
+            }
+            s_t[lane][pl] = o;
+        }
+        __syncthreads();
+        const int pix = pbase + lane;
+        if (pix < P) {
+            const int n = pix / HW;
+            const int q = pix - n * HW;
+#pragma unroll 4
+            for (int j = 0; j < 16; ++j) {
+                const int cc = row + 4 * j;
+                if (c0 + cc < C) dz[((size_t)n * C + c0 + cc) * HW + q] = s_t[cc][lane];
+            }
+        }
+        __syncthreads();
+    }
+    s_a[row][lane] = sum_g;
+    s_b[row][lane] = sum_gy;
+    __syncthreads();
+    if (row == 0 && c_ok) {
+        const float a = (s_a[0][lane] + s_a[1][lane]) + (s_a[2][lane] + s_a[3][lane]);
+        const float b = (s_b[0][lane] + s_b[1][lane]) + (s_b[2][lane] + s_b[3][lane]);
+        atomicAdd(dshift + c, a);
+        if (dgamma) {
+            const float ga = gamma[c];
+            atomicAdd(dgamma + c, ga != 0.0f ? b / ga : 0.0f);
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -787,12 +898,20 @@ extern "C" {
 int fi_conv2d_forward(const float *x, const float *weight, const float *bias, const float *scale,
                       const float *residual, float *y, int N, int Cin, int H, int W, int Cout, int R,
                       int S, int stride_h, int stride_w, int pad_h, int pad_w, int relu,
-                      int weight_layout, int out_h, int out_w, fi_stream_t stream)
+                      int weight_layout, int out_h, int out_w, int output_layout, fi_stream_t stream)
 {
     ConvGeom g;
     int rc = make_geom(g, N, Cin, H, W, Cout, R, S, stride_h, stride_w, pad_h, pad_w, out_h, out_w);
     if (rc != FI_OK) return rc;
     FI_REQUIRE(x && weight && y, "null pointer");
+    FI_REQUIRE(output_layout == 0 || output_layout == 1, "output_layout: 0 = [N][Cout][OH][OW], 1 = [N][OH][OW][Cout]");
+    if (output_layout == 1) {
+        FI_REQUIRE(Cout % 4 == 0 && residual == nullptr && (uintptr_t)y % 16 == 0,
+                   "channels-last output needs Cout % 4 == 0, a 16-byte aligned y and no fused residual");
+        FI_REQUIRE(Cin % BK == 0 && R * S <= 64 && (weight_layout == 1 || R * S == 1),
+                   "channels-last output is implemented on the tap-major path (Cin % 16 == 0, weight_layout 1)");
+        g.out_nhwc = 1;
+    }
     FI_REQUIRE(weight_layout == 0 || weight_layout == 1, "weight_layout: 0 = [Cout][Cin][R][S], 1 = [Cout][R][S][Cin]");
     // tap-major fast path: channels-last weights (any 1x1 weight is both layouts at once)
     const bool hwc = (Cin % BK == 0) && (R * S <= 64) && (weight_layout == 1 || R * S == 1);
@@ -814,14 +933,30 @@ int fi_conv2d_forward(const float *x, const float *weight, const float *bias, co
 
 int fi_bn_act_backward(const float *dy, const float *y, const float *scale, const float *gamma,
                        const float *beta, const float *residual, int N, int C, int HW, int relu,
-                       float *dz, float *g_out, float *dshift, float *dgamma, fi_stream_t stream)
+                       float *dz, float *g_out, float *dshift, float *dgamma, int layout,
+                       fi_stream_t stream)
 {
     FI_REQUIRE(N >= 1 && C >= 1 && HW >= 1, "sizes must be positive");
     FI_REQUIRE(dy && y && scale && dz && dshift, "null pointer");
     FI_REQUIRE(!dgamma || gamma, "dgamma needs gamma");
+    FI_REQUIRE(layout == 0 || layout == 1, "layout: 0 = dy,y [N][C][HW], 1 = dy,y [N][HW][C]");
     hipStream_t st = (hipStream_t)stream;
     FI_HIP_CHECK(hipMemsetAsync(dshift, 0, sizeof(float) * C, st));
     if (dgamma) FI_HIP_CHECK(hipMemsetAsync(dgamma, 0, sizeof(float) * C, st));
+    if (layout == 1) {
+        FI_REQUIRE(residual == nullptr && g_out == nullptr, "channels-last backward has no fused residual");
+        FI_REQUIRE((long)N * HW < 2147483647L, "too many pixels");
+        const int P = N * HW;
+        const int tiles = fi::ceil_div(P, 64);
+        const int cblk = fi::ceil_div(C, 64);
+        int tpb = fi::ceil_div(tiles * cblk, 2048);          // ~2048 workgroups
+        if (tpb < 1) tpb = 1;
+        fi::ProfScope prof(FI_K_BN_ACT_BWD, st);
+        hipLaunchKernelGGL(bn_act_bwd_cl_kernel, dim3(cblk, fi::ceil_div(tiles, tpb)), dim3(256), 0, st, dy, y,
+                           scale, gamma, beta, P, C, HW, relu, dz, dshift, dgamma, tpb);
+        FI_HIP_CHECK(hipGetLastError());
+        return FI_OK;
+    }
     // enough workgroups to fill the chip: C * chunks >= ~2048
     int chunks = fi::ceil_div(2048, C);
     if (chunks > N) chunks = N;

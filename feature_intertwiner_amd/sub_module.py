@@ -295,7 +295,9 @@ class Dev(nn.Module):
         def make_up(i, m):
             seq = self.upsample[i if cfg.DEV.MULTI_UPSAMPLER else 0]
             if isinstance(seq[0], Conv2d):
-                return conv_bn_act(m, seq[0], seq[1], relu=True)
+                # these maps feed only the two crops below: written channels-last by the conv epilogue so
+                # that RoIAlign reads (and its backward adds) whole cache lines per tap
+                return conv_bn_act(m, seq[0], seq[1], relu=True, channels_last_out=(self.roi_type == 'roi_align'))
             return seq(m)
         up_maps = [make_up(i, m) for i, m in enumerate(x)]
         pooled = self._crop(up_maps, boxes, box_ind, level, self.pool_size)

@@ -234,6 +234,8 @@ int fi_class_mean_backward(const float *grad_feat, const int32_t *gt,
  * zeros) -- used by the strided data gradient, which is a set of stride-1 correlations.
  * weight_layout 0: weight is [Cout,Cin,R,S] (as stored by the model); 1: [Cout,R,S,Cin]
  * (tap-major / channels-last; needs Cin % 16 == 0) -- selects the fast gather path.
+ * output_layout 0: y is [N,Cout,OH,OW]; 1: y is [N,OH,OW,Cout] (channels-last; Cout % 4 == 0, no
+ * residual) -- used for the maps that only the channels-last RoIAlign consumes.
  * The data gradient of a stride-1 convolution is this same call on dY with the flipped,
  * transposed weight [Cin,Cout,R,S] and padding R-1-pad.
  * fi_conv2d_weight_grad: dweight [Cout,Cin,R,S] = sum over images and pixels of
@@ -244,14 +246,16 @@ int fi_conv2d_forward(const float *x, const float *weight, const float *bias,
                       const float *scale, const float *residual, float *y, int N, int Cin,
                       int H, int W, int Cout, int R, int S, int stride_h, int stride_w,
                       int pad_h, int pad_w, int relu, int weight_layout, int out_h, int out_w,
-                      fi_stream_t stream);
+                      int output_layout, fi_stream_t stream);
 /* Backward of that fused epilogue (eval-mode BatchNorm folded into scale/shift, optional ReLU):
  * g = dy * (y > 0 | 1); dz = g * scale[c]; dshift[c] = sum g; dgamma[c] = sum g*(y-beta[c])/gamma[c].
+ * layout 1: dy and y are channels-last [N,HW,C] (dz is still written [N,C,HW]; no residual/g_out).
  * dy, y, dz, g_out are [N,C,HW]; g_out (optional) receives g (the gradient of a fused residual);
  * residual (optional) is the shortcut that was added in the epilogue (y - residual = BN output). */
 int fi_bn_act_backward(const float *dy, const float *y, const float *scale, const float *gamma,
                        const float *beta, const float *residual, int N, int C, int HW, int relu,
-                       float *dz, float *g_out, float *dshift, float *dgamma, fi_stream_t stream);
+                       float *dz, float *g_out, float *dshift, float *dgamma, int layout,
+                       fi_stream_t stream);
 int fi_conv2d_weight_grad(const float *x, const float *dy, float *dweight, int N, int Cin,
                           int H, int W, int Cout, int R, int S, int stride_h, int stride_w,
                           int pad_h, int pad_w, int weight_layout, fi_stream_t stream);

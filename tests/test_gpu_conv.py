@@ -133,3 +133,35 @@ def test_fused_conv_bn_act_matches_separate_ops(relu, res):
         pairs.append((rg.grad, rd.grad))
     for a, b in pairs:
         assert torch.allclose(a.cpu().double(), b, rtol=2e-4, atol=2e-4), (a.shape,)
+
+
+@pytest.mark.parametrize("shape", [(2, 32, 24, 20, 64), (3, 16, 9, 7, 36), (1, 64, 16, 16, 256)])
+def test_channels_last_output_matches_nchw(shape):
+    """conv + eval-BN + ReLU written channels-last by the epilogue (output_layout = 1) and its
+    backward through fi_bn_act_backward(layout = 1): values identical to the NCHW path, gradients
+    equal up to the summation order of the per-channel reductions."""
+    from feature_intertwiner_amd.conv import Conv2d, conv_bn_act
+    N, Cin, H, W, Cout = shape
+    torch.manual_seed(sum(shape))
+    conv = Conv2d(Cin, Cout, 3, padding=1).to(DEV)
+    bn = torch.nn.BatchNorm2d(Cout).to(DEV).eval()
+    with torch.no_grad():
+        bn.running_mean.normal_(0, 0.2)
+        bn.running_var.uniform_(0.5, 2.0)
+        bn.weight.normal_(1, 0.2)
+        bn.bias.normal_(0, 0.2)
+    x = torch.randn(N, Cin, H, W, device=DEV)
+    g = torch.randn(N, Cout, H, W, device=DEV)
+    res = {}
+    for cl in (False, True):
+        xi = x.clone().requires_grad_(True)
+        for p in list(conv.parameters()) + list(bn.parameters()):
+            p.grad = None
+        y = conv_bn_act(xi, conv, bn, relu=True, channels_last_out=cl)
+        assert y.is_contiguous(memory_format=torch.channels_last) == cl or (H * W == 1)
+        y.backward(g.contiguous(memory_format=torch.channels_last) if cl else g)
+        res[cl] = (y.detach().contiguous(), xi.grad, conv.weight.grad.clone(), conv.bias.grad.clone(),
+                   bn.weight.grad.clone(), bn.bias.grad.clone())
+    assert torch.equal(res[False][0].view(torch.int32), res[True][0].view(torch.int32))
+    for a, b in zip(res[False][1:], res[True][1:]):
+        assert (a - b).abs().max().item() <= 2e-5 * (a.abs().max().item() + 1e-6)
