@@ -42,7 +42,7 @@ constexpr int BN = 128;
 #define FI_CONV_BK 16
 #endif
 constexpr int BK = FI_CONV_BK;
-constexpr int PAD = 4;
+constexpr int PAD = 2;   // row pitch = 2 (mod 32) banks: the transposed tile stores of both kernels are conflict free
 
 // epilogue: y = acc * scale[m] + bias[m] (+ residual) (ReLU) -- scale/bias carry an eval-mode
 // BatchNorm folded by the caller, residual the bottleneck shortcut
@@ -60,6 +60,10 @@ struct ConvGeom {
     int out_nhwc; // 1: y is [N][OH][OW][Cout] (channels-last), else [N][Cout][OH][OW]
     unsigned mul_ohw, sft_ohw, mul_ow, sft_ow;   // magic numbers: n / d == umulhi(n, mul) >> sft
 };
+
+// Out-of-image taps of the tap-major gather read this instead of being masked after the load:
+// the loaded registers go to LDS untouched (no per-value select in the K loop).
+__device__ float g_zero_page[64];
 
 // exact for 0 <= n < 2^31 (mul = ceil(2^(32+sft) / d), 32 + sft = 31 + ceil(log2 d))
 __device__ __forceinline__ int fast_div(int n, unsigned mul, unsigned sft)
@@ -112,8 +116,10 @@ __device__ __forceinline__ void mma_tile(const float (*__restrict__ As)[BM + PAD
 // [Cout][R][S][Cin] (requires Cin % BK == 0).  A K-step then has ONE tap and BK consecutive
 // channels, so the halo test is a bit test of a per-thread tap mask and the gather address is
 // base + i*2*H*W: ~3 instructions per load instead of ~35 for the (ci, r, s) order.
+// 4 wavefronts per SIMD (<= 128 VGPRs, accumulators included): 1024 resident workgroups, so the
+// 4096 / 8192-tile grids of the P2-level layers run as whole waves of workgroups instead of 5.33
 template <int BM, int TR, int TS, bool HWC, bool ONHWC = false>
-__global__ __launch_bounds__(kThreads) void conv_fwd_kernel(const float *__restrict__ x,
+__global__ __launch_bounds__(kThreads, (BM <= 128 ? 4 : 1)) void conv_fwd_kernel(const float *__restrict__ x,
                                                             const float *__restrict__ w,
                                                             Epilogue ep,
                                                             float *__restrict__ y, ConvGeom g)
@@ -177,10 +183,23 @@ __global__ __launch_bounds__(kThreads) void conv_fwd_kernel(const float *__restr
         }
     }
 
+    // tap-major path: K % BK == 0, so a weight load is never partial; rows past Cout re-read the last
+    // row (their accumulators are never stored) -- branch-free, unconditional 16-byte loads
+    const float *__restrict__ a_row[A_LOADS];
+#pragma unroll
+    for (int i = 0; i < A_LOADS; ++i) a_row[i] = w + (size_t)min(m0 + am + i * A_ROWS, g.Cout - 1) * K + ak4;
+
     auto load_tiles = [&](int kt) {
         const int kbase = kt * BK;
+        if (HWC) {
 #pragma unroll
-        for (int i = 0; i < A_LOADS; ++i) {
+            for (int i = 0; i < A_LOADS; ++i) {
+                const float4 v = *reinterpret_cast<const float4 *>(a_row[i] + kbase);
+                a_reg[i][0] = v.x; a_reg[i][1] = v.y; a_reg[i][2] = v.z; a_reg[i][3] = v.w;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < (HWC ? 0 : A_LOADS); ++i) {
             const int m = m0 + am + i * A_ROWS;
             const int k = kbase + ak4;
             if (m < g.Cout && k_vec && k + 3 < K) {
@@ -199,11 +218,10 @@ __global__ __launch_bounds__(kThreads) void conv_fwd_kernel(const float *__restr
             const int r = rs / S, s = rs - (rs / S) * S;
             const bool ok = (tap_mask >> rs) & 1ULL;
             const int off0 = pix_off + r * g.W + s + (cur_ci0 + bk0) * HW;
-            const int base = ok ? off0 : 0;
+            const float *__restrict__ bp = ok ? (xn + off0) : g_zero_page;
             const int stride = ok ? 2 * HW : 0;
 #pragma unroll
-            for (int i = 0; i < BK / 2; ++i) b_reg[i] = xn[base + i * stride];
-            b_mask = ok ? 0xffffffffu : 0u;
+            for (int i = 0; i < BK / 2; ++i) b_reg[i] = bp[i * stride];
             cur_ci0 += BK;
             if (cur_ci0 >= g.Cin) {
                 cur_ci0 = 0;
@@ -233,7 +251,8 @@ __global__ __launch_bounds__(kThreads) void conv_fwd_kernel(const float *__restr
 #pragma unroll
             for (int q = 0; q < 4; ++q) As[buf][ak4 + q][am + i * A_ROWS] = a_reg[i][q];
 #pragma unroll
-        for (int i = 0; i < BK / 2; ++i) Bs[buf][bk0 + 2 * i][bj] = ((b_mask >> i) & 1u) ? b_reg[i] : 0.0f;
+        for (int i = 0; i < BK / 2; ++i)
+            Bs[buf][bk0 + 2 * i][bj] = (HWC || ((b_mask >> i) & 1u)) ? b_reg[i] : 0.0f;
     };
 
     f32x16 acc[MT][2];
@@ -553,24 +572,29 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(const float *__res
         const int oh = fast_div(q, g.mul_ow, g.sft_ow);
         const int ow = q - oh * g.OW;
         const float *__restrict__ dyn = dy + (size_t)n * g.Cout * OHW + q;
+        const int ih0 = oh * g.sh - g.ph, iw0 = ow * g.sw - g.pw;
+        const float *__restrict__ xn = x + (size_t)n * g.Cin * HW;
+        const int pix_off = ih0 * g.W + iw0;
+        if (HWC) {
+            // no per-value selects: pixels past the split and taps outside the image read the zero
+            // page; rows past Cout re-read the last row (their sums are never written)
+            const float *__restrict__ ap = ok ? dyn : g_zero_page;
+            const int a_stride = ok ? OHW : 0;
+#pragma unroll
+            for (int i = 0; i < A_LOADS; ++i) a_reg[i] = ap[min(m0 + am + W_COLS * i, g.Cout - 1) * a_stride];
+            const bool inb = ok && ((unsigned)(ih0 + h_r) < (unsigned)g.H) && ((unsigned)(iw0 + h_s) < (unsigned)g.W);
+            const float *__restrict__ bp = inb ? (xn + pix_off + b_off[0]) : g_zero_page;
+            const int stride = inb ? h_stride : 0;
+#pragma unroll
+            for (int i = 0; i < B_LOADS; ++i) b_reg[i] = bp[i * stride];
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < A_LOADS; ++i) {
             const int m = m0 + am + W_COLS * i;
             const bool inm = ok && m < g.Cout;
             a_reg[i] = dyn[inm ? m * OHW : 0];
             a_mask = (i == 0 ? 0u : a_mask) | (inm ? (1u << i) : 0u);
-        }
-        const int ih0 = oh * g.sh - g.ph, iw0 = ow * g.sw - g.pw;
-        const float *__restrict__ xn = x + (size_t)n * g.Cin * HW;
-        const int pix_off = ih0 * g.W + iw0;
-        if (HWC) {
-            const bool inb = ok && ((unsigned)(ih0 + h_r) < (unsigned)g.H) && ((unsigned)(iw0 + h_s) < (unsigned)g.W);
-            const int base = inb ? (pix_off + b_off[0]) : 0;
-            const int stride = inb ? h_stride : 0;
-#pragma unroll
-            for (int i = 0; i < B_LOADS; ++i) b_reg[i] = xn[base + i * stride];
-            b_mask = inb ? 0xffffffffu : 0u;
-            return;
         }
         b_mask = 0;
 #pragma unroll
@@ -583,9 +607,11 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(const float *__res
     };
     auto store_tiles = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < A_LOADS; ++i) As[buf][ap][am + W_COLS * i] = ((a_mask >> i) & 1u) ? a_reg[i] : 0.0f;
+        for (int i = 0; i < A_LOADS; ++i)
+            As[buf][ap][am + W_COLS * i] = (HWC || ((a_mask >> i) & 1u)) ? a_reg[i] : 0.0f;
 #pragma unroll
-        for (int i = 0; i < B_LOADS; ++i) Bs[buf][bp][bk + W_COLS * i] = ((b_mask >> i) & 1u) ? b_reg[i] : 0.0f;
+        for (int i = 0; i < B_LOADS; ++i)
+            Bs[buf][bp][bk + W_COLS * i] = (HWC || ((b_mask >> i) & 1u)) ? b_reg[i] : 0.0f;
     };
 
     f32x16 acc[MT][2];
