@@ -109,6 +109,69 @@ __device__ __forceinline__ void mma_tile(const float (*__restrict__ As)[BM + PAD
 #endif
 }
 
+// Epilogue shared by the forward kernels.  C/D layout of v_mfma_f32_32x32x2_f32:
+// col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5).
+template <int BM, bool ONHWC>
+__device__ __forceinline__ void conv_epilogue(const f32x16 (&acc)[BM / 64][2], const Epilogue &ep,
+                                              float *__restrict__ y, const ConvGeom &g, int m0, int p0,
+                                              int wm, int wn, int l31, int khalf)
+{
+    constexpr int MT = BM / 64;
+    const int OHW = g.OH * g.OW;
+    if (ONHWC) {     // a separate instantiation: the wider stores must not raise the NCHW kernel's VGPR count
+        // channels-last output: a lane owns 4 consecutive channels (e & 3) of its pixel -> one 16-byte
+        // store; lanes l and l+32 are adjacent (32 bytes), the 4 e-groups x MT tiles complete the
+        // 128..256-byte channel run of the pixel within this wavefront (merged in L2).
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int pp = p0 + wn * 64 + j * 32 + l31;
+            if (pp >= g.P) continue;
+            float *__restrict__ yb = y + (size_t)pp * g.Cout;
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int eg = 0; eg < 4; ++eg) {
+                    const int m = m0 + wm * (BM / 2) + i * 32 + 8 * eg + 4 * khalf;
+                    if (m < g.Cout) {            // Cout % 4 == 0 (checked by the launcher)
+                        float v[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            v[q] = acc[i][j][eg * 4 + q];
+                            if (ep.scale) v[q] = v[q] * ep.scale[m + q];
+                            if (ep.bias) v[q] += ep.bias[m + q];
+                            if (ep.relu) v[q] = fmaxf(v[q], 0.0f);
+                        }
+                        *reinterpret_cast<float4 *>(yb + m) = make_float4(v[0], v[1], v[2], v[3]);
+                        __builtin_amdgcn_sched_barrier(0);     // one group at a time: keeps the accumulators in AGPRs
+                    }
+                }
+        }
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int pp = p0 + wn * 64 + j * 32 + l31;
+        if (pp >= g.P) continue;
+        const int on = pp / OHW;
+        const int oq = pp - on * OHW;
+        float *__restrict__ yb = y + (size_t)on * g.Cout * OHW + oq;
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + wm * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * khalf;
+                if (m < g.Cout) {
+                    float v = acc[i][j][e];
+                    if (ep.scale) v = v * ep.scale[m];
+                    if (ep.bias) v += ep.bias[m];
+                    if (ep.residual) v += ep.residual[(size_t)on * g.Cout * OHW + oq + (size_t)m * OHW];
+                    if (ep.relu) v = fmaxf(v, 0.0f);
+                    yb[(size_t)m * OHW] = v;
+                }
+            }
+    }
+}
+
 // -------------------------------------------------------------------------------------
 // forward / dgrad
 // -------------------------------------------------------------------------------------
@@ -278,59 +341,7 @@ __global__ __launch_bounds__(kThreads, (BM <= 128 ? 4 : 1)) void conv_fwd_kernel
         __syncthreads();
     }
 
-    // ---- epilogue: C/D layout col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5) ------
-    if (ONHWC) {     // a separate instantiation: the wider stores must not raise the NCHW kernel's VGPR count
-        // channels-last output: a lane owns 4 consecutive channels (e & 3) of its pixel -> one 16-byte
-        // store; lanes l and l+32 are adjacent (32 bytes), the 4 e-groups x MT tiles complete the
-        // 128..256-byte channel run of the pixel within this wavefront (merged in L2).
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int pp = p0 + wn * 64 + j * 32 + l31;
-            if (pp >= g.P) continue;
-            float *__restrict__ yb = y + (size_t)pp * g.Cout;
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int eg = 0; eg < 4; ++eg) {
-                    const int m = m0 + wm * (BM / 2) + i * 32 + 8 * eg + 4 * khalf;
-                    if (m < g.Cout) {            // Cout % 4 == 0 (checked by the launcher)
-                        float v[4];
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            v[q] = acc[i][j][eg * 4 + q];
-                            if (ep.scale) v[q] = v[q] * ep.scale[m + q];
-                            if (ep.bias) v[q] += ep.bias[m + q];
-                            if (ep.relu) v[q] = fmaxf(v[q], 0.0f);
-                        }
-                        *reinterpret_cast<float4 *>(yb + m) = make_float4(v[0], v[1], v[2], v[3]);
-                        __builtin_amdgcn_sched_barrier(0);     // one group at a time: keeps the accumulators in AGPRs
-                    }
-                }
-        }
-        return;
-    }
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int pp = p0 + wn * 64 + j * 32 + l31;
-        if (pp >= g.P) continue;
-        const int on = pp / OHW;
-        const int oq = pp - on * OHW;
-        float *__restrict__ yb = y + (size_t)on * g.Cout * OHW + oq;
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int m = m0 + wm * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * khalf;
-                if (m < g.Cout) {
-                    float v = acc[i][j][e];
-                    if (ep.scale) v = v * ep.scale[m];
-                    if (ep.bias) v += ep.bias[m];
-                    if (ep.residual) v += ep.residual[(size_t)on * g.Cout * OHW + oq + (size_t)m * OHW];
-                    if (ep.relu) v = fmaxf(v, 0.0f);
-                    yb[(size_t)m * OHW] = v;
-                }
-            }
-    }
+    conv_epilogue<BM, ONHWC>(acc, ep, y, g, m0, p0, wm, wn, l31, khalf);
 }
 
 // -------------------------------------------------------------------------------------
