@@ -33,19 +33,24 @@ def _log_flops(kind, cout, R, S, flops, pixels=None):
 
 
 def _conv_fwd(x, w, b, stride, padding, relu=False, scale=None, residual=None, out_hw=None,
-              out_channels_last=False):
+              out_channels_last=False, w_tap_major=False, flip_taps=False):
     """w is [Cout, Cin, R, S].  When Cin % 16 == 0 the kernel's tap-major fast path is used: the
     weight is handed over channels-last ([Cout, R, S, Cin]; a copy of at most a few MB).
     out_channels_last: y is returned in torch.channels_last memory format ([N,OH,OW,Cout] in
     memory, written that way by the kernel epilogue)."""
     L = _lib.load()
     N, Cin, H, W = x.shape
-    Cout, _, R, S = w.shape
-    layout = 0
-    if Cin % 16 == 0 and R * S <= 64:
-        layout = 1
-        if R * S > 1:
-            w = w.permute(0, 2, 3, 1).contiguous()
+    if w_tap_major:                       # w is already [Cout, R, S, Cin] contiguous
+        Cout, R, S, _ = w.shape
+        layout = 2 if flip_taps else 1    # 2: taps applied in reverse order (data gradient)
+        assert Cin % 16 == 0 and R * S <= 64 and w.is_contiguous()
+    else:
+        Cout, _, R, S = w.shape
+        layout = 0
+        if Cin % 16 == 0 and R * S <= 64:
+            layout = 1
+            if R * S > 1:
+                w = w.permute(0, 2, 3, 1).contiguous()
     OH = (H + 2 * padding[0] - R) // stride[0] + 1
     OW = (W + 2 * padding[1] - S) // stride[1] + 1
     if out_hw is not None:
@@ -127,9 +132,16 @@ def _conv_backward(ctx_needs, x, w, dz, stride, padding):
     Cout, _, R, S = w.shape
     dx = dw = None
     if ctx_needs[0]:
-        wt = w.flip(2, 3).transpose(0, 1).contiguous()          # [Cin, Cout, R, S]
         if stride == (1, 1):
-            dx = _conv_fwd(dz, wt, None, (1, 1), (R - 1 - padding[0], S - 1 - padding[1]))
+            if Cout % 16 == 0 and R * S <= 64:
+                # transposed weight straight into the kernel's tap-major layout [Cin, R, S, Cout] (one copy);
+                # the tap flip is done by the kernel's weight indexing (weight_layout 2)
+                wt = w.permute(1, 2, 3, 0).contiguous()
+                dx = _conv_fwd(dz, wt, None, (1, 1), (R - 1 - padding[0], S - 1 - padding[1]), w_tap_major=True,
+                               flip_taps=True)
+            else:
+                wt = w.flip(2, 3).transpose(0, 1).contiguous()          # [Cin, Cout, R, S]
+                dx = _conv_fwd(dz, wt, None, (1, 1), (R - 1 - padding[0], S - 1 - padding[1]))
         else:
             dx = _strided_dgrad(dz, w, (H, W), stride, padding)
     if ctx_needs[1]:

@@ -58,6 +58,7 @@ struct ConvGeom {
     int K;        // Cin*R*S
     int P;        // N*OH*OW
     int out_nhwc; // 1: y is [N][OH][OW][Cout] (channels-last), else [N][Cout][OH][OW]
+    int flip;     // 1: tap-major weights are applied with the taps in reverse order (data gradient)
     unsigned mul_ohw, sft_ohw, mul_ow, sft_ow;   // magic numbers: n / d == umulhi(n, mul) >> sft
 };
 
@@ -255,9 +256,10 @@ __global__ __launch_bounds__(kThreads, (BM <= 128 ? 4 : 1)) void conv_fwd_kernel
     auto load_tiles = [&](int kt) {
         const int kbase = kt * BK;
         if (HWC) {
+            const int kw = g.flip ? ((RS - 1 - cur_rs) * g.Cin + cur_ci0) : kbase;    // wave-uniform
 #pragma unroll
             for (int i = 0; i < A_LOADS; ++i) {
-                const float4 v = *reinterpret_cast<const float4 *>(a_row[i] + kbase);
+                const float4 v = *reinterpret_cast<const float4 *>(a_row[i] + kw);
                 a_reg[i][0] = v.x; a_reg[i][1] = v.y; a_reg[i][2] = v.z; a_reg[i][3] = v.w;
             }
         }
@@ -569,6 +571,9 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(const float *__res
     // HWC: every column of this workgroup has the same tap; channels step by W_COLS
     const int h_r = b_r[0], h_s = b_s[0];
     const int h_stride = W_COLS * HW;
+    int a_off[A_LOADS];                            // dY row offsets of this thread's output channels
+#pragma unroll
+    for (int i = 0; i < A_LOADS; ++i) a_off[i] = min(m0 + am + W_COLS * i, g.Cout - 1) * OHW;
 
     // as in the forward kernel: loaded values stay untouched until store_tiles(); zeroing is a mask
     float a_reg[A_LOADS], b_reg[B_LOADS];
@@ -589,15 +594,19 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(const float *__res
         if (HWC) {
             // no per-value selects: pixels past the split and taps outside the image read the zero
             // page; rows past Cout re-read the last row (their sums are never written)
+            // (no integer multiplies in the loop: v_mul_lo_u32 is quarter rate)
             const float *__restrict__ ap = ok ? dyn : g_zero_page;
-            const int a_stride = ok ? OHW : 0;
+            const int a_sel = ok ? -1 : 0;
 #pragma unroll
-            for (int i = 0; i < A_LOADS; ++i) a_reg[i] = ap[min(m0 + am + W_COLS * i, g.Cout - 1) * a_stride];
+            for (int i = 0; i < A_LOADS; ++i) a_reg[i] = ap[a_off[i] & a_sel];
             const bool inb = ok && ((unsigned)(ih0 + h_r) < (unsigned)g.H) && ((unsigned)(iw0 + h_s) < (unsigned)g.W);
             const float *__restrict__ bp = inb ? (xn + pix_off + b_off[0]) : g_zero_page;
-            const int stride = inb ? h_stride : 0;
+            const size_t stride = inb ? (size_t)h_stride : 0;
 #pragma unroll
-            for (int i = 0; i < B_LOADS; ++i) b_reg[i] = bp[i * stride];
+            for (int i = 0; i < B_LOADS; ++i) {
+                b_reg[i] = *bp;
+                bp += stride;
+            }
             return;
         }
 #pragma unroll
@@ -685,6 +694,7 @@ int make_geom(ConvGeom &g, int N, int Cin, int H, int W, int Cout, int R, int S,
     g.N = N; g.Cin = Cin; g.H = H; g.W = W; g.Cout = Cout; g.R = R; g.S = S;
     g.sh = sh; g.sw = sw; g.ph = ph; g.pw = pw;
     g.out_nhwc = 0;
+    g.flip = 0;
     g.OH = out_h > 0 ? out_h : (H + 2 * ph - R) / sh + 1;   // explicit size: taps past the input read zeros
     g.OW = out_w > 0 ? out_w : (W + 2 * pw - S) / sw + 1;
     FI_REQUIRE(g.OH >= 1 && g.OW >= 1, "empty output");
@@ -945,14 +955,16 @@ int fi_conv2d_forward(const float *x, const float *weight, const float *bias, co
     if (output_layout == 1) {
         FI_REQUIRE(Cout % 4 == 0 && residual == nullptr && (uintptr_t)y % 16 == 0,
                    "channels-last output needs Cout % 4 == 0, a 16-byte aligned y and no fused residual");
-        FI_REQUIRE(Cin % BK == 0 && R * S <= 64 && (weight_layout == 1 || R * S == 1),
+        FI_REQUIRE(Cin % BK == 0 && R * S <= 64 && (weight_layout >= 1 || R * S == 1),
                    "channels-last output is implemented on the tap-major path (Cin % 16 == 0, weight_layout 1)");
         g.out_nhwc = 1;
     }
-    FI_REQUIRE(weight_layout == 0 || weight_layout == 1, "weight_layout: 0 = [Cout][Cin][R][S], 1 = [Cout][R][S][Cin]");
+    FI_REQUIRE(weight_layout >= 0 && weight_layout <= 2,
+               "weight_layout: 0 = [Cout][Cin][R][S], 1 = [Cout][R][S][Cin], 2 = 1 with the taps reversed");
     // tap-major fast path: channels-last weights (any 1x1 weight is both layouts at once)
-    const bool hwc = (Cin % BK == 0) && (R * S <= 64) && (weight_layout == 1 || R * S == 1);
-    FI_REQUIRE(hwc || weight_layout == 0, "weight_layout 1 needs Cin % 16 == 0 and R*S <= 64");
+    const bool hwc = (Cin % BK == 0) && (R * S <= 64) && (weight_layout >= 1 || R * S == 1);
+    FI_REQUIRE(hwc || weight_layout == 0, "weight_layout 1/2 needs Cin % 16 == 0 and R*S <= 64");
+    g.flip = (weight_layout == 2) ? 1 : 0;
     hipStream_t st = (hipStream_t)stream;
     const Epilogue ep = {bias, scale, residual, relu};
     const bool bm64 = use_bm64(Cout, g.P);

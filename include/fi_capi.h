@@ -233,7 +233,9 @@ int fi_class_mean_backward(const float *grad_feat, const int32_t *gt,
  * out_h/out_w > 0 override the output size (window taps that fall outside the input read
  * zeros) -- used by the strided data gradient, which is a set of stride-1 correlations.
  * weight_layout 0: weight is [Cout,Cin,R,S] (as stored by the model); 1: [Cout,R,S,Cin]
- * (tap-major / channels-last; needs Cin % 16 == 0) -- selects the fast gather path.
+ * (tap-major / channels-last; needs Cin % 16 == 0) -- selects the fast gather path; 2: as 1,
+ * but the taps are applied in reverse order (tap (r,s) of the window uses weight[R-1-r][S-1-s]) --
+ * with weight = W^T stored [Cin,R,S,Cout] that is the data gradient without a flipped copy.
  * output_layout 0: y is [N,Cout,OH,OW]; 1: y is [N,OH,OW,Cout] (channels-last; Cout % 4 == 0, no
  * residual) -- used for the maps that only the channels-last RoIAlign consumes.
  * The data gradient of a stride-1 convolution is this same call on dY with the flipped,
