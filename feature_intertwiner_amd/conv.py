@@ -13,6 +13,8 @@ csrc/conv_igemm.hip:
 7x7 crops, lib/sub_module.py:707; the 7x7 conv of feat_extract on 7x7 maps, :333) are
 plain matrix products and go to the library GEMM.
 """
+import weakref
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -163,14 +165,18 @@ class _ConvBnActFn(torch.autograd.Function):
     elementwise/reduction pass (fi_bn_act_backward) + the conv dgrad/wgrad kernels."""
 
     @staticmethod
-    def forward(ctx, x, w, b, gamma, beta, mean, var, eps, residual, relu, stride, padding, out_cl=False):
+    def forward(ctx, x, w, b, gamma, beta, mean, var, eps, residual, relu, stride, padding, out_cl=False,
+                fold=None):
         _lib.require_cuda(x, w)
         x = x.contiguous().float()
         w = w.contiguous().float()
-        scale = gamma * torch.rsqrt(var + eps)
-        shift = beta - mean * scale
-        if b is not None:
-            shift = shift + b * scale
+        if fold is not None:              # precomputed for the whole model by refresh_bn_folds()
+            scale, shift = fold
+        else:
+            scale = gamma * torch.rsqrt(var + eps)
+            shift = beta - mean * scale
+            if b is not None:
+                shift = shift + b * scale
         res = residual.contiguous().float() if residual is not None else None
         y = _conv_fwd(x, w, shift.contiguous(), stride, padding, relu=relu, scale=scale.contiguous(), residual=res,
                       out_channels_last=out_cl)
@@ -202,7 +208,48 @@ class _ConvBnActFn(torch.autograd.Function):
         dx, dw = _conv_backward(ctx.needs_input_grad, x, w, dz, stride, padding)
         db = dshift * scale if (has_bias and ctx.needs_input_grad[2]) else None
         dbeta = dshift if ctx.needs_input_grad[4] else None
-        return dx, dw, db, dgamma, dbeta, None, None, None, g_res, None, None, None, None
+        return dx, dw, db, dgamma, dbeta, None, None, None, g_res, None, None, None, None, None
+
+
+# ---- eval-BN fold (scale, shift) for every (conv, bn) pair, refreshed once per step ------------
+# Folding inside each layer costs ~5 tiny launches per layer (500 per step); refresh_bn_folds()
+# does all layers with a handful of torch._foreach_* launches.  A cached fold is used only while
+# the versions of the five tensors it was computed from are unchanged.
+_FOLD_PAIRS = weakref.WeakKeyDictionary()      # bn module -> conv module (filled by conv_bn_act)
+
+
+def _fold_key(conv, bn):
+    return (bn.weight._version, bn.bias._version, bn.running_mean._version, bn.running_var._version,
+            -1 if conv.bias is None else conv.bias._version, bn.weight.data_ptr())
+
+
+def _cached_fold(conv, bn):
+    c = getattr(bn, "_fi_fold", None)
+    if c is not None and c[2] == _fold_key(conv, bn):
+        return c[0], c[1]
+    return None
+
+
+@torch.no_grad()
+def refresh_bn_folds():
+    """Recompute scale = gamma/sqrt(var+eps), shift = beta + (conv_bias - mean)*scale for every
+    eval-mode (conv, bn) pair seen so far.  Call once per step before the forward pass."""
+    pairs = [(c, b) for b, c in _FOLD_PAIRS.items()
+             if not b.training and b.weight.is_cuda and _cached_fold(c, b) is None]
+    if not pairs:
+        return
+    gam = [b.weight for _, b in pairs]
+    inv = torch._foreach_add([b.running_var for _, b in pairs], [float(b.eps) for _, b in pairs])
+    torch._foreach_rsqrt_(inv)
+    scale = torch._foreach_mul(gam, inv)
+    shift = torch._foreach_mul([b.running_mean for _, b in pairs], scale)
+    shift = torch._foreach_sub([b.bias for _, b in pairs], shift)
+    wb = [i for i, (c, _) in enumerate(pairs) if c.bias is not None]
+    if wb:
+        torch._foreach_add_([shift[i] for i in wb],
+                            torch._foreach_mul([pairs[i][0].bias for i in wb], [scale[i] for i in wb]))
+    for (c, b), sc, sh in zip(pairs, scale, shift):
+        b._fi_fold = (sc, sh, _fold_key(c, b))
 
 
 def conv_bn_act(x, conv, bn, relu=True, residual=None, channels_last_out=False):
@@ -224,8 +271,10 @@ def conv_bn_act(x, conv, bn, relu=True, residual=None, channels_last_out=False):
         y = F.relu(y) if relu else y
         return y.contiguous(memory_format=torch.channels_last) if channels_last_out else y
     out_cl = bool(channels_last_out) and residual is None and conv.weight.shape[0] % 4 == 0
+    _FOLD_PAIRS[bn] = conv
     y = _ConvBnActFn.apply(x, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                           bn.eps, residual, relu, tuple(conv.stride), tuple(conv.padding), out_cl)
+                           bn.eps, residual, relu, tuple(conv.stride), tuple(conv.padding), out_cl,
+                           _cached_fold(conv, bn))
     return y.contiguous(memory_format=torch.channels_last) if (channels_last_out and not out_cl) else y
 
 

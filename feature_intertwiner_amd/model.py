@@ -6,6 +6,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+from .conv import refresh_bn_folds
 from .intertwiner import FeatureBuffer, merge_feat_vec
 from .layers import (compute_mrcnn_bbox_loss, compute_mrcnn_class_loss, compute_mrcnn_mask_loss,
                      compute_rpn_bbox_loss, compute_rpn_class_loss, detection_layer, generate_pyramid_priors,
@@ -79,6 +80,7 @@ class MaskRCNN(nn.Module):
             return self._inference(images, input[1])
         gt_class_ids, gt_boxes, gt_masks = input[1], input[2], input[3]
         self.eval()   # the reference always runs BN (and everything else) in eval mode
+        refresh_bn_folds()   # all eval-BN (scale, shift) pairs in a handful of launches
         proposal_cnt = cfg.RPN.POST_NMS_ROIS_INFERENCE   # also Q1
 
         p2, p3, p4, p5, p6, fpn_ot_loss = self.fpn(images, mode=mode)
@@ -132,6 +134,7 @@ class MaskRCNN(nn.Module):
         cfg = self.config
         bs = images.size(0)
         self.eval()
+        refresh_bn_folds()
         p2, p3, p4, p5, p6, _ = self.fpn(images, mode='inference')
         mrcnn_maps = [p2, p3, p4, p5]
         outs = [self.rpn(p) for p in (p2, p3, p4, p5, p6)]

@@ -165,3 +165,28 @@ def test_channels_last_output_matches_nchw(shape):
     assert torch.equal(res[False][0].view(torch.int32), res[True][0].view(torch.int32))
     for a, b in zip(res[False][1:], res[True][1:]):
         assert (a - b).abs().max().item() <= 2e-5 * (a.abs().max().item() + 1e-6)
+
+
+def test_bn_fold_cache_tracks_parameter_versions():
+    from feature_intertwiner_amd import conv as C
+    torch.manual_seed(3)
+    conv = C.Conv2d(16, 32, 3, padding=1).to(DEV)
+    bn = torch.nn.BatchNorm2d(32, eps=0.001).to(DEV).eval()
+    with torch.no_grad():
+        bn.running_var.uniform_(0.5, 2.0)
+        bn.running_mean.normal_()
+    x = torch.randn(2, 16, 8, 8, device=DEV)
+    y0 = C.conv_bn_act(x, conv, bn)                       # registers the pair, folds in-layer
+    assert C._cached_fold(conv, bn) is None
+    C.refresh_bn_folds()
+    sc, sh = C._cached_fold(conv, bn)
+    exp_sc = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+    assert torch.allclose(sc, exp_sc, rtol=1e-6) and torch.allclose(
+        sh, bn.bias + (conv.bias - bn.running_mean) * exp_sc, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(C.conv_bn_act(x, conv, bn), y0, rtol=1e-5, atol=1e-5)
+    with torch.no_grad():
+        bn.weight.mul_(2.0)                               # optimizer-style in-place update -> stale
+    assert C._cached_fold(conv, bn) is None
+    y1 = C.conv_bn_act(x, conv, bn)
+    C.refresh_bn_folds()
+    assert torch.allclose(C.conv_bn_act(x, conv, bn), y1, rtol=1e-5, atol=1e-5)
