@@ -16,17 +16,25 @@
 //       [BK x BN] slice straight from the NCHW input (for a fixed k, consecutive p are
 //       consecutive pixels of one input row -> coalesced), zero-filling the halo.
 // Tile: BM x 128 x 16 per 256-thread workgroup (BM = 128 or 64), 4 wavefronts as 2 x 2,
-// each owning a (BM/2) x 64 accumulator block of 32x32 MFMA tiles.  LDS tiles are stored
-// k-major ([BK][BM+4], [BK][BN+4]) so that an MFMA operand read is 32 consecutive floats
-// per half-wavefront (conflict-free ds_read_b32).  Global loads for K-step t+1 are issued
+// each owning a (BM/2) x 64 accumulator block of 32x32 MFMA tiles; <= 128 VGPRs so that 4
+// workgroups share a CU.  LDS tiles are stored k-major ([BK][BM+2], [BK][BN+2]: an MFMA operand
+// read is 32 consecutive floats per half-wavefront, and the row pitch of 2 banks (mod 32) makes
+// the transposed tile stores conflict free as well).  Global loads for K-step t+1 are issued
 // into registers before the MFMAs of step t and written to the other LDS buffer afterwards:
-// one barrier per K-step, HBM/L2 latency hidden behind 16..32 MFMAs (64 cycles each).
-// The epilogue adds the bias, optionally applies ReLU, and stores rows of 32 consecutive
-// pixels (128-byte segments).
+// one barrier per K-step, L2/HBM latency hidden behind 16..32 MFMAs (64 cycles each).
+//
+// What the K loop does NOT contain (each item was worth 3..8 % of the kernel): divergent
+// branches (weight rows past Cout re-read the last row; their sums are never stored), per-value
+// halo selects (a tap outside the image reads a zero page instead of being masked after the
+// load, so loaded registers go to LDS untouched), integer division (tap-major K order + magic
+// numbers), integer multiplies.  The fused epilogue applies scale/bias (an eval-mode BatchNorm
+// folded by the caller), the bottleneck shortcut and ReLU, and stores NCHW rows of 32 consecutive
+// pixels or, for maps that only the channels-last RoIAlign reads, NHWC 16-byte channel groups.
 //
 // The data gradient of a stride-1 convolution is the same kernel run on dY with the
-// flipped, transposed weights and padding R-1-pad.  The weight gradient is a second GEMM
-// with the reduction over pixels (split across workgroups, fp32 atomics into dW).
+// transposed weights applied with reversed taps (weight_layout 2) and padding R-1-pad.  The
+// weight gradient is a second GEMM with the reduction over pixels (split across workgroups,
+// fp32 atomics into dW).
 #include <stdint.h>
 #include <stdlib.h>
 
@@ -38,10 +46,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kThreads = 256;
 constexpr int BN = 128;
-#ifndef FI_CONV_BK
-#define FI_CONV_BK 16
-#endif
-constexpr int BK = FI_CONV_BK;
+constexpr int BK = 16;
 constexpr int PAD = 2;   // row pitch = 2 (mod 32) banks: the transposed tile stores of both kernels are conflict free
 
 // epilogue: y = acc * scale[m] + bias[m] (+ residual) (ReLU) -- scale/bias carry an eval-mode
@@ -86,9 +91,6 @@ __device__ __forceinline__ void mma_tile(const float (*__restrict__ As)[BM + PAD
     for (int i = 0; i < MT; ++i) af[0][i] = As[khalf][a_col + i * 32];
 #pragma unroll
     for (int j = 0; j < 2; ++j) bf[0][j] = Bs[khalf][b_col + j * 32];
-#ifdef FI_CONV_SETPRIO
-    __builtin_amdgcn_s_setprio(1);
-#endif
 #pragma unroll
     for (int kk = 0; kk < BK / 2; ++kk) {
         const int cur = kk & 1, nxt = cur ^ 1;
@@ -105,9 +107,6 @@ __device__ __forceinline__ void mma_tile(const float (*__restrict__ As)[BM + PAD
             for (int j = 0; j < 2; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i], bf[cur][j], acc[i][j], 0, 0, 0);
     }
-#ifdef FI_CONV_SETPRIO
-    __builtin_amdgcn_s_setprio(0);
-#endif
 }
 
 // Epilogue shared by the forward kernels.  C/D layout of v_mfma_f32_32x32x2_f32:
@@ -183,7 +182,7 @@ __device__ __forceinline__ void conv_epilogue(const f32x16 (&acc)[BM / 64][2], c
 // 4 wavefronts per SIMD (<= 128 VGPRs, accumulators included): 1024 resident workgroups, so the
 // 4096 / 8192-tile grids of the P2-level layers run as whole waves of workgroups instead of 5.33
 template <int BM, int TR, int TS, bool HWC, bool ONHWC = false>
-__global__ __launch_bounds__(kThreads, (BM <= 128 ? 4 : 1)) void conv_fwd_kernel(const float *__restrict__ x,
+__global__ __launch_bounds__(kThreads, 4) void conv_fwd_kernel(const float *__restrict__ x,
                                                             const float *__restrict__ w,
                                                             Epilogue ep,
                                                             float *__restrict__ y, ConvGeom g)
@@ -344,173 +343,6 @@ __global__ __launch_bounds__(kThreads, (BM <= 128 ? 4 : 1)) void conv_fwd_kernel
     }
 
     conv_epilogue<BM, ONHWC>(acc, ep, y, g, m0, p0, wm, wn, l31, khalf);
-}
-
-// -------------------------------------------------------------------------------------
-// forward / dgrad, wavefront-private tiles (tap-major weights only).
-// Same 64x64-per-wavefront accumulator block as conv_fwd_kernel, but every wavefront stages
-// its OWN [BK x 64] A and B slices in a private LDS region: there is no __syncthreads() in the
-// K loop (LDS operations of one wavefront execute in order), so the four wavefronts of a
-// workgroup -- which sit on four different SIMDs, each shared with other workgroups -- never
-// wait for each other.  Costs 2x the L2->LDS traffic of the shared-tile kernel (far below the
-// 64 B/clk/CU L1 rate at fp32-MFMA speed) and buys back the barrier stalls (PMC: 24 % of wave
-// cycles in s_waitcnt/s_barrier, MFMA pipe 67 % busy with the shared-tile kernel).
-// -------------------------------------------------------------------------------------
-template <int WM, int TR, int TS>     // WM = rows per wavefront (64 or 32)
-__global__ __launch_bounds__(kThreads) void conv_fwd_wave_kernel(const float *__restrict__ x,
-                                                                 const float *__restrict__ w,
-                                                                 Epilogue ep, float *__restrict__ y,
-                                                                 ConvGeom g)
-{
-    constexpr int MT = WM / 32;
-    constexpr int WN = 64;
-    __shared__ float As[4][BK][WM + PAD];
-    __shared__ float Bs[4][BK][WN + PAD];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int R = TR ? TR : g.R, S = TS ? TS : g.S;
-    const int RS = R * S;
-    const int K = g.K;
-    const int m0 = blockIdx.y * (2 * WM) + wm * WM;
-    const int p0 = blockIdx.x * (2 * WN) + wn * WN;
-    const int OHW = g.OH * g.OW;
-    const int HW = g.H * g.W;
-
-    // B gather: this lane's pixel, BK consecutive channels of the current tap
-    const int p = p0 + lane;
-    const bool p_ok = p < g.P;
-    int n = 0, oh = 0, ow = 0;
-    if (p_ok) {
-        n = fast_div(p, g.mul_ohw, g.sft_ohw);
-        const int q = p - n * OHW;
-        oh = fast_div(q, g.mul_ow, g.sft_ow);
-        ow = q - oh * g.OW;
-    }
-    const int ih0 = oh * g.sh - g.ph;
-    const int iw0 = ow * g.sw - g.pw;
-    const float *__restrict__ xn = x + (size_t)n * g.Cin * HW;
-    const int pix_off = ih0 * g.W + iw0;
-    unsigned long long tap_mask = 0;
-    for (int rs = 0; rs < RS; ++rs) {
-        const int r = rs / S, s = rs - (rs / S) * S;
-        if (p_ok && ((unsigned)(ih0 + r) < (unsigned)g.H) && ((unsigned)(iw0 + s) < (unsigned)g.W))
-            tap_mask |= 1ULL << rs;
-    }
-    int cur_rs = 0, cur_ci0 = 0;
-
-    // A loader: WM rows x BK k-values per K-step = WM*BK/4 float4 over 64 lanes
-    constexpr int A_TPR = BK / 4;
-    constexpr int A_ROWS = 64 / A_TPR;                 // rows per pass
-    constexpr int A_LOADS = WM / A_ROWS;
-    const int ak4 = (lane % A_TPR) * 4;
-    const int am = lane / A_TPR;
-
-    float a_reg[A_LOADS][4];
-    float b_reg[BK];
-
-    auto load_tiles = [&](int kt) {
-        const int kbase = kt * BK;
-#pragma unroll
-        for (int i = 0; i < A_LOADS; ++i) {
-            const int m = m0 + am + i * A_ROWS;
-            const int mc = min(m, g.Cout - 1);
-            const float4 v = *reinterpret_cast<const float4 *>(w + (size_t)mc * K + kbase + ak4);
-            const bool ok = m < g.Cout;
-            a_reg[i][0] = ok ? v.x : 0.0f; a_reg[i][1] = ok ? v.y : 0.0f;
-            a_reg[i][2] = ok ? v.z : 0.0f; a_reg[i][3] = ok ? v.w : 0.0f;
-        }
-        const int rs = cur_rs;
-        const int r = rs / S, s = rs - (rs / S) * S;
-        const bool ok = (tap_mask >> rs) & 1ULL;
-        const int off0 = pix_off + r * g.W + s + cur_ci0 * HW;
-        const int base = ok ? off0 : 0;
-        const int stride = ok ? HW : 0;
-#pragma unroll
-        for (int i = 0; i < BK; ++i) {
-            const float t = xn[base + i * stride];
-            b_reg[i] = ok ? t : 0.0f;
-        }
-        cur_ci0 += BK;
-        if (cur_ci0 >= g.Cin) {
-            cur_ci0 = 0;
-            ++cur_rs;
-        }
-    };
-    auto store_tiles = [&]() {
-#pragma unroll
-        for (int i = 0; i < A_LOADS; ++i)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) As[wave][ak4 + q][am + i * A_ROWS] = a_reg[i][q];
-#pragma unroll
-        for (int i = 0; i < BK; ++i) Bs[wave][i][lane] = b_reg[i];
-    };
-
-    f32x16 acc[MT][2];
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
-
-    const int nk = K / BK;            // Cin % BK == 0 on this path
-    const int l31 = lane & 31;
-    const int khalf = lane >> 5;
-    load_tiles(0);
-    for (int kt = 0; kt < nk; ++kt) {
-        store_tiles();
-        __builtin_amdgcn_wave_barrier();
-        if (kt + 1 < nk) load_tiles(kt + 1);
-        // fragments + MFMAs on this wavefront's private tile
-        float af[2][MT], bf[2][2];
-#pragma unroll
-        for (int i = 0; i < MT; ++i) af[0][i] = As[wave][khalf][l31 + i * 32];
-#pragma unroll
-        for (int j = 0; j < 2; ++j) bf[0][j] = Bs[wave][khalf][l31 + j * 32];
-#pragma unroll
-        for (int kk = 0; kk < BK / 2; ++kk) {
-            const int cur = kk & 1, nxt = cur ^ 1;
-            if (kk + 1 < BK / 2) {
-                const int kr = (kk + 1) * 2 + khalf;
-#pragma unroll
-                for (int i = 0; i < MT; ++i) af[nxt][i] = As[wave][kr][l31 + i * 32];
-#pragma unroll
-                for (int j = 0; j < 2; ++j) bf[nxt][j] = Bs[wave][kr][l31 + j * 32];
-            }
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i], bf[cur][j], acc[i][j], 0, 0, 0);
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
-
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int pp = p0 + j * 32 + l31;
-        if (pp >= g.P) continue;
-        const int on = fast_div(pp, g.mul_ohw, g.sft_ohw);
-        const int oq = pp - on * OHW;
-        float *__restrict__ yb = y + (size_t)on * g.Cout * OHW + oq;
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int m = m0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * khalf;
-                if (m < g.Cout) {
-                    float v = acc[i][j][e];
-                    if (ep.scale) v = v * ep.scale[m];
-                    if (ep.bias) v += ep.bias[m];
-                    if (ep.residual) v += ep.residual[(size_t)on * g.Cout * OHW + oq + (size_t)m * OHW];
-                    if (ep.relu) v = fmaxf(v, 0.0f);
-                    yb[(size_t)m * OHW] = v;
-                }
-            }
-    }
 }
 
 // -------------------------------------------------------------------------------------
@@ -726,16 +558,6 @@ void launch_fwd(const ConvGeom &g, const float *x, const float *w, const Epilogu
                 bool hwc, hipStream_t st)
 {
     dim3 grid(fi::ceil_div(g.P, BN), fi::ceil_div(g.Cout, BM));
-    static const int wave_mode = getenv("FI_CONV_WAVE") ? atoi(getenv("FI_CONV_WAVE")) : 0;
-    if (hwc && wave_mode && !g.out_nhwc) {
-        if (g.R == 3 && g.S == 3)
-            hipLaunchKernelGGL((conv_fwd_wave_kernel<BM / 2, 3, 3>), grid, dim3(kThreads), 0, st, x, w, ep, y, g);
-        else if (g.R == 1 && g.S == 1)
-            hipLaunchKernelGGL((conv_fwd_wave_kernel<BM / 2, 1, 1>), grid, dim3(kThreads), 0, st, x, w, ep, y, g);
-        else
-            hipLaunchKernelGGL((conv_fwd_wave_kernel<BM / 2, 0, 0>), grid, dim3(kThreads), 0, st, x, w, ep, y, g);
-        return;
-    }
     if (hwc && g.out_nhwc) {
         if (g.R == 3 && g.S == 3)
             hipLaunchKernelGGL((conv_fwd_kernel<BM, 3, 3, true, true>), grid, dim3(kThreads), 0, st, x, w, ep, y, g);
@@ -969,10 +791,7 @@ int fi_conv2d_forward(const float *x, const float *weight, const float *bias, co
     const Epilogue ep = {bias, scale, residual, relu};
     const bool bm64 = use_bm64(Cout, g.P);
     fi::ProfScope prof(FI_K_CONV_FWD + (bm64 ? 0 : 4) + window_class(R, S), st);
-    static const int bm256 = getenv("FI_CONV_BM256") ? atoi(getenv("FI_CONV_BM256")) : 0;
-    if (bm256 && !bm64 && hwc && Cout % 256 == 0 && (long)fi::ceil_div(g.P, BN) * (Cout / 256) >= 1024)
-        launch_fwd<256>(g, x, weight, ep, y, hwc, st);
-    else if (bm64)
+    if (bm64)
         launch_fwd<64>(g, x, weight, ep, y, hwc, st);
     else
         launch_fwd<128>(g, x, weight, ep, y, hwc, st);

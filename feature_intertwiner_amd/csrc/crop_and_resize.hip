@@ -543,12 +543,6 @@ __global__ void crop_taps_kernel(const float *__restrict__ boxes, int num_boxes,
 // chunk while the grid would not fill the chip (256 CUs x 8 workgroups).
 void pick_chunks(int num_boxes, int depth, int *chan_per_block, int *chunks)
 {
-    static const int forced = getenv("FI_CROP_CPB") ? atoi(getenv("FI_CROP_CPB")) : 0;  // tuning knob
-    if (forced > 0) {
-        *chan_per_block = forced;
-        *chunks = fi::ceil_div(depth, forced);
-        return;
-    }
     int cpb = fi::ceil_div(depth, 8);
     if (cpb < 1) cpb = 1;
     while (cpb > 8 && (long)num_boxes * fi::ceil_div(depth, cpb) < 2048) cpb = fi::ceil_div(cpb, 2);
