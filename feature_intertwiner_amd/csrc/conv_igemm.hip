@@ -501,6 +501,236 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(const float *__res
     }
 }
 
+// -------------------------------------------------------------------------------------
+// weight gradient, "same"-size stride-1 convolutions (OH == H, OW == W), tap-major dW.
+// In this GEMM BOTH operands are contiguous along the reduction index (pixels), so the tiles are
+// kept row-major in LDS ([channel][16 pixels + 4]) instead of being transposed on the way in:
+//   * global -> LDS: one 16-byte load and one ds_write_b128 per 4 pixels (the scalar kernel above:
+//     4 loads + 4 ds_write_b32 into 4 different LDS rows) -- the transposing store pass was the
+//     largest single cost of that kernel (ablation: 88 -> 117 TFLOP/s without it);
+//   * LDS -> MFMA: the two half-wavefronts of v_mfma_f32_32x32x2_f32 supply k and k' of each
+//     product pair; pairing (kk, kk + 8) makes a lane's 8 operands of a K-step CONTIGUOUS
+//     (pixels 8*khalf .. 8*khalf+7 of its row): 2 ds_read_b128 instead of 8 ds_read_b32.
+//     Row pitch 20 floats: 16 lanes x 16 bytes cover all 64 banks exactly once.
+// For a same-size convolution the input pixel of tap (r, s) is q + (r-ph)*W + (s-pw) for output
+// pixel q, so 4 consecutive output pixels read 4 consecutive input floats (across row ends too);
+// halo validity is a 4-bit mask applied when the tile is written to LDS.  Loads go through buffer
+// descriptors: an offset past the tensor returns 0 per dword, which covers the ragged pixel tail and
+// the last rows of the tensor.  A NEGATIVE start offset (first channel of the first image only)
+// would zero the whole 16 bytes, so those few K-steps use 4-byte loads (workgroup-uniform branch).
+// -------------------------------------------------------------------------------------
+template <int BM, int TR, int TS>
+__global__ __launch_bounds__(kThreads, 3) void conv_wgrad_vec_kernel(const float *__restrict__ x,
+                                                                     const float *__restrict__ dy,
+                                                                     float *__restrict__ dw, ConvGeom g,
+                                                                     int p_per_split)
+{
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    constexpr int MT = BM / 64;
+    constexpr int PITCH = BK + 4;
+    __shared__ __attribute__((aligned(16))) float As[2][BM][PITCH];    // dY   [m][pixel]
+    __shared__ __attribute__((aligned(16))) float Bs[2][BN][PITCH];    // Xcol [column][pixel]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int S = TS ? TS : g.S;
+    const int K = g.K;
+    const int m0 = blockIdx.y * BM;
+    const int k0 = blockIdx.x * BN;              // 128 columns = 128 input channels of ONE tap
+    const int HW = g.H * g.W;                    // == OH*OW
+    const int p_begin = blockIdx.z * p_per_split;
+    const int p_end = min(g.P, p_begin + p_per_split);
+    if (p_begin >= p_end) return;
+
+    const int rs = k0 / g.Cin;
+    const int ci0 = k0 - rs * g.Cin;
+    const int r = rs / S, s = rs - (rs / S) * S;
+    const int dr = r - g.ph, ds = s - g.pw;
+    const int off_tap = dr * g.W + ds;
+
+    const int lj = tid & 3;                      // which 4 of the step's 16 pixels
+    const int lr = tid >> 2;                     // row 0..63 (+64 per further load)
+    constexpr int A_LOADS = BM / 64;
+    constexpr int B_LOADS = BN / 64;
+    int a_row4[A_LOADS], b_row4[B_LOADS];        // byte offsets of this thread's rows
+#pragma unroll
+    for (int i = 0; i < A_LOADS; ++i) a_row4[i] = min(m0 + lr + 64 * i, g.Cout - 1) * HW * 4;
+#pragma unroll
+    for (int i = 0; i < B_LOADS; ++i) b_row4[i] = (ci0 + lr + 64 * i) * HW * 4;
+    const __amdgpu_buffer_rsrc_t dy_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(dy), 0, (int)((size_t)g.N * g.Cout * HW * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(x), 0, (int)((size_t)g.N * g.Cin * HW * 4), 0x00020000);
+    const int kOutOfRange = 0x7ffffff0;
+    // K-steps whose input offsets can be negative: first channel block, first image, first rows
+    const bool neg_block = (ci0 == 0) && (off_tap < 0);
+
+    u32x4 a_reg[A_LOADS], b_reg[B_LOADS];
+    unsigned b_mask = 0;
+    // Pixel state of this thread's 4-pixel group, advanced by 16 pixels per K-step with adds and
+    // compares only (VALU instructions in the K loop come straight out of the MFMA issue budget):
+    // image cn, pixel cq = coh*OW + cow, and the byte offsets of the group in dY / X.
+    constexpr bool k1x1 = (TR == 1 && TS == 1);
+    constexpr bool k3x3 = (TR == 3 && TS == 3);
+    int cp = p_begin + 4 * lj;
+    int cn = fast_div(cp, g.mul_ohw, g.sft_ohw);
+    int cq = cp - cn * HW;
+    int coh = fast_div(cq, g.mul_ow, g.sft_ow);
+    int cow = cq - coh * g.OW;
+    int a_cur = (cn * g.Cout * HW + cq) * 4;
+    int b_cur = (cn * g.Cin * HW + cq + off_tap) * 4;          // may be negative when neg_block
+    const int adv_h = BK / g.OW, adv_w = BK - adv_h * g.OW;
+    const int a_wrap = (g.Cout - 1) * HW * 4, b_wrap = (g.Cin - 1) * HW * 4;
+    auto load_tiles = [&](int pt) {
+        const bool ok = cp < p_end;
+        const int a_off = ok ? a_cur : kOutOfRange;
+#pragma unroll
+        for (int i = 0; i < A_LOADS; ++i)
+            a_reg[i] = __builtin_amdgcn_raw_buffer_load_b128(dy_rsrc, a_off + (ok ? a_row4[i] : 0), 0, 0);
+        // halo mask of the 4 pixels (they may continue on the next row)
+        unsigned mk = 0;
+        if (k1x1) {
+            mk = ok ? 0xFu : 0u;
+        } else if (k3x3) {
+            const int wrap = g.OW - cow;                        // elements e >= wrap sit on the next row
+            const unsigned low = wrap >= 4 ? 0xFu : ((1u << wrap) - 1u);
+            const bool row0 = (unsigned)(coh + dr) < (unsigned)g.H;
+            const bool row1 = (unsigned)(coh + 1 + dr) < (unsigned)g.H;
+            mk = (row0 ? low : 0u) | (row1 ? (0xFu & ~low) : 0u);
+            if (ds < 0) {                                       // the element in column 0 has no left neighbour
+                const unsigned kill = (cow == 0) ? 1u : (wrap < 4 ? (1u << wrap) : 0u);
+                mk &= ~kill;
+            } else if (ds > 0) {                                // the element in column OW-1 has no right neighbour
+                const int e1 = g.OW - 1 - cow;
+                mk &= ~(e1 < 4 ? (1u << e1) : 0u);
+            }
+            mk = ok ? mk : 0u;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                int owe = cow + e, ohe = coh;
+                if (owe >= g.OW) {
+                    owe -= g.OW;
+                    ohe += 1;
+                }
+                const bool v = ok && ((unsigned)(ohe + dr) < (unsigned)g.H) && ((unsigned)(owe + ds) < (unsigned)g.W);
+                mk |= v ? (1u << e) : 0u;
+            }
+        }
+        b_mask = mk;
+        const int b_base = b_cur;
+        // advance to the next K-step
+        cp += BK;
+        cq += BK;
+        cow += adv_w;
+        coh += adv_h;
+        a_cur += BK * 4;
+        b_cur += BK * 4;
+        if (cow >= g.OW) {
+            cow -= g.OW;
+            coh += 1;
+        }
+        if (cq >= HW) {
+            cq -= HW;
+            coh -= g.OH;
+            a_cur += a_wrap;
+            b_cur += b_wrap;
+        }
+        if (neg_block && pt + off_tap < 0 && pt < HW) {             // workgroup-uniform, a handful of K-steps
+#pragma unroll
+            for (int i = 0; i < B_LOADS; ++i) {
+                // per-element offsets: an element before the tensor start is always a halo element, and
+                // giving it an out-of-range offset also keeps the compiler from re-merging the four loads
+                const int o = b_base + b_row4[i];
+                b_reg[i].x = __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, (mk & 1u) ? o : kOutOfRange, 0, 0);
+                b_reg[i].y = __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, (mk & 2u) ? o + 4 : kOutOfRange, 0, 0);
+                b_reg[i].z = __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, (mk & 4u) ? o + 8 : kOutOfRange, 0, 0);
+                b_reg[i].w = __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, (mk & 8u) ? o + 12 : kOutOfRange, 0, 0);
+            }
+            return;
+        }
+        const int b_off = mk ? b_base : kOutOfRange;
+#pragma unroll
+        for (int i = 0; i < B_LOADS; ++i)
+            b_reg[i] = __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, b_off + (mk ? b_row4[i] : 0), 0, 0);
+    };
+    auto store_tiles = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < A_LOADS; ++i)
+            *reinterpret_cast<u32x4 *>(&As[buf][lr + 64 * i][4 * lj]) = a_reg[i];
+#pragma unroll
+        for (int i = 0; i < B_LOADS; ++i) {
+            u32x4 v = b_reg[i];
+            if (!k1x1) {               // a 1x1 tile has no halo: an invalid group was loaded as zeros
+                v.x = (b_mask & 1u) ? v.x : 0u;
+                v.y = (b_mask & 2u) ? v.y : 0u;
+                v.z = (b_mask & 4u) ? v.z : 0u;
+                v.w = (b_mask & 8u) ? v.w : 0u;
+            }
+            *reinterpret_cast<u32x4 *>(&Bs[buf][lr + 64 * i][4 * lj]) = v;
+        }
+    };
+
+    f32x16 acc[MT][2];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+    const int steps = (p_end - p_begin + BK - 1) / BK;
+    load_tiles(p_begin);
+    store_tiles(0);
+    __syncthreads();
+    const int l31 = lane & 31;
+    const int khalf = lane >> 5;
+    for (int st = 0; st < steps; ++st) {
+        const int buf = st & 1;
+        if (st + 1 < steps) load_tiles(p_begin + (st + 1) * BK);
+        float4 af[MT][2], bf[2][2];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const float *rowp = &As[buf][wm * (BM / 2) + i * 32 + l31][8 * khalf];
+            af[i][0] = *reinterpret_cast<const float4 *>(rowp);
+            af[i][1] = *reinterpret_cast<const float4 *>(rowp + 4);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const float *rowp = &Bs[buf][wn * 64 + j * 32 + l31][8 * khalf];
+            bf[j][0] = *reinterpret_cast<const float4 *>(rowp);
+            bf[j][1] = *reinterpret_cast<const float4 *>(rowp + 4);
+        }
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk)
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const float4 a4 = af[i][kk >> 2], b4 = bf[j][kk >> 2];
+                    const float a = (kk & 3) == 0 ? a4.x : (kk & 3) == 1 ? a4.y : (kk & 3) == 2 ? a4.z : a4.w;
+                    const float b = (kk & 3) == 0 ? b4.x : (kk & 3) == 1 ? b4.y : (kk & 3) == 2 ? b4.z : b4.w;
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i][j], 0, 0, 0);
+                }
+        if (st + 1 < steps) store_tiles(buf ^ 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int k = k0 + wn * 64 + j * 32 + l31;
+        if (k >= K) continue;
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + wm * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * khalf;
+                if (m < g.Cout) atomicAdd(dw + (size_t)m * K + k, acc[i][j][e]);
+            }
+    }
+}
+
 // 64-row tiles for narrow layers, and for grids that would leave the chip under-filled with
 // 128-row tiles (fewer than 2 workgroups per CU): C4/C5 of the backbone at batch 4.
 bool use_bm64(int Cout, int P)
@@ -589,6 +819,20 @@ void launch_wgrad(const ConvGeom &g, const float *x, const float *dy, float *dw,
                   int p_per_split, bool hwc, hipStream_t st)
 {
     dim3 grid(fi::ceil_div(g.K, BN), fi::ceil_div(g.Cout, BM), splits);
+    // same-size stride-1 layers (every 3x3/pad-1 and 1x1 layer of the model): row-major tiles, 16-byte LDS traffic
+    const bool same = g.sh == 1 && g.sw == 1 && g.OH == g.H && g.OW == g.W && (g.H * g.W) % 4 == 0 && g.W >= 4 &&
+                      (size_t)g.N * g.Cin * g.H * g.W * 4 < 0x7fffff00ULL &&
+                      (size_t)g.N * g.Cout * g.H * g.W * 4 < 0x7fffff00ULL &&
+                      ((uintptr_t)x % 16 == 0) && ((uintptr_t)dy % 16 == 0);
+    if (hwc && same) {
+        if (g.R == 3 && g.S == 3)
+            hipLaunchKernelGGL((conv_wgrad_vec_kernel<BM, 3, 3>), grid, dim3(kThreads), 0, st, x, dy, dw, g, p_per_split);
+        else if (g.R == 1 && g.S == 1)
+            hipLaunchKernelGGL((conv_wgrad_vec_kernel<BM, 1, 1>), grid, dim3(kThreads), 0, st, x, dy, dw, g, p_per_split);
+        else
+            hipLaunchKernelGGL((conv_wgrad_vec_kernel<BM, 0, 0>), grid, dim3(kThreads), 0, st, x, dy, dw, g, p_per_split);
+        return;
+    }
     if (hwc) {
         if (g.R == 3 && g.S == 3)
             hipLaunchKernelGGL((conv_wgrad_kernel<BM, 3, 3, true>), grid, dim3(kThreads), 0, st, x, dy, dw, g, p_per_split);

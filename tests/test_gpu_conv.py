@@ -23,6 +23,14 @@ CASES = [
     (2, 8, 15, 15, 130, 3, 3, 2, 0),
     (4, 256, 7, 7, 1024, 7, 7, 1, 0),      # full-window -> GEMM path
     (1, 1024, 8, 8, 2048, 1, 1, 1, 0),
+    # same-size stride-1 layers with Cin % 128 == 0: the row-major (16-byte) weight-gradient kernel
+    (2, 128, 14, 14, 256, 3, 3, 1, 1),     # rows of 14: pixel groups continue on the next row
+    (3, 256, 12, 20, 64, 3, 3, 1, 1),      # 64-row tiles, H != W
+    (1, 128, 4, 4, 128, 3, 3, 1, 1),       # narrowest map the kernel accepts
+    (2, 128, 6, 6, 96, 3, 3, 1, 1),        # Cout not a multiple of the tile
+    (2, 128, 5, 5, 64, 3, 3, 1, 1),        # H*W % 4 != 0 -> scalar kernel
+    (5, 128, 10, 10, 128, 1, 1, 1, 0),     # pixel count not a multiple of the K-step
+    (2, 128, 9, 8, 128, 5, 5, 1, 2),       # generic window
 ]
 
 
