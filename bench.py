@@ -138,6 +138,9 @@ def main():
     ap.add_argument("--rois", type=int, default=512)
     ap.add_argument("--ot-L", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mask-head-on-positive-slots", action="store_true",
+                    help="NOT the headline configuration: run the mask head only on the RoI slots that can hold "
+                         "positives (identical loss/gradients, see MaskRCNN.forward); recorded in config.variant")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -173,6 +176,7 @@ def main():
     torch.manual_seed(2000)
     cfg = make_config(args.backbone, args.image_size, args.batch_per_gpu, args.rois, dev_switch=True,
                       loss_choice="ot", ot_L=args.ot_L, gpu_count=world)
+    cfg.MRCNN.MASK_HEAD_ON_POSITIVE_SLOTS = bool(args.mask_head_on_positive_slots)
     model = MaskRCNN(cfg).to(dev)
     broadcast_parameters(model)
     opt = set_optimizer(model, cfg.TRAIN)
@@ -274,6 +278,8 @@ def main():
                                    % (args.backbone, args.image_size, args.image_size, args.batch_per_gpu, args.rois,
                                       args.ot_L),
                        "global_batch": global_batch, "parallelism": "dp%d" % world,
+                       "variant": ("mask head on positive slots only (dead-work elimination, not the reference's "
+                                   "schedule)" if args.mask_head_on_positive_slots else "reference schedule"),
                        "conv_stack": "hand-written fp32 MFMA implicit-GEMM kernels (csrc/conv_igemm.hip); "
                                      "full-window convs and nn.Linear on the library GEMM"},
             "losses": {k: round(float(v), 5) for k, v in terms.items()},

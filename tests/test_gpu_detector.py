@@ -240,3 +240,31 @@ def test_inference_path_runs():
                          (d[:, 1] >= windows[b, 1]) & (d[:, 3] <= windows[b, 3]))
         assert torch.all(det[b, int(n[b]):] == 0)
     assert torch.isfinite(masks).all() and masks.min() >= 0 and masks.max() <= 1
+
+
+def test_mask_head_on_positive_slots_is_exact():
+    """MRCNN.MASK_HEAD_ON_POSITIVE_SLOTS skips only work whose results are never read: same loss
+    terms, same gradients (up to the summation order of atomics)."""
+    from feature_intertwiner_amd.model import MaskRCNN
+    from feature_intertwiner_amd.synthetic import SyntheticProposals, synthetic_batch
+    from feature_intertwiner_amd.workflow import compute_loss
+    batch = synthetic_batch(2, 256, device=DEV)
+    res = {}
+    for flag in (False, True):
+        torch.manual_seed(11)
+        cfg = _cfg(backbone="resnet50", image_size=256, batch_size=2, train_rois_per_image=64, ot_L=5)
+        cfg.MRCNN.MASK_HEAD_ON_POSITIVE_SLOTS = flag
+        model = MaskRCNN(cfg).to(DEV)
+        model.proposal_hook = SyntheticProposals(batch[2], 256)
+        model.generator = torch.Generator(device=DEV).manual_seed(3)
+        loss, terms = compute_loss(model, list(batch), True, 1, None)
+        loss.backward()
+        res[flag] = (float(loss.detach()), {k: float(v) for k, v in terms.items()},
+                     {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None})
+    assert abs(res[False][0] - res[True][0]) <= 1e-5 * abs(res[False][0])
+    for k in res[False][1]:
+        assert abs(res[False][1][k] - res[True][1][k]) <= 1e-5 * max(1.0, abs(res[False][1][k])), k
+    assert res[False][2].keys() == res[True][2].keys()
+    for n, g in res[False][2].items():
+        d = (g - res[True][2][n]).abs().max().item()
+        assert d <= 2e-4 * (g.abs().max().item() + 1e-6), (n, d)
