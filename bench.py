@@ -68,13 +68,46 @@ def crop_algorithmic_bytes(log_entry):
     return 4 * N * C * crop * crop + 4 * C * total_u + 24 * N
 
 
-def cpu_baseline(model, batch, log_entries):
-    """Hot-path operators of ONE step on the CPU oracle (all host cores for RoIAlign forward,
-    one thread for backward / NMS / Sinkhorn, as the reference's C and Python do): the step's
-    RoIAlign 7x7 and 14x14 forward on the real RoIs and feature-map sizes, their backward, NMS
-    of 4 x 6000 clustered proposals, and 240 Sinkhorn problems (256 samples, L=50).  The dense
-    conv stack is NOT included (it has no hand-written CPU twin here); the value is therefore
-    images/s of the operator part only and is an upper bound on a full CPU step."""
+def cpu_conv_stack_seconds(shape_log, budget_s=40.0):
+    """The step's convolutions (forward + input/weight gradients) on the host CPU through torch /
+    oneDNN -- which is how the reference runs them on its CPU path.  Every distinct layer shape is
+    timed ONCE on a reduced batch (1 image of the 4, 32 RoIs of the 2048) and scaled by batch ratio
+    and multiplicity; shapes are taken largest-first and the loop stops at `budget_s`, the remainder
+    being extrapolated from the measured seconds per flop."""
+    import collections
+    import torch.nn.functional as F
+    counts = collections.Counter(shape_log)
+    flops = lambda k: 2.0 * k[0] * k[4] * k[1] * k[5] * k[6] * ((k[2] + 2 * k[8][0] - k[5]) // k[7][0] + 1) * \
+        ((k[3] + 2 * k[8][1] - k[6]) // k[7][1] + 1)
+    todo = sorted(counts.items(), key=lambda kv: -flops(kv[0]) * kv[1])
+    total, timed_flops, timed_s, rest_flops = 0.0, 0.0, 0.0, 0.0
+    t_start = time.time()
+    for k, cnt in todo:
+        N, Cin, H, W, Cout, R, S, st, pd = k
+        if time.time() - t_start > budget_s:
+            rest_flops += 3.0 * flops(k) * cnt
+            continue
+        n_s = max(1, N // 4) if N <= 16 else 32
+        x = torch.randn(n_s, Cin, H, W, requires_grad=True)
+        w = torch.randn(Cout, Cin, R, S, requires_grad=True)
+        t = time.time()
+        y = F.conv2d(x, w, None, st, pd)
+        y.backward(torch.ones_like(y))
+        dt = (time.time() - t) * (N / n_s)
+        total += dt * cnt
+        timed_s += dt * cnt
+        timed_flops += 3.0 * flops(k) * cnt
+    if rest_flops and timed_flops:
+        total += rest_flops * (timed_s / timed_flops)
+    return total, len(todo), (timed_flops / max(timed_flops + rest_flops, 1.0))
+
+
+def cpu_baseline(model, batch, log_entries, shape_log=None):
+    """ONE step's hot path on the host CPU.  Operators on the CPU oracle (all host cores for RoIAlign
+    forward, one thread for backward / NMS / Sinkhorn, as the reference's C and Python do): the
+    step's RoIAlign 7x7 and 14x14 forward on the real RoIs and feature-map sizes, their backward,
+    NMS of 4 x 6000 clustered proposals, and 240 Sinkhorn problems (256 samples, L=50).  Conv stack
+    through torch/oneDNN on all cores (cpu_conv_stack_seconds), as the reference's CPU path does."""
     import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oracle import oracle as O
@@ -119,11 +152,21 @@ def cpu_baseline(model, batch, log_entries):
     sk = (time.time() - t) * (240.0 / n_sk)
     detail["sinkhorn_240_ms"] = sk * 1e3
     t_total += sk
-    return {"value": bs / t_total, "unit": "images/sec (hot-path operators only, conv stack excluded)",
-            "cores": O.num_threads(), "kind": "port",
-            "sample": "one step's operator work on the CPU oracle: RoIAlign 7x7+14x14 fwd (OpenMP, %d threads) "
-                      "and bwd (serial) on the step's %d RoIs, NMS 4x6000 @0.7 (serial), Sinkhorn 240x256x256 "
-                      "L=50 (serial, 24 problems timed and scaled x10)" % (O.num_threads(), log_entries[0]["boxes"].size(0)),
+    sample = ("one step's operator work on the CPU oracle: RoIAlign 7x7+14x14 fwd (OpenMP, %d threads) "
+              "and bwd (serial) on the step's %d RoIs, NMS 4x6000 @0.7 (serial), Sinkhorn 240x256x256 "
+              "L=50 (serial, 24 problems timed and scaled x10)" % (O.num_threads(), log_entries[0]["boxes"].size(0)))
+    unit = "images/sec (hot-path operators only, conv stack excluded)"
+    if shape_log:
+        conv_s, n_shapes, frac = cpu_conv_stack_seconds(shape_log)
+        detail["conv_stack_fwd_bwd_ms"] = conv_s * 1e3
+        detail["operators_ms"] = t_total * 1e3
+        t_total += conv_s
+        unit = "images/sec (operators on the CPU oracle + conv stack on torch CPU/oneDNN)"
+        sample += ("; conv stack: %d distinct layer shapes, each timed once fwd+bwd with torch on %d threads on a "
+                   "reduced batch (1 of 4 images / 32 of 2048 RoIs) and scaled; %.0f%% of the conv flops timed, "
+                   "the rest extrapolated" % (n_shapes, torch.get_num_threads(), 100 * frac))
+    return {"value": bs / t_total, "unit": unit,
+            "cores": O.num_threads(), "kind": "port", "sample": sample,
             "detail_ms": {k: round(v, 1) for k, v in detail.items()}, "host_cpus": os.cpu_count()}
 
 
@@ -200,6 +243,7 @@ def main():
     _lib.prof_enable(True)
     car.LAUNCH_LOG = []
     ficonv.FLOP_LOG = {}
+    ficonv.SHAPE_LOG = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         terms = step()
@@ -213,6 +257,9 @@ def main():
     car.LAUNCH_LOG = None
     flop_log = ficonv.FLOP_LOG
     ficonv.FLOP_LOG = None
+    shape_log = ficonv.SHAPE_LOG
+    ficonv.SHAPE_LOG = None
+    shape_log = shape_log[:len(shape_log) // max(args.steps, 1)]       # the convolutions of ONE step
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -289,7 +336,7 @@ def main():
             try:
                 entries = [e for e in log if e["pyramid"] and e["crop"] in (7, 14) and e["boxes"].size(0) ==
                            args.batch_per_gpu * args.rois][-2:]
-                out["cpu_baseline"] = cpu_baseline(model, batch, entries)
+                out["cpu_baseline"] = cpu_baseline(model, batch, entries, shape_log)
             except Exception as ex:   # the baseline must never take the headline down
                 out["cpu_baseline"] = {"error": repr(ex)}
         print(json.dumps(out))

@@ -24,6 +24,15 @@ from . import _lib
 # bench.py sets this to a dict to accumulate the algorithmic flops (2*N*Cout*OH*OW*Cin*R*S) of
 # every launch, keyed by the device kernel instance (see _lib.conv_kernel_key).
 FLOP_LOG = None
+# bench.py sets this to a list to record the (N, Cin, H, W, Cout, R, S, stride, padding) of every
+# forward convolution of a step (used to time the same stack on the host CPU for cpu_baseline).
+SHAPE_LOG = None
+
+
+def _log_shape(x, w, stride, padding):
+    if SHAPE_LOG is not None:
+        SHAPE_LOG.append((x.shape[0], x.shape[1], x.shape[2], x.shape[3], w.shape[0], w.shape[2], w.shape[3],
+                          tuple(stride), tuple(padding)))
 
 
 def _log_flops(kind, cout, R, S, flops, pixels=None):
@@ -79,6 +88,7 @@ class _Conv2dFn(torch.autograd.Function):
         bc = b.contiguous().float() if b is not None else None
         ctx.save_for_backward(x, w)
         ctx.conf = (tuple(stride), tuple(padding), b is not None)
+        _log_shape(x, w, stride, padding)
         return _conv_fwd(x, w, bc, stride, padding)
 
     @staticmethod
@@ -178,6 +188,7 @@ class _ConvBnActFn(torch.autograd.Function):
             if b is not None:
                 shift = shift + b * scale
         res = residual.contiguous().float() if residual is not None else None
+        _log_shape(x, w, stride, padding)
         y = _conv_fwd(x, w, shift.contiguous(), stride, padding, relu=relu, scale=scale.contiguous(), residual=res,
                       out_channels_last=out_cl)
         ctx.out_cl = bool(out_cl)
