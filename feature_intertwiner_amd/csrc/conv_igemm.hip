@@ -64,6 +64,7 @@ struct ConvGeom {
     int P;        // N*OH*OW
     int out_nhwc; // 1: y is [N][OH][OW][Cout] (channels-last), else [N][Cout][OH][OW]
     int flip;     // 1: tap-major weights are applied with the taps in reverse order (data gradient)
+    int swz;      // 1: XCD-aware tile order (grid padded to a multiple of 8 tiles along x)
     unsigned mul_ohw, sft_ohw, mul_ow, sft_ow;   // magic numbers: n / d == umulhi(n, mul) >> sft
 };
 
@@ -198,8 +199,23 @@ __global__ __launch_bounds__(kThreads, 4) void conv_fwd_kernel(const float *__re
     const int R = TR ? TR : g.R, S = TS ? TS : g.S;
     const int RS = R * S;
     const int K = g.K;
-    const int m0 = blockIdx.y * BM;
-    const int p0 = blockIdx.x * BN;
+    // XCD-aware tile order.  Workgroups are handed to the 8 XCDs round-robin by linear id, and each
+    // XCD has its own L2: with the plain (x fast) order the 3 image rows a 3x3 tile needs are fetched
+    // by 3 different XCDs and the Cout tiles of one pixel tile run a whole grid apart (PMC: 2.6 GB
+    // fetched for a 268 MB input).  Here XCD c owns a contiguous band of pixel tiles and walks it with
+    // the Cout tiles innermost, so halo rows and the second Cout pass hit the same L2.
+    int tile_x = blockIdx.x, tile_y = blockIdx.y;
+    if (g.swz) {             // the launcher padded gridDim.x to a multiple of 8
+        const int ny = gridDim.y;
+        const int id = blockIdx.y * gridDim.x + blockIdx.x;
+        const int per_xcd = gridDim.x >> 3;                // pixel tiles per XCD band
+        const int xcd = id & 7, local = id >> 3;
+        tile_y = local % ny;
+        tile_x = xcd * per_xcd + local / ny;
+        if (tile_x * BN >= g.P) return;                    // padding tile
+    }
+    const int m0 = tile_y * BM;
+    const int p0 = tile_x * BN;
     const int OHW = g.OH * g.OW;
     const int HW = g.H * g.W;
 
@@ -537,10 +553,23 @@ __global__ __launch_bounds__(kThreads, 3) void conv_wgrad_vec_kernel(const float
     const int wm = wave >> 1, wn = wave & 1;
     const int S = TS ? TS : g.S;
     const int K = g.K;
-    const int m0 = blockIdx.y * BM;
-    const int k0 = blockIdx.x * BN;              // 128 columns = 128 input channels of ONE tap
+    // XCD-aware order: all (tap, channel-block, Cout-block) tiles of one pixel split run on the SAME
+    // XCD, so the dY / X ranges of that split are fetched into one L2 instead of all eight
+    // (gridDim.z is padded to a multiple of 8 by the launcher when g.swz is set).
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (g.swz) {
+        const int tiles = gridDim.x * gridDim.y;
+        const int id = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        const int xcd = id & 7, local = id >> 3;
+        const int t = local % tiles;
+        bz = xcd + 8 * (local / tiles);
+        bx = t % gridDim.x;
+        by = t / gridDim.x;
+    }
+    const int m0 = by * BM;
+    const int k0 = bx * BN;                      // 128 columns = 128 input channels of ONE tap
     const int HW = g.H * g.W;                    // == OH*OW
-    const int p_begin = blockIdx.z * p_per_split;
+    const int p_begin = bz * p_per_split;
     const int p_end = min(g.P, p_begin + p_per_split);
     if (p_begin >= p_end) return;
 
@@ -757,6 +786,7 @@ int make_geom(ConvGeom &g, int N, int Cin, int H, int W, int Cout, int R, int S,
     g.sh = sh; g.sw = sw; g.ph = ph; g.pw = pw;
     g.out_nhwc = 0;
     g.flip = 0;
+    g.swz = 0;
     g.OH = out_h > 0 ? out_h : (H + 2 * ph - R) / sh + 1;   // explicit size: taps past the input read zeros
     g.OW = out_w > 0 ? out_w : (W + 2 * pw - S) / sw + 1;
     FI_REQUIRE(g.OH >= 1 && g.OW >= 1, "empty output");
@@ -784,10 +814,18 @@ int make_geom(ConvGeom &g, int N, int Cin, int H, int W, int Cout, int R, int S,
 }
 
 template <int BM>
-void launch_fwd(const ConvGeom &g, const float *x, const float *w, const Epilogue &ep, float *y,
+void launch_fwd(const ConvGeom &g_in, const float *x, const float *w, const Epilogue &ep, float *y,
                 bool hwc, hipStream_t st)
 {
-    dim3 grid(fi::ceil_div(g.P, BN), fi::ceil_div(g.Cout, BM));
+    ConvGeom g = g_in;
+    int nx = fi::ceil_div(g.P, BN);
+    // XCD-aware order for large compute-bound grids; short-K 1x1 layers are bound by their output
+    // stream and small grids by occupancy -- both measured faster in the plain order
+    if (nx >= 512 && (g.R * g.S > 1 || g.K >= 128)) {
+        g.swz = 1;
+        nx = fi::ceil_div(nx, 8) * 8;
+    }
+    dim3 grid(nx, fi::ceil_div(g.Cout, BM));
     if (hwc && g.out_nhwc) {
         if (g.R == 3 && g.S == 3)
             hipLaunchKernelGGL((conv_fwd_kernel<BM, 3, 3, true, true>), grid, dim3(kThreads), 0, st, x, w, ep, y, g);
@@ -825,12 +863,18 @@ void launch_wgrad(const ConvGeom &g, const float *x, const float *dy, float *dw,
                       (size_t)g.N * g.Cout * g.H * g.W * 4 < 0x7fffff00ULL &&
                       ((uintptr_t)x % 16 == 0) && ((uintptr_t)dy % 16 == 0);
     if (hwc && same) {
+        ConvGeom gs = g;
+        dim3 vgrid = grid;
+        if (splits >= 8 && g.P >= 131072) {   // large layers: one split per XCD at a time (padding splits return at once)
+            gs.swz = 1;
+            vgrid.z = fi::ceil_div(splits, 8) * 8;
+        }
         if (g.R == 3 && g.S == 3)
-            hipLaunchKernelGGL((conv_wgrad_vec_kernel<BM, 3, 3>), grid, dim3(kThreads), 0, st, x, dy, dw, g, p_per_split);
+            hipLaunchKernelGGL((conv_wgrad_vec_kernel<BM, 3, 3>), vgrid, dim3(kThreads), 0, st, x, dy, dw, gs, p_per_split);
         else if (g.R == 1 && g.S == 1)
-            hipLaunchKernelGGL((conv_wgrad_vec_kernel<BM, 1, 1>), grid, dim3(kThreads), 0, st, x, dy, dw, g, p_per_split);
+            hipLaunchKernelGGL((conv_wgrad_vec_kernel<BM, 1, 1>), vgrid, dim3(kThreads), 0, st, x, dy, dw, gs, p_per_split);
         else
-            hipLaunchKernelGGL((conv_wgrad_vec_kernel<BM, 0, 0>), grid, dim3(kThreads), 0, st, x, dy, dw, g, p_per_split);
+            hipLaunchKernelGGL((conv_wgrad_vec_kernel<BM, 0, 0>), vgrid, dim3(kThreads), 0, st, x, dy, dw, gs, p_per_split);
         return;
     }
     if (hwc) {
