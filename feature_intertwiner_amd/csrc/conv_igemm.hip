@@ -149,28 +149,39 @@ __device__ __forceinline__ void conv_epilogue(const f32x16 (&acc)[BM / 64][2], c
         }
         return;
     }
+    // NCHW: per-channel scale / bias are read once per accumulator row (they do not depend on the
+    // pixel column j); a wavefront store covers 32 consecutive pixels of one channel plane.
+    size_t obase[2];
+    bool pok[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int pp = p0 + wn * 64 + j * 32 + l31;
-        if (pp >= g.P) continue;
-        const int on = pp / OHW;
-        const int oq = pp - on * OHW;
-        float *__restrict__ yb = y + (size_t)on * g.Cout * OHW + oq;
+        pok[j] = pp < g.P;
+        const int ppc = pok[j] ? pp : 0;
+        const int on = fast_div(ppc, g.mul_ohw, g.sft_ohw);
+        obase[j] = (size_t)on * g.Cout * OHW + (ppc - on * OHW);
+    }
 #pragma unroll
-        for (int i = 0; i < MT; ++i)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int m = m0 + wm * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * khalf;
-                if (m < g.Cout) {
+        for (int e = 0; e < 16; ++e) {
+            const int m = m0 + wm * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * khalf;
+            if (m < g.Cout) {
+                const float sc = ep.scale ? ep.scale[m] : 1.0f;
+                const float bi = ep.bias ? ep.bias[m] : 0.0f;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    if (!pok[j]) continue;
+                    const size_t o = obase[j] + (size_t)m * OHW;
                     float v = acc[i][j][e];
-                    if (ep.scale) v = v * ep.scale[m];
-                    if (ep.bias) v += ep.bias[m];
-                    if (ep.residual) v += ep.residual[(size_t)on * g.Cout * OHW + oq + (size_t)m * OHW];
+                    if (ep.scale) v = v * sc;
+                    if (ep.bias) v += bi;
+                    if (ep.residual) v += ep.residual[o];
                     if (ep.relu) v = fmaxf(v, 0.0f);
-                    yb[(size_t)m * OHW] = v;
+                    y[o] = v;
                 }
             }
-    }
+        }
 }
 
 // -------------------------------------------------------------------------------------
