@@ -81,17 +81,18 @@ __device__ __forceinline__ int fast_div(int n, unsigned mul, unsigned sft)
 // One K-step of MFMAs on a staged [BK][BM+PAD] x [BK][BN+PAD] tile pair.  The operand
 // fragments of sub-step kk+1 are read from LDS while the MFMAs of sub-step kk issue
 // (two register sets, statically indexed), so LDS latency is not exposed per sub-step.
-template <int BM>
+template <int BM, int BNT = BN>
 __device__ __forceinline__ void mma_tile(const float (*__restrict__ As)[BM + PAD],
-                                         const float (*__restrict__ Bs)[BN + PAD], int a_col, int b_col,
-                                         int khalf, f32x16 (&acc)[BM / 64][2])
+                                         const float (*__restrict__ Bs)[BNT + PAD], int a_col, int b_col,
+                                         int khalf, f32x16 (&acc)[BM / 64][BNT / 64])
 {
     constexpr int MT = BM / 64;
-    float af[2][MT], bf[2][2];
+    constexpr int NT = BNT / 64;
+    float af[2][MT], bf[2][NT];
 #pragma unroll
     for (int i = 0; i < MT; ++i) af[0][i] = As[khalf][a_col + i * 32];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) bf[0][j] = Bs[khalf][b_col + j * 32];
+    for (int j = 0; j < NT; ++j) bf[0][j] = Bs[khalf][b_col + j * 32];
 #pragma unroll
     for (int kk = 0; kk < BK / 2; ++kk) {
         const int cur = kk & 1, nxt = cur ^ 1;
@@ -100,32 +101,33 @@ __device__ __forceinline__ void mma_tile(const float (*__restrict__ As)[BM + PAD
 #pragma unroll
             for (int i = 0; i < MT; ++i) af[nxt][i] = As[kr][a_col + i * 32];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) bf[nxt][j] = Bs[kr][b_col + j * 32];
+            for (int j = 0; j < NT; ++j) bf[nxt][j] = Bs[kr][b_col + j * 32];
         }
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < NT; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i], bf[cur][j], acc[i][j], 0, 0, 0);
     }
 }
 
 // Epilogue shared by the forward kernels.  C/D layout of v_mfma_f32_32x32x2_f32:
 // col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5).
-template <int BM, bool ONHWC>
-__device__ __forceinline__ void conv_epilogue(const f32x16 (&acc)[BM / 64][2], const Epilogue &ep,
+template <int BM, bool ONHWC, int BNT = BN>
+__device__ __forceinline__ void conv_epilogue(const f32x16 (&acc)[BM / 64][BNT / 64], const Epilogue &ep,
                                               float *__restrict__ y, const ConvGeom &g, int m0, int p0,
                                               int wm, int wn, int l31, int khalf)
 {
     constexpr int MT = BM / 64;
+    constexpr int NT = BNT / 64;
     const int OHW = g.OH * g.OW;
     if (ONHWC) {     // a separate instantiation: the wider stores must not raise the NCHW kernel's VGPR count
         // channels-last output: a lane owns 4 consecutive channels (e & 3) of its pixel -> one 16-byte
         // store; lanes l and l+32 are adjacent (32 bytes), the 4 e-groups x MT tiles complete the
         // 128..256-byte channel run of the pixel within this wavefront (merged in L2).
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int pp = p0 + wn * 64 + j * 32 + l31;
+        for (int j = 0; j < NT; ++j) {
+            const int pp = p0 + wn * (BNT / 2) + j * 32 + l31;
             if (pp >= g.P) continue;
             float *__restrict__ yb = y + (size_t)pp * g.Cout;
 #pragma unroll
@@ -151,11 +153,11 @@ __device__ __forceinline__ void conv_epilogue(const f32x16 (&acc)[BM / 64][2], c
     }
     // NCHW: per-channel scale / bias are read once per accumulator row (they do not depend on the
     // pixel column j); a wavefront store covers 32 consecutive pixels of one channel plane.
-    size_t obase[2];
-    bool pok[2];
+    size_t obase[NT];
+    bool pok[NT];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int pp = p0 + wn * 64 + j * 32 + l31;
+    for (int j = 0; j < NT; ++j) {
+        const int pp = p0 + wn * (BNT / 2) + j * 32 + l31;
         pok[j] = pp < g.P;
         const int ppc = pok[j] ? pp : 0;
         const int on = fast_div(ppc, g.mul_ohw, g.sft_ohw);
@@ -170,7 +172,7 @@ __device__ __forceinline__ void conv_epilogue(const f32x16 (&acc)[BM / 64][2], c
                 const float sc = ep.scale ? ep.scale[m] : 1.0f;
                 const float bi = ep.bias ? ep.bias[m] : 0.0f;
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
+                for (int j = 0; j < NT; ++j) {
                     if (!pok[j]) continue;
                     const size_t o = obase[j] + (size_t)m * OHW;
                     float v = acc[i][j][e];
@@ -193,7 +195,7 @@ __device__ __forceinline__ void conv_epilogue(const f32x16 (&acc)[BM / 64][2], c
 // base + i*2*H*W: ~3 instructions per load instead of ~35 for the (ci, r, s) order.
 // 4 wavefronts per SIMD (<= 128 VGPRs, accumulators included): 1024 resident workgroups, so the
 // 4096 / 8192-tile grids of the P2-level layers run as whole waves of workgroups instead of 5.33
-template <int BM, int TR, int TS, bool HWC, bool ONHWC = false>
+template <int BM, int TR, int TS, bool HWC, bool ONHWC = false, int BNT = BN>
 __global__ __launch_bounds__(kThreads, 4) void conv_fwd_kernel(const float *__restrict__ x,
                                                             const float *__restrict__ w,
                                                             Epilogue ep,
@@ -201,7 +203,10 @@ __global__ __launch_bounds__(kThreads, 4) void conv_fwd_kernel(const float *__re
 {
     constexpr int MT = BM / 64;                 // 32-row MFMA tiles per wave along M
     __shared__ float As[2][BK][BM + PAD];
-    __shared__ float Bs[2][BK][BN + PAD];
+    constexpr int NT = BNT / 64;                // 32-column MFMA tiles per wave along the pixels
+    constexpr int B_RSTEP = kThreads / BNT;     // im2col rows covered per load pass: 2 (BNT 128) or 4 (BNT 64)
+    constexpr int B_LOADS = BK / B_RSTEP;       // 8 or 4 loads per thread and K-step
+    __shared__ float Bs[2][BK][BNT + PAD];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -223,16 +228,16 @@ __global__ __launch_bounds__(kThreads, 4) void conv_fwd_kernel(const float *__re
         const int xcd = id & 7, local = id >> 3;
         tile_y = local % ny;
         tile_x = xcd * per_xcd + local / ny;
-        if (tile_x * BN >= g.P) return;                    // padding tile
+        if (tile_x * BNT >= g.P) return;                    // padding tile
     }
     const int m0 = tile_y * BM;
-    const int p0 = tile_x * BN;
+    const int p0 = tile_x * BNT;
     const int OHW = g.OH * g.OW;
     const int HW = g.H * g.W;
 
     // ---- per-thread constants of the B (im2col) gather: one pixel column, 8 k rows ----
-    const int bj = tid & (BN - 1);
-    const int bk0 = tid >> 7;                   // 0 or 1; rows bk0, bk0+2, ... (wave-uniform)
+    const int bj = tid & (BNT - 1);
+    const int bk0 = tid / BNT;                  // first row; rows bk0, bk0 + B_RSTEP, ... (wave-uniform)
     const int p = p0 + bj;
     const bool p_ok = p < g.P;
     int n = 0, oh = 0, ow = 0;
@@ -259,7 +264,7 @@ __global__ __launch_bounds__(kThreads, 4) void conv_fwd_kernel(const float *__re
     // the compiler wait for it on the spot (s_waitcnt vmcnt) and the prefetch would be synchronous.
     // The halo / tail zeroing is therefore a bit mask applied when the tile is written to LDS.
     float a_reg[A_LOADS][4];
-    float b_reg[BK / 2];
+    float b_reg[B_LOADS];
     unsigned b_mask = 0;
 
     // HWC state: tap and channel base of the NEXT K-step to be loaded (calls are sequential)
@@ -310,9 +315,9 @@ __global__ __launch_bounds__(kThreads, 4) void conv_fwd_kernel(const float *__re
             const bool ok = (tap_mask >> rs) & 1ULL;
             const int off0 = pix_off + r * g.W + s + (cur_ci0 + bk0) * HW;
             const float *__restrict__ bp = ok ? (xn + off0) : g_zero_page;
-            const int stride = ok ? 2 * HW : 0;
+            const int stride = ok ? B_RSTEP * HW : 0;
 #pragma unroll
-            for (int i = 0; i < BK / 2; ++i) b_reg[i] = bp[i * stride];
+            for (int i = 0; i < B_LOADS; ++i) b_reg[i] = bp[i * stride];
             cur_ci0 += BK;
             if (cur_ci0 >= g.Cin) {
                 cur_ci0 = 0;
@@ -322,8 +327,8 @@ __global__ __launch_bounds__(kThreads, 4) void conv_fwd_kernel(const float *__re
         }
         b_mask = 0;
 #pragma unroll
-        for (int i = 0; i < BK / 2; ++i) {
-            const int k = __builtin_amdgcn_readfirstlane(kbase + bk0 + 2 * i);
+        for (int i = 0; i < B_LOADS; ++i) {
+            const int k = __builtin_amdgcn_readfirstlane(kbase + bk0 + B_RSTEP * i);
             const int kc = min(k, K - 1);
             const int ci = kc / RS;
             const int rs = kc - ci * RS;
@@ -342,15 +347,15 @@ __global__ __launch_bounds__(kThreads, 4) void conv_fwd_kernel(const float *__re
 #pragma unroll
             for (int q = 0; q < 4; ++q) As[buf][ak4 + q][am + i * A_ROWS] = a_reg[i][q];
 #pragma unroll
-        for (int i = 0; i < BK / 2; ++i)
-            Bs[buf][bk0 + 2 * i][bj] = (HWC || ((b_mask >> i) & 1u)) ? b_reg[i] : 0.0f;
+        for (int i = 0; i < B_LOADS; ++i)
+            Bs[buf][bk0 + B_RSTEP * i][bj] = (HWC || ((b_mask >> i) & 1u)) ? b_reg[i] : 0.0f;
     };
 
-    f32x16 acc[MT][2];
+    f32x16 acc[MT][NT];
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NT; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
@@ -364,12 +369,12 @@ __global__ __launch_bounds__(kThreads, 4) void conv_fwd_kernel(const float *__re
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
         if (kt + 1 < nk) load_tiles(kt + 1);          // lands while the MFMAs below run
-        mma_tile<BM>(As[buf], Bs[buf], wm * (BM / 2) + l31, wn * 64 + l31, khalf, acc);
+        mma_tile<BM, BNT>(As[buf], Bs[buf], wm * (BM / 2) + l31, wn * (BNT / 2) + l31, khalf, acc);
         if (kt + 1 < nk) store_tiles(buf ^ 1);
         __syncthreads();
     }
 
-    conv_epilogue<BM, ONHWC>(acc, ep, y, g, m0, p0, wm, wn, l31, khalf);
+    conv_epilogue<BM, ONHWC, BNT>(acc, ep, y, g, m0, p0, wm, wn, l31, khalf);
 }
 
 // -------------------------------------------------------------------------------------
@@ -829,6 +834,21 @@ void launch_fwd(const ConvGeom &g_in, const float *x, const float *w, const Epil
                 bool hwc, hipStream_t st)
 {
     ConvGeom g = g_in;
+    // 64-pixel tiles when even 64-row tiles leave fewer than 4 workgroups per CU (C4/C5 of the backbone
+    // at batch 4): twice the workgroups, so that 4 wavefronts share each SIMD's MFMA pipe
+    if constexpr (BM == 64) {
+        const long wgs = (long)fi::ceil_div(g.P, BN) * fi::ceil_div(g.Cout, BM);
+        if (hwc && !g.out_nhwc && wgs < 1024 && g.P >= 64) {
+            dim3 grid64(fi::ceil_div(g.P, 64), fi::ceil_div(g.Cout, BM));
+            if (g.R == 3 && g.S == 3)
+                hipLaunchKernelGGL((conv_fwd_kernel<64, 3, 3, true, false, 64>), grid64, dim3(kThreads), 0, st, x, w, ep, y, g);
+            else if (g.R == 1 && g.S == 1)
+                hipLaunchKernelGGL((conv_fwd_kernel<64, 1, 1, true, false, 64>), grid64, dim3(kThreads), 0, st, x, w, ep, y, g);
+            else
+                hipLaunchKernelGGL((conv_fwd_kernel<64, 0, 0, true, false, 64>), grid64, dim3(kThreads), 0, st, x, w, ep, y, g);
+            return;
+        }
+    }
     int nx = fi::ceil_div(g.P, BN);
     // XCD-aware order for large compute-bound grids; short-K 1x1 layers are bound by their output
     // stream and small grids by occupancy -- both measured faster in the plain order
