@@ -207,8 +207,9 @@ class _ConvBnActFn(torch.autograd.Function):
         N, C, OH, OW = y.shape
         dz = torch.empty(y.shape, device=y.device, dtype=torch.float32)
         g_res = torch.empty_like(y) if (has_res and ctx.needs_input_grad[8]) else None
-        dshift = torch.empty(C, device=y.device, dtype=torch.float32)
-        dgamma = torch.empty(C, device=y.device, dtype=torch.float32) if ctx.needs_input_grad[3] else None
+        sums = torch.empty((2, C), device=y.device, dtype=torch.float32)      # adjacent: ONE zero-fill inside the call
+        dshift = sums[0]
+        dgamma = sums[1] if ctx.needs_input_grad[3] else None
         with torch.cuda.device(y.device):
             _lib.check(L.fi_bn_act_backward(_lib.ptr(dy), _lib.ptr(y), _lib.ptr(scale), _lib.ptr(gamma),
                                             _lib.ptr(beta), _lib.ptr(res), N, C, OH * OW, 1 if relu else 0,

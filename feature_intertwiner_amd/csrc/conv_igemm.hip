@@ -1128,8 +1128,12 @@ int fi_bn_act_backward(const float *dy, const float *y, const float *scale, cons
     FI_REQUIRE(!dgamma || gamma, "dgamma needs gamma");
     FI_REQUIRE(layout == 0 || layout == 1, "layout: 0 = dy,y [N][C][HW], 1 = dy,y [N][HW][C]");
     hipStream_t st = (hipStream_t)stream;
-    FI_HIP_CHECK(hipMemsetAsync(dshift, 0, sizeof(float) * C, st));
-    if (dgamma) FI_HIP_CHECK(hipMemsetAsync(dgamma, 0, sizeof(float) * C, st));
+    if (dgamma == dshift + C) {                       // adjacent buffers: one fill
+        FI_HIP_CHECK(hipMemsetAsync(dshift, 0, sizeof(float) * 2 * C, st));
+    } else {
+        FI_HIP_CHECK(hipMemsetAsync(dshift, 0, sizeof(float) * C, st));
+        if (dgamma) FI_HIP_CHECK(hipMemsetAsync(dgamma, 0, sizeof(float) * C, st));
+    }
     if (layout == 1) {
         FI_REQUIRE(residual == nullptr && g_out == nullptr, "channels-last backward has no fused residual");
         FI_REQUIRE((long)N * HW < 2147483647L, "too many pixels");
