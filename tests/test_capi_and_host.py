@@ -54,6 +54,22 @@ def test_argument_validation_without_a_gpu():
     assert L.fi_nms_sorted(None, 1, 10, 3, 0.5, 0, 0, None, None, None, None) == -1
     assert L.fi_roi_pool_forward(None, None, 1, 1, 1, 4, 4, 0, 7, 1.0, None, None, None) == -1
     assert L.fi_class_mean_forward(None, None, 0, 8, 500, None, None, None) == -3
+    # channels-last pyramid crop: level array required with several maps, crop bounded by the LDS tile
+    import ctypes
+    ptrs = (ctypes.c_void_p * 2)(16, 32)
+    hs = (ctypes.c_int * 2)(8, 4)
+    assert L.fi_pyramid_crop_forward_nhwc(ptrs, hs, hs, 2, 16, 16, None, 1, 1, 64, 7, 7, 0.0, 16, None) == -1
+    assert b"level" in L.fi_last_error()
+    assert L.fi_pyramid_crop_forward_nhwc(ptrs, hs, hs, 0, 16, 16, 16, 1, 1, 64, 7, 7, 0.0, 16, None) == -1
+    # conv: layouts are validated before anything is launched
+    a = [16, 16, None, None, None, 16]
+    assert L.fi_conv2d_forward(*a, 1, 32, 8, 8, 64, 3, 3, 1, 1, 1, 1, 0, 5, 0, 0, 0, None) == -1
+    assert b"weight_layout" in L.fi_last_error()
+    assert L.fi_conv2d_forward(*a, 1, 32, 8, 8, 64, 3, 3, 1, 1, 1, 1, 0, 1, 0, 0, 2, None) == -1
+    assert b"output_layout" in L.fi_last_error()
+    assert L.fi_conv2d_forward(*a, 1, 30, 8, 8, 64, 3, 3, 1, 1, 1, 1, 0, 1, 0, 0, 0, None) == -1      # tap-major needs Cin % 16
+    assert L.fi_conv2d_forward(*a, 1, 32, 8, 8, 62, 3, 3, 1, 1, 1, 1, 0, 1, 0, 0, 1, None) == -1      # NHWC needs Cout % 4
+    assert L.fi_bn_act_backward(16, 16, 16, None, None, None, 1, 8, 16, 1, 16, None, 16, None, 3, None) == -1
 
 
 def test_reference_shaped_python_surface():
