@@ -223,6 +223,47 @@ class _ConvBnActFn(torch.autograd.Function):
         return dx, dw, db, dgamma, dbeta, None, None, None, g_res, None, None, None, None, None
 
 
+class _ConvBiasActFn(torch.autograd.Function):
+    """y = relu(conv(x) + bias) in one launch (layers without a BatchNorm: the RPN's shared conv,
+    lib/sub_module.py:256-259; the mask head's deconv, :779-780).  Backward reuses the fused
+    elementwise pass with a unit scale: it yields the ReLU-masked gradient and the bias gradient
+    together (instead of threshold_backward + a separate reduction)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, stride, padding):
+        _lib.require_cuda(x, w)
+        x = x.contiguous().float()
+        w = w.contiguous().float()
+        bc = b.contiguous().float() if b is not None else None
+        _log_shape(x, w, stride, padding)
+        y = _conv_fwd(x, w, bc, stride, padding, relu=True)
+        ctx.save_for_backward(x, w, y)
+        ctx.conf = (tuple(stride), tuple(padding), b is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y = ctx.saved_tensors
+        stride, padding, has_bias = ctx.conf
+        L = _lib.load()
+        dy = dy.contiguous().float()
+        N, C, OH, OW = y.shape
+        dz = torch.empty_like(y)
+        ones = torch.ones(C, device=y.device, dtype=torch.float32)
+        dshift = torch.empty(C, device=y.device, dtype=torch.float32)
+        with torch.cuda.device(y.device):
+            _lib.check(L.fi_bn_act_backward(_lib.ptr(dy), _lib.ptr(y), _lib.ptr(ones), None, None, None, N, C, OH * OW, 1,
+                                            _lib.ptr(dz), None, _lib.ptr(dshift), None, 0,
+                                            _lib.current_stream()), "fi_bn_act_backward")
+        dx, dw = _conv_backward(ctx.needs_input_grad, x, w, dz, stride, padding)
+        return dx, dw, (dshift if (has_bias and ctx.needs_input_grad[2]) else None), None, None
+
+
+def conv_bias_relu(x, weight, bias=None, stride=(1, 1), padding=(0, 0)):
+    """relu(conv2d(x, weight, bias)) fused (weight [Cout, Cin, R, S])."""
+    return _ConvBiasActFn.apply(x, weight, bias, tuple(stride), tuple(padding))
+
+
 # ---- eval-BN fold (scale, shift) for every (conv, bn) pair, refreshed once per step ------------
 # Folding inside each layer costs ~5 tiny launches per layer (500 per step); refresh_bn_folds()
 # does all layers with a handful of torch._foreach_* launches.  A cached fold is used only while
@@ -323,6 +364,19 @@ class ConvTranspose2x2(nn.ConvTranspose2d):
         w = self.weight.permute(1, 2, 3, 0).reshape(cout * 4, cin, 1, 1)
         b = self.bias.repeat_interleave(4) if self.bias is not None else None
         return F.pixel_shuffle(conv2d(x, w, b), 2)
+
+    def forward_unshuffled(self, x, relu=False):
+        """The same values BEFORE the pixel shuffle, as [N, 2, 2, Cout, H, W] with
+        out[n, c, 2h+a, 2w+b] == u[n, a, b, c, h, w] (optionally with ReLU fused into the 1x1 conv).
+        A following 1x1 convolution / elementwise op can consume u viewed as [N*4, Cout, H, W] and
+        only its (smaller) result needs shuffling -- the mask head moves 81 channels instead of 256."""
+        assert self.kernel_size == (2, 2) and self.stride == (2, 2) and self.padding == (0, 0) and \
+            self.output_padding == (0, 0) and self.groups == 1
+        cin, cout = self.weight.shape[0], self.weight.shape[1]
+        w = self.weight.permute(2, 3, 1, 0).reshape(4 * cout, cin, 1, 1)       # output channels ordered (a, b, c)
+        b = self.bias.repeat(4) if self.bias is not None else None
+        y = conv_bias_relu(x, w, b) if relu else conv2d(x, w, b)
+        return y.view(x.shape[0], 2, 2, cout, x.shape[2], x.shape[3])
 
 
 class Conv1d(nn.Conv1d):

@@ -359,6 +359,20 @@ def compute_mrcnn_bbox_loss(target_bbox, target_class_ids, pred_bbox):
     return (l * pos).sum() / (pos.sum() * 4).clamp(min=1)
 
 
+def compute_mrcnn_mask_loss_unshuffled(target_masks, target_class_ids, pred_u):
+    """compute_mrcnn_mask_loss for the mask head's un-shuffled output pred_u [b, R, 2, 2, K, h, w]
+    (pred[.., k, 2y+a, 2x+b] == pred_u[.., a, b, k, y, x]): the class channel is gathered first and only
+    that [b, R, 2, 2, h, w] slice is pixel-shuffled.  Same value and gradient."""
+    cls = target_class_ids.long()
+    b, R, _, _, K, h, w = pred_u.shape
+    idx = cls.view(b, R, 1, 1, 1, 1, 1).expand(-1, -1, 2, 2, 1, h, w)
+    pred = torch.gather(pred_u, 4, idx).squeeze(4)                                  # [b, R, 2, 2, h, w]
+    pred = pred.permute(0, 1, 4, 2, 5, 3).reshape(b, R, 2 * h, 2 * w)
+    pos = (cls > 0).float().view(b, R, 1, 1)
+    l = F.binary_cross_entropy(pred, target_masks, reduction='none')
+    return (l * pos).sum() / (pos.sum() * 4 * h * w).clamp(min=1)
+
+
 def compute_mrcnn_mask_loss(target_masks, target_class_ids, pred_masks):
     """pred_masks [b, R, num_classes, h, w] probabilities: positives only, class-specific mask."""
     cls = target_class_ids.long()

@@ -15,7 +15,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .conv import Conv2d, ConvTranspose2x2, conv_bn_act
+from .conv import Conv2d, ConvTranspose2x2, conv_bias_relu, conv_bn_act
 from .intertwiner import class_mean, roi_level
 from .roi_align.crop_and_resize import CropAndResizeFunction, pyramid_crop_and_resize
 from .roi_pooling.functions.roi_pool import RoIPoolFunction
@@ -195,7 +195,8 @@ class RPN(nn.Module):
         self.conv_bbox = Conv2d(512, 4 * anchors_per_location, kernel_size=1, stride=1)
 
     def forward(self, x):
-        x = self.relu(self.conv_shared(self.padding(x)))
+        c = self.conv_shared
+        x = conv_bias_relu(self.padding(x), c.weight, c.bias, c.stride, c.padding)      # conv + bias + ReLU, one launch
         logits = self.conv_class(x).permute(0, 2, 3, 1).contiguous().view(x.size(0), -1, 2)
         probs = self.softmax(logits)
         bbox = self.conv_bbox(x).permute(0, 2, 3, 1).contiguous().view(x.size(0), -1, 4)
@@ -412,10 +413,20 @@ class Mask(nn.Module):
         self.sigmoid = nn.Sigmoid()
         self.relu = nn.ReLU(inplace=True)
 
-    def forward(self, x):
+    def forward(self, x, shuffled=True):
+        """shuffled=True: [N, K, 28, 28] as the reference (lib/sub_module.py:769-787).
+        shuffled=False: the same values as [N, 2, 2, K, 14, 14] with out[n,k,2h+a,2w+b] = u[n,a,b,k,h,w]
+        (training: the loss gathers the class channel first and shuffles only that)."""
         x = conv_bn_act(x, self.conv1, self.bn1, relu=True)
         x = conv_bn_act(x, self.conv2, self.bn2, relu=True)
         x = conv_bn_act(x, self.conv3, self.bn3, relu=True)
         x = conv_bn_act(x, self.conv4, self.bn4, relu=True)
-        x = self.relu(self.deconv(x))
-        return self.sigmoid(self.conv5(x))
+        # deconv(k2,s2) = 1x1 conv to (a, b, c) channels; ReLU, conv5 (1x1) and sigmoid are per pixel, so
+        # they run before the pixel shuffle and only 81 channels are ever moved
+        u = self.deconv.forward_unshuffled(x, relu=True)                 # [N, 2, 2, 256, H, W]
+        n, h, w = u.shape[0], u.shape[4], u.shape[5]
+        y = self.sigmoid(self.conv5(u.view(n * 4, u.shape[3], h, w)))
+        y = y.view(n, 2, 2, y.shape[1], h, w)
+        if not shuffled:
+            return y
+        return y.permute(0, 3, 4, 1, 5, 2).reshape(n, y.shape[3], 2 * h, 2 * w)

@@ -198,3 +198,30 @@ def test_bn_fold_cache_tracks_parameter_versions():
     y1 = C.conv_bn_act(x, conv, bn)
     C.refresh_bn_folds()
     assert torch.allclose(C.conv_bn_act(x, conv, bn), y1, rtol=1e-5, atol=1e-5)
+
+
+def test_conv_bias_relu_and_unshuffled_deconv_match_torch():
+    from feature_intertwiner_amd.conv import ConvTranspose2x2, conv_bias_relu
+    torch.manual_seed(5)
+    x = torch.randn(3, 32, 9, 11, device=DEV)
+    w = torch.randn(48, 32, 3, 3, device=DEV) * 0.1
+    b = torch.randn(48, device=DEV)
+    g = torch.randn(3, 48, 9, 11, device=DEV)
+    res = []
+    for fused in (False, True):
+        xi, wi, bi = (t.clone().requires_grad_(True) for t in (x, w, b))
+        y = conv_bias_relu(xi, wi, bi, (1, 1), (1, 1)) if fused else F.relu(F.conv2d(xi, wi, bi, 1, 1))
+        y.backward(g)
+        res.append((y.detach(), xi.grad, wi.grad, bi.grad))
+    for a, c in zip(*res):
+        assert (a - c).abs().max().item() <= 1e-4 * (a.abs().max().item() + 1e-6)
+    # deconv: un-shuffled form (+ fused ReLU) vs torch's ConvTranspose2d + ReLU
+    ref = torch.nn.ConvTranspose2d(32, 24, 2, stride=2).to(DEV)
+    m = ConvTranspose2x2(32, 24, kernel_size=2, stride=2).to(DEV)
+    m.load_state_dict(ref.state_dict())
+    exp = F.relu(ref(x))
+    u = m.forward_unshuffled(x, relu=True)
+    assert u.shape == (3, 2, 2, 24, 9, 11)
+    got = u.permute(0, 3, 4, 1, 5, 2).reshape(3, 24, 18, 22)
+    assert torch.allclose(got, exp, rtol=1e-4, atol=1e-5)
+    assert torch.allclose(F.relu(m(x)), exp, rtol=1e-4, atol=1e-5)

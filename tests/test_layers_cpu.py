@@ -124,3 +124,22 @@ def test_config_and_state_dict_names():
     assert m.mask.deconv.weight.shape == (256, 256, 2, 2)
     assert m.priors.shape == (3 * (32 * 32 + 16 * 16 + 8 * 8 + 4 * 4 + 2 * 2), 4)
     assert not m.training or True
+
+
+def test_unshuffled_mask_loss_equals_standard_form():
+    """compute_mrcnn_mask_loss_unshuffled on the mask head's pre-shuffle layout == the standard loss
+    on the shuffled tensor (value and gradient)."""
+    from feature_intertwiner_amd import layers as L
+    torch.manual_seed(0)
+    b, R, K, h, w = 2, 6, 5, 3, 4
+    u = torch.rand(b, R, 2, 2, K, h, w).clamp(0.05, 0.95).requires_grad_(True)
+    std = u.detach().permute(0, 1, 4, 5, 2, 6, 3).reshape(b, R, K, 2 * h, 2 * w).requires_grad_(True)
+    cls = torch.tensor([[1, 3, 0, 0, 4, 2], [2, 0, 0, 1, 1, 0]], dtype=torch.int32)
+    tgt = (torch.rand(b, R, 2 * h, 2 * w) > 0.5).float()
+    l1 = L.compute_mrcnn_mask_loss_unshuffled(tgt, cls, u)
+    l2 = L.compute_mrcnn_mask_loss(tgt, cls, std)
+    assert abs(float(l1) - float(l2)) < 1e-6
+    l1.backward()
+    l2.backward()
+    g2 = std.grad.view(b, R, K, h, 2, w, 2).permute(0, 1, 4, 6, 2, 3, 5)
+    assert torch.allclose(u.grad, g2, atol=1e-7)
