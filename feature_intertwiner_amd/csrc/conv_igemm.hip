@@ -65,6 +65,7 @@ struct ConvGeom {
     int out_nhwc; // 1: y is [N][OH][OW][Cout] (channels-last), else [N][Cout][OH][OW]
     int flip;     // 1: tap-major weights are applied with the taps in reverse order (data gradient)
     int swz;      // 1: XCD-aware tile order (grid padded to a multiple of 8 tiles along x)
+    int vec_out;  // 1: NCHW output rows can be written 4 pixels at a time (OH*OW % 4 == 0, 16-byte aligned)
     unsigned mul_ohw, sft_ohw, mul_ow, sft_ow;   // magic numbers: n / d == umulhi(n, mul) >> sft
 };
 
@@ -116,11 +117,68 @@ __device__ __forceinline__ void mma_tile(const float (*__restrict__ As)[BM + PAD
 template <int BM, bool ONHWC, int BNT = BN>
 __device__ __forceinline__ void conv_epilogue(const f32x16 (&acc)[BM / 64][BNT / 64], const Epilogue &ep,
                                               float *__restrict__ y, const ConvGeom &g, int m0, int p0,
-                                              int wm, int wn, int l31, int khalf)
+                                              int wm, int wn, int l31, int khalf, float *__restrict__ scratch)
 {
     constexpr int MT = BM / 64;
     constexpr int NT = BNT / 64;
     const int OHW = g.OH * g.OW;
+    if (!ONHWC && g.vec_out) {
+        // NCHW through a wavefront-private LDS transpose: the MFMA layout gives a lane 16 different
+        // channels of ONE pixel (64 scalar stores, and 64 scalar shortcut loads, per lane and tile); after
+        // a [16 channels][32 pixels] round trip through LDS a lane owns 4 consecutive pixels of a channel:
+        // 16-byte stores / shortcut loads, 4x fewer memory instructions.  `scratch` is this wavefront's
+        // slice of the (no longer needed) operand tiles; LDS operations of one wavefront execute in order,
+        // so no barrier is involved.
+        constexpr int SP = 36;                       // scratch row pitch (floats): 16-byte aligned rows
+        const int lane = l31 + 32 * khalf;
+        const int rr = lane >> 3;                    // 0..7 (+8 for the second read)
+        const int c4 = (lane & 7) * 4;
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int pp = p0 + wn * (BNT / 2) + j * 32 + c4;
+                const bool pv = pp < g.P;            // P % 4 == 0 here: the 4 pixels are valid together
+                const int ppc = pv ? pp : 0;
+                const int on = fast_div(ppc, g.mul_ohw, g.sft_ohw);
+                const size_t obase = (size_t)on * g.Cout * OHW + (ppc - on * OHW);
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+#pragma unroll
+                    for (int e8 = 0; e8 < 8; ++e8) {
+                        const int e = half * 8 + e8;
+                        scratch[((e & 3) + 8 * ((e >> 2) & 1) + 4 * khalf) * SP + l31] = acc[i][j][e];
+                    }
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        const int row = rr + 8 * t;                                  // 0..15 within the half
+                        const int m = m0 + wm * (BM / 2) + i * 32 + half * 16 + row;
+                        float4 v = *reinterpret_cast<const float4 *>(&scratch[row * SP + c4]);
+                        if (pv && m < g.Cout) {
+                            const size_t o = obase + (size_t)m * OHW;
+                            if (ep.scale) {
+                                const float sc = ep.scale[m];
+                                v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
+                            }
+                            if (ep.bias) {
+                                const float bi = ep.bias[m];
+                                v.x += bi; v.y += bi; v.z += bi; v.w += bi;
+                            }
+                            if (ep.residual) {
+                                const float4 r = *reinterpret_cast<const float4 *>(ep.residual + o);
+                                v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+                            }
+                            if (ep.relu) {
+                                v.x = fmaxf(v.x, 0.0f); v.y = fmaxf(v.y, 0.0f);
+                                v.z = fmaxf(v.z, 0.0f); v.w = fmaxf(v.w, 0.0f);
+                            }
+                            *reinterpret_cast<float4 *>(y + o) = v;
+                        }
+                    }
+                }
+            }
+        return;
+    }
     if (ONHWC) {     // a separate instantiation: the wider stores must not raise the NCHW kernel's VGPR count
         // channels-last output: a lane owns 4 consecutive channels (e & 3) of its pixel -> one 16-byte
         // store; lanes l and l+32 are adjacent (32 bytes), the 4 e-groups x MT tiles complete the
@@ -202,11 +260,15 @@ __global__ __launch_bounds__(kThreads, 4) void conv_fwd_kernel(const float *__re
                                                             float *__restrict__ y, ConvGeom g)
 {
     constexpr int MT = BM / 64;                 // 32-row MFMA tiles per wave along M
-    __shared__ float As[2][BK][BM + PAD];
     constexpr int NT = BNT / 64;                // 32-column MFMA tiles per wave along the pixels
     constexpr int B_RSTEP = kThreads / BNT;     // im2col rows covered per load pass: 2 (BNT 128) or 4 (BNT 64)
     constexpr int B_LOADS = BK / B_RSTEP;       // 8 or 4 loads per thread and K-step
-    __shared__ float Bs[2][BK][BNT + PAD];
+    // one buffer: [2][BK][BM+PAD] weight tiles, then [2][BK][BNT+PAD] im2col tiles; the epilogue reuses it
+    constexpr int A_FLOATS = 2 * BK * (BM + PAD), B_FLOATS = 2 * BK * (BNT + PAD);
+    static_assert((A_FLOATS + B_FLOATS) / 4 >= 16 * 36, "epilogue scratch does not fit");
+    __shared__ __attribute__((aligned(16))) float smem[A_FLOATS + B_FLOATS];
+    float (*As)[BK][BM + PAD] = reinterpret_cast<float (*)[BK][BM + PAD]>(smem);
+    float (*Bs)[BK][BNT + PAD] = reinterpret_cast<float (*)[BK][BNT + PAD]>(smem + A_FLOATS);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -374,7 +436,8 @@ __global__ __launch_bounds__(kThreads, 4) void conv_fwd_kernel(const float *__re
         __syncthreads();
     }
 
-    conv_epilogue<BM, ONHWC, BNT>(acc, ep, y, g, m0, p0, wm, wn, l31, khalf);
+    conv_epilogue<BM, ONHWC, BNT>(acc, ep, y, g, m0, p0, wm, wn, l31, khalf,
+                                  smem + wave * (((A_FLOATS + B_FLOATS) / 4) & ~3));
 }
 
 // -------------------------------------------------------------------------------------
@@ -803,6 +866,7 @@ int make_geom(ConvGeom &g, int N, int Cin, int H, int W, int Cout, int R, int S,
     g.out_nhwc = 0;
     g.flip = 0;
     g.swz = 0;
+    g.vec_out = 0;
     g.OH = out_h > 0 ? out_h : (H + 2 * ph - R) / sh + 1;   // explicit size: taps past the input read zeros
     g.OW = out_w > 0 ? out_w : (W + 2 * pw - S) / sw + 1;
     FI_REQUIRE(g.OH >= 1 && g.OW >= 1, "empty output");
@@ -834,6 +898,8 @@ void launch_fwd(const ConvGeom &g_in, const float *x, const float *w, const Epil
                 bool hwc, hipStream_t st)
 {
     ConvGeom g = g_in;
+    g.vec_out = (!g.out_nhwc && (g.OH * g.OW) % 4 == 0 && ((uintptr_t)y % 16 == 0) &&
+                 (ep.residual == nullptr || (uintptr_t)ep.residual % 16 == 0)) ? 1 : 0;
     // 64-pixel tiles when even 64-row tiles leave fewer than 4 workgroups per CU (C4/C5 of the backbone
     // at batch 4): twice the workgroups, so that 4 wavefronts share each SIMD's MFMA pipe
     if constexpr (BM == 64) {
