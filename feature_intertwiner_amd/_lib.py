@@ -56,7 +56,7 @@ SIGNATURES = {
                                        c_void_p]),
     "fi_conv2d_forward": (c_int, [c_void_p] * 6 + [c_int] * 16 + [c_void_p]),
     "fi_bn_act_backward": (c_int, [c_void_p] * 6 + [c_int] * 4 + [c_void_p] * 4 + [c_int, c_void_p]),
-    "fi_conv2d_weight_grad": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 12 + [c_void_p]),
+    "fi_conv2d_weight_grad": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 12 + [c_void_p, c_void_p]),
     "fi_prof_enable": (None, [c_int]),
     "fi_prof_reset": (None, []),
     "fi_prof_get": (c_int, [c_int, _ip, ctypes.POINTER(c_float)]),

@@ -96,8 +96,11 @@ class _Conv2dFn(torch.autograd.Function):
         x, w = ctx.saved_tensors
         stride, padding, has_bias = ctx.conf
         dy = dy.contiguous().float()
-        dx, dw = _conv_backward(ctx.needs_input_grad, x, w, dy, stride, padding)
-        db = dy.sum((0, 2, 3)) if (has_bias and ctx.needs_input_grad[2]) else None
+        if has_bias and ctx.needs_input_grad[2]:
+            dx, dw, db = _conv_backward(ctx.needs_input_grad, x, w, dy, stride, padding, want_db=True)
+        else:
+            dx, dw = _conv_backward(ctx.needs_input_grad, x, w, dy, stride, padding)
+            db = None
         return dx, dw, db, None, None
 
 
@@ -137,12 +140,14 @@ def _strided_dgrad(dz, w, in_hw, stride, padding):
     return dx
 
 
-def _conv_backward(ctx_needs, x, w, dz, stride, padding):
-    """dX and dW of z = conv(x, w) given dz (shared by the plain and the fused functions)."""
+def _conv_backward(ctx_needs, x, w, dz, stride, padding, want_db=False):
+    """dX and dW of z = conv(x, w) given dz (shared by the plain and the fused functions).
+    want_db: also return sum(dz) over images and pixels (the bias gradient), accumulated by the
+    weight-gradient kernel from the dY tiles it stages anyway."""
     L = _lib.load()
     N, Cin, H, W = x.shape
     Cout, _, R, S = w.shape
-    dx = dw = None
+    dx = dw = db = None
     if ctx_needs[0]:
         if stride == (1, 1):
             if Cout % 16 == 0 and R * S <= 64:
@@ -161,13 +166,17 @@ def _conv_backward(ctx_needs, x, w, dz, stride, padding):
         dw = torch.empty((Cout, R, S, Cin) if (hwc and R * S > 1) else (Cout, Cin, R, S), device=x.device,
                          dtype=torch.float32)
         _log_flops("wgrad", Cout, R, S, 2 * N * Cout * dz.shape[2] * dz.shape[3] * Cin * R * S)
+        if want_db:
+            db = torch.empty(Cout, device=x.device, dtype=torch.float32)
         with torch.cuda.device(x.device):
             _lib.check(L.fi_conv2d_weight_grad(_lib.ptr(x), _lib.ptr(dz), _lib.ptr(dw), N, Cin, H, W, Cout,
                                                R, S, stride[0], stride[1], padding[0], padding[1], hwc,
-                                               _lib.current_stream()), "fi_conv2d_weight_grad")
+                                               _lib.ptr(db), _lib.current_stream()), "fi_conv2d_weight_grad")
         if hwc and R * S > 1:
             dw = dw.permute(0, 3, 1, 2)
-    return dx, dw
+    elif want_db:
+        db = dz.sum((0, 2, 3))
+    return (dx, dw, db) if want_db else (dx, dw)
 
 
 class _ConvBnActFn(torch.autograd.Function):

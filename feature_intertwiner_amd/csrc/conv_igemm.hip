@@ -452,7 +452,7 @@ template <int BM, int TR, int TS, bool HWC>
 __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(const float *__restrict__ x,
                                                               const float *__restrict__ dy,
                                                               float *__restrict__ dw, ConvGeom g,
-                                                              int p_per_split)
+                                                              int p_per_split, float *__restrict__ dbias)
 {
     constexpr int MT = BM / 64;
     __shared__ float As[2][BK][BM + PAD];       // dY tile  [p][m]
@@ -552,10 +552,19 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(const float *__res
             b_mask |= inb ? (1u << i) : 0u;
         }
     };
+    // bias gradient (sum of dY over images and pixels): the workgroups of the first column tile see
+    // every dY element of their rows exactly once on its way to LDS
+    const bool do_bias = dbias != nullptr && blockIdx.x == 0;
+    float bsum[A_LOADS];
+#pragma unroll
+    for (int i = 0; i < A_LOADS; ++i) bsum[i] = 0.0f;
     auto store_tiles = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < A_LOADS; ++i)
-            As[buf][ap][am + W_COLS * i] = (HWC || ((a_mask >> i) & 1u)) ? a_reg[i] : 0.0f;
+        for (int i = 0; i < A_LOADS; ++i) {
+            const float v = (HWC || ((a_mask >> i) & 1u)) ? a_reg[i] : 0.0f;
+            As[buf][ap][am + W_COLS * i] = v;
+            if (do_bias) bsum[i] += v;
+        }
 #pragma unroll
         for (int i = 0; i < B_LOADS; ++i)
             Bs[buf][bp][bk + W_COLS * i] = (HWC || ((b_mask >> i) & 1u)) ? b_reg[i] : 0.0f;
@@ -594,6 +603,18 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(const float *__res
                 if (m < g.Cout) atomicAdd(dw + (size_t)m * K + k, acc[i][j][e]);
             }
     }
+    if (do_bias) {                 // the 16 lanes that share `am` hold the 16 pixels of a K-step
+#pragma unroll
+        for (int i = 0; i < A_LOADS; ++i) {
+            float v = bsum[i];
+            v += __shfl_xor(v, 1, 64);
+            v += __shfl_xor(v, 2, 64);
+            v += __shfl_xor(v, 4, 64);
+            v += __shfl_xor(v, 8, 64);
+            const int m = m0 + am + W_COLS * i;
+            if (ap == 0 && m < g.Cout) atomicAdd(dbias + m, v);
+        }
+    }
 }
 
 // -------------------------------------------------------------------------------------
@@ -618,7 +639,7 @@ template <int BM, int TR, int TS>
 __global__ __launch_bounds__(kThreads, 3) void conv_wgrad_vec_kernel(const float *__restrict__ x,
                                                                      const float *__restrict__ dy,
                                                                      float *__restrict__ dw, ConvGeom g,
-                                                                     int p_per_split)
+                                                                     int p_per_split, float *__restrict__ dbias)
 {
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     constexpr int MT = BM / 64;
@@ -764,10 +785,18 @@ __global__ __launch_bounds__(kThreads, 3) void conv_wgrad_vec_kernel(const float
         for (int i = 0; i < B_LOADS; ++i)
             b_reg[i] = __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, b_off + (mk ? b_row4[i] : 0), 0, 0);
     };
+    const bool do_bias = dbias != nullptr && bx == 0;      // see conv_wgrad_kernel
+    float bsum[A_LOADS];
+#pragma unroll
+    for (int i = 0; i < A_LOADS; ++i) bsum[i] = 0.0f;
     auto store_tiles = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < A_LOADS; ++i)
+        for (int i = 0; i < A_LOADS; ++i) {
             *reinterpret_cast<u32x4 *>(&As[buf][lr + 64 * i][4 * lj]) = a_reg[i];
+            if (do_bias)
+                bsum[i] += (__uint_as_float(a_reg[i].x) + __uint_as_float(a_reg[i].y)) +
+                           (__uint_as_float(a_reg[i].z) + __uint_as_float(a_reg[i].w));
+        }
 #pragma unroll
         for (int i = 0; i < B_LOADS; ++i) {
             u32x4 v = b_reg[i];
@@ -836,6 +865,16 @@ __global__ __launch_bounds__(kThreads, 3) void conv_wgrad_vec_kernel(const float
                 const int m = m0 + wm * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * khalf;
                 if (m < g.Cout) atomicAdd(dw + (size_t)m * K + k, acc[i][j][e]);
             }
+    }
+    if (do_bias) {                 // the 4 lanes that share `lr` hold the 16 pixels of a K-step
+#pragma unroll
+        for (int i = 0; i < A_LOADS; ++i) {
+            float v = bsum[i];
+            v += __shfl_xor(v, 1, 64);
+            v += __shfl_xor(v, 2, 64);
+            const int m = m0 + lr + 64 * i;
+            if (lj == 0 && m < g.Cout) atomicAdd(dbias + m, v);
+        }
     }
 }
 
@@ -951,7 +990,7 @@ void launch_fwd(const ConvGeom &g_in, const float *x, const float *w, const Epil
 
 template <int BM>
 void launch_wgrad(const ConvGeom &g, const float *x, const float *dy, float *dw, int splits,
-                  int p_per_split, bool hwc, hipStream_t st)
+                  int p_per_split, bool hwc, float *dbias, hipStream_t st)
 {
     dim3 grid(fi::ceil_div(g.K, BN), fi::ceil_div(g.Cout, BM), splits);
     // same-size stride-1 layers (every 3x3/pad-1 and 1x1 layer of the model): row-major tiles, 16-byte LDS traffic
@@ -967,30 +1006,30 @@ void launch_wgrad(const ConvGeom &g, const float *x, const float *dy, float *dw,
             vgrid.z = fi::ceil_div(splits, 8) * 8;
         }
         if (g.R == 3 && g.S == 3)
-            hipLaunchKernelGGL((conv_wgrad_vec_kernel<BM, 3, 3>), vgrid, dim3(kThreads), 0, st, x, dy, dw, gs, p_per_split);
+            hipLaunchKernelGGL((conv_wgrad_vec_kernel<BM, 3, 3>), vgrid, dim3(kThreads), 0, st, x, dy, dw, gs, p_per_split, dbias);
         else if (g.R == 1 && g.S == 1)
-            hipLaunchKernelGGL((conv_wgrad_vec_kernel<BM, 1, 1>), vgrid, dim3(kThreads), 0, st, x, dy, dw, gs, p_per_split);
+            hipLaunchKernelGGL((conv_wgrad_vec_kernel<BM, 1, 1>), vgrid, dim3(kThreads), 0, st, x, dy, dw, gs, p_per_split, dbias);
         else
-            hipLaunchKernelGGL((conv_wgrad_vec_kernel<BM, 0, 0>), vgrid, dim3(kThreads), 0, st, x, dy, dw, gs, p_per_split);
+            hipLaunchKernelGGL((conv_wgrad_vec_kernel<BM, 0, 0>), vgrid, dim3(kThreads), 0, st, x, dy, dw, gs, p_per_split, dbias);
         return;
     }
     if (hwc) {
         if (g.R == 3 && g.S == 3)
-            hipLaunchKernelGGL((conv_wgrad_kernel<BM, 3, 3, true>), grid, dim3(kThreads), 0, st, x, dy, dw, g, p_per_split);
+            hipLaunchKernelGGL((conv_wgrad_kernel<BM, 3, 3, true>), grid, dim3(kThreads), 0, st, x, dy, dw, g, p_per_split, dbias);
         else if (g.R == 1 && g.S == 1)
-            hipLaunchKernelGGL((conv_wgrad_kernel<BM, 1, 1, true>), grid, dim3(kThreads), 0, st, x, dy, dw, g, p_per_split);
+            hipLaunchKernelGGL((conv_wgrad_kernel<BM, 1, 1, true>), grid, dim3(kThreads), 0, st, x, dy, dw, g, p_per_split, dbias);
         else
-            hipLaunchKernelGGL((conv_wgrad_kernel<BM, 0, 0, true>), grid, dim3(kThreads), 0, st, x, dy, dw, g, p_per_split);
+            hipLaunchKernelGGL((conv_wgrad_kernel<BM, 0, 0, true>), grid, dim3(kThreads), 0, st, x, dy, dw, g, p_per_split, dbias);
         return;
     }
     if (g.R == 3 && g.S == 3)
-        hipLaunchKernelGGL((conv_wgrad_kernel<BM, 3, 3, false>), grid, dim3(kThreads), 0, st, x, dy, dw, g, p_per_split);
+        hipLaunchKernelGGL((conv_wgrad_kernel<BM, 3, 3, false>), grid, dim3(kThreads), 0, st, x, dy, dw, g, p_per_split, dbias);
     else if (g.R == 1 && g.S == 1)
-        hipLaunchKernelGGL((conv_wgrad_kernel<BM, 1, 1, false>), grid, dim3(kThreads), 0, st, x, dy, dw, g, p_per_split);
+        hipLaunchKernelGGL((conv_wgrad_kernel<BM, 1, 1, false>), grid, dim3(kThreads), 0, st, x, dy, dw, g, p_per_split, dbias);
     else if (g.R == 7 && g.S == 7)
-        hipLaunchKernelGGL((conv_wgrad_kernel<BM, 7, 7, false>), grid, dim3(kThreads), 0, st, x, dy, dw, g, p_per_split);
+        hipLaunchKernelGGL((conv_wgrad_kernel<BM, 7, 7, false>), grid, dim3(kThreads), 0, st, x, dy, dw, g, p_per_split, dbias);
     else
-        hipLaunchKernelGGL((conv_wgrad_kernel<BM, 0, 0, false>), grid, dim3(kThreads), 0, st, x, dy, dw, g, p_per_split);
+        hipLaunchKernelGGL((conv_wgrad_kernel<BM, 0, 0, false>), grid, dim3(kThreads), 0, st, x, dy, dw, g, p_per_split, dbias);
 }
 
 // -------------------------------------------------------------------------------------
@@ -1229,7 +1268,7 @@ int fi_bn_act_backward(const float *dy, const float *y, const float *scale, cons
 
 int fi_conv2d_weight_grad(const float *x, const float *dy, float *dweight, int N, int Cin, int H,
                           int W, int Cout, int R, int S, int stride_h, int stride_w, int pad_h,
-                          int pad_w, int weight_layout, fi_stream_t stream)
+                          int pad_w, int weight_layout, float *dbias, fi_stream_t stream)
 {
     ConvGeom g;
     int rc = make_geom(g, N, Cin, H, W, Cout, R, S, stride_h, stride_w, pad_h, pad_w);
@@ -1240,6 +1279,7 @@ int fi_conv2d_weight_grad(const float *x, const float *dy, float *dweight, int N
     FI_REQUIRE(hwc || weight_layout == 0 , "weight_layout 1 needs Cin % 128 == 0");
     hipStream_t st = (hipStream_t)stream;
     FI_HIP_CHECK(hipMemsetAsync(dweight, 0, sizeof(float) * (size_t)Cout * g.K, st));
+    if (dbias) FI_HIP_CHECK(hipMemsetAsync(dbias, 0, sizeof(float) * (size_t)Cout, st));
     const int BMsel = Cout <= 64 ? 64 : 128;
     const long tiles = (long)fi::ceil_div(g.K, BN) * fi::ceil_div(Cout, BMsel);
     // enough workgroups to fill 256 CUs x 2, but at least 512 pixels per split
@@ -1252,9 +1292,9 @@ int fi_conv2d_weight_grad(const float *x, const float *dy, float *dweight, int N
     splits = fi::ceil_div(g.P, pps);
     fi::ProfScope prof(FI_K_CONV_WGRAD + (BMsel == 64 ? 0 : 4) + window_class(R, S), st);
     if (BMsel == 64)
-        launch_wgrad<64>(g, x, dy, dweight, splits, pps, hwc, st);
+        launch_wgrad<64>(g, x, dy, dweight, splits, pps, hwc, dbias, st);
     else
-        launch_wgrad<128>(g, x, dy, dweight, splits, pps, hwc, st);
+        launch_wgrad<128>(g, x, dy, dweight, splits, pps, hwc, dbias, st);
     FI_HIP_CHECK(hipGetLastError());
     return FI_OK;
 }

@@ -243,6 +243,7 @@ int fi_class_mean_backward(const float *grad_feat, const int32_t *gt,
  * fi_conv2d_weight_grad: dweight [Cout,Cin,R,S] = sum over images and pixels of
  * dy (x) patches(x); zero-filled by the call, accumulated with fp32 atomics over a split
  * of the pixel range.  weight_layout 1 writes dweight as [Cout,R,S,Cin] (needs Cin % 128 == 0).
+ * dbias (optional, [Cout]) receives the bias gradient sum(dy) from the same pass over dy.
  * ---------------------------------------------------------------------- */
 int fi_conv2d_forward(const float *x, const float *weight, const float *bias,
                       const float *scale, const float *residual, float *y, int N, int Cin,
@@ -260,7 +261,8 @@ int fi_bn_act_backward(const float *dy, const float *y, const float *scale, cons
                        fi_stream_t stream);
 int fi_conv2d_weight_grad(const float *x, const float *dy, float *dweight, int N, int Cin,
                           int H, int W, int Cout, int R, int S, int stride_h, int stride_w,
-                          int pad_h, int pad_w, int weight_layout, fi_stream_t stream);
+                          int pad_h, int pad_w, int weight_layout, float *dbias,
+                          fi_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * In-library kernel timing (HIP events recorded on the launch stream around
