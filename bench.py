@@ -173,7 +173,7 @@ def cpu_baseline(model, batch, log_entries, shape_log=None):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=16)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--backbone", default="resnet101")
     ap.add_argument("--image-size", type=int, default=1024)
