@@ -268,3 +268,33 @@ def test_mask_head_on_positive_slots_is_exact():
     for n, g in res[False][2].items():
         d = (g - res[True][2][n]).abs().max().item()
         assert d <= 2e-4 * (g.abs().max().item() + 1e-6), (n, d)
+
+
+@pytest.mark.parametrize("name,kw,size,bs", [
+    ("configs[0]: R50, 2 x 512^2, 64 RoIs, OT off", dict(backbone="resnet50", image_size=512, batch_size=2,
+                                                         train_rois_per_image=64, dev_switch=False), 512, 2),
+    ("configs[1]: R50, 4 x 1024^2, 256 RoIs", dict(backbone="resnet50", image_size=1024, batch_size=4,
+                                                   train_rois_per_image=256, ot_L=5), 1024, 4),
+])
+def test_baseline_configs_run(name, kw, size, bs):
+    """The other BASELINE.json configurations as plain 'does a train step run and stay finite' cases
+    (configs[2] is the bench workload; configs[0] exercises the non-intertwiner pyramid_roi_align path)."""
+    from feature_intertwiner_amd.model import MaskRCNN
+    from feature_intertwiner_amd.synthetic import SyntheticProposals, synthetic_batch
+    from feature_intertwiner_amd.workflow import set_optimizer, train_step
+    torch.manual_seed(2000)
+    cfg = _cfg(**kw)
+    model = MaskRCNN(cfg).to(DEV)
+    opt = set_optimizer(model, cfg.TRAIN)
+    batch = synthetic_batch(bs, size, device=DEV)
+    model.proposal_hook = SyntheticProposals(batch[2], size)
+    model.generator = torch.Generator(device=DEV).manual_seed(3)
+    first = last = None
+    for _ in range(3):
+        t = train_step(model, opt, list(batch), do_meta=cfg.DEV.SWITCH)
+        assert all(torch.isfinite(v) for v in t.values()), (name, t)
+        first = first if first is not None else float(t["total"])
+        last = float(t["total"])
+    assert last < first, (name, first, last)
+    del model, opt
+    torch.cuda.empty_cache()
