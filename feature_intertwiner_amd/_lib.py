@@ -50,8 +50,9 @@ SIGNATURES = {
                               c_void_p, c_void_p, c_void_p]),
     "fi_sinkhorn_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_int, c_int,
                                     c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "fi_class_mean_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "fi_class_mean_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,
-                                      c_void_p]),
+                                      c_void_p, c_void_p]),
     "fi_class_mean_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p,
                                        c_void_p]),
     "fi_conv2d_forward": (c_int, [c_void_p] * 6 + [c_int] * 16 + [c_void_p]),

@@ -23,9 +23,12 @@ class _ClassMean(torch.autograd.Function):
         N, F = f2.shape
         feat = torch.empty((F, num_classes), device=f2.device, dtype=torch.float32)
         cnt = torch.empty((num_classes,), device=f2.device, dtype=torch.float32)
+        ws = torch.empty((max(L.fi_class_mean_workspace_bytes(N, F, int(num_classes)), 4) // 4,),
+                         device=f2.device, dtype=torch.float32)
         with torch.cuda.device(f2.device):
             _lib.check(L.fi_class_mean_forward(_lib.ptr(f2), _lib.ptr(gt_c), N, F, int(num_classes),
-                                               _lib.ptr(feat), _lib.ptr(cnt), _lib.current_stream()),
+                                               _lib.ptr(feat), _lib.ptr(cnt), _lib.ptr(ws),
+                                               _lib.current_stream()),
                        "fi_class_mean_forward")
         ctx.save_for_backward(gt_c, cnt)
         ctx.shape = tuple(features.shape)

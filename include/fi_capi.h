@@ -212,8 +212,11 @@ int fi_sinkhorn_forward(const float *x, const float *y, int num_problems, int S,
  * feat [F, num_classes] (column c = mean of rows with class c, 0 if absent);
  * cnt  [num_classes] fp32 counts.
  * ---------------------------------------------------------------------- */
+size_t fi_class_mean_workspace_bytes(int N, int F, int num_classes);
+/* workspace: fi_class_mean_workspace_bytes(N, F, num_classes) bytes of device memory (partial sums
+ * of the row chunks; summed in a fixed order, so the result is deterministic). */
 int fi_class_mean_forward(const float *features, const int32_t *gt, int N, int F,
-                          int num_classes, float *feat, float *cnt,
+                          int num_classes, float *feat, float *cnt, float *workspace,
                           fi_stream_t stream);
 /* grad_features[n, f] = grad_feat[f, gt[n]] / cnt[gt[n]] for foreground rows, else 0. */
 int fi_class_mean_backward(const float *grad_feat, const int32_t *gt,

@@ -53,7 +53,8 @@ def test_argument_validation_without_a_gpu():
     assert L.fi_sinkhorn_forward(None, None, 1, 16, 1, 1.0, 0, 0, None, None, None, None, None) == -1
     assert L.fi_nms_sorted(None, 1, 10, 3, 0.5, 0, 0, None, None, None, None) == -1
     assert L.fi_roi_pool_forward(None, None, 1, 1, 1, 4, 4, 0, 7, 1.0, None, None, None) == -1
-    assert L.fi_class_mean_forward(None, None, 0, 8, 500, None, None, None) == -3
+    assert L.fi_class_mean_forward(None, None, 0, 8, 500, None, None, None, None) == -3
+    assert L.fi_class_mean_workspace_bytes(2048, 1024, 81) == 32 * 81 * 1024 * 4
     # channels-last pyramid crop: level array required with several maps, crop bounded by the LDS tile
     import ctypes
     ptrs = (ctypes.c_void_p * 2)(16, 32)
