@@ -636,7 +636,7 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(const float *__res
 // would zero the whole 16 bytes, so those few K-steps use 4-byte loads (workgroup-uniform branch).
 // -------------------------------------------------------------------------------------
 template <int BM, int TR, int TS>
-__global__ __launch_bounds__(kThreads, 3) void conv_wgrad_vec_kernel(const float *__restrict__ x,
+__global__ __launch_bounds__(kThreads, 4) void conv_wgrad_vec_kernel(const float *__restrict__ x,
                                                                      const float *__restrict__ dy,
                                                                      float *__restrict__ dw, ConvGeom g,
                                                                      int p_per_split, float *__restrict__ dbias)
@@ -1001,10 +1001,7 @@ void launch_wgrad(const ConvGeom &g, const float *x, const float *dy, float *dw,
     if (hwc && same) {
         ConvGeom gs = g;
         dim3 vgrid = grid;
-        if (splits >= 8 && g.P >= 131072) {   // large layers: one split per XCD at a time (padding splits return at once)
-            gs.swz = 1;
-            vgrid.z = fi::ceil_div(splits, 8) * 8;
-        }
+        if (splits % 8 == 0 && g.P >= 131072) gs.swz = 1;    // large layers: whole splits per XCD (no padding: it would add a round)
         if (g.R == 3 && g.S == 3)
             hipLaunchKernelGGL((conv_wgrad_vec_kernel<BM, 3, 3>), vgrid, dim3(kThreads), 0, st, x, dy, dw, gs, p_per_split, dbias);
         else if (g.R == 1 && g.S == 1)
@@ -1282,8 +1279,10 @@ int fi_conv2d_weight_grad(const float *x, const float *dy, float *dweight, int N
     if (dbias) FI_HIP_CHECK(hipMemsetAsync(dbias, 0, sizeof(float) * (size_t)Cout, st));
     const int BMsel = Cout <= 64 ? 64 : 128;
     const long tiles = (long)fi::ceil_div(g.K, BN) * fi::ceil_div(Cout, BMsel);
-    // enough workgroups to fill 256 CUs x 2, but at least 512 pixels per split
-    long want = (1024 + tiles - 1) / tiles;
+    // Split the pixel range so that tiles x splits fills the 1024 resident workgroup slots (256 CUs x 4)
+    // in ONE round: every workgroup has the same amount of work, so 1044 workgroups on 1024 slots take
+    // two rounds (the first version rounded UP and paid exactly that).  At least 512 pixels per split.
+    long want = 1024 / tiles;
     long max_splits = (g.P + 511) / 512;
     int splits = (int)(want < 1 ? 1 : (want > max_splits ? max_splits : want));
     if (splits < 1) splits = 1;
