@@ -78,13 +78,18 @@ for _i, _bm in enumerate((64, 128)):
         KERNEL_IDS["conv_wgrad_bm%d_%s" % (_bm, _w)] = 22 + 4 * _i + _j
 
 
-def conv_kernel_key(kind, cout, R, S, pixels=None):
+def conv_kernel_key(kind, cout, R, S, pixels=None, cin=None):
     """Name (KERNEL_IDS key) of the device kernel instance a convolution launch uses (mirrors
-    use_bm64() in csrc/conv_igemm.hip: 64-row tiles for narrow layers and under-filled grids)."""
+    use_bm64() and the tile choice of fi_conv2d_weight_grad in csrc/conv_igemm.hip: 64-row tiles for
+    narrow layers and under-filled grids)."""
     w = {(1, 1): "1x1", (3, 3): "3x3", (7, 7): "7x7"}.get((R, S), "other")
     bm64 = cout <= 64
     if kind == "fwd" and not bm64 and pixels is not None:
         bm64 = ((pixels + 127) // 128) * ((cout + 127) // 128) < 512
+    if kind == "wgrad" and not bm64 and pixels is not None and cin is not None:
+        tiles128 = ((cin * R * S + 127) // 128) * ((cout + 127) // 128)
+        max_splits = (pixels + 511) // 512
+        bm64 = tiles128 * min(max(1, 1024 // tiles128), max_splits) < 768
     return "conv_%s_bm%d_%s" % (kind, 64 if bm64 else 128, w)
 
 

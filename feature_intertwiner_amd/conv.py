@@ -35,9 +35,9 @@ def _log_shape(x, w, stride, padding):
                           tuple(stride), tuple(padding)))
 
 
-def _log_flops(kind, cout, R, S, flops, pixels=None):
+def _log_flops(kind, cout, R, S, flops, pixels=None, cin=None):
     if FLOP_LOG is not None:
-        k = _lib.conv_kernel_key(kind, cout, R, S, pixels)
+        k = _lib.conv_kernel_key(kind, cout, R, S, pixels, cin)
         e = FLOP_LOG.setdefault(k, [0, 0])
         e[0] += 1
         e[1] += flops
@@ -165,7 +165,8 @@ def _conv_backward(ctx_needs, x, w, dz, stride, padding, want_db=False):
         hwc = 1 if (Cin % 128 == 0) else 0         # tap-major fast path of the kernel
         dw = torch.empty((Cout, R, S, Cin) if (hwc and R * S > 1) else (Cout, Cin, R, S), device=x.device,
                          dtype=torch.float32)
-        _log_flops("wgrad", Cout, R, S, 2 * N * Cout * dz.shape[2] * dz.shape[3] * Cin * R * S)
+        _log_flops("wgrad", Cout, R, S, 2 * N * Cout * dz.shape[2] * dz.shape[3] * Cin * R * S,
+                   N * dz.shape[2] * dz.shape[3], Cin)
         if want_db:
             db = torch.empty(Cout, device=x.device, dtype=torch.float32)
         with torch.cuda.device(x.device):

@@ -1277,7 +1277,12 @@ int fi_conv2d_weight_grad(const float *x, const float *dy, float *dweight, int N
     hipStream_t st = (hipStream_t)stream;
     FI_HIP_CHECK(hipMemsetAsync(dweight, 0, sizeof(float) * (size_t)Cout * g.K, st));
     if (dbias) FI_HIP_CHECK(hipMemsetAsync(dbias, 0, sizeof(float) * (size_t)Cout, st));
-    const int BMsel = Cout <= 64 ? 64 : 128;
+    // 64-row tiles for narrow layers, and when 128-row tiles x the admissible splits (>= 512 pixels each)
+    // would fill less than 3/4 of the resident slots (C4/C5 1x1 layers at batch 4)
+    const long max_splits0 = (g.P + 511) / 512;
+    const long tiles128 = (long)fi::ceil_div(g.K, BN) * fi::ceil_div(Cout, 128);
+    const long reach128 = tiles128 * (1024 / tiles128 < max_splits0 ? (1024 / tiles128 < 1 ? 1 : 1024 / tiles128) : max_splits0);
+    const int BMsel = (Cout <= 64 || reach128 < 768) ? 64 : 128;
     const long tiles = (long)fi::ceil_div(g.K, BN) * fi::ceil_div(Cout, BMsel);
     // Split the pixel range so that tiles x splits fills the 1024 resident workgroup slots (256 CUs x 4)
     // in ONE round: every workgroup has the same amount of work, so 1044 workgroups on 1024 slots take
