@@ -66,6 +66,7 @@ struct ConvGeom {
     int flip;     // 1: tap-major weights are applied with the taps in reverse order (data gradient)
     int swz;      // 1: XCD-aware tile order (grid padded to a multiple of 8 tiles along x)
     int vec_out;  // 1: NCHW output rows can be written 4 pixels at a time (OH*OW % 4 == 0, 16-byte aligned)
+    int p_base;   // first output pixel of this launch (a layer may be split into a main and a tail launch)
     unsigned mul_ohw, sft_ohw, mul_ow, sft_ow;   // magic numbers: n / d == umulhi(n, mul) >> sft
 };
 
@@ -290,10 +291,10 @@ __global__ __launch_bounds__(kThreads, 4) void conv_fwd_kernel(const float *__re
         const int xcd = id & 7, local = id >> 3;
         tile_y = local % ny;
         tile_x = xcd * per_xcd + local / ny;
-        if (tile_x * BNT >= g.P) return;                    // padding tile
+        if (g.p_base + tile_x * BNT >= g.P) return;         // padding tile
     }
     const int m0 = tile_y * BM;
-    const int p0 = tile_x * BNT;
+    const int p0 = g.p_base + tile_x * BNT;
     const int OHW = g.OH * g.OW;
     const int HW = g.H * g.W;
 
@@ -906,6 +907,7 @@ int make_geom(ConvGeom &g, int N, int Cin, int H, int W, int Cout, int R, int S,
     g.flip = 0;
     g.swz = 0;
     g.vec_out = 0;
+    g.p_base = 0;
     g.OH = out_h > 0 ? out_h : (H + 2 * ph - R) / sh + 1;   // explicit size: taps past the input read zeros
     g.OW = out_w > 0 ? out_w : (W + 2 * pw - S) / sw + 1;
     FI_REQUIRE(g.OH >= 1 && g.OW >= 1, "empty output");
@@ -951,6 +953,31 @@ void launch_fwd(const ConvGeom &g_in, const float *x, const float *w, const Epil
                 hipLaunchKernelGGL((conv_fwd_kernel<64, 1, 1, true, false, 64>), grid64, dim3(kThreads), 0, st, x, w, ep, y, g);
             else
                 hipLaunchKernelGGL((conv_fwd_kernel<64, 0, 0, true, false, 64>), grid64, dim3(kThreads), 0, st, x, w, ep, y, g);
+            return;
+        }
+    }
+    // Tail launch.  All tiles of a layer cost the same, so a grid of r.f "rounds" of the 1024 resident
+    // workgroups ends with a round that uses a fraction f of the chip (mask head: 6272 tiles = 6.125
+    // rounds).  A small remainder is cut off and run as 64x64 tiles -- 4x the workgroups, a quarter of the
+    // work each -- so that it spreads over all CUs.
+    if constexpr (BM == 128) {
+        const long ny = fi::ceil_div(g.Cout, BM);
+        const long nx_all = fi::ceil_div(g.P, BN);
+        const long wgs = nx_all * ny, slots = 1024;
+        const long rem = wgs % slots;
+        if (hwc && !g.out_nhwc && g.p_base == 0 && wgs > slots && rem > 0 && rem * 3 < slots && slots % ny == 0) {
+            const long nx_main = (wgs / slots) * (slots / ny);
+            ConvGeom gm = g, gt = g;
+            gm.P = (int)(nx_main * BN);
+            launch_fwd<128>(gm, x, w, ep, y, hwc, st);          // p_base == 0, wgs % slots == 0: no recursion
+            gt.p_base = gm.P;
+            dim3 grid64(fi::ceil_div(g.P - gm.P, 64), fi::ceil_div(g.Cout, 64));
+            if (g.R == 3 && g.S == 3)
+                hipLaunchKernelGGL((conv_fwd_kernel<64, 3, 3, true, false, 64>), grid64, dim3(kThreads), 0, st, x, w, ep, y, gt);
+            else if (g.R == 1 && g.S == 1)
+                hipLaunchKernelGGL((conv_fwd_kernel<64, 1, 1, true, false, 64>), grid64, dim3(kThreads), 0, st, x, w, ep, y, gt);
+            else
+                hipLaunchKernelGGL((conv_fwd_kernel<64, 0, 0, true, false, 64>), grid64, dim3(kThreads), 0, st, x, w, ep, y, gt);
             return;
         }
     }

@@ -31,6 +31,7 @@ CASES = [
     (2, 128, 5, 5, 64, 3, 3, 1, 1),        # H*W % 4 != 0 -> scalar kernel
     (5, 128, 10, 10, 128, 1, 1, 1, 0),     # pixel count not a multiple of the K-step
     (2, 128, 9, 8, 128, 5, 5, 1, 2),       # generic window
+    (33, 16, 64, 64, 128, 3, 3, 1, 1),     # 1056 tiles on 1024 slots: main launch + 64x64-tile tail launch
 ]
 
 
