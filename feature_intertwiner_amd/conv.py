@@ -162,7 +162,12 @@ def _conv_backward(ctx_needs, x, w, dz, stride, padding, want_db=False):
         else:
             dx = _strided_dgrad(dz, w, (H, W), stride, padding)
     if ctx_needs[1]:
-        hwc = 1 if (Cin % 128 == 0) else 0         # tap-major fast path of the kernel
+        # tap-major dW ([Cout,R,S,Cin]): 128 channels of one tap per column tile, or -- same-size stride-1
+        # layers with Cin == 64 (the C2 stage) -- 64 channels of two taps (mirrors wgrad_same_size())
+        same = (stride == (1, 1) and dz.shape[2] == H and dz.shape[3] == W and (H * W) % 4 == 0 and W >= 4 and
+                x.numel() * 4 < 0x7fffff00 and dz.numel() * 4 < 0x7fffff00 and
+                x.data_ptr() % 16 == 0 and dz.data_ptr() % 16 == 0)
+        hwc = 1 if (Cin % 128 == 0 or (Cin == 64 and same)) else 0
         dw = torch.empty((Cout, R, S, Cin) if (hwc and R * S > 1) else (Cout, Cin, R, S), device=x.device,
                          dtype=torch.float32)
         _log_flops("wgrad", Cout, R, S, 2 * N * Cout * dz.shape[2] * dz.shape[3] * Cin * R * S,

@@ -636,7 +636,9 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(const float *__res
 // the last rows of the tensor.  A NEGATIVE start offset (first channel of the first image only)
 // would zero the whole 16 bytes, so those few K-steps use 4-byte loads (workgroup-uniform branch).
 // -------------------------------------------------------------------------------------
-template <int BM, int TR, int TS>
+// HALF: Cin == 64 -- a workgroup's 128 columns are the 64 channels of TWO consecutive taps (rows 0..63
+// of the X tile belong to tap t, rows 64..127 to tap t+1), so the C2-stage layers use this kernel too.
+template <int BM, int TR, int TS, bool HALF = false>
 __global__ __launch_bounds__(kThreads, 4) void conv_wgrad_vec_kernel(const float *__restrict__ x,
                                                                      const float *__restrict__ dy,
                                                                      float *__restrict__ dw, ConvGeom g,
@@ -674,11 +676,23 @@ __global__ __launch_bounds__(kThreads, 4) void conv_wgrad_vec_kernel(const float
     const int p_end = min(g.P, p_begin + p_per_split);
     if (p_begin >= p_end) return;
 
-    const int rs = k0 / g.Cin;
-    const int ci0 = k0 - rs * g.Cin;
-    const int r = rs / S, s = rs - (rs / S) * S;
-    const int dr = r - g.ph, ds = s - g.pw;
-    const int off_tap = dr * g.W + ds;
+    constexpr int NTAP = HALF ? 2 : 1;
+    const int RS = (TR ? TR : g.R) * S;
+    const int rs0 = k0 / g.Cin;
+    const int ci0 = HALF ? 0 : (k0 - rs0 * g.Cin);
+    int dr_t[NTAP], ds_t[NTAP], off_t[NTAP];
+    bool tap_ok[NTAP];
+#pragma unroll
+    for (int t = 0; t < NTAP; ++t) {
+        const int rs = rs0 + t;
+        tap_ok[t] = rs < RS;
+        const int rc = tap_ok[t] ? rs : 0;
+        const int r = rc / S, s = rc - (rc / S) * S;
+        dr_t[t] = r - g.ph;
+        ds_t[t] = s - g.pw;
+        off_t[t] = dr_t[t] * g.W + ds_t[t];
+    }
+    const int off_min = (NTAP == 2) ? min(off_t[0], off_t[1]) : off_t[0];
 
     const int lj = tid & 3;                      // which 4 of the step's 16 pixels
     const int lr = tid >> 2;                     // row 0..63 (+64 per further load)
@@ -688,17 +702,19 @@ __global__ __launch_bounds__(kThreads, 4) void conv_wgrad_vec_kernel(const float
 #pragma unroll
     for (int i = 0; i < A_LOADS; ++i) a_row4[i] = min(m0 + lr + 64 * i, g.Cout - 1) * HW * 4;
 #pragma unroll
-    for (int i = 0; i < B_LOADS; ++i) b_row4[i] = (ci0 + lr + 64 * i) * HW * 4;
+    for (int i = 0; i < B_LOADS; ++i) b_row4[i] = (HALF ? lr : (ci0 + lr + 64 * i)) * HW * 4;
     const __amdgpu_buffer_rsrc_t dy_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(dy), 0, (int)((size_t)g.N * g.Cout * HW * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(x), 0, (int)((size_t)g.N * g.Cin * HW * 4), 0x00020000);
     const int kOutOfRange = 0x7ffffff0;
     // K-steps whose input offsets can be negative: first channel block, first image, first rows
-    const bool neg_block = (ci0 == 0) && (off_tap < 0);
+    const bool neg_block = (ci0 == 0) && (off_min < 0);
 
     u32x4 a_reg[A_LOADS], b_reg[B_LOADS];
-    unsigned b_mask = 0;
+    unsigned b_mask[NTAP];
+#pragma unroll
+    for (int t = 0; t < NTAP; ++t) b_mask[t] = 0;
     // Pixel state of this thread's 4-pixel group, advanced by 16 pixels per K-step with adds and
     // compares only (VALU instructions in the K loop come straight out of the MFMA issue budget):
     // image cn, pixel cq = coh*OW + cow, and the byte offsets of the group in dY / X.
@@ -710,16 +726,10 @@ __global__ __launch_bounds__(kThreads, 4) void conv_wgrad_vec_kernel(const float
     int coh = fast_div(cq, g.mul_ow, g.sft_ow);
     int cow = cq - coh * g.OW;
     int a_cur = (cn * g.Cout * HW + cq) * 4;
-    int b_cur = (cn * g.Cin * HW + cq + off_tap) * 4;          // may be negative when neg_block
+    int b_cur = (cn * g.Cin * HW + cq) * 4;                    // + off_t[t]*4: may be negative when neg_block
     const int adv_h = BK / g.OW, adv_w = BK - adv_h * g.OW;
     const int a_wrap = (g.Cout - 1) * HW * 4, b_wrap = (g.Cin - 1) * HW * 4;
-    auto load_tiles = [&](int pt) {
-        const bool ok = cp < p_end;
-        const int a_off = ok ? a_cur : kOutOfRange;
-#pragma unroll
-        for (int i = 0; i < A_LOADS; ++i)
-            a_reg[i] = __builtin_amdgcn_raw_buffer_load_b128(dy_rsrc, a_off + (ok ? a_row4[i] : 0), 0, 0);
-        // halo mask of the 4 pixels (they may continue on the next row)
+    auto halo_mask = [&](int dr, int ds, bool ok) -> unsigned {
         unsigned mk = 0;
         if (k1x1) {
             mk = ok ? 0xFu : 0u;
@@ -749,7 +759,17 @@ __global__ __launch_bounds__(kThreads, 4) void conv_wgrad_vec_kernel(const float
                 mk |= v ? (1u << e) : 0u;
             }
         }
-        b_mask = mk;
+        return mk;
+    };
+    auto load_tiles = [&](int pt) {
+        const bool ok = cp < p_end;
+        const int a_off = ok ? a_cur : kOutOfRange;
+#pragma unroll
+        for (int i = 0; i < A_LOADS; ++i)
+            a_reg[i] = __builtin_amdgcn_raw_buffer_load_b128(dy_rsrc, a_off + (ok ? a_row4[i] : 0), 0, 0);
+        // halo masks of the 4 pixels (they may continue on the next row), one per tap of this tile
+#pragma unroll
+        for (int t = 0; t < NTAP; ++t) b_mask[t] = halo_mask(dr_t[t], ds_t[t], ok && tap_ok[t]);
         const int b_base = b_cur;
         // advance to the next K-step
         cp += BK;
@@ -768,12 +788,14 @@ __global__ __launch_bounds__(kThreads, 4) void conv_wgrad_vec_kernel(const float
             a_cur += a_wrap;
             b_cur += b_wrap;
         }
-        if (neg_block && pt + off_tap < 0 && pt < HW) {             // workgroup-uniform, a handful of K-steps
+        if (neg_block && pt + off_min < 0 && pt < HW) {             // workgroup-uniform, a handful of K-steps
 #pragma unroll
             for (int i = 0; i < B_LOADS; ++i) {
                 // per-element offsets: an element before the tensor start is always a halo element, and
                 // giving it an out-of-range offset also keeps the compiler from re-merging the four loads
-                const int o = b_base + b_row4[i];
+                const int t = HALF ? i : 0;
+                const unsigned mk = b_mask[t];
+                const int o = b_base + off_t[t] * 4 + b_row4[i];
                 b_reg[i].x = __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, (mk & 1u) ? o : kOutOfRange, 0, 0);
                 b_reg[i].y = __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, (mk & 2u) ? o + 4 : kOutOfRange, 0, 0);
                 b_reg[i].z = __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, (mk & 4u) ? o + 8 : kOutOfRange, 0, 0);
@@ -781,10 +803,13 @@ __global__ __launch_bounds__(kThreads, 4) void conv_wgrad_vec_kernel(const float
             }
             return;
         }
-        const int b_off = mk ? b_base : kOutOfRange;
 #pragma unroll
-        for (int i = 0; i < B_LOADS; ++i)
-            b_reg[i] = __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, b_off + (mk ? b_row4[i] : 0), 0, 0);
+        for (int i = 0; i < B_LOADS; ++i) {
+            const int t = HALF ? i : 0;
+            const unsigned mk = b_mask[t];
+            b_reg[i] = __builtin_amdgcn_raw_buffer_load_b128(
+                x_rsrc, mk ? (b_base + off_t[t] * 4 + b_row4[i]) : kOutOfRange, 0, 0);
+        }
     };
     const bool do_bias = dbias != nullptr && bx == 0;      // see conv_wgrad_kernel
     float bsum[A_LOADS];
@@ -802,10 +827,11 @@ __global__ __launch_bounds__(kThreads, 4) void conv_wgrad_vec_kernel(const float
         for (int i = 0; i < B_LOADS; ++i) {
             u32x4 v = b_reg[i];
             if (!k1x1) {               // a 1x1 tile has no halo: an invalid group was loaded as zeros
-                v.x = (b_mask & 1u) ? v.x : 0u;
-                v.y = (b_mask & 2u) ? v.y : 0u;
-                v.z = (b_mask & 4u) ? v.z : 0u;
-                v.w = (b_mask & 8u) ? v.w : 0u;
+                const unsigned mk = b_mask[HALF ? i : 0];
+                v.x = (mk & 1u) ? v.x : 0u;
+                v.y = (mk & 2u) ? v.y : 0u;
+                v.z = (mk & 4u) ? v.z : 0u;
+                v.w = (mk & 8u) ? v.w : 0u;
             }
             *reinterpret_cast<u32x4 *>(&Bs[buf][lr + 64 * i][4 * lj]) = v;
         }
@@ -1015,16 +1041,30 @@ void launch_fwd(const ConvGeom &g_in, const float *x, const float *w, const Epil
         hipLaunchKernelGGL((conv_fwd_kernel<BM, 0, 0, false>), grid, dim3(kThreads), 0, st, x, w, ep, y, g);
 }
 
+// same-size stride-1 layers (every 3x3/pad-1 and 1x1 layer of the model) can use the row-major kernel
+bool wgrad_same_size(const ConvGeom &g, const float *x, const float *dy)
+{
+    return g.sh == 1 && g.sw == 1 && g.OH == g.H && g.OW == g.W && (g.H * g.W) % 4 == 0 && g.W >= 4 &&
+           (size_t)g.N * g.Cin * g.H * g.W * 4 < 0x7fffff00ULL &&
+           (size_t)g.N * g.Cout * g.H * g.W * 4 < 0x7fffff00ULL && ((uintptr_t)x % 16 == 0) &&
+           ((uintptr_t)dy % 16 == 0);
+}
+
 template <int BM>
 void launch_wgrad(const ConvGeom &g, const float *x, const float *dy, float *dw, int splits,
                   int p_per_split, bool hwc, float *dbias, hipStream_t st)
 {
     dim3 grid(fi::ceil_div(g.K, BN), fi::ceil_div(g.Cout, BM), splits);
-    // same-size stride-1 layers (every 3x3/pad-1 and 1x1 layer of the model): row-major tiles, 16-byte LDS traffic
-    const bool same = g.sh == 1 && g.sw == 1 && g.OH == g.H && g.OW == g.W && (g.H * g.W) % 4 == 0 && g.W >= 4 &&
-                      (size_t)g.N * g.Cin * g.H * g.W * 4 < 0x7fffff00ULL &&
-                      (size_t)g.N * g.Cout * g.H * g.W * 4 < 0x7fffff00ULL &&
-                      ((uintptr_t)x % 16 == 0) && ((uintptr_t)dy % 16 == 0);
+    const bool same = wgrad_same_size(g, x, dy);
+    if (hwc && same && g.Cin == 64) {            // two taps per 128-column tile
+        if (g.R == 3 && g.S == 3)
+            hipLaunchKernelGGL((conv_wgrad_vec_kernel<BM, 3, 3, true>), grid, dim3(kThreads), 0, st, x, dy, dw, g, p_per_split, dbias);
+        else if (g.R == 1 && g.S == 1)
+            hipLaunchKernelGGL((conv_wgrad_vec_kernel<BM, 1, 1, true>), grid, dim3(kThreads), 0, st, x, dy, dw, g, p_per_split, dbias);
+        else
+            hipLaunchKernelGGL((conv_wgrad_vec_kernel<BM, 0, 0, true>), grid, dim3(kThreads), 0, st, x, dy, dw, g, p_per_split, dbias);
+        return;
+    }
     if (hwc && same) {
         ConvGeom gs = g;
         dim3 vgrid = grid;
@@ -1299,8 +1339,12 @@ int fi_conv2d_weight_grad(const float *x, const float *dy, float *dweight, int N
     if (rc != FI_OK) return rc;
     FI_REQUIRE(x && dy && dweight, "null pointer");
     FI_REQUIRE(weight_layout == 0 || weight_layout == 1, "weight_layout: 0 = [Cout][Cin][R][S], 1 = [Cout][R][S][Cin]");
-    const bool hwc = (Cin % BN == 0) && (weight_layout == 1 || R * S == 1);
-    FI_REQUIRE(hwc || weight_layout == 0 , "weight_layout 1 needs Cin % 128 == 0");
+    // tap-major dW: 128 input channels of one tap per column tile, or (Cin == 64, row-major kernel only)
+    // the 64 channels of two taps
+    const bool half = (Cin == 64) && wgrad_same_size(g, x, dy);
+    const bool hwc = ((Cin % BN == 0) || half) && (weight_layout == 1 || R * S == 1);
+    FI_REQUIRE(hwc || weight_layout == 0,
+               "weight_layout 1 needs Cin % 128 == 0, or Cin == 64 on a same-size stride-1 layer");
     hipStream_t st = (hipStream_t)stream;
     FI_HIP_CHECK(hipMemsetAsync(dweight, 0, sizeof(float) * (size_t)Cout * g.K, st));
     if (dbias) FI_HIP_CHECK(hipMemsetAsync(dbias, 0, sizeof(float) * (size_t)Cout, st));

@@ -245,7 +245,8 @@ int fi_class_mean_backward(const float *grad_feat, const int32_t *gt,
  * transposed weight [Cin,Cout,R,S] and padding R-1-pad.
  * fi_conv2d_weight_grad: dweight [Cout,Cin,R,S] = sum over images and pixels of
  * dy (x) patches(x); zero-filled by the call, accumulated with fp32 atomics over a split
- * of the pixel range.  weight_layout 1 writes dweight as [Cout,R,S,Cin] (needs Cin % 128 == 0).
+ * of the pixel range.  weight_layout 1 writes dweight as [Cout,R,S,Cin] (needs Cin % 128 == 0, or
+ * Cin == 64 on a same-size stride-1 layer with H*W % 4 == 0 and 16-byte aligned x, dy).
  * dbias (optional, [Cout]) receives the bias gradient sum(dy) from the same pass over dy.
  * ---------------------------------------------------------------------- */
 int fi_conv2d_forward(const float *x, const float *weight, const float *bias,

@@ -58,7 +58,8 @@ def main():
         t_f = timeit(lambda: _conv_fwd(x, w, b, (st, st), (pd, pd)))
         dw = torch.empty_like(w)
         dy = torch.randn_like(y)
-        hwc = 1 if Cin % 128 == 0 else 0
+        same = st == 1 and OH == H and OW == W and (H * W) % 4 == 0 and W >= 4
+        hwc = 1 if (Cin % 128 == 0 or (Cin == 64 and same)) else 0
 
         def wg():
             _lib.check(L.fi_conv2d_weight_grad(_lib.ptr(x), _lib.ptr(dy), _lib.ptr(dw), N, Cin, H, W, Cout, R, R,

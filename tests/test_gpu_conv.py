@@ -32,6 +32,9 @@ CASES = [
     (5, 128, 10, 10, 128, 1, 1, 1, 0),     # pixel count not a multiple of the K-step
     (2, 128, 9, 8, 128, 5, 5, 1, 2),       # generic window
     (33, 16, 64, 64, 128, 3, 3, 1, 1),     # 1056 tiles on 1024 slots: main launch + 64x64-tile tail launch
+    (2, 64, 14, 14, 64, 3, 3, 1, 1),       # Cin = 64: two taps per weight-gradient column tile (9 taps: last tile half empty)
+    (3, 64, 12, 20, 256, 1, 1, 1, 0),      # Cin = 64, 1x1: second half of the tile is past K
+    (2, 64, 16, 16, 96, 5, 5, 1, 2),       # Cin = 64, generic window (25 taps)
 ]
 
 
