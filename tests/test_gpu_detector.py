@@ -298,3 +298,45 @@ def test_baseline_configs_run(name, kw, size, bs):
     assert last < first, (name, first, last)
     del model, opt
     torch.cuda.empty_cache()
+
+
+def test_dev_stage_roi_pool_method_matches_oracle(oracle):
+    """ROIS.METHOD = 'roi_pool' (lib/sub_module.py:515-577 with RoIPoolFunction instead of
+    crop_and_resize): Dev's pooled 7x7 / 14x14 outputs vs the oracle's RoIPool per level, and one
+    train step with that method."""
+    from feature_intertwiner_amd.conv import conv_bn_act
+    from feature_intertwiner_amd.sub_module import Dev
+    cfg = _cfg(backbone="resnet50", image_size=256, batch_size=2, train_rois_per_image=48, dev_switch=True,
+               roi_method="roi_pool")
+    torch.manual_seed(0)
+    dev = Dev(cfg, 256).to(DEV).eval()
+    maps = [torch.randn(2, 256, s, s, device=DEV) for s in (64, 32, 16, 8)]
+    rs = np.random.RandomState(3)
+    rois_np = training_rois(rs, 2, 48)
+    rois = torch.from_numpy(rois_np).to(DEV)
+    cls = torch.randint(0, 81, (2, 48), device=DEV, dtype=torch.int32)
+    with torch.no_grad():
+        pooled, mask, _ = dev(maps, rois, cls)
+        up = [conv_bn_act(m, dev.upsample[0][0], dev.upsample[0][1], relu=True).cpu().numpy() for m in maps]
+    flat = rois_np.reshape(-1, 4)
+    level = oracle.roi_level(flat, 256 * 256)
+    ind = np.repeat(np.arange(2, dtype=np.float32), 48)
+    pix = np.stack([ind, flat[:, 1] * 256, flat[:, 0] * 256, flat[:, 3] * 256, flat[:, 2] * 256], 1).astype(np.float32)
+    for size, got in ((7, pooled), (14, mask)):
+        exp = np.zeros((96, 256, size, size), np.float32)
+        for l in range(2, 6):
+            sel = np.nonzero(level == l)[0]
+            if len(sel):
+                exp[sel] = oracle.roi_pool_forward(up[l - 2], pix[sel], size, size, 1.0 / (4 << (l - 2)))[0]
+        assert np.array_equal(got.cpu().numpy(), exp)
+
+    from feature_intertwiner_amd.model import MaskRCNN
+    from feature_intertwiner_amd.synthetic import SyntheticProposals, synthetic_batch
+    from feature_intertwiner_amd.workflow import set_optimizer, train_step
+    torch.manual_seed(4)
+    model = MaskRCNN(cfg).to(DEV)
+    opt = set_optimizer(model, cfg.TRAIN)
+    batch = synthetic_batch(2, 256, device=DEV)
+    model.proposal_hook = SyntheticProposals(batch[2], 256)
+    t = train_step(model, opt, list(batch))
+    assert all(torch.isfinite(v) for v in t.values()), t
