@@ -205,7 +205,12 @@ class MaskRCNN(nn.Module):
         elif choice == 'l1':
             per_cls = (SMALL - BIG).abs().mean(1)
         elif choice == 'kl':
-            per_cls = (BIG * (torch.log(BIG.clamp_min(1e-38)) - torch.log(SMALL))).mean(1)
+            # classes outside the selection have all-zero statistics: keep them out of the logarithms
+            # (the reference indexes the selected classes first, lib/model.py:187-201)
+            on = sel.view(-1, 1) > 0
+            sm = torch.where(on, SMALL, torch.ones_like(SMALL)).clamp_min(1e-38)
+            bg = torch.where(on, BIG, torch.zeros_like(BIG))
+            per_cls = (bg * (torch.log(bg.clamp_min(1e-38)) - torch.log(sm))).mean(1)
         else:
             raise ValueError(choice)
         return (per_cls * sel).sum() / sel.sum().clamp(min=1)

@@ -340,3 +340,24 @@ def test_dev_stage_roi_pool_method_matches_oracle(oracle):
     model.proposal_hook = SyntheticProposals(batch[2], 256)
     t = train_step(model, opt, list(batch))
     assert all(torch.isfinite(v) for v in t.values()), t
+
+
+@pytest.mark.parametrize("choice", ["l2", "l1", "kl"])
+def test_meta_loss_choices_run(choice):
+    """DEV.LOSS_CHOICE other than 'ot' (lib/model.py:197-204: mse / l1 / kl on sigmoid- resp.
+    softmax-activated class features): a train step runs, the meta term is finite and non-negative."""
+    from feature_intertwiner_amd.model import MaskRCNN
+    from feature_intertwiner_amd.synthetic import SyntheticProposals, synthetic_batch
+    from feature_intertwiner_amd.workflow import set_optimizer, train_step
+    torch.manual_seed(5)
+    cfg = _cfg(backbone="resnet50", image_size=256, batch_size=2, train_rois_per_image=64, loss_choice=choice)
+    model = MaskRCNN(cfg).to(DEV)
+    assert not hasattr(model, "ot_loss")
+    opt = set_optimizer(model, cfg.TRAIN)
+    batch = synthetic_batch(2, 256, device=DEV)
+    model.proposal_hook = SyntheticProposals(batch[2], 256)
+    model.generator = torch.Generator(device=DEV).manual_seed(3)
+    for _ in range(2):
+        t = train_step(model, opt, list(batch))
+        assert all(torch.isfinite(v) for v in t.values()), (choice, t)
+        assert float(t["meta"]) >= 0.0
