@@ -361,3 +361,28 @@ def test_meta_loss_choices_run(choice):
         t = train_step(model, opt, list(batch))
         assert all(torch.isfinite(v) for v in t.values()), (choice, t)
         assert float(t["meta"]) >= 0.0
+
+
+@pytest.mark.parametrize("tweak", ["BASELINE", "MULTI_UPSAMPLER", "UPSAMPLE_FAC2"])
+def test_dev_config_branches_run(tweak):
+    """Dev-stage switches of lib/config.py that change the graph: DEV.BASELINE (no intertwiner
+    statistics), DEV.MULTI_UPSAMPLER (one make-up layer per level), DEV.UPSAMPLE_FAC = 2 (transposed
+    3x3 conv as make-up layer, lib/sub_module.py:312-314)."""
+    from feature_intertwiner_amd.model import MaskRCNN
+    from feature_intertwiner_amd.synthetic import SyntheticProposals, synthetic_batch
+    from feature_intertwiner_amd.workflow import set_optimizer, train_step
+    torch.manual_seed(6)
+    cfg = _cfg(backbone="resnet50", image_size=256, batch_size=2, train_rois_per_image=48, ot_L=5)
+    if tweak == "BASELINE":
+        cfg.DEV.BASELINE = True
+    elif tweak == "MULTI_UPSAMPLER":
+        cfg.DEV.MULTI_UPSAMPLER = True
+    else:
+        cfg.DEV.UPSAMPLE_FAC = 2.0
+    model = MaskRCNN(cfg).to(DEV)
+    opt = set_optimizer(model, cfg.TRAIN)
+    batch = synthetic_batch(2, 256, device=DEV)
+    model.proposal_hook = SyntheticProposals(batch[2], 256)
+    model.generator = torch.Generator(device=DEV).manual_seed(3)
+    t = train_step(model, opt, list(batch), do_meta=not cfg.DEV.BASELINE)
+    assert all(torch.isfinite(v) for v in t.values()), (tweak, t)
