@@ -386,3 +386,21 @@ def test_dev_config_branches_run(tweak):
     model.generator = torch.Generator(device=DEV).manual_seed(3)
     t = train_step(model, opt, list(batch), do_meta=not cfg.DEV.BASELINE)
     assert all(torch.isfinite(v) for v in t.values()), (tweak, t)
+
+
+def test_fpn_ot_loss_branch_runs():
+    """TRAIN.FPN_OT_LOSS (lib/sub_module.py:179-212: 2-D OptTrans between adjacent pyramid levels,
+    off by default): one train step with it enabled."""
+    from feature_intertwiner_amd.model import MaskRCNN
+    from feature_intertwiner_amd.synthetic import SyntheticProposals, synthetic_batch
+    from feature_intertwiner_amd.workflow import set_optimizer, train_step
+    torch.manual_seed(7)
+    cfg = _cfg(backbone="resnet50", image_size=128, batch_size=2, train_rois_per_image=32, ot_L=5)
+    cfg.TRAIN.FPN_OT_LOSS = True
+    model = MaskRCNN(cfg).to(DEV)
+    opt = set_optimizer(model, cfg.TRAIN)
+    batch = synthetic_batch(2, 128, device=DEV)
+    model.proposal_hook = SyntheticProposals(batch[2], 128)
+    model.generator = torch.Generator(device=DEV).manual_seed(3)
+    t = train_step(model, opt, list(batch))
+    assert all(torch.isfinite(v) for v in t.values()), t
