@@ -404,3 +404,26 @@ def test_fpn_ot_loss_branch_runs():
     model.generator = torch.Generator(device=DEV).manual_seed(3)
     t = train_step(model, opt, list(batch))
     assert all(torch.isfinite(v) for v in t.values()), t
+
+
+def test_train_step_edge_batches():
+    """An image without any ground-truth object (all rows zero padding) and a history buffer longer
+    than one step (DEV.BUFFER_SIZE > 1, lib/model.py:159-166): losses stay finite."""
+    from feature_intertwiner_amd.model import MaskRCNN
+    from feature_intertwiner_amd.synthetic import SyntheticProposals, synthetic_batch
+    from feature_intertwiner_amd.workflow import set_optimizer, train_step
+    torch.manual_seed(8)
+    cfg = _cfg(backbone="resnet50", image_size=256, batch_size=2, train_rois_per_image=48, ot_L=5, buffer_size=3)
+    model = MaskRCNN(cfg).to(DEV)
+    opt = set_optimizer(model, cfg.TRAIN)
+    images, gt_cls, gt_boxes, gt_masks = synthetic_batch(2, 256, device=DEV)
+    hook = SyntheticProposals(gt_boxes.clone(), 256)
+    gt_cls[1] = 0
+    gt_boxes[1] = 0
+    gt_masks[1] = 0
+    model.proposal_hook = hook
+    model.generator = torch.Generator(device=DEV).manual_seed(3)
+    for _ in range(4):
+        t = train_step(model, opt, [images, gt_cls, gt_boxes, gt_masks])
+        assert all(torch.isfinite(v) for v in t.values()), t
+    assert model.feature_buffer.buffer.shape[0] == 3
