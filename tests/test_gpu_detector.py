@@ -427,3 +427,21 @@ def test_train_step_edge_batches():
         t = train_step(model, opt, [images, gt_cls, gt_boxes, gt_masks])
         assert all(torch.isfinite(v) for v in t.values()), t
     assert model.feature_buffer.buffer.shape[0] == 3
+
+
+def test_detection_layer_without_foreground():
+    """Every RoI classified as background (or below DET_MIN_CONFIDENCE): all-zero detections, as the
+    reference's early return (lib/layers.py:771-773)."""
+    from feature_intertwiner_amd import layers as L
+    cfg = _cfg(backbone="resnet50", image_size=256)
+    rois = torch.rand(2, 50, 4, device=DEV).sort(2)[0][:, :, [0, 1, 2, 3]]
+    probs = torch.zeros(100, 81, device=DEV)
+    probs[:, 0] = 1.0
+    deltas = torch.zeros(100, 81, 4, device=DEV)
+    win = torch.tensor([[0, 0, 256, 256]] * 2, device=DEV, dtype=torch.float32)
+    det = L.detection_layer(rois, probs, deltas, win, cfg)
+    assert det.shape == (2, 100, 6) and torch.all(det == 0)
+    cfg.TEST.DET_MIN_CONFIDENCE = 0.9
+    probs = torch.full((100, 81), 0.5 / 80, device=DEV)
+    probs[:, 3] = 0.5
+    assert torch.all(L.detection_layer(rois, probs, deltas, win, cfg) == 0)
