@@ -27,20 +27,45 @@ def save_model(model, path, epoch, iter, loss_data=None):
                 'loss_data': [] if loss_data is None else loss_data}, path)
 
 
-def load_model(model, path, map_location=None):
+def _read(path, map_location, trusted):
+    """The file holds tensors, python scalars/lists and two numpy arrays.  It is read with the
+    restricted unpickler (weights_only=True, numpy's array reconstruction allow-listed); a
+    third-party .pth that needs arbitrary pickles loads only with trusted=True."""
+    if trusted:
+        return torch.load(path, map_location=map_location, weights_only=False)
+    import numpy.core.multiarray as _ma        # numpy < 2 path of the same objects
+    safe = [np.ndarray, np.dtype, _ma._reconstruct]
+    try:
+        safe += [type(np.dtype(np.float32)), type(np.dtype(np.float64)), type(np.dtype(np.int64))]
+        import numpy._core.multiarray as _ma2
+        safe.append(_ma2._reconstruct)
+    except Exception:
+        pass
+    with torch.serialization.safe_globals(safe):
+        return torch.load(path, map_location=map_location, weights_only=True)
+
+
+def load_model(model, path, map_location=None, trusted=False):
     """Returns (start_epoch, start_iter, loss_data, missing_keys, unexpected_keys).  A resumed
     model continues at iter+1 (epoch roll-over needs the dataset size and is left to the caller,
-    tools/utils.py:333-339); a bare state dict is a pretrain model and starts at (1, 1)."""
-    ckpt = torch.load(path, map_location=map_location, weights_only=False)
+    tools/utils.py:333-339); a bare state dict is a pretrain model and starts at (1, 1).  The
+    history buffer is adopted only if its length equals cfg.DEV.BUFFER_SIZE; otherwise it is
+    re-initialised, as tools/utils.py:379-384 does."""
+    from .data_parallel import invalidate_derived_state
+    ckpt = _read(path, map_location, trusted)
     state = ckpt['state_dict'] if isinstance(ckpt, dict) and 'state_dict' in ckpt else ckpt
     result = model.load_state_dict(state, strict=False)
+    invalidate_derived_state(model)
     if not (isinstance(ckpt, dict) and 'epoch' in ckpt and 'iter' in ckpt):
         return 1, 1, [], result.missing_keys, result.unexpected_keys
     buf = ckpt.get('buffer', [])
     if isinstance(buf, np.ndarray) and buf.size:
         dev = next(model.parameters()).device
-        fb = FeatureBuffer(buf.shape[0], buf.shape[1], buf.shape[2], dev)
-        fb.buffer = torch.from_numpy(buf).to(dev)
-        fb.buffer_cnt = torch.from_numpy(np.asarray(ckpt['buffer_cnt'])).to(dev)
-        model.feature_buffer = fb
+        if buf.shape[0] == int(model.config.DEV.BUFFER_SIZE):
+            fb = FeatureBuffer(buf.shape[0], buf.shape[1], buf.shape[2], dev)
+            fb.buffer = torch.from_numpy(buf).to(dev)
+            fb.buffer_cnt = torch.from_numpy(np.asarray(ckpt['buffer_cnt'])).to(dev)
+            model.feature_buffer = fb
+        else:
+            model.initialize_buffer(dev)
     return int(ckpt['epoch']), int(ckpt['iter']) + 1, ckpt.get('loss_data', []), result.missing_keys, result.unexpected_keys

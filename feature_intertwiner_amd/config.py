@@ -39,7 +39,8 @@ def make_config(backbone="resnet101", image_size=1024, batch_size=4, train_rois_
                OT_ONE_DIM_FORM="conv", OT_L=ot_L, OT_EPSILON=1.0, LOSS_FAC=loss_fac, INST_LOSS=False,
                FEAT_BRANCH_POOL_SIZE=14, DIS_REG_LOSS=False, ASSIGN_BOX_ON_ALL_SCALE=False,
                BASELINE=False, BIG_SUPERVISE=False, STRUCTURE="beta", DIS_UPSAMPLER=False,
-               BIG_FEAT_DETACH=True, CLS_MERGE_FEAT=False)
+               BIG_FEAT_DETACH=True, CLS_MERGE_FEAT=False, CLS_MERGE_MANNER='simple_add', CLS_MERGE_FAC=0.5,
+               BIG_LOSS_FAC=1.0)
     c.MISC = NS(SEED=2000, GPU_COUNT=gpu_count)
     c.TEST = NS(DET_MAX_INSTANCES=100, DET_MIN_CONFIDENCE=0, DET_NMS_THRESHOLD=0.3)      # lib/config.py:150-157
     c.CTRL = NS(PHASE='train')

@@ -320,6 +320,17 @@ def refresh_bn_folds():
         b._fi_fold = (sc, sh, _fold_key(c, b))
 
 
+def invalidate_bn_folds(module=None):
+    """Forget cached (scale, shift) folds -- of `module`'s BatchNorms, or of every BatchNorm seen
+    so far.  Needed after writes that bypass the tensor version counters the cache is keyed on
+    (`.data.copy_`, dist.broadcast(t.data), load_state_dict under torch.no_grad is counted, but
+    `.data` surgery is not)."""
+    mods = module.modules() if module is not None else list(_FOLD_PAIRS.keys())
+    for m in mods:
+        if getattr(m, "_fi_fold", None) is not None:
+            m._fi_fold = None
+
+
 def conv_bn_act(x, conv, bn, relu=True, residual=None, channels_last_out=False):
     """act(bn(conv(x)) [+ residual]) for an eval-mode BatchNorm2d (the reference always evaluates
     BN with running statistics, lib/model.py:265-267).  Falls back to separate ops for a BN in

@@ -19,19 +19,26 @@ import torch.distributed as dist
 
 
 class _AllReduceSumIdentityGrad(torch.autograd.Function):
-    """y = sum over ranks of x.  Backward is the identity: every rank evaluates the same
-    function of the reduced statistics and back-propagates only through its own
-    contribution (the caller scales that loss term by world_size, workflow.compute_loss)."""
+    """y = sum over ranks of x; backward returns world_size * g.
+
+    Every rank evaluates the same function M of the reduced statistics and back-propagates
+    only through its own contribution s_g.  Gradients are AVERAGED over ranks afterwards, so
+    the path back into the local statistics carries the factor world_size:
+        (1/W) sum_g W * dM/ds * ds_g/dtheta = dM/dtheta   (the reference's single meta loss,
+    lib/workflow.py:180, 221), while parameters M owns itself (ot_loss.G_net / critic) receive
+    the same gradient on every rank and average to 1x.  (Scaling the loss term by W instead
+    would multiply the gradient of those parameters by W.)"""
 
     @staticmethod
     def forward(ctx, x, group):
+        ctx.world = dist.get_world_size(group)
         y = x.detach().clone()
         dist.all_reduce(y, op=dist.ReduceOp.SUM, group=group)
         return y
 
     @staticmethod
     def backward(ctx, g):
-        return g, None
+        return g * float(ctx.world), None
 
 
 def all_reduce_statistics(feat_sum, cnt_sum, group=None):
@@ -75,6 +82,7 @@ class GradientBuckets(object):
         self.device = params[0].device if params else torch.device("cpu")
         self.use_stream = self.device.type == "cuda"
         self.comm_stream = torch.cuda.Stream(device=self.device) if self.use_stream else None
+        self._verified_pattern = None
         self._reset()
         if self.world > 1:
             for p in params:
@@ -83,7 +91,7 @@ class GradientBuckets(object):
     def _reset(self):
         self.pending = [len(b) for b in self.buckets]
         self.next_to_launch = 0
-        self.inflight = []        # (bucket index, flat buffer, work handle)
+        self.inflight = []        # (bucket index, flat buffer, work handle, which params had a gradient)
 
     def _on_grad(self, p):
         bi = self.bucket_of[p]
@@ -95,7 +103,10 @@ class GradientBuckets(object):
         while self.next_to_launch < len(self.buckets) and (force or self.pending[self.next_to_launch] <= 0):
             bi = self.next_to_launch
             self.next_to_launch += 1
-            grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in self.buckets[bi]]
+            # a parameter without a gradient contributes zeros (the bucket layout is fixed) but is
+            # remembered: it must come out of the step with .grad still None (see __call__)
+            had = [p.grad is not None for p in self.buckets[bi]]
+            grads = [p.grad if h else torch.zeros_like(p) for p, h in zip(self.buckets[bi], had)]
             if self.use_stream:
                 self.comm_stream.wait_stream(torch.cuda.current_stream(self.device))
                 with torch.cuda.stream(self.comm_stream):
@@ -106,14 +117,37 @@ class GradientBuckets(object):
             else:
                 flat = torch._utils._flatten_dense_tensors(grads)
                 work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-            self.inflight.append((bi, flat, work))
+            self.inflight.append((bi, flat, work, had))
+
+    def _union_of_grad_patterns(self, local):
+        """Which parameters received a gradient on ANY rank.  The autograd graph has static shapes
+        and the same structure on every rank, so the local pattern normally IS the union; it is
+        verified with one tiny host-side collective whenever the local pattern changes (first step,
+        do_meta switching on, ...), never in steady state."""
+        if self._verified_pattern is not None and self._verified_pattern[0] == local:
+            return self._verified_pattern[1]
+        flags = torch.tensor([1.0 if h else 0.0 for h in local], dtype=torch.float32)
+        if self.device.type == "cuda" and dist.get_backend(self.group) == "nccl":
+            flags = flags.to(self.device)
+        dist.all_reduce(flags, op=dist.ReduceOp.MAX, group=self.group)
+        union = tuple(bool(v) for v in flags.cpu().tolist())
+        # cache only if every rank saw the same pattern (then it stays valid while local is unchanged)
+        same = torch.tensor([1.0 if union == local else 0.0])
+        if self.device.type == "cuda" and dist.get_backend(self.group) == "nccl":
+            same = same.to(self.device)
+        dist.all_reduce(same, op=dist.ReduceOp.MIN, group=self.group)
+        self._verified_pattern = (local, union) if float(same.item()) == 1.0 else None
+        return union
 
     def __call__(self):
         if self.world == 1:
             return
         self._launch_ready(force=True)        # parameters that got no gradient this step
         inv = 1.0 / float(self.world)
-        for bi, flat, work in self.inflight:
+        local = tuple(h for _, _, _, had in self.inflight for h in had)
+        union = self._union_of_grad_patterns(local)
+        k = 0
+        for bi, flat, work, had in self.inflight:
             work.wait()
             if self.use_stream:
                 cur = torch.cuda.current_stream(self.device)
@@ -121,12 +155,22 @@ class GradientBuckets(object):
                 flat.record_stream(cur)
             flat.mul_(inv)
             outs = torch._utils._unflatten_dense_tensors(flat, [p for p in self.buckets[bi]])
-            for p, g in zip(self.buckets[bi], outs):
-                if p.grad is None:
-                    p.grad = g.clone()
-                else:
+            for p, g, h in zip(self.buckets[bi], outs, had):
+                if h:
                     p.grad.copy_(g)
+                elif union[k]:
+                    p.grad = g.clone()        # some other rank had a gradient for it
+                # else: no rank produced a gradient -> .grad stays None, exactly as on one GPU
+                # (SGD then applies neither weight decay nor momentum to it)
+                k += 1
         self._reset()
+
+
+def invalidate_derived_state(module):
+    """Writes through `.data` (broadcast, checkpoint load, weight surgery) do not bump tensor
+    version counters; drop everything cached from parameter values (eval-BN folds, conv.py)."""
+    from .conv import invalidate_bn_folds
+    invalidate_bn_folds(module)
 
 
 def broadcast_parameters(module, src=0, group=None):
@@ -136,3 +180,4 @@ def broadcast_parameters(module, src=0, group=None):
         return
     for t in list(module.parameters()) + list(module.buffers()):
         dist.broadcast(t.data, src=src, group=group)
+    invalidate_derived_state(module)

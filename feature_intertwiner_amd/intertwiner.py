@@ -86,16 +86,108 @@ class FeatureBuffer(object):
         self.buffer_cnt = torch.zeros(buffer_size, 1, num_classes, device=device)
 
     @torch.no_grad()
-    def update(self, big_feat, big_cnt):
+    def update(self, big_feat, big_cnt, active=None):
         """big_feat [F, K], big_cnt [1, K] (already merged).  Returns the class features the
-        meta loss compares against, [F, K]."""
+        meta loss compares against, [F, K].  `active` (0-dim bool tensor, optional): when False
+        the buffer is left untouched -- the reference calls meta_loss, and with it this update,
+        only on steps that have small-object statistics (lib/workflow.py:190-194); a device-side
+        select keeps the step free of host synchronisation."""
         if self.buffer.size(0) == 1:
             feat_sum = self.buffer * self.buffer_cnt + big_feat.unsqueeze(0) * big_cnt.unsqueeze(0)
-            self.buffer_cnt += big_cnt.unsqueeze(0)
-            self.buffer = feat_sum / (self.buffer_cnt + EPS)
+            new_cnt = self.buffer_cnt + big_cnt.unsqueeze(0)
+            new_buf = feat_sum / (new_cnt + EPS)
+        else:
+            new_buf = torch.roll(self.buffer, -1, 0)
+            new_cnt = torch.roll(self.buffer_cnt, -1, 0)
+            new_buf[-1] = big_feat
+            new_cnt[-1] = big_cnt
+        if active is not None:
+            new_buf = torch.where(active, new_buf, self.buffer)
+            new_cnt = torch.where(active, new_cnt, self.buffer_cnt)
+        self.buffer, self.buffer_cnt = new_buf, new_cnt
+        if self.buffer.size(0) == 1:
             return self.buffer[0]
-        self.buffer = torch.roll(self.buffer, -1, 0)
-        self.buffer_cnt = torch.roll(self.buffer_cnt, -1, 0)
-        self.buffer[-1] = big_feat
-        self.buffer_cnt[-1] = big_cnt
         return (self.buffer * self.buffer_cnt).sum(0) / (self.buffer_cnt.sum(0) + EPS)
+
+
+def _masked_mean(per_row, weight):
+    return (per_row * weight).sum() / weight.sum().clamp(min=1)
+
+
+def _pair_loss(choice, SMALL, BIG, on, ot_module):
+    """Per-row loss between SMALL [n, F] (carries the gradient) and BIG [n, F] (constant) for the
+    rows with on[n] > 0 (lib/model.py:197-207).  l2 / l1 / kl are means over the features, so the
+    mean over the selected rows equals F.mse_loss / F.l1_loss / F.kl_div over the selected block."""
+    if choice == 'ot':
+        return ot_module(SMALL.unsqueeze(-1), BIG.unsqueeze(-1).contiguous())
+    if choice == 'l2':
+        return ((SMALL - BIG) ** 2).mean(1)
+    if choice == 'l1':
+        return (SMALL - BIG).abs().mean(1)
+    if choice == 'kl':
+        # rows outside the selection have all-zero statistics: keep them out of the logarithms (the
+        # reference indexes the selected rows first, lib/model.py:187-201).  F.kl_div(log q, p) is
+        # p * (log p - log q) with 0 where p == 0.
+        m = on.view(-1, 1) > 0
+        sm = torch.where(m, SMALL, torch.ones_like(SMALL)).clamp_min(1e-38)
+        bg = torch.where(m, BIG, torch.zeros_like(BIG))
+        return (bg * (torch.log(bg.clamp_min(1e-38)) - torch.log(sm))).mean(1)
+    raise ValueError(choice)
+
+
+def meta_loss(cfg, feature_buffer, ot_module, feat_input, reduce_fn=None):
+    """MaskRCNN.meta_loss (lib/model.py:143-210) on static shapes, with no host synchronisation.
+
+    feat_input = [big_feat, big_cnt, small_feat, small_cnt, small_output_all, small_gt_all];
+    big_*/small_* are [G, S, F, K] / [G, S, 1, K] stacks over (gpu, scale) as Dev.forward returns
+    them.  `reduce_fn(sum_feat, sum_cnt)` -- the data-parallel path -- all-reduces count-weighted
+    sums across ranks: algebraically the reference's gather-to-GPU-0 + _merge_feat_vec (:217-224).
+
+    * The history buffer is updated only when the step has small-object statistics, as the
+      reference guards the whole call with `small_feat.sum() != 0` (lib/workflow.py:190-194);
+      otherwise the loss is 0 and the buffer is untouched.
+    * Class selection (:176-181): foreground classes with a small count > 0 AND a buffer count > 0.
+      With BUFFER_SIZE > 1 the reference's `buffer_cnt.squeeze()` is [BUFFER_SIZE, K] and its
+      selection line does not execute (2-D nonzero); the count summed over the history is used.
+    * 'ot' returns one value per selected class in the reference (:207), which loss.backward()
+      cannot reduce (quirk Q10): the mean over the selected classes is taken, as l1/l2/kl do.
+    * DEV.INST_LOSS (:168-174, 184-186): rows of small_output_all whose class is in the buffer are
+      compared with the buffer column of their class.
+    """
+    big_feat, big_cnt, small_feat, small_cnt = feat_input[:4]
+
+    def merged(feat, cnt):
+        s = (feat * cnt).sum(0).sum(0)
+        c = cnt.sum(0).sum(0)
+        if reduce_fn is not None:
+            s, c = reduce_fn(s, c)
+        return s / (c + EPS), c, s
+
+    b_feat, b_cnt, _ = merged(big_feat.detach(), big_cnt.detach())
+    s_feat, s_cnt, s_sum = merged(small_feat, small_cnt.detach())
+    # lib/workflow.py:190: `small_feat.sum() != 0` (class means are >= 0 after ReLU / sigmoid /
+    # softmax, so the count-weighted sums vanish exactly when the means do)
+    active = s_sum.detach().sum() != 0
+    final_big = feature_buffer.update(b_feat, b_cnt, active)                  # [F, K]
+    buf_cnt = feature_buffer.buffer_cnt.sum(0)                                # [1, K]
+    choice = cfg.DEV.LOSS_CHOICE
+    if cfg.DEV.INST_LOSS:
+        rows, gt = feat_input[4], feat_input[5]
+        gt_l = gt.detach().long()
+        in_buf = (buf_cnt.view(-1) > 0)[gt_l]
+        on = ((gt_l != 0) & in_buf).float()
+        BIG = final_big.t()[gt_l].detach()                                    # [N, F]
+        per_row = _pair_loss(choice, rows, BIG, on, ot_module)
+        num, den = (per_row * on).sum(), on.sum()
+        if reduce_fn is not None:      # global mean over the instances of every rank
+            num, den = reduce_fn(num.view(1), den.view(1))
+            num, den = num.view(()), den.view(())
+        loss = num / den.clamp(min=1)
+    else:
+        s_cnt = s_cnt.clone()
+        s_cnt[0, 0] = 0                                                       # no background class
+        on = ((s_cnt > 0) & (buf_cnt > 0)).view(-1)[1:].float()               # foreground classes
+        SMALL = s_feat[:, 1:].t()                                             # [K-1, F]
+        BIG = final_big[:, 1:].t().detach()
+        loss = _masked_mean(_pair_loss(choice, SMALL, BIG, on, ot_module), on)
+    return torch.where(active, loss, torch.zeros_like(loss))

@@ -7,7 +7,7 @@ import torch
 import torch.nn as nn
 
 from .conv import refresh_bn_folds
-from .intertwiner import FeatureBuffer, merge_feat_vec
+from .intertwiner import FeatureBuffer, meta_loss
 from .layers import (compute_mrcnn_bbox_loss, compute_mrcnn_class_loss, compute_mrcnn_mask_loss_unshuffled,
                      compute_rpn_bbox_loss, compute_rpn_class_loss, detection_layer, generate_pyramid_priors,
                      prepare_det_target, prepare_rpn_target, proposal_layer)
@@ -166,51 +166,8 @@ class MaskRCNN(nn.Module):
 
     # ------------------------------------------------------------------ meta loss
     def meta_loss(self, feat_input, reduce_fn=None):
-        """lib/model.py:143-210 for DEV.INST_LOSS == False.
-
-        big_*/small_* are [G, S, ...] stacks over (gpu, scale).  `reduce_fn(sum_feat, sum_cnt)`
-        -- used by the data-parallel path -- all-reduces the count-weighted sums across ranks,
-        which is algebraically the reference's gather-to-GPU-0 + _merge_feat_vec.
-        Static shapes: the loss is evaluated for every foreground class and averaged over the
-        classes present in both the current small statistics and the buffer; the reference
-        selects those classes with nonzero() and leaves the OT loss as a per-class vector that
-        `loss.backward()` could not reduce -- mean is used here, as for
-        its l1/l2 choices."""
-        cfg = self.config
-        big_feat, big_cnt, small_feat, small_cnt = feat_input[:4]
+        """lib/model.py:143-210; see intertwiner.meta_loss for the static-shape formulation and the
+        quirks it mirrors or decides.  `reduce_fn` is the data-parallel statistics all-reduce."""
         if self.feature_buffer is None:
-            self.initialize_buffer(big_feat.device)
-
-        def merged(feat, cnt):
-            s = (feat * cnt).sum(0).sum(0)
-            c = cnt.sum(0).sum(0)
-            if reduce_fn is not None:
-                s, c = reduce_fn(s, c)
-            return s / (c + EPS), c
-
-        b_feat, b_cnt = merged(big_feat.detach(), big_cnt.detach())
-        final_big = self.feature_buffer.update(b_feat, b_cnt)                  # [1024, K]
-        s_feat, s_cnt = merged(small_feat, small_cnt.detach())
-        s_cnt = s_cnt.clone()
-        s_cnt[0, 0] = 0                                                       # no background class
-        buf_cnt = self.feature_buffer.buffer_cnt.sum(0)                       # [1, K]
-        sel = ((s_cnt > 0) & (buf_cnt > 0)).view(-1)[1:].float()              # foreground classes
-        SMALL = s_feat[:, 1:].t()                                             # [K-1, 1024]
-        BIG = final_big[:, 1:].t().detach()
-        choice = cfg.DEV.LOSS_CHOICE
-        if choice == 'ot':
-            per_cls = self.ot_loss(SMALL.unsqueeze(-1), BIG.unsqueeze(-1).contiguous())
-        elif choice == 'l2':
-            per_cls = ((SMALL - BIG) ** 2).mean(1)
-        elif choice == 'l1':
-            per_cls = (SMALL - BIG).abs().mean(1)
-        elif choice == 'kl':
-            # classes outside the selection have all-zero statistics: keep them out of the logarithms
-            # (the reference indexes the selected classes first, lib/model.py:187-201)
-            on = sel.view(-1, 1) > 0
-            sm = torch.where(on, SMALL, torch.ones_like(SMALL)).clamp_min(1e-38)
-            bg = torch.where(on, BIG, torch.zeros_like(BIG))
-            per_cls = (bg * (torch.log(bg.clamp_min(1e-38)) - torch.log(sm))).mean(1)
-        else:
-            raise ValueError(choice)
-        return (per_cls * sel).sum() / sel.sum().clamp(min=1)
+            self.initialize_buffer(feat_input[0].device)
+        return meta_loss(self.config, self.feature_buffer, getattr(self, "ot_loss", None), feat_input, reduce_fn)

@@ -248,6 +248,14 @@ class Dev(nn.Module):
                     self.last_op = nn.Sigmoid()
                 elif config.DEV.LOSS_CHOICE == 'kl':
                     self.last_op = nn.Softmax(dim=1)
+                if config.DEV.BIG_SUPERVISE:                 # lib/sub_module.py:352-353
+                    self.big_fc_layer = nn.Linear(1024, self.num_classs)
+            if config.DEV.DIS_UPSAMPLER:
+                raise NotImplementedError("DEV.DIS_UPSAMPLER=True builds no make-up layer, and the 'beta' forward "
+                                          "(lib/sub_module.py:550) then fails in the reference as well")
+            if config.DEV.ASSIGN_BOX_ON_ALL_SCALE:
+                raise NotImplementedError("DEV.ASSIGN_BOX_ON_ALL_SCALE (area-threshold level assignment, "
+                                          "lib/sub_module.py:441-454) is not built; every shipped config sets it False")
 
     def _feat_extract(self, v):
         fe = self.feat_extract
@@ -341,29 +349,42 @@ class Dev(nn.Module):
             big_lvl.append(torch.full_like(idx, lvl, dtype=torch.int32))
         big_idx = torch.cat(big_sel)
         big_level = torch.cat(big_lvl)
-        with torch.set_grad_enabled(not cfg.DEV.BIG_FEAT_DETACH):
+        big_loss = []
+        # the big branch needs a graph only when its class means are not detached or when it is
+        # supervised by its own classifier (:531-535: the CE loss reaches feat_extract either way)
+        with torch.set_grad_enabled(torch.is_grad_enabled() and
+                                    (not cfg.DEV.BIG_FEAT_DETACH or cfg.DEV.BIG_SUPERVISE)):
             if big_idx.numel():
                 big_pooled = self._crop(x, boxes[big_idx], box_ind[big_idx], big_level, self.feat_pool_size)
-                big_out = self._feat_extract(big_pooled)
-                if cfg.DEV.LOSS_CHOICE != 'ot':
-                    big_out = self.last_op(big_out)
+                big_raw = self._feat_extract(big_pooled)
+                big_out = self.last_op(big_raw) if cfg.DEV.LOSS_CHOICE != 'ot' else big_raw
                 big_out = big_out.view(big_idx.numel(), -1)
+                big_raw = big_raw.view(big_idx.numel(), -1)
             else:
-                big_out = small_output.new_zeros(0, small_output.size(1))
+                big_out = big_raw = small_output.new_zeros(0, small_output.size(1))
             big_gt = gt[big_idx]
+            if cfg.DEV.BIG_SUPERVISE:
+                ce = F.cross_entropy(self.big_fc_layer(big_raw), big_gt.long(), reduction='none') \
+                    if big_idx.numel() else big_raw.new_zeros(0)
             for i, lvl in enumerate((2, 3, 4)):
                 # a level without small boxes contributes no big statistics either (:456-467)
-                has_small = (level == lvl).any().to(big_gt.dtype)
-                g = torch.where(big_level == lvl, big_gt, torch.zeros_like(big_gt)) * has_small
+                has_small = (level == lvl).any()
+                at_lvl = big_level == lvl
+                g = torch.where(at_lvl, big_gt, torch.zeros_like(big_gt)) * has_small.to(big_gt.dtype)
                 f, c = class_mean(big_out, g, K)
                 big_feat.append(f)
                 big_cnt.append(c)
+                if cfg.DEV.BIG_SUPERVISE:       # mean CE over the level's big boxes (:531-535), 0 without any
+                    w = at_lvl.float() * has_small.float()
+                    big_loss.append(((ce * w).sum() / w.sum().clamp(min=1)).view(1))
+                else:
+                    big_loss.append(small_output.new_zeros(1))
         bf = torch.stack(big_feat).unsqueeze(0)
         if cfg.DEV.BIG_FEAT_DETACH:
             bf = bf.detach()
         feat_out = [bf, torch.stack(big_cnt).unsqueeze(0),
                     torch.stack(small_feat).unsqueeze(0), torch.stack(small_cnt).unsqueeze(0),
-                    small_output.new_zeros(1, 3, 1), small_output_all, small_gt_all]
+                    torch.stack(big_loss).unsqueeze(0), small_output_all, small_gt_all]
         return pooled, mask_and_feat, feat_out
 
 
@@ -385,6 +406,16 @@ class Classifier(nn.Module):
 
     def forward(self, x, small_feat_input=None, small_gt_index=None, mode='train'):
         x = conv_bn_act(x, self.conv1, self.bn1, relu=True)
+        cfg = self.config
+        if cfg.DEV.SWITCH and cfg.DEV.CLS_MERGE_FEAT and cfg.DEV.STRUCTURE == 'beta' and small_feat_input is not None:
+            # lib/sub_module.py:724-730.  Row i of small_feat_input is the i-th SMALL box in level-major
+            # order, not RoI i -- the reference adds them row by row all the same; mirrored.
+            on = (small_gt_index > 0).float()
+            if cfg.DEV.CLS_MERGE_MANNER == 'simple_add':
+                x = x + (small_feat_input * on.unsqueeze(1)).view(x.size(0), x.size(1), 1, 1)
+            else:                                           # 'linear_add'
+                wgt = (on * cfg.DEV.CLS_MERGE_FAC).view(x.size(0), 1, 1, 1)
+                x = (1 - wgt) * x + wgt * small_feat_input.view(x.size(0), x.size(1), 1, 1)
         x = conv_bn_act(x, self.conv2, self.bn2, relu=True)
         x = x.view(-1, 1024)
         logits = self.linear_class(x)

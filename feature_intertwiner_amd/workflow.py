@@ -15,28 +15,38 @@ def set_optimizer(net, opt):
 
 
 def compute_loss(model, inputs, do_meta=True, world_size=1, reduce_fn=None):
-    """Returns (loss to back-propagate, detached dict of its terms).
+    """Returns (loss to back-propagate, detached dict of its terms) -- lib/workflow.py:180-221.
 
-    Data parallel: the reference total is mean_g(L_det,g) + meta(global statistics)
-    (lib/workflow.py:180, 221).  With one process per GPU and gradients AVERAGED over ranks, the
-    meta term -- evaluated identically on every rank from all-reduced statistics, but reaching
-    the parameters only through the local small features -- is scaled by world_size so that the
-    averaged gradient equals the reference's."""
+    Data parallel: the reference total is mean_g(L_det,g) + meta(global statistics).
+    With one process per GPU and gradients AVERAGED over ranks, every rank adds the SAME meta
+    term evaluated from all-reduced statistics; the factor world_size that the path back into the
+    local statistics needs is applied inside `reduce_fn`'s backward (data_parallel.py), so that
+    parameters owned by the meta loss itself (ot_loss.*) are not over-weighted."""
     cfg = model.config
     (merged_loss, big_feat, big_cnt, small_feat, small_cnt, big_loss, small_output_all, small_gt_all,
      fpn_ot_loss) = model(inputs, 'train')
     detailed = merged_loss.mean(0)
     if cfg.DEV.SWITCH and not cfg.DEV.BASELINE:
+        if cfg.DEV.DIS_REG_LOSS:
+            # workflow.py:184-187 zeroes the VALUES (`.data[i] = 0`) of rpn_bbox, mrcnn_bbox and mask;
+            # torch.sum's backward does not look at values, so their gradients still flow -- mirrored
+            off = torch.tensor([0., 1., 0., 1., 1.], device=detailed.device)
+            detailed = detailed - detailed.detach() * off
         meta = model.meta_loss([big_feat, big_cnt, small_feat, small_cnt, small_output_all, small_gt_all],
                                reduce_fn=reduce_fn)
         meta = torch.where(meta < 0, torch.zeros_like(meta), meta)       # workflow.py:196-200
         meta = meta * cfg.DEV.LOSS_FAC if do_meta else torch.zeros_like(meta)
     else:
         meta = detailed.new_zeros(())
+    if cfg.DEV.SWITCH and cfg.DEV.BIG_SUPERVISE:                          # workflow.py:212-217
+        big = big_loss.mean() * cfg.DEV.BIG_LOSS_FAC
+    else:
+        big = detailed.new_zeros(())
     fpn_ot = cfg.TRAIN.FPN_OT_LOSS_FAC * fpn_ot_loss.mean()
-    loss = detailed.sum() + meta * float(world_size) + fpn_ot
+    loss = detailed.sum() + meta + big + fpn_ot
     terms = {"rpn_cls": detailed[0], "rpn_bbox": detailed[1], "mrcnn_cls": detailed[2],
-             "mrcnn_bbox": detailed[3], "mrcnn_mask": detailed[4], "meta": meta, "total": detailed.sum() + meta}
+             "mrcnn_bbox": detailed[3], "mrcnn_mask": detailed[4], "meta": meta, "big": big,
+             "total": detailed.sum() + meta + big}
     return loss, {k: v.detach() for k, v in terms.items()}
 
 

@@ -269,3 +269,76 @@ def roi_level(rois, image_area, base=224.0):
     lvl = np.rint(lvl)
     lvl = np.where(np.isfinite(lvl), lvl, -1e9)
     return np.clip(lvl, 2, 5).astype(np.int32)
+
+
+# ----------------------------------------------------------------------------
+# Intertwiner meta loss + history buffer (lib/model.py:143-224, lib/workflow.py:190-203)
+# ----------------------------------------------------------------------------
+META_EPS = np.float32(1e-20)
+
+
+def merge_feat_vec(box_feat, box_cnt):
+    """MaskRCNN._merge_feat_vec, lib/model.py:217-224: count-weighted mean over (gpu, scale)."""
+    s = (_f32(box_feat) * _f32(box_cnt)).sum(0).sum(0)
+    c = _f32(box_cnt).sum(0).sum(0)
+    return (s / (c + META_EPS)).astype(np.float32), c.astype(np.float32)
+
+
+class MetaLoss(object):
+    """Step-by-step restatement of MaskRCNN.meta_loss with its buffer state.
+
+    choice in {'l2','l1','kl','ot'}; `ot` = dict(g_w, g_b, c_w, c_b, epsilon, L) of the 1-D OptTrans.
+    __call__ returns the reference's return value: a scalar for l2/l1/kl, the per-row vector for
+    'ot' (:207), and 0 when nothing is selected or (lib/workflow.py:190-194) when the step has no
+    small-object statistics -- in which case the buffer is NOT updated."""
+
+    def __init__(self, choice, buffer_size, feat_dim, num_classes, inst_loss=False, ot=None):
+        self.choice, self.inst, self.ot = choice, inst_loss, ot
+        self.buffer = np.zeros((buffer_size, feat_dim, num_classes), np.float32)
+        self.buffer_cnt = np.zeros((buffer_size, 1, num_classes), np.float32)
+
+    def _update(self, big_feat, big_cnt):
+        bf, bc = merge_feat_vec(big_feat, big_cnt)
+        if self.buffer.shape[0] == 1:                                         # :153-158 running mean
+            feat_sum = self.buffer * self.buffer_cnt + bf[None] * bc[None]
+            self.buffer_cnt = self.buffer_cnt + bc[None]
+            self.buffer = (feat_sum / (self.buffer_cnt + META_EPS)).astype(np.float32)
+            return self.buffer[0]
+        self.buffer[:-1] = self.buffer[1:].copy()                             # :159-166 FIFO
+        self.buffer[-1] = bf
+        self.buffer_cnt[:-1] = self.buffer_cnt[1:].copy()
+        self.buffer_cnt[-1] = bc
+        return ((self.buffer * self.buffer_cnt).sum(0) / (self.buffer_cnt.sum(0) + META_EPS)).astype(np.float32)
+
+    def _pair(self, SMALL, BIG):
+        if self.choice == 'l2':
+            return np.float32(np.mean((SMALL.astype(np.float64) - BIG) ** 2))
+        if self.choice == 'l1':
+            return np.float32(np.mean(np.abs(SMALL.astype(np.float64) - BIG)))
+        if self.choice == 'kl':                         # F.kl_div(log SMALL, BIG), elementwise mean
+            b, s = BIG.astype(np.float64), SMALL.astype(np.float64)
+            with np.errstate(divide="ignore", invalid="ignore"):
+                t = np.where(b > 0, b * (np.log(b) - np.log(s)), 0.0)
+            return np.float32(t.mean())
+        o = self.ot
+        return opttrans_1d_forward(SMALL[:, :, None], BIG[:, :, None], o["g_w"], o["g_b"], o["c_w"], o["c_b"],
+                                   o.get("epsilon", 1.0), o.get("L", 5))
+
+    def __call__(self, big_feat, big_cnt, small_feat, small_cnt, small_output_all=None, small_gt_all=None):
+        if float(_f32(small_feat).sum()) == 0.0:                              # workflow.py:190-194
+            return np.float32(0)
+        final_big = self._update(big_feat, big_cnt)                           # [F, K]
+        buf_has = self.buffer_cnt.sum(0).reshape(-1) > 0   # == buffer_cnt.squeeze() > 0 when BUFFER_SIZE == 1 (:180)
+        if self.inst:                                                         # :168-174, 184-186
+            gt = np.asarray(small_gt_all).astype(np.int64)
+            idx = np.array([i for i in np.nonzero(gt)[0] if buf_has[gt[i]]], np.int64)
+            if idx.size == 0:
+                return np.float32(0)
+            return self._pair(_f32(small_output_all)[idx], final_big[:, gt[idx]].T.copy())
+        s_feat, s_cnt = merge_feat_vec(small_feat, small_cnt)
+        s_cnt = s_cnt.copy()
+        s_cnt[0, 0] = 0                                                       # :178 no background
+        idx = np.nonzero((s_cnt.reshape(-1) > 0) & buf_has)[0]
+        if idx.size == 0:
+            return np.float32(0)
+        return self._pair(s_feat[:, idx].T.copy(), final_big[:, idx].T.copy())

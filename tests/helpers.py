@@ -148,3 +148,52 @@ def golden_module_inputs(seed=7):
 
 
 GOLDEN_MODULE_SEEDS = dict(fpn=100, rpn=2000, classifier=3000, mask=4000, dev=5000)
+
+
+def golden_meta_inputs(step, K=11, F=1024, G=2, S=3, seed=31, activation="relu"):
+    """Seeded (big_feat, big_cnt, small_feat, small_cnt) stacks [G,S,F,K] / [G,S,1,K] of one training
+    step, as Dev.forward would return them (class means are 0 where the count is 0; background column
+    empty), shared by oracle/gen_golden_meta.py and the tests.  `activation`: 'relu' (OT features),
+    'sigmoid' (l1/l2) or 'softmax' (kl, over the feature axis).  Step 2 has NO small objects at all
+    (the reference then skips meta_loss and leaves the buffer alone, lib/workflow.py:190-194)."""
+    rs = np.random.RandomState(seed + 17 * step)
+
+    def stack(p_present):
+        cnt = (rs.randint(1, 6, (G, S, 1, K)) * (rs.uniform(size=(G, S, 1, K)) < p_present)).astype(np.float32)
+        cnt[..., 0] = 0
+        raw = rs.standard_normal((G, S, F, K)).astype(np.float32)
+        if activation == "relu":
+            f = np.maximum(raw, 0)
+        elif activation == "sigmoid":
+            f = 1.0 / (1.0 + np.exp(-raw))
+        else:
+            e = np.exp(raw - raw.max(2, keepdims=True))
+            f = e / e.sum(2, keepdims=True)
+        return (f * (cnt > 0)).astype(np.float32), cnt
+
+    bf, bc = stack(0.5)
+    sf, sc = stack(0.0 if step == 2 else 0.45)
+    return bf, bc, sf, sc
+
+
+def golden_meta_instances(step, n=48, K=11, F=1024, seed=77, activation="sigmoid"):
+    """Seeded (small_output_all [n,F], small_gt_all [n]) for the DEV.INST_LOSS branch; rows past the
+    small boxes are zero with class 0, as Dev.forward leaves them."""
+    rs = np.random.RandomState(seed + 13 * step)
+    raw = rs.standard_normal((n, F)).astype(np.float32)
+    out = np.maximum(raw, 0) if activation == "relu" else (1.0 / (1.0 + np.exp(-raw))).astype(np.float32)
+    gt = rs.randint(0, K, n).astype(np.int64)
+    gt[n - 10:] = 0
+    out[n - 10:] = 0
+    return out.astype(np.float32), gt
+
+
+def ot_full_weights(seed, ch=1024):
+    """Deterministic weights for a full-size 1-D OptTrans (G_net ch->ch, critic ch->ch/4, k=3):
+    same recipe as oracle/gen_golden_ot.full_weights."""
+    rs = np.random.RandomState(seed)
+    g_w = (rs.standard_normal((ch, ch, 3)) * (1.0 / np.sqrt(3 * ch))).astype(np.float32)
+    g_b = (rs.standard_normal((ch,)) * 0.05).astype(np.float32)
+    c_w = (rs.standard_normal((ch // 4, ch, 3)) * (1.0 / np.sqrt(3 * ch))).astype(np.float32)
+    c_b = (rs.standard_normal((ch // 4,)) * 0.05).astype(np.float32)
+    return g_w, g_b, c_w, c_b

@@ -1,7 +1,9 @@
 """CPU, world_size 2, gloo: the data-parallel engine (feature_intertwiner_amd/data_parallel.py)
-reproduces the reference update rule  d/dtheta [ mean_g L_det,g + M(sum_g s_g) ]
-(lib/workflow.py:180, 221) from per-rank backward + bucketed gradient averaging,
-and the intertwiner statistics all-reduce equals gather + _merge_feat_vec."""
+reproduces the reference update rule  d/dtheta [ mean_g L_det,g + M_phi(sum_g s_g) ]
+(lib/workflow.py:180, 221) from per-rank backward + bucketed gradient averaging --
+for the detector parameters theta AND for the meta loss's own parameters phi (ot_loss.*) -- the
+intertwiner statistics all-reduce equals gather + _merge_feat_vec, and parameters without a
+gradient keep `.grad is None` (so that SGD skips them exactly as on one GPU)."""
 import os
 import socket
 
@@ -19,13 +21,21 @@ def _free_port():
     return p
 
 
-def _net():
-    torch.manual_seed(0)
-    return nn.Sequential(nn.Linear(6, 16), nn.Tanh(), nn.Linear(16, 16), nn.Tanh(), nn.Linear(16, 5))
+class _Net(nn.Module):
+    """body: the detector; meta: a loss module with its OWN parameters fed by reduced statistics (the
+    role of ot_loss.G_net / critic); unused: never receives a gradient (ot_loss while do_meta is off);
+    rank1_only: used by rank 1 alone (the gradient-pattern union case)."""
 
+    def __init__(self):
+        super(_Net, self).__init__()
+        torch.manual_seed(0)
+        self.body = nn.Sequential(nn.Linear(6, 16), nn.Tanh(), nn.Linear(16, 16), nn.Tanh(), nn.Linear(16, 5))
+        self.meta = nn.Linear(5, 3)
+        self.unused = nn.Linear(4, 4)
+        self.rank1_only = nn.Parameter(torch.ones(5))
 
-def _meta(stat_sum):
-    return (stat_sum ** 2).sum() * 0.1 + stat_sum.sin().sum()
+    def meta_loss(self, stat_sum):
+        return (self.meta(stat_sum) ** 2).sum() * 0.1 + stat_sum.sin().sum()
 
 
 def _worker(rank, world, port, out):
@@ -33,7 +43,7 @@ def _worker(rank, world, port, out):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from feature_intertwiner_amd.data_parallel import GradientBuckets, all_reduce_statistics, broadcast_parameters
-    net = _net()
+    net = _Net()
     if rank == 1:
         for p in net.parameters():
             p.data.add_(1.0)            # replicas must be re-synchronised from rank 0
@@ -45,15 +55,18 @@ def _worker(rank, world, port, out):
     x = x_all[rank * 3:(rank + 1) * 3]                  # this rank's shard of the minibatch
     for it in range(2):                                 # twice: state must reset between steps
         net.zero_grad(set_to_none=True)
-        y = net(x)
+        y = net.body(x)
         det = (y ** 2).mean()
+        if rank == 1:
+            det = det + (y * net.rank1_only).mean()
         s_local = y.sum(0)                              # "count-weighted feature sums" of this rank
         cnt_local = torch.full((1, 5), float(rank + 1))
         s_sum, c_sum = all_reduce_statistics(s_local, cnt_local)
-        loss = det + float(world) * _meta(s_sum)
+        loss = det + net.meta_loss(s_sum)               # the SAME meta term on every rank, unscaled
         loss.backward()
         sync()
-    out[rank] = {"grads": [p.grad.detach().numpy().copy() for p in net.parameters()],
+    out[rank] = {"grads": {n: (None if p.grad is None else p.grad.detach().numpy().copy())
+                           for n, p in net.named_parameters()},
                  "s_sum": s_sum.detach().numpy().copy(), "c_sum": c_sum.detach().numpy().copy(),
                  "params": [p.data.numpy().copy() for p in net.parameters()]}
     dist.barrier()
@@ -66,30 +79,38 @@ def test_two_rank_update_equals_reference_rule():
     out = mgr.dict()
     mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
     # single-process statement of the reference: mean over replicas of the detector loss + ONE
-    # meta loss on the merged statistics
-    net = _net()
+    # meta loss on the merged statistics (lib/workflow.py:180, 221)
+    net = _Net()
     g = torch.Generator().manual_seed(100)
     x_all = torch.randn(world * 3, 6, generator=g)
-    ys = [net(x_all[r * 3:(r + 1) * 3]) for r in range(world)]
-    det = torch.stack([(y ** 2).mean() for y in ys]).mean()
+    ys = [net.body(x_all[r * 3:(r + 1) * 3]) for r in range(world)]
+    dets = [(y ** 2).mean() for y in ys]
+    dets[1] = dets[1] + (ys[1] * net.rank1_only).mean()
+    det = torch.stack(dets).mean()
     s_sum = sum(y.sum(0) for y in ys)
-    (det + _meta(s_sum)).backward()
-    ref = [p.grad for p in net.parameters()]
+    (det + net.meta_loss(s_sum)).backward()
+    ref = {n: p.grad for n, p in net.named_parameters()}
     import numpy as np
     for r in range(world):
         assert np.allclose(out[r]["s_sum"], s_sum.detach().numpy(), rtol=1e-6, atol=1e-6)
         assert np.array_equal(out[r]["c_sum"], np.full((1, 5), 3.0, np.float32))
-        for a, b in zip(out[r]["grads"], ref):
-            assert np.allclose(a, b.numpy(), rtol=1e-5, atol=1e-6)
+        for n, b in ref.items():
+            a = out[r]["grads"][n]
+            if b is None:
+                assert a is None, n              # no rank produced a gradient: stays None, as on one GPU
+            else:
+                assert a is not None and np.allclose(a, b.numpy(), rtol=1e-5, atol=1e-6), n
         for a, b in zip(out[r]["params"], net.parameters()):
             assert np.array_equal(a, b.data.numpy())    # broadcast made the replicas identical
-    for a, b in zip(out[0]["grads"], out[1]["grads"]):
-        assert np.array_equal(a, b)                     # every rank holds the same averaged gradient
+    assert ref["unused.weight"] is None and ref["meta.weight"] is not None and ref["rank1_only"] is not None
+    for n in ref:
+        a, b = out[0]["grads"][n], out[1]["grads"][n]
+        assert (a is None and b is None) or np.array_equal(a, b)      # every rank holds the same averaged gradient
 
 
 def test_single_process_is_a_no_op():
     from feature_intertwiner_amd.data_parallel import GradientBuckets, all_reduce_statistics
-    net = _net()
+    net = _Net().body
     sync = GradientBuckets(net)
     net(torch.randn(2, 6)).sum().backward()
     before = [p.grad.clone() for p in net.parameters()]
