@@ -55,8 +55,11 @@ class _SinkhornLoss(torch.autograd.Function):
             gx = -torch.bmm(plan, y) * g
             gy = -torch.bmm(plan.transpose(1, 2), x) * g
         else:
+            # d|x_i - y_j| / dx_i = (x_i - y_j) / |x_i - y_j|, and 0 at coincident points (the subgradient
+            # torch.norm's backward uses); dividing by a clamped distance instead would weight the
+            # (x_i - y_j) = 0 pairs -- every pair of ReLU-dead critic outputs -- by P / 1e-30
             dist = torch.cdist(x, y)
-            w = plan / dist.clamp_min(1e-30)
+            w = torch.where(dist > 0, plan / dist.clamp_min(1e-30), torch.zeros_like(plan))
             gx = (w.sum(2, keepdim=True) * x - torch.bmm(w, y)) * g
             gy = (w.sum(1).unsqueeze(2) * y - torch.bmm(w.transpose(1, 2), x)) * g
         return gx, gy, None, None, None
@@ -67,10 +70,14 @@ def sinkhorn_loss(x, y, epsilon_inv=1.0, L=5, C_form="cosine"):
     if C_form == "cosine":
         xn = x / (torch.norm(x, p=2, dim=2, keepdim=True) + EPS)
         yn = y / (torch.norm(y, p=2, dim=2, keepdim=True) + EPS)
-        return _SinkhornLoss.apply(xn, yn, epsilon_inv, L, 2)
+        loss = _SinkhornLoss.apply(xn, yn, epsilon_inv, L, 2)
     elif C_form == "l2":
-        return _SinkhornLoss.apply(x, y, epsilon_inv, L, 1)
-    raise ValueError("unknown C_form %r" % (C_form,))
+        loss = _SinkhornLoss.apply(x, y, epsilon_inv, L, 1)
+    else:
+        raise ValueError("unknown C_form %r" % (C_form,))
+    if _lib.TAP is not None:
+        _lib.TAP("sinkhorn", x=x, y=y, eps_inv=float(epsilon_inv), L=int(L), C_form=C_form, loss=loss)
+    return loss
 
 
 class OptTrans(nn.Module):

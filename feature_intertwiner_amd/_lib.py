@@ -98,6 +98,12 @@ def kernel_name(key):
 
 _lib = None
 
+# Test hook: `TAP(name, **tensors)` is called by the pyramid RoIAlign, NMS and Sinkhorn operators
+# right after their launch with their input and output tensors (references, no copies, no
+# synchronisation), so that a test can re-check what ran INSIDE a train step against the oracle.
+# None in production.
+TAP = None
+
 
 class FiError(RuntimeError):
     pass

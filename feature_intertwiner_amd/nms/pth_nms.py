@@ -25,6 +25,9 @@ def nms_sorted(boxes, thresh, max_keep=0, strict=False):
         _lib.check(L.fi_nms_sorted(_lib.ptr(b), bs, N, stride, float(thresh), 1 if strict else 0,
                                    int(max_keep), _lib.ptr(keep), _lib.ptr(num_out), _lib.ptr(ws),
                                    _lib.current_stream()), "fi_nms_sorted")
+    if _lib.TAP is not None:
+        _lib.TAP("nms_sorted", boxes=b, thresh=float(thresh), strict=bool(strict), max_keep=int(max_keep), keep=keep,
+                 num_out=num_out)
     if squeeze:
         return keep[0], num_out[0]
     return keep, num_out

@@ -100,6 +100,9 @@ class _PyramidCrop(torch.autograd.Function):
                 int(crop_height), int(crop_width), float(extrapolation_value), _lib.ptr(crops),
                 _lib.current_stream()), "fi_pyramid_crop_forward")
         ctx.channels_last = cl
+        if _lib.TAP is not None:
+            _lib.TAP("pyramid_crop", maps=maps, boxes=boxes_c, box_ind=ind_c, level=lvl_c, crops=crops,
+                     crop=int(crop_height))
         if LAUNCH_LOG is not None:
             LAUNCH_LOG.append({"pyramid": True, "nhwc": cl, "crop": int(crop_height), "depth": int(C), "boxes": boxes_c,
                                "level": lvl_c, "box_ind": ind_c, "shapes": [(m.shape[2], m.shape[3]) for m in maps]})

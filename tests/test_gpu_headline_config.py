@@ -1,0 +1,78 @@
+"""GPU: BASELINE configs[2] -- the configuration the headline metric is quoted on (ResNet-101-FPN,
+4 x 1024^2, 512 RoIs/image, OT intertwiner on, Sinkhorn L=50, 80 classes) -- for 2 full train steps,
+with the inputs and outputs of every RoIAlign, NMS and Sinkhorn launch INSIDE the step captured
+(feature_intertwiner_amd._lib.TAP) and re-checked against the CPU oracle: RoIAlign bit-exact, NMS keep
+indices exact, OT terms within 1e-4 relative (the north star's bars)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def test_configs2_full_size_two_steps_operators_vs_oracle(oracle):
+    from feature_intertwiner_amd import _lib
+    from feature_intertwiner_amd.config import make_config
+    from feature_intertwiner_amd.model import MaskRCNN
+    from feature_intertwiner_amd.synthetic import SyntheticProposals, synthetic_batch
+    from feature_intertwiner_amd.workflow import set_optimizer, train_step
+    torch.manual_seed(2000)
+    cfg = make_config("resnet101", 1024, 4, 512, dev_switch=True, loss_choice="ot", ot_L=50)
+    model = MaskRCNN(cfg).to(DEV)
+    opt = set_optimizer(model, cfg.TRAIN)
+    batch = synthetic_batch(4, 1024, device=DEV, seed=2000)
+    model.proposal_hook = SyntheticProposals(batch[2], 1024, seed=7)
+    model.generator = torch.Generator(device=DEV).manual_seed(11)
+    first = float(train_step(model, opt, list(batch))["total"])       # step 1 (fills the history buffer)
+
+    taps = []
+    _lib.TAP = lambda name, **kw: taps.append((name, {k: (v.detach().clone() if torch.is_tensor(v) else
+                                                         ([m.detach() for m in v] if isinstance(v, list) else v))
+                                                      for k, v in kw.items()}))
+    try:
+        terms = train_step(model, opt, list(batch))                   # step 2, captured
+    finally:
+        _lib.TAP = None
+    torch.cuda.synchronize()
+    assert all(torch.isfinite(v) for v in terms.values()), terms
+    assert float(terms["total"]) < first
+
+    names = [n for n, _ in taps]
+    assert names.count("nms_sorted") == 1 and names.count("sinkhorn") == 1
+    crops = [t for n, t in taps if n == "pyramid_crop"]
+    # Dev stage: 7x7 and 14x14 over all 2048 RoIs (channels-last make-up maps) + the 'big' 14x14 crop
+    kinds = sorted((c["crop"], c["boxes"].shape[0] == 2048) for c in crops)
+    assert kinds == [(7, True), (14, False), (14, True)], kinds
+
+    # ---- RoIAlign: bit-exact, every launch of the step ------------------------------------
+    for c in crops:
+        maps = [m.cpu().numpy() for m in c["maps"]]                   # logical NCHW whatever the memory format
+        boxes, ind, level = c["boxes"].cpu().numpy(), c["box_ind"].cpu().numpy(), c["level"].cpu().numpy()
+        got = c["crops"].cpu().numpy()
+        assert (level >= 2).all() and (level <= 5).all()
+        for l in range(2, 6):
+            sel = np.nonzero(level == l)[0]
+            if len(sel) == 0:
+                continue
+            exp = oracle.crop_and_resize_forward(maps[l - 2], boxes[sel], ind[sel], c["crop"], c["crop"])
+            assert np.array_equal(got[sel].view(np.uint32), exp.view(np.uint32)), (c["crop"], l)
+
+    # ---- NMS: keep indices exact (4 images x 6000 candidates, threshold 0.7, first 1000 kept) ----
+    t = dict(taps)["nms_sorted"]
+    dets = t["boxes"].cpu().numpy()
+    assert dets.shape == (4, 6000, 5) and t["thresh"] == pytest.approx(0.7) and not t["strict"]
+    keep, num = t["keep"].cpu().numpy(), t["num_out"].cpu().numpy()
+    for b in range(4):
+        exp = oracle.pth_nms(dets[b], 0.7)[:t["max_keep"]]
+        assert int(num[b]) == len(exp) and np.array_equal(keep[b, :len(exp)], exp), b
+    assert num.min() > 100
+
+    # ---- Sinkhorn: 3 x 80 problems of 256 x 256, L = 50, each term within 1e-4 relative ----------
+    t = dict(taps)["sinkhorn"]
+    x, y, got = t["x"].cpu().numpy(), t["y"].cpu().numpy(), t["loss"].cpu().numpy()
+    assert x.shape == (240, 256, 1) and t["L"] == 50 and t["C_form"] == "cosine"
+    exp = np.array([oracle.sinkhorn(x[p], y[p], t["eps_inv"], 50) for p in range(240)])
+    assert np.all(np.abs(got - exp) <= 1e-4 * np.abs(exp) + 1e-7), np.abs(got - exp).max()
+    del model, opt
+    torch.cuda.empty_cache()
