@@ -83,6 +83,7 @@ class GradientBuckets(object):
         self.use_stream = self.device.type == "cuda"
         self.comm_stream = torch.cuda.Stream(device=self.device) if self.use_stream else None
         self._verified_pattern = None
+        self.launch_log = None       # set to [] to record when each bucket is issued (tests)
         self._reset()
         if self.world > 1:
             for p in params:
@@ -103,6 +104,8 @@ class GradientBuckets(object):
         while self.next_to_launch < len(self.buckets) and (force or self.pending[self.next_to_launch] <= 0):
             bi = self.next_to_launch
             self.next_to_launch += 1
+            if self.launch_log is not None:      # (bucket, gradients still to come when it was issued)
+                self.launch_log.append((bi, sum(max(n, 0) for n in self.pending[bi + 1:])))
             # a parameter without a gradient contributes zeros (the bucket layout is fixed) but is
             # remembered: it must come out of the step with .grad still None (see __call__)
             had = [p.grad is not None for p in self.buckets[bi]]

@@ -50,6 +50,7 @@ def _worker(rank, world, port, out):
     broadcast_parameters(net)
     sync = GradientBuckets(net, bucket_bytes=300)      # tiny buckets: several collectives
     assert len(sync.buckets) > 2
+    sync.launch_log = []
     g = torch.Generator().manual_seed(100)
     x_all = torch.randn(world * 3, 6, generator=g)
     x = x_all[rank * 3:(rank + 1) * 3]                  # this rank's shard of the minibatch
@@ -64,7 +65,12 @@ def _worker(rank, world, port, out):
         s_sum, c_sum = all_reduce_statistics(s_local, cnt_local)
         loss = det + net.meta_loss(s_sum)               # the SAME meta term on every rank, unscaled
         loss.backward()
+        issued_in_backward = list(sync.launch_log)
         sync()
+    # overlap by construction: buckets are issued from autograd hooks while later gradients are still
+    # being computed -- at least the first bucket left with work outstanding, in bucket order
+    assert issued_in_backward and issued_in_backward[0][1] > 0, issued_in_backward
+    assert [b for b, _ in sync.launch_log[-len(sync.buckets):]] == list(range(len(sync.buckets)))
     out[rank] = {"grads": {n: (None if p.grad is None else p.grad.detach().numpy().copy())
                            for n, p in net.named_parameters()},
                  "s_sum": s_sum.detach().numpy().copy(), "c_sum": c_sum.detach().numpy().copy(),
