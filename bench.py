@@ -253,6 +253,8 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     _lib.prof_enable(False)
+    if sync is not None:
+        sync.check()               # replicas stayed consistent (host sync, outside the timed region)
     log = car.LAUNCH_LOG
     car.LAUNCH_LOG = None
     flop_log = ficonv.FLOP_LOG

@@ -56,8 +56,22 @@ class GradientBuckets(object):
 
         sync = GradientBuckets(model)
         ...
+        sync.begin(key)      # optional: names the graph variant of this step (e.g. do_meta on/off)
         loss.backward()      # buckets launch from autograd hooks as they fill
         sync()               # waits, writes the rank-mean gradients back into p.grad
+
+    Parameters without a gradient.  The autograd graph has static shapes and the same structure on
+    every rank, so which parameters receive a gradient depends only on the graph variant `key`.
+      * A parameter whose gradient is None at the end of backward keeps `.grad is None` (it rides
+        through the collective as zeros: the bucket layout is fixed) -- SGD then applies neither weight
+        decay nor momentum to it, exactly as on one GPU and in the reference.
+      * Buckets are issued strictly in order, so a bucket holding such a parameter would stall every
+        later bucket until the end of backward.  The first step of a `key` waits for everything; later
+        steps do not wait for parameters that had no gradient under the same `key`.  A gradient that
+        shows up for a parameter that was not waited for is a programming error and raises.
+      * Cross-rank consistency (a parameter with a gradient on one rank and none on another) cannot be
+        acted on without a host synchronisation; one flag per parameter travels with each bucket, a
+        device-side counter accumulates disagreements, and `check()` (tests, end of a run) raises on it.
     """
 
     def __init__(self, module, bucket_bytes=25 * 1024 * 1024, group=None):
@@ -82,21 +96,35 @@ class GradientBuckets(object):
         self.device = params[0].device if params else torch.device("cpu")
         self.use_stream = self.device.type == "cuda"
         self.comm_stream = torch.cuda.Stream(device=self.device) if self.use_stream else None
-        self._verified_pattern = None
         self.launch_log = None       # set to [] to record when each bucket is issued (tests)
+        self._absent = {}            # key -> set of parameters that produced no gradient under that key
+        self._key = None
+        self._violations = torch.zeros((), device=self.device)
         self._reset()
         if self.world > 1:
             for p in params:
                 p.register_post_accumulate_grad_hook(self._on_grad)
 
+    def begin(self, key=None):
+        """Call before backward.  `key` identifies the graph variant (anything hashable)."""
+        self._key = key
+        self._reset()
+
     def _reset(self):
-        self.pending = [len(b) for b in self.buckets]
+        absent = self._absent.get(self._key, ())
+        self.pending = [sum(1 for p in b if p not in absent) for b in self.buckets]
         self.next_to_launch = 0
         self.inflight = []        # (bucket index, flat buffer, work handle, which params had a gradient)
+        self._launched = set()
 
     def _on_grad(self, p):
         bi = self.bucket_of[p]
-        self.pending[bi] -= 1
+        if bi in self._launched:
+            raise RuntimeError("GradientBuckets: a gradient arrived for a parameter of bucket %d after the bucket was "
+                               "issued -- the set of parameters that receive gradients changed without a new "
+                               "begin(key)" % bi)
+        if p not in self._absent.get(self._key, ()):
+            self.pending[bi] -= 1
         self._launch_ready()
 
     def _launch_ready(self, force=False):
@@ -104,69 +132,61 @@ class GradientBuckets(object):
         while self.next_to_launch < len(self.buckets) and (force or self.pending[self.next_to_launch] <= 0):
             bi = self.next_to_launch
             self.next_to_launch += 1
+            self._launched.add(bi)
             if self.launch_log is not None:      # (bucket, gradients still to come when it was issued)
                 self.launch_log.append((bi, sum(max(n, 0) for n in self.pending[bi + 1:])))
-            # a parameter without a gradient contributes zeros (the bucket layout is fixed) but is
-            # remembered: it must come out of the step with .grad still None (see __call__)
+            # a parameter without a gradient contributes zeros (the bucket layout is fixed); one flag per
+            # parameter rides along for the cross-rank consistency counter
             had = [p.grad is not None for p in self.buckets[bi]]
             grads = [p.grad if h else torch.zeros_like(p) for p, h in zip(self.buckets[bi], had)]
+            flags = torch.tensor([1.0 if h else 0.0 for h in had], dtype=grads[0].dtype).to(self.device, non_blocking=True)
             if self.use_stream:
                 self.comm_stream.wait_stream(torch.cuda.current_stream(self.device))
                 with torch.cuda.stream(self.comm_stream):
-                    flat = torch._utils._flatten_dense_tensors(grads)
+                    flat = torch._utils._flatten_dense_tensors(grads + [flags])
                     for g in grads:
                         g.record_stream(self.comm_stream)
+                    flags.record_stream(self.comm_stream)
                     work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
             else:
-                flat = torch._utils._flatten_dense_tensors(grads)
+                flat = torch._utils._flatten_dense_tensors(grads + [flags])
                 work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-            self.inflight.append((bi, flat, work, had))
-
-    def _union_of_grad_patterns(self, local):
-        """Which parameters received a gradient on ANY rank.  The autograd graph has static shapes
-        and the same structure on every rank, so the local pattern normally IS the union; it is
-        verified with one tiny host-side collective whenever the local pattern changes (first step,
-        do_meta switching on, ...), never in steady state."""
-        if self._verified_pattern is not None and self._verified_pattern[0] == local:
-            return self._verified_pattern[1]
-        flags = torch.tensor([1.0 if h else 0.0 for h in local], dtype=torch.float32)
-        if self.device.type == "cuda" and dist.get_backend(self.group) == "nccl":
-            flags = flags.to(self.device)
-        dist.all_reduce(flags, op=dist.ReduceOp.MAX, group=self.group)
-        union = tuple(bool(v) for v in flags.cpu().tolist())
-        # cache only if every rank saw the same pattern (then it stays valid while local is unchanged)
-        same = torch.tensor([1.0 if union == local else 0.0])
-        if self.device.type == "cuda" and dist.get_backend(self.group) == "nccl":
-            same = same.to(self.device)
-        dist.all_reduce(same, op=dist.ReduceOp.MIN, group=self.group)
-        self._verified_pattern = (local, union) if float(same.item()) == 1.0 else None
-        return union
+            self.inflight.append((bi, flat, work, had, flags))
 
     def __call__(self):
         if self.world == 1:
             return
-        self._launch_ready(force=True)        # parameters that got no gradient this step
+        self._launch_ready(force=True)        # whatever is left (first step of a key; trailing bucket)
         inv = 1.0 / float(self.world)
-        local = tuple(h for _, _, _, had in self.inflight for h in had)
-        union = self._union_of_grad_patterns(local)
-        k = 0
-        for bi, flat, work, had in self.inflight:
+        absent = set()
+        for bi, flat, work, had, flags in self.inflight:
             work.wait()
             if self.use_stream:
                 cur = torch.cuda.current_stream(self.device)
                 cur.wait_stream(self.comm_stream)
                 flat.record_stream(cur)
-            flat.mul_(inv)
-            outs = torch._utils._unflatten_dense_tensors(flat, [p for p in self.buckets[bi]])
+            n = len(had)
+            # some rank had a gradient where this one had none (or vice versa): replicas would diverge
+            self._violations += ((flat[-n:] > 0) & (flat[-n:] < self.world)).sum()
+            flat[:-n].mul_(inv)
+            outs = torch._utils._unflatten_dense_tensors(flat[:-n], [p for p in self.buckets[bi]])
             for p, g, h in zip(self.buckets[bi], outs, had):
                 if h:
                     p.grad.copy_(g)
-                elif union[k]:
-                    p.grad = g.clone()        # some other rank had a gradient for it
-                # else: no rank produced a gradient -> .grad stays None, exactly as on one GPU
-                # (SGD then applies neither weight decay nor momentum to it)
-                k += 1
+                else:
+                    # no gradient here: .grad stays None, exactly as on one GPU
+                    if p.grad is not None:
+                        raise RuntimeError("GradientBuckets: gradient produced after its bucket was issued")
+                    absent.add(p)
+        self._absent[self._key] = absent
         self._reset()
+
+    def check(self):
+        """Host-synchronising: raises if any parameter ever had a gradient on some ranks only."""
+        n = int(self._violations.item())
+        if n:
+            raise RuntimeError("GradientBuckets: %d parameter-steps had a gradient on some ranks but not on others; "
+                               "the replicas have diverged" % n)
 
 
 def invalidate_derived_state(module):

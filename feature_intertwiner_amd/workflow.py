@@ -57,6 +57,8 @@ def train_step(model, optimizer, inputs, do_meta=True, grad_sync=None, world_siz
     cfg = model.config
     optimizer.zero_grad(set_to_none=True)
     loss, terms = compute_loss(model, inputs, do_meta, world_size, reduce_fn)
+    if grad_sync is not None and hasattr(grad_sync, "begin"):
+        grad_sync.begin(("do_meta", bool(do_meta)))     # the graph variant decides which parameters get gradients
     loss.backward()
     if grad_sync is not None:
         grad_sync()

@@ -24,7 +24,7 @@ def _free_port():
 class _Net(nn.Module):
     """body: the detector; meta: a loss module with its OWN parameters fed by reduced statistics (the
     role of ot_loss.G_net / critic); unused: never receives a gradient (ot_loss while do_meta is off);
-    rank1_only: used by rank 1 alone (the gradient-pattern union case)."""
+    rank1_only: used only when a test wants ranks to DISAGREE on which parameters get gradients."""
 
     def __init__(self):
         super(_Net, self).__init__()
@@ -38,7 +38,7 @@ class _Net(nn.Module):
         return (self.meta(stat_sum) ** 2).sum() * 0.1 + stat_sum.sin().sum()
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, asymmetric=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -54,11 +54,12 @@ def _worker(rank, world, port, out):
     g = torch.Generator().manual_seed(100)
     x_all = torch.randn(world * 3, 6, generator=g)
     x = x_all[rank * 3:(rank + 1) * 3]                  # this rank's shard of the minibatch
-    for it in range(2):                                 # twice: state must reset between steps
+    for it in range(3):                                 # state must reset between steps
         net.zero_grad(set_to_none=True)
+        sync.begin("with-meta")
         y = net.body(x)
         det = (y ** 2).mean()
-        if rank == 1:
+        if asymmetric and rank == 1:
             det = det + (y * net.rank1_only).mean()
         s_local = y.sum(0)                              # "count-weighted feature sums" of this rank
         cnt_local = torch.full((1, 5), float(rank + 1))
@@ -67,10 +68,20 @@ def _worker(rank, world, port, out):
         loss.backward()
         issued_in_backward = list(sync.launch_log)
         sync()
-    # overlap by construction: buckets are issued from autograd hooks while later gradients are still
-    # being computed -- at least the first bucket left with work outstanding, in bucket order
-    assert issued_in_backward and issued_in_backward[0][1] > 0, issued_in_backward
+    # overlap by construction: from the second step of a graph variant on, buckets are issued from autograd
+    # hooks while later gradients are still being computed (the never-used parameters are not waited for)
+    assert issued_in_backward and issued_in_backward[-len(sync.buckets)][1] > 0, issued_in_backward
     assert [b for b, _ in sync.launch_log[-len(sync.buckets):]] == list(range(len(sync.buckets)))
+    if asymmetric:
+        try:
+            sync.check()
+            out[rank] = "no error"
+        except RuntimeError as e:
+            out[rank] = "raised: " + str(e)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
+    sync.check()                                        # every rank agreed on who got gradients
     out[rank] = {"grads": {n: (None if p.grad is None else p.grad.detach().numpy().copy())
                            for n, p in net.named_parameters()},
                  "s_sum": s_sum.detach().numpy().copy(), "c_sum": c_sum.detach().numpy().copy(),
@@ -90,9 +101,7 @@ def test_two_rank_update_equals_reference_rule():
     g = torch.Generator().manual_seed(100)
     x_all = torch.randn(world * 3, 6, generator=g)
     ys = [net.body(x_all[r * 3:(r + 1) * 3]) for r in range(world)]
-    dets = [(y ** 2).mean() for y in ys]
-    dets[1] = dets[1] + (ys[1] * net.rank1_only).mean()
-    det = torch.stack(dets).mean()
+    det = torch.stack([(y ** 2).mean() for y in ys]).mean()
     s_sum = sum(y.sum(0) for y in ys)
     (det + net.meta_loss(s_sum)).backward()
     ref = {n: p.grad for n, p in net.named_parameters()}
@@ -108,10 +117,20 @@ def test_two_rank_update_equals_reference_rule():
                 assert a is not None and np.allclose(a, b.numpy(), rtol=1e-5, atol=1e-6), n
         for a, b in zip(out[r]["params"], net.parameters()):
             assert np.array_equal(a, b.data.numpy())    # broadcast made the replicas identical
-    assert ref["unused.weight"] is None and ref["meta.weight"] is not None and ref["rank1_only"] is not None
+    assert ref["unused.weight"] is None and ref["meta.weight"] is not None and ref["rank1_only"] is None
     for n in ref:
         a, b = out[0]["grads"][n], out[1]["grads"][n]
         assert (a is None and b is None) or np.array_equal(a, b)      # every rank holds the same averaged gradient
+
+
+def test_ranks_disagreeing_on_gradient_pattern_is_detected():
+    """A parameter with a gradient on one rank only would silently de-synchronise the replicas
+    (its .grad stays None where it was not produced); the consistency counter reports it."""
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), out, True), nprocs=world, join=True)
+    assert all(str(out[r]).startswith("raised: ") and "some ranks" in out[r] for r in range(world)), dict(out)
 
 
 def test_single_process_is_a_no_op():

@@ -95,8 +95,10 @@ def _worker(rank, port, variant, outdir):
     model.proposal_hook, model.generator = hook, gen
     opt.zero_grad(set_to_none=True)
     loss, terms = compute_loss(model, list(batch), do_meta, WORLD, all_reduce_statistics)
+    sync.begin(("do_meta", do_meta))
     loss.backward()
     sync()
+    sync.check()                  # every rank agreed on which parameters received gradients
     grads = {n: (None if p.grad is None else p.grad.detach().cpu()) for n, p in model.named_parameters()}
     torch.nn.utils.clip_grad_norm_([p for p in model.parameters() if p.grad is not None], cfg.TRAIN.MAX_GRAD_NORM)
     opt.step()
