@@ -4,9 +4,25 @@
 // lib/roi_pooling/src/roi_pooling_kernel.cu:24-93 / :128-203 (the CUDA kernel is the
 // only usable definition of the operator -- SURVEY Q4).  Oracle: orc_roi_pool_*.
 //
-// Forward: one workgroup per (RoI, channel chunk); the RoI's bin boundaries
-// (hstart/hend per pooled row, wstart/wend per pooled column, after rounding,
-// offsetting and clipping) are computed once into LDS instead of per output.
+// Forward (roi_pool_fwd_kernel): one workgroup per (RoI, channel chunk); the RoI's bin
+// boundaries (hstart/hend per pooled row, wstart/wend per pooled column, after rounding,
+// offsetting and clipping) are computed once into LDS.  Each wavefront then works on
+// (channel, window-column) pairs: a lane owns ONE column of the RoI window, so that a
+// wavefront load instruction fetches a contiguous row segment of the plane (the first
+// version gave every lane its own bin window: adjacent lanes on different rows, one cache
+// line per lane and step).  Narrow windows pack 2..8 channels into the 64 lanes.
+//   phase 1  per pooled row p: every lane walks its column down rows [hstart_p, hend_p)
+//            keeping (max, first row of the max) -> wavefront-private LDS colv/colh[p][lane]
+//   phase 2  per bin (p, q): one lane scans the <= bin-width columns of LDS in w order,
+//            v > best || (v == best && row < best_row)  ==  the reference's strict `>` in
+//            (h, w) scan order (first maximum wins, roi_pooling_kernel.cu:75-86)
+// Windows wider than 64 columns are processed in 64-column slabs with the running bin
+// state kept in LDS.  Pooled sizes above 28x28 use the simple per-bin kernel.
+// Measured (512 RoIs x 256 ch on a 2x256x256x256 map): 7x7 1269 -> 400 us, 14x14 -> 640 us.
+// What bounds it now: one row segment (<= 256 B) per vector-memory instruction; whole-map
+// windows read at 6.6 TB/s even when every byte is an L2 hit (scripts/roipool_probe.py), i.e.
+// the CU's load-instruction rate, not memory.  The next step is lanes = rows x 16-byte column
+// groups (4-8x fewer load instructions), at the price of per-lane bin bookkeeping.
 // Backward: the reference gathers -- every INPUT element loops over ALL RoIs
 // (O(B*C*H*W*N), 67 M threads x N at P2).  Here each pooled cell scatters its
 // gradient to its argmax with a hardware fp32 atomic, after re-checking the
@@ -46,7 +62,7 @@ __device__ __forceinline__ Roi decode_roi(const float *__restrict__ r, float sca
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return min(max(v, lo), hi); }
 
-__global__ __launch_bounds__(kThreads) void roi_pool_fwd_kernel(
+__global__ __launch_bounds__(kThreads) void roi_pool_fwd_simple_kernel(
     const float *__restrict__ features, const float *__restrict__ rois, int num_rois, int batch,
     int channels, int height, int width, int ph, int pw, float scale, int chan_per_block,
     int chunks, float *__restrict__ output, int *__restrict__ argmax)
@@ -106,6 +122,246 @@ __global__ __launch_bounds__(kThreads) void roi_pool_fwd_kernel(
     }
 }
 
+__device__ __forceinline__ void wave_lds_sync()
+{
+    // LDS traffic of one wavefront is issued and completed in order; this only stops the compiler from
+    // moving the reads of other lanes' data above the writes
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+constexpr int kWaves = kThreads / 64;
+
+// dynamic LDS per wavefront: colv[ph][64] floats, colh[ph][64] ints, then (wide windows only) the running
+// bin state binv[bins], binh[bins], binw[bins]
+__host__ __device__ inline size_t roi_pool_wave_lds(int ph, int pw) { return (size_t)ph * 64 * 8 + (size_t)ph * pw * 12; }
+
+__global__ __launch_bounds__(kThreads) void roi_pool_fwd_kernel(
+    const float *__restrict__ features, const float *__restrict__ rois, int num_rois, int batch,
+    int channels, int height, int width, int ph, int pw, float scale, int chan_per_block,
+    int chunks, float *__restrict__ output, int *__restrict__ argmax)
+{
+    __shared__ int s_h0[kMaxPool], s_h1[kMaxPool], s_w0[kMaxPool], s_w1[kMaxPool];
+    extern __shared__ __align__(16) unsigned char s_dyn[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    // XCD-aware order: workgroups are dispatched round-robin over the 8 XCDs (blockIdx % 8), each with its
+    // own 4 MB L2.  XCD x works through channel chunks x, x + 8, ... one after the other, each for ALL RoIs:
+    // the planes of one chunk (8 channels x batch x H x W floats) then stay L2-resident while every RoI
+    // window on them is read, instead of every RoI streaming its windows of all channels from memory.
+    const int xcd = blockIdx.x & 7;
+    const int j = blockIdx.x >> 3;
+    const int chunk = (j / num_rois) * 8 + xcd;
+    const int n = j % num_rois;
+    if (chunk >= chunks) return;
+    const int c_begin = chunk * chan_per_block;
+    const int c_count = min(chan_per_block, channels - c_begin);
+    const int bins = ph * pw;
+
+    const Roi r = decode_roi(rois + 5 * (size_t)n, scale, ph, pw);
+    if (tid < ph) {
+        const int hs = (int)floorf((float)tid * r.bin_h);
+        const int he = (int)ceilf((float)(tid + 1) * r.bin_h);
+        s_h0[tid] = clampi(hs + r.start_h, 0, height);
+        s_h1[tid] = clampi(he + r.start_h, 0, height);
+    }
+    if (tid >= 64 && tid < 64 + pw) {
+        const int q = tid - 64;
+        const int ws = (int)floorf((float)q * r.bin_w);
+        const int we = (int)ceilf((float)(q + 1) * r.bin_w);
+        s_w0[q] = clampi(ws + r.start_w, 0, width);
+        s_w1[q] = clampi(we + r.start_w, 0, width);
+    }
+    __syncthreads();
+
+    const size_t o_base = ((size_t)n * channels + c_begin) * bins;
+    const bool img_ok = r.img >= 0 && r.img < batch;
+    // window columns [w_lo, w_hi): bin bounds are monotone in q
+    const int w_lo = s_w0[0];
+    const int w_hi = s_w1[pw - 1];
+    const int w_win = max(w_hi - w_lo, 0);
+    const int h_hi = s_h1[ph - 1];                 // bin bounds are monotone in p as well
+    const bool stream_ok = r.bin_h >= 1.0f;
+    if (!img_ok || w_win == 0) {      // every bin is empty: 0 / -1 (roi_pooling_kernel.cu:70-72)
+        for (int idx = tid; idx < c_count * bins; idx += kThreads) {
+            output[o_base + idx] = 0.0f;
+            if (argmax) argmax[o_base + idx] = -1;
+        }
+        return;
+    }
+    // lanes = (channel sub-index, column): wp columns per channel, cpw channels per wavefront pass
+    // (narrow windows are latency-bound, not lane-bound: never pack so far that wavefronts sit idle)
+    const int cpw_max = max(1, chan_per_block / kWaves);
+    const int wp = max(w_win <= 8 ? 8 : (w_win <= 16 ? 16 : (w_win <= 32 ? 32 : 64)), 64 / cpw_max);
+    const int cpw = 64 / wp;
+    const int slabs = (w_win + 63) / 64;          // > 1 only when wp == 64
+    const int c_sub = lane / wp;
+    const int w_off = lane - c_sub * wp;
+
+    unsigned char *mine = s_dyn + (size_t)wave * roi_pool_wave_lds(ph, pw);
+    float *colv = (float *)mine;
+    int *colh = (int *)(mine + (size_t)ph * 64 * 4);
+    float *binv = (float *)(mine + (size_t)ph * 64 * 8);
+    int *binh = (int *)(binv + bins);
+    int *binw = binh + bins;
+
+    const int groups = (c_count + cpw - 1) / cpw;
+    for (int g = wave; g < groups; g += kWaves) {
+        const int c_loc = g * cpw + c_sub;
+        const bool c_ok = c_loc < c_count;
+        const int plane_off = ((r.img * channels) + c_begin + min(c_loc, c_count - 1)) * height * width;
+        const float *__restrict__ src = features + plane_off;
+        if (slabs > 1) {
+            for (int b = lane; b < bins; b += 64) {
+                binv[b] = -FLT_MAX;
+                binh[b] = -1;
+                binw[b] = -1;
+            }
+        }
+        for (int slab = 0; slab < slabs; ++slab) {
+            const int col0 = w_lo + slab * 64;                 // first column of this slab
+            const int wcol = col0 + w_off;
+            const bool col_ok = c_ok && wcol < w_hi;
+            const float *__restrict__ colp = src + min(wcol, width - 1);
+            // ---- phase 1: column maxima per pooled row --------------------------------------
+            // Bin bounds are the same for every lane: they are pulled into scalar registers (UNI) so that
+            // the bin bookkeeping is SALU work and scalar branches; the vector pipe only sees the loads and
+            // one compare + two selects per element.  Lanes without a column (window narrower than the lane
+            // group, channel past the end) read a valid dummy column and are reset when a bin is stored.
+#define UNI(x) __builtin_amdgcn_readfirstlane(x)
+            const int hi_u = UNI(h_hi);
+            if (stream_ok) {
+                // ONE pass down the window, 8 rows (8 independent loads) at a time.  With bin_h >= 1
+                // consecutive bins share at most their boundary row (hstart[p+1] >= hend[p] - 1, also after
+                // clamping), so two accumulators suffice: A for bin p, B for bin p + 1.
+                int p = 0;
+                while (p < ph && UNI(s_h1[p]) <= UNI(s_h0[p])) {     // leading empty bins (above the map)
+                    colv[p * 64 + lane] = -FLT_MAX;
+                    colh[p * 64 + lane] = -1;
+                    ++p;
+                }
+                float a_v = -FLT_MAX, b_v = -FLT_MAX;
+                int a_h = -1, b_h = -1;
+                const int h_lo = p < ph ? UNI(s_h0[p]) : 0;
+                int he_p = p < ph ? UNI(s_h1[p]) : 0x7fffffff;
+                int hs_n = p + 1 < ph ? UNI(s_h0[p + 1]) : 0x7fffffff;
+                int he_n = p + 1 < ph ? UNI(s_h1[p + 1]) : 0;
+                for (int h0 = h_lo; h0 < hi_u && p < ph; h0 += 8) {
+                    float v[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i)
+                        if (h0 + i < hi_u) v[i] = colp[(h0 + i) * width];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const int h = h0 + i;
+                        if (h < hi_u && p < ph) {
+                            if (v[i] > a_v) { a_v = v[i]; a_h = h; }
+                            if (h >= hs_n && h < he_n) {                 // boundary row shared with bin p + 1
+                                if (v[i] > b_v) { b_v = v[i]; b_h = h; }
+                            }
+                            while (p < ph && h + 1 >= he_p) {            // bin p is complete
+                                colv[p * 64 + lane] = col_ok ? a_v : -FLT_MAX;
+                                colh[p * 64 + lane] = col_ok ? a_h : -1;
+                                a_v = b_v; a_h = b_h;
+                                b_v = -FLT_MAX; b_h = -1;
+                                ++p;
+                                while (p < ph && UNI(s_h1[p]) <= UNI(s_h0[p])) {   // trailing empty bins
+                                    colv[p * 64 + lane] = -FLT_MAX;
+                                    colh[p * 64 + lane] = -1;
+                                    ++p;
+                                }
+                                he_p = p < ph ? UNI(s_h1[p]) : 0x7fffffff;
+                                hs_n = p + 1 < ph ? UNI(s_h0[p + 1]) : 0x7fffffff;
+                                he_n = p + 1 < ph ? UNI(s_h1[p + 1]) : 0;
+                            }
+                        }
+                    }
+                }
+                for (; p < ph; ++p) {                            // not reached for consistent tables
+                    colv[p * 64 + lane] = -FLT_MAX;
+                    colh[p * 64 + lane] = -1;
+                }
+            } else {
+                // RoIs shorter than the pooled height (bin_h < 1): a row can belong to several bins.  The
+                // window has fewer than ph rows: fetch them 8 at a time (independent loads -- one memory
+                // latency per batch instead of one per bin), then fold them into every bin they belong to;
+                // the per-bin accumulators live in the LDS column table.
+                for (int p = 0; p < ph; ++p) {
+                    colv[p * 64 + lane] = -FLT_MAX;
+                    colh[p * 64 + lane] = -1;
+                }
+                const int h_lo = UNI(s_h0[0]);
+                for (int h0 = h_lo; h0 < hi_u; h0 += 8) {
+                    float v[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i)
+                        v[i] = (col_ok && h0 + i < hi_u) ? colp[(h0 + i) * width] : -FLT_MAX;
+                    for (int p = 0; p < ph; ++p) {
+                        const int hs = UNI(s_h0[p]), he = UNI(s_h1[p]);
+                        if (he <= h0 || hs >= h0 + 8 || he <= hs) continue;
+                        float best = colv[p * 64 + lane];
+                        int bh = colh[p * 64 + lane];
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            const int h = h0 + i;
+                            if (h >= hs && h < he && v[i] > best) { best = v[i]; bh = h; }
+                        }
+                        colv[p * 64 + lane] = best;
+                        colh[p * 64 + lane] = bh;
+                    }
+                }
+            }
+#undef UNI
+            wave_lds_sync();
+            // ---- phase 2: bins from column maxima (w ascending; ties -> smaller row) ---------
+            const int pairs = cpw * bins;
+            for (int idx = lane; idx < pairs; idx += 64) {
+                const int cs = idx / bins;
+                const int bin = idx - cs * bins;
+                const int p = bin / pw;
+                const int q = bin - p * pw;
+                const int hs = s_h0[p], he = s_h1[p], ws = s_w0[q], we = s_w1[q];
+                const bool empty = (he <= hs) || (we <= ws);
+                float best = -FLT_MAX;
+                int bh = -1, bw = -1;
+                if (slabs > 1) {
+                    best = binv[bin];
+                    bh = binh[bin];
+                    bw = binw[bin];
+                }
+                const int a = max(ws, col0), e = min(we, col0 + 64);
+                const float *cv = colv + p * 64 + cs * wp - col0;
+                const int *ch = colh + p * 64 + cs * wp - col0;
+                for (int w = a; w < e; ++w) {
+                    const float v = cv[w];
+                    const int hh = ch[w];
+                    if (v > best || (v == best && hh >= 0 && (bh < 0 || hh < bh))) {
+                        best = v;
+                        bh = hh;
+                        bw = w;
+                    }
+                }
+                if (slabs > 1 && slab + 1 < slabs) {
+                    binv[bin] = best;
+                    binh[bin] = bh;
+                    binw[bin] = bw;
+                } else {
+                    const int cl = g * cpw + cs;
+                    if (cl < c_count) {
+                        const size_t o = o_base + (size_t)cl * bins + bin;
+                        const int po = ((r.img * channels) + c_begin + cl) * height * width;
+                        output[o] = empty ? 0.0f : best;
+                        if (argmax) argmax[o] = (empty || bh < 0) ? -1 : po + bh * width + bw;
+                    }
+                }
+            }
+            wave_lds_sync();
+        }
+    }
+}
+
 __global__ __launch_bounds__(kThreads) void roi_pool_bwd_kernel(
     const float *__restrict__ top_grad, const float *__restrict__ rois,
     const int *__restrict__ argmax, int num_rois, int batch, int channels, int height, int width,
@@ -160,14 +416,24 @@ int fi_roi_pool_forward(const float *features, const float *rois, int num_rois, 
                "features tensor too large for int32 argmax (reference limitation)");
     if (num_rois == 0) return FI_OK;
     FI_REQUIRE(features && rois && output, "null pointer");
-    int cpb = fi::ceil_div(channels, 8);
-    while (cpb > 8 && (long)num_rois * fi::ceil_div(channels, cpb) < 2048) cpb = fi::ceil_div(cpb, 2);
+    // 8 channels per workgroup: the largest RoIs (whole-map windows) set the critical path, so their
+    // channels are spread over many workgroups; narrow RoIs pack all 8 channels into one wavefront pass
+    const int cpb = 8;
     const int chunks = fi::ceil_div(channels, cpb);
+    FI_REQUIRE((long)num_rois * (chunks + 8) < 2147483647L, "grid too large");
     hipStream_t st = (hipStream_t)stream;
     fi::ProfScope prof(FI_K_ROIPOOL_FWD, st);
-    hipLaunchKernelGGL(roi_pool_fwd_kernel, dim3((unsigned)((long)num_rois * chunks)), dim3(kThreads),
-                       0, st, features, rois, num_rois, batch, channels, height, width, pooled_h,
-                       pooled_w, spatial_scale, cpb, chunks, output, argmax);
+    if (pooled_h > 28 || pooled_w > 28) {
+        hipLaunchKernelGGL(roi_pool_fwd_simple_kernel, dim3((unsigned)((long)num_rois * chunks)), dim3(kThreads),
+                           0, st, features, rois, num_rois, batch, channels, height, width, pooled_h,
+                           pooled_w, spatial_scale, cpb, chunks, output, argmax);
+    } else {
+        const size_t lds = roi_pool_wave_lds(pooled_h, pooled_w) * kWaves;     // <= 4 * (14 KB + 9.2 KB)
+        const long grid = (long)num_rois * fi::ceil_div(chunks, 8) * 8;
+        hipLaunchKernelGGL(roi_pool_fwd_kernel, dim3((unsigned)grid), dim3(kThreads),
+                           lds, st, features, rois, num_rois, batch, channels, height, width, pooled_h,
+                           pooled_w, spatial_scale, cpb, chunks, output, argmax);
+    }
     FI_HIP_CHECK(hipGetLastError());
     return FI_OK;
 }

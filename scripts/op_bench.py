@@ -159,9 +159,27 @@ def main():
 
     if "roipool" in ops:
         pix = torch.cat([ind.float().view(-1, 1), rois[:, [1, 0, 3, 2]] * 1024.0], 1).contiguous()
-        fn = RoIPoolFunction(7, 7, 0.25)
-        med, best = timeit(lambda: fn(image, pix), args.iters)
-        print(json.dumps({"op": "roi_pool_fwd", "shape": [N, C, 7, 7], "us_median": med * 1e6, "us_best": best * 1e6}))
+        rnd = lambda v: np.floor(np.abs(v) + 0.5) * np.sign(v)          # C round(): half away from zero
+        px = rois_np * 1024.0
+        rw = np.maximum(rnd(px[:, 3] * 0.25) - rnd(px[:, 1] * 0.25) + 1, 1)
+        rh = np.maximum(rnd(px[:, 2] * 0.25) - rnd(px[:, 0] * 0.25) + 1, 1)
+        for size in (7, 14):
+            fn = RoIPoolFunction(size, size, 0.25)
+            med, best = timeit(lambda: fn(image, pix), args.iters, kernel="roipool_fwd")
+            k = KERNEL_US[0] * 1e-6
+            # out + argmax written, every element of every RoI window read once per channel
+            b_alg = 4 * N * C * size * size * 2 + 4 * C * float((rw * rh).sum())
+            print(json.dumps({"op": "roi_pool_fwd", "shape": [N, C, size, size], "us_median": med * 1e6,
+                              "us_best": best * 1e6, "kernel_us": k * 1e6, "B_alg_MB": b_alg / 1e6,
+                              "GBps": b_alg / k / 1e9, "frac_hbm": b_alg / k / HBM_PEAK,
+                              "note": "window reads overlap between RoIs and the 134 MB map is Infinity-Cache "
+                                      "resident, so B_alg / t may exceed the HBM figure"}))
+            x = image.clone().requires_grad_(True)
+            out = fn(x, pix)
+            g = torch.randn_like(out)
+            medb, _ = timeit(lambda: torch.autograd.grad(out, x, g, retain_graph=True), args.iters, kernel="roipool_bwd")
+            print(json.dumps({"op": "roi_pool_bwd(+memset)", "shape": [N, C, size, size], "us_median": medb * 1e6,
+                              "kernel_us": KERNEL_US[0]}))
 
     if "nms" in ops:
         for bs in (1, 4):

@@ -36,6 +36,32 @@ def test_forward_exact(oracle, pool, scale):
     assert np.array_equal(fn.argmax.cpu().numpy(), exp_arg)
 
 
+@pytest.mark.parametrize("pool", [(7, 7), (14, 14), (28, 28), (30, 30)])
+def test_forward_exact_wide_windows_and_ties(oracle, pool):
+    """Windows wider than one 64-column slab, RoIs larger than the map, RoIs shorter than the pooled
+    height (bin_h < 1), and a map quantised to 5 values so that almost every bin has tied maxima:
+    the first maximum in (h, w) scan order must win everywhere.  (30x30 takes the simple kernel.)"""
+    from feature_intertwiner_amd.roi_pooling.functions.roi_pool import RoIPoolFunction
+    rs = np.random.RandomState(23)
+    B, C, H, W = 2, 11, 90, 200
+    feats = np.round(rs.standard_normal((B, C, H, W)) * 1.5).clip(-2, 2).astype(np.float32)
+    feats[1, 3] = -0.0
+    feats[1, 3, ::7, ::5] = 0.0                                    # signed zeros compare equal
+    n = 120
+    xy = rs.uniform(-30, 180, (n, 2))
+    wh = np.exp(rs.uniform(np.log(1), np.log(260), (n, 2)))
+    rois = np.concatenate([rs.randint(0, B, (n, 1)).astype(np.float64), xy, xy + wh], 1).astype(np.float32)
+    rois[0, 1:] = [-50, -50, 400, 300]                             # covers the whole map and more
+    rois[1, 1:] = [0, 0, 199, 89]                                  # exactly the map
+    rois[2, 1:] = [10, 85, 190, 88]                                # 4 rows high: bin_h < 1 for every pool here
+    rois[3, 1:] = [150, -3, 260, 2]                                # clipped on two sides
+    exp_out, exp_arg = oracle.roi_pool_forward(feats, rois, pool[0], pool[1], 1.0)
+    fn = RoIPoolFunction(pool[0], pool[1], 1.0)
+    got = fn(torch.from_numpy(feats).to(DEV), torch.from_numpy(rois).to(DEV))
+    assert np.array_equal(fn.argmax.cpu().numpy(), exp_arg)
+    assert np.array_equal(got.cpu().numpy().view(np.uint32), exp_out.view(np.uint32))
+
+
 def test_known_answers():
     """hand-computed cases (the reference ships no RoIPool tests -- parity unpinned there)."""
     from feature_intertwiner_amd.roi_pooling.functions.roi_pool import RoIPoolFunction
