@@ -313,6 +313,27 @@ def main():
                     "flops_model": "2*N*Cout*OH*OW*Cin*R*S per launch (fp32, exact MFMA)"}
         elif roof_roi is not None:
             roof = roof_roi
+        # ---- flop-weighted efficiency of the whole conv stack (every MFMA kernel instance) ----------
+        conv_stack = None
+        if flop_log:
+            tot_f = tot_ms = 0.0
+            per = {}
+            for name, v in kern.items():
+                if v["_key"] in flop_log:
+                    launches, flops = flop_log[v["_key"]]
+                    n, ms = _lib.prof_get(v["_key"])
+                    tot_f += flops
+                    tot_ms += ms
+                    per[name] = {"tflops": round(flops / (ms * 1e-3) / 1e12, 1), "ms_per_step": v["ms_per_step"],
+                                 "gflop_per_step": round(flops / args.steps / 1e9, 1)}
+            if tot_ms > 0:
+                ach = tot_f / (tot_ms * 1e-3) / 1e12
+                conv_stack = {"achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                              "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
+                              "tflop_per_step": round(tot_f / args.steps / 1e12, 3),
+                              "ms_per_step": round(tot_ms / args.steps, 2), "per_kernel": per,
+                              "note": "sum of algorithmic flops / sum of kernel time over every conv_fwd (forward + "
+                                      "data gradient) and conv_wgrad launch of the timed steps"}
         for v in kern.values():
             v.pop("_key", None)
         out = {
@@ -332,7 +353,7 @@ def main():
                        "conv_stack": "hand-written fp32 MFMA implicit-GEMM kernels (csrc/conv_igemm.hip); "
                                      "full-window convs and nn.Linear on the library GEMM"},
             "losses": {k: round(float(v), 5) for k, v in terms.items()},
-            "roofline": roof, "roofline_roialign": roof_roi, "kernels": kern,
+            "roofline": roof, "roofline_roialign": roof_roi, "conv_stack": conv_stack, "kernels": kern,
         }
         if world == 1 and not args.no_cpu_baseline:
             try:

@@ -342,3 +342,145 @@ class MetaLoss(object):
         if idx.size == 0:
             return np.float32(0)
         return self._pair(s_feat[:, idx].T.copy(), final_big[:, idx].T.copy())
+
+
+# ----------------------------------------------------------------------------
+# Target generation (lib/layers.py:224-433 generate_roi, :439-604 generate_target;
+# tools/box_utils.py:89-140 box_refinement, compute_iou).  The reference draws its random
+# sub-samples with torch.randperm / np.random.permutation; here the permutations are ARGUMENTS,
+# so that a test can replay the choice another implementation made and demand identical outputs.
+# ----------------------------------------------------------------------------
+IOU_EPS = np.float32(10e-20)     # tools/box_utils.py:4
+
+
+def compute_iou(boxes1, boxes2):
+    """tools/box_utils.py:112-140, fp32 in the reference's operation order; [N1, N2]."""
+    b1, b2 = _f32(boxes1)[:, None, :], _f32(boxes2)[None, :, :]
+    y1 = np.maximum(b1[..., 0], b2[..., 0])
+    x1 = np.maximum(b1[..., 1], b2[..., 1])
+    y2 = np.minimum(b1[..., 2], b2[..., 2])
+    x2 = np.minimum(b1[..., 3], b2[..., 3])
+    zero = np.float32(0)
+    inter = np.maximum(x2 - x1, zero) * np.maximum(y2 - y1, zero)
+    a1 = (b1[..., 2] - b1[..., 0]) * (b1[..., 3] - b1[..., 1])
+    a2 = (b2[..., 2] - b2[..., 0]) * (b2[..., 3] - b2[..., 1])
+    union = a1 + a2 - inter
+    return (inter / (union + IOU_EPS)).astype(np.float32)
+
+
+def box_refinement(box, gt_box):
+    """tools/box_utils.py:89-109."""
+    box, gt_box = _f32(box), _f32(gt_box)
+    half = np.float32(0.5)
+    h = box[:, 2] - box[:, 0]
+    w = box[:, 3] - box[:, 1]
+    cy = box[:, 0] + half * h
+    cx = box[:, 1] + half * w
+    gh = gt_box[:, 2] - gt_box[:, 0]
+    gw = gt_box[:, 3] - gt_box[:, 1]
+    gcy = gt_box[:, 0] + half * gh
+    gcx = gt_box[:, 1] + half * gw
+    with np.errstate(divide="ignore", invalid="ignore"):
+        return np.stack([(gcy - cy) / h, (gcx - cx) / w, np.log(gh / h), np.log(gw / w)], 1).astype(np.float32)
+
+
+def _split_crowd(gt_class_ids, gt_boxes, boxes_for_crowd):
+    """lib/layers.py:229-246 == :455-472: crowd rows (class < 0) are removed together with the zero
+    padding (only class > 0 rows are kept) and boxes overlapping a crowd by >= 0.001 are flagged."""
+    ids = np.asarray(gt_class_ids)
+    if (ids < 0).any():
+        crowd = gt_boxes[ids < 0]
+        keep = ids > 0
+        no_crowd = compute_iou(boxes_for_crowd, crowd).max(-1) < np.float32(0.001)
+        return keep, no_crowd
+    return np.ones(len(ids), bool), np.ones(len(boxes_for_crowd), bool)
+
+
+def generate_rpn_target(anchors, gt_class_ids, gt_boxes, cfg, perm_pos=None, perm_neg=None):
+    """generate_target, lib/layers.py:439-604 (one image).  Returns (match [A] in {1,-1,0},
+    bbox [TRAIN_ANCHORS_PER_IMAGE, 4] = refinements of the positive anchors in anchor order, NOT yet
+    divided by BBOX_STD_DEV -- prepare_rpn_target does that, :655).  perm_pos / perm_neg play the role
+    of np.random.permutation(len(ids)) at :521 / :543."""
+    anchors, gt_boxes = _f32(anchors), _f32(gt_boxes)
+    ids = np.asarray(gt_class_ids).astype(np.int64)
+    keep, no_crowd = _split_crowd(ids, gt_boxes, anchors)
+    had_crowd = (ids < 0).any()
+    if had_crowd:
+        gt_boxes, ids = gt_boxes[keep], ids[keep]
+    actual_gt_num = int((ids > 0).sum())
+    A = anchors.shape[0]
+    n_total = cfg.RPN.TRAIN_ANCHORS_PER_IMAGE
+    match = np.zeros(A, np.float32)
+    bbox = np.zeros((n_total, 4), np.float32)
+    overlaps = compute_iou(anchors, gt_boxes)                                     # [A, G]
+    iou_max, iou_argmax = overlaps.max(-1), overlaps.argmax(-1)
+    match[(iou_max < np.float32(cfg.RPN.TARGET_NEG_THRES)) & no_crowd] = -1       # :491
+    gt_iou_argmax = overlaps.argmax(0)                                            # :494
+    match[gt_iou_argmax[:actual_gt_num]] = 1                                      # :495 (valid GTs come first)
+    match[iou_max >= np.float32(cfg.RPN.TARGET_POS_THRES)] = 1                    # :498
+    pos_ids = np.nonzero(match == 1)[0]
+    pos_extra = len(pos_ids) - n_total // 2
+    if pos_extra > 0:                                                             # :516-527
+        match[pos_ids[np.asarray(perm_pos)[:pos_extra]]] = 0
+    neg_ids = np.nonzero(match == -1)[0]
+    neg_extra = len(neg_ids) - (n_total - int((match == 1).sum()))
+    if neg_extra > 0:                                                             # :541-546
+        match[neg_ids[np.asarray(perm_neg)[:neg_extra]]] = 0
+    pos_ids = np.nonzero(match == 1)[0]                                           # :597-604
+    bbox[:len(pos_ids)] = box_refinement(anchors[pos_ids], gt_boxes[iou_argmax[pos_ids]])
+    return match, bbox
+
+
+def generate_roi(cfg, proposals, gt_class_ids, gt_boxes, gt_masks, perm_pos, perm_neg, num_valid=None):
+    """generate_roi, lib/layers.py:224-376 (one image; boxes normalised).  Returns (rois, class_ids,
+    deltas, masks) -- positives first, then negatives -- or None where the reference returns None.
+    perm_pos / perm_neg stand for torch.randperm at :273 / :326.  num_valid: only the first num_valid
+    proposals are real (the build carries a count instead of zero rows, DESIGN quirk Q3; the reference
+    would let all-zero padding rows be drawn as negatives)."""
+    proposals, gt_boxes = _f32(proposals), _f32(gt_boxes)
+    ids = np.asarray(gt_class_ids).astype(np.int64)
+    gt_masks = _f32(gt_masks)
+    if num_valid is not None:
+        proposals = proposals[:num_valid]
+    keep, no_crowd = _split_crowd(ids, gt_boxes, proposals)
+    if (ids < 0).any():
+        ids, gt_boxes, gt_masks = ids[keep], gt_boxes[keep], gt_masks[keep]
+    overlaps = compute_iou(proposals, gt_boxes)
+    roi_iou_max = overlaps.max(-1) if overlaps.shape[1] else np.zeros(len(proposals), np.float32)
+    pos_bool = roi_iou_max >= np.float32(0.5)
+    neg_bool = (roi_iou_max < np.float32(0.5)) & no_crowd
+    R = cfg.ROIS.TRAIN_ROIS_PER_IMAGE
+    mh, mw = cfg.MRCNN.MASK_SHAPE
+    pos_cnt = neg_cnt = 0
+    if pos_bool.any():
+        pos_ind = np.nonzero(pos_bool)[0]
+        pos_cap = int(R * cfg.ROIS.ROI_POSITIVE_RATIO)
+        pos_ind = pos_ind[np.asarray(perm_pos)[:pos_cap]]
+        pos_cnt = len(pos_ind)
+        pos_rois = proposals[pos_ind]
+        assign = overlaps[pos_ind].argmax(1)
+        roi_gt = gt_boxes[assign]
+        cls = ids[assign].astype(np.int32)
+        deltas = box_refinement(pos_rois, roi_gt) / _f32(cfg.DATA.BBOX_STD_DEV)
+        boxes = pos_rois
+        if cfg.MRCNN.USE_MINI_MASK:                                               # :301-312
+            gh = roi_gt[:, 2:3] - roi_gt[:, 0:1]
+            gw = roi_gt[:, 3:4] - roi_gt[:, 1:2]
+            boxes = np.concatenate([(pos_rois[:, 0:1] - roi_gt[:, 0:1]) / gh, (pos_rois[:, 1:2] - roi_gt[:, 1:2]) / gw,
+                                    (pos_rois[:, 2:3] - roi_gt[:, 0:1]) / gh, (pos_rois[:, 3:4] - roi_gt[:, 1:2]) / gw], 1)
+        masks = crop_and_resize_forward(gt_masks[assign][:, None], boxes, np.arange(pos_cnt, dtype=np.int32), mh, mw)
+        masks = np.rint(masks[:, 0])                                              # torch.round: half to even
+    if neg_bool.any() and pos_cnt > 0:
+        neg_ind = np.nonzero(neg_bool)[0]
+        r = 1.0 / cfg.ROIS.ROI_POSITIVE_RATIO
+        neg_want = int(r * pos_cnt - pos_cnt)
+        neg_ind = neg_ind[np.asarray(perm_neg)[:neg_want]]
+        neg_cnt = len(neg_ind)
+        neg_rois = proposals[neg_ind]
+    if pos_cnt == 0:
+        return None          # (:359-371 can only be reached with pos_cnt > 0 because of the guard at :322)
+    if neg_cnt > 0:
+        return (np.concatenate([pos_rois, neg_rois], 0), np.concatenate([cls, np.zeros(neg_cnt, np.int32)]),
+                np.concatenate([deltas, np.zeros((neg_cnt, 4), np.float32)], 0),
+                np.concatenate([masks, np.zeros((neg_cnt, mh, mw), np.float32)], 0))
+    return pos_rois, cls, deltas, masks
