@@ -6,8 +6,7 @@
 arrays ([] when the intertwiner is off).  Module names and parameter shapes are the
 reference's (tests/golden/state_dict_keys.json pins them), so the authors' `.pth` files load
 by name; like the reference, loading is non-strict and also accepts a bare state dict (its
-"legacy / pretrain" case).  The Keras-h5 converter (tools/convert_from_keras.py) needs h5py,
-which this image does not have, and is out of scope.
+"legacy / pretrain" case).  The Keras weight importer is feature_intertwiner_amd/tools/convert_from_keras.py.
 """
 import numpy as np
 import torch

@@ -197,3 +197,65 @@ def ot_full_weights(seed, ch=1024):
     c_w = (rs.standard_normal((ch // 4, ch, 3)) * (1.0 / np.sqrt(3 * ch))).astype(np.float32)
     c_b = (rs.standard_normal((ch // 4,)) * 0.05).astype(np.float32)
     return g_w, g_b, c_w, c_b
+
+
+def keras_named_arrays(arch="resnet101", num_classes=81, seed=5, small=True):
+    """A Keras (matterport Mask R-CNN layout) weight dictionary: {'<layer>.<weight>:0': array} with conv
+    kernels HWIO, transposed-conv kernels HWOI, dense kernels (in, out) -- the input of
+    tools/convert_from_keras.py.  small=True divides every channel count by 16 (the name mapping and the
+    transposes are what is under test, not 250 MB of values).  Shared by oracle/gen_golden_keras.py and
+    tests/test_checkpoint_formats.py."""
+    rs = np.random.RandomState(seed)
+    d = 16 if small else 1
+    ch = lambda c: max(c // d, 1)
+    out = {}
+
+    def conv(name, kh, kw, cin, cout, bias=True):
+        out[name + ".kernel:0"] = rs.standard_normal((kh, kw, cin, cout)).astype(np.float32)
+        if bias:
+            out[name + ".bias:0"] = rs.standard_normal((cout,)).astype(np.float32)
+
+    def bn(name, c):
+        for w in ("gamma:0", "beta:0", "moving_mean:0", "moving_variance:0"):
+            out[name + "." + w] = rs.standard_normal((c,)).astype(np.float32)
+
+    conv("conv1", 7, 7, 3, ch(64))
+    bn("bn_conv1", ch(64))
+    blocks = {"resnet50": [3, 4, 6, 3], "resnet101": [3, 4, 23, 3]}[arch]
+    inpl = ch(64)
+    for stage, (nb, planes) in enumerate(zip(blocks, (64, 128, 256, 512)), start=2):
+        p = ch(planes)
+        for b in range(nb):
+            blk = "abcdefghijklmnopqrstuvwxyz"[b]
+            conv("res%d%s_branch2a" % (stage, blk), 1, 1, inpl, p)
+            bn("bn%d%s_branch2a" % (stage, blk), p)
+            conv("res%d%s_branch2b" % (stage, blk), 3, 3, p, p)
+            bn("bn%d%s_branch2b" % (stage, blk), p)
+            conv("res%d%s_branch2c" % (stage, blk), 1, 1, p, 4 * p)
+            bn("bn%d%s_branch2c" % (stage, blk), 4 * p)
+            if b == 0:
+                conv("res%d%s_branch1" % (stage, blk), 1, 1, inpl, 4 * p)
+                bn("bn%d%s_branch1" % (stage, blk), 4 * p)
+            inpl = 4 * p
+    f = ch(256)
+    for lvl, cin in zip((2, 3, 4, 5), (256, 512, 1024, 2048)):
+        conv("fpn_c%dp%d" % (lvl, lvl), 1, 1, ch(cin), f)
+        conv("fpn_p%d" % lvl, 3, 3, f, f)
+    conv("rpn_conv_shared", 3, 3, f, ch(512))
+    conv("rpn_class_raw", 1, 1, ch(512), 6)
+    conv("rpn_bbox_pred", 1, 1, ch(512), 12)
+    conv("mrcnn_class_conv1", 7, 7, f, ch(1024))
+    bn("mrcnn_class_bn1", ch(1024))
+    conv("mrcnn_class_conv2", 1, 1, ch(1024), ch(1024))
+    bn("mrcnn_class_bn2", ch(1024))
+    out["mrcnn_class_logits.kernel:0"] = rs.standard_normal((ch(1024), num_classes)).astype(np.float32)
+    out["mrcnn_class_logits.bias:0"] = rs.standard_normal((num_classes,)).astype(np.float32)
+    out["mrcnn_bbox_fc.kernel:0"] = rs.standard_normal((ch(1024), num_classes * 4)).astype(np.float32)
+    out["mrcnn_bbox_fc.bias:0"] = rs.standard_normal((num_classes * 4,)).astype(np.float32)
+    for i in range(1, 5):
+        conv("mrcnn_mask_conv%d" % i, 3, 3, f, f)
+        bn("mrcnn_mask_bn%d" % i, f)
+    out["mrcnn_mask_deconv.kernel:0"] = rs.standard_normal((2, 2, f, f)).astype(np.float32)     # (kh, kw, out, in)
+    out["mrcnn_mask_deconv.bias:0"] = rs.standard_normal((f,)).astype(np.float32)
+    conv("mrcnn_mask", 1, 1, f, num_classes)
+    return out

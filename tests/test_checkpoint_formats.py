@@ -1,0 +1,104 @@
+"""Weight / checkpoint formats.
+
+* Keras -> state-dict converter (tools/convert_from_keras.py:18-110) against goldens produced by running
+  the reference's own script (oracle/gen_golden_keras.py): same names, same shapes, same bytes.
+* The converted names are parameters/buffers of THIS package's modules (nothing falls on the floor).
+* GPU: save -> load -> the resumed model reproduces the next step's losses exactly (buffer included)."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import keras_named_arrays
+
+
+@pytest.mark.parametrize("arch", ["resnet50", "resnet101"])
+def test_keras_converter_equals_reference_script(golden_dir, arch):
+    from feature_intertwiner_amd.tools.convert_from_keras import convert
+    gold = json.load(open(os.path.join(golden_dir, "keras_convert.json")))[arch]
+    got = convert(keras_named_arrays(arch))
+    exp = {k: (tuple(shape), digest) for k, shape, digest in gold}
+    assert set(got) == set(exp)
+    for k, v in got.items():
+        assert tuple(v.shape) == exp[k][0], k
+        assert hashlib.sha256(v.numpy().astype(np.float32).tobytes()).hexdigest()[:16] == exp[k][1], k
+
+
+def test_keras_layouts_hwio_to_oihw():
+    from feature_intertwiner_amd.tools.convert_from_keras import convert, torch_module_name
+    k = np.arange(2 * 3 * 5 * 7, dtype=np.float32).reshape(2, 3, 5, 7)            # (kh, kw, in, out)
+    w = convert({"res3b_branch2b.kernel:0": k})["fpn.C3.1.conv2.weight"]
+    assert w.shape == (7, 5, 2, 3) and w[6, 4, 1, 2] == k[1, 2, 4, 6]
+    d = np.arange(12, dtype=np.float32).reshape(3, 4)                             # dense (in, out)
+    assert torch.equal(convert({"mrcnn_bbox_fc.kernel:0": d})["classifier.linear_bbox.weight"], torch.from_numpy(d.T.copy()))
+    t = np.arange(2 * 2 * 5 * 3, dtype=np.float32).reshape(2, 2, 5, 3)            # Conv2DTranspose (kh, kw, out, in)
+    assert convert({"mrcnn_mask_deconv.kernel:0": t})["mask.deconv.weight"].shape == (3, 5, 2, 2)   # torch: (in, out, kh, kw)
+    assert torch_module_name("res4w_branch2c") == "fpn.C4.22.conv3" and torch_module_name("bn5a_branch1") == "fpn.C5.0.downsample.1"
+    with pytest.raises(KeyError):
+        convert({"some_optimizer_slot.kernel:0": d})
+    assert len(convert({"some_optimizer_slot.kernel:0": d}, strict=False)) == 0
+
+
+def test_converted_names_exist_in_the_model(golden_dir):
+    """Every converted tensor name is a parameter or buffer of the (reference-named) modules."""
+    keys = json.load(open(os.path.join(golden_dir, "state_dict_keys.json")))["resnet101"]
+    have = set()
+    for prefix, mod in (("fpn", "fpn"), ("rpn", "rpn"), ("classifier", "classifier"), ("mask", "mask")):
+        have |= {prefix + "." + n for n, _ in keys[mod]}
+    from feature_intertwiner_amd.tools.convert_from_keras import convert
+    got = convert(keras_named_arrays("resnet101"))
+    missing = [k for k in got if k not in have]
+    assert not missing, missing[:5]
+    # and the converter covers the whole detector except what Keras does not have (BN batch counters, Dev, OT)
+    uncovered = [k for k in have if k not in got and not k.endswith("num_batches_tracked")]
+    assert not uncovered, uncovered[:5]
+
+
+@pytest.mark.gpu
+def test_resume_reproduces_the_next_step(tmp_path):
+    from feature_intertwiner_amd.checkpoint import load_model, save_model
+    from feature_intertwiner_amd.config import make_config
+    from feature_intertwiner_amd.model import MaskRCNN
+    from feature_intertwiner_amd.synthetic import SyntheticProposals, synthetic_batch
+    from feature_intertwiner_amd.workflow import compute_loss, set_optimizer, train_step
+    DEV = "cuda:0"
+    torch.manual_seed(3)
+    cfg = make_config("resnet50", 256, 2, 64, dev_switch=True, loss_choice="l2", buffer_size=1, loss_fac=50.0)
+    batch = synthetic_batch(2, 256, device=DEV)
+
+    def fresh():
+        m = MaskRCNN(cfg).to(DEV)
+        m.proposal_hook = SyntheticProposals(batch[2], 256, seed=7)
+        m.generator = torch.Generator(device=DEV).manual_seed(5)
+        return m
+    model = fresh()
+    opt = set_optimizer(model, cfg.TRAIN)
+    for _ in range(2):
+        train_step(model, opt, list(batch))
+    path = str(tmp_path / "ckpt.pth")
+    save_model(model, path, epoch=1, iter=2, loss_data=[1.0, 2.0])
+    hook_state = model.proposal_hook.gen.get_state()
+    gen_state = model.generator.get_state()
+    with torch.no_grad():
+        _, t_ref = compute_loss(model, list(batch))             # the next step's losses (also advances the buffer)
+
+    resumed = fresh()
+    ep, it, loss_data, missing, unexpected = load_model(resumed, path, map_location=DEV)
+    assert (ep, it, loss_data) == (1, 3, [1.0, 2.0]) and not missing and not unexpected
+    resumed.proposal_hook.gen.set_state(hook_state)
+    resumed.generator.set_state(gen_state)
+    with torch.no_grad():
+        _, t_new = compute_loss(resumed, list(batch))
+    for k in t_ref:
+        assert float(t_ref[k]) == float(t_new[k]), k           # same weights, same buffer, same kernels: identical
+    assert torch.equal(resumed.feature_buffer.buffer, model.feature_buffer.buffer)
+    assert float(t_ref["meta"]) > 0
+
+    # a checkpoint written with another BUFFER_SIZE: the history is re-initialised (tools/utils.py:379-384)
+    cfg3 = make_config("resnet50", 256, 2, 64, dev_switch=True, loss_choice="l2", buffer_size=3)
+    other = MaskRCNN(cfg3).to(DEV)
+    load_model(other, path, map_location=DEV)
+    assert other.feature_buffer.buffer.shape[0] == 3 and float(other.feature_buffer.buffer_cnt.sum()) == 0
