@@ -80,63 +80,48 @@ def sinkhorn_loss(x, y, epsilon_inv=1.0, L=5, C_form="cosine"):
     return loss
 
 
+def _generator(ch_x, ch_y, two_dim, upsample):
+    """G_net (lib/OT_module.py:24-41): maps the small-object feature towards the big-object one.
+    2-D: transposed 3x3 conv (stride 2 when the spatial size has to double) + BN + ReLU; 1-D: Conv1d k3 + ReLU."""
+    if not two_dim:
+        return nn.Sequential(Conv1d(ch_x, ch_y, kernel_size=3, padding=1, stride=1), nn.ReLU())
+    stride, out_pad = (2, 1) if upsample else (1, 0)
+    return nn.Sequential(nn.ConvTranspose2d(ch_x, ch_y, kernel_size=3, padding=1, stride=stride, output_padding=out_pad),
+                         nn.BatchNorm2d(ch_y), nn.ReLU())
+
+
+def _critic(ch_y, two_dim, one_dim_form):
+    """critic (lib/OT_module.py:43-65): the embedding whose channels are the OT samples."""
+    if two_dim:
+        layers = []
+        for cin, cout in ((ch_y, int(ch_y / 2)), (int(ch_y / 2), int(ch_y / 4))):
+            layers += [Conv2d(cin, cout, kernel_size=3, padding=1, stride=2), nn.BatchNorm2d(cout), nn.ReLU()]
+        return nn.Sequential(*layers)
+    if one_dim_form == 'conv':
+        return nn.Sequential(Conv1d(ch_y, int(ch_y / 4), kernel_size=3, padding=1, stride=1), nn.ReLU())
+    if one_dim_form == 'fc':
+        return nn.Linear(ch_y, int(ch_y / 8))
+    raise ValueError("DEV.OT_ONE_DIM_FORM must be 'conv' or 'fc', got %r" % (one_dim_form,))
+
+
 class OptTrans(nn.Module):
     def __init__(self, config, ch_x, spatial_x=-1, ch_y=-1, spatial_y=-1,
                  epsilon=1., L=5, remove_bias=False, C_form='cosine', no_bp_P_L=True, skip_critic=False):
         super(OptTrans, self).__init__()
-        self.config = config
-        self.epsilon = 1. / epsilon   # stored inverted, as the reference (:13)
-        self.L = L
-        self.remove_bias = remove_bias
-        self.no_bp_P_L = no_bp_P_L
-        self.C_form = C_form
-        self.skip_critic = skip_critic
-        self.two_dim = spatial_x > 1
         if not no_bp_P_L:
             raise NotImplementedError(
                 "OptTrans(no_bp_P_L=False) back-propagates through the Sinkhorn iterations; the HIP "
                 "kernel implements the detached-plan form the model uses (reference default)")
-
+        self.config = config
+        self.epsilon = 1. / epsilon   # stored inverted, as the reference (:13)
+        self.L, self.remove_bias, self.no_bp_P_L = L, remove_bias, no_bp_P_L
+        self.C_form, self.skip_critic = C_form, skip_critic
+        self.two_dim = spatial_x > 1
         ch_y = ch_x if ch_y == -1 else ch_y
         spatial_y = spatial_x if spatial_y == -1 else spatial_y
-
-        # G_net (:24-41)
-        if self.two_dim:
-            if spatial_x != spatial_y:
-                stride, out_pad = 2, 1   # upsample
-            else:
-                stride, out_pad = 1, 0   # keep spatial size
-            self.G_net = nn.Sequential(
-                nn.ConvTranspose2d(ch_x, ch_y, kernel_size=3, padding=1, stride=stride, output_padding=out_pad),
-                nn.BatchNorm2d(ch_y),
-                nn.ReLU(),
-            )
-        else:
-            self.G_net = nn.Sequential(
-                Conv1d(ch_x, ch_y, kernel_size=3, padding=1, stride=1),
-                nn.ReLU(),
-            )
-
-        # critic (:43-65)
-        if not self.skip_critic:
-            if self.two_dim:
-                self.critic = nn.Sequential(
-                    Conv2d(ch_y, int(ch_y / 2), kernel_size=3, padding=1, stride=2),
-                    nn.BatchNorm2d(int(ch_y / 2)),
-                    nn.ReLU(),
-                    Conv2d(int(ch_y / 2), int(ch_y / 4), kernel_size=3, padding=1, stride=2),
-                    nn.BatchNorm2d(int(ch_y / 4)),
-                    nn.ReLU(),
-                )
-            else:
-                form = getattr(getattr(config, "DEV", None), "OT_ONE_DIM_FORM", "conv")
-                if form == 'conv':
-                    self.critic = nn.Sequential(
-                        Conv1d(ch_y, int(ch_y / 4), kernel_size=3, padding=1, stride=1),
-                        nn.ReLU(),
-                    )
-                elif form == 'fc':
-                    self.critic = nn.Linear(ch_y, int(ch_y / 8))
+        self.G_net = _generator(ch_x, ch_y, self.two_dim, upsample=(spatial_x != spatial_y))
+        if not skip_critic:
+            self.critic = _critic(ch_y, self.two_dim, getattr(getattr(config, "DEV", None), "OT_ONE_DIM_FORM", "conv"))
 
     def forward(self, x, y):
         """x (small-object feature) [n, ch, 1] or [n, ch, h, w]; y (big-object feature, detached

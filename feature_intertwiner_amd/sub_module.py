@@ -52,18 +52,26 @@ def _bn(ch, eps=0.001, momentum=0.01):
     return nn.BatchNorm2d(ch, eps=eps, momentum=momentum)
 
 
+def _conv_bn(owner, index, cin, cout, kernel, stride=1, padding=0, eps=0.001, momentum=0.01):
+    """Register `conv<index>` / `bn<index>` on `owner` (the reference's parameter names, hence its state-dict
+    keys: lib/sub_module.py:90-98, 704-710, 757-768)."""
+    owner.add_module("conv%d" % index, Conv2d(cin, cout, kernel_size=kernel, stride=stride, padding=padding))
+    owner.add_module("bn%d" % index, nn.BatchNorm2d(cout, eps=eps, momentum=momentum))
+
+
 class Bottleneck(nn.Module):
+    """1x1 (strided) -> 3x3 -> 1x1 (x4 channels) with a projection shortcut where the shape changes
+    (lib/sub_module.py:84-128)."""
     expansion = 4
 
     def __init__(self, inplanes, planes, stride=1, downsample=None):
         super(Bottleneck, self).__init__()
-        self.conv1 = Conv2d(inplanes, planes, kernel_size=1, stride=stride)
-        self.bn1 = _bn(planes)
-        self.padding2 = SamePad2d(kernel_size=3, stride=1, folded=True)
-        self.conv2 = Conv2d(planes, planes, kernel_size=3, padding=1)
-        self.bn2 = _bn(planes)
-        self.conv3 = Conv2d(planes, planes * 4, kernel_size=1)
-        self.bn3 = _bn(planes * 4)
+        for index, (cin, cout, kernel, st, pad) in enumerate(((inplanes, planes, 1, stride, 0),
+                                                              (planes, planes, 3, 1, 1),
+                                                              (planes, planes * self.expansion, 1, 1, 0)), start=1):
+            if kernel == 3:
+                self.padding2 = SamePad2d(kernel_size=3, stride=1, folded=True)
+            _conv_bn(self, index, cin, cout, kernel, st, pad)
         self.relu = nn.ReLU(inplace=True)
         self.downsample = downsample
         self.stride = stride
@@ -79,40 +87,37 @@ class Bottleneck(nn.Module):
 
 
 class ResNet(nn.Module):
+    """Trunk C1..C5 (lib/sub_module.py:38-82).  One row per stage: (name, planes, stride of its first block);
+    block counts per architecture."""
+    DEPTHS = {"resnet50": (3, 4, 6, 3), "resnet101": (3, 4, 23, 3)}
+    STAGES = (("C2", 64, 1), ("C3", 128, 2), ("C4", 256, 2), ("C5", 512, 2))
+
     def __init__(self, architecture, stage5=False):
         super(ResNet, self).__init__()
-        assert architecture in ["resnet50", "resnet101"]
-        self.inplanes = 64
-        self.layers = [3, 4, {"resnet50": 6, "resnet101": 23}[architecture], 3]
-        self.block = Bottleneck
+        if architecture not in self.DEPTHS:
+            raise ValueError("architecture must be one of %s" % sorted(self.DEPTHS))
         self.stage5 = stage5
-        self.C1 = nn.Sequential(
-            Conv2d(3, 64, kernel_size=7, stride=2, padding=3),
-            _bn(64),
-            nn.ReLU(inplace=True),
-            SamePad2d(kernel_size=3, stride=2),
-            nn.MaxPool2d(kernel_size=3, stride=2),
-        )
-        self.C2 = self.make_layer(self.block, 64, self.layers[0])
-        self.C3 = self.make_layer(self.block, 128, self.layers[1], stride=2)
-        self.C4 = self.make_layer(self.block, 256, self.layers[2], stride=2)
-        self.C5 = self.make_layer(self.block, 512, self.layers[3], stride=2) if self.stage5 else None
+        self.block = Bottleneck
+        self.layers = list(self.DEPTHS[architecture])
+        self.inplanes = 64
+        self.C1 = nn.Sequential(Conv2d(3, 64, kernel_size=7, stride=2, padding=3), _bn(64), nn.ReLU(inplace=True),
+                                SamePad2d(kernel_size=3, stride=2), nn.MaxPool2d(kernel_size=3, stride=2))
+        for (name, planes, stride), depth in zip(self.STAGES, self.layers):
+            built = self.make_layer(Bottleneck, planes, depth, stride) if (name != "C5" or stage5) else None
+            setattr(self, name, built)
 
     def stages(self):
         return [self.C1, self.C2, self.C3, self.C4, self.C5]
 
     def make_layer(self, block, planes, blocks, stride=1):
-        downsample = None
-        if stride != 1 or self.inplanes != planes * block.expansion:
-            downsample = nn.Sequential(
-                Conv2d(self.inplanes, planes * block.expansion, kernel_size=1, stride=stride),
-                _bn(planes * block.expansion),
-            )
-        layers = [block(self.inplanes, planes, stride, downsample)]
-        self.inplanes = planes * block.expansion
-        for _ in range(1, blocks):
-            layers.append(block(self.inplanes, planes))
-        return nn.Sequential(*layers)
+        out_ch = planes * block.expansion
+        project = None
+        if stride != 1 or self.inplanes != out_ch:
+            project = nn.Sequential(Conv2d(self.inplanes, out_ch, kernel_size=1, stride=stride), _bn(out_ch))
+        chain = [block(self.inplanes, planes, stride, project)]
+        chain += [block(out_ch, planes) for _ in range(blocks - 1)]
+        self.inplanes = out_ch
+        return nn.Sequential(*chain)
 
 
 class FPN(nn.Module):
@@ -389,16 +394,13 @@ class Dev(nn.Module):
 
 
 class Classifier(nn.Module):
+    """Box head (lib/sub_module.py:698-747): full-window 7x7 conv, 1x1 conv, class and box linears."""
+
     def __init__(self, depth, num_classes, pool_size, config):
         super(Classifier, self).__init__()
-        self.depth = depth
-        self.pool_size = pool_size
-        self.num_classes = num_classes
-        self.config = config
-        self.conv1 = Conv2d(depth, 1024, kernel_size=pool_size, stride=1)
-        self.bn1 = _bn(1024)
-        self.conv2 = Conv2d(1024, 1024, kernel_size=1, stride=1)
-        self.bn2 = _bn(1024)
+        self.depth, self.pool_size, self.num_classes, self.config = depth, pool_size, num_classes, config
+        _conv_bn(self, 1, depth, 1024, pool_size)
+        _conv_bn(self, 2, 1024, 1024, 1)
         self.relu = nn.ReLU(inplace=True)
         self.linear_class = nn.Linear(1024, num_classes)
         self.softmax = nn.Softmax(dim=1)
@@ -426,19 +428,14 @@ class Classifier(nn.Module):
 
 
 class Mask(nn.Module):
+    """Mask head (lib/sub_module.py:750-787): four 3x3 conv+BN+ReLU, 2x2 stride-2 deconv, 1x1 conv to classes."""
+
     def __init__(self, depth, num_classes):
         super(Mask, self).__init__()
-        self.depth = depth
-        self.num_classes = num_classes
+        self.depth, self.num_classes = depth, num_classes
         self.padding = SamePad2d(kernel_size=3, stride=1, folded=True)
-        self.conv1 = Conv2d(depth, 256, kernel_size=3, stride=1, padding=1)
-        self.bn1 = nn.BatchNorm2d(256, eps=0.001)
-        self.conv2 = Conv2d(256, 256, kernel_size=3, stride=1, padding=1)
-        self.bn2 = nn.BatchNorm2d(256, eps=0.001)
-        self.conv3 = Conv2d(256, 256, kernel_size=3, stride=1, padding=1)
-        self.bn3 = nn.BatchNorm2d(256, eps=0.001)
-        self.conv4 = Conv2d(256, 256, kernel_size=3, stride=1, padding=1)
-        self.bn4 = nn.BatchNorm2d(256, eps=0.001)
+        for index in (1, 2, 3, 4):
+            _conv_bn(self, index, depth if index == 1 else 256, 256, 3, 1, 1, eps=0.001, momentum=0.1)
         self.deconv = ConvTranspose2x2(256, 256, kernel_size=2, stride=2)
         self.conv5 = Conv2d(256, num_classes, kernel_size=1, stride=1)
         self.sigmoid = nn.Sigmoid()
