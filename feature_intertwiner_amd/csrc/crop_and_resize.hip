@@ -133,8 +133,14 @@ __global__ __launch_bounds__(kThreads) void crop_fwd_kernel(
     __shared__ Tap s_tx[kMaxCrop];
 
     const int tid = threadIdx.x;
-    const int box = blockIdx.x / chunks;
-    const int chunk = blockIdx.x - box * chunks;
+    // XCD-aware, chunk-major order (see pick_fwd_chunks): block b runs on XCD b % 8; each XCD works through
+    // its channel chunks one after the other, each for ALL boxes, so that the few planes of one chunk stay
+    // resident in that XCD's 4 MB L2 while every RoI that overlaps them is gathered.
+    const int xcd = blockIdx.x & 7;
+    const int seq = blockIdx.x >> 3;
+    const int chunk = (seq / num_boxes) * 8 + xcd;
+    const int box = seq % num_boxes;
+    if (chunk >= chunks) return;
     const int c_begin = chunk * chan_per_block;
     const int c_count = min(chan_per_block, depth - c_begin);
     const int total = c_count * bins;
@@ -550,6 +556,15 @@ void pick_chunks(int num_boxes, int depth, int *chan_per_block, int *chunks)
     *chunks = fi::ceil_div(depth, cpb);
 }
 
+// forward kernel: 16 channels per workgroup, chunk-major per XCD (measured at 512 x 256 x 7 x 7 on one
+// 256^2 map: 4 / 8 / 16 / 32 channels -> 50.6 / 33.2 / 30.8 / 34.3 us; the box-major order of round 1: 34.4)
+void pick_fwd_chunks(int depth, int *chan_per_block, int *chunks)
+{
+    const int cpb = 16;
+    *chan_per_block = cpb;
+    *chunks = fi::ceil_div(depth, cpb);
+}
+
 template <typename K, typename... Args>
 int launch_sized(int crop_h, int crop_w, K k77, K k1414, K k2828, K kgen, dim3 grid,
                  hipStream_t st, Args... args)
@@ -588,8 +603,8 @@ int forward_impl(const LevelSet &ls, const float *boxes, const int32_t *box_ind,
 {
     if (num_boxes == 0) return FI_OK;
     int cpb, chunks;
-    pick_chunks(num_boxes, depth, &cpb, &chunks);
-    const long nblk = (long)num_boxes * chunks;
+    pick_fwd_chunks(depth, &cpb, &chunks);
+    const long nblk = (long)num_boxes * fi::ceil_div(chunks, 8) * 8;
     FI_REQUIRE(nblk < 2147483647L, "grid too large");
     fi::ProfScope prof(FI_K_CROP_FWD_7X7 + size_class(crop_h, crop_w), st);
     return launch_sized(crop_h, crop_w, crop_fwd_kernel<7, 7>, crop_fwd_kernel<14, 14>,
