@@ -56,13 +56,16 @@ SIGNATURES = {
     "fi_class_mean_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p,
                                        c_void_p]),
     "fi_conv2d_forward": (c_int, [c_void_p] * 6 + [c_int] * 16 + [c_void_p]),
-    "fi_bn_act_backward": (c_int, [c_void_p] * 6 + [c_int] * 4 + [c_void_p] * 4 + [c_int, c_void_p]),
-    "fi_conv2d_weight_grad": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 12 + [c_void_p, c_void_p]),
+    "fi_bn_act_backward": (c_int, [c_void_p] * 6 + [c_int] * 4 + [c_void_p] * 5 + [c_int, c_int, c_void_p]),
+    "fi_conv2d_weight_grad": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 12 + [c_void_p, c_int, c_void_p]),
+    "fi_weight_transpose_batch": (c_int, [c_void_p, c_int, ctypes.c_long, c_void_p]),
     "fi_prof_enable": (None, [c_int]),
     "fi_prof_reset": (None, []),
     "fi_prof_get": (c_int, [c_int, _ip, ctypes.POINTER(c_float)]),
     "fi_prof_kernel_name": (c_char_p, [c_int]),
 }
+
+OUTPUTS_ZEROED = 1      # FI_OUTPUTS_ZEROED
 
 KERNEL_IDS = {
     "crop_fwd_7x7": 0, "crop_fwd_14x14": 1, "crop_fwd_28x28": 2, "crop_fwd_generic": 3,
@@ -148,6 +151,52 @@ def require_cuda(*tensors):
         if t is not None and not t.is_cuda:
             raise FiError("feature_intertwiner_amd operators run on the GPU only "
                           "(got a %s tensor); there is no CPU fallback" % t.device)
+
+
+_CONST = {}
+
+
+def const_tensor(values, device, dtype=torch.float32):
+    """Small constant (python numbers / numpy array) as a device tensor, created ONCE per (values, device):
+    torch.tensor(list, device=gpu) inside the step is a pageable host-to-device copy, i.e. a full stream
+    synchronisation every time."""
+    try:
+        key = (tuple(float(v) for v in values), str(device), dtype)
+    except TypeError:
+        key = ((float(values),), str(device), dtype)
+        values = [values]
+    t = _CONST.get(key)
+    if t is None:
+        t = torch.tensor([float(v) for v in values], dtype=dtype, device=device)
+        _CONST[key] = t
+    return t
+
+
+def async_host_read(t):
+    """Start copying a small device tensor to pinned host memory on a side stream and return a function
+    that waits for JUST that copy: the caller keeps enqueueing independent work on the current stream in
+    between, so the device does not drain while the host waits for a count."""
+    dev = t.device
+    side = _SIDE.get(dev)
+    if side is None:
+        side = _SIDE[dev] = torch.cuda.Stream(device=dev)
+    host = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+    ready = torch.cuda.Event()
+    ready.record(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        side.wait_event(ready)
+        host.copy_(t, non_blocking=True)
+        done = torch.cuda.Event()
+        done.record(side)
+    t.record_stream(side)
+
+    def wait():
+        done.synchronize()
+        return host
+    return wait
+
+
+_SIDE = {}
 
 
 def prof_enable(on=True):

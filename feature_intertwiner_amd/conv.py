@@ -43,6 +43,15 @@ def _log_flops(kind, cout, R, S, flops, pixels=None, cin=None):
         e[1] += flops
 
 
+def _dense(w):
+    """A weight as the kernels can read it: NCHW-contiguous or channels-last-contiguous, no copy if it
+    already is one of the two (parameters with Cin % 16 == 0 are stored channels-last, see
+    prepare_step)."""
+    if w.is_contiguous() or (w.dim() == 4 and w.is_contiguous(memory_format=torch.channels_last)):
+        return w
+    return w.contiguous()
+
+
 def _conv_fwd(x, w, b, stride, padding, relu=False, scale=None, residual=None, out_hw=None,
               out_channels_last=False, w_tap_major=False, flip_taps=False):
     """w is [Cout, Cin, R, S].  When Cin % 16 == 0 the kernel's tap-major fast path is used: the
@@ -61,7 +70,9 @@ def _conv_fwd(x, w, b, stride, padding, relu=False, scale=None, residual=None, o
         if Cin % 16 == 0 and R * S <= 64:
             layout = 1
             if R * S > 1:
-                w = w.permute(0, 2, 3, 1).contiguous()
+                w = w.permute(0, 2, 3, 1).contiguous()       # free for a channels-last parameter
+        else:
+            w = w.contiguous()
     OH = (H + 2 * padding[0] - R) // stride[0] + 1
     OW = (W + 2 * padding[1] - S) // stride[1] + 1
     if out_hw is not None:
@@ -84,7 +95,7 @@ class _Conv2dFn(torch.autograd.Function):
     def forward(ctx, x, w, b, stride, padding):
         _lib.require_cuda(x, w)
         x = x.contiguous().float()
-        w = w.contiguous().float()
+        w = _dense(w.float())
         bc = b.contiguous().float() if b is not None else None
         ctx.save_for_backward(x, w)
         ctx.conf = (tuple(stride), tuple(padding), b is not None)
@@ -140,10 +151,12 @@ def _strided_dgrad(dz, w, in_hw, stride, padding):
     return dx
 
 
-def _conv_backward(ctx_needs, x, w, dz, stride, padding, want_db=False):
+def _conv_backward(ctx_needs, x, w, dz, stride, padding, want_db=False, add_to_dx=None):
     """dX and dW of z = conv(x, w) given dz (shared by the plain and the fused functions).
     want_db: also return sum(dz) over images and pixels (the bias gradient), accumulated by the
-    weight-gradient kernel from the dY tiles it stages anyway."""
+    weight-gradient kernel from the dY tiles it stages anyway.
+    add_to_dx: a tensor shaped like x that is added to dX inside the data-gradient kernel's epilogue
+    (the shortcut gradient of a bottleneck, instead of a separate add pass)."""
     L = _lib.load()
     N, Cin, H, W = x.shape
     Cout, _, R, S = w.shape
@@ -151,16 +164,22 @@ def _conv_backward(ctx_needs, x, w, dz, stride, padding, want_db=False):
     if ctx_needs[0]:
         if stride == (1, 1):
             if Cout % 16 == 0 and R * S <= 64:
-                # transposed weight straight into the kernel's tap-major layout [Cin, R, S, Cout] (one copy);
-                # the tap flip is done by the kernel's weight indexing (weight_layout 2)
-                wt = w.permute(1, 2, 3, 0).contiguous()
+                # transposed weight in the kernel's tap-major layout [Cin, R, S, Cout]: re-laid-out for all
+                # layers by one launch per step (prepare_step); otherwise one copy here.  The tap flip is
+                # done by the kernel's weight indexing (weight_layout 2)
+                wt = _cached_wt(w)
+                if wt is None:
+                    wt = w.permute(1, 2, 3, 0).contiguous()
                 dx = _conv_fwd(dz, wt, None, (1, 1), (R - 1 - padding[0], S - 1 - padding[1]), w_tap_major=True,
-                               flip_taps=True)
+                               flip_taps=True, residual=add_to_dx)
+                add_to_dx = None
             else:
                 wt = w.flip(2, 3).transpose(0, 1).contiguous()          # [Cin, Cout, R, S]
                 dx = _conv_fwd(dz, wt, None, (1, 1), (R - 1 - padding[0], S - 1 - padding[1]))
         else:
             dx = _strided_dgrad(dz, w, (H, W), stride, padding)
+        if add_to_dx is not None:
+            dx = dx + add_to_dx
     if ctx_needs[1]:
         # tap-major dW ([Cout,R,S,Cin]): 128 channels of one tap per column tile, or -- same-size stride-1
         # layers with Cin == 64 (the C2 stage) -- 64 channels of two taps (mirrors wgrad_same_size())
@@ -168,8 +187,11 @@ def _conv_backward(ctx_needs, x, w, dz, stride, padding, want_db=False):
                 x.numel() * 4 < 0x7fffff00 and dz.numel() * 4 < 0x7fffff00 and
                 x.data_ptr() % 16 == 0 and dz.data_ptr() % 16 == 0)
         hwc = 1 if (Cin % 128 == 0 or (Cin == 64 and same)) else 0
-        dw = torch.empty((Cout, R, S, Cin) if (hwc and R * S > 1) else (Cout, Cin, R, S), device=x.device,
-                         dtype=torch.float32)
+        shape = (Cout, R, S, Cin) if (hwc and R * S > 1) else (Cout, Cin, R, S)
+        # pre-zeroed slice of the step's gradient arena (one fill per step instead of one per layer)
+        dw = _arena_take(("dw", w.data_ptr()), Cout * Cin * R * S)
+        flags = _lib.OUTPUTS_ZEROED if (dw is not None and not want_db) else 0
+        dw = dw.view(shape) if dw is not None else torch.empty(shape, device=x.device, dtype=torch.float32)
         _log_flops("wgrad", Cout, R, S, 2 * N * Cout * dz.shape[2] * dz.shape[3] * Cin * R * S,
                    N * dz.shape[2] * dz.shape[3], Cin)
         if want_db:
@@ -177,12 +199,123 @@ def _conv_backward(ctx_needs, x, w, dz, stride, padding, want_db=False):
         with torch.cuda.device(x.device):
             _lib.check(L.fi_conv2d_weight_grad(_lib.ptr(x), _lib.ptr(dz), _lib.ptr(dw), N, Cin, H, W, Cout,
                                                R, S, stride[0], stride[1], padding[0], padding[1], hwc,
-                                               _lib.ptr(db), _lib.current_stream()), "fi_conv2d_weight_grad")
+                                               _lib.ptr(db), flags, _lib.current_stream()), "fi_conv2d_weight_grad")
         if hwc and R * S > 1:
             dw = dw.permute(0, 3, 1, 2)
     elif want_db:
         db = dz.sum((0, 2, 3))
     return (dx, dw, db) if want_db else (dx, dw)
+
+
+# ---- per-step derived state: W^T for the data gradient, zeroed gradient arena ---------------------
+_WT = {}           # weight data_ptr -> (W^T [Cin,R,S,Cout], weight version it was made from)
+_ARENA = {"buf": None, "slots": {}, "used": set()}
+_PLAN = weakref.WeakKeyDictionary()      # model -> cached layer lists / descriptor table
+
+
+def _cached_wt(w):
+    e = _WT.get(w.data_ptr())
+    if e is not None and e[1] == w._version and e[0].shape == (w.shape[1], w.shape[2], w.shape[3], w.shape[0]):
+        return e[0]
+    return None
+
+
+def _arena_take(key, numel):
+    """The zeroed slot reserved for `key` in this step's arena, once per step (a layer applied several
+    times per step -- RPN on 5 levels -- must not hand the same buffer to autograd twice)."""
+    slot = _ARENA["slots"].get(key)
+    if slot is None or _ARENA["buf"] is None or key in _ARENA["used"] or slot[1] != numel:
+        return None
+    _ARENA["used"].add(key)
+    return _ARENA["buf"][slot[0]:slot[0] + numel]
+
+
+def invalidate_step_state():
+    _WT.clear()
+    _ARENA["buf"] = None
+    _ARENA["slots"] = {}
+    _ARENA["used"] = set()
+
+
+def prepare_step(model):
+    """See _prepare_step; the caller's grad mode decides whether a gradient arena is laid out."""
+    _prepare_step(model, torch.is_grad_enabled())
+
+
+@torch.no_grad()
+def _prepare_step(model, grad_on):
+    """Once per forward pass of `model` (MaskRCNN.forward calls it):
+      * eval-BN folds for every (conv, bn) pair (refresh_bn_folds);
+      * convolution weights with Cin % 16 == 0 are STORED channels-last ([Cout][R][S][Cin] in memory, same
+        logical shape and state-dict contents), which is the forward kernel's layout and the layout the
+        weight-gradient kernel writes -- no per-call re-layout, no layout-contract clone in AccumulateGrad;
+      * W^T [Cin][R][S][Cout] of every stride-1 layer for the data-gradient kernel, all layers in ONE launch;
+      * when gradients are enabled: one zero-filled arena with a slot per weight gradient and per BatchNorm's
+        (d shift, d gamma, d conv-bias) sums, so that the ~300 per-layer fills of a backward pass become one.
+    """
+    refresh_bn_folds()
+    dev = next(model.parameters()).device
+    if dev.type != "cuda":
+        return
+    plan = _PLAN.get(model)
+    ptrs = tuple(p.data_ptr() for p in model.parameters())
+    if plan is None or plan["ptrs"] != ptrs:
+        convs = [m for m in model.modules() if isinstance(m, Conv2d)]
+        for m in convs:
+            w = m.weight
+            if w.shape[1] % 16 == 0 and w.shape[2] * w.shape[3] > 1 and \
+                    not w.is_contiguous(memory_format=torch.channels_last):
+                w.data = w.data.contiguous(memory_format=torch.channels_last)
+        tr = [m for m in convs if tuple(m.stride) == (1, 1) and m.weight.shape[0] % 16 == 0 and
+              m.weight.shape[1] % 16 == 0 and m.weight.shape[2] * m.weight.shape[3] <= 64 and m.weight.requires_grad]
+        import numpy as np
+        desc = np.zeros(len(tr), dtype=np.dtype([("src", "<u8"), ("dst", "<u8"), ("rows", "<i4"), ("cols", "<i4"),
+                                                 ("taps", "<i4"), ("pad", "<i4"), ("tile_base", "<i8")]))
+        wts, base = [], 0
+        for i, m in enumerate(tr):
+            co, ci, r, s_ = m.weight.shape
+            wt = torch.empty((ci, r, s_, co), device=dev, dtype=torch.float32)
+            wts.append(wt)
+            desc[i] = (m.weight.data_ptr(), wt.data_ptr(), co, ci, r * s_, 0, base)
+            base += r * s_ * ((co + 31) // 32) * ((ci + 31) // 32)
+        table = torch.from_numpy(desc.view(np.uint8).copy()).to(dev) if len(tr) else None
+        slots, off = {}, 0
+        for m in convs:
+            if m.weight.requires_grad:
+                slots[("dw", m.weight.data_ptr())] = (off, m.weight.numel())
+                off += (m.weight.numel() + 3) // 4 * 4
+        for bn in [m for m in model.modules() if isinstance(m, nn.BatchNorm2d)]:
+            slots[("bn", bn.weight.data_ptr())] = (off, 3 * bn.num_features)
+            off += (3 * bn.num_features + 3) // 4 * 4
+        plan = {"ptrs": tuple(p.data_ptr() for p in model.parameters()), "tr": tr, "wts": wts, "table": table,
+                "tiles": base, "slots": slots, "arena_floats": off, "versions": None}
+        _PLAN[model] = plan
+    versions = tuple(m.weight._version for m in plan["tr"])
+    if plan["table"] is not None and (plan["versions"] != versions or not all(
+            _cached_wt(m.weight) is not None for m in plan["tr"][:1])):
+        L = _lib.load()
+        with torch.cuda.device(dev):
+            _lib.check(L.fi_weight_transpose_batch(_lib.ptr(plan["table"]), len(plan["tr"]), plan["tiles"],
+                                                   _lib.current_stream()), "fi_weight_transpose_batch")
+        for m, wt in zip(plan["tr"], plan["wts"]):
+            _WT[m.weight.data_ptr()] = (wt, m.weight._version)
+        plan["versions"] = versions
+    if grad_on and plan["arena_floats"]:
+        _ARENA["buf"] = torch.zeros(plan["arena_floats"], device=dev, dtype=torch.float32)
+        _ARENA["slots"] = plan["slots"]
+        _ARENA["used"] = set()
+    else:
+        _ARENA["buf"] = None
+
+
+class GradBox(object):
+    """Hands a gradient from one autograd node to another: a bottleneck's last convolution leaves the
+    gradient of its identity shortcut here, and the block's first convolution -- whose data gradient flows
+    into the same tensor -- adds it inside its kernel epilogue (see Bottleneck.forward)."""
+    __slots__ = ("value",)
+
+    def __init__(self):
+        self.value = None
 
 
 class _ConvBnActFn(torch.autograd.Function):
@@ -191,10 +324,10 @@ class _ConvBnActFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, b, gamma, beta, mean, var, eps, residual, relu, stride, padding, out_cl=False,
-                fold=None):
+                fold=None, res_grad_to=None, dx_add_from=None):
         _lib.require_cuda(x, w)
         x = x.contiguous().float()
-        w = w.contiguous().float()
+        w = _dense(w.float())
         if fold is not None:              # precomputed for the whole model by refresh_bn_folds()
             scale, shift = fold
         else:
@@ -207,6 +340,7 @@ class _ConvBnActFn(torch.autograd.Function):
         y = _conv_fwd(x, w, shift.contiguous(), stride, padding, relu=relu, scale=scale.contiguous(), residual=res,
                       out_channels_last=out_cl)
         ctx.out_cl = bool(out_cl)
+        ctx.res_grad_to, ctx.dx_add_from = res_grad_to, dx_add_from
         ctx.save_for_backward(x, w, y, scale, gamma, beta, res)
         ctx.conf = (tuple(stride), tuple(padding), b is not None, bool(relu), residual is not None, eps, mean, var)
         return y
@@ -222,20 +356,31 @@ class _ConvBnActFn(torch.autograd.Function):
         N, C, OH, OW = y.shape
         dz = torch.empty(y.shape, device=y.device, dtype=torch.float32)
         g_res = torch.empty_like(y) if (has_res and ctx.needs_input_grad[8]) else None
-        sums = torch.empty((2, C), device=y.device, dtype=torch.float32)      # adjacent: ONE zero-fill inside the call
-        dshift = sums[0]
-        dgamma = sums[1] if ctx.needs_input_grad[3] else None
+        # (d shift, d gamma, d conv-bias) adjacent: a slot of the step's zeroed arena, or ONE fill in the call
+        sums = _arena_take(("bn", gamma.data_ptr()), 3 * C)
+        flags = _lib.OUTPUTS_ZEROED if sums is not None else 0
+        if sums is None:
+            sums = torch.empty(3 * C, device=y.device, dtype=torch.float32)
+        dshift = sums[:C]
+        dgamma = sums[C:2 * C] if ctx.needs_input_grad[3] else None
+        want_db = has_bias and ctx.needs_input_grad[2]
+        db = sums[2 * C:] if want_db else None
         with torch.cuda.device(y.device):
             _lib.check(L.fi_bn_act_backward(_lib.ptr(dy), _lib.ptr(y), _lib.ptr(scale), _lib.ptr(gamma),
                                             _lib.ptr(beta), _lib.ptr(res), N, C, OH * OW, 1 if relu else 0,
                                             _lib.ptr(dz),
-                                            _lib.ptr(g_res), _lib.ptr(dshift), _lib.ptr(dgamma),
-                                            1 if ctx.out_cl else 0,
+                                            _lib.ptr(g_res), _lib.ptr(dshift), _lib.ptr(dgamma), _lib.ptr(db),
+                                            1 if ctx.out_cl else 0, flags,
                                             _lib.current_stream()), "fi_bn_act_backward")
-        dx, dw = _conv_backward(ctx.needs_input_grad, x, w, dz, stride, padding)
-        db = dshift * scale if (has_bias and ctx.needs_input_grad[2]) else None
+        if g_res is not None and ctx.res_grad_to is not None:
+            ctx.res_grad_to.value = g_res           # picked up by the block's first convolution
+            g_res = None
+        add = None
+        if ctx.dx_add_from is not None:
+            add, ctx.dx_add_from.value = ctx.dx_add_from.value, None
+        dx, dw = _conv_backward(ctx.needs_input_grad, x, w, dz, stride, padding, add_to_dx=add)
         dbeta = dshift if ctx.needs_input_grad[4] else None
-        return dx, dw, db, dgamma, dbeta, None, None, None, g_res, None, None, None, None, None
+        return dx, dw, db, dgamma, dbeta, None, None, None, g_res, None, None, None, None, None, None, None
 
 
 class _ConvBiasActFn(torch.autograd.Function):
@@ -248,7 +393,7 @@ class _ConvBiasActFn(torch.autograd.Function):
     def forward(ctx, x, w, b, stride, padding):
         _lib.require_cuda(x, w)
         x = x.contiguous().float()
-        w = w.contiguous().float()
+        w = _dense(w.float())
         bc = b.contiguous().float() if b is not None else None
         _log_shape(x, w, stride, padding)
         y = _conv_fwd(x, w, bc, stride, padding, relu=True)
@@ -264,14 +409,24 @@ class _ConvBiasActFn(torch.autograd.Function):
         dy = dy.contiguous().float()
         N, C, OH, OW = y.shape
         dz = torch.empty_like(y)
-        ones = torch.ones(C, device=y.device, dtype=torch.float32)
+        ones = _ones(C, y.device)
         dshift = torch.empty(C, device=y.device, dtype=torch.float32)
         with torch.cuda.device(y.device):
             _lib.check(L.fi_bn_act_backward(_lib.ptr(dy), _lib.ptr(y), _lib.ptr(ones), None, None, None, N, C, OH * OW, 1,
-                                            _lib.ptr(dz), None, _lib.ptr(dshift), None, 0,
+                                            _lib.ptr(dz), None, _lib.ptr(dshift), None, None, 0, 0,
                                             _lib.current_stream()), "fi_bn_act_backward")
         dx, dw = _conv_backward(ctx.needs_input_grad, x, w, dz, stride, padding)
         return dx, dw, (dshift if (has_bias and ctx.needs_input_grad[2]) else None), None, None
+
+
+_ONES = {}
+
+
+def _ones(n, device):
+    t = _ONES.get((n, str(device)))
+    if t is None:
+        t = _ONES[(n, str(device))] = torch.ones(n, device=device, dtype=torch.float32)
+    return t
 
 
 def conv_bias_relu(x, weight, bias=None, stride=(1, 1), padding=(0, 0)):
@@ -321,6 +476,11 @@ def refresh_bn_folds():
 
 
 def invalidate_bn_folds(module=None):
+    invalidate_step_state()
+    _invalidate_bn_folds(module)
+
+
+def _invalidate_bn_folds(module=None):
     """Forget cached (scale, shift) folds -- of `module`'s BatchNorms, or of every BatchNorm seen
     so far.  Needed after writes that bypass the tensor version counters the cache is keyed on
     (`.data.copy_`, dist.broadcast(t.data), load_state_dict under torch.no_grad is counted, but
@@ -331,7 +491,8 @@ def invalidate_bn_folds(module=None):
             m._fi_fold = None
 
 
-def conv_bn_act(x, conv, bn, relu=True, residual=None, channels_last_out=False):
+def conv_bn_act(x, conv, bn, relu=True, residual=None, channels_last_out=False, res_grad_to=None,
+                dx_add_from=None):
     """act(bn(conv(x)) [+ residual]) for an eval-mode BatchNorm2d (the reference always evaluates
     BN with running statistics, lib/model.py:265-267).  Falls back to separate ops for a BN in
     training mode or a full-window (GEMM) convolution.  channels_last_out: return the result in
@@ -339,6 +500,7 @@ def conv_bn_act(x, conv, bn, relu=True, residual=None, channels_last_out=False):
     R, S = conv.weight.shape[2], conv.weight.shape[3]
     gemm_path = ((x.shape[2], x.shape[3]) == (R, S) and tuple(conv.padding) == (0, 0)) or x.shape[2] * x.shape[3] == 1
     if bn.training or gemm_path or not bn.track_running_stats:
+        assert res_grad_to is None and dx_add_from is None, "gradient hand-off needs the fused conv+BN path"
         if gemm_path and not bn.training and bn.track_running_stats:
             # [N,C,1,1]: MIOpen's spatial inference BN takes ~0.4 ms on 8 MB here; the affine form is ~10 us
             scale = bn.weight * torch.rsqrt(bn.running_var + bn.eps)
@@ -353,7 +515,7 @@ def conv_bn_act(x, conv, bn, relu=True, residual=None, channels_last_out=False):
     _FOLD_PAIRS[bn] = conv
     y = _ConvBnActFn.apply(x, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                            bn.eps, residual, relu, tuple(conv.stride), tuple(conv.padding), out_cl,
-                           _cached_fold(conv, bn))
+                           _cached_fold(conv, bn), res_grad_to, dx_add_from)
     return y.contiguous(memory_format=torch.channels_last) if (channels_last_out and not out_cl) else y
 
 

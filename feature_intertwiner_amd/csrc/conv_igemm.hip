@@ -1113,7 +1113,8 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const float *__restrict
                                                          int HW, int relu,
                                                          float *__restrict__ dz, float *__restrict__ g_out,
                                                          float *__restrict__ dshift,
-                                                         float *__restrict__ dgamma, int imgs_per_block)
+                                                         float *__restrict__ dgamma, float *__restrict__ dbias,
+                                                         int imgs_per_block)
 {
     __shared__ float s_a[4], s_b[4];
     const int c = blockIdx.x;
@@ -1172,6 +1173,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const float *__restrict
         const float a = (s_a[0] + s_a[1]) + (s_a[2] + s_a[3]);
         const float b = (s_b[0] + s_b[1]) + (s_b[2] + s_b[3]);
         atomicAdd(dshift + c, a);
+        if (dbias) atomicAdd(dbias + c, a * sc);       // gradient of a conv bias folded into the shift
         if (dgamma) {
             const float ga = gamma[c];
             atomicAdd(dgamma + c, ga != 0.0f ? b / ga : 0.0f);
@@ -1190,7 +1192,8 @@ __global__ __launch_bounds__(256) void bn_act_bwd_cl_kernel(const float *__restr
                                                             const float *__restrict__ beta, int P, int C,
                                                             int HW, int relu, float *__restrict__ dz,
                                                             float *__restrict__ dshift,
-                                                            float *__restrict__ dgamma, int tiles_per_block)
+                                                            float *__restrict__ dgamma, float *__restrict__ dbias,
+                                                            int tiles_per_block)
 {
     __shared__ float s_t[64][65];
     __shared__ float s_a[4][64], s_b[4][64];
@@ -1241,9 +1244,50 @@ __global__ __launch_bounds__(256) void bn_act_bwd_cl_kernel(const float *__restr
         const float a = (s_a[0][lane] + s_a[1][lane]) + (s_a[2][lane] + s_a[3][lane]);
         const float b = (s_b[0][lane] + s_b[1][lane]) + (s_b[2][lane] + s_b[3][lane]);
         atomicAdd(dshift + c, a);
+        if (dbias) atomicAdd(dbias + c, a * scale[c]);
         if (dgamma) {
             const float ga = gamma[c];
             atomicAdd(dgamma + c, ga != 0.0f ? b / ga : 0.0f);
+        }
+    }
+}
+
+// ---- batched weight transposes ---------------------------------------------------------------------
+// The data-gradient kernel wants W^T in the tap-major layout [Cin][R][S][Cout]; parameters live as
+// [Cout][R][S][Cin].  All layers are re-laid-out by ONE launch per step (fi_weight_transpose_batch) instead
+// of one strided copy per layer and step (~150 launches of 9 us).  A workgroup transposes one 32 x 32 tile
+// of one tap of one layer through LDS; the layer is found by bisection of the tile prefix table.
+__global__ __launch_bounds__(256) void weight_transpose_kernel(const FiTransposeDesc *__restrict__ descs, int n,
+                                                               long total_tiles)
+{
+    __shared__ float s_t[32][33];
+    for (long t = blockIdx.x; t < total_tiles; t += gridDim.x) {
+        int lo = 0, hi = n - 1;
+        while (lo < hi) {                              // last descriptor with tile_base <= t
+            const int mid = (lo + hi + 1) >> 1;
+            if (descs[mid].tile_base <= t) lo = mid; else hi = mid - 1;
+        }
+        const FiTransposeDesc d = descs[lo];
+        const int tr = (d.rows + 31) >> 5, tc = (d.cols + 31) >> 5;
+        long local = t - d.tile_base;
+        const int tap = (int)(local / ((long)tr * tc));
+        local -= (long)tap * tr * tc;
+        const int r0 = (int)(local / tc) * 32, c0 = (int)(local % tc) * 32;
+        const float *__restrict__ src = (const float *)d.src + (size_t)tap * d.cols;           // [rows][taps][cols]
+        float *__restrict__ dst = (float *)d.dst + (size_t)tap * d.rows;                       // [cols][taps][rows]
+        const size_t src_pitch = (size_t)d.taps * d.cols, dst_pitch = (size_t)d.taps * d.rows;
+        const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int r = r0 + ty + 8 * k, c = c0 + tx;
+            if (r < d.rows && c < d.cols) s_t[ty + 8 * k][tx] = src[(size_t)r * src_pitch + c];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = c0 + ty + 8 * k, r = r0 + tx;
+            if (r < d.rows && c < d.cols) dst[(size_t)c * dst_pitch + r] = s_t[tx][ty + 8 * k];
         }
     }
 }
@@ -1289,19 +1333,22 @@ int fi_conv2d_forward(const float *x, const float *weight, const float *bias, co
 
 int fi_bn_act_backward(const float *dy, const float *y, const float *scale, const float *gamma,
                        const float *beta, const float *residual, int N, int C, int HW, int relu,
-                       float *dz, float *g_out, float *dshift, float *dgamma, int layout,
-                       fi_stream_t stream)
+                       float *dz, float *g_out, float *dshift, float *dgamma, float *dbias, int layout,
+                       int flags, fi_stream_t stream)
 {
     FI_REQUIRE(N >= 1 && C >= 1 && HW >= 1, "sizes must be positive");
     FI_REQUIRE(dy && y && scale && dz && dshift, "null pointer");
     FI_REQUIRE(!dgamma || gamma, "dgamma needs gamma");
     FI_REQUIRE(layout == 0 || layout == 1, "layout: 0 = dy,y [N][C][HW], 1 = dy,y [N][HW][C]");
     hipStream_t st = (hipStream_t)stream;
-    if (dgamma == dshift + C) {                       // adjacent buffers: one fill
-        FI_HIP_CHECK(hipMemsetAsync(dshift, 0, sizeof(float) * 2 * C, st));
-    } else {
-        FI_HIP_CHECK(hipMemsetAsync(dshift, 0, sizeof(float) * C, st));
-        if (dgamma) FI_HIP_CHECK(hipMemsetAsync(dgamma, 0, sizeof(float) * C, st));
+    if (!(flags & FI_OUTPUTS_ZEROED)) {
+        if (dgamma == dshift + C && (!dbias || dbias == dshift + 2 * C)) {      // adjacent buffers: one fill
+            FI_HIP_CHECK(hipMemsetAsync(dshift, 0, sizeof(float) * (dbias ? 3 : 2) * C, st));
+        } else {
+            FI_HIP_CHECK(hipMemsetAsync(dshift, 0, sizeof(float) * C, st));
+            if (dgamma) FI_HIP_CHECK(hipMemsetAsync(dgamma, 0, sizeof(float) * C, st));
+            if (dbias) FI_HIP_CHECK(hipMemsetAsync(dbias, 0, sizeof(float) * C, st));
+        }
     }
     if (layout == 1) {
         FI_REQUIRE(residual == nullptr && g_out == nullptr, "channels-last backward has no fused residual");
@@ -1313,7 +1360,7 @@ int fi_bn_act_backward(const float *dy, const float *y, const float *scale, cons
         if (tpb < 1) tpb = 1;
         fi::ProfScope prof(FI_K_BN_ACT_BWD, st);
         hipLaunchKernelGGL(bn_act_bwd_cl_kernel, dim3(cblk, fi::ceil_div(tiles, tpb)), dim3(256), 0, st, dy, y,
-                           scale, gamma, beta, P, C, HW, relu, dz, dshift, dgamma, tpb);
+                           scale, gamma, beta, P, C, HW, relu, dz, dshift, dgamma, dbias, tpb);
         FI_HIP_CHECK(hipGetLastError());
         return FI_OK;
     }
@@ -1325,14 +1372,14 @@ int fi_bn_act_backward(const float *dy, const float *y, const float *scale, cons
     chunks = fi::ceil_div(N, ipb);
     fi::ProfScope prof(FI_K_BN_ACT_BWD, st);
     hipLaunchKernelGGL(bn_act_bwd_kernel, dim3(C, chunks), dim3(256), 0, st, dy, y, scale, gamma, beta, residual,
-                       N, C, HW, relu, dz, g_out, dshift, dgamma, ipb);
+                       N, C, HW, relu, dz, g_out, dshift, dgamma, dbias, ipb);
     FI_HIP_CHECK(hipGetLastError());
     return FI_OK;
 }
 
 int fi_conv2d_weight_grad(const float *x, const float *dy, float *dweight, int N, int Cin, int H,
                           int W, int Cout, int R, int S, int stride_h, int stride_w, int pad_h,
-                          int pad_w, int weight_layout, float *dbias, fi_stream_t stream)
+                          int pad_w, int weight_layout, float *dbias, int flags, fi_stream_t stream)
 {
     ConvGeom g;
     int rc = make_geom(g, N, Cin, H, W, Cout, R, S, stride_h, stride_w, pad_h, pad_w);
@@ -1346,8 +1393,10 @@ int fi_conv2d_weight_grad(const float *x, const float *dy, float *dweight, int N
     FI_REQUIRE(hwc || weight_layout == 0,
                "weight_layout 1 needs Cin % 128 == 0, or Cin == 64 on a same-size stride-1 layer");
     hipStream_t st = (hipStream_t)stream;
-    FI_HIP_CHECK(hipMemsetAsync(dweight, 0, sizeof(float) * (size_t)Cout * g.K, st));
-    if (dbias) FI_HIP_CHECK(hipMemsetAsync(dbias, 0, sizeof(float) * (size_t)Cout, st));
+    if (!(flags & FI_OUTPUTS_ZEROED)) {
+        FI_HIP_CHECK(hipMemsetAsync(dweight, 0, sizeof(float) * (size_t)Cout * g.K, st));
+        if (dbias) FI_HIP_CHECK(hipMemsetAsync(dbias, 0, sizeof(float) * (size_t)Cout, st));
+    }
     // 64-row tiles for narrow layers, and when 128-row tiles x the admissible splits (>= 512 pixels each)
     // would fill less than 3/4 of the resident slots (C4/C5 1x1 layers at batch 4)
     const long max_splits0 = (g.P + 511) / 512;
@@ -1370,6 +1419,18 @@ int fi_conv2d_weight_grad(const float *x, const float *dy, float *dweight, int N
         launch_wgrad<64>(g, x, dy, dweight, splits, pps, hwc, dbias, st);
     else
         launch_wgrad<128>(g, x, dy, dweight, splits, pps, hwc, dbias, st);
+    FI_HIP_CHECK(hipGetLastError());
+    return FI_OK;
+}
+
+int fi_weight_transpose_batch(const FiTransposeDesc *descs_dev, int n, long total_tiles, fi_stream_t stream)
+{
+    FI_REQUIRE(n >= 0 && total_tiles >= 0, "bad sizes");
+    if (n == 0 || total_tiles == 0) return FI_OK;
+    FI_REQUIRE(descs_dev != nullptr, "null descriptor table");
+    const long grid = total_tiles < 65536 ? total_tiles : 65536;
+    hipLaunchKernelGGL(weight_transpose_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, descs_dev, n,
+                       total_tiles);
     FI_HIP_CHECK(hipGetLastError());
     return FI_OK;
 }

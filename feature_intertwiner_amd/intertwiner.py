@@ -71,8 +71,8 @@ def roi_level(rois, image_area, base=224.0):
     [2, 5].  rois [..., 4] normalised (y1, x1, y2, x2)."""
     h = rois[..., 2] - rois[..., 0]
     w = rois[..., 3] - rois[..., 1]
-    area = torch.tensor(float(image_area), device=rois.device, dtype=torch.float32)
-    ln2 = torch.log(torch.tensor(2.0, device=rois.device))
+    area = _lib.const_tensor([float(image_area)], rois.device)[0]
+    ln2 = torch.log(_lib.const_tensor([2.0], rois.device)[0])
     lvl = 4 + torch.log(torch.sqrt(h * w) / (base / torch.sqrt(area))) / ln2
     lvl = torch.nan_to_num(lvl.round(), nan=2.0, posinf=5.0, neginf=2.0)
     return lvl.clamp(2, 5).to(torch.int32)

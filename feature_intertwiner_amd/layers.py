@@ -13,6 +13,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
+from ._lib import const_tensor
 from .nms.pth_nms import nms_sorted
 from .roi_align.crop_and_resize import CropAndResizeFunction
 
@@ -110,7 +111,7 @@ def proposal_layer(inputs, proposal_count, nms_threshold, priors, config, propos
     object-like proposals among the random-weight RPN output; it must keep scores sorted.
     """
     scores = inputs[0][:, :, 1]
-    deltas = inputs[1] * torch.as_tensor(config.DATA.BBOX_STD_DEV, device=scores.device).view(1, 1, 4)
+    deltas = inputs[1] * const_tensor(config.DATA.BBOX_STD_DEV, scores.device).view(1, 1, 4)
     anchors = priors.to(scores.device)
     pre_nms_limit = min(config.RPN.PRE_NMS_LIMIT, anchors.size(0))
     scores, order = torch.topk(scores, pre_nms_limit, dim=1, sorted=True)
@@ -126,7 +127,7 @@ def proposal_layer(inputs, proposal_count, nms_threshold, priors, config, propos
     keep = keep[:, :proposal_count]
     valid = torch.arange(keep.size(1), device=keep.device).unsqueeze(0) < num.unsqueeze(1)
     boxes_keep = torch.gather(boxes, 1, keep.unsqueeze(2).expand(-1, -1, 4)) * valid.unsqueeze(2).float()
-    norm = torch.tensor([height, width, height, width], device=boxes.device)
+    norm = const_tensor([height, width, height, width], boxes.device)
     return boxes_keep / norm, num
 
 
@@ -151,11 +152,11 @@ def detection_layer(rois, probs, deltas, windows, config, feature=None):
     max_det = int(config.TEST.DET_MAX_INSTANCES)
     class_scores, class_ids = torch.max(probs, dim=1)
     idx = torch.arange(class_ids.size(0), device=probs.device)
-    std = torch.as_tensor(config.DATA.BBOX_STD_DEV, device=probs.device, dtype=probs.dtype).view(1, 4)
+    std = const_tensor(config.DATA.BBOX_STD_DEV, probs.device).view(1, 4)
     deltas_specific = deltas[idx, class_ids] * std
     refined = apply_box_deltas(rois.reshape(1, -1, 4), deltas_specific.unsqueeze(0)).view(bs, N, 4)
     h, w = float(config.DATA.IMAGE_SHAPE[0]), float(config.DATA.IMAGE_SHAPE[1])
-    refined = refined * torch.tensor([h, w, h, w], device=probs.device)
+    refined = refined * const_tensor([h, w, h, w], probs.device)
     win = windows.to(refined.dtype).view(bs, 1, 4)
     refined = torch.stack([torch.maximum(torch.minimum(refined[..., 0], win[..., 2]), win[..., 0]),
                            torch.maximum(torch.minimum(refined[..., 1], win[..., 3]), win[..., 1]),
@@ -173,7 +174,7 @@ def detection_layer(rois, probs, deltas, windows, config, feature=None):
     ok_s, cls_s = g(ok), g(class_ids)
     box_s = torch.gather(refined, 1, order.unsqueeze(2).expand(-1, -1, 4))
     shift = torch.where(ok_s, cls_s.to(box_s.dtype) * _CLASS_STRIDE, torch.zeros_like(key))
-    dummy = torch.tensor([0.0, 0.0, 1.0, 1.0], device=probs.device)     # class-0 slot: no real box lives there
+    dummy = const_tensor([0.0, 0.0, 1.0, 1.0], probs.device)     # class-0 slot: no real box lives there
     nms_in = torch.where(ok_s.unsqueeze(2), box_s, dummy.expand_as(box_s)).clone()
     nms_in[..., 1] += shift
     nms_in[..., 3] += shift
@@ -226,14 +227,17 @@ def prepare_rpn_target(anchors, gt_class_ids, gt_boxes, config, generator=None):
     A = anchors.size(0)
     valid_gt = gt_class_ids > 0
     crowd = gt_class_ids < 0
-    overlaps = bbox_overlaps(anchors.unsqueeze(0), gt_boxes)                 # [b, A, G]
-    ov_gt = torch.where(valid_gt.unsqueeze(1), overlaps, torch.zeros_like(overlaps))
-    no_crowd = torch.where(crowd.unsqueeze(1), overlaps, torch.zeros_like(overlaps)).amax(2) < 0.001
-    iou_max, iou_argmax = ov_gt.max(dim=2)
+    # IoU as [b, G, A]: the reduction over the 261 888 anchors (each GT's best anchor) then runs along the
+    # contiguous axis, and the per-anchor max over <= 100 GTs is an elementwise sweep (the [b, A, G] form
+    # spent 0.9 ms in one strided argmax)
+    overlaps = bbox_overlaps(gt_boxes, anchors.unsqueeze(0))                 # [b, G, A]
+    ov_gt = torch.where(valid_gt.unsqueeze(2), overlaps, torch.zeros_like(overlaps))
+    no_crowd = torch.where(crowd.unsqueeze(2), overlaps, torch.zeros_like(overlaps)).amax(1) < 0.001
+    iou_max, iou_argmax = ov_gt.max(dim=1)                                    # [b, A]
     match = torch.zeros(b, A, device=gt_boxes.device)
     match = torch.where((iou_max < config.RPN.TARGET_NEG_THRES) & no_crowd, -torch.ones_like(match), match)
     # every valid GT claims its best anchor (:495-497)
-    gt_best = ov_gt.argmax(dim=1)                                             # [b, G]
+    gt_best = ov_gt.argmax(dim=2)                                             # [b, G]
     claim = torch.zeros(b, A, device=gt_boxes.device, dtype=torch.int32)
     claim.scatter_add_(1, gt_best, valid_gt.to(torch.int32))      # padded GTs add 0
     claim = claim > 0
@@ -247,7 +251,7 @@ def prepare_rpn_target(anchors, gt_class_ids, gt_boxes, config, generator=None):
     match = pos.float() - neg.float()
     gt_for_anchor = torch.gather(gt_boxes, 1, iou_argmax.unsqueeze(2).expand(-1, -1, 4))
     deltas = box_refinement(anchors.unsqueeze(0).expand(b, -1, -1), gt_for_anchor)
-    deltas = deltas / torch.as_tensor(config.DATA.BBOX_STD_DEV, device=deltas.device)
+    deltas = deltas / const_tensor(config.DATA.BBOX_STD_DEV, deltas.device)
     deltas = torch.where(pos.unsqueeze(2), deltas, torch.zeros_like(deltas))
     return match, deltas
 
@@ -304,7 +308,7 @@ def prepare_det_target(proposals, num_proposals, gt_class_ids, gt_boxes, gt_mask
     roi_gt_boxes = torch.gather(gt_boxes, 1, roi_assign.unsqueeze(2).expand(-1, -1, 4))
     cls = torch.gather(gt_class_ids, 1, roi_assign)
     target_class_ids = torch.where(is_pos, cls, torch.zeros_like(cls)).to(torch.int32)
-    deltas = box_refinement(rois, roi_gt_boxes) / torch.as_tensor(config.DATA.BBOX_STD_DEV, device=dev)
+    deltas = box_refinement(rois, roi_gt_boxes) / const_tensor(config.DATA.BBOX_STD_DEV, dev)
     target_deltas = torch.where(is_pos.unsqueeze(2), deltas, torch.zeros_like(deltas))
 
     # mask targets: crop the GT mini-mask with the RoI expressed in mini-mask space (:301-322)

@@ -6,7 +6,8 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from .conv import refresh_bn_folds
+from ._lib import const_tensor
+from .conv import prepare_step
 from .intertwiner import FeatureBuffer, meta_loss
 from .layers import (compute_mrcnn_bbox_loss, compute_mrcnn_class_loss, compute_mrcnn_mask_loss_unshuffled,
                      compute_rpn_bbox_loss, compute_rpn_class_loss, detection_layer, generate_pyramid_priors,
@@ -80,7 +81,7 @@ class MaskRCNN(nn.Module):
             return self._inference(images, input[1])
         gt_class_ids, gt_boxes, gt_masks = input[1], input[2], input[3]
         self.eval()   # the reference always runs BN (and everything else) in eval mode
-        refresh_bn_folds()   # all eval-BN (scale, shift) pairs in a handful of launches
+        prepare_step(self)   # BN folds, weight layouts and the zeroed gradient arena: a handful of launches
         proposal_cnt = cfg.RPN.POST_NMS_ROIS_INFERENCE   # also Q1
 
         p2, p3, p4, p5, p6, fpn_ot_loss = self.fpn(images, mode=mode)
@@ -93,7 +94,7 @@ class MaskRCNN(nn.Module):
             proposals, num_prop = proposal_layer([rpn_probs, rpn_bbox], proposal_cnt, cfg.RPN.NMS_THRESHOLD,
                                                  self.priors, cfg, self.proposal_hook)
             h, w = float(cfg.DATA.IMAGE_SHAPE[0]), float(cfg.DATA.IMAGE_SHAPE[1])
-            scale = torch.tensor([h, w, h, w], device=images.device)
+            scale = const_tensor([h, w, h, w], images.device)
             target_rpn_match, target_rpn_deltas = prepare_rpn_target(self.priors, gt_class_ids, gt_boxes, cfg,
                                                                      self.generator)
             rois, target_class_ids, target_deltas, target_mask = prepare_det_target(
@@ -144,7 +145,7 @@ class MaskRCNN(nn.Module):
         cfg = self.config
         bs = images.size(0)
         self.eval()
-        refresh_bn_folds()
+        prepare_step(self)
         p2, p3, p4, p5, p6, _ = self.fpn(images, mode='inference')
         mrcnn_maps = [p2, p3, p4, p5]
         outs = [self.rpn(p) for p in (p2, p3, p4, p5, p6)]
@@ -158,7 +159,7 @@ class MaskRCNN(nn.Module):
         windows = meta if meta.size(1) == 4 else meta[:, 4:8]
         detections = detection_layer(proposals, mrcnn_class, mrcnn_bbox, windows, cfg)
         h, w = float(cfg.DATA.IMAGE_SHAPE[0]), float(cfg.DATA.IMAGE_SHAPE[1])
-        scale = torch.tensor([h, w, h, w], device=images.device)
+        scale = const_tensor([h, w, h, w], images.device)
         _, pooled_mask, _ = self.dev_roi(mrcnn_maps, detections[:, :, :4] / scale)
         mrcnn_mask = self.mask(pooled_mask)
         mrcnn_mask = mrcnn_mask.view(bs, -1, mrcnn_mask.size(1), mrcnn_mask.size(2), mrcnn_mask.size(3))

@@ -15,7 +15,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .conv import Conv2d, ConvTranspose2x2, conv_bias_relu, conv_bn_act
+from . import _lib
+from .conv import Conv2d, ConvTranspose2x2, GradBox, conv_bias_relu, conv_bn_act
 from .intertwiner import class_mean, roi_level
 from .roi_align.crop_and_resize import CropAndResizeFunction, pyramid_crop_and_resize
 from .roi_pooling.functions.roi_pool import RoIPoolFunction
@@ -52,6 +53,12 @@ def _bn(ch, eps=0.001, momentum=0.01):
     return nn.BatchNorm2d(ch, eps=eps, momentum=momentum)
 
 
+def _fused_path(x, *bns):
+    """conv_bn_act takes its one-launch path for these layers (eval-mode BN with running statistics, a
+    real spatial extent)."""
+    return x.is_cuda and x.shape[2] * x.shape[3] > 1 and all((not b.training) and b.track_running_stats for b in bns)
+
+
 def _conv_bn(owner, index, cin, cout, kernel, stride=1, padding=0, eps=0.001, momentum=0.01):
     """Register `conv<index>` / `bn<index>` on `owner` (the reference's parameter names, hence its state-dict
     keys: lib/sub_module.py:90-98, 704-710, 757-768)."""
@@ -78,6 +85,15 @@ class Bottleneck(nn.Module):
 
     def forward(self, x):
         # conv + eval-BN (+ shortcut) + ReLU are one kernel launch each (conv.conv_bn_act)
+        if self.downsample is None and _fused_path(x, self.bn1, self.bn3) and x.requires_grad and torch.is_grad_enabled():
+            # identity shortcut: x receives two gradients, conv1's data gradient and the shortcut's.  The
+            # shortcut gradient (produced by conv3's backward, which always runs first) is handed to
+            # conv1's backward and added inside its data-gradient kernel, instead of a separate pass over
+            # two block-sized tensors (33 blocks in ResNet-101).
+            box = GradBox()
+            out = conv_bn_act(x, self.conv1, self.bn1, relu=True, dx_add_from=box)
+            out = conv_bn_act(out, self.conv2, self.bn2, relu=True)
+            return conv_bn_act(out, self.conv3, self.bn3, relu=True, residual=x, res_grad_to=box)
         out = conv_bn_act(x, self.conv1, self.bn1, relu=True)
         out = conv_bn_act(out, self.conv2, self.bn2, relu=True)
         residual = x
@@ -305,6 +321,15 @@ class Dev(nn.Module):
             raise NotImplementedError("only DEV.STRUCTURE='beta' executes in the reference (SURVEY Q9)")
 
         train_phase = roi_cls_gt is not None
+        # The only data-dependent SHAPES of the stage are how many RoIs sit on levels 2..4 ('small' rows fed
+        # to feat_extract) and how many 'big' boxes each level sees.  All of them come back in ONE small
+        # read; the copy runs on a side stream and is awaited only after the make-up convolutions (which do
+        # not depend on the RoIs) have been enqueued, so the device keeps working while the host waits.
+        # (The reference synchronises per level: nonzero / .any() at lib/sub_module.py:456, 475, 483, 541.)
+        lv = torch.arange(2, 6, device=level.device, dtype=level.dtype)
+        per_level = (level.unsqueeze(0) == lv.unsqueeze(1)).sum(1)                 # [n2, n3, n4, n5]
+        counts_ready = _lib.async_host_read(per_level) if level.is_cuda else (lambda: per_level)
+
         # make-up layer on every level, then ONE launch per crop size over all levels
         def make_up(i, m):
             seq = self.upsample[i if cfg.DEV.MULTI_UPSAMPLER else 0]
@@ -314,30 +339,31 @@ class Dev(nn.Module):
                 return conv_bn_act(m, seq[0], seq[1], relu=True, channels_last_out=(self.roi_type == 'roi_align'))
             return seq(m)
         up_maps = [make_up(i, m) for i, m in enumerate(x)]
+        n2, n3, n4, n5 = (int(v) for v in counts_ready().tolist())
         pooled = self._crop(up_maps, boxes, box_ind, level, self.pool_size)
         mask_and_feat = self._crop(up_maps, boxes, box_ind, level, self.mask_pool_size)
         if cfg.DEV.BASELINE:
             return pooled, mask_and_feat, []
 
         # 'small' features of the RoIs on levels 2..4 (levels with meta loss, :434-435), written
-        # level-major like the reference's small_output_all / small_gt_all (:583-598)
-        meta_lvl = level <= 4
-        small_rows = torch.nonzero(meta_lvl).view(-1)
-        order = small_rows[torch.sort(level[small_rows], stable=True)[1]]
+        # level-major like the reference's small_output_all / small_gt_all (:583-598): a stable sort by
+        # level puts them first, in (level, original index) order
+        n_small = n2 + n3 + n4
+        order = torch.sort(level, stable=True)[1][:n_small]
         small_output = self._feat_extract(mask_and_feat[order])
         if cfg.DEV.LOSS_CHOICE != 'ot':
             small_output = self.last_op(small_output)
-        small_output = small_output.view(order.numel(), -1)
+        small_output = small_output.view(n_small, -1)
         total_box = bs * R
         small_output_all = small_output.new_zeros(total_box, small_output.size(1))
-        small_output_all[:order.numel()] = small_output
+        small_output_all[:n_small] = small_output
         small_gt_all = small_output.new_zeros(total_box)
         if not train_phase:
-            small_gt_all[:order.numel()] = 1
+            small_gt_all[:n_small] = 1
             return pooled, mask_and_feat, [small_output_all, small_gt_all]
 
         gt = roi_cls_gt.reshape(-1).to(torch.int32)
-        small_gt_all[:order.numel()] = gt[order].float()
+        small_gt_all[:n_small] = gt[order].float()
         lvl_o = level[order]
         gt_o = gt[order]
         K = self.num_classs
@@ -346,10 +372,13 @@ class Dev(nn.Module):
             f, c = class_mean(small_output, torch.where(lvl_o == lvl, gt_o, torch.zeros_like(gt_o)), K)
             small_feat.append(f)
             small_cnt.append(c)
-        # 'big' boxes: RoIs of higher levels pooled 14x14 from the RAW level map (:498-507)
+        # 'big' boxes: RoIs of higher levels pooled 14x14 from the RAW level map (:498-507); level l sees
+        # the RoIs of every higher level, so an RoI of level 5 appears three times
+        n_big = {2: n3 + n4 + n5, 3: n4 + n5, 4: n5}
+        has_small = {2: n2 > 0, 3: n3 > 0, 4: n4 > 0}
         big_sel, big_lvl = [], []
         for lvl in (2, 3, 4):
-            idx = torch.nonzero(self._find_big_box2(lvl, level)).view(-1)
+            idx = torch.nonzero_static(level > lvl, size=n_big[lvl]).view(-1)
             big_sel.append(idx)
             big_lvl.append(torch.full_like(idx, lvl, dtype=torch.int32))
         big_idx = torch.cat(big_sel)
@@ -373,14 +402,13 @@ class Dev(nn.Module):
                     if big_idx.numel() else big_raw.new_zeros(0)
             for i, lvl in enumerate((2, 3, 4)):
                 # a level without small boxes contributes no big statistics either (:456-467)
-                has_small = (level == lvl).any()
                 at_lvl = big_level == lvl
-                g = torch.where(at_lvl, big_gt, torch.zeros_like(big_gt)) * has_small.to(big_gt.dtype)
+                g = torch.where(at_lvl, big_gt, torch.zeros_like(big_gt)) if has_small[lvl] else torch.zeros_like(big_gt)
                 f, c = class_mean(big_out, g, K)
                 big_feat.append(f)
                 big_cnt.append(c)
-                if cfg.DEV.BIG_SUPERVISE:       # mean CE over the level's big boxes (:531-535), 0 without any
-                    w = at_lvl.float() * has_small.float()
+                if cfg.DEV.BIG_SUPERVISE and has_small[lvl]:     # mean CE over the level's big boxes (:531-535)
+                    w = at_lvl.float()
                     big_loss.append(((ce * w).sum() / w.sum().clamp(min=1)).view(1))
                 else:
                     big_loss.append(small_output.new_zeros(1))

@@ -4,6 +4,8 @@ clipping, SGD step.  The reference's epoch/stage loops, logging, visdom and chec
 are out of scope (SURVEY 2.1 #8)."""
 import torch
 
+from ._lib import const_tensor
+
 
 def set_optimizer(net, opt):
     """tools/utils.py:474-501: SGD, weight decay on everything except BatchNorm affine
@@ -30,7 +32,7 @@ def compute_loss(model, inputs, do_meta=True, world_size=1, reduce_fn=None):
         if cfg.DEV.DIS_REG_LOSS:
             # workflow.py:184-187 zeroes the VALUES (`.data[i] = 0`) of rpn_bbox, mrcnn_bbox and mask;
             # torch.sum's backward does not look at values, so their gradients still flow -- mirrored
-            off = torch.tensor([0., 1., 0., 1., 1.], device=detailed.device)
+            off = const_tensor([0., 1., 0., 1., 1.], detailed.device)
             detailed = detailed - detailed.detach() * off
         meta = model.meta_loss([big_feat, big_cnt, small_feat, small_cnt, small_output_all, small_gt_all],
                                reduce_fn=reduce_fn)

@@ -258,15 +258,32 @@ int fi_conv2d_forward(const float *x, const float *weight, const float *bias,
  * g = dy * (y > 0 | 1); dz = g * scale[c]; dshift[c] = sum g; dgamma[c] = sum g*(y-beta[c])/gamma[c].
  * layout 1: dy and y are channels-last [N,HW,C] (dz is still written [N,C,HW]; no residual/g_out).
  * dy, y, dz, g_out are [N,C,HW]; g_out (optional) receives g (the gradient of a fused residual);
- * residual (optional) is the shortcut that was added in the epilogue (y - residual = BN output). */
+ * residual (optional) is the shortcut that was added in the epilogue (y - residual = BN output).
+ * dbias (optional, [C]) additionally receives dshift[c] * scale[c] -- the gradient of a convolution bias
+ * that was folded into the shift.  flags: FI_OUTPUTS_ZEROED = the caller has already zero-filled the
+ * accumulated outputs (dshift, dgamma, dbias; dweight, dbias of fi_conv2d_weight_grad), e.g. as slices of
+ * one arena cleared once per step, so the per-call fills are skipped. */
+#define FI_OUTPUTS_ZEROED 1
 int fi_bn_act_backward(const float *dy, const float *y, const float *scale, const float *gamma,
                        const float *beta, const float *residual, int N, int C, int HW, int relu,
-                       float *dz, float *g_out, float *dshift, float *dgamma, int layout,
-                       fi_stream_t stream);
+                       float *dz, float *g_out, float *dshift, float *dgamma, float *dbias,
+                       int layout, int flags, fi_stream_t stream);
 int fi_conv2d_weight_grad(const float *x, const float *dy, float *dweight, int N, int Cin,
                           int H, int W, int Cout, int R, int S, int stride_h, int stride_w,
-                          int pad_h, int pad_w, int weight_layout, float *dbias,
+                          int pad_h, int pad_w, int weight_layout, float *dbias, int flags,
                           fi_stream_t stream);
+/* All layers' W^T for the data-gradient kernel in one launch: for every descriptor, src is
+ * [rows][taps][cols] (a weight stored [Cout][R][S][Cin]) and dst becomes [cols][taps][rows]
+ * ([Cin][R][S][Cout]).  tile_base = number of 32x32 tiles of all earlier descriptors
+ * (taps * ceil(rows/32) * ceil(cols/32) each); the table lives in device memory. */
+typedef struct {
+    const void *src;
+    void *dst;
+    int rows, cols, taps, pad_;
+    long tile_base;
+} FiTransposeDesc;
+int fi_weight_transpose_batch(const FiTransposeDesc *descs_dev, int n, long total_tiles,
+                              fi_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * In-library kernel timing (HIP events recorded on the launch stream around

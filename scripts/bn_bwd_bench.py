@@ -11,7 +11,7 @@ for (N, C, H, W, res) in [(4, 256, 256, 256, True), (4, 64, 256, 256, False), (4
     sums = torch.empty(2, C, device="cuda")
     def run():
         _lib.check(L.fi_bn_act_backward(_lib.ptr(dy), _lib.ptr(y), _lib.ptr(sc), _lib.ptr(ga), _lib.ptr(be), _lib.ptr(r),
-                                        N, C, H * W, 1, _lib.ptr(dz), _lib.ptr(gres), _lib.ptr(sums[0]), _lib.ptr(sums[1]), 0,
+                                        N, C, H * W, 1, _lib.ptr(dz), _lib.ptr(gres), _lib.ptr(sums[0]), _lib.ptr(sums[1]), None, 0, 0,
                                         _lib.current_stream()), "bn")
     for _ in range(5): run()
     torch.cuda.synchronize()

@@ -63,7 +63,7 @@ def main():
 
         def wg():
             _lib.check(L.fi_conv2d_weight_grad(_lib.ptr(x), _lib.ptr(dy), _lib.ptr(dw), N, Cin, H, W, Cout, R, R,
-                                               st, st, pd, pd, hwc, None, _lib.current_stream()), "wgrad")
+                                               st, st, pd, pd, hwc, None, 0, _lib.current_stream()), "wgrad")
         t_w = timeit(wg)
         print(json.dumps({"layer": name, "GFLOP": round(flops / 1e9, 1), "fwd_us": round(t_f * 1e6, 1),
                           "fwd_TFLOPs": round(flops / t_f / 1e12, 1), "wgrad_us": round(t_w * 1e6, 1),

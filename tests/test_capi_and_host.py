@@ -70,7 +70,7 @@ def test_argument_validation_without_a_gpu():
     assert b"output_layout" in L.fi_last_error()
     assert L.fi_conv2d_forward(*a, 1, 30, 8, 8, 64, 3, 3, 1, 1, 1, 1, 0, 1, 0, 0, 0, None) == -1      # tap-major needs Cin % 16
     assert L.fi_conv2d_forward(*a, 1, 32, 8, 8, 62, 3, 3, 1, 1, 1, 1, 0, 1, 0, 0, 1, None) == -1      # NHWC needs Cout % 4
-    assert L.fi_bn_act_backward(16, 16, 16, None, None, None, 1, 8, 16, 1, 16, None, 16, None, 3, None) == -1
+    assert L.fi_bn_act_backward(16, 16, 16, None, None, None, 1, 8, 16, 1, 16, None, 16, None, None, 3, 0, None) == -1
 
 
 def test_reference_shaped_python_surface():
