@@ -68,6 +68,103 @@ def crop_algorithmic_bytes(log_entry):
     return 4 * N * C * crop * crop + 4 * C * total_u + 24 * N
 
 
+def crop_dedup_bytes(log_entry, batch):
+    """The same launch with every map element counted ONCE however many RoIs tap it: 4*N*C*ch*cw (write)
+    + 4*C*|union over RoIs of their taps| per (image, level) + 24*N.  Training RoIs are jittered copies of a
+    few objects and overlap heavily, so this is what can at most come from memory; B_min (per-RoI unique
+    taps) is what the kernel must gather."""
+    from feature_intertwiner_amd import _lib
+    L = _lib.load()
+    boxes, level, ind, shapes, crop, C = (log_entry[k] for k in ("boxes", "level", "box_ind", "shapes", "crop", "depth"))
+    N = boxes.size(0)
+    dev = boxes.device
+    uniq = 0
+    for li, (H, W) in enumerate(shapes):
+        sel = torch.nonzero(level == li + 2).view(-1)
+        n = sel.numel()
+        if n == 0:
+            continue
+        b = boxes[sel].contiguous()
+        o = {k: torch.empty((n, crop), device=dev, dtype=torch.float32 if k.endswith("frac") else torch.int32)
+             for k in ("y_valid", "y0", "y1", "y_frac", "x_valid", "x0", "x1", "x_frac")}
+        _lib.check(L.fi_crop_and_resize_taps(_lib.ptr(b), n, H, W, crop, crop, _lib.ptr(o["y_valid"]),
+                                             _lib.ptr(o["y0"]), _lib.ptr(o["y1"]), _lib.ptr(o["y_frac"]),
+                                             _lib.ptr(o["x_valid"]), _lib.ptr(o["x0"]), _lib.ptr(o["x1"]),
+                                             _lib.ptr(o["x_frac"]), _lib.current_stream()), "taps")
+        rows = torch.cat([o["y0"], o["y1"]], 1).long()                       # [n, 2*crop]
+        rv = torch.cat([o["y_valid"], o["y_valid"]], 1) > 0
+        cols = torch.cat([o["x0"], o["x1"]], 1).long()
+        cv = torch.cat([o["x_valid"], o["x_valid"]], 1) > 0
+        img = ind[sel].long().view(n, 1, 1)
+        flat = (img * H + rows.unsqueeze(2)) * W + cols.unsqueeze(1)          # [n, 2c, 2c]
+        ok = rv.unsqueeze(2) & cv.unsqueeze(1)
+        mask = torch.zeros(batch * H * W, device=dev, dtype=torch.bool)
+        mask[flat[ok]] = True
+        uniq += int(mask.sum())
+    return 4 * N * C * crop * crop + 4 * C * uniq + 24 * N
+
+
+def pmc_traffic(kernel_substrings, extra_args, timeout_s=170):
+    """HBM-side bytes per launch of the named kernels from rocprofv3's FETCH_SIZE / WRITE_SIZE, collected as
+    MI355X_MICROARCH.md prescribes: each counter in its OWN `--pmc` pass (with --kernel-trace only), values in
+    KB, and calibrated on a streaming copy of known size run in the same process (fi_calib_copy, 16 bytes
+    per lane: on gfx950 FETCH_SIZE reports half the bytes of such a read).  The profiled child is this
+    script with --pmc-child: the calibration copies, then the same train step.  Returns
+    {substring: {"fetch": B, "write": B, "launches": n}}, "calibration": {...}} or {"error": ...}."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return {"error": "rocprofv3 not found"}
+    out = {}
+    calib_bytes = 256 * 1024 * 1024
+    raw = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="fi_pmc_", dir=os.environ.get("TMPDIR", "/tmp"))
+        cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "p", "--",
+               sys.executable, os.path.abspath(__file__), "--pmc-child"] + extra_args
+        try:
+            subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s, check=False,
+                           cwd=os.environ.get("TMPDIR", "/tmp"))
+        except subprocess.TimeoutExpired:
+            shutil.rmtree(d, ignore_errors=True)
+            return {"error": "rocprofv3 --pmc %s timed out after %d s" % (counter, timeout_s)}
+        files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+        if not files:
+            shutil.rmtree(d, ignore_errors=True)
+            return {"error": "rocprofv3 --pmc %s produced no counter file" % counter}
+        per_dispatch = {}
+        with open(files[0]) as f:
+            for r in csv.DictReader(f):
+                if r.get("Counter_Name") != counter:
+                    continue
+                key = (r.get("Dispatch_Id"), r["Kernel_Name"])
+                per_dispatch[key] = per_dispatch.get(key, 0.0) + float(r["Counter_Value"])
+        shutil.rmtree(d, ignore_errors=True)
+        for (_, name), v in per_dispatch.items():
+            raw.setdefault((counter, name), []).append(v * 1024.0)            # KB -> bytes
+    def mean_of(counter, sub):
+        vals = [v for (c, n), vs in raw.items() if c == counter and sub in n for v in vs]
+        return (sum(vals) / len(vals), len(vals)) if vals else (None, 0)
+    cf, ncal = mean_of("FETCH_SIZE", "fi_calib_copy_kernel")
+    cw, _ = mean_of("WRITE_SIZE", "fi_calib_copy_kernel")
+    if not cf or not cw:
+        return {"error": "calibration kernel not found in the counter output"}
+    f_fac, w_fac = calib_bytes / cf, calib_bytes / cw
+    out["calibration"] = {"kernel": "fi_calib_copy_kernel (256 MiB read + 256 MiB written, 16 B/lane)",
+                          "FETCH_SIZE_reported_MB": round(cf / 1e6, 1), "WRITE_SIZE_reported_MB": round(cw / 1e6, 1),
+                          "fetch_factor": round(f_fac, 3), "write_factor": round(w_fac, 3), "launches": ncal}
+    for sub in kernel_substrings:
+        fe, n = mean_of("FETCH_SIZE", sub)
+        wr, _ = mean_of("WRITE_SIZE", sub)
+        if fe is not None and wr is not None:
+            out[sub] = {"fetch": fe * f_fac, "write": wr * w_fac, "launches": n}
+    return out
+
+
 def cpu_conv_stack_seconds(shape_log, budget_s=40.0):
     """The step's convolutions (forward + input/weight gradients) on the host CPU through torch /
     oneDNN -- which is how the reference runs them on its CPU path.  Every distinct layer shape is
@@ -181,6 +278,10 @@ def main():
     ap.add_argument("--rois", type=int, default=512)
     ap.add_argument("--ot-L", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 --pmc passes that fill roofline.traffic")
+    ap.add_argument("--profile-steps", type=int, default=4,
+                    help="extra steps AFTER the timed region, run with in-library HIP-event timing for the roofline objects")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--mask-head-on-positive-slots", action="store_true",
                     help="NOT the headline configuration: run the mask head only on the RoI slots that can hold "
                          "positives (identical loss/gradients, see MaskRCNN.forward); recorded in config.variant")
@@ -233,17 +334,25 @@ def main():
         return train_step(model, opt, list(batch), do_meta=True, grad_sync=sync, world_size=world,
                           reduce_fn=reduce_fn)
 
+    if args.pmc_child:
+        # profiled under `rocprofv3 --pmc <one counter>`: calibration copies of known size, then the step
+        a = torch.empty(64 * 1024 * 1024, device=dev)
+        b = torch.empty_like(a)
+        for _ in range(4):
+            _lib.check(_lib.load().fi_calib_copy(_lib.ptr(a), _lib.ptr(b), a.numel(), _lib.current_stream()), "calib")
+        del a, b
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        return
+
     for _ in range(args.warmup):
         terms = step()
+    # ---- the timed region: exactly K steps, nothing recorded (no event timing, no logging) ----------
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    _lib.prof_reset()
-    _lib.prof_enable(True)
-    car.LAUNCH_LOG = []
-    ficonv.FLOP_LOG = {}
-    ficonv.SHAPE_LOG = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         terms = step()
@@ -252,16 +361,28 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    _lib.prof_enable(False)
     if sync is not None:
         sync.check()               # replicas stayed consistent (host sync, outside the timed region)
+    # ---- a separate profiled pass for the roofline objects (HIP events around every library kernel) --
+    prof_steps = max(1, args.profile_steps)
+    _lib.prof_reset()
+    _lib.prof_enable(True)
+    car.LAUNCH_LOG = []
+    ficonv.FLOP_LOG = {}
+    ficonv.SHAPE_LOG = []
+    t1 = time.perf_counter()
+    for _ in range(prof_steps):
+        step()
+    torch.cuda.synchronize()
+    prof_elapsed = time.perf_counter() - t1
+    _lib.prof_enable(False)
     log = car.LAUNCH_LOG
     car.LAUNCH_LOG = None
     flop_log = ficonv.FLOP_LOG
     ficonv.FLOP_LOG = None
     shape_log = ficonv.SHAPE_LOG
     ficonv.SHAPE_LOG = None
-    shape_log = shape_log[:len(shape_log) // max(args.steps, 1)]       # the convolutions of ONE step
+    shape_log = shape_log[:len(shape_log) // prof_steps]       # the convolutions of ONE step
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -284,6 +405,7 @@ def main():
         if n7 and fwd7:
             e = fwd7[-1]
             b_alg = crop_algorithmic_bytes(e)
+            b_dedup = crop_dedup_bytes(e, args.batch_per_gpu)
             dur = ms7 / n7 * 1e-3
             ach = b_alg / dur / 1e9
             roof_roi = {"kernel": _lib.kernel_name(roi_kernel), "map_layout": "NHWC" if e.get("nhwc") else "NCHW",
@@ -291,13 +413,17 @@ def main():
                     "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4),
                     "traffic": None, "algorithmic_bytes_per_launch": int(b_alg),
                     "avg_launch_us": round(dur * 1e6, 2), "launches_timed": n7,
-                    "rois_per_launch": int(e["boxes"].size(0)), "bytes_model": "B_min (SURVEY 8d)"}
+                    "rois_per_launch": int(e["boxes"].size(0)), "bytes_model": "B_min (SURVEY 8d): output + each RoI's distinct taps",
+                    "dedup_bytes_per_launch": int(b_dedup),
+                    "achieved_dedup": round(b_dedup / dur / 1e9, 1), "frac_dedup": round(b_dedup / dur / 1e9 / HBM_PEAK_GBPS, 4),
+                    "dedup_model": "output + the UNION of all RoIs' taps per (image, level): the jittered-GT RoIs overlap, "
+                                   "so this is the most that can come from memory; the rest of B_min is served by L2"}
         kern = {}
         for k in _lib.KERNEL_IDS:
             n, ms = _lib.prof_get(k)
             if n:
                 kern[_lib.kernel_name(k)] = {"launches": n, "avg_us": round(ms / n * 1e3, 2),
-                                             "ms_per_step": round(ms / args.steps, 3), "_key": k}
+                                             "ms_per_step": round(ms / prof_steps, 3), "_key": k}
         # ---- roofline of the DOMINANT kernel (largest share of the step) ------------------------
         dom = max(kern.items(), key=lambda kv: kv[1]["ms_per_step"]) if kern else None
         roof = None
@@ -309,7 +435,7 @@ def main():
                     "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
                     "algorithmic_flops_per_launch": int(flops / max(launches, 1)),
                     "avg_launch_us": round(ms / n * 1e3, 2), "launches_timed": n,
-                    "share_of_step": round(dom[1]["ms_per_step"] / ms_per_step, 4),
+                    "share_of_step": round(dom[1]["ms_per_step"] / (prof_elapsed / prof_steps * 1e3), 4),
                     "flops_model": "2*N*Cout*OH*OW*Cin*R*S per launch (fp32, exact MFMA)"}
         elif roof_roi is not None:
             roof = roof_roi
@@ -325,15 +451,66 @@ def main():
                     tot_f += flops
                     tot_ms += ms
                     per[name] = {"tflops": round(flops / (ms * 1e-3) / 1e12, 1), "ms_per_step": v["ms_per_step"],
-                                 "gflop_per_step": round(flops / args.steps / 1e9, 1)}
+                                 "gflop_per_step": round(flops / prof_steps / 1e9, 1)}
             if tot_ms > 0:
                 ach = tot_f / (tot_ms * 1e-3) / 1e12
                 conv_stack = {"achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                               "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
-                              "tflop_per_step": round(tot_f / args.steps / 1e12, 3),
-                              "ms_per_step": round(tot_ms / args.steps, 2), "per_kernel": per,
+                              "tflop_per_step": round(tot_f / prof_steps / 1e12, 3),
+                              "ms_per_step": round(tot_ms / prof_steps, 2), "per_kernel": per,
                               "note": "sum of algorithmic flops / sum of kernel time over every conv_fwd (forward + "
                                       "data gradient) and conv_wgrad launch of the timed steps"}
+        # ---- NMS and Sinkhorn figures -------------------------------------------------------
+        n_m, ms_m = _lib.prof_get("nms_mask")
+        n_s, ms_s = _lib.prof_get("nms_scan")
+        nms_obj = None
+        if n_m:
+            nb, nbx = args.batch_per_gpu, cfg.RPN.PRE_NMS_LIMIT
+            b_nms = nb * (20 * nbx + 8 * nbx * ((nbx + 63) // 64))
+            us_m, us_s = ms_m / n_m * 1e3, (ms_s / n_s * 1e3 if n_s else 0.0)
+            nms_obj = {"images": nb, "boxes_per_image": nbx, "mask_kernel_us": round(us_m, 1), "scan_kernel_us": round(us_s, 1),
+                       "algorithmic_bytes": b_nms, "mask_GBps": round(b_nms / (us_m * 1e-6) / 1e9, 1),
+                       "mask_frac_hbm": round(b_nms / (us_m * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4),
+                       "pair_tests_per_us": round(nb * nbx * nbx / 2 / us_m, 0),
+                       "bytes_model": "20*N read + 8*N*ceil(N/64) mask written, per image (SURVEY 8d); the kernel is "
+                                      "bound by the N^2/2 IoU tests (VALU), not by these bytes"}
+        n_k, ms_k = _lib.prof_get("sinkhorn")
+        sk_obj = None
+        if n_k:
+            ncls = cfg.DATASET.NUM_CLASSES - 1
+            fl = 3 * ncls * 2 * args.ot_L * 2 * 256 * 256
+            us_k = ms_k / n_k * 1e3
+            sk_obj = {"problems": 3 * ncls, "samples": 256, "L": args.ot_L, "kernel_us": round(us_k, 1),
+                      "GFLOPs": round(fl / (us_k * 1e-6) / 1e9, 1),
+                      "frac_fp32_vector_peak": round(fl / (us_k * 1e-6) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
+                      "bound": "on-chip (fp32 FMA + LDS/barrier latency); the HBM roofline does not apply: "
+                               "inputs are 2 x 256 floats per problem"}
+        # ---- HBM-side traffic of the dominant kernel and of RoIAlign from the PMC counters ----------------
+        if world == 1 and not args.no_pmc and roof is not None:
+            child = ["--backbone", args.backbone, "--image-size", str(args.image_size), "--batch-per-gpu",
+                     str(args.batch_per_gpu), "--rois", str(args.rois), "--ot-L", str(args.ot_L)]
+            if args.mask_head_on_positive_slots:
+                child.append("--mask-head-on-positive-slots")
+            subs = [roof["kernel"].split("<")[0] + "<" + roof["kernel"].split("<")[1].rstrip(">")]
+            if roof_roi is not None:
+                subs.append(roof_roi["kernel"].rstrip(">"))
+            t_p = time.time()
+            tr = pmc_traffic(subs, child)
+            if "error" in tr:
+                roof["traffic_error"] = tr["error"]
+            else:
+                for obj, sub in ((roof, subs[0]), (roof_roi, subs[1] if len(subs) > 1 else None)):
+                    if obj is not None and sub in tr:
+                        obj["traffic"] = int(tr[sub]["fetch"] + tr[sub]["write"])
+                        obj["traffic_detail"] = {"fetch_bytes": int(tr[sub]["fetch"]), "write_bytes": int(tr[sub]["write"]),
+                                                 "launches_counted": tr[sub]["launches"], "calibration": tr["calibration"],
+                                                 "method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE in separate "
+                                                           "passes over the same train step, KB -> bytes, scaled by the factors "
+                                                           "measured on fi_calib_copy_kernel in the same run",
+                                                 "collection_s": round(time.time() - t_p, 1)}
+                if roof_roi is not None and roof_roi.get("traffic"):
+                    roof_roi["traffic_GBps"] = round(roof_roi["traffic"] / (roof_roi["avg_launch_us"] * 1e-6) / 1e9, 1)
+                    roof_roi["traffic_frac_hbm"] = round(roof_roi["traffic_GBps"] / HBM_PEAK_GBPS, 4)
         for v in kern.values():
             v.pop("_key", None)
         out = {
@@ -353,7 +530,11 @@ def main():
                        "conv_stack": "hand-written fp32 MFMA implicit-GEMM kernels (csrc/conv_igemm.hip); "
                                      "full-window convs and nn.Linear on the library GEMM"},
             "losses": {k: round(float(v), 5) for k, v in terms.items()},
-            "roofline": roof, "roofline_roialign": roof_roi, "conv_stack": conv_stack, "kernels": kern,
+            "roofline": roof, "roofline_roialign": roof_roi, "conv_stack": conv_stack, "nms": nms_obj, "sinkhorn": sk_obj,
+            "timing": {"timed_region": "%d steps, no event recording / logging" % args.steps,
+                       "profiled_pass": "%d further steps with HIP-event timing of every library kernel: %.2f ms/step"
+                                        % (prof_steps, prof_elapsed / prof_steps * 1e3)},
+            "kernels": kern,
         }
         if world == 1 and not args.no_cpu_baseline:
             try:

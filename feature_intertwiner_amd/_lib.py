@@ -59,6 +59,7 @@ SIGNATURES = {
     "fi_bn_act_backward": (c_int, [c_void_p] * 6 + [c_int] * 4 + [c_void_p] * 5 + [c_int, c_int, c_void_p]),
     "fi_conv2d_weight_grad": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 12 + [c_void_p, c_int, c_void_p]),
     "fi_weight_transpose_batch": (c_int, [c_void_p, c_int, ctypes.c_long, c_void_p]),
+    "fi_calib_copy": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     "fi_prof_enable": (None, [c_int]),
     "fi_prof_reset": (None, []),
     "fi_prof_get": (c_int, [c_int, _ip, ctypes.POINTER(c_float)]),

@@ -143,9 +143,10 @@ def _strided_dgrad(dz, w, in_hw, stride, padding):
                 continue
             pad_h, pad_w = Th - 1 - ch0, Tw - 1 - cw0
             assert pad_h >= 0 and pad_w >= 0, "unsupported stride/padding combination"
-            rows = [r0 + sh * (Th - 1 - u) for u in range(Th)]
-            cols = [s0 + sw * (Tw - 1 - u) for u in range(Tw)]
-            k = w[:, :, rows][:, :, :, cols].transpose(0, 1).contiguous()      # [Cin, Cout, Th, Tw]
+            # taps r0 + sh*t, t = Th-1 .. 0 (and the same along the width): a strided slice, reversed.
+            # (Indexing with Python lists would build index tensors on the host: a synchronising copy each.)
+            k = w[:, :, r0:r0 + sh * (Th - 1) + 1:sh, s0:s0 + sw * (Tw - 1) + 1:sw].flip(2, 3)
+            k = k.transpose(0, 1).contiguous()                                  # [Cin, Cout, Th, Tw]
             out = _conv_fwd(dz, k, None, (1, 1), (pad_h, pad_w), out_hw=(qa, qb))
             dx[:, :, a::sh, b::sw] = out
     return dx

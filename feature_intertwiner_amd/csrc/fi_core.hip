@@ -82,7 +82,25 @@ static void drain_locked()
 
 }  // namespace fi
 
+// Calibration kernel for the memory-side PMC counters (FETCH_SIZE / WRITE_SIZE): a plain streaming copy,
+// 16 bytes per lane, whose HBM traffic is known exactly (n floats read, n floats written).
+__global__ __launch_bounds__(256) void fi_calib_copy_kernel(const float4 *__restrict__ src,
+                                                            float4 *__restrict__ dst, size_t n4)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+}
+
 extern "C" {
+
+int fi_calib_copy(const float *src, float *dst, size_t n_floats, fi_stream_t stream)
+{
+    FI_REQUIRE(src && dst && n_floats % 4 == 0, "calibration copy needs 16-byte multiples");
+    FI_REQUIRE(((uintptr_t)src | (uintptr_t)dst) % 16 == 0, "calibration copy needs 16-byte aligned buffers");
+    hipLaunchKernelGGL(fi_calib_copy_kernel, dim3(8192), dim3(256), 0, (hipStream_t)stream,
+                       (const float4 *)src, (float4 *)dst, n_floats / 4);
+    FI_HIP_CHECK(hipGetLastError());
+    return FI_OK;
+}
 
 const char *fi_version(void) { return "fi_hip 0.1.0 gfx950"; }
 

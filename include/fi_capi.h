@@ -320,6 +320,9 @@ enum {
     FI_K_CROP_BWD_NHWC_GENERIC = 36,
     FI_K_COUNT = 37
 };
+/* Streaming copy of n_floats floats (16 bytes per lane) with exactly known memory traffic: the
+ * calibration point for rocprofv3's FETCH_SIZE / WRITE_SIZE (MI355X_MICROARCH.md, HBM section). */
+int fi_calib_copy(const float *src, float *dst, size_t n_floats, fi_stream_t stream);
 void fi_prof_enable(int on);
 void fi_prof_reset(void);
 /* Synchronises the recorded events, then returns launches and summed ms. */

@@ -1,8 +1,19 @@
+# Regenerates the round's evidence under gpurun_out/ (copy what is to be judged into profiles/).
+#   bash scripts/refresh_profiles.sh r02
 set -x
+R=${1:-r02}
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
-timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -4 > gpurun_out/pytest_gpu.txt
-timeout 400 python bench.py > gpurun_out/r01_bench_n1.json 2> gpurun_out/r01_bench_n1.err
-timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof7 -o b -- python bench.py --steps 4 --warmup 2 --no-cpu-baseline > gpurun_out/r01_bench_n1_under_rocprof.json 2>/dev/null
-f=$(find /tmp/prof7 -name 'b_kernel_stats.csv' | head -1); head -61 $f > gpurun_out/r01_bench_n1_kernel_stats.csv
-timeout 300 python scripts/op_bench.py > gpurun_out/r01_op_bench.txt 2>&1
-cat gpurun_out/pytest_gpu.txt; cat gpurun_out/r01_bench_n1.json | cut -c1-600
+O=$GRAFT_REPO_ROOT/gpurun_out
+( cd /tmp && timeout 600 python $GRAFT_REPO_ROOT/bench.py > $O/${R}_bench_n1.json 2> $O/${R}_bench_n1.err )
+# rocprofv3 per-kernel summary of the same command (headline flags, fewer steps; no nested PMC passes)
+rm -rf /tmp/prof7; ( cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof7 -o b -- python $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 2 --profile-steps 1 --no-cpu-baseline --no-pmc > $O/${R}_bench_n1_under_rocprof.json 2>/dev/null )
+f=$(find /tmp/prof7 -name 'b_kernel_stats.csv' | head -1)
+( head -81 $f; grep -E "crop_|nms_|sinkhorn|roi_pool|class_mean|weight_transpose" $f ) | awk '!seen[$0]++' > $O/${R}_bench_n1_kernel_stats.csv
+# operator micro-benchmarks, and the rocprofv3 summary of the RoI operators in that run
+timeout 300 python scripts/op_bench.py > $O/${R}_op_bench.txt 2>&1
+rm -rf /tmp/prof8; ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof8 -o c -- python $GRAFT_REPO_ROOT/scripts/op_bench.py --ops crop,nhwc,roipool,nms,sinkhorn > /dev/null 2>&1 )
+f=$(find /tmp/prof8 -name 'c_kernel_stats.csv' | head -1); grep -E "Name|crop_|roi_pool|nms_|sinkhorn" $f > $O/${R}_op_bench_kernel_stats.csv
+# MFMA utilisation of the dominant convolution (PMC passes, one counter group per run)
+bash scripts/conv_prof.sh "FPN P2" > $O/${R}_pmc_conv_mfma.txt 2>&1
+timeout 200 python scripts/roipool_probe.py > $O/${R}_roipool_probe.txt 2>&1
+ls -la $O | tail -12

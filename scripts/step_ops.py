@@ -29,15 +29,29 @@ rows = sorted(ka, key=lambda e: -e.count)
 print("%-46s %7s %12s %12s" % ("op", "count", "cpu_ms", "device_ms"))
 for e in rows[:45]:
     print("%-46s %7d %12.2f %12.2f" % (e.key[:46], e.count, e.cpu_time_total / 1e3, getattr(e, "device_time_total", getattr(e, "cuda_time_total", 0)) / 1e3))
-# call sites of the frequent small ops
-want = ("aten::copy_", "aten::add", "aten::add_", "aten::mul", "aten::fill_", "aten::zero_", "aten::clone", "aten::contiguous")
+# call sites of the frequent small ops: nearest python frame of this package (forward) or the autograd
+# node that issued them (backward)
+want = ("aten::copy_", "aten::add", "aten::add_", "aten::mul", "aten::fill_", "aten::zero_", "aten::clone",
+        "aten::contiguous", "hipMemcpyAsync", "hipMemcpyWithStream", "aten::_to_copy", "aten::sub", "aten::div")
 sites = collections.Counter()
 for ev in prof.events():
-    if ev.name in want and ev.stack:
-        fr = [s for s in ev.stack if "/root/repo" in s or "feature_intertwiner" in s or "autograd" in s][:2]
-        sites[(ev.name, " <- ".join(f.split("/")[-1] for f in fr) or "(autograd engine)")] += 1
-for (name, site), n in sites.most_common(40):
-    print("%5d  %-14s %s" % (n, name, site[:150]))
+    if ev.name not in want:
+        continue
+    site = None
+    for f in (ev.stack or []):
+        if "feature_intertwiner" in f or "bench.py" in f or "workflow" in f:
+            site = f.split("/")[-1][:90]
+            break
+    if site is None:
+        p_ = ev.cpu_parent
+        while p_ is not None:
+            if "evaluate_function" in p_.name or "Backward" in p_.name or "Optimizer" in p_.name:
+                site = p_.name[:90]
+                break
+            p_ = p_.cpu_parent
+    sites[(ev.name, site or "?")] += 1
+for (name, site), n in sites.most_common(60):
+    print("%5d  %-16s %s" % (n, name, site))
 
 # GPU busy vs wall: union of device-side kernel intervals inside the profiled step
 iv = []
