@@ -58,6 +58,8 @@ SIGNATURES = {
     "fi_conv2d_forward": (c_int, [c_void_p] * 6 + [c_int] * 16 + [c_void_p]),
     "fi_bn_act_backward": (c_int, [c_void_p] * 6 + [c_int] * 4 + [c_void_p] * 5 + [c_int, c_int, c_void_p]),
     "fi_conv2d_weight_grad": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 12 + [c_void_p, c_int, c_void_p]),
+    "fi_conv2d_forward_bf16": (c_int, [c_void_p] * 6 + [c_int] * 16 + [c_void_p]),
+    "fi_conv2d_weight_grad_bf16": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 12 + [c_void_p]),
     "fi_weight_transpose_batch": (c_int, [c_void_p, c_int, ctypes.c_long, c_void_p]),
     "fi_calib_copy": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     "fi_prof_enable": (None, [c_int]),
@@ -75,6 +77,7 @@ KERNEL_IDS = {
     "class_mean": 13, "bn_act_bwd": 30,
     "crop_fwd_nhwc_7x7": 31, "crop_fwd_nhwc_14x14": 32, "crop_fwd_nhwc_generic": 33,
     "crop_bwd_nhwc_7x7": 34, "crop_bwd_nhwc_14x14": 35, "crop_bwd_nhwc_generic": 36,
+    "conv_bf16_fwd": 37, "conv_bf16_wgrad": 38,
 }
 for _i, _bm in enumerate((64, 128)):
     for _j, _w in enumerate(("1x1", "3x3", "7x7", "other")):

@@ -11,12 +11,14 @@ import numpy as np
 
 def make_config(backbone="resnet101", image_size=1024, batch_size=4, train_rois_per_image=200,
                 dev_switch=True, loss_choice="ot", ot_L=5, roi_method="roi_align", gpu_count=1,
-                num_classes=81, buffer_size=1, loss_fac=1000.0):
+                num_classes=81, buffer_size=1, loss_fac=1000.0, conv_precision="fp32"):
     """Defaults = reference defaults; configs/104/meta_104_conv.yaml sets SWITCH, LOSS_CHOICE='ot',
     BUFFER_SIZE=1, LOSS_FAC=1000 and structure 'beta' with UPSAMPLE_FAC=1 is the only Dev branch
     that runs."""
     c = NS()
-    c.MODEL = NS(BACKBONE=backbone, BACKBONE_STRIDES=[4, 8, 16, 32, 64])
+    # CONV_PRECISION (not in the reference): 'fp32' = exact fp32 MFMA convolutions (default, the headline);
+    # 'bf16' = bf16-input / fp32-accumulate MFMA convolutions, BASELINE configs[4]'s reduced-precision path
+    c.MODEL = NS(BACKBONE=backbone, BACKBONE_STRIDES=[4, 8, 16, 32, 64], CONV_PRECISION=conv_precision)
     c.DATASET = NS(NUM_CLASSES=num_classes)
     c.RPN = NS(ANCHOR_SCALES=(32, 64, 128, 256, 512), ANCHOR_RATIOS=[0.5, 1, 2], ANCHOR_STRIDE=1,
                NMS_THRESHOLD=0.7, TRAIN_ANCHORS_PER_IMAGE=256, PRE_NMS_LIMIT=6000,

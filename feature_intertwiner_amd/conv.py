@@ -29,6 +29,23 @@ FLOP_LOG = None
 SHAPE_LOG = None
 
 
+# Arithmetic of the MFMA convolutions: "fp32" (exact, v_mfma_f32_32x32x2_f32 -- the headline) or "bf16"
+# (operands rounded to bf16, fp32 accumulation, v_mfma_f32_32x32x16_bf16 -- BASELINE configs[4]'s reduced-
+# precision conv path).  Read when a forward pass runs; the backward of that pass uses the same setting.
+_PRECISION = "fp32"
+
+
+def set_conv_precision(mode):
+    global _PRECISION
+    if mode not in ("fp32", "bf16"):
+        raise ValueError("conv precision must be 'fp32' or 'bf16'")
+    _PRECISION = mode
+
+
+def conv_precision():
+    return _PRECISION
+
+
 def _log_shape(x, w, stride, padding):
     if SHAPE_LOG is not None:
         SHAPE_LOG.append((x.shape[0], x.shape[1], x.shape[2], x.shape[3], w.shape[0], w.shape[2], w.shape[3],
@@ -37,7 +54,7 @@ def _log_shape(x, w, stride, padding):
 
 def _log_flops(kind, cout, R, S, flops, pixels=None, cin=None):
     if FLOP_LOG is not None:
-        k = _lib.conv_kernel_key(kind, cout, R, S, pixels, cin)
+        k = ("conv_" + kind) if kind.startswith("bf16") else _lib.conv_kernel_key(kind, cout, R, S, pixels, cin)
         e = FLOP_LOG.setdefault(k, [0, 0])
         e[0] += 1
         e[1] += flops
@@ -53,7 +70,7 @@ def _dense(w):
 
 
 def _conv_fwd(x, w, b, stride, padding, relu=False, scale=None, residual=None, out_hw=None,
-              out_channels_last=False, w_tap_major=False, flip_taps=False):
+              out_channels_last=False, w_tap_major=False, flip_taps=False, precision=None):
     """w is [Cout, Cin, R, S].  When Cin % 16 == 0 the kernel's tap-major fast path is used: the
     weight is handed over channels-last ([Cout, R, S, Cin]; a copy of at most a few MB).
     out_channels_last: y is returned in torch.channels_last memory format ([N,OH,OW,Cout] in
@@ -77,11 +94,16 @@ def _conv_fwd(x, w, b, stride, padding, relu=False, scale=None, residual=None, o
     OW = (W + 2 * padding[1] - S) // stride[1] + 1
     if out_hw is not None:
         OH, OW = out_hw
-    _log_flops("fwd", Cout, R, S, 2 * N * Cout * OH * OW * Cin * R * S, N * OH * OW)
+    if not ((_PRECISION == "bf16" if precision is None else precision == "bf16") and layout >= 1 and Cin % 32 == 0):
+        _log_flops("fwd", Cout, R, S, 2 * N * Cout * OH * OW * Cin * R * S, N * OH * OW)
     y = torch.empty((N, Cout, OH, OW), device=x.device, dtype=torch.float32,
                     memory_format=torch.channels_last if out_channels_last else torch.contiguous_format)
+    bf16 = (_PRECISION == "bf16" if precision is None else precision == "bf16") and layout >= 1 and Cin % 32 == 0
+    fn = L.fi_conv2d_forward_bf16 if bf16 else L.fi_conv2d_forward
+    if bf16:
+        _log_flops("bf16_fwd", Cout, R, S, 2 * N * Cout * OH * OW * Cin * R * S)
     with torch.cuda.device(x.device):
-        _lib.check(L.fi_conv2d_forward(_lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(scale), _lib.ptr(residual),
+        _lib.check(fn(_lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(scale), _lib.ptr(residual),
                                        _lib.ptr(y), N, Cin, H, W, Cout,
                                        R, S, stride[0], stride[1], padding[0], padding[1], 1 if relu else 0,
                                        layout, OH if out_hw is not None else 0, OW if out_hw is not None else 0,
@@ -99,6 +121,7 @@ class _Conv2dFn(torch.autograd.Function):
         bc = b.contiguous().float() if b is not None else None
         ctx.save_for_backward(x, w)
         ctx.conf = (tuple(stride), tuple(padding), b is not None)
+        ctx.precision = _PRECISION
         _log_shape(x, w, stride, padding)
         return _conv_fwd(x, w, bc, stride, padding)
 
@@ -108,9 +131,10 @@ class _Conv2dFn(torch.autograd.Function):
         stride, padding, has_bias = ctx.conf
         dy = dy.contiguous().float()
         if has_bias and ctx.needs_input_grad[2]:
-            dx, dw, db = _conv_backward(ctx.needs_input_grad, x, w, dy, stride, padding, want_db=True)
+            dx, dw, db = _conv_backward(ctx.needs_input_grad, x, w, dy, stride, padding, want_db=True,
+                                        precision=ctx.precision)
         else:
-            dx, dw = _conv_backward(ctx.needs_input_grad, x, w, dy, stride, padding)
+            dx, dw = _conv_backward(ctx.needs_input_grad, x, w, dy, stride, padding, precision=ctx.precision)
             db = None
         return dx, dw, db, None, None
 
@@ -124,7 +148,7 @@ def _class_taps(a, size_k, s, p):
     return r0, T, c0
 
 
-def _strided_dgrad(dz, w, in_hw, stride, padding):
+def _strided_dgrad(dz, w, in_hw, stride, padding, precision=None):
     """Data gradient of a strided convolution WITHOUT zero-stuffing: the input positions split into
     stride_h*stride_w residue classes; each class is a stride-1 correlation of dz with the sub-kernel
     of the taps that reach it (e.g. 3x3/stride 2/pad 1: 1, 2, 2 and 4 taps instead of 9 everywhere)."""
@@ -147,12 +171,12 @@ def _strided_dgrad(dz, w, in_hw, stride, padding):
             # (Indexing with Python lists would build index tensors on the host: a synchronising copy each.)
             k = w[:, :, r0:r0 + sh * (Th - 1) + 1:sh, s0:s0 + sw * (Tw - 1) + 1:sw].flip(2, 3)
             k = k.transpose(0, 1).contiguous()                                  # [Cin, Cout, Th, Tw]
-            out = _conv_fwd(dz, k, None, (1, 1), (pad_h, pad_w), out_hw=(qa, qb))
+            out = _conv_fwd(dz, k, None, (1, 1), (pad_h, pad_w), out_hw=(qa, qb), precision=precision)
             dx[:, :, a::sh, b::sw] = out
     return dx
 
 
-def _conv_backward(ctx_needs, x, w, dz, stride, padding, want_db=False, add_to_dx=None):
+def _conv_backward(ctx_needs, x, w, dz, stride, padding, want_db=False, add_to_dx=None, precision=None):
     """dX and dW of z = conv(x, w) given dz (shared by the plain and the fused functions).
     want_db: also return sum(dz) over images and pixels (the bias gradient), accumulated by the
     weight-gradient kernel from the dY tiles it stages anyway.
@@ -172,13 +196,13 @@ def _conv_backward(ctx_needs, x, w, dz, stride, padding, want_db=False, add_to_d
                 if wt is None:
                     wt = w.permute(1, 2, 3, 0).contiguous()
                 dx = _conv_fwd(dz, wt, None, (1, 1), (R - 1 - padding[0], S - 1 - padding[1]), w_tap_major=True,
-                               flip_taps=True, residual=add_to_dx)
+                               flip_taps=True, residual=add_to_dx, precision=precision)
                 add_to_dx = None
             else:
                 wt = w.flip(2, 3).transpose(0, 1).contiguous()          # [Cin, Cout, R, S]
-                dx = _conv_fwd(dz, wt, None, (1, 1), (R - 1 - padding[0], S - 1 - padding[1]))
+                dx = _conv_fwd(dz, wt, None, (1, 1), (R - 1 - padding[0], S - 1 - padding[1]), precision=precision)
         else:
-            dx = _strided_dgrad(dz, w, (H, W), stride, padding)
+            dx = _strided_dgrad(dz, w, (H, W), stride, padding, precision)
         if add_to_dx is not None:
             dx = dx + add_to_dx
     if ctx_needs[1]:
@@ -188,19 +212,29 @@ def _conv_backward(ctx_needs, x, w, dz, stride, padding, want_db=False, add_to_d
                 x.numel() * 4 < 0x7fffff00 and dz.numel() * 4 < 0x7fffff00 and
                 x.data_ptr() % 16 == 0 and dz.data_ptr() % 16 == 0)
         hwc = 1 if (Cin % 128 == 0 or (Cin == 64 and same)) else 0
+        # bf16 weight gradient: always tap-major, so the parameter must be stored that way (or be 1x1)
+        bf16 = precision == "bf16" and (R * S == 1 or (Cin % 16 == 0 and w.is_contiguous(memory_format=torch.channels_last)))
+        if bf16:
+            hwc = 1
         shape = (Cout, R, S, Cin) if (hwc and R * S > 1) else (Cout, Cin, R, S)
         # pre-zeroed slice of the step's gradient arena (one fill per step instead of one per layer)
         dw = _arena_take(("dw", w.data_ptr()), Cout * Cin * R * S)
-        flags = _lib.OUTPUTS_ZEROED if (dw is not None and not want_db) else 0
+        flags = _lib.OUTPUTS_ZEROED if (dw is not None and (bf16 or not want_db)) else 0
         dw = dw.view(shape) if dw is not None else torch.empty(shape, device=x.device, dtype=torch.float32)
-        _log_flops("wgrad", Cout, R, S, 2 * N * Cout * dz.shape[2] * dz.shape[3] * Cin * R * S,
-                   N * dz.shape[2] * dz.shape[3], Cin)
         if want_db:
-            db = torch.empty(Cout, device=x.device, dtype=torch.float32)
+            db = dz.sum((0, 2, 3)) if bf16 else torch.empty(Cout, device=x.device, dtype=torch.float32)
         with torch.cuda.device(x.device):
-            _lib.check(L.fi_conv2d_weight_grad(_lib.ptr(x), _lib.ptr(dz), _lib.ptr(dw), N, Cin, H, W, Cout,
-                                               R, S, stride[0], stride[1], padding[0], padding[1], hwc,
-                                               _lib.ptr(db), flags, _lib.current_stream()), "fi_conv2d_weight_grad")
+            if bf16:
+                _log_flops("bf16_wgrad", Cout, R, S, 2 * N * Cout * dz.shape[2] * dz.shape[3] * Cin * R * S)
+                _lib.check(L.fi_conv2d_weight_grad_bf16(_lib.ptr(x), _lib.ptr(dz), _lib.ptr(dw), N, Cin, H, W, Cout,
+                                                        R, S, stride[0], stride[1], padding[0], padding[1], flags,
+                                                        _lib.current_stream()), "fi_conv2d_weight_grad_bf16")
+            else:
+                _log_flops("wgrad", Cout, R, S, 2 * N * Cout * dz.shape[2] * dz.shape[3] * Cin * R * S,
+                           N * dz.shape[2] * dz.shape[3], Cin)
+                _lib.check(L.fi_conv2d_weight_grad(_lib.ptr(x), _lib.ptr(dz), _lib.ptr(dw), N, Cin, H, W, Cout,
+                                                   R, S, stride[0], stride[1], padding[0], padding[1], hwc,
+                                                   _lib.ptr(db), flags, _lib.current_stream()), "fi_conv2d_weight_grad")
         if hwc and R * S > 1:
             dw = dw.permute(0, 3, 1, 2)
     elif want_db:
@@ -341,6 +375,7 @@ class _ConvBnActFn(torch.autograd.Function):
         y = _conv_fwd(x, w, shift.contiguous(), stride, padding, relu=relu, scale=scale.contiguous(), residual=res,
                       out_channels_last=out_cl)
         ctx.out_cl = bool(out_cl)
+        ctx.precision = _PRECISION
         ctx.res_grad_to, ctx.dx_add_from = res_grad_to, dx_add_from
         ctx.save_for_backward(x, w, y, scale, gamma, beta, res)
         ctx.conf = (tuple(stride), tuple(padding), b is not None, bool(relu), residual is not None, eps, mean, var)
@@ -379,7 +414,7 @@ class _ConvBnActFn(torch.autograd.Function):
         add = None
         if ctx.dx_add_from is not None:
             add, ctx.dx_add_from.value = ctx.dx_add_from.value, None
-        dx, dw = _conv_backward(ctx.needs_input_grad, x, w, dz, stride, padding, add_to_dx=add)
+        dx, dw = _conv_backward(ctx.needs_input_grad, x, w, dz, stride, padding, add_to_dx=add, precision=ctx.precision)
         dbeta = dshift if ctx.needs_input_grad[4] else None
         return dx, dw, db, dgamma, dbeta, None, None, None, g_res, None, None, None, None, None, None, None
 
@@ -399,6 +434,7 @@ class _ConvBiasActFn(torch.autograd.Function):
         _log_shape(x, w, stride, padding)
         y = _conv_fwd(x, w, bc, stride, padding, relu=True)
         ctx.save_for_backward(x, w, y)
+        ctx.precision = _PRECISION
         ctx.conf = (tuple(stride), tuple(padding), b is not None)
         return y
 
@@ -416,7 +452,7 @@ class _ConvBiasActFn(torch.autograd.Function):
             _lib.check(L.fi_bn_act_backward(_lib.ptr(dy), _lib.ptr(y), _lib.ptr(ones), None, None, None, N, C, OH * OW, 1,
                                             _lib.ptr(dz), None, _lib.ptr(dshift), None, None, 0, 0,
                                             _lib.current_stream()), "fi_bn_act_backward")
-        dx, dw = _conv_backward(ctx.needs_input_grad, x, w, dz, stride, padding)
+        dx, dw = _conv_backward(ctx.needs_input_grad, x, w, dz, stride, padding, precision=ctx.precision)
         return dx, dw, (dshift if (has_bias and ctx.needs_input_grad[2]) else None), None, None
 
 

@@ -1,0 +1,505 @@
+// conv_bf16.hip -- bf16-input, fp32-accumulate implicit-GEMM convolution on the CDNA4 matrix cores
+// (v_mfma_f32_32x32x16_bf16): the reduced-precision conv path of BASELINE configs[4] ("fp16 MFMA conv
+// path"), selected by configuration and never used for the fp32 headline (conv_igemm.hip is exact fp32).
+//
+// Tensors stay fp32 in memory (NCHW activations, tap-major [Cout][R][S][Cin] weights, fp32 outputs and
+// gradients), so every other kernel of the step is untouched; operands are rounded to bf16 (RNE) on their
+// way into LDS and products are accumulated in fp32 by the MFMA.  Against the exact kernel the result
+// differs by the rounding of the two operands (2^-9 relative each), not by accumulation.
+//
+// Forward / data gradient (one kernel, as in conv_igemm.hip):   Y[m][p] = sum_k A[m][k] B[k][p]
+//   m = output channel, p = (image, oh, ow), k = (tap, ci) tap-major; tile 128 x 128 x 32 (BM = 64 for
+//   narrow layers) per 256-thread workgroup, 4 wavefronts as 2 x 2, each (BM/2) x 64 of 32x32 MFMA tiles.
+//   The MFMA wants both operands K-contiguous per lane (8 bf16 = one ds_read_b128):
+//     A (weights) is K-contiguous in memory: float4 loads, 16 values -> two ds_write_b128;
+//     B (im2col, never materialised) is PIXEL-contiguous in memory: a thread loads 4 consecutive pixels
+//     of two adjacent channels (two unaligned float4 loads; pixels that straddle a row end or the halo
+//     take a guarded scalar path) and writes four (c, c+1) bf16 pairs -> LDS rows [pixel][k].
+//   Global loads of K-tile t+1 are in flight during the MFMAs of tile t (register staging, two LDS
+//   buffers, one barrier per K-tile).
+// Weight gradient:   dW[m][(tap, ci)] = sum_p dY[m][p] X_tap[ci][p]: both operands are pixel-contiguous
+//   in memory = K-contiguous for the MFMA, so both tiles are float4 loads -> ds_write_b64; the pixel range
+//   is split across workgroups and accumulated with fp32 atomics (as the fp32 kernel does).
+#include <stdint.h>
+
+#include "fi_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef f32x4 f32x4_a4 __attribute__((aligned(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+constexpr int kThreads = 256;
+constexpr int TN = 128;      // pixel tile (forward) / (tap, ci) tile (weight gradient)
+constexpr int TK = 32;       // K per tile: two MFMA k-steps of 16
+constexpr int LP = 40;       // LDS row pitch in bf16 (80 B: 16-byte aligned rows, 20-bank stride)
+
+struct Geom {
+    int N, Cin, H, W, Cout, R, S, sh, sw, ph, pw, OH, OW;
+    int P;          // N*OH*OW
+    int flip;       // taps of the weight applied in reverse order (data gradient)
+    int out_nhwc;
+};
+
+struct Epi {
+    const float *bias, *scale, *residual;
+    int relu;
+};
+
+__device__ __forceinline__ bf16x2 pack2(float a, float b)
+{
+    bf16x2 r;
+    r.x = (__bf16)a;
+    r.y = (__bf16)b;
+    return r;
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward / data gradient
+// ------------------------------------------------------------------------------------------------
+template <int BM>
+__global__ __launch_bounds__(kThreads) void conv_bf16_fwd_kernel(const float *__restrict__ x,
+                                                                 const float *__restrict__ w, Epi ep,
+                                                                 float *__restrict__ y, Geom g)
+{
+    constexpr int MT = BM / 64;
+    __shared__ __align__(16) __bf16 As[2][BM][LP];
+    __shared__ __align__(16) __bf16 Bs[2][TN][LP];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int m0 = blockIdx.x * BM;
+    const int p0 = blockIdx.y * TN;
+    const int RS = g.R * g.S;
+    const int OHW = g.OH * g.OW;
+    const size_t HW = (size_t)g.H * g.W;
+
+    // ---- A loader: thread -> (row, 16-float half of the 32-wide K slice) --------------------------
+    const int a_row = tid >> 1, a_half = tid & 1;
+    const bool a_on = a_row < BM;
+    const int a_m = min(m0 + a_row, g.Cout - 1);             // rows past Cout re-read the last row
+    const float *__restrict__ a_src = w + (size_t)a_m * RS * g.Cin + a_half * 16;
+
+    // ---- B loader: thread -> (channel pair kp, pixel quad q); two quads per thread ----------------
+    const int kp = tid >> 4;                                 // 0..15 -> channels 2kp, 2kp+1 of the slice
+    const int q0 = tid & 15;                                 // quads q0 and q0 + 16
+    int b_n[2], b_oh[2], b_ow[2], b_cnt[2];
+    size_t b_base[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int p = p0 + 4 * (q0 + 16 * u);
+        b_cnt[u] = max(0, min(4, g.P - p));                  // pixels of the quad that exist
+        const int pc = min(p, g.P - 1);
+        const int n = pc / OHW, rem = pc - n * OHW;
+        b_n[u] = n;
+        b_oh[u] = rem / g.OW;
+        b_ow[u] = rem - b_oh[u] * g.OW;
+        b_base[u] = (size_t)n * g.Cin * HW;
+    }
+
+    f32x16 acc[MT][2];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+    f32x4 ra[4];               // A: 16 consecutive k of one row
+    f32x4 rb[2][2];            // B: [quad][channel of the pair] 4 pixels
+    const int cblocks = g.Cin / TK;
+    const int ktiles = RS * cblocks;
+
+    auto load_tile = [&](int kt) {
+        const int tap = kt / cblocks;
+        const int c0 = (kt - tap * cblocks) * TK;
+        const int wt = g.flip ? (RS - 1 - tap) : tap;
+        if (a_on) {
+            const float *pa = a_src + (size_t)wt * g.Cin + c0;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) ra[v] = *reinterpret_cast<const f32x4 *>(pa + 4 * v);
+        }
+        const int r = tap / g.S, s = tap - r * g.S;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int ih = b_oh[u] * g.sh - g.ph + r;
+            const int iw = b_ow[u] * g.sw - g.pw + s;
+            const float *px = x + b_base[u] + (size_t)(c0 + 2 * kp) * HW;
+            const bool same_row = (b_ow[u] + 3 < g.OW) && b_cnt[u] == 4;
+            if (g.sw == 1 && same_row && ih >= 0 && ih < g.H && iw >= 0 && iw + 3 < g.W) {
+                const float *p = px + (size_t)ih * g.W + iw;
+                rb[u][0] = *reinterpret_cast<const f32x4_a4 *>(p);
+                rb[u][1] = *reinterpret_cast<const f32x4_a4 *>(p + HW);
+            } else {
+                // quad straddling an output row / the halo / the end of the pixel range, or a strided layer
+                int oh = b_oh[u], ow = b_ow[u], n = b_n[u];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float v0 = 0.0f, v1 = 0.0f;
+                    if (j < b_cnt[u]) {
+                        const int ihj = oh * g.sh - g.ph + r, iwj = ow * g.sw - g.pw + s;
+                        if (ihj >= 0 && ihj < g.H && iwj >= 0 && iwj < g.W) {
+                            const float *p = x + (size_t)n * g.Cin * HW + (size_t)(c0 + 2 * kp) * HW + (size_t)ihj * g.W + iwj;
+                            v0 = p[0];
+                            v1 = p[HW];
+                        }
+                    }
+                    rb[u][0][j] = v0;
+                    rb[u][1][j] = v1;
+                    if (++ow == g.OW) {
+                        ow = 0;
+                        if (++oh == g.OH) {
+                            oh = 0;
+                            ++n;
+                        }
+                    }
+                }
+            }
+        }
+    };
+
+    auto store_tile = [&](int buf) {
+        if (a_on) {
+            bf16x8 lo, hi;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                lo[e] = (__bf16)ra[0][e];
+                lo[4 + e] = (__bf16)ra[1][e];
+                hi[e] = (__bf16)ra[2][e];
+                hi[4 + e] = (__bf16)ra[3][e];
+            }
+            *reinterpret_cast<bf16x8 *>(&As[buf][a_row][a_half * 16]) = lo;
+            *reinterpret_cast<bf16x8 *>(&As[buf][a_row][a_half * 16 + 8]) = hi;
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int prow = 4 * (q0 + 16 * u);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                *reinterpret_cast<bf16x2 *>(&Bs[buf][prow + j][2 * kp]) = pack2(rb[u][0][j], rb[u][1][j]);
+        }
+    };
+
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    for (int kt = 0; kt < ktiles; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < ktiles) load_tile(kt + 1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 af[MT], bfr[2];
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+                af[i] = *reinterpret_cast<const bf16x8 *>(&As[cur][wm * (BM / 2) + i * 32 + l31][ks * 16 + lh * 8]);
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                bfr[j] = *reinterpret_cast<const bf16x8 *>(&Bs[cur][wn * 64 + j * 32 + l31][ks * 16 + lh * 8]);
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < ktiles) store_tile(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: C/D layout col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5) ---------
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int p = p0 + wn * 64 + j * 32 + l31;
+        if (p >= g.P) continue;
+        const int n = p / OHW, rem = p - n * OHW;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int mb = m0 + wm * (BM / 2) + i * 32 + 4 * lh;
+            if (g.out_nhwc) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int m = mb + 8 * q;
+                    if (m >= g.Cout) continue;                           // Cout % 4 == 0
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float t = acc[i][j][4 * q + e];
+                        if (ep.scale) t *= ep.scale[m + e];
+                        if (ep.bias) t += ep.bias[m + e];
+                        if (ep.relu) t = fmaxf(t, 0.0f);
+                        v[e] = t;
+                    }
+                    *reinterpret_cast<f32x4 *>(y + (size_t)p * g.Cout + m) = v;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int m = mb + (e & 3) + 8 * (e >> 2);
+                    if (m >= g.Cout) continue;
+                    float t = acc[i][j][e];
+                    if (ep.scale) t *= ep.scale[m];
+                    if (ep.bias) t += ep.bias[m];
+                    const size_t o = ((size_t)n * g.Cout + m) * OHW + rem;
+                    if (ep.residual) t += ep.residual[o];
+                    if (ep.relu) t = fmaxf(t, 0.0f);
+                    y[o] = t;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight gradient (tap-major dW [Cout][R*S][Cin]), stride 1 or general
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void conv_bf16_wgrad_kernel(const float *__restrict__ x,
+                                                                   const float *__restrict__ dy,
+                                                                   float *__restrict__ dw, Geom g,
+                                                                   int cin_tiles, int chunks_per_image,
+                                                                   int chunk_pixels)
+{
+    constexpr int BM = 128;
+    __shared__ __align__(16) __bf16 As[2][BM][LP];      // dY  [cout][pixel]
+    __shared__ __align__(16) __bf16 Bs[2][TN][LP];      // X   [ci][pixel]   (for one tap)
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int RS = g.R * g.S;
+    const int OHW = g.OH * g.OW;
+    const size_t HW = (size_t)g.H * g.W;
+
+    const int m0 = blockIdx.x * BM;
+    const int tap = blockIdx.y / cin_tiles;
+    const int ci0 = (blockIdx.y - tap * cin_tiles) * TN;
+    const int r = tap / g.S, s = tap - r * g.S;
+    // this workgroup's share of the reduction: images and pixel chunks z, z + gridDim.z, ...
+    const int total_chunks = g.N * chunks_per_image;
+
+    // loader mapping (both tiles): thread -> (row = tid / 2 of 128, 16 consecutive pixels = 4 quads)
+    const int row = tid >> 1, half = tid & 1;
+    const int a_m = min(m0 + row, g.Cout - 1);
+    const int b_c = min(ci0 + row, g.Cin - 1);
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+    f32x4 ra[4], rb[4];
+    int cur_chunk = blockIdx.z;
+    int kpos = 0;                                       // pixel offset inside the chunk of the NEXT tile to load
+    bool more = cur_chunk < total_chunks;
+
+    auto load_tile = [&]() {
+        const int n = cur_chunk / chunks_per_image;
+        const int pbase = (cur_chunk - n * chunks_per_image) * chunk_pixels + kpos + half * 16;
+        const int pend = min(OHW, (cur_chunk - n * chunks_per_image + 1) * chunk_pixels);
+        const float *pa = dy + ((size_t)n * g.Cout + a_m) * OHW;
+        const float *pb = x + ((size_t)n * g.Cin + b_c) * HW;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int p = pbase + 4 * v;
+            if (p + 3 < pend && (OHW & 3) == 0) {
+                ra[v] = *reinterpret_cast<const f32x4_a4 *>(pa + p);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ra[v][e] = (p + e < pend) ? pa[p + e] : 0.0f;
+            }
+            // the same 4 output pixels seen through the tap
+            const int oh = p / g.OW, ow = p - oh * g.OW;
+            const int ih = oh * g.sh - g.ph + r, iw = ow * g.sw - g.pw + s;
+            if (g.sw == 1 && p + 3 < pend && ow + 3 < g.OW && ih >= 0 && ih < g.H && iw >= 0 && iw + 3 < g.W) {
+                rb[v] = *reinterpret_cast<const f32x4_a4 *>(pb + (size_t)ih * g.W + iw);
+            } else {
+                int o2 = oh, w2 = ow;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float t = 0.0f;
+                    if (p + e < pend) {
+                        const int ih2 = o2 * g.sh - g.ph + r, iw2 = w2 * g.sw - g.pw + s;
+                        if (ih2 >= 0 && ih2 < g.H && iw2 >= 0 && iw2 < g.W) t = pb[(size_t)ih2 * g.W + iw2];
+                    }
+                    rb[v][e] = t;
+                    if (++w2 == g.OW) {
+                        w2 = 0;
+                        ++o2;
+                    }
+                }
+            }
+        }
+        // advance to the next K-tile of this workgroup
+        kpos += TK;
+        const int clen = pend - (cur_chunk - n * chunks_per_image) * chunk_pixels;
+        if (kpos >= clen) {
+            kpos = 0;
+            cur_chunk += gridDim.z;
+            more = cur_chunk < total_chunks;
+        }
+    };
+
+    auto store_tile = [&](int buf) {
+        bf16x8 a0, a1, b0, b1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            a0[e] = (__bf16)ra[0][e];
+            a0[4 + e] = (__bf16)ra[1][e];
+            a1[e] = (__bf16)ra[2][e];
+            a1[4 + e] = (__bf16)ra[3][e];
+            b0[e] = (__bf16)rb[0][e];
+            b0[4 + e] = (__bf16)rb[1][e];
+            b1[e] = (__bf16)rb[2][e];
+            b1[4 + e] = (__bf16)rb[3][e];
+        }
+        *reinterpret_cast<bf16x8 *>(&As[buf][row][half * 16]) = a0;
+        *reinterpret_cast<bf16x8 *>(&As[buf][row][half * 16 + 8]) = a1;
+        *reinterpret_cast<bf16x8 *>(&Bs[buf][row][half * 16]) = b0;
+        *reinterpret_cast<bf16x8 *>(&Bs[buf][row][half * 16 + 8]) = b1;
+    };
+
+    if (!more) return;                                  // uniform: no share of the reduction
+    load_tile();
+    store_tile(0);
+    __syncthreads();
+    int cur = 0;
+    while (true) {
+        const bool have_next = more;
+        if (have_next) load_tile();
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 af[2], bfr[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                af[i] = *reinterpret_cast<const bf16x8 *>(&As[cur][wm * 64 + i * 32 + l31][ks * 16 + lh * 8]);
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                bfr[j] = *reinterpret_cast<const bf16x8 *>(&Bs[cur][wn * 64 + j * 32 + l31][ks * 16 + lh * 8]);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+        if (!have_next) break;
+        store_tile(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // dW[m][tap][ci]: lanes run over ci (contiguous) -> coalesced fp32 atomics
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int ci = ci0 + wn * 64 + j * 32 + l31;
+        if (ci >= g.Cin) continue;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int mb = m0 + wm * 64 + i * 32 + 4 * lh;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = mb + (e & 3) + 8 * (e >> 2);
+                if (m < g.Cout) atomicAdd(dw + ((size_t)m * RS + tap) * g.Cin + ci, acc[i][j][e]);
+            }
+        }
+    }
+}
+
+int make_geom(Geom &g, int N, int Cin, int H, int W, int Cout, int R, int S, int sh, int sw, int ph, int pw,
+              int out_h, int out_w)
+{
+    FI_REQUIRE(N >= 1 && Cin >= 1 && H >= 1 && W >= 1 && Cout >= 1 && R >= 1 && S >= 1, "sizes must be positive");
+    FI_REQUIRE(sh >= 1 && sw >= 1 && ph >= 0 && pw >= 0, "bad stride / padding");
+    g = Geom{};
+    g.N = N; g.Cin = Cin; g.H = H; g.W = W; g.Cout = Cout; g.R = R; g.S = S;
+    g.sh = sh; g.sw = sw; g.ph = ph; g.pw = pw;
+    g.OH = out_h > 0 ? out_h : (H + 2 * ph - R) / sh + 1;
+    g.OW = out_w > 0 ? out_w : (W + 2 * pw - S) / sw + 1;
+    FI_REQUIRE(g.OH >= 1 && g.OW >= 1, "empty output");
+    FI_REQUIRE((long)N * g.OH * g.OW < 2147483647L, "too many output pixels");
+    g.P = N * g.OH * g.OW;
+    return FI_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int fi_conv2d_forward_bf16(const float *x, const float *weight, const float *bias, const float *scale,
+                           const float *residual, float *y, int N, int Cin, int H, int W, int Cout, int R,
+                           int S, int stride_h, int stride_w, int pad_h, int pad_w, int relu,
+                           int weight_layout, int out_h, int out_w, int output_layout, fi_stream_t stream)
+{
+    Geom g;
+    int rc = make_geom(g, N, Cin, H, W, Cout, R, S, stride_h, stride_w, pad_h, pad_w, out_h, out_w);
+    if (rc != FI_OK) return rc;
+    FI_REQUIRE(x && weight && y, "null pointer");
+    if (Cin % TK != 0 || !(weight_layout == 1 || weight_layout == 2 || R * S == 1)) {
+        fi::set_error("the bf16 path needs Cin %% 32 == 0 and tap-major weights (got Cin = %d, layout %d)", Cin,
+                      weight_layout);
+        return FI_ERR_UNSUPPORTED;
+    }
+    FI_REQUIRE(output_layout == 0 || (Cout % 4 == 0 && residual == nullptr && (uintptr_t)y % 16 == 0),
+               "channels-last output needs Cout % 4 == 0, a 16-byte aligned y and no fused residual");
+    FI_REQUIRE(((uintptr_t)weight % 16) == 0, "weights must be 16-byte aligned");
+    g.flip = weight_layout == 2;
+    g.out_nhwc = output_layout == 1;
+    const Epi ep = {bias, scale, residual, relu};
+    hipStream_t st = (hipStream_t)stream;
+    const int ptiles = fi::ceil_div(g.P, TN);
+    FI_REQUIRE(ptiles <= 65535, "too many pixel tiles");
+    fi::ProfScope prof(FI_K_CONV_BF16_FWD, st);
+    if (Cout <= 64) {
+        hipLaunchKernelGGL(conv_bf16_fwd_kernel<64>, dim3(fi::ceil_div(Cout, 64), ptiles), dim3(kThreads), 0, st, x, weight,
+                           ep, y, g);
+    } else {
+        hipLaunchKernelGGL(conv_bf16_fwd_kernel<128>, dim3(fi::ceil_div(Cout, 128), ptiles), dim3(kThreads), 0, st, x,
+                           weight, ep, y, g);
+    }
+    FI_HIP_CHECK(hipGetLastError());
+    return FI_OK;
+}
+
+int fi_conv2d_weight_grad_bf16(const float *x, const float *dy, float *dweight, int N, int Cin, int H, int W,
+                               int Cout, int R, int S, int stride_h, int stride_w, int pad_h, int pad_w,
+                               int flags, fi_stream_t stream)
+{
+    Geom g;
+    int rc = make_geom(g, N, Cin, H, W, Cout, R, S, stride_h, stride_w, pad_h, pad_w, 0, 0);
+    if (rc != FI_OK) return rc;
+    FI_REQUIRE(x && dy && dweight, "null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const int RS = R * S;
+    if (!(flags & FI_OUTPUTS_ZEROED))
+        FI_HIP_CHECK(hipMemsetAsync(dweight, 0, sizeof(float) * (size_t)Cout * RS * Cin, st));
+    const int OHW = g.OH * g.OW;
+    const int mt = fi::ceil_div(Cout, 128), cin_tiles = fi::ceil_div(Cin, TN);
+    const long tiles = (long)mt * RS * cin_tiles;
+    // split the reduction (N images x chunks of pixels) so that ~2048 workgroups exist; a chunk is a
+    // multiple of 32 pixels and never crosses an image
+    long want = 2048 / tiles;
+    if (want < 1) want = 1;
+    int chunks_per_image = 1;
+    if (want > N) chunks_per_image = (int)((want + N - 1) / N);
+    int chunk_pixels = fi::ceil_div(fi::ceil_div(OHW, chunks_per_image), TK) * TK;
+    if (chunk_pixels < 4 * TK) chunk_pixels = 4 * TK;
+    chunks_per_image = fi::ceil_div(OHW, chunk_pixels);
+    long z = (long)N * chunks_per_image;
+    if (z > want) z = want;
+    if (z > 65535) z = 65535;
+    FI_REQUIRE((long)RS * cin_tiles <= 65535, "too many (tap, ci) tiles");
+    fi::ProfScope prof(FI_K_CONV_BF16_WGRAD, st);
+    hipLaunchKernelGGL(conv_bf16_wgrad_kernel, dim3(mt, RS * cin_tiles, (unsigned)z), dim3(kThreads), 0, st, x, dy,
+                       dweight, g, cin_tiles, chunks_per_image, chunk_pixels);
+    FI_HIP_CHECK(hipGetLastError());
+    return FI_OK;
+}
+
+}  // extern "C"

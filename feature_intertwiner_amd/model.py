@@ -7,7 +7,7 @@ import torch
 import torch.nn as nn
 
 from ._lib import const_tensor
-from .conv import prepare_step
+from .conv import conv_precision, prepare_step, set_conv_precision
 from .intertwiner import FeatureBuffer, meta_loss
 from .layers import (compute_mrcnn_bbox_loss, compute_mrcnn_class_loss, compute_mrcnn_mask_loss_unshuffled,
                      compute_rpn_bbox_loss, compute_rpn_class_loss, detection_layer, generate_pyramid_priors,
@@ -69,6 +69,17 @@ class MaskRCNN(nn.Module):
 
     # ------------------------------------------------------------------ forward (train)
     def forward(self, input, mode='train'):
+        """Runs _forward with the convolution arithmetic this model is configured for
+        (config.MODEL.CONV_PRECISION); the process-wide setting is restored afterwards (the backward pass
+        of every layer uses the precision its forward ran with)."""
+        prev = conv_precision()
+        set_conv_precision(getattr(self.config.MODEL, "CONV_PRECISION", "fp32"))
+        try:
+            return self._forward(input, mode)
+        finally:
+            set_conv_precision(prev)
+
+    def _forward(self, input, mode='train'):
         """input = [images [b,3,S,S], gt_class_ids [b,G], gt_boxes [b,G,4] pixels, gt_masks [b,G,56,56]].
         Returns (loss_merge [1,5], big_feat, big_cnt, small_feat, small_cnt, big_loss,
         small_output_all, small_gt_all, fpn_ot_loss) as lib/model.py:466-469."""

@@ -286,6 +286,23 @@ int fi_weight_transpose_batch(const FiTransposeDesc *descs_dev, int n, long tota
                               fi_stream_t stream);
 
 /* ------------------------------------------------------------------------
+ * bf16-input, fp32-accumulate variants (v_mfma_f32_32x32x16_bf16) for BASELINE configs[4]'s reduced-
+ * precision conv path.  Same tensors as above (fp32 in memory, operands rounded to bf16 on their way into
+ * LDS); selected by configuration, never by the fp32 headline.  fi_conv2d_forward_bf16 takes the
+ * arguments of fi_conv2d_forward and needs Cin % 32 == 0 with tap-major weights (weight_layout 1 or 2;
+ * FI_ERR_UNSUPPORTED otherwise -- callers fall back to the fp32 kernel, e.g. for the 3-channel stem).
+ * fi_conv2d_weight_grad_bf16 writes dweight tap-major [Cout][R][S][Cin] (any sizes / strides).
+ * ---------------------------------------------------------------------- */
+int fi_conv2d_forward_bf16(const float *x, const float *weight, const float *bias,
+                           const float *scale, const float *residual, float *y, int N, int Cin,
+                           int H, int W, int Cout, int R, int S, int stride_h, int stride_w,
+                           int pad_h, int pad_w, int relu, int weight_layout, int out_h, int out_w,
+                           int output_layout, fi_stream_t stream);
+int fi_conv2d_weight_grad_bf16(const float *x, const float *dy, float *dweight, int N, int Cin,
+                               int H, int W, int Cout, int R, int S, int stride_h, int stride_w,
+                               int pad_h, int pad_w, int flags, fi_stream_t stream);
+
+/* ------------------------------------------------------------------------
  * In-library kernel timing (HIP events recorded on the launch stream around
  * each kernel launch while enabled).  Used by bench.py for the roofline object;
  * off by default, zero cost when off.
@@ -318,7 +335,9 @@ enum {
     FI_K_CROP_BWD_NHWC_7X7 = 34,
     FI_K_CROP_BWD_NHWC_14X14 = 35,
     FI_K_CROP_BWD_NHWC_GENERIC = 36,
-    FI_K_COUNT = 37
+    FI_K_CONV_BF16_FWD = 37,         /* bf16-input MFMA convolution (forward + data gradient) */
+    FI_K_CONV_BF16_WGRAD = 38,
+    FI_K_COUNT = 39
 };
 /* Streaming copy of n_floats floats (16 bytes per lane) with exactly known memory traffic: the
  * calibration point for rocprofv3's FETCH_SIZE / WRITE_SIZE (MI355X_MICROARCH.md, HBM section). */

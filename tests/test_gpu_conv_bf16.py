@@ -1,0 +1,150 @@
+"""bf16-input / fp32-accumulate MFMA convolution (csrc/conv_bf16.hip, BASELINE configs[4]'s reduced-
+precision conv path) against float64 torch references.
+
+Two bars per quantity:
+  * TIGHT, against the same op evaluated in float64 on operands ROUNDED TO BF16 first: the kernel rounds
+    exactly those operands and accumulates in fp32, so only fp32 summation order remains --
+    |d| <= 2e-5 * sqrt(K) * max|ref| (the bar of the exact fp32 kernel, tests/test_gpu_conv.py).  A wrong
+    MFMA operand layout, tap order or halo would miss this by orders of magnitude.
+  * LOOSE, against the unrounded float64 op: the price of bf16 operands, 2 * 2^-9 relative per product:
+    |d| <= 1.2e-2 * sqrt(K) * rms(x) * rms(w)  (stated so that the fp32-vs-bf16 gap is a documented number).
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+CASES = [
+    # N, Cin, H, W, Cout, R, S, stride, pad
+    (2, 64, 20, 24, 64, 1, 1, 1, 0),       # BM = 64 tile
+    (2, 256, 14, 14, 256, 3, 3, 1, 1),     # rows of 14: quads straddle output rows
+    (3, 64, 19, 23, 96, 3, 3, 1, 1),       # odd sizes, Cout tail, pixel tail
+    (2, 128, 12, 20, 81, 1, 1, 1, 0),      # Cout = 81 (mask conv5)
+    (2, 256, 13, 17, 128, 1, 1, 2, 0),     # 1x1 stride 2 (scalar gather path)
+    (2, 256, 14, 14, 512, 3, 3, 2, 1),     # 3x3 stride 2
+    (1, 32, 9, 8, 40, 5, 5, 1, 2),         # generic window
+    (4, 96, 8, 8, 130, 3, 3, 1, 1),        # Cin = 3 K-tiles per tap
+    (1, 1024, 8, 8, 256, 1, 1, 1, 0),      # long K
+]
+
+
+def _bf(t):
+    return t.to(torch.bfloat16).double()
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_bf16_conv_forward_backward(case):
+    from feature_intertwiner_amd import conv as C
+    N, Cin, H, W, Cout, R, S, st, pd = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, R, S, generator=g) / math.sqrt(Cin * R * S)
+    b = torch.randn(Cout, generator=g)
+    gy = torch.randn(N, Cout, (H + 2 * pd - R) // st + 1, (W + 2 * pd - S) // st + 1, generator=g)
+
+    def ref(xd, wd, gyd):
+        xd, wd = xd.clone().requires_grad_(True), wd.clone().requires_grad_(True)
+        y = F.conv2d(xd, wd, b.double(), stride=st, padding=pd)
+        return y.detach(), xd, wd, y
+    # forward reference on bf16-rounded operands; gradient references with the operands THEIR kernel rounds:
+    # dX = conv_T(bf16(dY), bf16(W)),  dW = corr(bf16(dY), bf16(X))
+    y_t = F.conv2d(_bf(x), _bf(w), b.double(), stride=st, padding=pd)
+    xd = _bf(x).requires_grad_(True)
+    wd = _bf(w).requires_grad_(True)
+    F.conv2d(xd, wd, None, stride=st, padding=pd).backward(_bf(gy))
+    y_full = F.conv2d(x.double(), w.double(), b.double(), stride=st, padding=pd)
+
+    C.set_conv_precision("bf16")
+    try:
+        xg = x.to(DEV).requires_grad_(True)
+        wg = w.to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)   # as parameters are stored
+        bg = b.to(DEV).requires_grad_(True)
+        C.FLOP_LOG = {}
+        y = C.conv2d(xg, wg, bg, (st, st), (pd, pd))
+        y.backward(gy.to(DEV))
+        used = dict(C.FLOP_LOG)
+    finally:
+        C.set_conv_precision("fp32")
+        C.FLOP_LOG = None
+    assert "conv_bf16_fwd" in used and "conv_bf16_wgrad" in used, used        # the bf16 kernels really ran
+    K = Cin * R * S
+    tight = lambda r, k: 2e-5 * math.sqrt(k) * (r.abs().max().item() + 1e-6)
+    assert (y.detach().cpu().double() - y_t).abs().max().item() <= tight(y_t, K)
+    if Cout % 32 == 0:
+        assert (xg.grad.cpu().double() - xd.grad).abs().max().item() <= tight(xd.grad, Cout * R * S)
+    else:
+        # the data gradient contracts over Cout: not a multiple of 32 -> the exact fp32 kernel ran (unrounded)
+        xf, wf = x.double().requires_grad_(True), w.double()
+        F.conv2d(xf, wf, None, stride=st, padding=pd).backward(gy.double())
+        assert (xg.grad.cpu().double() - xf.grad).abs().max().item() <= tight(xf.grad, Cout * R * S)
+    P = N * gy.shape[2] * gy.shape[3]
+    assert (wg.grad.cpu().double() - wd.grad).abs().max().item() <= tight(wd.grad, P)
+    assert (bg.grad.cpu().double() - gy.double().sum((0, 2, 3))).abs().max().item() <= tight(gy.double().sum((0, 2, 3)), P)
+    # the documented cost of bf16 operands
+    loose = 1.2e-2 * math.sqrt(K) * x.double().pow(2).mean().sqrt().item() * w.double().pow(2).mean().sqrt().item()
+    assert (y.detach().cpu().double() - y_full).abs().max().item() <= loose
+
+
+def test_bf16_fused_epilogue_and_layouts():
+    """conv + eval-BN + shortcut + ReLU in the bf16 kernel (NCHW) and the channels-last output used by the
+    Dev make-up layer; values equal the fp32 kernel run on bf16-rounded operands."""
+    from feature_intertwiner_amd import conv as C
+    torch.manual_seed(5)
+    conv = C.Conv2d(64, 128, 3, padding=1).to(DEV)
+    bn = torch.nn.BatchNorm2d(128).to(DEV).eval()
+    with torch.no_grad():
+        bn.running_mean.normal_(0, 0.2)
+        bn.running_var.uniform_(0.5, 1.5)
+        bn.weight.normal_(1, 0.1)
+        bn.bias.normal_(0, 0.1)
+    x = torch.randn(2, 64, 18, 22, device=DEV)
+    res = torch.randn(2, 128, 18, 22, device=DEV)
+    rounded = C.Conv2d(64, 128, 3, padding=1).to(DEV)
+    with torch.no_grad():
+        rounded.weight.copy_(conv.weight.to(torch.bfloat16).float())
+        rounded.bias.copy_(conv.bias)
+    xr = x.to(torch.bfloat16).float()
+    with torch.no_grad():
+        exp = C.conv_bn_act(xr, rounded, bn, relu=True, residual=res)                     # exact fp32 kernel
+        exp_cl = C.conv_bn_act(xr, rounded, bn, relu=True, channels_last_out=True)
+        C.set_conv_precision("bf16")
+        try:
+            got = C.conv_bn_act(x, conv, bn, relu=True, residual=res)
+            got_cl = C.conv_bn_act(x, conv, bn, relu=True, channels_last_out=True)
+        finally:
+            C.set_conv_precision("fp32")
+    assert got_cl.is_contiguous(memory_format=torch.channels_last)
+    for a, e in ((got, exp), (got_cl, exp_cl)):
+        assert (a - e).abs().max().item() <= 2e-5 * math.sqrt(64 * 9) * e.abs().max().item()
+
+
+def test_bf16_train_step_tracks_fp32():
+    """The detector's train step with the bf16 conv path: same losses as the fp32 path within the bf16
+    operand error accumulated through ~100 layers (5 % on each term), and it learns."""
+    from feature_intertwiner_amd import conv as C
+    from feature_intertwiner_amd.config import make_config
+    from feature_intertwiner_amd.model import MaskRCNN
+    from feature_intertwiner_amd.synthetic import SyntheticProposals, synthetic_batch
+    from feature_intertwiner_amd.workflow import compute_loss, set_optimizer, train_step
+    batch = synthetic_batch(2, 256, device=DEV)
+    terms = {}
+    for mode in ("fp32", "bf16"):
+        torch.manual_seed(7)
+        cfg = make_config("resnet50", 256, 2, 64, dev_switch=True, loss_choice="l2", conv_precision=mode)
+        model = MaskRCNN(cfg).to(DEV)
+        model.proposal_hook = SyntheticProposals(batch[2], 256, seed=7)
+        model.generator = torch.Generator(device=DEV).manual_seed(5)
+        with torch.no_grad():
+            _, terms[mode] = compute_loss(model, list(batch))
+        if mode == "bf16":
+            opt = set_optimizer(model, cfg.TRAIN)
+            hist = [float(train_step(model, opt, list(batch))["total"]) for _ in range(5)]
+            assert hist[-1] < hist[0] and all(math.isfinite(h) for h in hist)
+    assert C.conv_precision() == "fp32"            # the model restores the process-wide default after its pass
+    for k in ("rpn_cls", "rpn_bbox", "mrcnn_cls", "mrcnn_bbox", "mrcnn_mask"):
+        a, b = float(terms["fp32"][k]), float(terms["bf16"][k])
+        assert abs(a - b) <= 0.05 * abs(a) + 1e-3, (k, a, b)
