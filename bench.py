@@ -32,6 +32,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+BF16_MFMA_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 MFMA (the 5 PF headline figure includes 2:1 sparsity)
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 = fp32 vector peak
 
 
@@ -277,6 +278,10 @@ def main():
     ap.add_argument("--batch-per-gpu", type=int, default=4)
     ap.add_argument("--rois", type=int, default=512)
     ap.add_argument("--ot-L", type=int, default=50)
+    ap.add_argument("--config", default="cfg3", choices=["cfg3", "cfg5"],
+                    help="cfg3 = BASELINE configs[2], the headline (default); cfg5 = the single-GPU slice of BASELINE "
+                         "configs[4]: 1333x800 padded to 1344^2, 2 images/GPU, 1000 RoIs/image + mask head, bf16 MFMA convs")
+    ap.add_argument("--conv-precision", default=None, choices=["fp32", "bf16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 --pmc passes that fill roofline.traffic")
     ap.add_argument("--profile-steps", type=int, default=4,
@@ -286,6 +291,10 @@ def main():
                     help="NOT the headline configuration: run the mask head only on the RoI slots that can hold "
                          "positives (identical loss/gradients, see MaskRCNN.forward); recorded in config.variant")
     args = ap.parse_args()
+    if args.config == "cfg5":
+        args.image_size, args.batch_per_gpu, args.rois = 1344, 2, 1000
+        args.conv_precision = args.conv_precision or "bf16"
+    args.conv_precision = args.conv_precision or "fp32"
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -319,7 +328,7 @@ def main():
 
     torch.manual_seed(2000)
     cfg = make_config(args.backbone, args.image_size, args.batch_per_gpu, args.rois, dev_switch=True,
-                      loss_choice="ot", ot_L=args.ot_L, gpu_count=world)
+                      loss_choice="ot", ot_L=args.ot_L, gpu_count=world, conv_precision=args.conv_precision)
     cfg.MRCNN.MASK_HEAD_ON_POSITIVE_SLOTS = bool(args.mask_head_on_positive_slots)
     model = MaskRCNN(cfg).to(dev)
     broadcast_parameters(model)
@@ -431,12 +440,14 @@ def main():
             launches, flops = flop_log[dom[1]["_key"]]
             n, ms = _lib.prof_get(dom[1]["_key"])
             ach = flops / (ms * 1e-3) / 1e12
-            roof = {"kernel": dom[0], "bound": "mfma", "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+            peak = BF16_MFMA_PEAK_TFLOPS if "bf16" in dom[0] else FP32_MFMA_PEAK_TFLOPS
+            roof = {"kernel": dom[0], "bound": "mfma", "achieved": round(ach, 2), "peak": peak,
+                    "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
                     "algorithmic_flops_per_launch": int(flops / max(launches, 1)),
                     "avg_launch_us": round(ms / n * 1e3, 2), "launches_timed": n,
                     "share_of_step": round(dom[1]["ms_per_step"] / (prof_elapsed / prof_steps * 1e3), 4),
-                    "flops_model": "2*N*Cout*OH*OW*Cin*R*S per launch (fp32, exact MFMA)"}
+                    "flops_model": "2*N*Cout*OH*OW*Cin*R*S per launch (%s)" % (
+                        "bf16 operands, fp32 accumulation" if "bf16" in dom[0] else "fp32, exact MFMA")}
         elif roof_roi is not None:
             roof = roof_roi
         # ---- flop-weighted efficiency of the whole conv stack (every MFMA kernel instance) ----------
@@ -454,8 +465,9 @@ def main():
                                  "gflop_per_step": round(flops / prof_steps / 1e9, 1)}
             if tot_ms > 0:
                 ach = tot_f / (tot_ms * 1e-3) / 1e12
-                conv_stack = {"achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                              "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
+                cs_peak = FP32_MFMA_PEAK_TFLOPS if args.conv_precision == "fp32" else BF16_MFMA_PEAK_TFLOPS
+                conv_stack = {"achieved": round(ach, 2), "peak": cs_peak, "unit": "TFLOP/s",
+                              "frac": round(ach / cs_peak, 4),
                               "tflop_per_step": round(tot_f / prof_steps / 1e12, 3),
                               "ms_per_step": round(tot_ms / prof_steps, 2), "per_kernel": per,
                               "note": "sum of algorithmic flops / sum of kernel time over every conv_fwd (forward + "
@@ -488,7 +500,8 @@ def main():
         # ---- HBM-side traffic of the dominant kernel and of RoIAlign from the PMC counters ----------------
         if world == 1 and not args.no_pmc and roof is not None:
             child = ["--backbone", args.backbone, "--image-size", str(args.image_size), "--batch-per-gpu",
-                     str(args.batch_per_gpu), "--rois", str(args.rois), "--ot-L", str(args.ot_L)]
+                     str(args.batch_per_gpu), "--rois", str(args.rois), "--ot-L", str(args.ot_L), "--conv-precision",
+                     args.conv_precision]
             if args.mask_head_on_positive_slots:
                 child.append("--mask-head-on-positive-slots")
             subs = [roof["kernel"].split("<")[0] + "<" + roof["kernel"].split("<")[1].rstrip(">")]
@@ -517,18 +530,22 @@ def main():
             "metric": "images/sec (train step, ResNet-101-FPN 1024^2, 512 RoIs)", "value": round(value, 4),
             "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32",
+            "vs_baseline": None, "dtype": "f32" if args.conv_precision == "fp32" else "bf16 (conv operands; fp32 accumulation, fp32 elsewhere)",
             "data": "synthetic (seeded N(0,1)*64 images, 20 GT boxes/img, random-init weights, "
                     "GT-jittered proposals planted among RPN candidates before NMS)",
-            "config": {"workload": "BASELINE configs[2]: %s-FPN, %dx%d, %d images/GPU, %d RoIs/image, OT intertwiner "
+            "config": {"workload": ("BASELINE configs[2]" if args.config == "cfg3" else
+                                    "single-GPU slice of BASELINE configs[4] (1333x800 padded to a /64 multiple, SURVEY Q8)") +
+                                   ": %s-FPN, %dx%d, %d images/GPU, %d RoIs/image, OT intertwiner "
                                    "on (Sinkhorn L=%d, 256 samples, 80 classes), full train step fwd+loss+bwd+clip+SGD"
                                    % (args.backbone, args.image_size, args.image_size, args.batch_per_gpu, args.rois,
                                       args.ot_L),
                        "global_batch": global_batch, "parallelism": "dp%d" % world,
                        "variant": ("mask head on positive slots only (dead-work elimination, not the reference's "
                                    "schedule)" if args.mask_head_on_positive_slots else "reference schedule"),
-                       "conv_stack": "hand-written fp32 MFMA implicit-GEMM kernels (csrc/conv_igemm.hip); "
-                                     "full-window convs and nn.Linear on the library GEMM"},
+                       "conv_stack": ("hand-written fp32 MFMA implicit-GEMM kernels (csrc/conv_igemm.hip)" if
+                                      args.conv_precision == "fp32" else "hand-written bf16-input / fp32-accumulate MFMA "
+                                      "kernels (csrc/conv_bf16.hip; layers with Cin % 32 != 0 on the fp32 kernels)") +
+                                     "; full-window convs and nn.Linear on the library GEMM"},
             "losses": {k: round(float(v), 5) for k, v in terms.items()},
             "roofline": roof, "roofline_roialign": roof_roi, "conv_stack": conv_stack, "nms": nms_obj, "sinkhorn": sk_obj,
             "timing": {"timed_region": "%d steps, no event recording / logging" % args.steps,

@@ -61,23 +61,44 @@ __device__ __forceinline__ bf16x2 pack2(float a, float b)
 // ------------------------------------------------------------------------------------------------
 // forward / data gradient
 // ------------------------------------------------------------------------------------------------
+// The GEMM's pixel axis runs over a VIRTUAL pixel space in which every output row is padded to a multiple
+// of 4 pixels: pv = ((n*OH + oh)*OWQ + qx)*4 + j, OWQ = ceil(OW/4).  A quad of 4 consecutive virtual pixels
+// then never straddles an output row, so (stride 1) its 4 taps are 4 consecutive floats of ONE input row:
+// one 16-byte load at a column clamped into the row, plus a register shift where the quad hangs over the
+// left / right halo -- no divergent per-pixel path (on 14x14 maps half of all quads touch a row end).
+// Padding pixels are computed and dropped (14 -> 16: 14 % more MFMA work on the RoI heads, 0 % on maps whose
+// width is a multiple of 4).
+__device__ __forceinline__ float pick4(const f32x4 &v, int i)
+{
+    return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w));
+}
+
 template <int BM>
-__global__ __launch_bounds__(kThreads) void conv_bf16_fwd_kernel(const float *__restrict__ x,
+__global__ __launch_bounds__(kThreads, 2) void conv_bf16_fwd_kernel(const float *__restrict__ x,
                                                                  const float *__restrict__ w, Epi ep,
-                                                                 float *__restrict__ y, Geom g)
+                                                                 float *__restrict__ y, Geom g, int mtiles,
+                                                                 int ptiles)
 {
     constexpr int MT = BM / 64;
     __shared__ __align__(16) __bf16 As[2][BM][LP];
     __shared__ __align__(16) __bf16 Bs[2][TN][LP];
 
+    // XCD-aware tile order: block b runs on XCD b % 8; the Cout tiles of one pixel tile follow each other on
+    // the same XCD, so the activation tile is fetched into ONE L2 and re-read there
+    const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
+    const int pt = (seq / mtiles) * 8 + xcd;
+    if (pt >= ptiles) return;
+    const int m0 = (seq % mtiles) * BM;
+    const int p0 = pt * TN;
+
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int l31 = lane & 31, lh = lane >> 5;
-    const int m0 = blockIdx.x * BM;
-    const int p0 = blockIdx.y * TN;
     const int RS = g.R * g.S;
     const int OHW = g.OH * g.OW;
+    const int OWQ = (g.OW + 3) >> 2;
+    const int PV = g.N * g.OH * OWQ * 4;                     // virtual pixels
     const size_t HW = (size_t)g.H * g.W;
 
     // ---- A loader: thread -> (row, 16-float half of the 32-wide K slice) --------------------------
@@ -86,22 +107,23 @@ __global__ __launch_bounds__(kThreads) void conv_bf16_fwd_kernel(const float *__
     const int a_m = min(m0 + a_row, g.Cout - 1);             // rows past Cout re-read the last row
     const float *__restrict__ a_src = w + (size_t)a_m * RS * g.Cin + a_half * 16;
 
-    // ---- B loader: thread -> (channel pair kp, pixel quad q); two quads per thread ----------------
+    // ---- B loader: thread -> (channel pair kp, quads q0 and q0 + 16 of the tile) ------------------
     const int kp = tid >> 4;                                 // 0..15 -> channels 2kp, 2kp+1 of the slice
-    const int q0 = tid & 15;                                 // quads q0 and q0 + 16
-    int b_n[2], b_oh[2], b_ow[2], b_cnt[2];
-    size_t b_base[2];
+    const int q0 = tid & 15;
+    int b_oh[2], b_ow[2], b_ok[2];
+    const float *b_img[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-        const int p = p0 + 4 * (q0 + 16 * u);
-        b_cnt[u] = max(0, min(4, g.P - p));                  // pixels of the quad that exist
-        const int pc = min(p, g.P - 1);
-        const int n = pc / OHW, rem = pc - n * OHW;
-        b_n[u] = n;
-        b_oh[u] = rem / g.OW;
-        b_ow[u] = rem - b_oh[u] * g.OW;
-        b_base[u] = (size_t)n * g.Cin * HW;
+        const int pv = p0 + 4 * (q0 + 16 * u);
+        b_ok[u] = pv < PV;
+        const int quad = min(pv, PV - 4) >> 2;               // (n*OH + oh)*OWQ + qx
+        const int row = quad / OWQ;
+        b_ow[u] = (quad - row * OWQ) * 4;
+        const int n = row / g.OH;
+        b_oh[u] = row - n * g.OH;
+        b_img[u] = x + (size_t)n * g.Cin * HW + (size_t)(2 * kp) * HW;
     }
+    const bool fast = (g.sw == 1) && (g.W >= 4);
 
     f32x16 acc[MT][2];
 #pragma unroll
@@ -111,68 +133,64 @@ __global__ __launch_bounds__(kThreads) void conv_bf16_fwd_kernel(const float *__
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
-    f32x4 ra[4];               // A: 16 consecutive k of one row
-    f32x4 rb[2][2];            // B: [quad][channel of the pair] 4 pixels
     const int cblocks = g.Cin / TK;
     const int ktiles = RS * cblocks;
 
-    auto load_tile = [&](int kt) {
+    struct Regs {
+        f32x4 a[4];            // A: 16 consecutive k of one row
+        f32x4 b[2][2];         // B: [quad][channel of the pair] 4 pixels (raw 16-byte loads)
+        int d[2];              // B: column shift of the quad's load (0 inside the row) / -99: all zero
+    };
+
+    auto load_tile = [&](int kt, Regs &R) {
         const int tap = kt / cblocks;
         const int c0 = (kt - tap * cblocks) * TK;
         const int wt = g.flip ? (RS - 1 - tap) : tap;
         if (a_on) {
             const float *pa = a_src + (size_t)wt * g.Cin + c0;
 #pragma unroll
-            for (int v = 0; v < 4; ++v) ra[v] = *reinterpret_cast<const f32x4 *>(pa + 4 * v);
+            for (int v = 0; v < 4; ++v) R.a[v] = *reinterpret_cast<const f32x4 *>(pa + 4 * v);
         }
         const int r = tap / g.S, s = tap - r * g.S;
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            const int ih = b_oh[u] * g.sh - g.ph + r;
-            const int iw = b_ow[u] * g.sw - g.pw + s;
-            const float *px = x + b_base[u] + (size_t)(c0 + 2 * kp) * HW;
-            const bool same_row = (b_ow[u] + 3 < g.OW) && b_cnt[u] == 4;
-            if (g.sw == 1 && same_row && ih >= 0 && ih < g.H && iw >= 0 && iw + 3 < g.W) {
-                const float *p = px + (size_t)ih * g.W + iw;
-                rb[u][0] = *reinterpret_cast<const f32x4_a4 *>(p);
-                rb[u][1] = *reinterpret_cast<const f32x4_a4 *>(p + HW);
+            const float *px = b_img[u] + (size_t)c0 * HW;
+            if (fast) {
+                const int ih = b_oh[u] - g.ph + r;
+                const int iw0 = b_ow[u] - g.pw + s;
+                const int iwc = min(max(iw0, 0), g.W - 4);
+                const bool row_ok = b_ok[u] && ih >= 0 && ih < g.H && iw0 > -4 && iw0 < g.W;
+                const float *p = px + (size_t)min(max(ih, 0), g.H - 1) * g.W + iwc;
+                R.b[u][0] = *reinterpret_cast<const f32x4_a4 *>(p);
+                R.b[u][1] = *reinterpret_cast<const f32x4_a4 *>(p + HW);
+                R.d[u] = row_ok ? (iw0 - iwc) : -99;
             } else {
-                // quad straddling an output row / the halo / the end of the pixel range, or a strided layer
-                int oh = b_oh[u], ow = b_ow[u], n = b_n[u];
+                // strided layers / maps narrower than 4: guarded scalar gather
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     float v0 = 0.0f, v1 = 0.0f;
-                    if (j < b_cnt[u]) {
-                        const int ihj = oh * g.sh - g.ph + r, iwj = ow * g.sw - g.pw + s;
-                        if (ihj >= 0 && ihj < g.H && iwj >= 0 && iwj < g.W) {
-                            const float *p = x + (size_t)n * g.Cin * HW + (size_t)(c0 + 2 * kp) * HW + (size_t)ihj * g.W + iwj;
-                            v0 = p[0];
-                            v1 = p[HW];
-                        }
+                    const int ih = b_oh[u] * g.sh - g.ph + r, iw = (b_ow[u] + j) * g.sw - g.pw + s;
+                    if (b_ok[u] && b_ow[u] + j < g.OW && ih >= 0 && ih < g.H && iw >= 0 && iw < g.W) {
+                        v0 = px[(size_t)ih * g.W + iw];
+                        v1 = px[HW + (size_t)ih * g.W + iw];
                     }
-                    rb[u][0][j] = v0;
-                    rb[u][1][j] = v1;
-                    if (++ow == g.OW) {
-                        ow = 0;
-                        if (++oh == g.OH) {
-                            oh = 0;
-                            ++n;
-                        }
-                    }
+                    R.b[u][0][j] = v0;
+                    R.b[u][1][j] = v1;
                 }
+                R.d[u] = 0;
             }
         }
     };
 
-    auto store_tile = [&](int buf) {
+    auto store_tile = [&](int buf, const Regs &R) {
         if (a_on) {
             bf16x8 lo, hi;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                lo[e] = (__bf16)ra[0][e];
-                lo[4 + e] = (__bf16)ra[1][e];
-                hi[e] = (__bf16)ra[2][e];
-                hi[4 + e] = (__bf16)ra[3][e];
+                lo[e] = (__bf16)R.a[0][e];
+                lo[4 + e] = (__bf16)R.a[1][e];
+                hi[e] = (__bf16)R.a[2][e];
+                hi[4 + e] = (__bf16)R.a[3][e];
             }
             *reinterpret_cast<bf16x8 *>(&As[buf][a_row][a_half * 16]) = lo;
             *reinterpret_cast<bf16x8 *>(&As[buf][a_row][a_half * 16 + 8]) = hi;
@@ -180,18 +198,27 @@ __global__ __launch_bounds__(kThreads) void conv_bf16_fwd_kernel(const float *__
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int prow = 4 * (q0 + 16 * u);
+            f32x4 c0v = R.b[u][0], c1v = R.b[u][1];
+            const int d = R.d[u];
+            if (d != 0) {                                   // quad over a row end (or entirely outside)
+                f32x4 t0, t1;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int k = j + d;                    // source element; outside 0..3 <=> outside the row
+                    const bool ok = (unsigned)k < 4u;
+                    t0[j] = ok ? pick4(c0v, k) : 0.0f;
+                    t1[j] = ok ? pick4(c1v, k) : 0.0f;
+                }
+                c0v = t0;
+                c1v = t1;
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                *reinterpret_cast<bf16x2 *>(&Bs[buf][prow + j][2 * kp]) = pack2(rb[u][0][j], rb[u][1][j]);
+                *reinterpret_cast<bf16x2 *>(&Bs[buf][prow + j][2 * kp]) = pack2(c0v[j], c1v[j]);
         }
     };
 
-    load_tile(0);
-    store_tile(0);
-    __syncthreads();
-    for (int kt = 0; kt < ktiles; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < ktiles) load_tile(kt + 1);
+    auto mma = [&](int cur) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             bf16x8 af[MT], bfr[2];
@@ -207,16 +234,42 @@ __global__ __launch_bounds__(kThreads) void conv_bf16_fwd_kernel(const float *__
                 for (int j = 0; j < 2; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
         }
-        if (kt + 1 < ktiles) store_tile(cur ^ 1);
+    };
+
+    // Two K-tiles of global loads in flight (register sets R0 / R1), two LDS buffers: while tile t is in the
+    // MFMAs, tile t+1 sits in registers waiting to be converted and tile t+2's loads are being issued.
+    Regs R0, R1;
+    load_tile(0, R0);
+    if (ktiles > 1) load_tile(1, R1);
+    store_tile(0, R0);
+    __syncthreads();
+    for (int kt = 0; kt < ktiles; kt += 2) {
+        // even tile: LDS buffer 0; R1 holds tile kt+1; R0 is free for tile kt+2
+        if (kt + 2 < ktiles) load_tile(kt + 2, R0);
+        mma(0);
+        if (kt + 1 < ktiles) store_tile(1, R1);
+        __syncthreads();
+        // odd tile: LDS buffer 1; R0 holds tile kt+2; R1 is free for tile kt+3
+        if (kt + 1 < ktiles) {
+            if (kt + 3 < ktiles) load_tile(kt + 3, R1);
+            mma(1);
+            if (kt + 2 < ktiles) store_tile(0, R0);
+        }
         __syncthreads();
     }
 
     // ---- epilogue: C/D layout col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5) ---------
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        const int p = p0 + wn * 64 + j * 32 + l31;
-        if (p >= g.P) continue;
-        const int n = p / OHW, rem = p - n * OHW;
+        const int pv = p0 + wn * 64 + j * 32 + l31;
+        if (pv >= PV) continue;
+        const int quad = pv >> 2;
+        const int row = quad / OWQ;
+        const int ow = (quad - row * OWQ) * 4 + (pv & 3);
+        if (ow >= g.OW) continue;                                        // padding pixel of the virtual space
+        const int n = row / g.OH;
+        const int rem = (row - n * g.OH) * g.OW + ow;
+        const size_t p = (size_t)n * OHW + rem;
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
             const int mb = m0 + wm * (BM / 2) + i * 32 + 4 * lh;
@@ -234,7 +287,7 @@ __global__ __launch_bounds__(kThreads) void conv_bf16_fwd_kernel(const float *__
                         if (ep.relu) t = fmaxf(t, 0.0f);
                         v[e] = t;
                     }
-                    *reinterpret_cast<f32x4 *>(y + (size_t)p * g.Cout + m) = v;
+                    *reinterpret_cast<f32x4 *>(y + p * g.Cout + m) = v;
                 }
             } else {
 #pragma unroll
@@ -453,15 +506,20 @@ int fi_conv2d_forward_bf16(const float *x, const float *weight, const float *bia
     g.out_nhwc = output_layout == 1;
     const Epi ep = {bias, scale, residual, relu};
     hipStream_t st = (hipStream_t)stream;
-    const int ptiles = fi::ceil_div(g.P, TN);
-    FI_REQUIRE(ptiles <= 65535, "too many pixel tiles");
+    const long pv = (long)g.N * g.OH * ((g.OW + 3) / 4) * 4;          // virtual pixel space (rows padded to quads)
+    FI_REQUIRE(pv < 2147483647L, "too many output pixels");
+    const int ptiles = fi::ceil_div((int)pv, TN);
+    const int bm = Cout <= 64 ? 64 : 128;
+    const int mtiles = fi::ceil_div(Cout, bm);
+    const long grid = (long)mtiles * fi::ceil_div(ptiles, 8) * 8;
+    FI_REQUIRE(grid < 2147483647L, "grid too large");
     fi::ProfScope prof(FI_K_CONV_BF16_FWD, st);
-    if (Cout <= 64) {
-        hipLaunchKernelGGL(conv_bf16_fwd_kernel<64>, dim3(fi::ceil_div(Cout, 64), ptiles), dim3(kThreads), 0, st, x, weight,
-                           ep, y, g);
+    if (bm == 64) {
+        hipLaunchKernelGGL(conv_bf16_fwd_kernel<64>, dim3((unsigned)grid), dim3(kThreads), 0, st, x, weight, ep, y, g,
+                           mtiles, ptiles);
     } else {
-        hipLaunchKernelGGL(conv_bf16_fwd_kernel<128>, dim3(fi::ceil_div(Cout, 128), ptiles), dim3(kThreads), 0, st, x,
-                           weight, ep, y, g);
+        hipLaunchKernelGGL(conv_bf16_fwd_kernel<128>, dim3((unsigned)grid), dim3(kThreads), 0, st, x, weight, ep, y, g,
+                           mtiles, ptiles);
     }
     FI_HIP_CHECK(hipGetLastError());
     return FI_OK;

@@ -44,28 +44,37 @@ def timeit(fn, iters=10, warm=3):
 
 
 def main():
-    only = sys.argv[1] if len(sys.argv) > 1 else None
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    only = args[0] if args else None
+    bf16 = "--bf16" in sys.argv
     L = _lib.load()
+    prec = "bf16" if bf16 else "fp32"
     for name, N, Cin, H, W, Cout, R, st, pd in SHAPES:
         if only and only not in name:
             continue
         x = torch.randn(N, Cin, H, W, device=DEV)
         w = torch.randn(Cout, Cin, R, R, device=DEV) * 0.05
         b = torch.randn(Cout, device=DEV)
-        y = _conv_fwd(x, w, b, (st, st), (pd, pd))
+        y = _conv_fwd(x, w, b, (st, st), (pd, pd), precision=prec)
         OH, OW = y.shape[2], y.shape[3]
         flops = 2.0 * N * Cout * OH * OW * Cin * R * R
-        t_f = timeit(lambda: _conv_fwd(x, w, b, (st, st), (pd, pd)))
+        t_f = timeit(lambda: _conv_fwd(x, w, b, (st, st), (pd, pd), precision=prec))
         dw = torch.empty_like(w)
         dy = torch.randn_like(y)
         same = st == 1 and OH == H and OW == W and (H * W) % 4 == 0 and W >= 4
         hwc = 1 if (Cin % 128 == 0 or (Cin == 64 and same)) else 0
 
+        dwt = torch.empty(Cout, R, R, Cin, device=DEV)
+
         def wg():
+            if bf16:
+                _lib.check(L.fi_conv2d_weight_grad_bf16(_lib.ptr(x), _lib.ptr(dy), _lib.ptr(dwt), N, Cin, H, W, Cout, R, R,
+                                                        st, st, pd, pd, 0, _lib.current_stream()), "wgrad")
+                return
             _lib.check(L.fi_conv2d_weight_grad(_lib.ptr(x), _lib.ptr(dy), _lib.ptr(dw), N, Cin, H, W, Cout, R, R,
                                                st, st, pd, pd, hwc, None, 0, _lib.current_stream()), "wgrad")
         t_w = timeit(wg)
-        print(json.dumps({"layer": name, "GFLOP": round(flops / 1e9, 1), "fwd_us": round(t_f * 1e6, 1),
+        print(json.dumps({"precision": prec, "layer": name, "GFLOP": round(flops / 1e9, 1), "fwd_us": round(t_f * 1e6, 1),
                           "fwd_TFLOPs": round(flops / t_f / 1e12, 1), "wgrad_us": round(t_w * 1e6, 1),
                           "wgrad_TFLOPs": round(flops / t_w / 1e12, 1)}))
 
