@@ -142,34 +142,63 @@ __global__ __launch_bounds__(kThreads, 2) void conv_bf16_fwd_kernel(const float 
         int d[2];              // B: column shift of the quad's load (0 inside the row) / -99: all zero
     };
 
-    auto load_tile = [&](int kt, Regs &R) {
-        const int tap = kt / cblocks;
-        const int c0 = (kt - tap * cblocks) * TK;
-        const int wt = g.flip ? (RS - 1 - tap) : tap;
-        if (a_on) {
-            const float *pa = a_src + (size_t)wt * g.Cin + c0;
-#pragma unroll
-            for (int v = 0; v < 4; ++v) R.a[v] = *reinterpret_cast<const f32x4 *>(pa + 4 * v);
-        }
-        const int r = tap / g.S, s = tap - r * g.S;
+    // Load cursor: K-tiles are visited tap-major, channel blocks inside a tap.  Everything that depends on
+    // the tap (input row, clamped column, halo shift, weight tap) is computed once per tap; inside a tap a
+    // tile is three pointer increments -- no index arithmetic in the steady state.
+    int cur_tap = 0, cur_cb = 0;
+    const float *pa = a_src;
+    const float *pb[2] = {b_img[0], b_img[1]};
+    int dcur[2] = {0, 0};
+    const size_t cstep = (size_t)TK * HW;
+    auto begin_tap = [&](int tap) {
+        const int r = tap / g.S, s_ = tap - r * g.S;
+        pa = a_src + (size_t)(g.flip ? (RS - 1 - tap) : tap) * g.Cin;
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            const float *px = b_img[u] + (size_t)c0 * HW;
-            if (fast) {
-                const int ih = b_oh[u] - g.ph + r;
-                const int iw0 = b_ow[u] - g.pw + s;
-                const int iwc = min(max(iw0, 0), g.W - 4);
-                const bool row_ok = b_ok[u] && ih >= 0 && ih < g.H && iw0 > -4 && iw0 < g.W;
-                const float *p = px + (size_t)min(max(ih, 0), g.H - 1) * g.W + iwc;
-                R.b[u][0] = *reinterpret_cast<const f32x4_a4 *>(p);
-                R.b[u][1] = *reinterpret_cast<const f32x4_a4 *>(p + HW);
-                R.d[u] = row_ok ? (iw0 - iwc) : -99;
-            } else {
-                // strided layers / maps narrower than 4: guarded scalar gather
+            const int ih = b_oh[u] - g.ph + r;
+            const int iw0 = b_ow[u] - g.pw + s_;
+            const int iwc = min(max(iw0, 0), g.W - 4);
+            const bool row_ok = b_ok[u] && ih >= 0 && ih < g.H && iw0 > -4 && iw0 < g.W;
+            pb[u] = b_img[u] + (size_t)min(max(ih, 0), g.H - 1) * g.W + iwc;
+            dcur[u] = row_ok ? (iw0 - iwc) : -99;
+        }
+    };
+    if (fast) begin_tap(0);
+
+    auto load_tile = [&](Regs &R) {
+        if (fast) {
+            if (a_on) {
+#pragma unroll
+                for (int v = 0; v < 4; ++v) R.a[v] = *reinterpret_cast<const f32x4 *>(pa + 4 * v);
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                R.b[u][0] = *reinterpret_cast<const f32x4_a4 *>(pb[u]);
+                R.b[u][1] = *reinterpret_cast<const f32x4_a4 *>(pb[u] + HW);
+                R.d[u] = dcur[u];
+                pb[u] += cstep;
+            }
+            pa += TK;
+            if (++cur_cb == cblocks) {
+                cur_cb = 0;
+                if (++cur_tap < RS) begin_tap(cur_tap);
+            }
+        } else {
+            // strided layers / maps narrower than 4: guarded scalar gather
+            const int tap = cur_tap, c0 = cur_cb * TK;
+            const int r = tap / g.S, s_ = tap - r * g.S;
+            if (a_on) {
+                const float *p = a_src + (size_t)(g.flip ? (RS - 1 - tap) : tap) * g.Cin + c0;
+#pragma unroll
+                for (int v = 0; v < 4; ++v) R.a[v] = *reinterpret_cast<const f32x4 *>(p + 4 * v);
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const float *px = b_img[u] + (size_t)c0 * HW;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     float v0 = 0.0f, v1 = 0.0f;
-                    const int ih = b_oh[u] * g.sh - g.ph + r, iw = (b_ow[u] + j) * g.sw - g.pw + s;
+                    const int ih = b_oh[u] * g.sh - g.ph + r, iw = (b_ow[u] + j) * g.sw - g.pw + s_;
                     if (b_ok[u] && b_ow[u] + j < g.OW && ih >= 0 && ih < g.H && iw >= 0 && iw < g.W) {
                         v0 = px[(size_t)ih * g.W + iw];
                         v1 = px[HW + (size_t)ih * g.W + iw];
@@ -179,9 +208,17 @@ __global__ __launch_bounds__(kThreads, 2) void conv_bf16_fwd_kernel(const float 
                 }
                 R.d[u] = 0;
             }
+            if (++cur_cb == cblocks) {
+                cur_cb = 0;
+                ++cur_tap;
+            }
         }
     };
 
+    // LDS rows of the B tile are PERMUTED: pixel j of quad q lives in row j*32 + q.  The four stores of a
+    // thread (one per pixel of its quad) then go, across the 64 lanes, to 16 consecutive rows x 4 channel
+    // pairs = 64 different banks (row pitch 20 dwords); the natural order 4q + j put 16 lanes on 4 banks.
+    // The MFMA column index n therefore means pixel 4*(n & 31) + (n >> 5) -- see the epilogue.
     auto store_tile = [&](int buf, const Regs &R) {
         if (a_on) {
             bf16x8 lo, hi;
@@ -197,7 +234,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_bf16_fwd_kernel(const float 
         }
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            const int prow = 4 * (q0 + 16 * u);
+            const int q = q0 + 16 * u;
             f32x4 c0v = R.b[u][0], c1v = R.b[u][1];
             const int d = R.d[u];
             if (d != 0) {                                   // quad over a row end (or entirely outside)
@@ -214,7 +251,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_bf16_fwd_kernel(const float 
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                *reinterpret_cast<bf16x2 *>(&Bs[buf][prow + j][2 * kp]) = pack2(c0v[j], c1v[j]);
+                *reinterpret_cast<bf16x2 *>(&Bs[buf][j * 32 + q][2 * kp]) = pack2(c0v[j], c1v[j]);
         }
     };
 
@@ -239,19 +276,19 @@ __global__ __launch_bounds__(kThreads, 2) void conv_bf16_fwd_kernel(const float 
     // Two K-tiles of global loads in flight (register sets R0 / R1), two LDS buffers: while tile t is in the
     // MFMAs, tile t+1 sits in registers waiting to be converted and tile t+2's loads are being issued.
     Regs R0, R1;
-    load_tile(0, R0);
-    if (ktiles > 1) load_tile(1, R1);
+    load_tile(R0);
+    if (ktiles > 1) load_tile(R1);
     store_tile(0, R0);
     __syncthreads();
     for (int kt = 0; kt < ktiles; kt += 2) {
         // even tile: LDS buffer 0; R1 holds tile kt+1; R0 is free for tile kt+2
-        if (kt + 2 < ktiles) load_tile(kt + 2, R0);
+        if (kt + 2 < ktiles) load_tile(R0);
         mma(0);
         if (kt + 1 < ktiles) store_tile(1, R1);
         __syncthreads();
         // odd tile: LDS buffer 1; R0 holds tile kt+2; R1 is free for tile kt+3
         if (kt + 1 < ktiles) {
-            if (kt + 3 < ktiles) load_tile(kt + 3, R1);
+            if (kt + 3 < ktiles) load_tile(R1);
             mma(1);
             if (kt + 2 < ktiles) store_tile(0, R0);
         }
@@ -259,48 +296,69 @@ __global__ __launch_bounds__(kThreads, 2) void conv_bf16_fwd_kernel(const float 
     }
 
     // ---- epilogue: C/D layout col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5) ---------
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int pv = p0 + wn * 64 + j * 32 + l31;
-        if (pv >= PV) continue;
+    // column n = wn*64 + j*32 + l31 is pixel 4*l31 + (2*wn + j) of the tile (row permutation above): a lane
+    // holds the two ADJACENT pixels 2*wn, 2*wn + 1 of quad l31 -> 8-byte NCHW stores
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef f32x2 f32x2_a4 __attribute__((aligned(4)));
+    {
+        const int pv = p0 + 4 * l31 + 2 * wn;
         const int quad = pv >> 2;
         const int row = quad / OWQ;
-        const int ow = (quad - row * OWQ) * 4 + (pv & 3);
-        if (ow >= g.OW) continue;                                        // padding pixel of the virtual space
+        const int ow = (quad - row * OWQ) * 4 + 2 * wn;
         const int n = row / g.OH;
         const int rem = (row - n * g.OH) * g.OW + ow;
+        const bool ok0 = pv < PV && ow < g.OW, ok1 = pv < PV && ow + 1 < g.OW;
         const size_t p = (size_t)n * OHW + rem;
+        if (ok0) {
 #pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            const int mb = m0 + wm * (BM / 2) + i * 32 + 4 * lh;
-            if (g.out_nhwc) {
+            for (int i = 0; i < MT; ++i) {
+                const int mb = m0 + wm * (BM / 2) + i * 32 + 4 * lh;
+                if (g.out_nhwc) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int m = mb + 8 * q;
-                    if (m >= g.Cout) continue;                           // Cout % 4 == 0
-                    f32x4 v;
+                    for (int j = 0; j < 2; ++j) {
+                        if (j == 1 && !ok1) continue;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float t = acc[i][j][4 * q + e];
-                        if (ep.scale) t *= ep.scale[m + e];
-                        if (ep.bias) t += ep.bias[m + e];
-                        if (ep.relu) t = fmaxf(t, 0.0f);
-                        v[e] = t;
+                        for (int q = 0; q < 4; ++q) {
+                            const int m = mb + 8 * q;
+                            if (m >= g.Cout) continue;                       // Cout % 4 == 0
+                            f32x4 v;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                float t = acc[i][j][4 * q + e];
+                                if (ep.scale) t *= ep.scale[m + e];
+                                if (ep.bias) t += ep.bias[m + e];
+                                if (ep.relu) t = fmaxf(t, 0.0f);
+                                v[e] = t;
+                            }
+                            *reinterpret_cast<f32x4 *>(y + (p + j) * g.Cout + m) = v;
+                        }
                     }
-                    *reinterpret_cast<f32x4 *>(y + p * g.Cout + m) = v;
-                }
-            } else {
+                } else {
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int m = mb + (e & 3) + 8 * (e >> 2);
-                    if (m >= g.Cout) continue;
-                    float t = acc[i][j][e];
-                    if (ep.scale) t *= ep.scale[m];
-                    if (ep.bias) t += ep.bias[m];
-                    const size_t o = ((size_t)n * g.Cout + m) * OHW + rem;
-                    if (ep.residual) t += ep.residual[o];
-                    if (ep.relu) t = fmaxf(t, 0.0f);
-                    y[o] = t;
+                    for (int e = 0; e < 16; ++e) {
+                        const int m = mb + (e & 3) + 8 * (e >> 2);
+                        if (m >= g.Cout) continue;
+                        float t0 = acc[i][0][e], t1 = acc[i][1][e];
+                        if (ep.scale) { t0 *= ep.scale[m]; t1 *= ep.scale[m]; }
+                        if (ep.bias) { t0 += ep.bias[m]; t1 += ep.bias[m]; }
+                        const size_t o = ((size_t)n * g.Cout + m) * OHW + rem;
+                        if (ok1) {
+                            if (ep.residual) {
+                                const f32x2 rr = *reinterpret_cast<const f32x2_a4 *>(ep.residual + o);
+                                t0 += rr.x;
+                                t1 += rr.y;
+                            }
+                            if (ep.relu) { t0 = fmaxf(t0, 0.0f); t1 = fmaxf(t1, 0.0f); }
+                            f32x2 v;
+                            v.x = t0;
+                            v.y = t1;
+                            *reinterpret_cast<f32x2_a4 *>(y + o) = v;
+                        } else {
+                            if (ep.residual) t0 += ep.residual[o];
+                            if (ep.relu) t0 = fmaxf(t0, 0.0f);
+                            y[o] = t0;
+                        }
+                    }
                 }
             }
         }
@@ -310,7 +368,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_bf16_fwd_kernel(const float 
 // ------------------------------------------------------------------------------------------------
 // weight gradient (tap-major dW [Cout][R*S][Cin]), stride 1 or general
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kThreads) void conv_bf16_wgrad_kernel(const float *__restrict__ x,
+__global__ __launch_bounds__(kThreads) void conv_bf16_wgrad_generic_kernel(const float *__restrict__ x,
                                                                    const float *__restrict__ dy,
                                                                    float *__restrict__ dw, Geom g,
                                                                    int cin_tiles, int chunks_per_image,
@@ -465,6 +523,198 @@ __global__ __launch_bounds__(kThreads) void conv_bf16_wgrad_kernel(const float *
     }
 }
 
+// Stride-1 weight gradient, fast form.  The reduction index runs over the same VIRTUAL pixel space as the
+// forward kernel (rows padded to quads); a K-tile is 8 consecutive quads.  Loader: thread -> (quad of the
+// tile = tid & 7, rows (tid >> 3) + 32 v): the 8 lanes of a row fetch its whole 128-byte slice of the
+// K-tile, a thread owns ONE quad, so the quad's geometry (image, row, clamped columns, halo shift) is
+// advanced incrementally once per tile -- no divisions, no per-element validity tests in the loop.
+// Both operands use the clamped 16-byte load + register shift of the forward kernel: dY where the row
+// width is not a multiple of 4, X where the tap pushes the quad over the halo.
+template <int BM, int BNC>
+__global__ __launch_bounds__(kThreads, 2) void conv_bf16_wgrad_kernel(const float *__restrict__ x,
+                                                                      const float *__restrict__ dy,
+                                                                      float *__restrict__ dw, Geom g, int cin_tiles,
+                                                                      int ktiles_total, int ktiles_per_split)
+{
+    constexpr int MT = BM / 64, NT = BNC / 64;
+    constexpr int AV = BM / 32, BV = BNC / 32;          // row passes of the loaders
+    __shared__ __align__(16) __bf16 As[2][BM][LP];       // dY  [cout][pixel]
+    __shared__ __align__(16) __bf16 Bs[2][BNC][LP];      // X   [ci][pixel]   (for one tap)
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int RS = g.R * g.S;
+    const int OHW = g.OH * g.OW;
+    const int OWQ = (g.OW + 3) >> 2;
+    const int TQ = g.N * g.OH * OWQ;                    // quads in the virtual pixel space
+    const size_t HW = (size_t)g.H * g.W;
+
+    const int m0 = blockIdx.x * BM;
+    const int tap = blockIdx.y / cin_tiles;
+    const int ci0 = (blockIdx.y - tap * cin_tiles) * BNC;
+    const int r = tap / g.S, s_ = tap - r * g.S;
+    const int kt_beg = blockIdx.z * ktiles_per_split;
+    const int kt_end = min(ktiles_total, kt_beg + ktiles_per_split);
+    if (kt_beg >= kt_end) return;
+
+    const int q = tid & 7, r0 = tid >> 3;
+    // rows this thread stages (clamped: rows past the end re-read the last row, their sums are never stored)
+    size_t a_row_off[AV], b_row_off[BV];
+#pragma unroll
+    for (int v = 0; v < AV; ++v) a_row_off[v] = (size_t)min(m0 + r0 + 32 * v, g.Cout - 1) * OHW;
+#pragma unroll
+    for (int v = 0; v < BV; ++v) b_row_off[v] = (size_t)min(ci0 + r0 + 32 * v, g.Cin - 1) * HW;
+
+    // the thread's quad: position and derived load state
+    int qn, qoh, qx;
+    {
+        const int Q = kt_beg * 8 + q;
+        const int row = Q / OWQ;
+        qx = Q - row * OWQ;
+        qn = row / g.OH;
+        qoh = row - qn * g.OH;
+    }
+    const float *pa = dy;
+    const float *pb = x;
+    int da = -99, db = -99;
+    auto locate = [&]() {
+        const bool live = qn < g.N;
+        const int n = min(qn, g.N - 1);
+        const int ow0 = 4 * qx;
+        const int owc = min(ow0, g.OW - 4);
+        pa = dy + (size_t)n * g.Cout * OHW + (size_t)qoh * g.OW + owc;
+        da = live ? (ow0 - owc) : -99;                    // elements j with j + da > 3 lie past the row end
+        const int ih = qoh - g.ph + r;
+        const int iw0 = ow0 - g.pw + s_;
+        const int iwc = min(max(iw0, 0), g.W - 4);
+        const bool ok = live && ih >= 0 && ih < g.H && iw0 > -4 && iw0 < g.W;
+        pb = x + (size_t)n * g.Cin * HW + (size_t)min(max(ih, 0), g.H - 1) * g.W + iwc;
+        db = ok ? (iw0 - iwc) : -99;
+    };
+    auto advance = [&]() {
+        qx += 8;
+        while (qx >= OWQ) {
+            qx -= OWQ;
+            if (++qoh == g.OH) {
+                qoh = 0;
+                ++qn;
+            }
+        }
+        locate();
+    };
+    locate();
+
+    struct Regs {
+        f32x4 a[AV], b[BV];
+        int da, db;
+    };
+    auto load_tile = [&](Regs &R) {
+#pragma unroll
+        for (int v = 0; v < AV; ++v) R.a[v] = *reinterpret_cast<const f32x4_a4 *>(pa + a_row_off[v]);
+#pragma unroll
+        for (int v = 0; v < BV; ++v) R.b[v] = *reinterpret_cast<const f32x4_a4 *>(pb + b_row_off[v]);
+        R.da = da;
+        R.db = db;
+        advance();
+    };
+    auto shifted = [&](const f32x4 &v, int d) {
+        f32x4 t;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = j + d;
+            t[j] = ((unsigned)k < 4u) ? pick4(v, k) : 0.0f;
+        }
+        return t;
+    };
+    auto store_tile = [&](int buf, const Regs &R) {
+        // dY: the quad may hang over the END of its row (da > 0): those pixels are padding -> zero.  A
+        // shift never brings in pixels of the previous quad: j + da >= da.
+#pragma unroll
+        for (int v = 0; v < AV; ++v) {
+            f32x4 t = R.a[v];
+            if (R.da != 0) t = shifted(t, R.da);
+            bf16x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = (__bf16)t[j];
+            *reinterpret_cast<bf16x4 *>(&As[buf][r0 + 32 * v][4 * q]) = o;
+        }
+#pragma unroll
+        for (int v = 0; v < BV; ++v) {
+            f32x4 t = R.b[v];
+            if (R.db != 0) t = shifted(t, R.db);
+            bf16x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = (__bf16)t[j];
+            *reinterpret_cast<bf16x4 *>(&Bs[buf][r0 + 32 * v][4 * q]) = o;
+        }
+    };
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+    auto mma = [&](int cur) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 af[MT], bfr[NT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+                af[i] = *reinterpret_cast<const bf16x8 *>(&As[cur][wm * (BM / 2) + i * 32 + l31][ks * 16 + lh * 8]);
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+                bfr[j] = *reinterpret_cast<const bf16x8 *>(&Bs[cur][wn * (BNC / 2) + j * 32 + l31][ks * 16 + lh * 8]);
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    // NOTE: a padding pixel of dY that is zeroed makes its whole K-column vanish, so the matching X values
+    // (whatever the clamped load fetched) do not matter.
+    const int ktiles = kt_end - kt_beg;
+    Regs R0, R1;
+    load_tile(R0);
+    if (ktiles > 1) load_tile(R1);
+    store_tile(0, R0);
+    __syncthreads();
+    for (int kt = 0; kt < ktiles; kt += 2) {
+        if (kt + 2 < ktiles) load_tile(R0);
+        mma(0);
+        if (kt + 1 < ktiles) store_tile(1, R1);
+        __syncthreads();
+        if (kt + 1 < ktiles) {
+            if (kt + 3 < ktiles) load_tile(R1);
+            mma(1);
+            if (kt + 2 < ktiles) store_tile(0, R0);
+        }
+        __syncthreads();
+    }
+
+    // dW[m][tap][ci]: lanes run over ci (contiguous) -> coalesced fp32 atomics
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int ci = ci0 + wn * (BNC / 2) + j * 32 + l31;
+        if (ci >= g.Cin) continue;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int mb = m0 + wm * (BM / 2) + i * 32 + 4 * lh;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = mb + (e & 3) + 8 * (e >> 2);
+                if (m < g.Cout) atomicAdd(dw + ((size_t)m * RS + tap) * g.Cin + ci, acc[i][j][e]);
+            }
+        }
+    }
+    (void)TQ;
+}
+
 int make_geom(Geom &g, int N, int Cin, int H, int W, int Cout, int R, int S, int sh, int sw, int ph, int pw,
               int out_h, int out_w)
 {
@@ -538,10 +788,42 @@ int fi_conv2d_weight_grad_bf16(const float *x, const float *dy, float *dweight, 
     if (!(flags & FI_OUTPUTS_ZEROED))
         FI_HIP_CHECK(hipMemsetAsync(dweight, 0, sizeof(float) * (size_t)Cout * RS * Cin, st));
     const int OHW = g.OH * g.OW;
+    fi::ProfScope prof(FI_K_CONV_BF16_WGRAD, st);
+    if (stride_h == 1 && stride_w == 1 && g.OW >= 4 && W >= 4) {
+        const int bm = Cout <= 64 ? 64 : 128, bnc = Cin <= 64 ? 64 : 128;
+        const int mt = fi::ceil_div(Cout, bm), cin_tiles = fi::ceil_div(Cin, bnc);
+        const long tiles = (long)mt * RS * cin_tiles;
+        const long tq = (long)N * g.OH * ((g.OW + 3) / 4);
+        FI_REQUIRE(tq * 4 < 2147483647L, "too many pixels");
+        const int ktiles_total = (int)((tq + 7) / 8);
+        // split the reduction so that ~2048 workgroups exist, at least 8 K-tiles each
+        long z = 2048 / tiles;
+        if (z < 1) z = 1;
+        if (z > ktiles_total / 8) z = ktiles_total / 8 > 0 ? ktiles_total / 8 : 1;
+        if (z > 65535) z = 65535;
+        const int per = fi::ceil_div(ktiles_total, (int)z);
+        z = fi::ceil_div(ktiles_total, per);
+        FI_REQUIRE((long)RS * cin_tiles <= 65535, "too many (tap, ci) tiles");
+        const dim3 grid(mt, RS * cin_tiles, (unsigned)z);
+        if (bm == 128 && bnc == 128)
+            hipLaunchKernelGGL((conv_bf16_wgrad_kernel<128, 128>), grid, dim3(kThreads), 0, st, x, dy, dweight, g, cin_tiles,
+                               ktiles_total, per);
+        else if (bm == 128)
+            hipLaunchKernelGGL((conv_bf16_wgrad_kernel<128, 64>), grid, dim3(kThreads), 0, st, x, dy, dweight, g, cin_tiles,
+                               ktiles_total, per);
+        else if (bnc == 128)
+            hipLaunchKernelGGL((conv_bf16_wgrad_kernel<64, 128>), grid, dim3(kThreads), 0, st, x, dy, dweight, g, cin_tiles,
+                               ktiles_total, per);
+        else
+            hipLaunchKernelGGL((conv_bf16_wgrad_kernel<64, 64>), grid, dim3(kThreads), 0, st, x, dy, dweight, g, cin_tiles,
+                               ktiles_total, per);
+        FI_HIP_CHECK(hipGetLastError());
+        return FI_OK;
+    }
     const int mt = fi::ceil_div(Cout, 128), cin_tiles = fi::ceil_div(Cin, TN);
     const long tiles = (long)mt * RS * cin_tiles;
-    // split the reduction (N images x chunks of pixels) so that ~2048 workgroups exist; a chunk is a
-    // multiple of 32 pixels and never crosses an image
+    // generic form (strided layers, maps narrower than 4): split the reduction (N images x chunks of pixels)
+    // so that ~2048 workgroups exist; a chunk is a multiple of 32 pixels and never crosses an image
     long want = 2048 / tiles;
     if (want < 1) want = 1;
     int chunks_per_image = 1;
@@ -553,8 +835,7 @@ int fi_conv2d_weight_grad_bf16(const float *x, const float *dy, float *dweight, 
     if (z > want) z = want;
     if (z > 65535) z = 65535;
     FI_REQUIRE((long)RS * cin_tiles <= 65535, "too many (tap, ci) tiles");
-    fi::ProfScope prof(FI_K_CONV_BF16_WGRAD, st);
-    hipLaunchKernelGGL(conv_bf16_wgrad_kernel, dim3(mt, RS * cin_tiles, (unsigned)z), dim3(kThreads), 0, st, x, dy,
+    hipLaunchKernelGGL(conv_bf16_wgrad_generic_kernel, dim3(mt, RS * cin_tiles, (unsigned)z), dim3(kThreads), 0, st, x, dy,
                        dweight, g, cin_tiles, chunks_per_image, chunk_pixels);
     FI_HIP_CHECK(hipGetLastError());
     return FI_OK;
