@@ -79,7 +79,10 @@ __global__ __launch_bounds__(kThreads, 2) void conv_bf16_fwd_kernel(const float 
                                                                  float *__restrict__ y, Geom g, int mtiles,
                                                                  int ptiles)
 {
-    constexpr int MT = BM / 64;
+    // wavefront layout: WM x WN wavefronts, each a 32 x (128 / WN) block of the tile.  BM = 128: 4 x 1 -- a
+    // lane then owns all 4 pixels of its quad (see the row permutation of the B tile), so the epilogue
+    // stores 16 bytes per lane; BM = 64: 2 x 2 (two adjacent pixels per lane).
+    constexpr int WM = BM / 32, WN = 4 / WM, NT = (TN / WN) / 32;
     __shared__ __align__(16) __bf16 As[2][BM][LP];
     __shared__ __align__(16) __bf16 Bs[2][TN][LP];
 
@@ -93,7 +96,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_bf16_fwd_kernel(const float 
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave - wm * WN;
     const int l31 = lane & 31, lh = lane >> 5;
     const int RS = g.R * g.S;
     const int OHW = g.OH * g.OW;
@@ -125,13 +128,11 @@ __global__ __launch_bounds__(kThreads, 2) void conv_bf16_fwd_kernel(const float 
     }
     const bool fast = (g.sw == 1) && (g.W >= 4);
 
-    f32x16 acc[MT][2];
+    f32x16 acc[NT];
 #pragma unroll
-    for (int i = 0; i < MT; ++i)
+    for (int j = 0; j < NT; ++j)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+        for (int e = 0; e < 16; ++e) acc[j][e] = 0.0f;
 
     const int cblocks = g.Cin / TK;
     const int ktiles = RS * cblocks;
@@ -258,18 +259,14 @@ __global__ __launch_bounds__(kThreads, 2) void conv_bf16_fwd_kernel(const float 
     auto mma = [&](int cur) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 af[MT], bfr[2];
+            bf16x8 bfr[NT];
+            const bf16x8 af = *reinterpret_cast<const bf16x8 *>(&As[cur][wm * 32 + l31][ks * 16 + lh * 8]);
 #pragma unroll
-            for (int i = 0; i < MT; ++i)
-                af[i] = *reinterpret_cast<const bf16x8 *>(&As[cur][wm * (BM / 2) + i * 32 + l31][ks * 16 + lh * 8]);
+            for (int j = 0; j < NT; ++j)
+                bfr[j] = *reinterpret_cast<const bf16x8 *>(&Bs[cur][wn * (TN / WN) + j * 32 + l31][ks * 16 + lh * 8]);
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
-                bfr[j] = *reinterpret_cast<const bf16x8 *>(&Bs[cur][wn * 64 + j * 32 + l31][ks * 16 + lh * 8]);
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < NT; ++j)
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr[j], acc[j], 0, 0, 0);
         }
     };
 
@@ -296,67 +293,82 @@ __global__ __launch_bounds__(kThreads, 2) void conv_bf16_fwd_kernel(const float 
     }
 
     // ---- epilogue: C/D layout col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5) ---------
-    // column n = wn*64 + j*32 + l31 is pixel 4*l31 + (2*wn + j) of the tile (row permutation above): a lane
-    // holds the two ADJACENT pixels 2*wn, 2*wn + 1 of quad l31 -> 8-byte NCHW stores
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
-    typedef f32x2 f32x2_a4 __attribute__((aligned(4)));
+    // column n = wn*(128/WN) + j*32 + l31 is pixel 4*l31 + (NT*wn + j) of the tile (row permutation above): a
+    // lane holds NT ADJACENT pixels of quad l31 -> one 16-byte (NT = 4) or 8-byte (NT = 2) NCHW store
     {
-        const int pv = p0 + 4 * l31 + 2 * wn;
+        const int jx0 = NT * wn;
+        const int pv = p0 + 4 * l31 + jx0;
         const int quad = pv >> 2;
         const int row = quad / OWQ;
-        const int ow = (quad - row * OWQ) * 4 + 2 * wn;
+        const int ow = (quad - row * OWQ) * 4 + jx0;
         const int n = row / g.OH;
         const int rem = (row - n * g.OH) * g.OW + ow;
-        const bool ok0 = pv < PV && ow < g.OW, ok1 = pv < PV && ow + 1 < g.OW;
+        const int nvalid = pv < PV ? min(NT, g.OW - ow) : 0;            // pixels of this lane inside the row
         const size_t p = (size_t)n * OHW + rem;
-        if (ok0) {
+        const int mb = m0 + wm * 32 + 4 * lh;
+        if (nvalid > 0) {
+            if (g.out_nhwc) {
 #pragma unroll
-            for (int i = 0; i < MT; ++i) {
-                const int mb = m0 + wm * (BM / 2) + i * 32 + 4 * lh;
-                if (g.out_nhwc) {
+                for (int j = 0; j < NT; ++j) {
+                    if (j >= nvalid) continue;
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        if (j == 1 && !ok1) continue;
+                    for (int q = 0; q < 4; ++q) {
+                        const int m = mb + 8 * q;
+                        if (m >= g.Cout) continue;                       // Cout % 4 == 0
+                        f32x4 v;
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const int m = mb + 8 * q;
-                            if (m >= g.Cout) continue;                       // Cout % 4 == 0
+                        for (int e = 0; e < 4; ++e) {
+                            float t = acc[j][4 * q + e];
+                            if (ep.scale) t *= ep.scale[m + e];
+                            if (ep.bias) t += ep.bias[m + e];
+                            if (ep.relu) t = fmaxf(t, 0.0f);
+                            v[e] = t;
+                        }
+                        *reinterpret_cast<f32x4 *>(y + (p + j) * g.Cout + m) = v;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int m = mb + (e & 3) + 8 * (e >> 2);
+                    if (m >= g.Cout) continue;
+                    const float sc = ep.scale ? ep.scale[m] : 1.0f;
+                    const float bi = ep.bias ? ep.bias[m] : 0.0f;
+                    const size_t o = ((size_t)n * g.Cout + m) * OHW + rem;
+                    float t[NT];
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) t[j] = acc[j][e] * sc + bi;
+                    if (nvalid == NT) {
+                        if constexpr (NT == 4) {
+                            if (ep.residual) {
+                                const f32x4 rr = *reinterpret_cast<const f32x4_a4 *>(ep.residual + o);
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) t[j] += rr[j];
+                            }
                             f32x4 v;
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                float t = acc[i][j][4 * q + e];
-                                if (ep.scale) t *= ep.scale[m + e];
-                                if (ep.bias) t += ep.bias[m + e];
-                                if (ep.relu) t = fmaxf(t, 0.0f);
-                                v[e] = t;
-                            }
-                            *reinterpret_cast<f32x4 *>(y + (p + j) * g.Cout + m) = v;
-                        }
-                    }
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const int m = mb + (e & 3) + 8 * (e >> 2);
-                        if (m >= g.Cout) continue;
-                        float t0 = acc[i][0][e], t1 = acc[i][1][e];
-                        if (ep.scale) { t0 *= ep.scale[m]; t1 *= ep.scale[m]; }
-                        if (ep.bias) { t0 += ep.bias[m]; t1 += ep.bias[m]; }
-                        const size_t o = ((size_t)n * g.Cout + m) * OHW + rem;
-                        if (ok1) {
+                            for (int j = 0; j < 4; ++j) v[j] = ep.relu ? fmaxf(t[j], 0.0f) : t[j];
+                            *reinterpret_cast<f32x4_a4 *>(y + o) = v;
+                        } else {
+                            typedef float f32x2 __attribute__((ext_vector_type(2)));
+                            typedef f32x2 f32x2_a4 __attribute__((aligned(4)));
                             if (ep.residual) {
                                 const f32x2 rr = *reinterpret_cast<const f32x2_a4 *>(ep.residual + o);
-                                t0 += rr.x;
-                                t1 += rr.y;
+                                t[0] += rr.x;
+                                t[1] += rr.y;
                             }
-                            if (ep.relu) { t0 = fmaxf(t0, 0.0f); t1 = fmaxf(t1, 0.0f); }
                             f32x2 v;
-                            v.x = t0;
-                            v.y = t1;
+                            v.x = ep.relu ? fmaxf(t[0], 0.0f) : t[0];
+                            v.y = ep.relu ? fmaxf(t[1], 0.0f) : t[1];
                             *reinterpret_cast<f32x2_a4 *>(y + o) = v;
-                        } else {
-                            if (ep.residual) t0 += ep.residual[o];
-                            if (ep.relu) t0 = fmaxf(t0, 0.0f);
-                            y[o] = t0;
+                        }
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < NT; ++j) {
+                            if (j >= nvalid) continue;
+                            float u = t[j];
+                            if (ep.residual) u += ep.residual[o + j];
+                            y[o + j] = ep.relu ? fmaxf(u, 0.0f) : u;
                         }
                     }
                 }
@@ -759,7 +771,8 @@ int fi_conv2d_forward_bf16(const float *x, const float *weight, const float *bia
     const long pv = (long)g.N * g.OH * ((g.OW + 3) / 4) * 4;          // virtual pixel space (rows padded to quads)
     FI_REQUIRE(pv < 2147483647L, "too many output pixels");
     const int ptiles = fi::ceil_div((int)pv, TN);
-    const int bm = Cout <= 64 ? 64 : 128;
+    // 64-row tiles for narrow layers and for grids that would leave CUs idle (C5 at batch 4: 128 workgroups)
+    const int bm = (Cout <= 64 || (long)fi::ceil_div(Cout, 128) * ptiles < 512) ? 64 : 128;
     const int mtiles = fi::ceil_div(Cout, bm);
     const long grid = (long)mtiles * fi::ceil_div(ptiles, 8) * 8;
     FI_REQUIRE(grid < 2147483647L, "grid too large");
