@@ -229,3 +229,39 @@ def test_conv_bias_relu_and_unshuffled_deconv_match_torch():
     got = u.permute(0, 3, 4, 1, 5, 2).reshape(3, 24, 18, 22)
     assert torch.allclose(got, exp, rtol=1e-4, atol=1e-5)
     assert torch.allclose(F.relu(m(x)), exp, rtol=1e-4, atol=1e-5)
+
+
+def test_derived_state_follows_data_writes():
+    """Writes through `.data` (broadcast, checkpoint surgery) bypass tensor version counters: the cached
+    eval-BN folds and the per-step W^T copies must be dropped by invalidate_derived_state, after which the
+    next pass uses the new values (stale folds after dist.broadcast(t.data))."""
+    from feature_intertwiner_amd import conv as C
+    from feature_intertwiner_amd.data_parallel import invalidate_derived_state
+    torch.manual_seed(3)
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.conv = C.Conv2d(32, 48, 3, padding=1)
+            self.bn = torch.nn.BatchNorm2d(48)
+
+        def forward(self, x):
+            C.prepare_step(self)
+            return C.conv_bn_act(x, self.conv, self.bn, relu=True)
+    net = Net().to(DEV).eval()
+    x = torch.randn(2, 32, 12, 12, device=DEV, requires_grad=True)
+
+    def ref():
+        y = F.relu(F.batch_norm(F.conv2d(x, net.conv.weight, net.conv.bias, padding=1), net.bn.running_mean,
+                                net.bn.running_var, net.bn.weight, net.bn.bias, False, 0.0, net.bn.eps))
+        return y
+    y0 = net(x)
+    assert torch.allclose(y0, ref(), rtol=1e-4, atol=1e-4)
+    net.bn.running_mean.data.fill_(0.37)            # no version bump
+    net.conv.weight.data.mul_(1.5)
+    invalidate_derived_state(net)
+    y1 = net(x)
+    assert torch.allclose(y1, ref(), rtol=1e-4, atol=1e-4) and not torch.allclose(y1, y0, atol=1e-3)
+    gx, = torch.autograd.grad(y1.sum(), x)          # the data gradient uses the refreshed W^T
+    gr, = torch.autograd.grad(ref().sum(), x)
+    assert torch.allclose(gx, gr, rtol=1e-3, atol=1e-4)
