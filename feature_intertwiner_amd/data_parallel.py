@@ -41,9 +41,17 @@ class _AllReduceSumIdentityGrad(torch.autograd.Function):
         return g * float(ctx.world), None
 
 
+def _force_collectives():
+    """FI_DP_FORCE=1: run every collective even in a 1-rank group (tests/test_gpu_rccl_single_rank.py drives
+    the RCCL code path -- process-group init, side stream, async work handles -- on a one-GPU box)."""
+    import os
+    return os.environ.get("FI_DP_FORCE") == "1"
+
+
 def all_reduce_statistics(feat_sum, cnt_sum, group=None):
     """reduce_fn for MaskRCNN.meta_loss: one collective for both tensors."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()) or \
+            (dist.get_world_size(group) == 1 and not _force_collectives()):
         return feat_sum, cnt_sum
     flat = torch.cat([feat_sum.reshape(-1), cnt_sum.reshape(-1)])
     flat = _AllReduceSumIdentityGrad.apply(flat, group)
@@ -100,8 +108,10 @@ class GradientBuckets(object):
         self._absent = {}            # key -> set of parameters that produced no gradient under that key
         self._key = None
         self._violations = torch.zeros((), device=self.device)
+        self._flag_cache = {}
         self._reset()
-        if self.world > 1:
+        self.active = self.world > 1 or (dist.is_initialized() and _force_collectives())
+        if self.active:
             for p in params:
                 p.register_post_accumulate_grad_hook(self._on_grad)
 
@@ -139,14 +149,19 @@ class GradientBuckets(object):
             # parameter rides along for the cross-rank consistency counter
             had = [p.grad is not None for p in self.buckets[bi]]
             grads = [p.grad if h else torch.zeros_like(p) for p, h in zip(self.buckets[bi], had)]
-            flags = torch.tensor([1.0 if h else 0.0 for h in had], dtype=grads[0].dtype).to(self.device, non_blocking=True)
+            # the flag vector of a (bucket, pattern) pair is built once and kept on the device: a host-to-device
+            # copy from a hook would synchronise the host with the main stream at every bucket
+            fkey = (bi, tuple(had))
+            flags = self._flag_cache.get(fkey)
+            if flags is None:
+                flags = torch.tensor([1.0 if h else 0.0 for h in had], dtype=grads[0].dtype, device=self.device)
+                self._flag_cache[fkey] = flags
             if self.use_stream:
                 self.comm_stream.wait_stream(torch.cuda.current_stream(self.device))
                 with torch.cuda.stream(self.comm_stream):
                     flat = torch._utils._flatten_dense_tensors(grads + [flags])
                     for g in grads:
                         g.record_stream(self.comm_stream)
-                    flags.record_stream(self.comm_stream)
                     work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
             else:
                 flat = torch._utils._flatten_dense_tensors(grads + [flags])
@@ -154,7 +169,7 @@ class GradientBuckets(object):
             self.inflight.append((bi, flat, work, had, flags))
 
     def __call__(self):
-        if self.world == 1:
+        if not self.active:
             return
         self._launch_ready(force=True)        # whatever is left (first step of a key; trailing bucket)
         inv = 1.0 / float(self.world)
