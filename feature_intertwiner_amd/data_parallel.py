@@ -59,6 +59,17 @@ def all_reduce_statistics(feat_sum, cnt_sum, group=None):
     return flat[:n].view_as(feat_sum), flat[n:].view_as(cnt_sum)
 
 
+def _mem_flat(t):
+    """1-D view of a dense tensor in MEMORY order (no copy): gradients of channels-last parameters are
+    channels-last themselves, and flattening them in logical order would cost a strided copy per tensor
+    on the way into and out of every bucket."""
+    if t.is_contiguous():
+        return t.view(-1)
+    if t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last):
+        return t.permute(0, 2, 3, 1).reshape(-1)          # a view for channels-last strides
+    return t.reshape(-1)
+
+
 class GradientBuckets(object):
     """Bucketed, overlapped gradient all-reduce.
 
@@ -156,15 +167,16 @@ class GradientBuckets(object):
             if flags is None:
                 flags = torch.tensor([1.0 if h else 0.0 for h in had], dtype=grads[0].dtype, device=self.device)
                 self._flag_cache[fkey] = flags
+            pieces = [_mem_flat(g) for g in grads] + [flags]
             if self.use_stream:
                 self.comm_stream.wait_stream(torch.cuda.current_stream(self.device))
                 with torch.cuda.stream(self.comm_stream):
-                    flat = torch._utils._flatten_dense_tensors(grads + [flags])
+                    flat = torch.cat(pieces)
                     for g in grads:
                         g.record_stream(self.comm_stream)
                     work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
             else:
-                flat = torch._utils._flatten_dense_tensors(grads + [flags])
+                flat = torch.cat(pieces)
                 work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
             self.inflight.append((bi, flat, work, had, flags))
 
@@ -184,15 +196,20 @@ class GradientBuckets(object):
             # some rank had a gradient where this one had none (or vice versa): replicas would diverge
             self._violations += ((flat[-n:] > 0) & (flat[-n:] < self.world)).sum()
             flat[:-n].mul_(inv)
-            outs = torch._utils._unflatten_dense_tensors(flat[:-n], [p for p in self.buckets[bi]])
-            for p, g, h in zip(self.buckets[bi], outs, had):
+            dst, src, off = [], [], 0
+            for p, h in zip(self.buckets[bi], had):
+                k = p.numel()
                 if h:
-                    p.grad.copy_(g)
+                    dst.append(_mem_flat(p.grad))             # memory order, as it was packed
+                    src.append(flat[off:off + k])
                 else:
                     # no gradient here: .grad stays None, exactly as on one GPU
                     if p.grad is not None:
                         raise RuntimeError("GradientBuckets: gradient produced after its bucket was issued")
                     absent.add(p)
+                off += k
+            if dst:
+                torch._foreach_copy_(dst, src)                # a few launches per bucket, not one per parameter
         self._absent[self._key] = absent
         self._reset()
 
