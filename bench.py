@@ -269,6 +269,28 @@ def cpu_baseline(model, batch, log_entries, shape_log=None):
 
 
 def main():
+    # The contract is ONE JSON line on stdout.  RCCL prints a version banner to the C-level stdout when the
+    # first communicator is created, and libraries may print more: everything written to fd 1 while the
+    # benchmark runs is sent to stderr, and the JSON line goes to the real stdout at the end.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        line = _main()
+    finally:
+        sys.stdout.flush()
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)        # C stdio buffers (the RCCL banner) must drain to stderr too
+        except Exception:
+            pass
+        os.dup2(real_stdout, 1)
+        os.close(real_stdout)
+    if line is not None:
+        print(line, flush=True)
+
+
+def _main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=16)
@@ -309,8 +331,12 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # FI_DP_FORCE=1 (measurement only): run the data-parallel engine over RCCL even with ONE rank, to price its
+    # per-step machinery (bucket packing, collectives, write-back) on a one-GPU box
+    force_dp = os.environ.get("FI_DP_FORCE") == "1"
+    if world > 1 or force_dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
         if share:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
@@ -333,8 +359,8 @@ def main():
     model = MaskRCNN(cfg).to(dev)
     broadcast_parameters(model)
     opt = set_optimizer(model, cfg.TRAIN)
-    sync = GradientBuckets(model) if world > 1 else None
-    reduce_fn = all_reduce_statistics if world > 1 else None
+    sync = GradientBuckets(model) if (world > 1 or force_dp) else None
+    reduce_fn = all_reduce_statistics if (world > 1 or force_dp) else None
     batch = synthetic_batch(args.batch_per_gpu, args.image_size, device=dev, seed=2000 + rank)
     model.proposal_hook = SyntheticProposals(batch[2], args.image_size, seed=7 + rank)
     model.generator = torch.Generator(device=dev).manual_seed(11 + rank)
@@ -343,6 +369,7 @@ def main():
         return train_step(model, opt, list(batch), do_meta=True, grad_sync=sync, world_size=world,
                           reduce_fn=reduce_fn)
 
+    result_line = None
     if args.pmc_child:
         # profiled under `rocprofv3 --pmc <one counter>`: calibration copies of known size, then the step
         a = torch.empty(64 * 1024 * 1024, device=dev)
@@ -353,7 +380,7 @@ def main():
         for _ in range(3):
             step()
         torch.cuda.synchronize()
-        return
+        return None
 
     for _ in range(args.warmup):
         terms = step()
@@ -560,9 +587,10 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(model, batch, entries, shape_log)
             except Exception as ex:   # the baseline must never take the headline down
                 out["cpu_baseline"] = {"error": repr(ex)}
-        print(json.dumps(out))
-    if world > 1:
+        result_line = json.dumps(out)
+    if world > 1 or force_dp:
         dist.destroy_process_group()
+    return result_line
 
 
 if __name__ == "__main__":
