@@ -19,10 +19,11 @@
 // Windows wider than 64 columns are processed in 64-column slabs with the running bin
 // state kept in LDS.  Pooled sizes above 28x28 use the simple per-bin kernel.
 // Measured (512 RoIs x 256 ch on a 2x256x256x256 map): 7x7 1269 -> 400 us, 14x14 -> 640 us.
-// What bounds it now: one row segment (<= 256 B) per vector-memory instruction; whole-map
+// What bounds THIS form: one row segment (<= 256 B) per vector-memory instruction; whole-map
 // windows read at 6.6 TB/s even when every byte is an L2 hit (scripts/roipool_probe.py), i.e.
-// the CU's load-instruction rate, not memory.  The next step is lanes = rows x 16-byte column
-// groups (4-8x fewer load instructions), at the price of per-lane bin bookkeeping.
+// the CU's load-instruction rate, not memory.  roi_pool_fwd_v2_kernel (below) therefore gives a
+// lane 16 bytes of ONE pooled row: 7x7 181 us, 14x14 408 us, whole-map windows at 14-17 TB/s from
+// L2.  This form remains for pooled heights 17..28 and maps narrower than 4.
 // Backward: the reference gathers -- every INPUT element loops over ALL RoIs
 // (O(B*C*H*W*N), 67 M threads x N at P2).  Here each pooled cell scatters its
 // gradient to its argmax with a hardware fp32 atomic, after re-checking the
@@ -362,6 +363,187 @@ __global__ __launch_bounds__(kThreads) void roi_pool_fwd_kernel(
     }
 }
 
+// ---- forward, second form: lanes = (pooled row p, group of 4 columns) -------------------------------------
+// The kernel above issues one vector-memory instruction per window ROW (<= 256 bytes), and the CU's rate
+// of such instructions is what bounds it (6.6 TB/s even on L2 hits).  Here a lane owns FOUR consecutive
+// columns (one 16-byte load) of ONE pooled row p and walks only the rows of that bin: a wavefront load
+// covers ph bins x up to 64/ph column groups at once, so a 33 x 32 window is read in ~6 instructions per
+// channel instead of 32, and no cross-lane reduction is needed -- each lane ends with the (max, first row)
+// of its 4 columns for its pooled row, exactly the column table phase 2 consumes.  Rows shared by two bins
+// are simply read by both lanes.  Windows wider than 4 * (64 / ph) columns take several slabs; narrow ones
+// pack several channels into the wavefront.  (ph <= 16 and W >= 4; the first form handles the rest.)
+typedef float quad_t __attribute__((ext_vector_type(4)));
+typedef quad_t quad_a4 __attribute__((aligned(4)));
+
+__host__ __device__ inline size_t roi_pool_v2_wave_lds(int ph, int pw) { return 64 * 4 * 8 + (size_t)ph * pw * 12; }
+
+__global__ __launch_bounds__(kThreads) void roi_pool_fwd_v2_kernel(
+    const float *__restrict__ features, const float *__restrict__ rois, int num_rois, int batch,
+    int channels, int height, int width, int ph, int pw, float scale, int chan_per_block,
+    int chunks, float *__restrict__ output, int *__restrict__ argmax)
+{
+    __shared__ int s_h0[kMaxPool], s_h1[kMaxPool], s_w0[kMaxPool], s_w1[kMaxPool];
+    extern __shared__ __align__(16) unsigned char s_dyn[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int xcd = blockIdx.x & 7;              // XCD chunk-major order, as above
+    const int jb = blockIdx.x >> 3;
+    const int chunk = (jb / num_rois) * 8 + xcd;
+    const int n = jb % num_rois;
+    if (chunk >= chunks) return;
+    const int c_begin = chunk * chan_per_block;
+    const int c_count = min(chan_per_block, channels - c_begin);
+    const int bins = ph * pw;
+
+    const Roi r = decode_roi(rois + 5 * (size_t)n, scale, ph, pw);
+    if (tid < ph) {
+        const int hs = (int)floorf((float)tid * r.bin_h);
+        const int he = (int)ceilf((float)(tid + 1) * r.bin_h);
+        s_h0[tid] = clampi(hs + r.start_h, 0, height);
+        s_h1[tid] = clampi(he + r.start_h, 0, height);
+    }
+    if (tid >= 64 && tid < 64 + pw) {
+        const int q = tid - 64;
+        const int ws = (int)floorf((float)q * r.bin_w);
+        const int we = (int)ceilf((float)(q + 1) * r.bin_w);
+        s_w0[q] = clampi(ws + r.start_w, 0, width);
+        s_w1[q] = clampi(we + r.start_w, 0, width);
+    }
+    __syncthreads();
+
+    const size_t o_base = ((size_t)n * channels + c_begin) * bins;
+    const bool img_ok = r.img >= 0 && r.img < batch;
+    const int w_lo = s_w0[0];
+    const int w_hi = s_w1[pw - 1];
+    const int w_win = max(w_hi - w_lo, 0);
+    if (!img_ok || w_win == 0) {      // every bin is empty: 0 / -1 (roi_pooling_kernel.cu:70-72)
+        for (int idx = tid; idx < c_count * bins; idx += kThreads) {
+            output[o_base + idx] = 0.0f;
+            if (argmax) argmax[o_base + idx] = -1;
+        }
+        return;
+    }
+    const int CG = min(64 / ph, (w_win + 3) >> 2);          // column groups per slab
+    const int SW = 4 * CG;                                  // slab width in columns
+    const int slabs = (w_win + SW - 1) / SW;
+    const int per_ch = ph * CG;                             // lanes per channel
+    const int cpw = max(1, min(64 / per_ch, max(1, chan_per_block / kWaves)));
+    const int cs = lane / per_ch;
+    const int rem = lane - cs * per_ch;
+    const int p = rem / CG, g = rem - p * CG;
+    const bool lane_on = cs < cpw;
+
+    unsigned char *mine = s_dyn + (size_t)wave * roi_pool_v2_wave_lds(ph, pw);
+    float *colv = (float *)mine;                             // [cpw][ph][SW]   (cpw * ph * SW <= 256)
+    int *colh = (int *)(mine + 64 * 4 * 4);
+    float *binv = (float *)(mine + 64 * 4 * 8);              // running bin state, windows of several slabs
+    int *binh = (int *)(binv + bins);
+    int *binw = binh + bins;
+
+    const int hs = lane_on ? s_h0[p] : 0, he = lane_on ? s_h1[p] : 0;
+    const int groups = (c_count + cpw - 1) / cpw;
+    for (int g0 = wave; g0 < groups; g0 += kWaves) {
+        const int c_loc = g0 * cpw + cs;
+        const bool c_ok = lane_on && c_loc < c_count;
+        const int plane_off = ((r.img * channels) + c_begin + min(c_loc, c_count - 1)) * height * width;
+        const float *__restrict__ src = features + plane_off;
+        if (slabs > 1) {
+            for (int b = lane; b < bins; b += 64) {
+                binv[b] = -FLT_MAX;
+                binh[b] = -1;
+                binw[b] = -1;
+            }
+        }
+        for (int slab = 0; slab < slabs; ++slab) {
+            const int col0 = w_lo + slab * SW;
+            const int startcol = min(col0 + 4 * g, width - 4);   // the last group is pulled back inside the row
+            const bool on = c_ok && (col0 + 4 * g < w_hi);
+            // ---- phase 1: this lane's 4 columns over the rows of its bin ------------------------------
+            quad_t best = {-FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX};
+            int bh0 = -1, bh1 = -1, bh2 = -1, bh3 = -1;
+            if (on) {
+                const float *__restrict__ colp = src + startcol;
+                // rows of the bin, 4 independent 16-byte loads in flight; rows past the bin's end re-read its
+                // last row (an equal value never replaces the recorded first maximum)
+                for (int h = hs; h < he; h += 4) {
+                    quad_t v[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        v[u] = *reinterpret_cast<const quad_a4 *>(colp + (size_t)min(h + u, he - 1) * width);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int hu = min(h + u, he - 1);
+                        if (v[u].x > best.x) { best.x = v[u].x; bh0 = hu; }
+                        if (v[u].y > best.y) { best.y = v[u].y; bh1 = hu; }
+                        if (v[u].z > best.z) { best.z = v[u].z; bh2 = hu; }
+                        if (v[u].w > best.w) { best.w = v[u].w; bh3 = hu; }
+                    }
+                }
+            }
+            if (on) {
+                // (columns at or past w_hi are never read by phase 2, so lanes without a column write nothing;
+                // a pulled-back last group rewrites columns of its neighbour with identical values)
+                const int base = (cs * ph + p) * SW + (startcol - col0);
+                const float bv[4] = {best.x, best.y, best.z, best.w};
+                const int bhh[4] = {bh0, bh1, bh2, bh3};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int ce = startcol - col0 + e;              // column inside the slab
+                    if (ce >= 0 && ce < SW) {
+                        colv[base + e] = bv[e];
+                        colh[base + e] = bhh[e];
+                    }
+                }
+            }
+            wave_lds_sync();
+            // ---- phase 2: bins from column maxima (w ascending; ties -> smaller row) -------------------
+            const int pairs = cpw * bins;
+            for (int idx = lane; idx < pairs; idx += 64) {
+                const int cs2 = idx / bins;
+                const int bin = idx - cs2 * bins;
+                const int p2 = bin / pw;
+                const int q2 = bin - p2 * pw;
+                const int h0 = s_h0[p2], h1 = s_h1[p2], ws = s_w0[q2], we = s_w1[q2];
+                const bool empty = (h1 <= h0) || (we <= ws);
+                float bst = -FLT_MAX;
+                int bh = -1, bw = -1;
+                if (slabs > 1) {
+                    bst = binv[bin];
+                    bh = binh[bin];
+                    bw = binw[bin];
+                }
+                const int a = max(ws, col0), e = min(we, col0 + SW);
+                const float *cv = colv + (cs2 * ph + p2) * SW - col0;
+                const int *ch = colh + (cs2 * ph + p2) * SW - col0;
+                for (int w = a; w < e; ++w) {
+                    const float v = cv[w];
+                    const int hh = ch[w];
+                    if (v > bst || (v == bst && hh >= 0 && (bh < 0 || hh < bh))) {
+                        bst = v;
+                        bh = hh;
+                        bw = w;
+                    }
+                }
+                if (slabs > 1 && slab + 1 < slabs) {
+                    binv[bin] = bst;
+                    binh[bin] = bh;
+                    binw[bin] = bw;
+                } else {
+                    const int cl = g0 * cpw + cs2;
+                    if (cl < c_count) {
+                        const size_t o = o_base + (size_t)cl * bins + bin;
+                        const int po = ((r.img * channels) + c_begin + cl) * height * width;
+                        output[o] = empty ? 0.0f : bst;
+                        if (argmax) argmax[o] = (empty || bh < 0) ? -1 : po + bh * width + bw;
+                    }
+                }
+            }
+            wave_lds_sync();
+        }
+    }
+}
+
 __global__ __launch_bounds__(kThreads) void roi_pool_bwd_kernel(
     const float *__restrict__ top_grad, const float *__restrict__ rois,
     const int *__restrict__ argmax, int num_rois, int batch, int channels, int height, int width,
@@ -418,7 +600,7 @@ int fi_roi_pool_forward(const float *features, const float *rois, int num_rois, 
     FI_REQUIRE(features && rois && output, "null pointer");
     // 8 channels per workgroup: the largest RoIs (whole-map windows) set the critical path, so their
     // channels are spread over many workgroups; narrow RoIs pack all 8 channels into one wavefront pass
-    const int cpb = 8;
+    const int cpb = pooled_h >= 14 ? 4 : 8;     // measured: 7x7 181 us at 4 or 8 (237 at 2, 235 at 16); 14x14 408 / 458 us
     const int chunks = fi::ceil_div(channels, cpb);
     FI_REQUIRE((long)num_rois * (chunks + 8) < 2147483647L, "grid too large");
     hipStream_t st = (hipStream_t)stream;
@@ -427,6 +609,12 @@ int fi_roi_pool_forward(const float *features, const float *rois, int num_rois, 
         hipLaunchKernelGGL(roi_pool_fwd_simple_kernel, dim3((unsigned)((long)num_rois * chunks)), dim3(kThreads),
                            0, st, features, rois, num_rois, batch, channels, height, width, pooled_h,
                            pooled_w, spatial_scale, cpb, chunks, output, argmax);
+    } else if (pooled_h <= 16 && width >= 4) {
+        const size_t lds = roi_pool_v2_wave_lds(pooled_h, pooled_w) * kWaves;  // 4 * (2 KB + bins * 12 B)
+        const long grid = (long)num_rois * fi::ceil_div(chunks, 8) * 8;
+        hipLaunchKernelGGL(roi_pool_fwd_v2_kernel, dim3((unsigned)grid), dim3(kThreads), lds, st, features, rois,
+                           num_rois, batch, channels, height, width, pooled_h, pooled_w, spatial_scale, cpb, chunks,
+                           output, argmax);
     } else {
         const size_t lds = roi_pool_wave_lds(pooled_h, pooled_w) * kWaves;     // <= 4 * (14 KB + 9.2 KB)
         const long grid = (long)num_rois * fi::ceil_div(chunks, 8) * 8;
