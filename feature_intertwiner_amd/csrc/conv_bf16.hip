@@ -73,7 +73,9 @@ __device__ __forceinline__ float pick4(const f32x4 &v, int i)
     return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w));
 }
 
-template <int BM>
+// SWT = column stride of the fast gather (1 or 2).  Stride 2: the 4 outputs of a quad tap input columns
+// iw0, iw0 + 2, iw0 + 4, iw0 + 6 -- two 16-byte loads (8 consecutive floats), every second element.
+template <int BM, int SWT>
 __global__ __launch_bounds__(kThreads, 2) void conv_bf16_fwd_kernel(const float *__restrict__ x,
                                                                  const float *__restrict__ w, Epi ep,
                                                                  float *__restrict__ y, Geom g, int mtiles,
@@ -126,7 +128,8 @@ __global__ __launch_bounds__(kThreads, 2) void conv_bf16_fwd_kernel(const float 
         b_oh[u] = row - n * g.OH;
         b_img[u] = x + (size_t)n * g.Cin * HW + (size_t)(2 * kp) * HW;
     }
-    const bool fast = (g.sw == 1) && (g.W >= 4);
+    constexpr int NL = SWT;                                  // 16-byte loads per channel and quad
+    const bool fast = (g.sw == SWT) && (g.W >= 4 * SWT);
 
     f32x16 acc[NT];
 #pragma unroll
@@ -139,7 +142,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_bf16_fwd_kernel(const float 
 
     struct Regs {
         f32x4 a[4];            // A: 16 consecutive k of one row
-        f32x4 b[2][2];         // B: [quad][channel of the pair] 4 pixels (raw 16-byte loads)
+        f32x4 b[2][2][NL];     // B: [quad][channel of the pair][16-byte load] raw input columns
         int d[2];              // B: column shift of the quad's load (0 inside the row) / -99: all zero
     };
 
@@ -156,10 +159,10 @@ __global__ __launch_bounds__(kThreads, 2) void conv_bf16_fwd_kernel(const float 
         pa = a_src + (size_t)(g.flip ? (RS - 1 - tap) : tap) * g.Cin;
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            const int ih = b_oh[u] - g.ph + r;
-            const int iw0 = b_ow[u] - g.pw + s_;
-            const int iwc = min(max(iw0, 0), g.W - 4);
-            const bool row_ok = b_ok[u] && ih >= 0 && ih < g.H && iw0 > -4 && iw0 < g.W;
+            const int ih = b_oh[u] * g.sh - g.ph + r;
+            const int iw0 = b_ow[u] * SWT - g.pw + s_;
+            const int iwc = min(max(iw0, 0), g.W - 4 * SWT);
+            const bool row_ok = b_ok[u] && ih >= 0 && ih < g.H && iw0 > -4 * SWT && iw0 < g.W;
             pb[u] = b_img[u] + (size_t)min(max(ih, 0), g.H - 1) * g.W + iwc;
             dcur[u] = row_ok ? (iw0 - iwc) : -99;
         }
@@ -174,8 +177,11 @@ __global__ __launch_bounds__(kThreads, 2) void conv_bf16_fwd_kernel(const float 
             }
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                R.b[u][0] = *reinterpret_cast<const f32x4_a4 *>(pb[u]);
-                R.b[u][1] = *reinterpret_cast<const f32x4_a4 *>(pb[u] + HW);
+#pragma unroll
+                for (int l = 0; l < NL; ++l) {
+                    R.b[u][0][l] = *reinterpret_cast<const f32x4_a4 *>(pb[u] + 4 * l);
+                    R.b[u][1][l] = *reinterpret_cast<const f32x4_a4 *>(pb[u] + HW + 4 * l);
+                }
                 R.d[u] = dcur[u];
                 pb[u] += cstep;
             }
@@ -204,10 +210,10 @@ __global__ __launch_bounds__(kThreads, 2) void conv_bf16_fwd_kernel(const float 
                         v0 = px[(size_t)ih * g.W + iw];
                         v1 = px[HW + (size_t)ih * g.W + iw];
                     }
-                    R.b[u][0][j] = v0;
-                    R.b[u][1][j] = v1;
+                    R.b[u][0][0][j] = v0;
+                    R.b[u][1][0][j] = v1;
                 }
-                R.d[u] = 0;
+                R.d[u] = -77;                                // values are already in place
             }
             if (++cur_cb == cblocks) {
                 cur_cb = 0;
@@ -236,16 +242,21 @@ __global__ __launch_bounds__(kThreads, 2) void conv_bf16_fwd_kernel(const float 
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int q = q0 + 16 * u;
-            f32x4 c0v = R.b[u][0], c1v = R.b[u][1];
+            f32x4 c0v = R.b[u][0][0], c1v = R.b[u][1][0];
             const int d = R.d[u];
-            if (d != 0) {                                   // quad over a row end (or entirely outside)
+            if (d != -77 && (SWT == 2 || d != 0)) {          // quad over a row end / outside, or strided gather
                 f32x4 t0, t1;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const int k = j + d;                    // source element; outside 0..3 <=> outside the row
-                    const bool ok = (unsigned)k < 4u;
-                    t0[j] = ok ? pick4(c0v, k) : 0.0f;
-                    t1[j] = ok ? pick4(c1v, k) : 0.0f;
+                    const int k = SWT * j + d;              // source element; outside 0..4*SWT-1 <=> outside the row
+                    const bool ok = (unsigned)k < (unsigned)(4 * SWT);
+                    float e0 = pick4(R.b[u][0][0], k & 3), e1 = pick4(R.b[u][1][0], k & 3);
+                    if (SWT == 2 && k >= 4) {
+                        e0 = pick4(R.b[u][0][NL - 1], k & 3);
+                        e1 = pick4(R.b[u][1][NL - 1], k & 3);
+                    }
+                    t0[j] = ok ? e0 : 0.0f;
+                    t1[j] = ok ? e1 : 0.0f;
                 }
                 c0v = t0;
                 c1v = t1;
@@ -535,14 +546,14 @@ __global__ __launch_bounds__(kThreads) void conv_bf16_wgrad_generic_kernel(const
     }
 }
 
-// Stride-1 weight gradient, fast form.  The reduction index runs over the same VIRTUAL pixel space as the
+// Weight gradient, fast form (column stride 1 or 2, any row stride).  The reduction index runs over the same VIRTUAL pixel space as the
 // forward kernel (rows padded to quads); a K-tile is 8 consecutive quads.  Loader: thread -> (quad of the
 // tile = tid & 7, rows (tid >> 3) + 32 v): the 8 lanes of a row fetch its whole 128-byte slice of the
 // K-tile, a thread owns ONE quad, so the quad's geometry (image, row, clamped columns, halo shift) is
 // advanced incrementally once per tile -- no divisions, no per-element validity tests in the loop.
 // Both operands use the clamped 16-byte load + register shift of the forward kernel: dY where the row
 // width is not a multiple of 4, X where the tap pushes the quad over the halo.
-template <int BM, int BNC>
+template <int BM, int BNC, int SWT>
 __global__ __launch_bounds__(kThreads, 2) void conv_bf16_wgrad_kernel(const float *__restrict__ x,
                                                                       const float *__restrict__ dy,
                                                                       float *__restrict__ dw, Geom g, int cin_tiles,
@@ -550,6 +561,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_bf16_wgrad_kernel(const floa
 {
     constexpr int MT = BM / 64, NT = BNC / 64;
     constexpr int AV = BM / 32, BV = BNC / 32;          // row passes of the loaders
+    constexpr int NL = SWT;                             // 16-byte loads per X row and quad (column stride 1 or 2)
     __shared__ __align__(16) __bf16 As[2][BM][LP];       // dY  [cout][pixel]
     __shared__ __align__(16) __bf16 Bs[2][BNC][LP];      // X   [ci][pixel]   (for one tap)
 
@@ -598,10 +610,10 @@ __global__ __launch_bounds__(kThreads, 2) void conv_bf16_wgrad_kernel(const floa
         const int owc = min(ow0, g.OW - 4);
         pa = dy + (size_t)n * g.Cout * OHW + (size_t)qoh * g.OW + owc;
         da = live ? (ow0 - owc) : -99;                    // elements j with j + da > 3 lie past the row end
-        const int ih = qoh - g.ph + r;
-        const int iw0 = ow0 - g.pw + s_;
-        const int iwc = min(max(iw0, 0), g.W - 4);
-        const bool ok = live && ih >= 0 && ih < g.H && iw0 > -4 && iw0 < g.W;
+        const int ih = qoh * g.sh - g.ph + r;
+        const int iw0 = ow0 * SWT - g.pw + s_;
+        const int iwc = min(max(iw0, 0), g.W - 4 * SWT);
+        const bool ok = live && ih >= 0 && ih < g.H && iw0 > -4 * SWT && iw0 < g.W;
         pb = x + (size_t)n * g.Cin * HW + (size_t)min(max(ih, 0), g.H - 1) * g.W + iwc;
         db = ok ? (iw0 - iwc) : -99;
     };
@@ -619,14 +631,16 @@ __global__ __launch_bounds__(kThreads, 2) void conv_bf16_wgrad_kernel(const floa
     locate();
 
     struct Regs {
-        f32x4 a[AV], b[BV];
+        f32x4 a[AV], b[BV][NL];
         int da, db;
     };
     auto load_tile = [&](Regs &R) {
 #pragma unroll
         for (int v = 0; v < AV; ++v) R.a[v] = *reinterpret_cast<const f32x4_a4 *>(pa + a_row_off[v]);
 #pragma unroll
-        for (int v = 0; v < BV; ++v) R.b[v] = *reinterpret_cast<const f32x4_a4 *>(pb + b_row_off[v]);
+        for (int v = 0; v < BV; ++v)
+#pragma unroll
+            for (int l = 0; l < NL; ++l) R.b[v][l] = *reinterpret_cast<const f32x4_a4 *>(pb + b_row_off[v] + 4 * l);
         R.da = da;
         R.db = db;
         advance();
@@ -654,8 +668,17 @@ __global__ __launch_bounds__(kThreads, 2) void conv_bf16_wgrad_kernel(const floa
         }
 #pragma unroll
         for (int v = 0; v < BV; ++v) {
-            f32x4 t = R.b[v];
-            if (R.db != 0) t = shifted(t, R.db);
+            f32x4 t = R.b[v][0];
+            if (SWT == 2) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int k = 2 * j + R.db;               // element of the 8 loaded floats
+                    const float e = k >= 4 ? pick4(R.b[v][NL - 1], k & 3) : pick4(R.b[v][0], k & 3);
+                    t[j] = ((unsigned)k < 8u) ? e : 0.0f;
+                }
+            } else if (R.db != 0) {
+                t = shifted(t, R.db);
+            }
             bf16x4 o;
 #pragma unroll
             for (int j = 0; j < 4; ++j) o[j] = (__bf16)t[j];
@@ -777,13 +800,10 @@ int fi_conv2d_forward_bf16(const float *x, const float *weight, const float *bia
     const long grid = (long)mtiles * fi::ceil_div(ptiles, 8) * 8;
     FI_REQUIRE(grid < 2147483647L, "grid too large");
     fi::ProfScope prof(FI_K_CONV_BF16_FWD, st);
-    if (bm == 64) {
-        hipLaunchKernelGGL(conv_bf16_fwd_kernel<64>, dim3((unsigned)grid), dim3(kThreads), 0, st, x, weight, ep, y, g,
-                           mtiles, ptiles);
-    } else {
-        hipLaunchKernelGGL(conv_bf16_fwd_kernel<128>, dim3((unsigned)grid), dim3(kThreads), 0, st, x, weight, ep, y, g,
-                           mtiles, ptiles);
-    }
+    const bool s2 = (stride_w == 2 && W >= 8);
+    auto k = bm == 64 ? (s2 ? conv_bf16_fwd_kernel<64, 2> : conv_bf16_fwd_kernel<64, 1>)
+                      : (s2 ? conv_bf16_fwd_kernel<128, 2> : conv_bf16_fwd_kernel<128, 1>);
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(kThreads), 0, st, x, weight, ep, y, g, mtiles, ptiles);
     FI_HIP_CHECK(hipGetLastError());
     return FI_OK;
 }
@@ -802,7 +822,7 @@ int fi_conv2d_weight_grad_bf16(const float *x, const float *dy, float *dweight, 
         FI_HIP_CHECK(hipMemsetAsync(dweight, 0, sizeof(float) * (size_t)Cout * RS * Cin, st));
     const int OHW = g.OH * g.OW;
     fi::ProfScope prof(FI_K_CONV_BF16_WGRAD, st);
-    if (stride_h == 1 && stride_w == 1 && g.OW >= 4 && W >= 4) {
+    if ((stride_w == 1 || stride_w == 2) && g.OW >= 4 && W >= 4 * stride_w) {
         const int bm = Cout <= 64 ? 64 : 128, bnc = Cin <= 64 ? 64 : 128;
         const int mt = fi::ceil_div(Cout, bm), cin_tiles = fi::ceil_div(Cin, bnc);
         const long tiles = (long)mt * RS * cin_tiles;
@@ -818,18 +838,12 @@ int fi_conv2d_weight_grad_bf16(const float *x, const float *dy, float *dweight, 
         z = fi::ceil_div(ktiles_total, per);
         FI_REQUIRE((long)RS * cin_tiles <= 65535, "too many (tap, ci) tiles");
         const dim3 grid(mt, RS * cin_tiles, (unsigned)z);
-        if (bm == 128 && bnc == 128)
-            hipLaunchKernelGGL((conv_bf16_wgrad_kernel<128, 128>), grid, dim3(kThreads), 0, st, x, dy, dweight, g, cin_tiles,
-                               ktiles_total, per);
-        else if (bm == 128)
-            hipLaunchKernelGGL((conv_bf16_wgrad_kernel<128, 64>), grid, dim3(kThreads), 0, st, x, dy, dweight, g, cin_tiles,
-                               ktiles_total, per);
-        else if (bnc == 128)
-            hipLaunchKernelGGL((conv_bf16_wgrad_kernel<64, 128>), grid, dim3(kThreads), 0, st, x, dy, dweight, g, cin_tiles,
-                               ktiles_total, per);
-        else
-            hipLaunchKernelGGL((conv_bf16_wgrad_kernel<64, 64>), grid, dim3(kThreads), 0, st, x, dy, dweight, g, cin_tiles,
-                               ktiles_total, per);
+        const bool s2 = stride_w == 2;
+        auto k = bm == 128 ? (bnc == 128 ? (s2 ? conv_bf16_wgrad_kernel<128, 128, 2> : conv_bf16_wgrad_kernel<128, 128, 1>)
+                                         : (s2 ? conv_bf16_wgrad_kernel<128, 64, 2> : conv_bf16_wgrad_kernel<128, 64, 1>))
+                           : (bnc == 128 ? (s2 ? conv_bf16_wgrad_kernel<64, 128, 2> : conv_bf16_wgrad_kernel<64, 128, 1>)
+                                         : (s2 ? conv_bf16_wgrad_kernel<64, 64, 2> : conv_bf16_wgrad_kernel<64, 64, 1>));
+        hipLaunchKernelGGL(k, grid, dim3(kThreads), 0, st, x, dy, dweight, g, cin_tiles, ktiles_total, per);
         FI_HIP_CHECK(hipGetLastError());
         return FI_OK;
     }

@@ -55,11 +55,14 @@ for (name, site), n in sites.most_common(60):
 
 # GPU busy vs wall: union of device-side kernel intervals inside the profiled step
 iv = []
+named = []
 for ev in prof.events():
     dt = getattr(ev, "device_type", None)
     if str(dt).endswith("CUDA") and ev.time_range is not None:
         iv.append((ev.time_range.start, ev.time_range.end))
+        named.append((ev.time_range.start, ev.time_range.end, ev.name))
 iv.sort()
+named.sort()
 busy, cur_s, cur_e = 0.0, None, None
 gaps = []
 for s_, e_ in iv:
@@ -75,6 +78,10 @@ if cur_e is not None:
 span = iv[-1][1] - iv[0][0] if iv else 0
 print("device kernels: %d, span %.2f ms, busy %.2f ms, idle %.2f ms" % (len(iv), span / 1e3, busy / 1e3, (span - busy) / 1e3))
 gaps.sort(reverse=True)
+for gap, at in gaps[:6]:
+    before = [n for s0, e0, n in named if abs(e0 - at) < 1e-3 or (e0 <= at and at - e0 < 5)][-1:]
+    after = [n for s0, e0, n in named if s0 >= at][:1]
+    print("gap %8.1f us  after %-60s before %-60s" % (gap, (before or ["?"])[0][:60], (after or ["?"])[0][:60]))
 print("largest idle gaps (us):", [round(g[0], 1) for g in gaps[:25]])
 print("gaps > 20us: %d totalling %.2f ms; gaps <= 20us: %d totalling %.2f ms" % (
     sum(1 for g in gaps if g[0] > 20), sum(g[0] for g in gaps if g[0] > 20) / 1e3,
