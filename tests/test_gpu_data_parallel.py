@@ -168,3 +168,52 @@ def test_two_rank_model_step_equals_single_process_rule(variant):
         assert all(k in ratio for k in ("ot_loss.G_net.0.weight", "ot_loss.critic.0.weight"))
         assert model.ot_loss.G_net[0].weight.grad.abs().max().item() > 1e-8 * gmax
     print("max relative gradient deviation per sub-module:", {k: "%.1e" % v for k, v in worst.items()})
+
+
+def _worker_cfg4(rank, port, outdir):
+    """BASELINE configs[3] per-rank workload: ResNet-101-FPN, 2 x 1024^2 per rank, 512 RoIs/image, OT on."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+    from feature_intertwiner_amd.config import make_config
+    from feature_intertwiner_amd.data_parallel import GradientBuckets, all_reduce_statistics, broadcast_parameters
+    from feature_intertwiner_amd.model import MaskRCNN
+    from feature_intertwiner_amd.synthetic import SyntheticProposals, synthetic_batch
+    from feature_intertwiner_amd.workflow import set_optimizer, train_step
+    torch.manual_seed(4321)
+    cfg = make_config("resnet101", 1024, 2, 512, dev_switch=True, loss_choice="ot", ot_L=50, gpu_count=WORLD)
+    model = MaskRCNN(cfg).to(DEV)
+    broadcast_parameters(model)
+    opt = set_optimizer(model, cfg.TRAIN)
+    sync = GradientBuckets(model)
+    batch = synthetic_batch(2, 1024, device=DEV, seed=2000 + rank)
+    model.proposal_hook = SyntheticProposals(batch[2], 1024, seed=7 + rank)
+    model.generator = torch.Generator(device=DEV).manual_seed(11 + rank)
+    hist = []
+    for _ in range(2):
+        t = train_step(model, opt, list(batch), grad_sync=sync, world_size=WORLD, reduce_fn=all_reduce_statistics)
+        hist.append({k: float(v) for k, v in t.items()})
+    sync.check()
+    torch.cuda.synchronize()
+    torch.save({"hist": hist, "param_digest": _digest(model), "buffer_cnt": model.feature_buffer.buffer_cnt.cpu(),
+                "buckets": len(sync.buckets)}, os.path.join(outdir, "rank%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_configs3_slice_two_ranks_full_size():
+    """BASELINE configs[3] (ResNet-101-FPN, data parallel, 2 images per GPU) with two of its ranks, at full
+    size, for two steps: every rank's losses are finite, the shared meta term and history buffer agree, and the
+    replicas are bit-identical after each rank applied the averaged gradient."""
+    with tempfile.TemporaryDirectory() as outdir:
+        mp.spawn(_worker_cfg4, args=(_free_port(), outdir), nprocs=WORLD, join=True)
+        res = [torch.load(os.path.join(outdir, "rank%d.pt" % r), weights_only=False) for r in range(WORLD)]
+    assert res[0]["param_digest"] == res[1]["param_digest"]
+    assert torch.equal(res[0]["buffer_cnt"], res[1]["buffer_cnt"]) and float(res[0]["buffer_cnt"].sum()) > 0
+    assert res[0]["buckets"] >= 8
+    for step in range(2):
+        assert res[0]["hist"][step]["meta"] == res[1]["hist"][step]["meta"]          # one meta term, evaluated on both
+        for r in range(WORLD):
+            assert all(np.isfinite(v) for v in res[r]["hist"][step].values()), res[r]["hist"][step]
+    assert res[0]["hist"][1]["total"] < res[0]["hist"][0]["total"]

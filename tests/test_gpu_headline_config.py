@@ -76,3 +76,61 @@ def test_configs2_full_size_two_steps_operators_vs_oracle(oracle):
     assert np.all(np.abs(got - exp) <= 1e-4 * np.abs(exp) + 1e-7), np.abs(got - exp).max()
     del model, opt
     torch.cuda.empty_cache()
+
+
+def test_configs4_slice_full_size_bf16(oracle):
+    """The single-GPU slice of BASELINE configs[4]: ResNet-101-FPN, 1333x800 padded to 1344^2,
+    2 images per GPU, 1000 RoIs per image with the mask head, bf16-input MFMA convolutions.  Two full train
+    steps; the RoIAlign and NMS launches inside the step stay bit-exact / index-exact against the oracle
+    (they do not depend on the conv arithmetic), the losses are finite and go down."""
+    from feature_intertwiner_amd import _lib, conv as C
+    from feature_intertwiner_amd.config import make_config
+    from feature_intertwiner_amd.model import MaskRCNN
+    from feature_intertwiner_amd.synthetic import SyntheticProposals, synthetic_batch
+    from feature_intertwiner_amd.workflow import set_optimizer, train_step
+    torch.manual_seed(2000)
+    cfg = make_config("resnet101", 1344, 2, 1000, dev_switch=True, loss_choice="ot", ot_L=50, conv_precision="bf16")
+    model = MaskRCNN(cfg).to(DEV)
+    opt = set_optimizer(model, cfg.TRAIN)
+    batch = synthetic_batch(2, 1344, device=DEV, seed=2000)
+    model.proposal_hook = SyntheticProposals(batch[2], 1344, seed=7)
+    model.generator = torch.Generator(device=DEV).manual_seed(11)
+    first = float(train_step(model, opt, list(batch))["total"])
+    taps = []
+    C.FLOP_LOG = {}
+    _lib.TAP = lambda name, **kw: taps.append((name, {k: (v.detach().clone() if torch.is_tensor(v) else
+                                                         ([m.detach() for m in v] if isinstance(v, list) else v))
+                                                      for k, v in kw.items()}))
+    try:
+        terms = train_step(model, opt, list(batch))
+    finally:
+        _lib.TAP = None
+        used, C.FLOP_LOG = dict(C.FLOP_LOG), None
+    torch.cuda.synchronize()
+    assert all(torch.isfinite(v) for v in terms.values()), terms
+    assert float(terms["total"]) < first
+    # the bf16 kernels carried the conv stack (the 3-channel stem and a few narrow layers stay on fp32)
+    bf = sum(f for k, (n, f) in used.items() if "bf16" in k)
+    assert bf > 0.97 * sum(f for n, f in used.values()), {k: v[1] / 1e9 for k, v in used.items()}
+    assert C.conv_precision() == "fp32"
+    crops = [t for n, t in taps if n == "pyramid_crop"]
+    assert sorted((c["crop"], c["boxes"].shape[0] == 2000) for c in crops) == [(7, True), (14, False), (14, True)]
+    c7 = [c for c in crops if c["crop"] == 7][0]
+    assert [tuple(m.shape[2:]) for m in c7["maps"]] == [(336, 336), (168, 168), (84, 84), (42, 42)]
+    for c in crops:
+        maps = [m.cpu().numpy() for m in c["maps"]]
+        boxes, ind, level = c["boxes"].cpu().numpy(), c["box_ind"].cpu().numpy(), c["level"].cpu().numpy()
+        got = c["crops"].cpu().numpy()
+        for l in range(2, 6):
+            sel = np.nonzero(level == l)[0]
+            if len(sel):
+                exp = oracle.crop_and_resize_forward(maps[l - 2], boxes[sel], ind[sel], c["crop"], c["crop"])
+                assert np.array_equal(got[sel].view(np.uint32), exp.view(np.uint32)), (c["crop"], l)
+    t = dict(taps)["nms_sorted"]
+    dets, keep, num = t["boxes"].cpu().numpy(), t["keep"].cpu().numpy(), t["num_out"].cpu().numpy()
+    assert dets.shape == (2, 6000, 5)
+    for b in range(2):
+        exp = oracle.pth_nms(dets[b], 0.7)[:t["max_keep"]]
+        assert int(num[b]) == len(exp) and np.array_equal(keep[b, :len(exp)], exp)
+    del model, opt
+    torch.cuda.empty_cache()
