@@ -519,6 +519,165 @@ __global__ __launch_bounds__(kThreads) void crop_bwd_cl_kernel(
     }
 }
 
+// Channels-last backward for crops with more bins than source cells (14 x 14 crops of the mask branch: a box
+// of a pyramid level covers about 8..21 source rows/columns, so its 4 * 196 bilinear contributions per channel
+// land on 64..441 distinct cells).  GATHER form: the sample coordinates of an axis are monotone in the bin
+// index, so the bins whose lower (upper) tap is source row r form ONE contiguous range; a thread owns a
+// (source cell, channel) pair, sums its <= 2 x 2 ranges of bins from the LDS copy of the box's gradient block
+// and issues ONE global atomic -- 2..10x fewer atomics than the scatter form (crop_bwd_cl_kernel), no LDS
+// atomics, no tile to clear.  Boxes with a footprint wider than 64 rows or columns (not produced by the level
+// assignment; the tests do) take the scatter loop.
+constexpr int kGatherCpb = 32;    // channels per workgroup: 128-byte runs in the channels-last maps
+constexpr int kGatherSpan = 64;   // footprint rows / columns with a range table entry
+
+// ranges of bins per source row: byte 0 = first bin with i0 == row, byte 1 = their count, byte 2 = first bin
+// with i1 == row, byte 3 = their count
+__device__ __forceinline__ unsigned tap_ranges(const Tap *__restrict__ taps, int n, int row)
+{
+    int a0 = 0, n0 = 0, a1 = 0, n1 = 0;
+    for (int k = 0; k < n; ++k) {
+        const Tap t = taps[k];
+        if (!t.valid) continue;
+        if (t.i0 == row) {
+            if (n0 == 0) a0 = k;
+            ++n0;
+        }
+        if (t.i1 == row) {
+            if (n1 == 0) a1 = k;
+            ++n1;
+        }
+    }
+    return (unsigned)a0 | ((unsigned)n0 << 8) | ((unsigned)a1 << 16) | ((unsigned)n1 << 24);
+}
+
+template <int CH, int CW>
+__global__ __launch_bounds__(kThreads) void crop_bwd_cl_gather_kernel(
+    LevelSetMut ls, const float *__restrict__ grads, const float *__restrict__ boxes,
+    const int *__restrict__ box_ind, const int *__restrict__ level, int num_boxes, int batch,
+    int depth, int crop_h_rt, int crop_w_rt, int chunks)
+{
+    const int crop_h = CH ? CH : crop_h_rt;
+    const int crop_w = CW ? CW : crop_w_rt;
+    const int bins = crop_h * crop_w;
+    const int pitch = bins | 1;
+    extern __shared__ float s_dyn[];          // [kGatherCpb][pitch]: the box's gradient block
+    __shared__ Tap s_ty[kMaxCrop];
+    __shared__ Tap s_tx[kMaxCrop];
+    __shared__ int s_lim[4];                  // ymin, ymax, xmin, xmax over the valid taps
+    __shared__ unsigned s_rows[kGatherSpan], s_cols[kGatherSpan];
+
+    const int tid = threadIdx.x;
+    const int box = blockIdx.x / chunks;
+    const int chunk = blockIdx.x - box * chunks;
+    const int c_begin = chunk * kGatherCpb;
+    const int c_count = min(kGatherCpb, depth - c_begin);
+    const int total = c_count * bins;
+
+    BoxHeader h;
+    if (!load_box(ls, boxes, box_ind, level, box, batch, h)) return;
+    if (tid == 0) {
+        s_lim[0] = 0x7fffffff; s_lim[1] = -1; s_lim[2] = 0x7fffffff; s_lim[3] = -1;
+    }
+    __syncthreads();
+    if (tid < crop_h) {
+        const Tap t = make_tap(h.y1, h.y2, h.H, crop_h, tid);
+        s_ty[tid] = t;
+        if (t.valid) {
+            atomicMin(&s_lim[0], t.i0);
+            atomicMax(&s_lim[1], t.i1);
+        }
+    }
+    if (tid >= 64 && tid < 64 + crop_w) {
+        const Tap t = make_tap(h.x1, h.x2, h.W, crop_w, tid - 64);
+        s_tx[tid - 64] = t;
+        if (t.valid) {
+            atomicMin(&s_lim[2], t.i0);
+            atomicMax(&s_lim[3], t.i1);
+        }
+    }
+    const float *__restrict__ gsrc = grads + ((size_t)box * depth + c_begin) * bins;
+    for (int i = tid; i < total; i += kThreads) {
+        const int cc = i / bins;
+        s_dyn[cc * pitch + (i - cc * bins)] = gsrc[i];
+    }
+    __syncthreads();
+    const int ymin = s_lim[0], xmin = s_lim[2];
+    const int fh = s_lim[1] - ymin + 1, fw = s_lim[3] - xmin + 1;
+    if (fh <= 0 || fw <= 0) return;           // every sample of an axis lies outside the map
+    float *__restrict__ dst = ls.img[h.lvl] + (size_t)h.img * h.H * h.W * depth + c_begin;
+    const int W = h.W;
+
+    if (fh > kGatherSpan || fw > kGatherSpan) {          // scatter form
+        const int c = tid % kGatherCpb;
+        const int g = tid / kGatherCpb;
+        constexpr int ng = kThreads / kGatherCpb;
+        if (c >= c_count) return;
+        for (int b = g; b < bins; b += ng) {
+            const int y = b / crop_w;
+            const int x = b - y * crop_w;
+            const Tap ty = s_ty[y];
+            const Tap tx = s_tx[x];
+            if (!(ty.valid & tx.valid)) continue;
+            const float gv = s_dyn[c * pitch + b];
+            const float gtop = (1.0f - ty.frac) * gv;
+            const float gbot = ty.frac * gv;
+            const float wx0 = 1.0f - tx.frac;
+            const size_t r0 = (size_t)ty.i0 * W, r1 = (size_t)ty.i1 * W;
+            atomicAdd(dst + (r0 + tx.i0) * depth + c, wx0 * gtop);
+            atomicAdd(dst + (r0 + tx.i1) * depth + c, tx.frac * gtop);
+            atomicAdd(dst + (r1 + tx.i0) * depth + c, wx0 * gbot);
+            atomicAdd(dst + (r1 + tx.i1) * depth + c, tx.frac * gbot);
+        }
+        return;
+    }
+
+    if (tid < fh) s_rows[tid] = tap_ranges(s_ty, crop_h, ymin + tid);
+    if (tid >= 64 && tid < 64 + fw) s_cols[tid - 64] = tap_ranges(s_tx, crop_w, xmin + tid - 64);
+    __syncthreads();
+
+    // a wavefront covers 2 cells x 32 channels: two 128-byte runs per atomic instruction
+    const int c = tid % kGatherCpb;
+    if (c >= c_count) return;
+    const float *__restrict__ gc = s_dyn + c * pitch;
+    const int cells = fh * fw;
+    int py = 0, px = tid / kGatherCpb;          // cell = py * fw + px, advanced incrementally
+    while (px >= fw) {
+        px -= fw;
+        ++py;
+    }
+    constexpr int step = kThreads / kGatherCpb;
+    for (int cell = tid / kGatherCpb; cell < cells; cell += step) {
+        const unsigned ri = s_rows[py], ci = s_cols[px];
+        if ((ri & 0xff00ff00u) && (ci & 0xff00ff00u)) {
+            float sum = 0.0f;
+#pragma unroll
+            for (int ky = 0; ky < 2; ++ky) {
+                const int ya = (ri >> (16 * ky)) & 0xff, yn = (ri >> (16 * ky + 8)) & 0xff;
+                for (int y = ya; y < ya + yn; ++y) {
+                    const float fy = s_ty[y].frac;
+                    const float wy = ky ? fy : 1.0f - fy;
+                    float rowsum = 0.0f;
+#pragma unroll
+                    for (int kx = 0; kx < 2; ++kx) {
+                        const int xa = (ci >> (16 * kx)) & 0xff, xn = (ci >> (16 * kx + 8)) & 0xff;
+                        for (int x = xa; x < xa + xn; ++x) {
+                            const float fx = s_tx[x].frac;
+                            rowsum += (kx ? fx : 1.0f - fx) * gc[y * crop_w + x];
+                        }
+                    }
+                    sum += wy * rowsum;
+                }
+            }
+            atomicAdd(dst + ((size_t)(ymin + py) * W + (xmin + px)) * depth + c, sum);
+        }
+        px += step;
+        while (px >= fw) {
+            px -= fw;
+            ++py;
+        }
+    }
+}
+
 __global__ void crop_taps_kernel(const float *__restrict__ boxes, int num_boxes, int H, int W,
                                  int crop_h, int crop_w, int *y_valid, int *y0, int *y1,
                                  float *y_frac, int *x_valid, int *x0, int *x1, float *x_frac)
@@ -688,6 +847,20 @@ int backward_cl_impl(const LevelSetMut &ls, const float *grads, const float *box
     }
     if (num_boxes == 0) return FI_OK;
     const int bins = crop_h * crop_w;
+    const int cls = cl_size_class(crop_h, crop_w);
+    if (bins >= 100 && bins <= 220) {
+        // more bins than source cells per box: gather form, one atomic per touched cell
+        const int chunks = fi::ceil_div(depth, kGatherCpb);
+        const long nblk = (long)num_boxes * chunks;
+        FI_REQUIRE(nblk < 2147483647L, "grid too large");
+        const size_t lds = sizeof(float) * (size_t)kGatherCpb * (bins | 1);
+        fi::ProfScope prof(FI_K_CROP_BWD_NHWC_7X7 + cls, st);
+        auto k = cls == 1 ? crop_bwd_cl_gather_kernel<14, 14> : crop_bwd_cl_gather_kernel<0, 0>;
+        hipLaunchKernelGGL(k, dim3((unsigned)nblk), dim3(kThreads), lds, st, ls, grads, boxes, box_ind, level,
+                           num_boxes, batch, depth, crop_h, crop_w, chunks);
+        FI_HIP_CHECK(hipGetLastError());
+        return FI_OK;
+    }
     const int cpb = pick_cl_chunk(depth, bins);
     if (cpb == 0) {
         fi::set_error("channels-last crop supports crop_h*crop_w <= 220 (got %dx%d)", crop_h, crop_w);
@@ -697,7 +870,6 @@ int backward_cl_impl(const LevelSetMut &ls, const float *grads, const float *box
     const long nblk = (long)num_boxes * chunks;
     FI_REQUIRE(nblk < 2147483647L, "grid too large");
     const size_t lds = sizeof(float) * (size_t)cpb * (bins | 1);
-    const int cls = cl_size_class(crop_h, crop_w);
     fi::ProfScope prof(FI_K_CROP_BWD_NHWC_7X7 + cls, st);
     auto k = cls == 0 ? crop_bwd_cl_kernel<7, 7> : cls == 1 ? crop_bwd_cl_kernel<14, 14> : crop_bwd_cl_kernel<0, 0>;
     hipLaunchKernelGGL(k, dim3((unsigned)nblk), dim3(kThreads), lds, st, ls, grads, boxes, box_ind, level,

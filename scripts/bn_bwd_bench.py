@@ -1,24 +1,47 @@
-"""fi_bn_act_backward on the big activation shapes of the step (GB/s = (reads + writes) / time)."""
-import json, os, sys, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+"""fi_bn_act_backward on the ResNet-101 layer shapes of the headline step (N=4, 1024^2): time and achieved
+HBM rate per shape, narrow (conv1/conv2: dy,y read, dz written) and wide (conv3: + shortcut read and the
+masked gradient for the shortcut written)."""
+import os, sys
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 from feature_intertwiner_amd import _lib
+
+dev = "cuda:0"
 L = _lib.load()
-for (N, C, H, W, res) in [(4, 256, 256, 256, True), (4, 64, 256, 256, False), (4, 1024, 64, 64, True), (2048, 256, 14, 14, False)]:
-    y = torch.randn(N, C, H, W, device="cuda").relu_(); dy = torch.randn_like(y)
-    r = torch.randn_like(y) if res else None
-    sc = torch.rand(C, device="cuda") + 0.5; ga = torch.rand(C, device="cuda") + 0.5; be = torch.randn(C, device="cuda")
-    dz = torch.empty_like(y); gres = torch.empty_like(y) if res else None
-    sums = torch.empty(2, C, device="cuda")
+N = 4
+SHAPES = [(64, 256, 6, False), (256, 256, 3, True), (128, 128, 8, False), (512, 128, 4, True),
+          (256, 64, 46, False), (1024, 64, 23, True), (512, 32, 6, False), (2048, 32, 3, True)]
+total = 0.0
+for C, S, per_step, wide in SHAPES:
+    HW = S * S
+    dy = torch.randn(N, C, S, S, device=dev)
+    y = torch.randn(N, C, S, S, device=dev).relu_()
+    res = torch.randn(N, C, S, S, device=dev) if wide else None
+    dz = torch.empty_like(y)
+    g = torch.empty_like(y) if wide else None
+    scale = torch.rand(C, device=dev) + 0.5
+    gamma = torch.rand(C, device=dev) + 0.5
+    beta = torch.randn(C, device=dev)
+    sums = torch.zeros(3 * C, device=dev)
+
     def run():
-        _lib.check(L.fi_bn_act_backward(_lib.ptr(dy), _lib.ptr(y), _lib.ptr(sc), _lib.ptr(ga), _lib.ptr(be), _lib.ptr(r),
-                                        N, C, H * W, 1, _lib.ptr(dz), _lib.ptr(gres), _lib.ptr(sums[0]), _lib.ptr(sums[1]), None, 0, 0,
-                                        _lib.current_stream()), "bn")
-    for _ in range(5): run()
+        _lib.check(L.fi_bn_act_backward(_lib.ptr(dy), _lib.ptr(y), _lib.ptr(scale), _lib.ptr(gamma), _lib.ptr(beta),
+                                        _lib.ptr(res), N, C, HW, 1, _lib.ptr(dz), _lib.ptr(g), _lib.ptr(sums[:C]),
+                                        _lib.ptr(sums[C:2 * C]), None, 0, _lib.OUTPUTS_ZEROED, _lib.current_stream()), "bn")
+    for _ in range(5):
+        run()
     torch.cuda.synchronize()
-    a = torch.cuda.Event(enable_timing=True); b = torch.cuda.Event(enable_timing=True)
-    a.record()
-    for _ in range(20): run()
-    b.record(); b.synchronize()
-    t = a.elapsed_time(b) / 20 * 1e-3
-    nbytes = y.numel() * 4 * (3 + (2 if res else 0))
-    print(json.dumps({"shape": [N, C, H, W], "residual": res, "us": round(t * 1e6, 1), "GBps": round(nbytes / t / 1e9, 1)}))
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 50
+    e0.record()
+    for _ in range(reps):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / reps
+    nbytes = 4 * N * C * HW * (5 if wide else 3)
+    total += us * per_step
+    print("C=%5d %3dx%-3d %-6s %8.1f us  %7.0f GB/s   x%d/step = %.2f ms" % (C, S, S, "wide" if wide else "narrow", us,
+                                                                             nbytes / us / 1e3, per_step, us * per_step / 1e3))
+print("per step: %.2f ms" % (total / 1e3))

@@ -34,6 +34,7 @@ for e in rows[:45]:
 want = ("aten::copy_", "aten::add", "aten::add_", "aten::mul", "aten::fill_", "aten::zero_", "aten::clone",
         "aten::contiguous", "hipMemcpyAsync", "hipMemcpyWithStream", "aten::_to_copy", "aten::sub", "aten::div")
 sites = collections.Counter()
+site_dev = collections.Counter()
 for ev in prof.events():
     if ev.name not in want:
         continue
@@ -50,8 +51,10 @@ for ev in prof.events():
                 break
             p_ = p_.cpu_parent
     sites[(ev.name, site or "?")] += 1
-for (name, site), n in sites.most_common(60):
-    print("%5d  %-16s %s" % (n, name, site))
+    site_dev[(ev.name, site or "?")] += sum(k.duration for k in (ev.kernels or []))
+print("%5s %9s  %-16s %s" % ("count", "device_us", "op", "call site"))
+for (name, site), us in site_dev.most_common(70):
+    print("%5d %9.1f  %-16s %s" % (sites[(name, site)], us, name, site))
 
 # GPU busy vs wall: union of device-side kernel intervals inside the profiled step
 iv = []
