@@ -72,7 +72,7 @@ struct ConvGeom {
 
 // Out-of-image taps of the tap-major gather read this instead of being masked after the load:
 // the loaded registers go to LDS untouched (no per-value select in the K loop).
-__device__ float g_zero_page[64];
+__device__ __attribute__((aligned(16))) float g_zero_page[64];
 
 // exact for 0 <= n < 2^31 (mul = ceil(2^(32+sft) / d), 32 + sft = 31 + ceil(log2 d))
 __device__ __forceinline__ int fast_div(int n, unsigned mul, unsigned sft)
@@ -113,6 +113,79 @@ __device__ __forceinline__ void mma_tile(const float (*__restrict__ As)[BM + PAD
     }
 }
 
+// NCHW epilogue of a FULL tile (every row < Cout, every pixel < P): no predicate anywhere, so the code is one
+// basic block and the compiler batches the loads.  (The general path below tests scale / bias / residual /
+// bounds per group of 4 pixels: its ISA is a chain of `global_load; s_waitcnt vmcnt(0)` -- scale, bias, shortcut,
+// 48 dependent round trips per lane -- which on the short-K 1x1 layers, where all resident workgroups reach
+// the epilogue together, cost 10..15 % of the kernel.)  Absent scale / bias are read from a dummy page and
+// dropped by a select, so that the arithmetic stays exactly `acc [*scale] [+bias] [+shortcut] [relu]`.
+template <int BM, int BNT, bool HAS_RES>
+__device__ __forceinline__ void conv_epilogue_full(const f32x16 (&acc)[BM / 64][BNT / 64], const Epilogue &ep,
+                                                   float *__restrict__ y, const ConvGeom &g, int m0, int p0,
+                                                   int wm, int wn, int l31, int khalf,
+                                                   float *__restrict__ scratch)
+{
+    constexpr int MT = BM / 64;
+    constexpr int NT = BNT / 64;
+    constexpr int SP = 36;                       // scratch row pitch (floats): 16-byte aligned rows
+    const int OHW = g.OH * g.OW;
+    const int lane = l31 + 32 * khalf;
+    const int rr = lane >> 3;                    // 0..7 (+8 for the second read)
+    const int c4 = (lane & 7) * 4;
+    const bool has_sc = ep.scale != nullptr, has_bi = ep.bias != nullptr, relu = ep.relu != 0;
+    const float *__restrict__ sp = has_sc ? ep.scale : g_zero_page;
+    const float *__restrict__ bp = has_bi ? ep.bias : g_zero_page;
+    const int smul = has_sc ? 1 : 0, bmul = has_bi ? 1 : 0;
+    const int mrow = m0 + wm * (BM / 2) + rr;
+    float scv[MT][4], biv[MT][4];                // rows mrow + i*32 + 8*q, q = half*2 + t
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            scv[i][q] = sp[(mrow + i * 32 + 8 * q) * smul];
+            biv[i][q] = bp[(mrow + i * 32 + 8 * q) * bmul];
+        }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int pp = p0 + wn * (BNT / 2) + j * 32 + c4;
+        const int on = fast_div(pp, g.mul_ohw, g.sft_ohw);
+        const size_t obase = (size_t)on * g.Cout * OHW + (pp - on * OHW) + (size_t)mrow * OHW;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            float4 r[4];
+            if (HAS_RES) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    r[q] = *reinterpret_cast<const float4 *>(ep.residual + obase + (size_t)(i * 32 + 8 * q) * OHW);
+            }
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+#pragma unroll
+                for (int e8 = 0; e8 < 8; ++e8) {
+                    const int e = half * 8 + e8;
+                    scratch[((e & 3) + 8 * ((e >> 2) & 1) + 4 * khalf) * SP + l31] = acc[i][j][e];
+                }
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int q = half * 2 + t;
+                    float4 v = *reinterpret_cast<const float4 *>(&scratch[(rr + 8 * t) * SP + c4]);
+                    const float sc = scv[i][q], bi = biv[i][q];
+                    v.x = has_sc ? v.x * sc : v.x; v.y = has_sc ? v.y * sc : v.y;
+                    v.z = has_sc ? v.z * sc : v.z; v.w = has_sc ? v.w * sc : v.w;
+                    v.x = has_bi ? v.x + bi : v.x; v.y = has_bi ? v.y + bi : v.y;
+                    v.z = has_bi ? v.z + bi : v.z; v.w = has_bi ? v.w + bi : v.w;
+                    if (HAS_RES) {
+                        v.x += r[q].x; v.y += r[q].y; v.z += r[q].z; v.w += r[q].w;
+                    }
+                    v.x = relu ? fmaxf(v.x, 0.0f) : v.x; v.y = relu ? fmaxf(v.y, 0.0f) : v.y;
+                    v.z = relu ? fmaxf(v.z, 0.0f) : v.z; v.w = relu ? fmaxf(v.w, 0.0f) : v.w;
+                    *reinterpret_cast<float4 *>(y + obase + (size_t)(i * 32 + 8 * q) * OHW) = v;
+                }
+            }
+        }
+    }
+}
+
 // Epilogue shared by the forward kernels.  C/D layout of v_mfma_f32_32x32x2_f32:
 // col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5).
 template <int BM, bool ONHWC, int BNT = BN>
@@ -123,6 +196,13 @@ __device__ __forceinline__ void conv_epilogue(const f32x16 (&acc)[BM / 64][BNT /
     constexpr int MT = BM / 64;
     constexpr int NT = BNT / 64;
     const int OHW = g.OH * g.OW;
+    if (!ONHWC && g.vec_out && p0 + BNT <= g.P && m0 + BM <= g.Cout) {
+        if (ep.residual)
+            conv_epilogue_full<BM, BNT, true>(acc, ep, y, g, m0, p0, wm, wn, l31, khalf, scratch);
+        else
+            conv_epilogue_full<BM, BNT, false>(acc, ep, y, g, m0, p0, wm, wn, l31, khalf, scratch);
+        return;
+    }
     if (!ONHWC && g.vec_out) {
         // NCHW through a wavefront-private LDS transpose: the MFMA layout gives a lane 16 different
         // channels of ONE pixel (64 scalar stores, and 64 scalar shortcut loads, per lane and tile); after

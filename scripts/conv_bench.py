@@ -59,6 +59,10 @@ def main():
         OH, OW = y.shape[2], y.shape[3]
         flops = 2.0 * N * Cout * OH * OW * Cin * R * R
         t_f = timeit(lambda: _conv_fwd(x, w, b, (st, st), (pd, pd), precision=prec))
+        # the fused epilogue of a bottleneck's last convolution: eval-BN scale/shift + shortcut + ReLU
+        sc = torch.rand(Cout, device=DEV) + 0.5
+        res = torch.randn_like(y)
+        t_e = timeit(lambda: _conv_fwd(x, w, b, (st, st), (pd, pd), relu=True, scale=sc, residual=res, precision=prec))
         dw = torch.empty_like(w)
         dy = torch.randn_like(y)
         same = st == 1 and OH == H and OW == W and (H * W) % 4 == 0 and W >= 4
@@ -75,7 +79,7 @@ def main():
                                                st, st, pd, pd, hwc, None, 0, _lib.current_stream()), "wgrad")
         t_w = timeit(wg)
         print(json.dumps({"precision": prec, "layer": name, "GFLOP": round(flops / 1e9, 1), "fwd_us": round(t_f * 1e6, 1),
-                          "fwd_TFLOPs": round(flops / t_f / 1e12, 1), "wgrad_us": round(t_w * 1e6, 1),
+                          "fwd_TFLOPs": round(flops / t_f / 1e12, 1), "fwd_fused_us": round(t_e * 1e6, 1), "wgrad_us": round(t_w * 1e6, 1),
                           "wgrad_TFLOPs": round(flops / t_w / 1e12, 1)}))
 
 
