@@ -110,6 +110,10 @@ __device__ __forceinline__ void mma_tile(const float (*__restrict__ As)[BM + PAD
 #pragma unroll
             for (int j = 0; j < NT; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i], bf[cur][j], acc[i][j], 0, 0, 0);
+        // issue order: the LDS reads of sub-step kk+1 BEFORE the MFMAs of sub-step kk (the compiler otherwise
+        // reuses one register set and reads after the MFMAs issue: LDS latency exposed once per sub-step)
+        __builtin_amdgcn_sched_group_barrier(0x100, MT + NT, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, MT * NT, 0);
     }
 }
 
