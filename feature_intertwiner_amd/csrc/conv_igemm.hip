@@ -68,6 +68,7 @@ struct ConvGeom {
     int vec_out;  // 1: NCHW output rows can be written 4 pixels at a time (OH*OW % 4 == 0, 16-byte aligned)
     int p_base;   // first output pixel of this launch (a layer may be split into a main and a tail launch)
     unsigned mul_ohw, sft_ohw, mul_ow, sft_ow;   // magic numbers: n / d == umulhi(n, mul) >> sft
+    const float *zero;   // device address of g_zero_page (a kernel argument: no GOT load inside the K loop)
 };
 
 // Out-of-image taps of the tap-major gather read this instead of being masked after the load:
@@ -137,8 +138,8 @@ __device__ __forceinline__ void conv_epilogue_full(const f32x16 (&acc)[BM / 64][
     const int rr = lane >> 3;                    // 0..7 (+8 for the second read)
     const int c4 = (lane & 7) * 4;
     const bool has_sc = ep.scale != nullptr, has_bi = ep.bias != nullptr, relu = ep.relu != 0;
-    const float *__restrict__ sp = has_sc ? ep.scale : g_zero_page;
-    const float *__restrict__ bp = has_bi ? ep.bias : g_zero_page;
+    const float *__restrict__ sp = has_sc ? ep.scale : g.zero;
+    const float *__restrict__ bp = has_bi ? ep.bias : g.zero;
     const int smul = has_sc ? 1 : 0, bmul = has_bi ? 1 : 0;
     const int mrow = m0 + wm * (BM / 2) + rr;
     float scv[MT][4], biv[MT][4];                // rows mrow + i*32 + 8*q, q = half*2 + t
@@ -461,7 +462,7 @@ __global__ __launch_bounds__(kThreads, 4) void conv_fwd_kernel(const float *__re
             const int r = rs / S, s = rs - (rs / S) * S;
             const bool ok = (tap_mask >> rs) & 1ULL;
             const int off0 = pix_off + r * g.W + s + (cur_ci0 + bk0) * HW;
-            const float *__restrict__ bp = ok ? (xn + off0) : g_zero_page;
+            const float *__restrict__ bp = ok ? (xn + off0) : g.zero;
             const int stride = ok ? B_RSTEP * HW : 0;
 #pragma unroll
             for (int i = 0; i < B_LOADS; ++i) b_reg[i] = bp[i * stride];
@@ -607,12 +608,12 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(const float *__res
             // no per-value selects: pixels past the split and taps outside the image read the zero
             // page; rows past Cout re-read the last row (their sums are never written)
             // (no integer multiplies in the loop: v_mul_lo_u32 is quarter rate)
-            const float *__restrict__ ap = ok ? dyn : g_zero_page;
+            const float *__restrict__ ap = ok ? dyn : g.zero;
             const int a_sel = ok ? -1 : 0;
 #pragma unroll
             for (int i = 0; i < A_LOADS; ++i) a_reg[i] = ap[a_off[i] & a_sel];
             const bool inb = ok && ((unsigned)(ih0 + h_r) < (unsigned)g.H) && ((unsigned)(iw0 + h_s) < (unsigned)g.W);
-            const float *__restrict__ bp = inb ? (xn + pix_off + b_off[0]) : g_zero_page;
+            const float *__restrict__ bp = inb ? (xn + pix_off + b_off[0]) : g.zero;
             const size_t stride = inb ? (size_t)h_stride : 0;
 #pragma unroll
             for (int i = 0; i < B_LOADS; ++i) {
@@ -1006,6 +1007,20 @@ int window_class(int R, int S)
     return 3;
 }
 
+// device address of g_zero_page on the current device (looked up once per device)
+const float *zero_page()
+{
+    static const float *cache[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    if (!cache[dev]) {
+        void *p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_zero_page)) != hipSuccess) return nullptr;
+        cache[dev] = static_cast<const float *>(p);
+    }
+    return cache[dev];
+}
+
 int make_geom(ConvGeom &g, int N, int Cin, int H, int W, int Cout, int R, int S, int sh, int sw,
               int ph, int pw, int out_h = 0, int out_w = 0)
 {
@@ -1017,6 +1032,8 @@ int make_geom(ConvGeom &g, int N, int Cin, int H, int W, int Cout, int R, int S,
     g.flip = 0;
     g.swz = 0;
     g.vec_out = 0;
+    g.zero = zero_page();
+    FI_REQUIRE(g.zero != nullptr, "zero page lookup failed");
     g.p_base = 0;
     g.OH = out_h > 0 ? out_h : (H + 2 * ph - R) / sh + 1;   // explicit size: taps past the input read zeros
     g.OW = out_w > 0 ? out_w : (W + 2 * pw - S) / sw + 1;
