@@ -16,4 +16,14 @@ f=$(find /tmp/prof8 -name 'c_kernel_stats.csv' | head -1); grep -E "Name|crop_|r
 # MFMA utilisation of the dominant convolution (PMC passes, one counter group per run)
 bash scripts/conv_prof.sh "FPN P2" > $O/${R}_pmc_conv_mfma.txt 2>&1
 timeout 200 python scripts/roipool_probe.py > $O/${R}_roipool_probe.txt 2>&1
-ls -la $O | tail -12
+# BASELINE configs[4] single-GPU slice (bf16 MFMA convs, 2 x 1344^2, 1000 RoIs/img) and the headline workload on the bf16 kernels
+( cd /tmp && timeout 400 python $GRAFT_REPO_ROOT/bench.py --config cfg5 --no-cpu-baseline --no-pmc > $O/${R}_bench_cfg5_bf16.json 2>/dev/null )
+( cd /tmp && timeout 400 python $GRAFT_REPO_ROOT/bench.py --conv-precision bf16 --no-cpu-baseline --no-pmc > $O/${R}_bench_cfg3_bf16.json 2>/dev/null )
+# per-layer view of the step's kernels (grid size = layer shape) from a kernel trace of the headline command
+rm -rf /tmp/prof9; ( cd /tmp && timeout 400 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof9 -o kt -- python $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 2 --profile-steps 0 --no-cpu-baseline --no-pmc > /dev/null 2>&1 )
+f=$(find /tmp/prof9 -name 'kt_kernel_trace.csv' | head -1)
+python scripts/trace_groups.py $f conv_ 7 | head -60 > $O/${R}_conv_layers.txt
+python scripts/trace_groups.py $f bn_act 7 > $O/${R}_bn_bwd_layers.txt
+timeout 200 python scripts/conv_bench.py > $O/${R}_conv_bench.txt 2>&1
+timeout 200 python scripts/conv_bench.py --bf16 > $O/${R}_conv_bench_bf16.txt 2>&1
+ls -la $O | tail -20
