@@ -73,6 +73,47 @@ __device__ __forceinline__ float pick4(const f32x4 &v, int i)
     return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w));
 }
 
+// NCHW epilogue of a tile that lies completely inside the output (all 32 rows of the lane's wavefront block
+// below Cout, every quad complete): no predicate, one basic block, so the scale / bias / shortcut loads of a
+// group of 4 rows are issued together instead of one dependent round trip each (the general path's ISA is a
+// chain of `global_load; s_waitcnt vmcnt(0)`: +40 % on a fused 1x1 layer).  Absent scale / bias are dropped by
+// a select so the arithmetic stays `acc [*scale] [+bias] [+shortcut] [relu]`.
+template <int NT, bool HAS_RES>
+__device__ __forceinline__ void epilogue_full_nchw(const f32x16 (&acc)[NT], const Epi &ep, float *__restrict__ y,
+                                                   size_t obase, int OHW, int mb)
+{
+    typedef float f32xN __attribute__((ext_vector_type(NT)));
+    typedef f32xN f32xN_a4 __attribute__((aligned(4)));
+    const bool has_sc = ep.scale != nullptr, has_bi = ep.bias != nullptr, relu = ep.relu != 0;
+    const float *__restrict__ sp = has_sc ? ep.scale + mb : y;        // any readable address when absent
+    const float *__restrict__ bp = has_bi ? ep.bias + mb : y;
+    const int smul = has_sc ? 1 : 0, bmul = has_bi ? 1 : 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float sc[4], bi[4];
+        f32xN rr[4];
+#pragma unroll
+        for (int e4 = 0; e4 < 4; ++e4) {
+            sc[e4] = sp[(8 * q + e4) * smul];
+            bi[e4] = bp[(8 * q + e4) * bmul];
+            if (HAS_RES) rr[e4] = *reinterpret_cast<const f32xN_a4 *>(ep.residual + obase + (size_t)(8 * q + e4) * OHW);
+        }
+#pragma unroll
+        for (int e4 = 0; e4 < 4; ++e4) {
+            f32xN v;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                float t = acc[j][4 * q + e4];
+                t = has_sc ? t * sc[e4] : t;
+                t = has_bi ? t + bi[e4] : t;
+                if (HAS_RES) t += rr[e4][j];
+                v[j] = relu ? fmaxf(t, 0.0f) : t;
+            }
+            *reinterpret_cast<f32xN_a4 *>(y + obase + (size_t)(8 * q + e4) * OHW) = v;
+        }
+    }
+}
+
 // SWT = column stride of the fast gather (1 or 2).  Stride 2: the 4 outputs of a quad tap input columns
 // iw0, iw0 + 2, iw0 + 4, iw0 + 6 -- two 16-byte loads (8 consecutive floats), every second element.
 template <int BM, int SWT>
@@ -317,6 +358,16 @@ __global__ __launch_bounds__(kThreads, 2) void conv_bf16_fwd_kernel(const float 
         const int nvalid = pv < PV ? min(NT, g.OW - ow) : 0;            // pixels of this lane inside the row
         const size_t p = (size_t)n * OHW + rem;
         const int mb = m0 + wm * 32 + 4 * lh;
+        // workgroup-uniform: the whole tile is inside the output and every quad is complete
+        const bool full = !g.out_nhwc && (g.OW & 3) == 0 && p0 + TN <= PV && m0 + BM <= g.Cout;
+        if (full) {
+            const size_t obase = ((size_t)n * g.Cout + mb) * OHW + rem;
+            if (ep.residual)
+                epilogue_full_nchw<NT, true>(acc, ep, y, obase, OHW, mb);
+            else
+                epilogue_full_nchw<NT, false>(acc, ep, y, obase, OHW, mb);
+            return;
+        }
         if (nvalid > 0) {
             if (g.out_nhwc) {
 #pragma unroll
