@@ -1205,6 +1205,11 @@ void launch_wgrad(const ConvGeom &g, const float *x, const float *dy, float *dw,
 //   dgamma[c] = sum g * (y - beta[c]) / gamma[c]      (x_hat recovered from y where g != 0)
 // One pass over dy and y; one workgroup per (channel, image chunk); fp32 atomics for the sums.
 // -------------------------------------------------------------------------------------
+// HAS_RES / HAS_G are template parameters so that the loop body is ONE basic block: with run-time tests the
+// shortcut load sat behind a branch and was issued only after dy and y had arrived (two dependent memory
+// round trips per 16 bytes and lane); here the 2 x (2..3) loads of two consecutive 16-byte groups are issued
+// together.
+template <bool HAS_RES, bool HAS_G>
 __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const float *__restrict__ dy,
                                                          const float *__restrict__ y,
                                                          const float *__restrict__ scale,
@@ -1225,38 +1230,63 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const float *__restrict
     const float be = beta ? beta[c] : 0.0f;
     float sum_g = 0.0f, sum_gy = 0.0f;
     const bool vec = (HW & 3) == 0;
-    for (int n = n0; n < n1; ++n) {
+    const bool norelu = relu == 0;
+    auto group = [&](const float4 d, float4 v, const float4 r, size_t at) {
+        float4 g;
+        g.x = (norelu || v.x > 0.0f) ? d.x : 0.0f;
+        g.y = (norelu || v.y > 0.0f) ? d.y : 0.0f;
+        g.z = (norelu || v.z > 0.0f) ? d.z : 0.0f;
+        g.w = (norelu || v.w > 0.0f) ? d.w : 0.0f;
+        if (HAS_RES) {   // BN output = y - shortcut wherever the gradient is non-zero
+            v.x -= r.x; v.y -= r.y; v.z -= r.z; v.w -= r.w;
+        }
+        sum_g += (g.x + g.y) + (g.z + g.w);
+        sum_gy += (g.x * (v.x - be) + g.y * (v.y - be)) + (g.z * (v.z - be) + g.w * (v.w - be));
+        if (HAS_G) *reinterpret_cast<float4 *>(g_out + at) = g;
+        float4 o;
+        o.x = g.x * sc; o.y = g.y * sc; o.z = g.z * sc; o.w = g.w * sc;
+        *reinterpret_cast<float4 *>(dz + at) = o;
+    };
+    for (int n = n0; vec && n < n1; ++n) {
         const size_t base = ((size_t)n * C + c) * HW;
-        if (vec) {
-            for (int i = threadIdx.x * 4; i < HW; i += 1024) {
-                const float4 d = *reinterpret_cast<const float4 *>(dy + base + i);
-                float4 v = *reinterpret_cast<const float4 *>(y + base + i);
-                float4 g;
-                g.x = (!relu || v.x > 0.0f) ? d.x : 0.0f;
-                g.y = (!relu || v.y > 0.0f) ? d.y : 0.0f;
-                g.z = (!relu || v.z > 0.0f) ? d.z : 0.0f;
-                g.w = (!relu || v.w > 0.0f) ? d.w : 0.0f;
-                if (residual) {   // BN output = y - shortcut wherever the gradient is non-zero
-                    const float4 r = *reinterpret_cast<const float4 *>(residual + base + i);
-                    v.x -= r.x; v.y -= r.y; v.z -= r.z; v.w -= r.w;
+        {
+            int i = threadIdx.x * 4;
+            for (; i + 1024 < HW; i += 2048) {          // two groups per trip, all loads first
+                const float4 d0 = *reinterpret_cast<const float4 *>(dy + base + i);
+                const float4 v0 = *reinterpret_cast<const float4 *>(y + base + i);
+                const float4 d1 = *reinterpret_cast<const float4 *>(dy + base + i + 1024);
+                const float4 v1 = *reinterpret_cast<const float4 *>(y + base + i + 1024);
+                float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0;
+                if (HAS_RES) {
+                    r0 = *reinterpret_cast<const float4 *>(residual + base + i);
+                    r1 = *reinterpret_cast<const float4 *>(residual + base + i + 1024);
                 }
-                sum_g += (g.x + g.y) + (g.z + g.w);
-                sum_gy += (g.x * (v.x - be) + g.y * (v.y - be)) + (g.z * (v.z - be) + g.w * (v.w - be));
-                if (g_out) *reinterpret_cast<float4 *>(g_out + base + i) = g;
-                float4 o;
-                o.x = g.x * sc; o.y = g.y * sc; o.z = g.z * sc; o.w = g.w * sc;
-                *reinterpret_cast<float4 *>(dz + base + i) = o;
+                group(d0, v0, r0, base + i);
+                group(d1, v1, r1, base + i + 1024);
             }
-        } else {
-            for (int i = threadIdx.x; i < HW; i += 256) {
-                const float d = dy[base + i], v = y[base + i];
-                const float g = (!relu || v > 0.0f) ? d : 0.0f;
-                const float vb = residual ? (v - residual[base + i]) : v;
-                sum_g += g;
-                sum_gy += g * (vb - be);
-                if (g_out) g_out[base + i] = g;
-                dz[base + i] = g * sc;
+            if (i < HW) {
+                const float4 d0 = *reinterpret_cast<const float4 *>(dy + base + i);
+                const float4 v0 = *reinterpret_cast<const float4 *>(y + base + i);
+                float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (HAS_RES) r0 = *reinterpret_cast<const float4 *>(residual + base + i);
+                group(d0, v0, r0, base + i);
             }
+        }
+    }
+    if (!vec) {
+        // planes whose size is not a multiple of 4 (7x7 = 49: RoI heads): the workgroup walks the flattened
+        // (image, element) index of its channel, so all 256 lanes stay busy on planes smaller than 256
+        const int total = (n1 - n0) * HW;
+        for (int idx = threadIdx.x; idx < total; idx += 256) {
+            const int n = idx / HW;
+            const size_t at = ((size_t)(n0 + n) * C + c) * HW + (idx - n * HW);
+            const float d = dy[at], v = y[at];
+            const float g = (norelu || v > 0.0f) ? d : 0.0f;
+            const float vb = HAS_RES ? (v - residual[at]) : v;
+            sum_g += g;
+            sum_gy += g * (vb - be);
+            if (HAS_G) g_out[at] = g;
+            dz[at] = g * sc;
         }
     }
 #pragma unroll
@@ -1465,6 +1495,7 @@ int fi_bn_act_backward(const float *dy, const float *y, const float *scale, cons
         FI_HIP_CHECK(hipGetLastError());
         return FI_OK;
     }
+    FI_REQUIRE((long)N * HW < 2147483647L, "too many elements per channel");
     // enough workgroups to fill the chip: C * chunks >= ~2048
     int chunks = fi::ceil_div(2048, C);
     if (chunks > N) chunks = N;
@@ -1472,7 +1503,9 @@ int fi_bn_act_backward(const float *dy, const float *y, const float *scale, cons
     const int ipb = fi::ceil_div(N, chunks);
     chunks = fi::ceil_div(N, ipb);
     fi::ProfScope prof(FI_K_BN_ACT_BWD, st);
-    hipLaunchKernelGGL(bn_act_bwd_kernel, dim3(C, chunks), dim3(256), 0, st, dy, y, scale, gamma, beta, residual,
+    auto k = residual ? (g_out ? bn_act_bwd_kernel<true, true> : bn_act_bwd_kernel<true, false>)
+                      : (g_out ? bn_act_bwd_kernel<false, true> : bn_act_bwd_kernel<false, false>);
+    hipLaunchKernelGGL(k, dim3(C, chunks), dim3(256), 0, st, dy, y, scale, gamma, beta, residual,
                        N, C, HW, relu, dz, g_out, dshift, dgamma, dbias, ipb);
     FI_HIP_CHECK(hipGetLastError());
     return FI_OK;
