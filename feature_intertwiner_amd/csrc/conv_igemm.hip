@@ -1032,8 +1032,7 @@ int make_geom(ConvGeom &g, int N, int Cin, int H, int W, int Cout, int R, int S,
     g.flip = 0;
     g.swz = 0;
     g.vec_out = 0;
-    g.zero = zero_page();
-    FI_REQUIRE(g.zero != nullptr, "zero page lookup failed");
+    g.zero = nullptr;      // set by the entry points once the arguments are validated (needs the device)
     g.p_base = 0;
     g.OH = out_h > 0 ? out_h : (H + 2 * ph - R) / sh + 1;   // explicit size: taps past the input read zeros
     g.OW = out_w > 0 ? out_w : (W + 2 * pw - S) / sw + 1;
@@ -1450,6 +1449,8 @@ int fi_conv2d_forward(const float *x, const float *weight, const float *bias, co
     const bool hwc = (Cin % BK == 0) && (R * S <= 64) && (weight_layout >= 1 || R * S == 1);
     FI_REQUIRE(hwc || weight_layout == 0, "weight_layout 1/2 needs Cin % 16 == 0 and R*S <= 64");
     g.flip = (weight_layout == 2) ? 1 : 0;
+    g.zero = zero_page();
+    FI_REQUIRE(g.zero != nullptr, "zero page lookup failed (no HIP device?)");
     hipStream_t st = (hipStream_t)stream;
     const Epilogue ep = {bias, scale, residual, relu};
     const bool bm64 = use_bm64(Cout, g.P);
@@ -1526,6 +1527,8 @@ int fi_conv2d_weight_grad(const float *x, const float *dy, float *dweight, int N
     const bool hwc = ((Cin % BN == 0) || half) && (weight_layout == 1 || R * S == 1);
     FI_REQUIRE(hwc || weight_layout == 0,
                "weight_layout 1 needs Cin % 128 == 0, or Cin == 64 on a same-size stride-1 layer");
+    g.zero = zero_page();
+    FI_REQUIRE(g.zero != nullptr, "zero page lookup failed (no HIP device?)");
     hipStream_t st = (hipStream_t)stream;
     if (!(flags & FI_OUTPUTS_ZEROED)) {
         FI_HIP_CHECK(hipMemsetAsync(dweight, 0, sizeof(float) * (size_t)Cout * g.K, st));
