@@ -201,6 +201,33 @@ def async_host_read(t):
 
 
 _SIDE = {}
+_SIDE2 = {}
+
+
+def run_on_side_stream(fn, *args):
+    """Run fn(*args) (network-independent small kernels, e.g. RPN target generation) on a second stream so that
+    its launch-latency-bound kernels interleave with the convolutions of the current stream.  Returns a
+    function that makes the current stream wait for the result and returns it (a tuple/list of tensors or a
+    tensor).  Inputs must already be complete on the current stream when this is called."""
+    dev = torch.cuda.current_device()
+    cur = torch.cuda.current_stream(dev)
+    side = _SIDE2.get(dev)
+    if side is None:
+        side = _SIDE2[dev] = torch.cuda.Stream(device=dev)
+    side.wait_stream(cur)
+    with torch.cuda.stream(side):
+        out = fn(*args)
+    done = torch.cuda.Event()
+    done.record(side)
+
+    def wait():
+        now = torch.cuda.current_stream(dev)
+        now.wait_event(done)
+        for t in (out if isinstance(out, (tuple, list)) else (out,)):
+            if torch.is_tensor(t):
+                t.record_stream(now)      # allocated from the side stream's pool, consumed here
+        return out
+    return wait
 
 
 def prof_enable(on=True):

@@ -1,0 +1,62 @@
+"""GPU time of the non-kernel-library sections of one headline step: proposal layer, RPN / detection target
+generation, the five losses (forward), measured with events around the calls inside a real step."""
+import os, sys, collections
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import feature_intertwiner_amd.model as M
+from feature_intertwiner_amd.config import make_config
+from feature_intertwiner_amd.synthetic import SyntheticProposals, synthetic_batch
+from feature_intertwiner_amd.workflow import set_optimizer, train_step
+
+dev = "cuda:0"
+torch.manual_seed(2000)
+cfg = make_config("resnet101", 1024, 4, 512, dev_switch=True, loss_choice="ot", ot_L=50)
+model = M.MaskRCNN(cfg).to(dev)
+opt = set_optimizer(model, cfg.TRAIN)
+batch = synthetic_batch(4, 1024, device=dev, seed=2000)
+model.proposal_hook = SyntheticProposals(batch[2], 1024, seed=7)
+model.generator = torch.Generator(device=dev).manual_seed(11)
+for _ in range(2):
+    train_step(model, opt, list(batch))
+rec = collections.OrderedDict()
+NAMES = ["proposal_layer", "prepare_rpn_target", "prepare_det_target", "compute_rpn_class_loss", "compute_rpn_bbox_loss",
+         "compute_mrcnn_class_loss", "compute_mrcnn_bbox_loss", "compute_mrcnn_mask_loss_unshuffled"]
+
+
+def wrap(name, fn):
+    def w(*a, **k):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = fn(*a, **k)
+        e1.record()
+        rec.setdefault(name, []).append((e0, e1))
+        return out
+    return w
+
+
+orig = {}
+for n in NAMES:
+    orig[n] = getattr(M, n)
+    setattr(M, n, wrap(n, orig[n]))
+for mod_name, attr in (("dev_roi", None), ("classifier", None), ("mask", None), ("fpn", None)):
+    m = getattr(model, mod_name)
+    m.forward = wrap(mod_name + ".forward", m.forward)
+model.meta_loss = wrap("meta_loss(fwd)", model.meta_loss)
+e_a, e_b, e_c, e_d = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+from feature_intertwiner_amd.workflow import compute_loss
+opt.zero_grad(set_to_none=True)
+e_a.record()
+loss, terms = compute_loss(model, list(batch), True, 1, None)
+e_b.record()
+loss.backward()
+e_c.record()
+torch.nn.utils.clip_grad_norm_([p for p in model.parameters() if p.grad is not None], cfg.TRAIN.MAX_GRAD_NORM)
+opt.step()
+e_d.record()
+torch.cuda.synchronize()
+for n, evs in rec.items():
+    print("%-40s %8.3f ms" % (n, sum(a.elapsed_time(b) for a, b in evs)))
+print("%-40s %8.3f ms" % ("forward + losses", e_a.elapsed_time(e_b)))
+print("%-40s %8.3f ms" % ("backward", e_b.elapsed_time(e_c)))
+print("%-40s %8.3f ms" % ("clip + SGD", e_c.elapsed_time(e_d)))
