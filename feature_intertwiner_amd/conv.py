@@ -114,7 +114,7 @@ def _conv_fwd(x, w, b, stride, padding, relu=False, scale=None, residual=None, o
 
 class _Conv2dFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, b, stride, padding):
+    def forward(ctx, x, w, b, stride, padding, residual=None):
         _lib.require_cuda(x, w)
         x = x.contiguous().float()
         w = _dense(w.float())
@@ -123,7 +123,8 @@ class _Conv2dFn(torch.autograd.Function):
         ctx.conf = (tuple(stride), tuple(padding), b is not None)
         ctx.precision = _PRECISION
         _log_shape(x, w, stride, padding)
-        return _conv_fwd(x, w, bc, stride, padding)
+        res = residual.contiguous().float() if residual is not None else None      # y = conv(x) + b + residual
+        return _conv_fwd(x, w, bc, stride, padding, residual=res)
 
     @staticmethod
     def backward(ctx, dy):
@@ -136,7 +137,7 @@ class _Conv2dFn(torch.autograd.Function):
         else:
             dx, dw = _conv_backward(ctx.needs_input_grad, x, w, dy, stride, padding, precision=ctx.precision)
             db = None
-        return dx, dw, db, None, None
+        return dx, dw, db, None, None, (dy if ctx.needs_input_grad[5] else None)
 
 
 def _class_taps(a, size_k, s, p):
@@ -295,7 +296,7 @@ def _prepare_step(model, grad_on):
     plan = _PLAN.get(model)
     ptrs = tuple(p.data_ptr() for p in model.parameters())
     if plan is None or plan["ptrs"] != ptrs:
-        convs = [m for m in model.modules() if isinstance(m, Conv2d)]
+        convs = [m for m in model.modules() if isinstance(m, Conv2d) and not m.full_window]
         for m in convs:
             w = m.weight
             if w.shape[1] % 16 == 0 and w.shape[2] * w.shape[3] > 1 and \
@@ -556,20 +557,25 @@ def conv_bn_act(x, conv, bn, relu=True, residual=None, channels_last_out=False, 
     return y.contiguous(memory_format=torch.channels_last) if (channels_last_out and not out_cl) else y
 
 
-def conv2d(x, weight, bias=None, stride=(1, 1), padding=(0, 0)):
-    """Functional form.  Full-window kernels become one library GEMM."""
+def conv2d(x, weight, bias=None, stride=(1, 1), padding=(0, 0), residual=None):
+    """Functional form: conv(x) + bias [+ residual, added in the kernel epilogue].  Full-window kernels become
+    one library GEMM."""
     R, S = weight.shape[2], weight.shape[3]
-    if (x.shape[2], x.shape[3]) == (R, S) and tuple(padding) == (0, 0) and R * S > 1:
+    gemm = ((x.shape[2], x.shape[3]) == (R, S) and tuple(padding) == (0, 0) and R * S > 1) or \
+        (x.shape[2] * x.shape[3] == 1 and R * S == 1)
+    if gemm:
         y = F.linear(x.reshape(x.shape[0], -1), weight.reshape(weight.shape[0], -1), bias)
-        return y.view(x.shape[0], weight.shape[0], 1, 1)
-    if x.shape[2] * x.shape[3] == 1 and R * S == 1:
-        y = F.linear(x.reshape(x.shape[0], -1), weight.reshape(weight.shape[0], -1), bias)
-        return y.view(x.shape[0], weight.shape[0], 1, 1)
-    return _Conv2dFn.apply(x, weight, bias, tuple(stride), tuple(padding))
+        y = y.view(x.shape[0], weight.shape[0], 1, 1)
+        return y if residual is None else y + residual
+    return _Conv2dFn.apply(x, weight, bias, tuple(stride), tuple(padding), residual)
 
 
 class Conv2d(nn.Conv2d):
     """nn.Conv2d (groups=1, dilation=1, zero padding) on the MFMA implicit-GEMM kernels."""
+
+    # set by the owner for a layer that only ever sees inputs of its kernel's size (the heads' 7x7 "fc"
+    # convolutions): it runs as a GEMM, so its weight stays row-major and gets no tap-major extras
+    full_window = False
 
     def forward(self, x):
         if self.groups != 1 or self.dilation != (1, 1) or self.padding_mode != 'zeros' or \

@@ -16,7 +16,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import _lib
-from .conv import Conv2d, ConvTranspose2x2, GradBox, conv_bias_relu, conv_bn_act
+from .conv import Conv2d, ConvTranspose2x2, GradBox, conv2d, conv_bias_relu, conv_bn_act
 from .intertwiner import class_mean, roi_level
 from .roi_align.crop_and_resize import CropAndResizeFunction, pyramid_crop_and_resize
 from .roi_pooling.functions.roi_pool import RoIPoolFunction
@@ -47,6 +47,20 @@ class SamePad2d(nn.Module):
 
     def __repr__(self):
         return self.__class__.__name__
+
+
+def _pad_maxpool(x, pad, pool):
+    """SamePad2d + MaxPool2d of the stem (lib/sub_module.py:44-45).  The padding is on the right / bottom only
+    and the input comes out of a ReLU, so the zero column it adds never changes a maximum: pooling with
+    ceil_mode (the overhanging window ignores what is outside) gives the same values without materialising the
+    padded copy (0.25 GB at 4 x 1024^2), forward and backward."""
+    l, r, t, b = pad.pads(x.size(2), x.size(3))
+    k, s_ = nn.modules.utils._pair(pool.kernel_size), nn.modules.utils._pair(pool.stride)
+    if l == 0 and t == 0 and r < k[1] and b < k[0] and tuple(nn.modules.utils._pair(pool.padding)) == (0, 0):
+        y = F.max_pool2d(x, k, s_, 0, ceil_mode=True)
+        if y.shape[2] == (x.size(2) + b - k[0]) // s_[0] + 1 and y.shape[3] == (x.size(3) + r - k[1]) // s_[1] + 1:
+            return y
+    return pool(pad(x))
 
 
 def _bn(ch, eps=0.001, momentum=0.01):
@@ -170,7 +184,7 @@ class FPN(nn.Module):
         bs = x.size(0)
         ot_loss = x.new_zeros(bs, 3)
         x = conv_bn_act(x, self.C1[0], self.C1[1], relu=True)       # C1 = conv, bn, relu, pad, maxpool
-        x = self.C1[4](self.C1[3](x))
+        x = _pad_maxpool(x, self.C1[3], self.C1[4])
         c2 = self.C2(x)
         c3 = self.C3(c2)
         c4 = self.C4(c3)
@@ -189,9 +203,11 @@ class FPN(nn.Module):
             p2 = t2 + up(p3)
             ot_loss = torch.stack((l0, l1, l2), 1)
         else:
-            p4 = self.P4_conv1(c4) + up(p5)
-            p3 = self.P3_conv1(c3) + up(p4)
-            p2 = self.P2_conv1(c2) + up(p3)
+            # lateral 1x1 conv + top-down map in the conv epilogue (no separate add pass)
+            lat = lambda m, c, top: conv2d(c, m.weight, m.bias, m.stride, m.padding, residual=up(top))
+            p4 = lat(self.P4_conv1, c4, p5)
+            p3 = lat(self.P3_conv1, c3, p4)
+            p2 = lat(self.P2_conv1, c2, p3)
         p5 = self.P5_conv2(p5)
         p4 = self.P4_conv2(p4)
         p3 = self.P3_conv2(p3)
@@ -218,9 +234,15 @@ class RPN(nn.Module):
     def forward(self, x):
         c = self.conv_shared
         x = conv_bias_relu(self.padding(x), c.weight, c.bias, c.stride, c.padding)      # conv + bias + ReLU, one launch
-        logits = self.conv_class(x).permute(0, 2, 3, 1).contiguous().view(x.size(0), -1, 2)
+        # the two 1x1 heads as ONE convolution over their stacked filters (every output channel is computed
+        # exactly as before): the 512-channel map is read once instead of twice in forward, data gradient and
+        # weight gradient, and autograd has no two data gradients to add
+        ncls = self.conv_class.weight.shape[0]
+        both = conv2d(x, torch.cat((self.conv_class.weight, self.conv_bbox.weight), 0),
+                      torch.cat((self.conv_class.bias, self.conv_bbox.bias), 0))
+        logits = both[:, :ncls].permute(0, 2, 3, 1).contiguous().view(x.size(0), -1, 2)
         probs = self.softmax(logits)
-        bbox = self.conv_bbox(x).permute(0, 2, 3, 1).contiguous().view(x.size(0), -1, 4)
+        bbox = both[:, ncls:].permute(0, 2, 3, 1).contiguous().view(x.size(0), -1, 4)
         return [logits, probs, bbox]
 
 
@@ -265,6 +287,7 @@ class Dev(nn.Module):
                     Conv2d(512, 1024, kernel_size=k, stride=1), nn.BatchNorm2d(1024), nn.ReLU(inplace=True),
                     Conv2d(1024, 1024, kernel_size=1, stride=1), nn.BatchNorm2d(1024), nn.ReLU(inplace=True),
                 )
+                self.feat_extract[3].full_window = True          # k x k kernel on the k x k map: a GEMM
                 if config.DEV.LOSS_CHOICE in ('l2', 'l1'):
                     self.last_op = nn.Sigmoid()
                 elif config.DEV.LOSS_CHOICE == 'kl':
@@ -428,6 +451,7 @@ class Classifier(nn.Module):
         super(Classifier, self).__init__()
         self.depth, self.pool_size, self.num_classes, self.config = depth, pool_size, num_classes, config
         _conv_bn(self, 1, depth, 1024, pool_size)
+        self.conv1.full_window = pool_size > 1
         _conv_bn(self, 2, 1024, 1024, 1)
         self.relu = nn.ReLU(inplace=True)
         self.linear_class = nn.Linear(1024, num_classes)
