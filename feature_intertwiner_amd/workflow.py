@@ -4,6 +4,7 @@ clipping, SGD step.  The reference's epoch/stage loops, logging, visdom and chec
 are out of scope (SURVEY 2.1 #8)."""
 import torch
 
+from . import optim
 from ._lib import const_tensor
 
 
@@ -64,6 +65,10 @@ def train_step(model, optimizer, inputs, do_meta=True, grad_sync=None, world_siz
     loss.backward()
     if grad_sync is not None:
         grad_sync()
+    if optim.supported(optimizer):
+        # clip_grad_norm_ + SGD step in three launches (csrc/sgd.hip) instead of ~8 passes over all parameters
+        optim.clip_and_step(optimizer, cfg.TRAIN.MAX_GRAD_NORM if cfg.TRAIN.CLIP_GRAD else None)
+        return terms
     if cfg.TRAIN.CLIP_GRAD:
         torch.nn.utils.clip_grad_norm_([p for p in model.parameters() if p.grad is not None],
                                        cfg.TRAIN.MAX_GRAD_NORM)

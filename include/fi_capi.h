@@ -339,6 +339,31 @@ enum {
     FI_K_CONV_BF16_WGRAD = 38,
     FI_K_COUNT = 39
 };
+/* ------------------------------------------------------------------------
+ * Optimiser step of the training iteration: torch.nn.utils.clip_grad_norm_(params, max_norm) followed by
+ * torch.optim.SGD(momentum, weight_decay).step() (/root/reference/lib/workflow.py:226-230,
+ * tools/utils.py:474-501) for all parameters in three launches: sum of squares per 8192-float chunk, one
+ * workgroup that reduces the chunk sums in a fixed order to the norm and the clip factor
+ * min(1, max_norm / (norm + 1e-6)), and one pass that applies
+ *     g = grad * clip;  g += weight_decay * p;  buf = momentum * buf + g;  p -= lr * buf
+ * (buf == NULL: no momentum; a zero-initialised buf reproduces torch's first step, buf = g).  The scaled
+ * gradient is written back when the clip factor is not 1 (clip_grad_norm_ leaves it scaled).  param / grad /
+ * buf of one descriptor must share one dense memory layout.  descs_dev: device array sorted by chunk_base,
+ * chunk_base = running sum of fi_sgd_chunks(numel); partial_ws: total_chunks floats; norm_coef: 2 floats
+ * (out: norm, clip factor).  max_norm <= 0 disables clipping.
+ * ---------------------------------------------------------------------- */
+typedef struct {
+    void *param;
+    void *grad;
+    void *buf;
+    long numel;
+    long chunk_base;
+    float weight_decay, lr, momentum, pad_;
+} FiSgdDesc;
+long fi_sgd_chunks(long numel);
+int fi_sgd_clip_step(const FiSgdDesc *descs_dev, int n, long total_chunks, float max_norm, float *partial_ws,
+                     float *norm_coef, fi_stream_t stream);
+
 /* Streaming copy of n_floats floats (16 bytes per lane) with exactly known memory traffic: the
  * calibration point for rocprofv3's FETCH_SIZE / WRITE_SIZE (MI355X_MICROARCH.md, HBM section). */
 int fi_calib_copy(const float *src, float *dst, size_t n_floats, fi_stream_t stream);
