@@ -7,6 +7,8 @@ optimizer object stays the owner of the hyper-parameters and of the momentum buf
 (`optimizer.state[p]['momentum_buffer']`), so its state dict -- and the reference's checkpoint file -- is
 unchanged; only the arithmetic moves into one pass over the parameters.
 """
+import weakref
+
 import numpy as np
 import torch
 
@@ -14,7 +16,7 @@ from . import _lib
 
 _DESC = np.dtype([("param", "<u8"), ("grad", "<u8"), ("buf", "<u8"), ("numel", "<i8"), ("chunk_base", "<i8"),
                   ("weight_decay", "<f4"), ("lr", "<f4"), ("momentum", "<f4"), ("pad", "<f4")])
-_CACHE = {}      # id(optimizer) -> {"key", "table", "partial", "out", "chunks", "n"}
+_CACHE = weakref.WeakKeyDictionary()      # optimizer -> {"key", "table", "partial", "out", "chunks", "n"}
 
 
 def _dense_same_layout(p, g):
@@ -63,7 +65,7 @@ def clip_and_step(optimizer, max_norm):
     dev = entries[0][0].device
     key = tuple((p.data_ptr(), g.data_ptr(), 0 if b is None else b.data_ptr(), p.numel(), wd, lr, mom)
                 for p, g, b, wd, lr, mom in entries)
-    c = _CACHE.get(id(optimizer))
+    c = _CACHE.get(optimizer)
     if c is None or c["key"] != key:
         desc = np.zeros(len(entries), dtype=_DESC)
         base = 0
@@ -72,7 +74,7 @@ def clip_and_step(optimizer, max_norm):
             base += int(L.fi_sgd_chunks(p.numel()))
         host = torch.from_numpy(desc.view(np.uint8).copy()).pin_memory()
         table = host.to(dev, non_blocking=True)
-        c = _CACHE[id(optimizer)] = {"key": key, "table": table, "host": host, "chunks": base, "n": len(entries),
+        c = _CACHE[optimizer] = {"key": key, "table": table, "host": host, "chunks": base, "n": len(entries),
                                      "partial": torch.empty(max(base, 1), device=dev, dtype=torch.float32),
                                      "out": torch.empty(2, device=dev, dtype=torch.float32)}
     with torch.cuda.device(dev):
