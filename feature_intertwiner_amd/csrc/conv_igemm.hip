@@ -43,6 +43,8 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4_v __attribute__((ext_vector_type(4)));
+typedef f32x4_v f32x4_u __attribute__((aligned(4)));    // 16-byte load from a 4-byte aligned address
 
 constexpr int kThreads = 256;
 constexpr int BN = 128;
@@ -527,6 +529,375 @@ __global__ __launch_bounds__(kThreads, 4) void conv_fwd_kernel(const float *__re
 }
 
 // -------------------------------------------------------------------------------------
+// 3x3 / stride 1 / pad 1 (forward and data gradient): the input PATCH lives in LDS
+// -------------------------------------------------------------------------------------
+// conv_fwd_kernel gathers the im2col tile of every tap from global memory: for a 3x3 layer each input element
+// is fetched 9 times (from L2), every K-step of 16 channels x 1 tap costs 10 global loads, 16 LDS stores and
+// a barrier per thread for 32 MFMAs per wavefront.  Here a workgroup owns a tile of 8 rows x 16 columns of
+// output pixels and stages, per block of 16 input channels, the (8+2) x (16+8) input patch ONCE; the nine
+// taps are nine different LDS offsets into it.  Weights do not go through LDS at all: the 4 wavefronts of a
+// workgroup own 32 output channels each (4 x 1 layout), so a lane loads its MFMA A-operand -- 8 consecutive
+// input channels of one output channel and tap -- straight from the tap-major weight into registers.
+// Per 16 channels: 288 MFMAs per wavefront against 4 patch loads + 18 weight loads, 8 LDS stores and ONE
+// barrier per thread (conv_fwd_kernel: 90 loads, 144 LDS stores, 9 barriers).
+//
+// Rows are addressed in the STACKED row space Y = n*H + y of the whole batch, so that 14x14 RoI maps fill
+// 8-row tiles without per-RoI padding; a tap that would cross into the neighbouring image reads a row of
+// zeros kept at the end of the patch instead.  MFMA column n = l31 + 32*j is pixel 4*l31 + j of the tile
+// (quad l31 = 4 consecutive columns), so a lane ends up with 4 adjacent pixels of 16 channels: 16-byte
+// NCHW stores without a transpose.
+constexpr int PT_TH = 8, PT_TW = 16;        // 2-D tile: 8 stacked rows x 16 columns = 128 pixels
+constexpr int PT_PW = 24;                   // patch row: six 16-byte groups (2-D: columns X0-4 .. X0+19; flat: -4 .. 19)
+
+// FLAT = false: 2-D tiles (maps whose width is a multiple of 16).
+// FLAT = true : maps of 12..16 columns (14 x 14 RoI maps): a tile is 128 CONSECUTIVE pixels of the flattened
+//               (stacked row, column) space -- no tile column is wasted on a 14-wide map; a lane's 4 pixels may
+//               then sit on two rows, so every pixel carries its own patch offsets.
+template <bool FLAT>
+struct PatchShape {
+    static constexpr int ROWS = FLAT ? 13 : PT_TH + 2;         // patch rows (flat: up to 11 rows of 12+ pixels, + halo)
+    static constexpr int ZR = ROWS;                              // + one row of zeros
+    static constexpr int PP = FLAT ? 338 : 266;                  // floats per channel: (ROWS+1)*24 + 2 -> 8*PP = 16 (mod 32) banks
+    static constexpr int ITEMS = BK * ROWS * (PT_PW / 4);        // 16-byte groups per channel block
+    static constexpr int PER_THREAD = (ITEMS + kThreads - 1) / kThreads;
+    static constexpr int NJ = FLAT ? 4 : 1;                      // distinct patch offsets per lane and kernel row
+};
+
+struct PatchGeom {
+    int N, Cin, H, W, Cout;
+    int flip;            // taps applied in reverse order (data gradient)
+    int tiles_x;         // 2-D: column tiles per row
+    int ptiles, mtiles;  // pixel tiles, Cout tiles
+    int vec4;            // 2-D: W % 4 == 0 and 16-byte aligned tensors -> 16-byte stores / shortcut loads
+    const float *zero;
+};
+
+// predicate-free NCHW epilogue of conv3x3_patch_kernel<false>: the loads of a group of 4 rows are issued together
+template <bool HAS_RES>
+__device__ __forceinline__ void patch_epilogue_vec(const f32x16 (&acc)[4], const Epilogue &ep, float *__restrict__ y,
+                                                   size_t obase, size_t HW, int mb, const float *__restrict__ sp,
+                                                   const float *__restrict__ bp, int smul, int bmul, bool has_sc,
+                                                   bool has_bi, bool relu)
+{
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float sc[4], bi[4];
+        float4 rr[4];
+#pragma unroll
+        for (int e4 = 0; e4 < 4; ++e4) {
+            const int m = mb + 8 * q + e4;
+            sc[e4] = sp[m * smul];
+            bi[e4] = bp[m * bmul];
+            if (HAS_RES) rr[e4] = *reinterpret_cast<const float4 *>(ep.residual + obase + (size_t)(8 * q + e4) * HW);
+        }
+#pragma unroll
+        for (int e4 = 0; e4 < 4; ++e4) {
+            float t[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float v = acc[j][4 * q + e4];
+                v = has_sc ? v * sc[e4] : v;
+                v = has_bi ? v + bi[e4] : v;
+                t[j] = v;
+            }
+            if (HAS_RES) {
+                t[0] += rr[e4].x; t[1] += rr[e4].y; t[2] += rr[e4].z; t[3] += rr[e4].w;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) t[j] = relu ? fmaxf(t[j], 0.0f) : t[j];
+            *reinterpret_cast<float4 *>(y + obase + (size_t)(8 * q + e4) * HW) = make_float4(t[0], t[1], t[2], t[3]);
+        }
+    }
+}
+
+// flat tiles: the lane's pixels (0,1) and (2,3) are two pairs, each inside one row (W even): 8-byte accesses.
+// Loads are unconditional (clamped rows / pixels), only the stores are predicated.
+template <bool HAS_RES>
+__device__ __forceinline__ void patch_epilogue_pairs(const f32x16 (&acc)[4], const Epilogue &ep, float *__restrict__ y,
+                                                     const size_t (&opair)[2], const bool (&okp)[2], size_t HW, int mb,
+                                                     int Cout, const float *__restrict__ sp,
+                                                     const float *__restrict__ bp, int smul, int bmul, bool has_sc,
+                                                     bool has_bi, bool relu)
+{
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float sc[4], bi[4];
+        float2 rr[4][2];
+        int mrow[4];
+#pragma unroll
+        for (int e4 = 0; e4 < 4; ++e4) {
+            mrow[e4] = min(mb + 8 * q + e4, Cout - 1) - mb;          // clamped row, relative to mb
+            sc[e4] = sp[(mb + mrow[e4]) * smul];
+            bi[e4] = bp[(mb + mrow[e4]) * bmul];
+            if (HAS_RES) {
+                rr[e4][0] = *reinterpret_cast<const float2 *>(ep.residual + opair[0] + (size_t)mrow[e4] * HW);
+                rr[e4][1] = *reinterpret_cast<const float2 *>(ep.residual + opair[1] + (size_t)mrow[e4] * HW);
+            }
+        }
+#pragma unroll
+        for (int e4 = 0; e4 < 4; ++e4) {
+            float t[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float v = acc[j][4 * q + e4];
+                v = has_sc ? v * sc[e4] : v;
+                v = has_bi ? v + bi[e4] : v;
+                t[j] = v;
+            }
+            if (HAS_RES) {
+                t[0] += rr[e4][0].x; t[1] += rr[e4][0].y; t[2] += rr[e4][1].x; t[3] += rr[e4][1].y;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) t[j] = relu ? fmaxf(t[j], 0.0f) : t[j];
+            const bool row_ok = mb + 8 * q + e4 < Cout;
+            if (row_ok && okp[0]) *reinterpret_cast<float2 *>(y + opair[0] + (size_t)mrow[e4] * HW) = make_float2(t[0], t[1]);
+            if (row_ok && okp[1]) *reinterpret_cast<float2 *>(y + opair[1] + (size_t)mrow[e4] * HW) = make_float2(t[2], t[3]);
+        }
+    }
+}
+
+template <bool FLAT>
+__global__ __launch_bounds__(kThreads, 3) void conv3x3_patch_kernel(const float *__restrict__ x,
+                                                                   const float *__restrict__ w, Epilogue ep,
+                                                                   float *__restrict__ y, PatchGeom g)
+{
+    using SH = PatchShape<FLAT>;
+    __shared__ __attribute__((aligned(16))) float Ps[2][BK][SH::PP];
+
+    // XCD-aware order: XCD c owns a contiguous band of pixel tiles, Cout tiles innermost
+    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+    const int per_xcd = (g.ptiles + 7) >> 3;
+    const int mt = local % g.mtiles;
+    const int pt = xcd * per_xcd + local / g.mtiles;
+    if (pt >= g.ptiles) return;
+    const int m0 = mt * 128;
+    const int NH = g.N * g.H;
+    const size_t HW = (size_t)g.H * g.W;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, khalf = lane >> 5;
+
+    // ---- tile geometry: stacked row / column of the lane's 4 pixels, patch origin ------------------------
+    int Yj[4], xj[4];                 // stacked row (n*H + y) and column of pixel j of the lane's quad
+    int Yp0, Xp0;                     // stacked row of patch row 0, image column of patch column 0
+    if (FLAT) {
+        const int P0 = pt * 128;
+        Yp0 = P0 / g.W - 1;
+        Xp0 = -4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int p = P0 + 4 * l31 + j;
+            Yj[j] = p / g.W;
+            xj[j] = p - Yj[j] * g.W;
+        }
+    } else {
+        const int tile_y = pt / g.tiles_x, tile_x = pt - tile_y * g.tiles_x;
+        Yp0 = tile_y * PT_TH - 1;
+        Xp0 = tile_x * PT_TW - 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            Yj[j] = tile_y * PT_TH + (l31 >> 2);
+            xj[j] = tile_x * PT_TW + (l31 & 3) * 4 + j;
+        }
+    }
+
+    // ---- A operand: 8 consecutive channels of (output channel, tap), straight into registers --------
+    const int am = min(m0 + wave * 32 + l31, g.Cout - 1);          // rows past Cout re-read the last row
+    const float *__restrict__ a_base = w + (size_t)am * 9 * g.Cin + khalf * 8;
+    auto load_a = [&](float (&a)[8], int tap, int cb) {
+        const float *__restrict__ p = a_base + (size_t)(g.flip ? 8 - tap : tap) * g.Cin + cb * BK;
+        const float4 v0 = *reinterpret_cast<const float4 *>(p);
+        const float4 v1 = *reinterpret_cast<const float4 *>(p + 4);
+        a[0] = v0.x; a[1] = v0.y; a[2] = v0.z; a[3] = v0.w;
+        a[4] = v1.x; a[5] = v1.y; a[6] = v1.z; a[7] = v1.w;
+    };
+
+    // ---- B operand: patch offset of (row of pixel j + r - 1, column of pixel j - 1), per kernel row r ----
+    // a tap that would leave the pixel's image reads the row of zeros (ZR) instead
+    int rowbase[3][SH::NJ];
+#pragma unroll
+    for (int j = 0; j < SH::NJ; ++j) {
+        const int yo = Yj[j] - (Yj[j] / g.H) * g.H;                // row inside its image
+        const int pr = Yj[j] - Yp0;                                // patch row of the pixel's own row (r = 1)
+        const int col = xj[j] - Xp0 - 1;
+        rowbase[0][j] = (yo != 0 ? pr - 1 : SH::ZR) * PT_PW + col;
+        rowbase[1][j] = pr * PT_PW + col;
+        rowbase[2][j] = (yo != g.H - 1 ? pr + 1 : SH::ZR) * PT_PW + col;
+    }
+
+    // ---- patch staging: work items of one 16-byte group (4 columns of one patch row and channel) ------
+    int it_goff[SH::PER_THREAD], it_lds[SH::PER_THREAD], it_mask[SH::PER_THREAD];
+#pragma unroll
+    for (int i = 0; i < SH::PER_THREAD; ++i) {
+        const int wi = tid + kThreads * i;
+        const int ch = wi / (SH::ROWS * 6);
+        const int rem = wi - ch * (SH::ROWS * 6);
+        const int prow = rem / 6, grp = rem - prow * 6;
+        const int Ys = Yp0 + prow;
+        const int xx = Xp0 + grp * 4;
+        const bool item = wi < SH::ITEMS;
+        const bool row_ok = item && Ys >= 0 && Ys < NH;
+        const int n = row_ok ? Ys / g.H : 0;
+        const int yy = row_ok ? Ys - n * g.H : 0;
+        int mask = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (row_ok && xx + e >= 0 && xx + e < g.W) mask |= 1 << e;
+        it_mask[i] = item ? mask : -1;                             // -1: no item
+        it_goff[i] = (int)(((size_t)n * g.Cin + ch) * HW + (size_t)yy * g.W) + xx;   // < 2^31 (launcher)
+        it_lds[i] = ch * SH::PP + prow * PT_PW + grp * 4;
+    }
+    float4 preg[SH::PER_THREAD];
+    auto stage_load = [&](int cb) {
+        const float *__restrict__ xb = x + (size_t)cb * BK * HW;
+#pragma unroll
+        for (int i = 0; i < SH::PER_THREAD; ++i) {
+            const int m = it_mask[i];
+            if (m == 15) {
+                const f32x4_v v = *reinterpret_cast<const f32x4_u *>(xb + it_goff[i]);
+                preg[i] = make_float4(v.x, v.y, v.z, v.w);
+            } else {
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (m > 0) {
+                    const float *__restrict__ q = xb + it_goff[i];
+                    if (m & 1) v.x = q[0];
+                    if (m & 2) v.y = q[1];
+                    if (m & 4) v.z = q[2];
+                    if (m & 8) v.w = q[3];
+                }
+                preg[i] = v;
+            }
+        }
+    };
+    auto stage_store = [&](int buf) {
+        float *__restrict__ pb = &Ps[buf][0][0];
+#pragma unroll
+        for (int i = 0; i < SH::PER_THREAD; ++i) {
+            if (it_mask[i] < 0) continue;
+            float2 *__restrict__ d = reinterpret_cast<float2 *>(pb + it_lds[i]);        // 8-byte aligned
+            d[0] = make_float2(preg[i].x, preg[i].y);
+            d[1] = make_float2(preg[i].z, preg[i].w);
+        }
+    };
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[j][e] = 0.0f;
+
+    // zero rows of both buffers (never overwritten), first patch
+    for (int i = tid; i < 2 * BK * PT_PW; i += kThreads) {
+        const int b = i / (BK * PT_PW), r = i - b * (BK * PT_PW);
+        const int ch = r / PT_PW;
+        Ps[b][ch][SH::ZR * PT_PW + (r - ch * PT_PW)] = 0.0f;
+    }
+    const int ncb = g.Cin / BK;
+    stage_load(0);
+    stage_store(0);
+    __syncthreads();
+
+    // 72 sub-steps (9 taps x 8 channel pairs) of 4 MFMAs per channel block, software pipelined: the 4 LDS reads
+    // of sub-step i+1 and (at the start of a tap) the 2 weight loads of the NEXT tap are issued before the MFMAs
+    // of sub-step i.  Register sets rotate statically (weights: tap % 3, LDS values: sub-step & 1).
+    float areg[3][8];
+    float breg[2][4];
+    auto bload = [&](float (&bv)[4], const float *__restrict__ pbuf, int r, int sft) {
+        if (FLAT) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bv[j] = pbuf[rowbase[r][j] + sft];
+        } else {
+            const float *__restrict__ bp = pbuf + rowbase[r][0] + sft;
+            bv[0] = bp[0]; bv[1] = bp[1]; bv[2] = bp[2]; bv[3] = bp[3];
+        }
+    };
+    load_a(areg[0], 0, 0);
+    for (int cb = 0; cb < ncb; ++cb) {
+        const float *__restrict__ pbuf = &Ps[cb & 1][0][0] + khalf * 8 * SH::PP;
+        const bool more = cb + 1 < ncb;
+        if (more) stage_load(cb + 1);                     // lands while the 288 MFMAs below run
+        bload(breg[0], pbuf, 0, 0);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            if (t < 8) load_a(areg[(t + 1) % 3], t + 1, cb);
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {
+                const int step = t * 8 + kk;
+                if (step + 1 < 72) {
+                    const int t2 = (step + 1) / 8, k2 = (step + 1) % 8;
+                    bload(breg[(step + 1) & 1], pbuf, t2 / 3, (t2 % 3) + k2 * SH::PP);
+                }
+                const float av = areg[t % 3][kk];
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, breg[step & 1][0], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, breg[step & 1][1], acc[1], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, breg[step & 1][2], acc[2], 0, 0, 0);
+                acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, breg[step & 1][3], acc[3], 0, 0, 0);
+                if (kk == 0 && t < 8) __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);     // weight loads of tap t+1
+                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);                            // LDS reads of sub-step i+1
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                            // MFMAs of sub-step i
+            }
+        }
+        if (more) {
+            load_a(areg[0], 0, cb + 1);
+            stage_store((cb + 1) & 1);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane = 4 pixels x 16 channels (rows (e&3) + 8*(e>>2) + 4*khalf) ---------------------------
+    const int mb = m0 + wave * 32 + 4 * khalf;
+    const bool has_sc = ep.scale != nullptr, has_bi = ep.bias != nullptr, relu = ep.relu != 0;
+    const float *__restrict__ sp = has_sc ? ep.scale : g.zero;
+    const float *__restrict__ bp = has_bi ? ep.bias : g.zero;
+    const int smul = has_sc ? 1 : 0, bmul = has_bi ? 1 : 0;
+    if (FLAT) {
+        size_t opair[2];
+        bool okp[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            okp[h] = Yj[2 * h] < NH;                       // W even: a pair is inside one row, valid together
+            const int Yc = min(Yj[2 * h], NH - 1);
+            const int n_img = Yc / g.H;
+            opair[h] = ((size_t)n_img * g.Cout + mb) * HW + (size_t)(Yc - n_img * g.H) * g.W + xj[2 * h];
+        }
+        if (ep.residual)
+            patch_epilogue_pairs<true>(acc, ep, y, opair, okp, HW, mb, g.Cout, sp, bp, smul, bmul, has_sc, has_bi, relu);
+        else
+            patch_epilogue_pairs<false>(acc, ep, y, opair, okp, HW, mb, g.Cout, sp, bp, smul, bmul, has_sc, has_bi, relu);
+        return;
+    }
+    const int Yo = Yj[0], xo = xj[0];
+    if (Yo >= NH || xo >= g.W) return;
+    const int n_img = Yo / g.H;
+    const size_t obase = ((size_t)n_img * g.Cout + mb) * HW + (size_t)(Yo - n_img * g.H) * g.W + xo;
+    if (g.vec4 && m0 + 128 <= g.Cout) {      // xo % 4 == 0 and W % 4 == 0: the quad is inside the row
+        if (ep.residual)
+            patch_epilogue_vec<true>(acc, ep, y, obase, HW, mb, sp, bp, smul, bmul, has_sc, has_bi, relu);
+        else
+            patch_epilogue_vec<false>(acc, ep, y, obase, HW, mb, sp, bp, smul, bmul, has_sc, has_bi, relu);
+        return;
+    }
+    // general: rows past Cout and columns past W are skipped; 4-byte accesses
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int m = mb + (e & 3) + 8 * (e >> 2);
+        if (m >= g.Cout) continue;
+        const float sc = sp[m * smul], bi = bp[m * bmul];
+        const size_t o = obase + (size_t)((e & 3) + 8 * (e >> 2)) * HW;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (xo + j >= g.W) continue;
+            float v = acc[j][e];
+            v = has_sc ? v * sc : v;
+            v = has_bi ? v + bi : v;
+            if (ep.residual) v += ep.residual[o + j];
+            y[o + j] = relu ? fmaxf(v, 0.0f) : v;
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------
 // weight gradient:  dW[m][k] = sum_p dY[m][p] * Xcol[k][p]
 //   GEMM rows m = output channel, columns k = (ci, r, s), reduction over pixels p.
 //   blockIdx.z splits the pixel range; partial sums are added with fp32 atomics.
@@ -999,6 +1370,25 @@ bool use_bm64(int Cout, int P)
     return tiles128 < 512;
 }
 
+// conv3x3_patch_kernel: 3x3 / stride 1 / pad 1, same-size NCHW output, tap-major weights, 16-channel blocks,
+// 128-row Cout tiles, and at least 512 workgroups (smaller grids keep the 64x64-tile kernel).
+// Returns 0 (not eligible), 1 (2-D tiles: width a multiple of 16) or 2 (flat tiles: even widths 12..16, e.g. the
+// 14 x 14 RoI maps; 8-byte aligned tensors).
+int patch_eligible(const ConvGeom &g, bool hwc, int weight_layout, bool bm64, const float *y, const float *residual)
+{
+    if (!(g.R == 3 && g.S == 3 && g.sh == 1 && g.sw == 1 && g.ph == 1 && g.pw == 1)) return 0;
+    if (!hwc || weight_layout < 1 || g.out_nhwc || bm64 || g.OH != g.H || g.OW != g.W) return 0;
+    if ((long)g.N * g.Cin * g.H * g.W >= 2147483647L || (long)g.N * g.Cout * g.H * g.W >= 2147483647L) return 0;
+    const long mt = fi::ceil_div(g.Cout, 128);
+    if (g.W % PT_TW == 0)
+        return (long)fi::ceil_div(g.N * g.H, PT_TH) * (g.W / PT_TW) * mt >= 512 ? 1 : 0;
+    // flat tiles: 128 consecutive pixels touch at most (W + 126) / W rows, + 2 halo rows <= 13 patch rows
+    if (g.W < 16 && g.W % 2 == 0 && (g.W + 126) / g.W + 2 <= PatchShape<true>::ROWS && (uintptr_t)y % 8 == 0 &&
+        (residual == nullptr || (uintptr_t)residual % 8 == 0))
+        return (long)fi::ceil_div(g.N * g.H * g.W, 128) * mt >= 512 ? 2 : 0;
+    return 0;
+}
+
 int window_class(int R, int S)
 {
     if (R == 1 && S == 1) return 0;
@@ -1455,6 +1845,25 @@ int fi_conv2d_forward(const float *x, const float *weight, const float *bias, co
     const Epilogue ep = {bias, scale, residual, relu};
     const bool bm64 = use_bm64(Cout, g.P);
     fi::ProfScope prof(FI_K_CONV_FWD + (bm64 ? 0 : 4) + window_class(R, S), st);
+    // 3x3 / stride 1 / pad 1 layers with enough tiles to fill the chip: input patch in LDS (conv3x3_patch_kernel)
+    const int patch_mode = getenv("FI_NO_PATCH") ? 0 : patch_eligible(g, hwc, weight_layout, bm64, y, residual);
+    if (patch_mode) {
+        PatchGeom pg;
+        pg.N = N; pg.Cin = Cin; pg.H = H; pg.W = W; pg.Cout = Cout;
+        pg.flip = g.flip;
+        pg.tiles_x = fi::ceil_div(W, PT_TW);
+        pg.ptiles = patch_mode == 2 ? fi::ceil_div(N * H * W, 128) : fi::ceil_div(N * H, PT_TH) * pg.tiles_x;
+        pg.mtiles = fi::ceil_div(Cout, 128);
+        pg.vec4 = (W % 4 == 0 && (uintptr_t)y % 16 == 0 && (residual == nullptr || (uintptr_t)residual % 16 == 0)) ? 1 : 0;
+        pg.zero = g.zero;
+        const long blocks = (long)fi::ceil_div(pg.ptiles, 8) * 8 * pg.mtiles;
+        if (patch_mode == 2)
+            hipLaunchKernelGGL(conv3x3_patch_kernel<true>, dim3((unsigned)blocks), dim3(kThreads), 0, st, x, weight, ep, y, pg);
+        else
+            hipLaunchKernelGGL(conv3x3_patch_kernel<false>, dim3((unsigned)blocks), dim3(kThreads), 0, st, x, weight, ep, y, pg);
+        FI_HIP_CHECK(hipGetLastError());
+        return FI_OK;
+    }
     if (bm64)
         launch_fwd<64>(g, x, weight, ep, y, hwc, st);
     else

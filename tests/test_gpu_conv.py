@@ -35,6 +35,11 @@ CASES = [
     (2, 64, 14, 14, 64, 3, 3, 1, 1),       # Cin = 64: two taps per weight-gradient column tile (9 taps: last tile half empty)
     (3, 64, 12, 20, 256, 1, 1, 1, 0),      # Cin = 64, 1x1: second half of the tile is past K
     (2, 64, 16, 16, 96, 5, 5, 1, 2),       # Cin = 64, generic window (25 taps)
+    # 3x3 / stride 1 / pad 1 with >= 512 tiles: conv3x3_patch_kernel (input patch in LDS)
+    (2, 32, 128, 128, 160, 3, 3, 1, 1),    # second Cout tile partial -> general epilogue
+    (171, 48, 14, 14, 256, 3, 3, 1, 1),    # RoI maps: flat 128-pixel tiles across image boundaries (W = 14), odd tail tile
+    (90, 256, 14, 14, 272, 3, 3, 1, 1),    # flat tiles, forward AND data gradient, partial third Cout tile
+    (52, 144, 20, 20, 144, 3, 3, 1, 1),    # forward AND data gradient (flipped taps) on the patch kernel; W = 20: partial column tile
 ]
 
 
@@ -265,3 +270,30 @@ def test_derived_state_follows_data_writes():
     gx, = torch.autograd.grad(y1.sum(), x)          # the data gradient uses the refreshed W^T
     gr, = torch.autograd.grad(ref().sum(), x)
     assert torch.allclose(gx, gr, rtol=1e-3, atol=1e-4)
+
+
+def test_patch_kernel_fused_epilogue():
+    """conv3x3_patch_kernel with the fused scale / shift / shortcut / ReLU epilogue (a bottleneck's conv + eval-BN)."""
+    from feature_intertwiner_amd.conv import _conv_fwd
+    g = torch.Generator().manual_seed(5)
+    N, Cin, H, W, Cout = 8, 32, 64, 64, 256
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)
+    b, sc = torch.randn(Cout, generator=g), torch.rand(Cout, generator=g) + 0.5
+    res = torch.randn(N, Cout, H, W, generator=g)
+    ref = F.relu(F.conv2d(x.double(), w.double(), None, padding=1) * sc.double().view(1, -1, 1, 1) +
+                 b.double().view(1, -1, 1, 1) + res.double())
+    for kw in (dict(relu=True, scale=sc.to(DEV), residual=res.to(DEV)), dict(relu=False, scale=None, residual=None)):
+        y = _conv_fwd(x.to(DEV), w.to(DEV), b.to(DEV), (1, 1), (1, 1), **kw)
+        r = ref if kw["relu"] else F.conv2d(x.double(), w.double(), b.double(), padding=1)
+        assert (y.cpu().double() - r).abs().max().item() <= 2e-5 * math.sqrt(Cin * 9) * r.abs().max().item()
+    # flat tiles (14 x 14 maps) with the same epilogue
+    N, Cin, H, W, Cout = 400, 16, 14, 14, 200
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)
+    b, sc = torch.randn(Cout, generator=g), torch.rand(Cout, generator=g) + 0.5
+    res = torch.randn(N, Cout, H, W, generator=g)
+    ref = F.relu(F.conv2d(x.double(), w.double(), None, padding=1) * sc.double().view(1, -1, 1, 1) +
+                 b.double().view(1, -1, 1, 1) + res.double())
+    y = _conv_fwd(x.to(DEV), w.to(DEV), b.to(DEV), (1, 1), (1, 1), relu=True, scale=sc.to(DEV), residual=res.to(DEV))
+    assert (y.cpu().double() - ref).abs().max().item() <= 2e-5 * math.sqrt(Cin * 9) * ref.abs().max().item()
