@@ -1371,17 +1371,18 @@ bool use_bm64(int Cout, int P)
 }
 
 // conv3x3_patch_kernel: 3x3 / stride 1 / pad 1, same-size NCHW output, tap-major weights, 16-channel blocks,
-// 128-row Cout tiles, and at least 512 workgroups (smaller grids keep the 64x64-tile kernel).
+// 128-row Cout tiles, and at least 256 workgroups (one per CU: measured faster than the 64x64-tile kernel down
+// to there -- C4 of ResNet at batch 4 -- and slower below).
 // Returns 0 (not eligible), 1 (2-D tiles: width a multiple of 16) or 2 (flat tiles: even widths 12..16, e.g. the
 // 14 x 14 RoI maps; 8-byte aligned tensors).
-int patch_eligible(const ConvGeom &g, bool hwc, int weight_layout, bool bm64, const float *y, const float *residual)
+int patch_eligible(const ConvGeom &g, bool hwc, int weight_layout, const float *y, const float *residual)
 {
     if (!(g.R == 3 && g.S == 3 && g.sh == 1 && g.sw == 1 && g.ph == 1 && g.pw == 1)) return 0;
-    if (!hwc || weight_layout < 1 || g.out_nhwc || bm64 || g.OH != g.H || g.OW != g.W) return 0;
+    if (!hwc || weight_layout < 1 || g.out_nhwc || g.Cout <= 64 || g.OH != g.H || g.OW != g.W) return 0;
     if ((long)g.N * g.Cin * g.H * g.W >= 2147483647L || (long)g.N * g.Cout * g.H * g.W >= 2147483647L) return 0;
     const long mt = fi::ceil_div(g.Cout, 128);
     if (g.W % PT_TW == 0)
-        return (long)fi::ceil_div(g.N * g.H, PT_TH) * (g.W / PT_TW) * mt >= 512 ? 1 : 0;
+        return (long)fi::ceil_div(g.N * g.H, PT_TH) * (g.W / PT_TW) * mt >= 256 ? 1 : 0;
     // flat tiles: 128 consecutive pixels touch at most (W + 126) / W rows, + 2 halo rows <= 13 patch rows
     if (g.W < 16 && g.W % 2 == 0 && (g.W + 126) / g.W + 2 <= PatchShape<true>::ROWS && (uintptr_t)y % 8 == 0 &&
         (residual == nullptr || (uintptr_t)residual % 8 == 0))
@@ -1846,7 +1847,7 @@ int fi_conv2d_forward(const float *x, const float *weight, const float *bias, co
     const bool bm64 = use_bm64(Cout, g.P);
     fi::ProfScope prof(FI_K_CONV_FWD + (bm64 ? 0 : 4) + window_class(R, S), st);
     // 3x3 / stride 1 / pad 1 layers with enough tiles to fill the chip: input patch in LDS (conv3x3_patch_kernel)
-    const int patch_mode = getenv("FI_NO_PATCH") ? 0 : patch_eligible(g, hwc, weight_layout, bm64, y, residual);
+    const int patch_mode = getenv("FI_NO_PATCH") ? 0 : patch_eligible(g, hwc, weight_layout, y, residual);
     if (patch_mode) {
         PatchGeom pg;
         pg.N = N; pg.Cin = Cin; pg.H = H; pg.W = W; pg.Cout = Cout;
