@@ -148,7 +148,10 @@ def pmc_traffic(kernel_substrings, extra_args, timeout_s=170):
         for (_, name), v in per_dispatch.items():
             raw.setdefault((counter, name), []).append(v * 1024.0)            # KB -> bytes
     def mean_of(counter, sub):
-        vals = [v for (c, n), vs in raw.items() if c == counter and sub in n for v in vs]
+        # the library's profile slot "conv_wgrad_kernel<BM, R, S>" covers two device kernels: the row-major
+        # conv_wgrad_vec_kernel (nearly every launch) and the scalar conv_wgrad_kernel
+        alts = (sub, sub.replace("conv_wgrad_kernel<", "conv_wgrad_vec_kernel<")) if "conv_wgrad_kernel<" in sub else (sub,)
+        vals = [v for (c, n), vs in raw.items() if c == counter and any(a in n for a in alts) for v in vs]
         return (sum(vals) / len(vals), len(vals)) if vals else (None, 0)
     cf, ncal = mean_of("FETCH_SIZE", "fi_calib_copy_kernel")
     cw, _ = mean_of("WRITE_SIZE", "fi_calib_copy_kernel")

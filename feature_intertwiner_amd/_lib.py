@@ -79,12 +79,27 @@ KERNEL_IDS = {
     "class_mean": 13, "bn_act_bwd": 30,
     "crop_fwd_nhwc_7x7": 31, "crop_fwd_nhwc_14x14": 32, "crop_fwd_nhwc_generic": 33,
     "crop_bwd_nhwc_7x7": 34, "crop_bwd_nhwc_14x14": 35, "crop_bwd_nhwc_generic": 36,
-    "conv_bf16_fwd": 37, "conv_bf16_wgrad": 38,
+    "conv_bf16_fwd": 37, "conv_bf16_wgrad": 38, "conv3x3_patch": 39, "conv3x3_patch_flat": 40,
 }
 for _i, _bm in enumerate((64, 128)):
     for _j, _w in enumerate(("1x1", "3x3", "7x7", "other")):
         KERNEL_IDS["conv_fwd_bm%d_%s" % (_bm, _w)] = 14 + 4 * _i + _j
         KERNEL_IDS["conv_wgrad_bm%d_%s" % (_bm, _w)] = 22 + 4 * _i + _j
+
+
+def patch_mode(N, Cin, H, W, Cout, R, S, stride, padding, tap_major, out_hw_same, out_channels_last):
+    """Mirrors patch_eligible() in csrc/conv_igemm.hip: 0 = conv_fwd_kernel, 1 = conv3x3_patch_kernel<false>
+    (2-D tiles), 2 = conv3x3_patch_kernel<true> (flat tiles of 14-wide RoI maps)."""
+    if (R, S) != (3, 3) or tuple(stride) != (1, 1) or tuple(padding) != (1, 1):
+        return 0
+    if not tap_major or out_channels_last or Cout <= 64 or not out_hw_same:
+        return 0
+    mt = (Cout + 127) // 128
+    if W % 16 == 0:
+        return 1 if ((N * H + 7) // 8) * (W // 16) * mt >= 256 else 0
+    if W < 16 and W % 2 == 0 and (W + 126) // W + 2 <= 13:
+        return 2 if ((N * H * W + 127) // 128) * mt >= 512 else 0
+    return 0
 
 
 def conv_kernel_key(kind, cout, R, S, pixels=None, cin=None):

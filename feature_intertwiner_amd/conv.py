@@ -52,9 +52,12 @@ def _log_shape(x, w, stride, padding):
                           tuple(stride), tuple(padding)))
 
 
-def _log_flops(kind, cout, R, S, flops, pixels=None, cin=None):
+def _log_flops(kind, cout, R, S, flops, pixels=None, cin=None, patch=0):
     if FLOP_LOG is not None:
-        k = ("conv_" + kind) if kind.startswith("bf16") else _lib.conv_kernel_key(kind, cout, R, S, pixels, cin)
+        if patch:
+            k = "conv3x3_patch" if patch == 1 else "conv3x3_patch_flat"
+        else:
+            k = ("conv_" + kind) if kind.startswith("bf16") else _lib.conv_kernel_key(kind, cout, R, S, pixels, cin)
         e = FLOP_LOG.setdefault(k, [0, 0])
         e[0] += 1
         e[1] += flops
@@ -95,7 +98,9 @@ def _conv_fwd(x, w, b, stride, padding, relu=False, scale=None, residual=None, o
     if out_hw is not None:
         OH, OW = out_hw
     if not ((_PRECISION == "bf16" if precision is None else precision == "bf16") and layout >= 1 and Cin % 32 == 0):
-        _log_flops("fwd", Cout, R, S, 2 * N * Cout * OH * OW * Cin * R * S, N * OH * OW)
+        _log_flops("fwd", Cout, R, S, 2 * N * Cout * OH * OW * Cin * R * S, N * OH * OW,
+                   patch=_lib.patch_mode(N, Cin, H, W, Cout, R, S, stride, padding, layout >= 1,
+                                         (OH, OW) == (H, W), out_channels_last) if FLOP_LOG is not None else 0)
     y = torch.empty((N, Cout, OH, OW), device=x.device, dtype=torch.float32,
                     memory_format=torch.channels_last if out_channels_last else torch.contiguous_format)
     bf16 = (_PRECISION == "bf16" if precision is None else precision == "bf16") and layout >= 1 and Cin % 32 == 0

@@ -71,6 +71,7 @@ struct ConvGeom {
     int p_base;   // first output pixel of this launch (a layer may be split into a main and a tail launch)
     unsigned mul_ohw, sft_ohw, mul_ow, sft_ow;   // magic numbers: n / d == umulhi(n, mul) >> sft
     const float *zero;   // device address of g_zero_page (a kernel argument: no GOT load inside the K loop)
+    int wg_gx, wg_gy, wg_splits;   // weight gradient with swz: logical grid (column tiles, Cout tiles, pixel splits) of a 1-D launch
 };
 
 // Out-of-image taps of the tap-major gather read this instead of being masked after the load:
@@ -1112,18 +1113,22 @@ __global__ __launch_bounds__(kThreads, 4) void conv_wgrad_vec_kernel(const float
     const int wm = wave >> 1, wn = wave & 1;
     const int S = TS ? TS : g.S;
     const int K = g.K;
-    // XCD-aware order: all (tap, channel-block, Cout-block) tiles of one pixel split run on the SAME
-    // XCD, so the dY / X ranges of that split are fetched into one L2 instead of all eight
-    // (gridDim.z is padded to a multiple of 8 by the launcher when g.swz is set).
+    // XCD-aware order (1-D launch): the workgroups, sorted by (pixel split, tile), are cut into 8 contiguous
+    // bands, one per XCD.  The (tap, channel-block, Cout-block) tiles of a pixel split walk the same dY / X
+    // ranges in lockstep, so a split is fetched into ONE L2 and re-read there; in the plain order its 36 tiles
+    // sit on all 8 XCDs and each streams its ranges from memory (PMC: 6.0 GB fetched per launch for 0.54 GB of
+    // operands on the P2-level layers -- the kernel ran at the HBM/Infinity-Cache rate, not at the MFMA rate).
     int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
     if (g.swz) {
-        const int tiles = gridDim.x * gridDim.y;
-        const int id = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-        const int xcd = id & 7, local = id >> 3;
-        const int t = local % tiles;
-        bz = xcd + 8 * (local / tiles);
-        bx = t % gridDim.x;
-        by = t / gridDim.x;
+        const int tiles = g.wg_gx * g.wg_gy;
+        const int nblk = tiles * g.wg_splits;
+        const int per_xcd = (nblk + 7) >> 3;
+        const int idx = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+        if (idx >= nblk) return;
+        bz = idx / tiles;
+        const int t = idx - bz * tiles;
+        by = t / g.wg_gx;
+        bx = t - by * g.wg_gx;
     }
     const int m0 = by * BM;
     const int k0 = bx * BN;                      // 128 columns = 128 input channels of ONE tap
@@ -1559,7 +1564,12 @@ void launch_wgrad(const ConvGeom &g, const float *x, const float *dy, float *dw,
     if (hwc && same) {
         ConvGeom gs = g;
         dim3 vgrid = grid;
-        if (splits % 8 == 0 && g.P >= 131072) gs.swz = 1;    // large layers: whole splits per XCD (no padding: it would add a round)
+        if (g.P >= 32768 && !getenv("FI_NO_WG_SWZ")) {       // XCD-aware 1-D launch (see the kernel)
+            gs.swz = 1;
+            gs.wg_gx = (int)grid.x; gs.wg_gy = (int)grid.y; gs.wg_splits = splits;
+            const long nblk = (long)grid.x * grid.y * splits;
+            vgrid = dim3((unsigned)(((nblk + 7) / 8) * 8), 1, 1);
+        }
         if (g.R == 3 && g.S == 3)
             hipLaunchKernelGGL((conv_wgrad_vec_kernel<BM, 3, 3>), vgrid, dim3(kThreads), 0, st, x, dy, dw, gs, p_per_split, dbias);
         else if (g.R == 1 && g.S == 1)
@@ -1845,9 +1855,10 @@ int fi_conv2d_forward(const float *x, const float *weight, const float *bias, co
     hipStream_t st = (hipStream_t)stream;
     const Epilogue ep = {bias, scale, residual, relu};
     const bool bm64 = use_bm64(Cout, g.P);
-    fi::ProfScope prof(FI_K_CONV_FWD + (bm64 ? 0 : 4) + window_class(R, S), st);
     // 3x3 / stride 1 / pad 1 layers with enough tiles to fill the chip: input patch in LDS (conv3x3_patch_kernel)
     const int patch_mode = getenv("FI_NO_PATCH") ? 0 : patch_eligible(g, hwc, weight_layout, y, residual);
+    fi::ProfScope prof(patch_mode ? FI_K_CONV3X3_PATCH + (patch_mode - 1)
+                                  : FI_K_CONV_FWD + (bm64 ? 0 : 4) + window_class(R, S), st);
     if (patch_mode) {
         PatchGeom pg;
         pg.N = N; pg.Cin = Cin; pg.H = H; pg.W = W; pg.Cout = Cout;

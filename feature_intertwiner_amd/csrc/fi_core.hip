@@ -149,7 +149,8 @@ const char *fi_prof_kernel_name(int kernel_id)
         "conv_wgrad_kernel<128, 0, 0>", "bn_act_bwd_kernel",
         "crop_fwd_cl_kernel<7, 7>", "crop_fwd_cl_kernel<14, 14>", "crop_fwd_cl_kernel<0, 0>",
         "crop_bwd_cl_kernel<7, 7>", "crop_bwd_cl_kernel<14, 14>", "crop_bwd_cl_kernel<0, 0>",
-        "conv_bf16_fwd_kernel", "conv_bf16_wgrad_kernel"};
+        "conv_bf16_fwd_kernel", "conv_bf16_wgrad_kernel",
+        "conv3x3_patch_kernel<false>", "conv3x3_patch_kernel<true>"};
     if (kernel_id < 0 || kernel_id >= FI_K_COUNT) return "?";
     return names[kernel_id];
 }
