@@ -9,7 +9,7 @@ import csv,sys,collections
 acc=collections.defaultdict(list)
 for r in csv.DictReader(open(sys.argv[1])):
     n=r['Kernel_Name']
-    if 'conv_' in n:
+    if 'conv' in n:
         acc[(n[28:62], r['Counter_Name'])].append(float(r['Counter_Value']))
 for k,v in sorted(acc.items()): print(k, len(v), sum(v)/len(v))
 P
