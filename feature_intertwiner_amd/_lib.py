@@ -79,7 +79,7 @@ KERNEL_IDS = {
     "class_mean": 13, "bn_act_bwd": 30,
     "crop_fwd_nhwc_7x7": 31, "crop_fwd_nhwc_14x14": 32, "crop_fwd_nhwc_generic": 33,
     "crop_bwd_nhwc_7x7": 34, "crop_bwd_nhwc_14x14": 35, "crop_bwd_nhwc_generic": 36,
-    "conv_bf16_fwd": 37, "conv_bf16_wgrad": 38, "conv3x3_patch": 39, "conv3x3_patch_flat": 40,
+    "conv_bf16_fwd": 37, "conv_bf16_wgrad": 38, "conv3x3_patch": 39, "conv3x3_patch_flat": 40, "conv1x1_reg": 41,
 }
 for _i, _bm in enumerate((64, 128)):
     for _j, _w in enumerate(("1x1", "3x3", "7x7", "other")):
@@ -100,6 +100,13 @@ def patch_mode(N, Cin, H, W, Cout, R, S, stride, padding, tap_major, out_hw_same
     if W < 16 and W % 2 == 0 and (W + 126) // W + 2 <= 13:
         return 2 if ((N * H * W + 127) // 128) * mt >= 512 else 0
     return 0
+
+
+def reg1x1_mode(N, Cin, H, W, Cout, R, S, stride, padding, out_channels_last):
+    """Mirrors the conv1x1_reg_kernel dispatch in fi_conv2d_forward (csrc/conv_igemm.hip)."""
+    return ((R, S) == (1, 1) and tuple(stride) == (1, 1) and tuple(padding) == (0, 0) and not out_channels_last and
+            Cin % 32 == 0 and Cin >= 128 and Cout > 64 and (H * W) % 4 == 0 and
+            ((N * H * W + 127) // 128) * ((Cout + 127) // 128) >= 256)
 
 
 def conv_kernel_key(kind, cout, R, S, pixels=None, cin=None):

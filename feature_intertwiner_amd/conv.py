@@ -55,7 +55,7 @@ def _log_shape(x, w, stride, padding):
 def _log_flops(kind, cout, R, S, flops, pixels=None, cin=None, patch=0):
     if FLOP_LOG is not None:
         if patch:
-            k = "conv3x3_patch" if patch == 1 else "conv3x3_patch_flat"
+            k = {1: "conv3x3_patch", 2: "conv3x3_patch_flat", 3: "conv1x1_reg"}[patch]
         else:
             k = ("conv_" + kind) if kind.startswith("bf16") else _lib.conv_kernel_key(kind, cout, R, S, pixels, cin)
         e = FLOP_LOG.setdefault(k, [0, 0])
@@ -99,8 +99,10 @@ def _conv_fwd(x, w, b, stride, padding, relu=False, scale=None, residual=None, o
         OH, OW = out_hw
     if not ((_PRECISION == "bf16" if precision is None else precision == "bf16") and layout >= 1 and Cin % 32 == 0):
         _log_flops("fwd", Cout, R, S, 2 * N * Cout * OH * OW * Cin * R * S, N * OH * OW,
-                   patch=_lib.patch_mode(N, Cin, H, W, Cout, R, S, stride, padding, layout >= 1,
-                                         (OH, OW) == (H, W), out_channels_last) if FLOP_LOG is not None else 0)
+                   patch=(_lib.patch_mode(N, Cin, H, W, Cout, R, S, stride, padding, layout >= 1,
+                                          (OH, OW) == (H, W), out_channels_last) or
+                          (3 if _lib.reg1x1_mode(N, Cin, H, W, Cout, R, S, stride, padding, out_channels_last) else 0))
+                   if FLOP_LOG is not None else 0)
     y = torch.empty((N, Cout, OH, OW), device=x.device, dtype=torch.float32,
                     memory_format=torch.channels_last if out_channels_last else torch.contiguous_format)
     bf16 = (_PRECISION == "bf16" if precision is None else precision == "bf16") and layout >= 1 and Cin % 32 == 0

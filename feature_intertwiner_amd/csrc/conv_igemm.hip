@@ -899,6 +899,163 @@ __global__ __launch_bounds__(kThreads, 3) void conv3x3_patch_kernel(const float 
 }
 
 // -------------------------------------------------------------------------------------
+// 1x1 / stride 1 (forward and data gradient) on the structure of conv3x3_patch_kernel
+// -------------------------------------------------------------------------------------
+// A workgroup owns 128 consecutive pixels of the flattened [n][H*W] space x 128 output channels.  Per block of 32
+// input channels the pixel tile [32 ch][128 px] is staged with four 16-byte loads + four 16-byte LDS stores per
+// thread (conv_fwd_kernel: 16 scalar loads + 16 scalar LDS stores, and the weights through LDS as well); weights
+// go straight from memory into the MFMA A-operand registers (4 wavefronts x 32 output channels).  MFMA column
+// n = l31 + 32j is pixel 4*l31 + j, so the lane's four B values are ONE 16-byte LDS read per channel, and its
+// results are 4 adjacent pixels x 16 channels (16-byte NCHW stores, predicate-free epilogue on full tiles).
+constexpr int P1_CB = 32;                   // channels per stage
+constexpr int P1_PP = 132;                  // floats per channel row: 128 pixels + 4 (16-byte aligned, bank shift 4)
+
+struct Conv1x1Geom {
+    int N, Cin, HW, Cout;
+    int ptiles, mtiles;
+    int vec4;                               // 16-byte aligned y / residual
+    const float *zero;
+};
+
+__global__ __launch_bounds__(kThreads, 3) void conv1x1_reg_kernel(const float *__restrict__ x,
+                                                                 const float *__restrict__ w, Epilogue ep,
+                                                                 float *__restrict__ y, Conv1x1Geom g)
+{
+    __shared__ __attribute__((aligned(16))) float Ps[2][P1_CB][P1_PP];
+    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+    const int per_xcd = (g.ptiles + 7) >> 3;
+    const int mt = local % g.mtiles;
+    const int pt = xcd * per_xcd + local / g.mtiles;
+    if (pt >= g.ptiles) return;
+    const int m0 = mt * 128;
+    const int P = g.N * g.HW;
+    const int P0 = pt * 128;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, khalf = lane >> 5;
+
+    // ---- A operand: 8 consecutive input channels of one output channel ------------------------------
+    const int am = min(m0 + wave * 32 + l31, g.Cout - 1);
+    const float *__restrict__ a_base = w + (size_t)am * g.Cin + khalf * 8;
+    auto load_a = [&](float (&a)[8], int c16) {           // c16: 16-channel group index
+        const float *__restrict__ p = a_base + c16 * 16;
+        const float4 v0 = *reinterpret_cast<const float4 *>(p);
+        const float4 v1 = *reinterpret_cast<const float4 *>(p + 4);
+        a[0] = v0.x; a[1] = v0.y; a[2] = v0.z; a[3] = v0.w;
+        a[4] = v1.x; a[5] = v1.y; a[6] = v1.z; a[7] = v1.w;
+    };
+
+    // ---- staging: thread = (pixel group of 4, channels (tid >> 5) + 8 i) ----------------------------
+    const int sg = tid & 31;                               // pixel group of the tile
+    const int sc = tid >> 5;                               // first channel (of the stage)
+    const int sp = P0 + 4 * sg;
+    const bool s_ok = sp < P;                              // P % 4 == 0: a group is valid as a whole
+    const int s_n = s_ok ? sp / g.HW : 0;
+    const size_t s_off = ((size_t)s_n * g.Cin + sc) * g.HW + (s_ok ? sp - s_n * g.HW : 0);
+    const size_t cstep = (size_t)8 * g.HW;
+    float4 pr0, pr1, pr2, pr3;              // (separate variables: as an array the compiler kept them in scratch)
+    auto stage_load = [&](int cb) {
+        const float *__restrict__ q = s_ok ? x + s_off + (size_t)cb * P1_CB * g.HW : g.zero;
+        const size_t st = s_ok ? cstep : 0;
+        pr0 = *reinterpret_cast<const float4 *>(q);
+        pr1 = *reinterpret_cast<const float4 *>(q + st);
+        pr2 = *reinterpret_cast<const float4 *>(q + 2 * st);
+        pr3 = *reinterpret_cast<const float4 *>(q + 3 * st);
+    };
+    auto stage_store = [&](int buf) {
+        *reinterpret_cast<float4 *>(&Ps[buf][sc][4 * sg]) = pr0;
+        *reinterpret_cast<float4 *>(&Ps[buf][sc + 8][4 * sg]) = pr1;
+        *reinterpret_cast<float4 *>(&Ps[buf][sc + 16][4 * sg]) = pr2;
+        *reinterpret_cast<float4 *>(&Ps[buf][sc + 24][4 * sg]) = pr3;
+    };
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[j][e] = 0.0f;
+
+    const int ncb = g.Cin / P1_CB;
+    stage_load(0);
+    stage_store(0);
+    __syncthreads();
+
+    // 16 sub-steps (2 channel groups x 8 channel pairs) of 4 MFMAs per stage; the 16-byte LDS read of sub-step
+    // i+1 and the weight loads of the next channel group are issued before the MFMAs of sub-step i
+    float areg[2][8];
+    float4 breg[2];
+    load_a(areg[0], 0);
+    for (int cb = 0; cb < ncb; ++cb) {
+        const float *__restrict__ pbuf = &Ps[cb & 1][khalf * 8][4 * l31];
+        const bool more = cb + 1 < ncb;
+        if (more) stage_load(cb + 1);
+        breg[0] = *reinterpret_cast<const float4 *>(pbuf);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);          // the read of sub-step 0
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (h == 0) load_a(areg[1], 2 * cb + 1);
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {
+                const int step = h * 8 + kk;
+                if (step + 1 < 16) {
+                    const int h2 = (step + 1) / 8, k2 = (step + 1) % 8;
+                    breg[(step + 1) & 1] = *reinterpret_cast<const float4 *>(pbuf + (h2 * 16 + k2) * P1_PP);
+                }
+                const float av = areg[h][kk];
+                const float4 bv = breg[step & 1];
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv.x, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv.y, acc[1], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv.z, acc[2], 0, 0, 0);
+                acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv.w, acc[3], 0, 0, 0);
+                if (kk == 0 && h == 0) __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            }
+        }
+        if (more) {
+            load_a(areg[0], 2 * cb + 2);
+            stage_store((cb + 1) & 1);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue --------------------------------------------------------------------------------------
+    const int po = P0 + 4 * l31;
+    if (po >= P) return;
+    const int n_img = po / g.HW;
+    const int mb = m0 + wave * 32 + 4 * khalf;
+    const size_t HW = (size_t)g.HW;
+    const size_t obase = ((size_t)n_img * g.Cout + mb) * HW + (po - n_img * g.HW);
+    const bool has_sc = ep.scale != nullptr, has_bi = ep.bias != nullptr, relu = ep.relu != 0;
+    const float *__restrict__ spp = has_sc ? ep.scale : g.zero;
+    const float *__restrict__ bpp = has_bi ? ep.bias : g.zero;
+    const int smul = has_sc ? 1 : 0, bmul = has_bi ? 1 : 0;
+    if (g.vec4 && m0 + 128 <= g.Cout) {
+        if (ep.residual)
+            patch_epilogue_vec<true>(acc, ep, y, obase, HW, mb, spp, bpp, smul, bmul, has_sc, has_bi, relu);
+        else
+            patch_epilogue_vec<false>(acc, ep, y, obase, HW, mb, spp, bpp, smul, bmul, has_sc, has_bi, relu);
+        return;
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int m = mb + (e & 3) + 8 * (e >> 2);
+        if (m >= g.Cout) continue;
+        const float sc = spp[m * smul], bi = bpp[m * bmul];
+        const size_t o = obase + (size_t)((e & 3) + 8 * (e >> 2)) * HW;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float v = acc[j][e];
+            v = has_sc ? v * sc : v;
+            v = has_bi ? v + bi : v;
+            if (ep.residual) v += ep.residual[o + j];
+            y[o + j] = relu ? fmaxf(v, 0.0f) : v;
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------
 // weight gradient:  dW[m][k] = sum_p dY[m][p] * Xcol[k][p]
 //   GEMM rows m = output channel, columns k = (ci, r, s), reduction over pixels p.
 //   blockIdx.z splits the pixel range; partial sums are added with fp32 atomics.
@@ -1857,8 +2014,28 @@ int fi_conv2d_forward(const float *x, const float *weight, const float *bias, co
     const bool bm64 = use_bm64(Cout, g.P);
     // 3x3 / stride 1 / pad 1 layers with enough tiles to fill the chip: input patch in LDS (conv3x3_patch_kernel)
     const int patch_mode = getenv("FI_NO_PATCH") ? 0 : patch_eligible(g, hwc, weight_layout, y, residual);
+    // 1x1 / stride 1 layers: weights in registers, pixel tile staged 32 channels at a time (conv1x1_reg_kernel);
+    // layers with fewer than 128 input channels are bound by their output stream and measured faster on
+    // conv_fwd_kernel (4 workgroups per CU)
+    const bool reg1x1 = !getenv("FI_NO_REG1X1") && R == 1 && S == 1 && stride_h == 1 && stride_w == 1 && pad_h == 0 &&
+                        pad_w == 0 && !g.out_nhwc && Cin % P1_CB == 0 && Cin >= 128 && Cout > 64 && (H * W) % 4 == 0 &&
+                        (uintptr_t)x % 16 == 0 && (long)N * Cin * H * W < 2147483647L &&
+                        (long)fi::ceil_div(N * H * W, 128) * fi::ceil_div(Cout, 128) >= 256;
     fi::ProfScope prof(patch_mode ? FI_K_CONV3X3_PATCH + (patch_mode - 1)
-                                  : FI_K_CONV_FWD + (bm64 ? 0 : 4) + window_class(R, S), st);
+                       : reg1x1 ? FI_K_CONV1X1_REG
+                                : FI_K_CONV_FWD + (bm64 ? 0 : 4) + window_class(R, S), st);
+    if (reg1x1) {
+        Conv1x1Geom cg;
+        cg.N = N; cg.Cin = Cin; cg.HW = H * W; cg.Cout = Cout;
+        cg.ptiles = fi::ceil_div(N * H * W, 128);
+        cg.mtiles = fi::ceil_div(Cout, 128);
+        cg.vec4 = ((uintptr_t)y % 16 == 0 && (residual == nullptr || (uintptr_t)residual % 16 == 0)) ? 1 : 0;
+        cg.zero = g.zero;
+        const long blocks = (long)fi::ceil_div(cg.ptiles, 8) * 8 * cg.mtiles;
+        hipLaunchKernelGGL(conv1x1_reg_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, st, x, weight, ep, y, cg);
+        FI_HIP_CHECK(hipGetLastError());
+        return FI_OK;
+    }
     if (patch_mode) {
         PatchGeom pg;
         pg.N = N; pg.Cin = Cin; pg.H = H; pg.W = W; pg.Cout = Cout;

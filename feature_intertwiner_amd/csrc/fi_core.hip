@@ -150,7 +150,7 @@ const char *fi_prof_kernel_name(int kernel_id)
         "crop_fwd_cl_kernel<7, 7>", "crop_fwd_cl_kernel<14, 14>", "crop_fwd_cl_kernel<0, 0>",
         "crop_bwd_cl_kernel<7, 7>", "crop_bwd_cl_kernel<14, 14>", "crop_bwd_cl_kernel<0, 0>",
         "conv_bf16_fwd_kernel", "conv_bf16_wgrad_kernel",
-        "conv3x3_patch_kernel<false>", "conv3x3_patch_kernel<true>"};
+        "conv3x3_patch_kernel<false>", "conv3x3_patch_kernel<true>", "conv1x1_reg_kernel"};
     if (kernel_id < 0 || kernel_id >= FI_K_COUNT) return "?";
     return names[kernel_id];
 }
