@@ -92,12 +92,14 @@ def patch_mode(N, Cin, H, W, Cout, R, S, stride, padding, tap_major, out_hw_same
     (2-D tiles), 2 = conv3x3_patch_kernel<true> (flat tiles of 14-wide RoI maps)."""
     if (R, S) != (3, 3) or tuple(stride) != (1, 1) or tuple(padding) != (1, 1):
         return 0
-    if not tap_major or out_channels_last or Cout <= 64 or not out_hw_same:
+    if not tap_major or Cout <= 64 or not out_hw_same:
+        return 0
+    if out_channels_last and not (W % 16 == 0 and Cout % 128 == 0):
         return 0
     mt = (Cout + 127) // 128
     if W % 16 == 0:
         return 1 if ((N * H + 7) // 8) * (W // 16) * mt >= 256 else 0
-    if W < 16 and W % 2 == 0 and (W + 126) // W + 2 <= 13:
+    if W < 16 and W % 2 == 0 and (W + 126) // W + 2 <= 13 and not out_channels_last:
         return 2 if ((N * H * W + 127) // 128) * mt >= 512 else 0
     return 0
 

@@ -570,6 +570,7 @@ struct PatchGeom {
     int tiles_x;         // 2-D: column tiles per row
     int ptiles, mtiles;  // pixel tiles, Cout tiles
     int vec4;            // 2-D: W % 4 == 0 and 16-byte aligned tensors -> 16-byte stores / shortcut loads
+    int out_nhwc;        // 2-D only: y is [N][H][W][Cout] (Cout % 128 == 0, no shortcut): 16-byte channel groups
     const float *zero;
 };
 
@@ -870,6 +871,33 @@ __global__ __launch_bounds__(kThreads, 3) void conv3x3_patch_kernel(const float 
     }
     const int Yo = Yj[0], xo = xj[0];
     if (Yo >= NH || xo >= g.W) return;
+    if (g.out_nhwc) {
+        // channels-last output (maps that only the channels-last RoIAlign reads): the lane's accumulator rows
+        // (e & 3) are 4 consecutive channels of one pixel -> one 16-byte store per pixel and group of rows
+        float *__restrict__ yp = y + ((size_t)Yo * g.W + xo) * g.Cout + mb;      // stacked row == n*H + y
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float sc[4], bi[4];
+#pragma unroll
+            for (int e4 = 0; e4 < 4; ++e4) {
+                sc[e4] = sp[(mb + 8 * q + e4) * smul];
+                bi[e4] = bp[(mb + 8 * q + e4) * bmul];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float t[4];
+#pragma unroll
+                for (int e4 = 0; e4 < 4; ++e4) {
+                    float v = acc[j][4 * q + e4];
+                    v = has_sc ? v * sc[e4] : v;
+                    v = has_bi ? v + bi[e4] : v;
+                    t[e4] = relu ? fmaxf(v, 0.0f) : v;
+                }
+                *reinterpret_cast<float4 *>(yp + (size_t)j * g.Cout + 8 * q) = make_float4(t[0], t[1], t[2], t[3]);
+            }
+        }
+        return;
+    }
     const int n_img = Yo / g.H;
     const size_t obase = ((size_t)n_img * g.Cout + mb) * HW + (size_t)(Yo - n_img * g.H) * g.W + xo;
     if (g.vec4 && m0 + 128 <= g.Cout) {      // xo % 4 == 0 and W % 4 == 0: the quad is inside the row
@@ -1540,7 +1568,8 @@ bool use_bm64(int Cout, int P)
 int patch_eligible(const ConvGeom &g, bool hwc, int weight_layout, const float *y, const float *residual)
 {
     if (!(g.R == 3 && g.S == 3 && g.sh == 1 && g.sw == 1 && g.ph == 1 && g.pw == 1)) return 0;
-    if (!hwc || weight_layout < 1 || g.out_nhwc || g.Cout <= 64 || g.OH != g.H || g.OW != g.W) return 0;
+    if (!hwc || weight_layout < 1 || g.Cout <= 64 || g.OH != g.H || g.OW != g.W) return 0;
+    if (g.out_nhwc && !(g.W % PT_TW == 0 && g.Cout % 128 == 0 && residual == nullptr && (uintptr_t)y % 16 == 0)) return 0;
     if ((long)g.N * g.Cin * g.H * g.W >= 2147483647L || (long)g.N * g.Cout * g.H * g.W >= 2147483647L) return 0;
     const long mt = fi::ceil_div(g.Cout, 128);
     if (g.W % PT_TW == 0)
@@ -2044,6 +2073,7 @@ int fi_conv2d_forward(const float *x, const float *weight, const float *bias, co
         pg.ptiles = patch_mode == 2 ? fi::ceil_div(N * H * W, 128) : fi::ceil_div(N * H, PT_TH) * pg.tiles_x;
         pg.mtiles = fi::ceil_div(Cout, 128);
         pg.vec4 = (W % 4 == 0 && (uintptr_t)y % 16 == 0 && (residual == nullptr || (uintptr_t)residual % 16 == 0)) ? 1 : 0;
+        pg.out_nhwc = g.out_nhwc;
         pg.zero = g.zero;
         const long blocks = (long)fi::ceil_div(pg.ptiles, 8) * 8 * pg.mtiles;
         if (patch_mode == 2)

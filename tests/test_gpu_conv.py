@@ -287,6 +287,11 @@ def test_patch_kernel_fused_epilogue():
         y = _conv_fwd(x.to(DEV), w.to(DEV), b.to(DEV), (1, 1), (1, 1), **kw)
         r = ref if kw["relu"] else F.conv2d(x.double(), w.double(), b.double(), padding=1)
         assert (y.cpu().double() - r).abs().max().item() <= 2e-5 * math.sqrt(Cin * 9) * r.abs().max().item()
+    # channels-last output of the 2-D patch kernel (the make-up layers of the RoI stage)
+    y = _conv_fwd(x.to(DEV), w.to(DEV), b.to(DEV), (1, 1), (1, 1), relu=True, scale=sc.to(DEV), out_channels_last=True)
+    assert y.is_contiguous(memory_format=torch.channels_last)
+    r = F.relu(F.conv2d(x.double(), w.double(), None, padding=1) * sc.double().view(1, -1, 1, 1) + b.double().view(1, -1, 1, 1))
+    assert (y.cpu().double() - r).abs().max().item() <= 2e-5 * math.sqrt(Cin * 9) * r.abs().max().item()
     # flat tiles (14 x 14 maps) with the same epilogue
     N, Cin, H, W, Cout = 400, 16, 14, 14, 200
     x = torch.randn(N, Cin, H, W, generator=g)
