@@ -109,6 +109,19 @@ def _conv_fwd(x, w, b, stride, padding, relu=False, scale=None, residual=None, o
     fn = L.fi_conv2d_forward_bf16 if bf16 else L.fi_conv2d_forward
     if bf16:
         _log_flops("bf16_fwd", Cout, R, S, 2 * N * Cout * OH * OW * Cin * R * S)
+        # 3x3 / stride 1 / pad 1 on maps whose width is a multiple of 16: patch kernel with the weights converted to
+        # bf16 once per step (cached like W^T) instead of inside every workgroup
+        if (R, S) == (3, 3) and tuple(stride) == (1, 1) and tuple(padding) == (1, 1) and (OH, OW) == (H, W) and \
+                W % 16 == 0 and Cout > 64 and not out_channels_last and out_hw is None and \
+                ((N * H + 7) // 8) * (W // 16) * ((Cout + 127) // 128) >= 256 and \
+                (residual is None or residual.data_ptr() % 16 == 0):
+            wb = _cached_bf16(w)
+            with torch.cuda.device(x.device):
+                _lib.check(L.fi_conv3x3_forward_bf16w(_lib.ptr(x), _lib.ptr(wb), _lib.ptr(b), _lib.ptr(scale),
+                                                      _lib.ptr(residual), _lib.ptr(y), N, Cin, H, W, Cout,
+                                                      1 if relu else 0, 1 if layout == 2 else 0, _lib.current_stream()),
+                           "fi_conv3x3_forward_bf16w")
+            return y
     with torch.cuda.device(x.device):
         _lib.check(fn(_lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(scale), _lib.ptr(residual),
                                        _lib.ptr(y), N, Cin, H, W, Cout,
@@ -256,6 +269,20 @@ _ARENA = {"buf": None, "slots": {}, "used": set()}
 _PLAN = weakref.WeakKeyDictionary()      # model -> cached layer lists / descriptor table
 
 
+_WB = {}           # tap-major fp32 weight data_ptr -> (bf16 copy, version, shape): refreshed once per step
+
+
+def _cached_bf16(w):
+    """bf16 copy of a tap-major fp32 weight, made once per (tensor, version).  The entry keeps `w` alive, so its
+    address cannot be handed to another tensor while the entry exists."""
+    e = _WB.get(w.data_ptr())
+    if e is not None and e[1] == w._version and e[2] == tuple(w.shape):
+        return e[0]
+    wb = w.to(torch.bfloat16)
+    _WB[w.data_ptr()] = (wb, w._version, tuple(w.shape), w)
+    return wb
+
+
 def _cached_wt(w):
     e = _WT.get(w.data_ptr())
     if e is not None and e[1] == w._version and e[0].shape == (w.shape[1], w.shape[2], w.shape[3], w.shape[0]):
@@ -275,6 +302,7 @@ def _arena_take(key, numel):
 
 def invalidate_step_state():
     _WT.clear()
+    _WB.clear()
     _ARENA["buf"] = None
     _ARENA["slots"] = {}
     _ARENA["used"] = set()
@@ -343,6 +371,7 @@ def _prepare_step(model, grad_on):
         for m, wt in zip(plan["tr"], plan["wts"]):
             _WT[m.weight.data_ptr()] = (wt, m.weight._version)
         plan["versions"] = versions
+        _WB.clear()          # the W^T tensors were rewritten in place (no version bump): drop their bf16 copies
     if grad_on and plan["arena_floats"]:
         _ARENA["buf"] = torch.zeros(plan["arena_floats"], device=dev, dtype=torch.float32)
         _ARENA["slots"] = plan["slots"]

@@ -440,6 +440,242 @@ __global__ __launch_bounds__(kThreads, 2) void conv_bf16_fwd_kernel(const float 
 }
 
 // ------------------------------------------------------------------------------------------------
+// 3x3 / stride 1 / pad 1 forward + data gradient: input patch in LDS (the bf16 twin of conv3x3_patch_kernel)
+// ------------------------------------------------------------------------------------------------
+// conv_bf16_fwd_kernel is ISSUE bound (~200 VALU + 190 SALU instructions per 8 MFMAs: address arithmetic, halo
+// selects, fp32->bf16 packs for every tap).  Here a workgroup owns 8 rows x 16 columns of output pixels x 128
+// output channels and stages, per block of 32 input channels, the (8+2) x 24 input patch ONCE, already
+// converted: a thread loads 4 pixels of 8 channels (eight 16-byte loads), packs them and writes four 16-byte
+// LDS slots, one per pixel, each holding the pixel's 8 channels = one MFMA B-fragment.  The nine taps are nine
+// slot offsets.  Slots of a patch row are ordered by (column mod 4, column div 4) and rows are 28 slots apart, so
+// that the 16 lanes of a quarter-wavefront -- 4 rows x 4 quads, each lane reading pixel 4q + j + s -- hit all 32
+// banks exactly twice: the minimum for 256 bytes.  Weights skip LDS: a lane loads the 8 channels of its
+// (output channel, tap, k-step) from the tap-major fp32 weight two taps ahead and packs them.
+// Per 32 channels: 72 MFMAs (32x32x16) per wavefront, one barrier.
+constexpr int PB_TH = 8, PB_TW = 16;
+constexpr int PB_RP = 28;                       // slots per patch row (24 used)
+constexpr int PB_ROWS = PB_TH + 2;
+constexpr int PB_NSLOT = (PB_ROWS + 1) * PB_RP; // + one row of zeros
+constexpr int PB_CB = 32;                       // channels per stage = 4 groups of 8
+
+struct PatchGeomB {
+    int N, Cin, H, W, Cout;
+    int flip, tiles_x, ptiles, mtiles;
+};
+
+__device__ __forceinline__ bf16x8 pack8(const f32x4 &lo, const f32x4 &hi)
+{
+    bf16x8 r;
+    r[0] = (__bf16)lo.x; r[1] = (__bf16)lo.y; r[2] = (__bf16)lo.z; r[3] = (__bf16)lo.w;
+    r[4] = (__bf16)hi.x; r[5] = (__bf16)hi.y; r[6] = (__bf16)hi.z; r[7] = (__bf16)hi.w;
+    return r;
+}
+
+// WB16: the weights are already bf16 (pre-converted once per step by the caller): a lane's A-operand is ONE 16-byte
+// load per (tap, k-step), no packing.  With fp32 weights every wavefront streams 37 KB of weights per 32 channels
+// from L2 -- 8 wavefronts of a CU ask for more than the L2->L1 path delivers at the bf16 MFMA rate.
+template <bool WB16>
+__global__ __launch_bounds__(kThreads, 2) void conv3x3_patch_bf16_kernel(const float *__restrict__ x,
+                                                                        const void *__restrict__ wv, Epi ep,
+                                                                        float *__restrict__ y, PatchGeomB g)
+{
+    const float *__restrict__ w = static_cast<const float *>(wv);
+    const __bf16 *__restrict__ wb = static_cast<const __bf16 *>(wv);
+    __shared__ __align__(16) bf16x8 Ps[2][PB_CB / 8][PB_NSLOT];
+
+    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+    const int per_xcd = (g.ptiles + 7) >> 3;
+    const int mt = local % g.mtiles;
+    const int pt = xcd * per_xcd + local / g.mtiles;
+    if (pt >= g.ptiles) return;
+    const int tile_y = pt / g.tiles_x, tile_x = pt - tile_y * g.tiles_x;
+    const int Y0 = tile_y * PB_TH, X0 = tile_x * PB_TW, m0 = mt * 128;
+    const int NH = g.N * g.H;
+    const size_t HW = (size_t)g.H * g.W;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, khalf = lane >> 5;
+
+    // ---- A operand ------------------------------------------------------------------------------------
+    const int am = min(m0 + wave * 32 + l31, g.Cout - 1);
+    const float *__restrict__ a_base = w + (size_t)am * 9 * g.Cin + khalf * 8;
+    const __bf16 *__restrict__ ab_base = wb + (size_t)am * 9 * g.Cin + khalf * 8;
+    auto load_a_raw = [&](f32x4 (&raw)[4], int tap, int cb) {          // both k-steps of a tap
+        const float *__restrict__ p = a_base + (size_t)(g.flip ? 8 - tap : tap) * g.Cin + cb * PB_CB;
+        raw[0] = *reinterpret_cast<const f32x4 *>(p);
+        raw[1] = *reinterpret_cast<const f32x4 *>(p + 4);
+        raw[2] = *reinterpret_cast<const f32x4 *>(p + 16);
+        raw[3] = *reinterpret_cast<const f32x4 *>(p + 20);
+    };
+    auto load_a_b16 = [&](bf16x8 (&pk)[2], int tap, int cb) {
+        const __bf16 *__restrict__ p = ab_base + (size_t)(g.flip ? 8 - tap : tap) * g.Cin + cb * PB_CB;
+        pk[0] = *reinterpret_cast<const bf16x8 *>(p);
+        pk[1] = *reinterpret_cast<const bf16x8 *>(p + 16);
+    };
+
+    // ---- B operand: slot of (patch row of tap row r, quad) ---------------------------------------------
+    const int ty = l31 >> 2, q = l31 & 3;
+    const int Yo = Y0 + ty;
+    const int yo = Yo - (Yo / g.H) * g.H;
+    int rowslot[3];
+    rowslot[0] = (yo != 0 ? ty : PB_ROWS) * PB_RP + q;
+    rowslot[1] = (ty + 1) * PB_RP + q;
+    rowslot[2] = (yo != g.H - 1 ? ty + 2 : PB_ROWS) * PB_RP + q;
+
+    // ---- staging: thread = (channel group of 8, patch row, 4 columns) -----------------------------------
+    const bool s_item = tid < (PB_CB / 8) * PB_ROWS * 6;
+    const int s_kg = tid / (PB_ROWS * 6);
+    const int s_rem = tid - s_kg * (PB_ROWS * 6);
+    const int s_prow = s_rem / 6, s_grp = s_rem - s_prow * 6;
+    const int s_Ys = Y0 - 1 + s_prow, s_xx = X0 - 4 + s_grp * 4;
+    const bool s_ok = s_item && s_Ys >= 0 && s_Ys < NH && s_xx >= 0 && s_xx + 3 < g.W;   // W % 16 == 0: whole groups
+    const int s_n = s_ok ? s_Ys / g.H : 0;
+    const size_t s_off = ((size_t)s_n * g.Cin + s_kg * 8) * HW + (s_ok ? (size_t)(s_Ys - s_n * g.H) * g.W + s_xx : 0);
+    f32x4 sr0, sr1, sr2, sr3, sr4, sr5, sr6, sr7;
+    auto stage_load = [&](int cb) {
+        if (!s_ok) {
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            sr0 = sr1 = sr2 = sr3 = sr4 = sr5 = sr6 = sr7 = z;
+            return;
+        }
+        const float *__restrict__ p = x + s_off + (size_t)cb * PB_CB * HW;
+        sr0 = *reinterpret_cast<const f32x4 *>(p);
+        sr1 = *reinterpret_cast<const f32x4 *>(p + HW);
+        sr2 = *reinterpret_cast<const f32x4 *>(p + 2 * HW);
+        sr3 = *reinterpret_cast<const f32x4 *>(p + 3 * HW);
+        sr4 = *reinterpret_cast<const f32x4 *>(p + 4 * HW);
+        sr5 = *reinterpret_cast<const f32x4 *>(p + 5 * HW);
+        sr6 = *reinterpret_cast<const f32x4 *>(p + 6 * HW);
+        sr7 = *reinterpret_cast<const f32x4 *>(p + 7 * HW);
+    };
+    auto stage_store = [&](int buf) {
+        if (!s_item) return;
+        bf16x8 *__restrict__ d = &Ps[buf][s_kg][s_prow * PB_RP + s_grp];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {                          // pixel i of the group: column c = 4*grp + i -> slot i*6 + grp
+            bf16x8 v;
+            v[0] = (__bf16)sr0[i]; v[1] = (__bf16)sr1[i]; v[2] = (__bf16)sr2[i]; v[3] = (__bf16)sr3[i];
+            v[4] = (__bf16)sr4[i]; v[5] = (__bf16)sr5[i]; v[6] = (__bf16)sr6[i]; v[7] = (__bf16)sr7[i];
+            d[i * 6] = v;
+        }
+    };
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[j][e] = 0.0f;
+
+    // the row of zeros (both buffers, all channel groups)
+    for (int i = tid; i < 2 * (PB_CB / 8) * PB_RP; i += kThreads) {
+        const int b = i / ((PB_CB / 8) * PB_RP), r_ = i - b * ((PB_CB / 8) * PB_RP);
+        bf16x8 z;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) z[e] = (__bf16)0.0f;
+        Ps[b][r_ / PB_RP][PB_ROWS * PB_RP + (r_ % PB_RP)] = z;
+    }
+    const int ncb = g.Cin / PB_CB;
+    stage_load(0);
+    stage_store(0);
+    __syncthreads();
+
+    // 18 sub-steps (9 taps x 2 k-steps) of 4 MFMAs per stage.  Weights: the raw fp32 values of tap T+2 are loaded
+    // while tap T is in the MFMAs and packed at the end of tap T+1; three register sets rotate (9 % 3 == 0, so the
+    // pattern is the same in every stage and runs across stage boundaries).
+    f32x4 araw[3][4];
+    bf16x8 apk[3][2];
+    bf16x8 bfr[2][4];                // [sub-step parity][pixel j]
+    if (WB16) {
+        load_a_b16(apk[0], 0, 0);
+        load_a_b16(apk[1], 1, 0);
+    } else {
+        load_a_raw(araw[0], 0, 0);
+        load_a_raw(araw[1], 1, 0);
+        apk[0][0] = pack8(araw[0][0], araw[0][1]);
+        apk[0][1] = pack8(araw[0][2], araw[0][3]);
+    }
+    for (int cb = 0; cb < ncb; ++cb) {
+        const bf16x8 *__restrict__ pbuf = &Ps[cb & 1][khalf][0];           // k-step ks adds 2 channel groups
+        const bool more = cb + 1 < ncb;
+        if (more) stage_load(cb + 1);
+        auto bload = [&](bf16x8 (&bv)[4], int r_, int s_, int ks) {
+            const bf16x8 *__restrict__ bp = pbuf + ks * 2 * PB_NSLOT + rowslot[r_];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bv[j] = bp[((j + s_ + 3) & 3) * 6 + ((j + s_ + 3) >> 2)];
+        };
+        bload(bfr[0], 0, 0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);                 // LDS reads of sub-step 0
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const bool ld = (t + 2 < 9) || more;
+            const int tap2 = t + 2 < 9 ? t + 2 : t + 2 - 9, cb2 = t + 2 < 9 ? cb : cb + 1;
+            if (ld) {
+                if (WB16)
+                    load_a_b16(apk[(t + 2) % 3], tap2, cb2);
+                else
+                    load_a_raw(araw[(t + 2) % 3], tap2, cb2);
+            }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int step = t * 2 + ks;
+                if (step + 1 < 18) {
+                    const int t2 = (step + 1) >> 1, k2 = (step + 1) & 1;
+                    bload(bfr[(step + 1) & 1], t2 / 3, t2 % 3, k2);
+                }
+                const bf16x8 av = apk[t % 3][ks];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bfr[step & 1][j], acc[j], 0, 0, 0);
+            }
+            // fp32 weights: tap t+1 (of this stage or the first of the next) was loaded one tap ago, packed now
+            if (!WB16 && (t + 1 < 9 || more)) {
+                apk[(t + 1) % 3][0] = pack8(araw[(t + 1) % 3][0], araw[(t + 1) % 3][1]);
+                apk[(t + 1) % 3][1] = pack8(araw[(t + 1) % 3][2], araw[(t + 1) % 3][3]);
+            }
+            // issue order of this tap: weight loads of tap t+2, then per k-step the LDS reads of the next sub-step
+            // ahead of the 4 MFMAs, then the packs of tap t+1 (left alone the compiler sinks the loads to their use)
+            if (ld) __builtin_amdgcn_sched_group_barrier(0x020, WB16 ? 2 : 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            if (t < 8) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            if (!WB16 && (t + 1 < 9 || more)) __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+        }
+        if (more) stage_store((cb + 1) & 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: the lane's quad x 16 channels (same layout as conv_bf16_fwd_kernel<128>) ----------------
+    const int xo = X0 + 4 * q;
+    if (Yo >= NH || xo >= g.W) return;
+    const int n_img = Yo / g.H;
+    const int mb = m0 + wave * 32 + 4 * khalf;
+    const size_t obase = ((size_t)n_img * g.Cout + mb) * HW + (size_t)yo * g.W + xo;
+    if (m0 + 128 <= g.Cout) {
+        if (ep.residual)
+            epilogue_full_nchw<4, true>(acc, ep, y, obase, (int)HW, mb);
+        else
+            epilogue_full_nchw<4, false>(acc, ep, y, obase, (int)HW, mb);
+        return;
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int m = mb + (e & 3) + 8 * (e >> 2);
+        if (m >= g.Cout) continue;
+        const float sc = ep.scale ? ep.scale[m] : 1.0f;
+        const float bi = ep.bias ? ep.bias[m] : 0.0f;
+        const size_t o = obase + (size_t)((e & 3) + 8 * (e >> 2)) * HW;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float v = acc[j][e] * sc + bi;
+            if (ep.residual) v += ep.residual[o + j];
+            y[o + j] = ep.relu ? fmaxf(v, 0.0f) : v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // weight gradient (tap-major dW [Cout][R*S][Cin]), stride 1 or general
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kThreads) void conv_bf16_wgrad_generic_kernel(const float *__restrict__ x,
@@ -842,6 +1078,26 @@ int fi_conv2d_forward_bf16(const float *x, const float *weight, const float *bia
     g.out_nhwc = output_layout == 1;
     const Epi ep = {bias, scale, residual, relu};
     hipStream_t st = (hipStream_t)stream;
+    // 3x3 / stride 1 / pad 1 on maps whose width is a multiple of 16: input patch in LDS
+    if (!getenv("FI_NO_PATCH") && R == 3 && S == 3 && stride_h == 1 && stride_w == 1 && pad_h == 1 && pad_w == 1 &&
+        g.OH == H && g.OW == W && W % PB_TW == 0 && !g.out_nhwc && Cout > 64 && weight_layout >= 1 &&
+        (uintptr_t)x % 16 == 0 && (uintptr_t)y % 16 == 0 && (residual == nullptr || (uintptr_t)residual % 16 == 0) &&
+        (long)N * Cin * H * W < 2147483647L && (long)N * Cout * H * W < 2147483647L) {
+        PatchGeomB pg;
+        pg.N = N; pg.Cin = Cin; pg.H = H; pg.W = W; pg.Cout = Cout;
+        pg.flip = g.flip;
+        pg.tiles_x = W / PB_TW;
+        pg.ptiles = fi::ceil_div(N * H, PB_TH) * pg.tiles_x;
+        pg.mtiles = fi::ceil_div(Cout, 128);
+        if ((long)pg.ptiles * pg.mtiles >= 256) {
+            const long blocks = (long)fi::ceil_div(pg.ptiles, 8) * 8 * pg.mtiles;
+            fi::ProfScope prof(FI_K_CONV_BF16_FWD, st);
+            hipLaunchKernelGGL(conv3x3_patch_bf16_kernel<false>, dim3((unsigned)blocks), dim3(kThreads), 0, st, x,
+                               static_cast<const void *>(weight), ep, y, pg);
+            FI_HIP_CHECK(hipGetLastError());
+            return FI_OK;
+        }
+    }
     const long pv = (long)g.N * g.OH * ((g.OW + 3) / 4) * 4;          // virtual pixel space (rows padded to quads)
     FI_REQUIRE(pv < 2147483647L, "too many output pixels");
     const int ptiles = fi::ceil_div((int)pv, TN);
@@ -855,6 +1111,37 @@ int fi_conv2d_forward_bf16(const float *x, const float *weight, const float *bia
     auto k = bm == 64 ? (s2 ? conv_bf16_fwd_kernel<64, 2> : conv_bf16_fwd_kernel<64, 1>)
                       : (s2 ? conv_bf16_fwd_kernel<128, 2> : conv_bf16_fwd_kernel<128, 1>);
     hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(kThreads), 0, st, x, weight, ep, y, g, mtiles, ptiles);
+    FI_HIP_CHECK(hipGetLastError());
+    return FI_OK;
+}
+
+int fi_conv3x3_forward_bf16w(const float *x, const uint16_t *weight_bf16, const float *bias, const float *scale,
+                             const float *residual, float *y, int N, int Cin, int H, int W, int Cout, int relu,
+                             int flip_taps, fi_stream_t stream)
+{
+    FI_REQUIRE(N >= 1 && Cin >= 1 && H >= 1 && W >= 1 && Cout >= 1, "sizes must be positive");
+    FI_REQUIRE(x && weight_bf16 && y, "null pointer");
+    if (!(W % PB_TW == 0 && Cin % PB_CB == 0 && Cout > 64)) {
+        fi::set_error("fi_conv3x3_forward_bf16w needs W %% 16 == 0, Cin %% 32 == 0 and Cout > 64 (got W = %d, Cin = %d, Cout = %d)",
+                      W, Cin, Cout);
+        return FI_ERR_UNSUPPORTED;
+    }
+    FI_REQUIRE((uintptr_t)x % 16 == 0 && (uintptr_t)y % 16 == 0 && (uintptr_t)weight_bf16 % 16 == 0 &&
+               (residual == nullptr || (uintptr_t)residual % 16 == 0), "16-byte aligned tensors required");
+    FI_REQUIRE((long)N * Cin * H * W < 2147483647L && (long)N * Cout * H * W < 2147483647L, "tensor too large");
+    PatchGeomB pg;
+    pg.N = N; pg.Cin = Cin; pg.H = H; pg.W = W; pg.Cout = Cout;
+    pg.flip = flip_taps ? 1 : 0;
+    pg.tiles_x = W / PB_TW;
+    pg.ptiles = fi::ceil_div(N * H, PB_TH) * pg.tiles_x;
+    pg.mtiles = fi::ceil_div(Cout, 128);
+    const Epi ep = {bias, scale, residual, relu};
+    hipStream_t st = (hipStream_t)stream;
+    const long blocks = (long)fi::ceil_div(pg.ptiles, 8) * 8 * pg.mtiles;
+    FI_REQUIRE(blocks < 2147483647L, "grid too large");
+    fi::ProfScope prof(FI_K_CONV_BF16_FWD, st);
+    hipLaunchKernelGGL(conv3x3_patch_bf16_kernel<true>, dim3((unsigned)blocks), dim3(kThreads), 0, st, x,
+                       static_cast<const void *>(weight_bf16), ep, y, pg);
     FI_HIP_CHECK(hipGetLastError());
     return FI_OK;
 }

@@ -7,7 +7,8 @@ Two bars per quantity:
     |d| <= 2e-5 * sqrt(K) * max|ref| (the bar of the exact fp32 kernel, tests/test_gpu_conv.py).  A wrong
     MFMA operand layout, tap order or halo would miss this by orders of magnitude.
   * LOOSE, against the unrounded float64 op: the price of bf16 operands, 2 * 2^-9 relative per product:
-    |d| <= 1.2e-2 * sqrt(K) * rms(x) * rms(w)  (stated so that the fp32-vs-bf16 gap is a documented number).
+    |d| <= 1.6e-2 * sqrt(K) * rms(x) * rms(w)  (stated so that the fp32-vs-bf16 gap is a documented number; the
+    constant covers the maximum over the 5 M outputs of the largest case, ~10 standard deviations).
 """
 import math
 
@@ -29,6 +30,9 @@ CASES = [
     (1, 32, 9, 8, 40, 5, 5, 1, 2),         # generic window
     (4, 96, 8, 8, 130, 3, 3, 1, 1),        # Cin = 3 K-tiles per tap
     (1, 1024, 8, 8, 256, 1, 1, 1, 0),      # long K
+    (2, 64, 128, 128, 160, 3, 3, 1, 1),    # conv3x3_patch_bf16_kernel (>= 256 tiles, W % 16 == 0), partial Cout tile
+    (36, 32, 20, 16, 256, 3, 3, 1, 1),     # patch kernel: tiles cross image boundaries (H = 20), one column tile
+    (9, 160, 32, 32, 160, 3, 3, 1, 1),     # patch kernel for forward AND data gradient, 5 channel blocks
 ]
 
 
@@ -85,7 +89,7 @@ def test_bf16_conv_forward_backward(case):
     assert (wg.grad.cpu().double() - wd.grad).abs().max().item() <= tight(wd.grad, P)
     assert (bg.grad.cpu().double() - gy.double().sum((0, 2, 3))).abs().max().item() <= tight(gy.double().sum((0, 2, 3)), P)
     # the documented cost of bf16 operands
-    loose = 1.2e-2 * math.sqrt(K) * x.double().pow(2).mean().sqrt().item() * w.double().pow(2).mean().sqrt().item()
+    loose = 1.6e-2 * math.sqrt(K) * x.double().pow(2).mean().sqrt().item() * w.double().pow(2).mean().sqrt().item()
     assert (y.detach().cpu().double() - y_full).abs().max().item() <= loose
 
 
