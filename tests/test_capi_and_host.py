@@ -62,6 +62,13 @@ def test_argument_validation_without_a_gpu():
     assert L.fi_pyramid_crop_forward_nhwc(ptrs, hs, hs, 2, 16, 16, None, 1, 1, 64, 7, 7, 0.0, 16, None) == -1
     assert b"level" in L.fi_last_error()
     assert L.fi_pyramid_crop_forward_nhwc(ptrs, hs, hs, 0, 16, 16, 16, 1, 1, 64, 7, 7, 0.0, 16, None) == -1
+    # bf16-weight patch convolution and the optimiser step validate before touching the device
+    assert L.fi_conv3x3_forward_bf16w(16, 16, None, None, None, 16, 1, 32, 8, 20, 128, 0, 0, None) == -3
+    assert b"W % 16" in L.fi_last_error()
+    assert L.fi_conv3x3_forward_bf16w(None, 16, None, None, None, 16, 1, 32, 8, 16, 128, 0, 0, None) == -1
+    assert L.fi_sgd_chunks(0) == 0 and L.fi_sgd_chunks(1) == 1 and L.fi_sgd_chunks(8193) == 2
+    assert L.fi_sgd_clip_step(None, 0, 0, 1.0, None, None, None) == 0
+    assert L.fi_sgd_clip_step(None, 3, 5, 1.0, None, None, None) == -1
     # conv: layouts are validated before anything is launched
     a = [16, 16, None, None, None, 16]
     assert L.fi_conv2d_forward(*a, 1, 32, 8, 8, 64, 3, 3, 1, 1, 1, 1, 0, 5, 0, 0, 0, None) == -1
