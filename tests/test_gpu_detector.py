@@ -445,3 +445,31 @@ def test_detection_layer_without_foreground():
     probs = torch.full((100, 81), 0.5 / 80, device=DEV)
     probs[:, 3] = 0.5
     assert torch.all(L.detection_layer(rois, probs, deltas, win, cfg) == 0)
+
+
+def test_rpn_targets_on_the_side_stream_equal_the_inline_call():
+    """MaskRCNN.forward generates the RPN targets on a second stream while the backbone runs
+    (_lib.run_on_side_stream): same values, same generator consumption as the inline call."""
+    from feature_intertwiner_amd import _lib
+    from feature_intertwiner_amd.config import make_config
+    from feature_intertwiner_amd.layers import prepare_rpn_target
+    from feature_intertwiner_amd.model import MaskRCNN
+    from feature_intertwiner_amd.synthetic import synthetic_batch
+    torch.manual_seed(3)
+    cfg = make_config("resnet50", 256, 2, 64, dev_switch=False)
+    model = MaskRCNN(cfg).to(DEV)
+    batch = synthetic_batch(2, 256, device=DEV, seed=9)
+    g1 = torch.Generator(device=DEV).manual_seed(5)
+    g2 = torch.Generator(device=DEV).manual_seed(5)
+    with torch.no_grad():
+        inline = prepare_rpn_target(model.priors, batch[1], batch[2], cfg, g1)
+        # keep the main stream busy so that the side stream really overlaps something
+        busy = torch.randn(4096, 4096, device=DEV)
+        ready = _lib.run_on_side_stream(prepare_rpn_target, model.priors, batch[1], batch[2], cfg, g2)
+        for _ in range(4):
+            busy = busy @ busy * 1e-4
+        side = ready()
+    torch.cuda.synchronize()
+    for a, b in zip(inline, side):
+        assert torch.equal(a, b)
+    assert torch.equal(g1.get_state(), g2.get_state())

@@ -30,13 +30,28 @@ def test_configs2_full_size_two_steps_operators_vs_oracle(oracle):
     _lib.TAP = lambda name, **kw: taps.append((name, {k: (v.detach().clone() if torch.is_tensor(v) else
                                                          ([m.detach() for m in v] if isinstance(v, list) else v))
                                                       for k, v in kw.items()}))
+    from feature_intertwiner_amd import conv as C
+    C.FLOP_LOG = {}
+    _lib.prof_reset()
+    _lib.prof_enable(True)
     try:
         terms = train_step(model, opt, list(batch))                   # step 2, captured
     finally:
         _lib.TAP = None
+        _lib.prof_enable(False)
+        used, C.FLOP_LOG = dict(C.FLOP_LOG), None
     torch.cuda.synchronize()
     assert all(torch.isfinite(v) for v in terms.values()), terms
     assert float(terms["total"]) < first
+    # kernel selection of the headline step: the 3x3 / stride 1 layers run on the patch kernels (2-D tiles on the
+    # pyramid maps, flat tiles on the 14 x 14 RoI maps), the wide 1x1 layers on conv1x1_reg_kernel -- and the
+    # Python-side bookkeeping (bench.py's per-kernel flops) agrees with what the library launched
+    for key in ("conv3x3_patch", "conv3x3_patch_flat", "conv1x1_reg"):
+        assert key in used and used[key][0] > 0, (key, sorted(used))
+        launches, _ = _lib.prof_get(key)
+        assert launches == used[key][0], (key, launches, used[key][0])
+    flops = {k: v[1] for k, v in used.items()}
+    assert flops["conv3x3_patch"] + flops["conv3x3_patch_flat"] > 0.4 * sum(flops.values())
 
     names = [n for n, _ in taps]
     assert names.count("nms_sorted") == 1 and names.count("sinkhorn") == 1
