@@ -302,3 +302,35 @@ def test_patch_kernel_fused_epilogue():
                  b.double().view(1, -1, 1, 1) + res.double())
     y = _conv_fwd(x.to(DEV), w.to(DEV), b.to(DEV), (1, 1), (1, 1), relu=True, scale=sc.to(DEV), residual=res.to(DEV))
     assert (y.cpu().double() - ref).abs().max().item() <= 2e-5 * math.sqrt(Cin * 9) * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("case", [
+    (4, 256, 256, 256, 256, 3, 1),      # P2-level 3x3: conv3x3_patch_kernel<false> forward + data gradient, vec weight gradient
+    (2006, 256, 14, 14, 256, 3, 1),     # mask-head 3x3 at the step's RoI count: flat patch tiles
+    (4, 1024, 64, 64, 256, 1, 0),       # C4 1x1: conv1x1_reg_kernel
+    (4, 256, 64, 64, 1024, 1, 0),       # C4 conv3 1x1
+])
+def test_full_size_adjoint_identities(case):
+    """Size-independent properties at the layer sizes of BASELINE configs[2] (no CPU reference at these sizes):
+    the data gradient is the adjoint of the forward map in x, the weight gradient its adjoint in w,
+        <dy, conv(x, w)> == <dgrad(dy), x> == <wgrad(dy, x), w>,
+    and the forward map is linear in x.  Sums in float64 on the device; bar 2e-6 relative to the products' scale."""
+    from feature_intertwiner_amd.conv import conv2d
+    N, Cin, H, W, Cout, R, pd = case
+    g = torch.Generator(device=DEV).manual_seed(sum(case))
+    x = torch.randn(N, Cin, H, W, device=DEV, generator=g).requires_grad_(True)
+    w = (torch.randn(Cout, Cin, R, R, device=DEV, generator=g) / math.sqrt(Cin * R * R))
+    w = (w.contiguous(memory_format=torch.channels_last) if R > 1 else w).requires_grad_(True)
+    y = conv2d(x, w, None, (1, 1), (pd, pd))
+    dy = torch.randn(y.shape, device=DEV, generator=g)
+    y.backward(dy)
+    dot = lambda a, b: float((a.double() * b.double()).sum())
+    lhs = dot(dy, y.detach())
+    scale = math.sqrt(float(dy.double().pow(2).sum()) * float(y.detach().double().pow(2).sum()))
+    assert abs(lhs - dot(x.grad, x.detach())) <= 2e-6 * scale
+    assert abs(lhs - dot(w.grad, w.detach())) <= 2e-6 * scale
+    with torch.no_grad():
+        x2 = torch.randn(N, Cin, H, W, device=DEV, generator=g)
+        ysum = conv2d(x.detach() + x2, w.detach(), None, (1, 1), (pd, pd))
+        y2 = conv2d(x2, w.detach(), None, (1, 1), (pd, pd))
+        assert float((ysum - y.detach() - y2).abs().max()) <= 2e-5 * math.sqrt(Cin * R * R) * float(ysum.abs().max())
