@@ -22,7 +22,7 @@ timeout 200 python scripts/roipool_probe.py > $O/${R}_roipool_probe.txt 2>&1
 # per-layer view of the step's kernels (grid size = layer shape) from a kernel trace of the headline command
 rm -rf /tmp/prof9; ( cd /tmp && timeout 400 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof9 -o kt -- python $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 2 --profile-steps 0 --no-cpu-baseline --no-pmc > /dev/null 2>&1 )
 f=$(find /tmp/prof9 -name 'kt_kernel_trace.csv' | head -1)
-python scripts/trace_groups.py $f conv_ 7 | head -60 > $O/${R}_conv_layers.txt
+python scripts/trace_groups.py $f conv 7 | head -70 > $O/${R}_conv_layers.txt
 python scripts/trace_groups.py $f bn_act 7 > $O/${R}_bn_bwd_layers.txt
 timeout 200 python scripts/conv_bench.py > $O/${R}_conv_bench.txt 2>&1
 timeout 200 python scripts/conv_bench.py --bf16 > $O/${R}_conv_bench_bf16.txt 2>&1
