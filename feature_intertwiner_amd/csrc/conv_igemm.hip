@@ -559,8 +559,12 @@ struct PatchShape {
     static constexpr int ROWS = FLAT ? 13 : PT_TH + 2;         // patch rows (flat: up to 11 rows of 12+ pixels, + halo)
     static constexpr int ZR = ROWS;                              // + one row of zeros
     static constexpr int PP = FLAT ? 338 : 266;                  // floats per channel: (ROWS+1)*24 + 2 -> 8*PP = 16 (mod 32) banks
-    static constexpr int ITEMS = BK * ROWS * (PT_PW / 4);        // 16-byte groups per channel block
+    // staged 16-byte groups per patch row.  Flat maps are at most 16 columns wide and a patch row starts at image
+    // column -4: groups 0 and 5 (columns -4..-1 and 16..19) are outside every image -- zeroed once, never staged.
+    static constexpr int GROUPS = FLAT ? 4 : PT_PW / 4;
+    static constexpr int ITEMS = BK * ROWS * GROUPS;             // 16-byte groups per channel block
     static constexpr int PER_THREAD = (ITEMS + kThreads - 1) / kThreads;
+    static constexpr int STAGE_LOADS = PER_THREAD * (FLAT ? 2 : 1);   // global loads per thread and channel block
     static constexpr int NJ = FLAT ? 4 : 1;                      // distinct patch offsets per lane and kernel row
 };
 
@@ -733,9 +737,9 @@ __global__ __launch_bounds__(kThreads, 3) void conv3x3_patch_kernel(const float 
 #pragma unroll
     for (int i = 0; i < SH::PER_THREAD; ++i) {
         const int wi = tid + kThreads * i;
-        const int ch = wi / (SH::ROWS * 6);
-        const int rem = wi - ch * (SH::ROWS * 6);
-        const int prow = rem / 6, grp = rem - prow * 6;
+        const int ch = wi / (SH::ROWS * SH::GROUPS);
+        const int rem = wi - ch * (SH::ROWS * SH::GROUPS);
+        const int prow = rem / SH::GROUPS, grp = rem - prow * SH::GROUPS + (FLAT ? 1 : 0);
         const int Ys = Yp0 + prow;
         const int xx = Xp0 + grp * 4;
         const bool item = wi < SH::ITEMS;
@@ -756,19 +760,22 @@ __global__ __launch_bounds__(kThreads, 3) void conv3x3_patch_kernel(const float 
 #pragma unroll
         for (int i = 0; i < SH::PER_THREAD; ++i) {
             const int m = it_mask[i];
-            if (m == 15) {
-                const f32x4_v v = *reinterpret_cast<const f32x4_u *>(xb + it_goff[i]);
-                preg[i] = make_float4(v.x, v.y, v.z, v.w);
+            if (FLAT) {
+                // W is even and the group starts at a multiple of 4: each half of the group is inside or outside the
+                // image as a whole -> two 8-byte loads, the outside ones redirected to the page of zeros (no branches,
+                // so the loads of all items are in flight together)
+                const float *__restrict__ q = xb + it_goff[i];
+                const float *__restrict__ q0 = (m & 3) == 3 ? q : g.zero;
+                const float *__restrict__ q1 = (m & 12) == 12 ? q + 2 : g.zero;
+                const float2 v0 = *reinterpret_cast<const float2 *>(q0);
+                const float2 v1 = *reinterpret_cast<const float2 *>(q1);
+                preg[i] = make_float4(v0.x, v0.y, v1.x, v1.y);
             } else {
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (m > 0) {
-                    const float *__restrict__ q = xb + it_goff[i];
-                    if (m & 1) v.x = q[0];
-                    if (m & 2) v.y = q[1];
-                    if (m & 4) v.z = q[2];
-                    if (m & 8) v.w = q[3];
-                }
-                preg[i] = v;
+                // W is a multiple of 16 and the group starts at a multiple of 4: a group is inside the image as a
+                // whole (mask 15) or not at all -> one 16-byte load, redirected to the page of zeros when outside
+                const float *__restrict__ q = m == 15 ? xb + it_goff[i] : g.zero;
+                const f32x4_v v = *reinterpret_cast<const f32x4_u *>(q);
+                preg[i] = make_float4(v.x, v.y, v.z, v.w);
             }
         }
     };
@@ -789,11 +796,17 @@ __global__ __launch_bounds__(kThreads, 3) void conv3x3_patch_kernel(const float 
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[j][e] = 0.0f;
 
-    // zero rows of both buffers (never overwritten), first patch
-    for (int i = tid; i < 2 * BK * PT_PW; i += kThreads) {
-        const int b = i / (BK * PT_PW), r = i - b * (BK * PT_PW);
-        const int ch = r / PT_PW;
-        Ps[b][ch][SH::ZR * PT_PW + (r - ch * PT_PW)] = 0.0f;
+    // zero rows of both buffers (never overwritten; flat: also the never-staged outer column groups), first patch
+    if (FLAT) {
+        float *__restrict__ pz = &Ps[0][0][0];
+        for (int i = tid; i < 2 * BK * SH::PP; i += kThreads) pz[i] = 0.0f;
+        __syncthreads();
+    } else {
+        for (int i = tid; i < 2 * BK * PT_PW; i += kThreads) {
+            const int b = i / (BK * PT_PW), r = i - b * (BK * PT_PW);
+            const int ch = r / PT_PW;
+            Ps[b][ch][SH::ZR * PT_PW + (r - ch * PT_PW)] = 0.0f;
+        }
     }
     const int ncb = g.Cin / BK;
     stage_load(0);
@@ -818,11 +831,18 @@ __global__ __launch_bounds__(kThreads, 3) void conv3x3_patch_kernel(const float 
     for (int cb = 0; cb < ncb; ++cb) {
         const float *__restrict__ pbuf = &Ps[cb & 1][0][0] + khalf * 8 * SH::PP;
         const bool more = cb + 1 < ncb;
-        if (more) stage_load(cb + 1);                     // lands while the 288 MFMAs below run
         bload(breg[0], pbuf, 0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);          // the reads of sub-step 0 (keeps the groups below aligned:
+                                                                    // without it every read group slides one sub-step back)
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             if (t < 8) load_a(areg[(t + 1) % 3], t + 1, cb);
+            // the next patch is requested behind the weights of tap 2: the first wait that covers it is the one for
+            // the weights of tap 3, two taps (64 MFMAs) later -- at the top of the block it would sit in front of the
+            // wait for tap 0's weights
+            // (unconditional -- a branch here would make the waits behind it count for the path without the loads;
+            // the last block re-reads its own patch from L2 and drops it)
+            if (t == 1) stage_load(more ? cb + 1 : cb);
 #pragma unroll
             for (int kk = 0; kk < 8; ++kk) {
                 const int step = t * 8 + kk;
@@ -836,6 +856,7 @@ __global__ __launch_bounds__(kThreads, 3) void conv3x3_patch_kernel(const float 
                 acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, breg[step & 1][2], acc[2], 0, 0, 0);
                 acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, breg[step & 1][3], acc[3], 0, 0, 0);
                 if (kk == 0 && t < 8) __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);     // weight loads of tap t+1
+                if (kk == 0 && t == 1) __builtin_amdgcn_sched_group_barrier(0x020, SH::STAGE_LOADS, 0);   // next patch
                 __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);                            // LDS reads of sub-step i+1
                 __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                            // MFMAs of sub-step i
             }
@@ -1565,7 +1586,8 @@ bool use_bm64(int Cout, int P)
 // to there -- C4 of ResNet at batch 4 -- and slower below).
 // Returns 0 (not eligible), 1 (2-D tiles: width a multiple of 16) or 2 (flat tiles: even widths 12..16, e.g. the
 // 14 x 14 RoI maps; 8-byte aligned tensors).
-int patch_eligible(const ConvGeom &g, bool hwc, int weight_layout, const float *y, const float *residual)
+int patch_eligible(const ConvGeom &g, bool hwc, int weight_layout, const float *x, const float *y,
+                   const float *residual)
 {
     if (!(g.R == 3 && g.S == 3 && g.sh == 1 && g.sw == 1 && g.ph == 1 && g.pw == 1)) return 0;
     if (!hwc || weight_layout < 1 || g.Cout <= 64 || g.OH != g.H || g.OW != g.W) return 0;
@@ -1575,7 +1597,8 @@ int patch_eligible(const ConvGeom &g, bool hwc, int weight_layout, const float *
     if (g.W % PT_TW == 0)
         return (long)fi::ceil_div(g.N * g.H, PT_TH) * (g.W / PT_TW) * mt >= 256 ? 1 : 0;
     // flat tiles: 128 consecutive pixels touch at most (W + 126) / W rows, + 2 halo rows <= 13 patch rows
-    if (g.W < 16 && g.W % 2 == 0 && (g.W + 126) / g.W + 2 <= PatchShape<true>::ROWS && (uintptr_t)y % 8 == 0 &&
+    if (g.W < 16 && g.W % 2 == 0 && (g.W + 126) / g.W + 2 <= PatchShape<true>::ROWS && (uintptr_t)x % 8 == 0 &&
+        (uintptr_t)y % 8 == 0 &&
         (residual == nullptr || (uintptr_t)residual % 8 == 0))
         return (long)fi::ceil_div(g.N * g.H * g.W, 128) * mt >= 512 ? 2 : 0;
     return 0;
@@ -2042,7 +2065,7 @@ int fi_conv2d_forward(const float *x, const float *weight, const float *bias, co
     const Epilogue ep = {bias, scale, residual, relu};
     const bool bm64 = use_bm64(Cout, g.P);
     // 3x3 / stride 1 / pad 1 layers with enough tiles to fill the chip: input patch in LDS (conv3x3_patch_kernel)
-    const int patch_mode = getenv("FI_NO_PATCH") ? 0 : patch_eligible(g, hwc, weight_layout, y, residual);
+    const int patch_mode = getenv("FI_NO_PATCH") ? 0 : patch_eligible(g, hwc, weight_layout, x, y, residual);
     // 1x1 / stride 1 layers: weights in registers, pixel tile staged 32 channels at a time (conv1x1_reg_kernel);
     // layers with fewer than 128 input channels are bound by their output stream and measured faster on
     // conv_fwd_kernel (4 workgroups per CU)
