@@ -1301,7 +1301,13 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(const float *__res
 // -------------------------------------------------------------------------------------
 // HALF: Cin == 64 -- a workgroup's 128 columns are the 64 channels of TWO consecutive taps (rows 0..63
 // of the X tile belong to tap t, rows 64..127 to tap t+1), so the C2-stage layers use this kernel too.
-template <int BM, int TR, int TS, bool HALF = false>
+// U16: OW % 16 == 0 -- the 16 pixels of a K-step lie inside ONE row, so image / row / column of the step are
+// wave-uniform: the pixel state advances on the scalar unit, the row halo becomes a scalar select of the load
+// offset and the column halo a fix-up of one element on the 2 steps of a row that touch an edge (uniform
+// branch).  v_mfma and the other vector instructions of a wavefront's SIMD do not overlap (64 extra v_add per
+// K-step cost 8 % on this kernel), so every vector instruction removed from the K loop is MFMA time: the general
+// path spends ~80 of them per 32 MFMAs on per-lane pixel bookkeeping and halo masks, this one ~15.
+template <int BM, int TR, int TS, bool HALF = false, bool U16 = false>
 __global__ __launch_bounds__(kThreads, 4) void conv_wgrad_vec_kernel(const float *__restrict__ x,
                                                                      const float *__restrict__ dy,
                                                                      float *__restrict__ dw, ConvGeom g,
@@ -1362,7 +1368,10 @@ __global__ __launch_bounds__(kThreads, 4) void conv_wgrad_vec_kernel(const float
     const int off_min = (NTAP == 2) ? min(off_t[0], off_t[1]) : off_t[0];
 
     const int lj = tid & 3;                      // which 4 of the step's 16 pixels
-    const int lr = tid >> 2;                     // row 0..63 (+64 per further load)
+    // row 0..63 (+64 per further load).  The 4 lane quads of a 16-lane group take rows 0, 4, 8, 12 (+ group index):
+    // with a pitch of 5 16-byte chunks their ds_write_b128 start at chunks 0, 4, 8, 12 (mod 16) -- all 64 banks once;
+    // consecutive rows would start at 0, 5, 10, 15 and the last quad would run into the first one's banks.
+    const int lr = (wave << 4) | (((tid >> 2) & 3) << 2) | ((tid >> 4) & 3);
     constexpr int A_LOADS = BM / 64;
     constexpr int B_LOADS = BN / 64;
     int a_row4[A_LOADS], b_row4[B_LOADS];        // byte offsets of this thread's rows
@@ -1428,7 +1437,66 @@ __global__ __launch_bounds__(kThreads, 4) void conv_wgrad_vec_kernel(const float
         }
         return mk;
     };
+    // U16 state (uniform -> SGPRs): first pixel of the step, its image / row / column, byte offsets of the step
+    int u_cp = p_begin, u_cq = 0, u_coh = 0, u_cow = 0, u_a = 0, u_b = 0;
+    int a_lane[A_LOADS], b_lane[B_LOADS];        // per-thread part of the load offsets (row + the 4-pixel group)
+    bool u_edge[NTAP];                           // this step's tile has a column-halo element (latched for the store)
+    int u_bl = 0;                                // u_b of the step whose tile is in the registers
+#pragma unroll
+    for (int t = 0; t < NTAP; ++t) u_edge[t] = false;
+    if constexpr (U16) {
+        const int n0 = fast_div(p_begin, g.mul_ohw, g.sft_ohw);
+        u_cq = p_begin - n0 * HW;
+        u_coh = fast_div(u_cq, g.mul_ow, g.sft_ow);
+        u_cow = u_cq - u_coh * g.OW;
+        u_a = (n0 * g.Cout * HW + u_cq) * 4;
+        u_b = (n0 * g.Cin * HW + u_cq) * 4;
+#pragma unroll
+        for (int i = 0; i < A_LOADS; ++i) a_lane[i] = a_row4[i] + 16 * lj;
+#pragma unroll
+        for (int i = 0; i < B_LOADS; ++i) b_lane[i] = b_row4[i] + 16 * lj;
+    }
     auto load_tiles = [&](int pt) {
+        if constexpr (U16) {
+            const bool ok = u_cp < p_end;
+#pragma unroll
+            for (int i = 0; i < A_LOADS; ++i)
+                a_reg[i] = __builtin_amdgcn_raw_buffer_load_b128(dy_rsrc, ok ? a_lane[i] + u_a : kOutOfRange, 0, 0);
+            bool rv[NTAP];                       // the tap's input row exists (else: zeros via an out-of-range offset)
+#pragma unroll
+            for (int t = 0; t < NTAP; ++t) {
+                rv[t] = ok && tap_ok[t] && (unsigned)(u_coh + dr_t[t]) < (unsigned)g.H;
+                u_edge[t] = rv[t] && ((ds_t[t] < 0 && u_cow == 0) || (ds_t[t] > 0 && u_cow == g.OW - BK));
+            }
+            const int b_base = u_b;
+            u_cp += BK;
+            u_cq += BK;
+            u_cow += BK;
+            u_a += BK * 4;
+            u_b += BK * 4;
+            if (u_cow >= g.OW) {
+                u_cow = 0;
+                u_coh += 1;
+            }
+            if (u_cq >= HW) {
+                u_cq -= HW;
+                u_coh = 0;
+                u_a += a_wrap;
+                u_b += b_wrap;
+            }
+            // The only negative offset of a valid row: tap (0, -1) at the first pixel of the tensor (-4 bytes; a
+            // negative offset would zero all 16 bytes).  That group is loaded from offset 0 instead and shifted by one
+            // element when the tile is stored (it is a column-halo step: the fix-up branch below runs anyway).
+            u_bl = b_base;
+#pragma unroll
+            for (int i = 0; i < B_LOADS; ++i) {
+                const int t = HALF ? i : 0;
+                int o = b_base + off_t[t] * 4 + b_lane[i];
+                if (neg_block) o = max(o, 0);
+                b_reg[i] = __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, rv[t] ? o : kOutOfRange, 0, 0);
+            }
+            return;
+        }
         const bool ok = cp < p_end;
         const int a_off = ok ? a_cur : kOutOfRange;
 #pragma unroll
@@ -1479,28 +1547,50 @@ __global__ __launch_bounds__(kThreads, 4) void conv_wgrad_vec_kernel(const float
         }
     };
     const bool do_bias = dbias != nullptr && bx == 0;      // see conv_wgrad_kernel
-    float bsum[A_LOADS];
+    f32x4_v bsum[A_LOADS];                                 // per 4-pixel group element: two v_pk_add_f32 per load
 #pragma unroll
-    for (int i = 0; i < A_LOADS; ++i) bsum[i] = 0.0f;
+    for (int i = 0; i < A_LOADS; ++i) bsum[i] = f32x4_v{0.0f, 0.0f, 0.0f, 0.0f};
     auto store_tiles = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < A_LOADS; ++i) {
             *reinterpret_cast<u32x4 *>(&As[buf][lr + 64 * i][4 * lj]) = a_reg[i];
-            if (do_bias)
-                bsum[i] += (__uint_as_float(a_reg[i].x) + __uint_as_float(a_reg[i].y)) +
-                           (__uint_as_float(a_reg[i].z) + __uint_as_float(a_reg[i].w));
+            if (do_bias) {
+                asm volatile("");                    // keep this a (uniform) branch: if-converted, every launch pays for it
+                bsum[i] += __builtin_bit_cast(f32x4_v, a_reg[i]);
+            }
         }
 #pragma unroll
         for (int i = 0; i < B_LOADS; ++i) {
-            u32x4 v = b_reg[i];
-            if (!k1x1) {               // a 1x1 tile has no halo: an invalid group was loaded as zeros
-                const unsigned mk = b_mask[HALF ? i : 0];
-                v.x = (mk & 1u) ? v.x : 0u;
-                v.y = (mk & 2u) ? v.y : 0u;
-                v.z = (mk & 4u) ? v.z : 0u;
-                v.w = (mk & 8u) ? v.w : 0u;
+            if constexpr (U16) {
+                // rows outside the image were loaded as zeros.  The element beside the map (2 steps of a row) is
+                // zeroed in LDS behind the thread's own 16-byte store -- patching the registers instead would put a
+                // copy of the tile on the common path.
+                const int t = HALF ? i : 0;
+                float *__restrict__ dst = &Bs[buf][lr + 64 * i][4 * lj];
+                *reinterpret_cast<u32x4 *>(dst) = b_reg[i];
+                if (!k1x1 && u_edge[t]) {
+                    if (ds_t[t] < 0) {
+                        if (neg_block && u_bl + off_t[t] * 4 + b_lane[i] < 0) {       // loaded one element to the right
+                            dst[3] = __uint_as_float(b_reg[i].z);
+                            dst[2] = __uint_as_float(b_reg[i].y);
+                            dst[1] = __uint_as_float(b_reg[i].x);
+                        }
+                        if (lj == 0) dst[0] = 0.0f;
+                    } else if (lj == 3) {
+                        dst[3] = 0.0f;
+                    }
+                }
+            } else {
+                u32x4 v = b_reg[i];
+                if (!k1x1) {           // a 1x1 tile has no halo: an invalid group was loaded as zeros
+                    const unsigned mk = b_mask[HALF ? i : 0];
+                    v.x = (mk & 1u) ? v.x : 0u;
+                    v.y = (mk & 2u) ? v.y : 0u;
+                    v.z = (mk & 4u) ? v.z : 0u;
+                    v.w = (mk & 8u) ? v.w : 0u;
+                }
+                *reinterpret_cast<u32x4 *>(&Bs[buf][lr + 64 * i][4 * lj]) = v;
             }
-            *reinterpret_cast<u32x4 *>(&Bs[buf][lr + 64 * i][4 * lj]) = v;
         }
     };
 
@@ -1563,7 +1653,7 @@ __global__ __launch_bounds__(kThreads, 4) void conv_wgrad_vec_kernel(const float
     if (do_bias) {                 // the 4 lanes that share `lr` hold the 16 pixels of a K-step
 #pragma unroll
         for (int i = 0; i < A_LOADS; ++i) {
-            float v = bsum[i];
+            float v = (bsum[i].x + bsum[i].y) + (bsum[i].z + bsum[i].w);
             v += __shfl_xor(v, 1, 64);
             v += __shfl_xor(v, 2, 64);
             const int m = m0 + lr + 64 * i;
@@ -1763,9 +1853,15 @@ void launch_wgrad(const ConvGeom &g, const float *x, const float *dy, float *dw,
     const bool same = wgrad_same_size(g, x, dy);
     if (hwc && same && g.Cin == 64) {            // two taps per 128-column tile
         if (g.R == 3 && g.S == 3)
-            hipLaunchKernelGGL((conv_wgrad_vec_kernel<BM, 3, 3, true>), grid, dim3(kThreads), 0, st, x, dy, dw, g, p_per_split, dbias);
+            if (g.OW % BK == 0)
+                hipLaunchKernelGGL((conv_wgrad_vec_kernel<BM, 3, 3, true, true>), grid, dim3(kThreads), 0, st, x, dy, dw, g, p_per_split, dbias);
+            else
+                hipLaunchKernelGGL((conv_wgrad_vec_kernel<BM, 3, 3, true>), grid, dim3(kThreads), 0, st, x, dy, dw, g, p_per_split, dbias);
         else if (g.R == 1 && g.S == 1)
-            hipLaunchKernelGGL((conv_wgrad_vec_kernel<BM, 1, 1, true>), grid, dim3(kThreads), 0, st, x, dy, dw, g, p_per_split, dbias);
+            if (g.OW % BK == 0)
+                hipLaunchKernelGGL((conv_wgrad_vec_kernel<BM, 1, 1, true, true>), grid, dim3(kThreads), 0, st, x, dy, dw, g, p_per_split, dbias);
+            else
+                hipLaunchKernelGGL((conv_wgrad_vec_kernel<BM, 1, 1, true>), grid, dim3(kThreads), 0, st, x, dy, dw, g, p_per_split, dbias);
         else
             hipLaunchKernelGGL((conv_wgrad_vec_kernel<BM, 0, 0, true>), grid, dim3(kThreads), 0, st, x, dy, dw, g, p_per_split, dbias);
         return;
@@ -1780,9 +1876,15 @@ void launch_wgrad(const ConvGeom &g, const float *x, const float *dy, float *dw,
             vgrid = dim3((unsigned)(((nblk + 7) / 8) * 8), 1, 1);
         }
         if (g.R == 3 && g.S == 3)
-            hipLaunchKernelGGL((conv_wgrad_vec_kernel<BM, 3, 3>), vgrid, dim3(kThreads), 0, st, x, dy, dw, gs, p_per_split, dbias);
+            if (g.OW % BK == 0)
+                hipLaunchKernelGGL((conv_wgrad_vec_kernel<BM, 3, 3, false, true>), vgrid, dim3(kThreads), 0, st, x, dy, dw, gs, p_per_split, dbias);
+            else
+                hipLaunchKernelGGL((conv_wgrad_vec_kernel<BM, 3, 3>), vgrid, dim3(kThreads), 0, st, x, dy, dw, gs, p_per_split, dbias);
         else if (g.R == 1 && g.S == 1)
-            hipLaunchKernelGGL((conv_wgrad_vec_kernel<BM, 1, 1>), vgrid, dim3(kThreads), 0, st, x, dy, dw, gs, p_per_split, dbias);
+            if (g.OW % BK == 0)
+                hipLaunchKernelGGL((conv_wgrad_vec_kernel<BM, 1, 1, false, true>), vgrid, dim3(kThreads), 0, st, x, dy, dw, gs, p_per_split, dbias);
+            else
+                hipLaunchKernelGGL((conv_wgrad_vec_kernel<BM, 1, 1>), vgrid, dim3(kThreads), 0, st, x, dy, dw, gs, p_per_split, dbias);
         else
             hipLaunchKernelGGL((conv_wgrad_vec_kernel<BM, 0, 0>), vgrid, dim3(kThreads), 0, st, x, dy, dw, gs, p_per_split, dbias);
         return;
