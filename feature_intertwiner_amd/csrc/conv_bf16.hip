@@ -458,6 +458,9 @@ constexpr int PB_ROWS = PB_TH + 2;
 constexpr int PB_NSLOT = (PB_ROWS + 1) * PB_RP; // + one row of zeros
 constexpr int PB_CB = 32;                       // channels per stage = 4 groups of 8
 
+// staging loads of threads whose patch group lies outside the image are redirected here (no branch around the loads)
+__device__ __attribute__((aligned(16))) float g_zero_quad[4];
+
 struct PatchGeomB {
     int N, Cin, H, W, Cout;
     int flip, tiles_x, ptiles, mtiles;
@@ -533,21 +536,21 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_patch_bf16_kernel(const f
     const int s_n = s_ok ? s_Ys / g.H : 0;
     const size_t s_off = ((size_t)s_n * g.Cin + s_kg * 8) * HW + (s_ok ? (size_t)(s_Ys - s_n * g.H) * g.W + s_xx : 0);
     f32x4 sr0, sr1, sr2, sr3, sr4, sr5, sr6, sr7;
+    // Branch-free: a group outside the image reads the 16 zero bytes of g_zero_quad eight times (channel stride 0).
+    // With a branch around the loads the compiler kept the eight registers in scratch and waited for the loads at
+    // the join, i.e. at the top of every channel block.
+    const float *__restrict__ s_base = s_ok ? x + s_off : g_zero_quad;
+    const size_t s_cs = s_ok ? HW : 0;                     // channel stride
     auto stage_load = [&](int cb) {
-        if (!s_ok) {
-            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            sr0 = sr1 = sr2 = sr3 = sr4 = sr5 = sr6 = sr7 = z;
-            return;
-        }
-        const float *__restrict__ p = x + s_off + (size_t)cb * PB_CB * HW;
+        const float *__restrict__ p = s_base + (size_t)cb * PB_CB * s_cs;
         sr0 = *reinterpret_cast<const f32x4 *>(p);
-        sr1 = *reinterpret_cast<const f32x4 *>(p + HW);
-        sr2 = *reinterpret_cast<const f32x4 *>(p + 2 * HW);
-        sr3 = *reinterpret_cast<const f32x4 *>(p + 3 * HW);
-        sr4 = *reinterpret_cast<const f32x4 *>(p + 4 * HW);
-        sr5 = *reinterpret_cast<const f32x4 *>(p + 5 * HW);
-        sr6 = *reinterpret_cast<const f32x4 *>(p + 6 * HW);
-        sr7 = *reinterpret_cast<const f32x4 *>(p + 7 * HW);
+        sr1 = *reinterpret_cast<const f32x4 *>(p + s_cs);
+        sr2 = *reinterpret_cast<const f32x4 *>(p + 2 * s_cs);
+        sr3 = *reinterpret_cast<const f32x4 *>(p + 3 * s_cs);
+        sr4 = *reinterpret_cast<const f32x4 *>(p + 4 * s_cs);
+        sr5 = *reinterpret_cast<const f32x4 *>(p + 5 * s_cs);
+        sr6 = *reinterpret_cast<const f32x4 *>(p + 6 * s_cs);
+        sr7 = *reinterpret_cast<const f32x4 *>(p + 7 * s_cs);
     };
     auto stage_store = [&](int buf) {
         if (!s_item) return;
@@ -598,7 +601,6 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_patch_bf16_kernel(const f
     for (int cb = 0; cb < ncb; ++cb) {
         const bf16x8 *__restrict__ pbuf = &Ps[cb & 1][khalf][0];           // k-step ks adds 2 channel groups
         const bool more = cb + 1 < ncb;
-        if (more) stage_load(cb + 1);
         auto bload = [&](bf16x8 (&bv)[4], int r_, int s_, int ks) {
             const bf16x8 *__restrict__ bp = pbuf + ks * 2 * PB_NSLOT + rowslot[r_];
 #pragma unroll
@@ -616,6 +618,9 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_patch_bf16_kernel(const f
                 else
                     load_a_raw(araw[(t + 2) % 3], tap2, cb2);
             }
+            // the next patch is requested behind the weights of tap 2 (no wait covers it before the one for tap 3's
+            // weights), unconditionally: the last stage re-reads its own patch and drops it
+            if (t == 0) stage_load(more ? cb + 1 : cb);
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 const int step = t * 2 + ks;
@@ -636,6 +641,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_patch_bf16_kernel(const f
             // issue order of this tap: weight loads of tap t+2, then per k-step the LDS reads of the next sub-step
             // ahead of the 4 MFMAs, then the packs of tap t+1 (left alone the compiler sinks the loads to their use)
             if (ld) __builtin_amdgcn_sched_group_barrier(0x020, WB16 ? 2 : 4, 0);
+            if (t == 0) __builtin_amdgcn_sched_group_barrier(0x020, 8, 0);
             __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
             if (t < 8) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
