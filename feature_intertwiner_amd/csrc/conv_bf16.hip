@@ -1043,6 +1043,228 @@ __global__ __launch_bounds__(kThreads, 2) void conv_bf16_wgrad_kernel(const floa
     (void)TQ;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Weight gradient of same-size stride-1 layers (3x3 / pad 1 and 1x1): FLAT pixel space, 64-pixel K-tiles.
+//
+// conv_bf16_wgrad_kernel above spends ~50 vector instructions per MFMA (dynamic register shifts for the tap
+// column, quad geometry with clamps, per-element picks), and on CDNA4 a wavefront's v_mfma and its other vector
+// instructions do not overlap: it runs at 8 % of the bf16 peak.  For the layers that carry the time the input
+// pixel of tap (r, s) is simply q + (r-1)*W + (s-1) for output pixel q of the same image, so 4 consecutive output
+// pixels read 4 consecutive input floats -- across row ends too: ONE (4-byte aligned) 16-byte buffer load per
+// group, no shift.  What is left per thread and 64-pixel tile: 16 loads, 32 v_cvt_pk, 16 ds_write_b64 and ~40
+// instructions of pixel bookkeeping against 16 MFMAs (512 cycles) per wavefront.  Halo elements are zeroed on a
+// divergent path that only wavefronts with a row end inside their tile take.  The pixel axis is the plain
+// (n, y, x) order (requires H*W % 4 == 0 so that a group never straddles two images), i.e. no padded pixels.
+// ------------------------------------------------------------------------------------------------
+constexpr int FK = 64;             // pixels per K-tile: 4 MFMA k-steps of 16
+constexpr int FLP = FK + 8;        // LDS row pitch in bf16 (144 B = 9 16-byte chunks: 16 rows cover all banks once)
+
+template <int BM, int BNC, bool K3>
+__global__ __launch_bounds__(kThreads, 2) void conv_bf16_wgrad_flat_kernel(const float *__restrict__ x,
+                                                                           const float *__restrict__ dy,
+                                                                           float *__restrict__ dw, Geom g, int cin_tiles,
+                                                                           int p_per_split, int mtiles, int splits)
+{
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    constexpr int MT = BM / 64, NT = BNC / 64;
+    constexpr int AV = BM / 16, BV = BNC / 16;          // row passes of the loaders: thread = (group tid & 15, row tid >> 4)
+    __shared__ __align__(16) __bf16 As[2][BM][FLP];      // dY  [cout][pixel]
+    __shared__ __align__(16) __bf16 Bs[2][BNC][FLP];     // X   [ci][pixel]   (one tap)
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int RS = K3 ? 9 : 1;
+    const int HW = g.H * g.W;
+
+    // XCD-aware order (1-D launch, workgroup b runs on XCD b % 8): the workgroups, sorted by (pixel split, tile),
+    // are cut into 8 contiguous bands.  All (tap, ci tile, cout tile) workgroups of a split walk the same dY / X
+    // ranges, so a split is fetched into ONE L2 and re-read there (plain order: 36 tiles of a split on 8 XCDs,
+    // 9.8 GB of operand reads per launch on the P2-level layers -- the kernel ran at the Infinity-Cache rate).
+    const int tiles_per_split = mtiles * RS * cin_tiles;
+    const int nblk = tiles_per_split * splits;
+    const int per_xcd = (nblk + 7) >> 3;
+    const int idx = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (idx >= nblk) return;
+    const int bz = idx / tiles_per_split;
+    const int tl = idx - bz * tiles_per_split;
+    const int by = tl / mtiles, bx = tl - by * mtiles;
+    const int m0 = bx * BM;
+    const int tap = by / cin_tiles;
+    const int ci0 = (by - tap * cin_tiles) * BNC;
+    const int dr = K3 ? tap / 3 - 1 : 0, ds = K3 ? tap - (tap / 3) * 3 - 1 : 0;
+    const int off = dr * g.W + ds;
+    const int p_begin = bz * p_per_split;
+    const int p_end = min(g.P, p_begin + p_per_split);
+    if (p_begin >= p_end) return;
+
+    const int gq = tid & 15, lr = tid >> 4;
+    const __amdgpu_buffer_rsrc_t dy_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(dy), 0, (int)((size_t)g.N * g.Cout * HW * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(x), 0, (int)((size_t)g.N * g.Cin * HW * 4), 0x00020000);
+    const int kOutOfRange = 0x7ffffff0;
+    const int rs16 = 16 * HW * 4;                       // byte distance of two row passes
+    // a NEGATIVE offset would zero the whole 16 bytes: the few groups in front of the tensor (first rows of the first
+    // image, channel 0) are loaded from offset 0 and shifted when the tile is stored
+    const bool neg_block = ci0 == 0 && off < 0;
+    const int o_floor = neg_block ? 0 : (int)0x80000000;
+
+    // pixel state of the thread's group, advanced by 64 pixels per tile with adds and compares
+    int cp = p_begin + 4 * gq;
+    int cq, coh, cow, a_cur, b_cur;
+    {
+        const int cn = cp / HW;
+        cq = cp - cn * HW;
+        coh = cq / g.W;
+        cow = cq - coh * g.W;
+        a_cur = (cn * g.Cout * HW + cq + (m0 + lr) * HW) * 4;
+        b_cur = (cn * g.Cin * HW + cq + (ci0 + lr) * HW + off) * 4;
+    }
+    const int adv_h = FK / g.W, adv_w = FK - adv_h * g.W;
+    const int a_wrap = (g.Cout - 1) * HW * 4, b_wrap = (g.Cin - 1) * HW * 4;
+
+    struct Regs {
+        u32x4 a[AV], b[BV];
+        unsigned mk;       // validity of the 4 elements of the X group (tap halo, pixel range)
+        int bo;            // unclamped offset of the X group in row pass 0
+    };
+    auto load_tile = [&](Regs &R) {
+        const bool ok = cp < p_end;
+        unsigned mk = 0xFu;
+        if (K3) {
+            const int wrap = g.W - cow;                        // elements e >= wrap sit on the next row
+            const unsigned low = wrap >= 4 ? 0xFu : ((1u << wrap) - 1u);
+            const bool row0 = (unsigned)(coh + dr) < (unsigned)g.H;
+            const bool row1 = (unsigned)(coh + 1 + dr) < (unsigned)g.H;
+            mk = (row0 ? low : 0u) | (row1 ? (0xFu & ~low) : 0u);
+            if (ds < 0) {                                      // the element in column 0 has no left neighbour
+                const unsigned kill = (cow == 0) ? 1u : (wrap < 4 ? (1u << wrap) : 0u);
+                mk &= ~kill;
+            } else if (ds > 0) {                               // the element in column W-1 has no right neighbour
+                const int e1 = g.W - 1 - cow;
+                mk &= ~(e1 < 4 ? (1u << e1) : 0u);
+            }
+        }
+        mk = ok ? mk : 0u;
+        // dY needs no validity test: a tile only runs past p_end in the last split, where p_end == P and the offsets
+        // of pixels >= P lie behind the tensor (the buffer returns zeros)
+#pragma unroll
+        for (int i = 0; i < AV; ++i) R.a[i] = __builtin_amdgcn_raw_buffer_load_b128(dy_rsrc, a_cur + i * rs16, 0, 0);
+        const int b0 = mk ? max(b_cur, o_floor) : kOutOfRange;
+        const int bi = mk ? b_cur : kOutOfRange;
+        R.b[0] = __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, b0, 0, 0);
+#pragma unroll
+        for (int i = 1; i < BV; ++i) R.b[i] = __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, bi + i * rs16, 0, 0);
+        R.mk = mk;
+        R.bo = b_cur;
+        cp += FK;
+        cq += FK;
+        cow += adv_w;
+        coh += adv_h;
+        a_cur += FK * 4;
+        b_cur += FK * 4;
+        if (cow >= g.W) {
+            cow -= g.W;
+            coh += 1;
+        }
+        if (cq >= HW) {                                        // H*W >= 64: at most one image boundary per tile
+            cq -= HW;
+            coh -= g.H;
+            a_cur += a_wrap;
+            b_cur += b_wrap;
+        }
+    };
+    auto cvt4 = [](const u32x4 &v) {
+        bf16x4 o;
+        o[0] = (__bf16)__uint_as_float(v.x);
+        o[1] = (__bf16)__uint_as_float(v.y);
+        o[2] = (__bf16)__uint_as_float(v.z);
+        o[3] = (__bf16)__uint_as_float(v.w);
+        return o;
+    };
+    auto store_tile = [&](int buf, Regs &R) {
+#pragma unroll
+        for (int i = 0; i < AV; ++i) *reinterpret_cast<bf16x4 *>(&As[buf][lr + 16 * i][4 * gq]) = cvt4(R.a[i]);
+        if (K3 && R.mk != 0xFu) {                               // a row end / image edge inside the group: rare
+            const unsigned mk = R.mk;
+            if (neg_block && R.bo < 0 && R.bo > -16) {          // loaded from offset 0: element e holds x[e], wanted x[e - k]
+                const int k = (-R.bo) >> 2;                    // 1..3
+                const u32x4 v = R.b[0];
+                u32x4 t;
+                t.x = 0u;
+                t.y = k == 1 ? v.x : 0u;
+                t.z = k == 1 ? v.y : (k == 2 ? v.x : 0u);
+                t.w = k == 1 ? v.z : (k == 2 ? v.y : v.x);
+                R.b[0] = t;
+            }
+#pragma unroll
+            for (int i = 0; i < BV; ++i) {
+                R.b[i].x = (mk & 1u) ? R.b[i].x : 0u;
+                R.b[i].y = (mk & 2u) ? R.b[i].y : 0u;
+                R.b[i].z = (mk & 4u) ? R.b[i].z : 0u;
+                R.b[i].w = (mk & 8u) ? R.b[i].w : 0u;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < BV; ++i) *reinterpret_cast<bf16x4 *>(&Bs[buf][lr + 16 * i][4 * gq]) = cvt4(R.b[i]);
+    };
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+    auto mma = [&](int cur) {
+#pragma unroll
+        for (int ks = 0; ks < FK / 16; ++ks) {
+            bf16x8 af[MT], bfr[NT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+                af[i] = *reinterpret_cast<const bf16x8 *>(&As[cur][wm * (BM / 2) + i * 32 + l31][ks * 16 + lh * 8]);
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+                bfr[j] = *reinterpret_cast<const bf16x8 *>(&Bs[cur][wn * (BNC / 2) + j * 32 + l31][ks * 16 + lh * 8]);
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    const int tiles = (p_end - p_begin + FK - 1) / FK;
+    Regs R;
+    load_tile(R);
+    store_tile(0, R);
+    __syncthreads();
+    for (int t = 0; t < tiles; ++t) {
+        const int cur = t & 1;
+        if (t + 1 < tiles) load_tile(R);
+        mma(cur);
+        if (t + 1 < tiles) store_tile(cur ^ 1, R);
+        __syncthreads();
+    }
+
+    // dW[m][tap][ci]: lanes run over ci (contiguous) -> coalesced fp32 atomics
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int ci = ci0 + wn * (BNC / 2) + j * 32 + l31;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int mb = m0 + wm * (BM / 2) + i * 32 + 4 * lh;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = mb + (e & 3) + 8 * (e >> 2);
+                atomicAdd(dw + ((size_t)m * RS + tap) * g.Cin + ci, acc[i][j][e]);
+            }
+        }
+    }
+}
+
 int make_geom(Geom &g, int N, int Cin, int H, int W, int Cout, int R, int S, int sh, int sw, int ph, int pw,
               int out_h, int out_w)
 {
@@ -1166,6 +1388,37 @@ int fi_conv2d_weight_grad_bf16(const float *x, const float *dy, float *dweight, 
         FI_HIP_CHECK(hipMemsetAsync(dweight, 0, sizeof(float) * (size_t)Cout * RS * Cin, st));
     const int OHW = g.OH * g.OW;
     fi::ProfScope prof(FI_K_CONV_BF16_WGRAD, st);
+    // same-size stride-1 layers with whole channel tiles: flat pixel space (conv_bf16_wgrad_flat_kernel)
+    {
+        const bool k3 = R == 3 && S == 3 && pad_h == 1 && pad_w == 1, k1 = R == 1 && S == 1 && pad_h == 0 && pad_w == 0;
+        const int HWf = H * W;
+        const int bm = Cout % 128 == 0 ? 128 : (Cout % 64 == 0 ? 64 : 0), bnc = Cin % 128 == 0 ? 128 : (Cin % 64 == 0 ? 64 : 0);
+        if ((k3 || k1) && stride_h == 1 && stride_w == 1 && g.OH == H && g.OW == W && HWf % 4 == 0 && HWf >= FK && W >= 4 &&
+            bm && bnc && (size_t)N * Cin * HWf * 4 < 0x7fffff00ULL && (size_t)N * Cout * HWf * 4 < 0x7fffff00ULL &&
+            (uintptr_t)x % 16 == 0 && (uintptr_t)dy % 16 == 0 && !getenv("FI_NO_BF16_FLAT")) {
+            const int mt = Cout / bm, cin_tiles = Cin / bnc;
+            const long tiles = (long)mt * RS * cin_tiles;
+            const int ptiles = fi::ceil_div(g.P, FK);
+            // split the pixel range so that ~2048 workgroups exist, at least 8 K-tiles each
+            long z = 2048 / tiles;
+            if (z < 1) z = 1;
+            if (z > ptiles / 8) z = ptiles / 8 > 0 ? ptiles / 8 : 1;
+            if (z > 65535) z = 65535;
+            const int per = fi::ceil_div(ptiles, (int)z);
+            z = fi::ceil_div(ptiles, per);
+            FI_REQUIRE((long)RS * cin_tiles <= 65535, "too many (tap, ci) tiles");
+            const long nblk = tiles * z;
+            FI_REQUIRE(nblk + 8 < 2147483647L, "too many workgroups");
+            const dim3 grid((unsigned)(((nblk + 7) / 8) * 8));
+            auto k = k3 ? (bm == 128 ? (bnc == 128 ? conv_bf16_wgrad_flat_kernel<128, 128, true> : conv_bf16_wgrad_flat_kernel<128, 64, true>)
+                                     : (bnc == 128 ? conv_bf16_wgrad_flat_kernel<64, 128, true> : conv_bf16_wgrad_flat_kernel<64, 64, true>))
+                        : (bm == 128 ? (bnc == 128 ? conv_bf16_wgrad_flat_kernel<128, 128, false> : conv_bf16_wgrad_flat_kernel<128, 64, false>)
+                                     : (bnc == 128 ? conv_bf16_wgrad_flat_kernel<64, 128, false> : conv_bf16_wgrad_flat_kernel<64, 64, false>));
+            hipLaunchKernelGGL(k, grid, dim3(kThreads), 0, st, x, dy, dweight, g, cin_tiles, per * FK, mt, (int)z);
+            FI_HIP_CHECK(hipGetLastError());
+            return FI_OK;
+        }
+    }
     if ((stride_w == 1 || stride_w == 2) && g.OW >= 4 && W >= 4 * stride_w) {
         const int bm = Cout <= 64 ? 64 : 128, bnc = Cin <= 64 ? 64 : 128;
         const int mt = fi::ceil_div(Cout, bm), cin_tiles = fi::ceil_div(Cin, bnc);
