@@ -109,11 +109,15 @@ def _conv_fwd(x, w, b, stride, padding, relu=False, scale=None, residual=None, o
     fn = L.fi_conv2d_forward_bf16 if bf16 else L.fi_conv2d_forward
     if bf16:
         _log_flops("bf16_fwd", Cout, R, S, 2 * N * Cout * OH * OW * Cin * R * S)
-        # 3x3 / stride 1 / pad 1 on maps whose width is a multiple of 16: patch kernel with the weights converted to
-        # bf16 once per step (cached like W^T) instead of inside every workgroup
+        # 3x3 / stride 1 / pad 1 on maps whose width is a multiple of 16 (or 14-wide RoI maps): patch kernel with the
+        # weights converted to bf16 once per step (cached like W^T) instead of inside every workgroup
+        mt = (Cout + 127) // 128
+        tiled = W % 16 == 0 and ((N * H + 7) // 8) * (W // 16) * mt >= 256
+        # flat 128-pixel tiles for the 14 x 14 RoI maps (even widths below 16)
+        flat = W % 16 != 0 and W < 16 and W % 2 == 0 and (W + 126) // W + 2 <= 13 and \
+            ((N * H * W + 127) // 128) * mt >= 512
         if (R, S) == (3, 3) and tuple(stride) == (1, 1) and tuple(padding) == (1, 1) and (OH, OW) == (H, W) and \
-                W % 16 == 0 and Cout > 64 and not out_channels_last and out_hw is None and \
-                ((N * H + 7) // 8) * (W // 16) * ((Cout + 127) // 128) >= 256 and \
+                (tiled or flat) and Cout > 64 and not out_channels_last and out_hw is None and \
                 (residual is None or residual.data_ptr() % 16 == 0):
             wb = _cached_bf16(w)
             with torch.cuda.device(x.device):

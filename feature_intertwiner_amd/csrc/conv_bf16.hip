@@ -22,6 +22,8 @@
 //   is split across workgroups and accumulated with fp32 atomics (as the fp32 kernel does).
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "fi_common.h"
 
 namespace {
@@ -456,6 +458,10 @@ constexpr int PB_TH = 8, PB_TW = 16;
 constexpr int PB_RP = 28;                       // slots per patch row (24 used)
 constexpr int PB_ROWS = PB_TH + 2;
 constexpr int PB_NSLOT = (PB_ROWS + 1) * PB_RP; // + one row of zeros
+// FLAT tiles (maps of 12..16 columns, e.g. the 14 x 14 RoI maps -- see conv3x3_patch_kernel<true> in conv_igemm.hip):
+// a tile is 128 CONSECUTIVE pixels of the flattened (stacked row, column) space; up to 11 rows + halo
+constexpr int PB_ROWS_FLAT = 13;
+constexpr int PB_NSLOT_FLAT = (PB_ROWS_FLAT + 1) * PB_RP;
 constexpr int PB_CB = 32;                       // channels per stage = 4 groups of 8
 
 // staging loads of threads whose patch group lies outside the image are redirected here (no branch around the loads)
@@ -477,22 +483,27 @@ __device__ __forceinline__ bf16x8 pack8(const f32x4 &lo, const f32x4 &hi)
 // WB16: the weights are already bf16 (pre-converted once per step by the caller): a lane's A-operand is ONE 16-byte
 // load per (tap, k-step), no packing.  With fp32 weights every wavefront streams 37 KB of weights per 32 channels
 // from L2 -- 8 wavefronts of a CU ask for more than the L2->L1 path delivers at the bf16 MFMA rate.
-template <bool WB16>
+template <bool WB16, bool FLAT = false>
 __global__ __launch_bounds__(kThreads, 2) void conv3x3_patch_bf16_kernel(const float *__restrict__ x,
                                                                         const void *__restrict__ wv, Epi ep,
                                                                         float *__restrict__ y, PatchGeomB g)
 {
+    constexpr int ROWS = FLAT ? PB_ROWS_FLAT : PB_ROWS;
+    constexpr int NSLOT = FLAT ? PB_NSLOT_FLAT : PB_NSLOT;
+    constexpr int SGRP = FLAT ? 4 : 6;            // staged 4-column groups per patch row (flat: columns 0..15 only)
     const float *__restrict__ w = static_cast<const float *>(wv);
     const __bf16 *__restrict__ wb = static_cast<const __bf16 *>(wv);
-    __shared__ __align__(16) bf16x8 Ps[2][PB_CB / 8][PB_NSLOT];
+    __shared__ __align__(16) bf16x8 Ps[2][PB_CB / 8][NSLOT];
 
     const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
     const int per_xcd = (g.ptiles + 7) >> 3;
     const int mt = local % g.mtiles;
     const int pt = xcd * per_xcd + local / g.mtiles;
     if (pt >= g.ptiles) return;
-    const int tile_y = pt / g.tiles_x, tile_x = pt - tile_y * g.tiles_x;
-    const int Y0 = tile_y * PB_TH, X0 = tile_x * PB_TW, m0 = mt * 128;
+    const int tile_y = FLAT ? 0 : pt / g.tiles_x, tile_x = FLAT ? 0 : pt - tile_y * g.tiles_x;
+    // 2-D: first stacked row / column of the tile.  Flat: stacked row of the tile's first pixel; the patch always
+    // starts at image column -4
+    const int Y0 = FLAT ? (pt * 128) / g.W : tile_y * PB_TH, X0 = FLAT ? 0 : tile_x * PB_TW, m0 = mt * 128;
     const int NH = g.N * g.H;
     const size_t HW = (size_t)g.H * g.W;
 
@@ -525,16 +536,41 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_patch_bf16_kernel(const f
     rowslot[0] = (yo != 0 ? ty : PB_ROWS) * PB_RP + q;
     rowslot[1] = (ty + 1) * PB_RP + q;
     rowslot[2] = (yo != g.H - 1 ? ty + 2 : PB_ROWS) * PB_RP + q;
+    // flat: the lane's 4 pixels may sit on two rows -> one slot per (kernel row, kernel column, pixel)
+    int fslot[FLAT ? 3 : 1][FLAT ? 3 : 1][FLAT ? 4 : 1];
+    int fY[4], fx[4];
+    if constexpr (FLAT) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int p = pt * 128 + 4 * l31 + j;
+            fY[j] = p / g.W;
+            fx[j] = p - fY[j] * g.W;
+            const int yj = fY[j] - (fY[j] / g.H) * g.H;
+            const int pr = fY[j] - Y0 + 1;                         // patch row of the pixel's own row
+#pragma unroll
+            for (int r_ = 0; r_ < 3; ++r_) {
+                const int prow = r_ == 0 ? (yj != 0 ? pr - 1 : ROWS) : (r_ == 1 ? pr : (yj != g.H - 1 ? pr + 1 : ROWS));
+#pragma unroll
+                for (int s_ = 0; s_ < 3; ++s_) {
+                    const int c = fx[j] + s_ + 3;                  // patch column (column 0 = image column -4)
+                    fslot[r_][s_][j] = prow * PB_RP + (c & 3) * 6 + (c >> 2);
+                }
+            }
+        }
+    }
 
     // ---- staging: thread = (channel group of 8, patch row, 4 columns) -----------------------------------
-    const bool s_item = tid < (PB_CB / 8) * PB_ROWS * 6;
-    const int s_kg = tid / (PB_ROWS * 6);
-    const int s_rem = tid - s_kg * (PB_ROWS * 6);
-    const int s_prow = s_rem / 6, s_grp = s_rem - s_prow * 6;
+    const bool s_item = tid < (PB_CB / 8) * ROWS * SGRP;
+    const int s_kg = tid / (ROWS * SGRP);
+    const int s_rem = tid - s_kg * (ROWS * SGRP);
+    const int s_prow = s_rem / SGRP, s_grp = s_rem - s_prow * SGRP + (FLAT ? 1 : 0);
     const int s_Ys = Y0 - 1 + s_prow, s_xx = X0 - 4 + s_grp * 4;
-    const bool s_ok = s_item && s_Ys >= 0 && s_Ys < NH && s_xx >= 0 && s_xx + 3 < g.W;   // W % 16 == 0: whole groups
+    // 2-D (W % 16 == 0): whole groups.  Flat (W even): a group that hangs over the row end by 2 columns is loaded 2
+    // columns to the left (inside the row) and moved into place when it is stored
+    const int s_sh = FLAT && s_xx < g.W && s_xx + 3 >= g.W ? s_xx + 4 - g.W : 0;
+    const bool s_ok = s_item && s_Ys >= 0 && s_Ys < NH && s_xx >= 0 && s_xx < g.W;
     const int s_n = s_ok ? s_Ys / g.H : 0;
-    const size_t s_off = ((size_t)s_n * g.Cin + s_kg * 8) * HW + (s_ok ? (size_t)(s_Ys - s_n * g.H) * g.W + s_xx : 0);
+    const size_t s_off = ((size_t)s_n * g.Cin + s_kg * 8) * HW + (s_ok ? (size_t)(s_Ys - s_n * g.H) * g.W + s_xx - s_sh : 0);
     f32x4 sr0, sr1, sr2, sr3, sr4, sr5, sr6, sr7;
     // Branch-free: a group outside the image reads the 16 zero bytes of g_zero_quad eight times (channel stride 0).
     // With a branch around the loads the compiler kept the eight registers in scratch and waited for the loads at
@@ -543,17 +579,22 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_patch_bf16_kernel(const f
     const size_t s_cs = s_ok ? HW : 0;                     // channel stride
     auto stage_load = [&](int cb) {
         const float *__restrict__ p = s_base + (size_t)cb * PB_CB * s_cs;
-        sr0 = *reinterpret_cast<const f32x4 *>(p);
-        sr1 = *reinterpret_cast<const f32x4 *>(p + s_cs);
-        sr2 = *reinterpret_cast<const f32x4 *>(p + 2 * s_cs);
-        sr3 = *reinterpret_cast<const f32x4 *>(p + 3 * s_cs);
-        sr4 = *reinterpret_cast<const f32x4 *>(p + 4 * s_cs);
-        sr5 = *reinterpret_cast<const f32x4 *>(p + 5 * s_cs);
-        sr6 = *reinterpret_cast<const f32x4 *>(p + 6 * s_cs);
-        sr7 = *reinterpret_cast<const f32x4 *>(p + 7 * s_cs);
+        typedef typename std::conditional<FLAT, f32x4_a4, f32x4>::type ld_t;      // flat rows start 8-byte aligned
+        sr0 = *reinterpret_cast<const ld_t *>(p);
+        sr1 = *reinterpret_cast<const ld_t *>(p + s_cs);
+        sr2 = *reinterpret_cast<const ld_t *>(p + 2 * s_cs);
+        sr3 = *reinterpret_cast<const ld_t *>(p + 3 * s_cs);
+        sr4 = *reinterpret_cast<const ld_t *>(p + 4 * s_cs);
+        sr5 = *reinterpret_cast<const ld_t *>(p + 5 * s_cs);
+        sr6 = *reinterpret_cast<const ld_t *>(p + 6 * s_cs);
+        sr7 = *reinterpret_cast<const ld_t *>(p + 7 * s_cs);
     };
     auto stage_store = [&](int buf) {
         if (!s_item) return;
+        if (FLAT && s_sh != 0) {                               // s_sh == 2: elements 2, 3 are columns W-2, W-1; then halo
+            auto mv = [](f32x4 &v) { v = f32x4{v.z, v.w, 0.0f, 0.0f}; };
+            mv(sr0); mv(sr1); mv(sr2); mv(sr3); mv(sr4); mv(sr5); mv(sr6); mv(sr7);
+        }
         bf16x8 *__restrict__ d = &Ps[buf][s_kg][s_prow * PB_RP + s_grp];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {                          // pixel i of the group: column c = 4*grp + i -> slot i*6 + grp
@@ -570,13 +611,22 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_patch_bf16_kernel(const f
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[j][e] = 0.0f;
 
-    // the row of zeros (both buffers, all channel groups)
-    for (int i = tid; i < 2 * (PB_CB / 8) * PB_RP; i += kThreads) {
-        const int b = i / ((PB_CB / 8) * PB_RP), r_ = i - b * ((PB_CB / 8) * PB_RP);
+    // the row of zeros (both buffers, all channel groups); flat: also the never-staged outer column groups
+    if constexpr (FLAT) {
         bf16x8 z;
 #pragma unroll
         for (int e = 0; e < 8; ++e) z[e] = (__bf16)0.0f;
-        Ps[b][r_ / PB_RP][PB_ROWS * PB_RP + (r_ % PB_RP)] = z;
+        bf16x8 *__restrict__ pz = &Ps[0][0][0];
+        for (int i = tid; i < 2 * (PB_CB / 8) * NSLOT; i += kThreads) pz[i] = z;
+        __syncthreads();
+    } else {
+        for (int i = tid; i < 2 * (PB_CB / 8) * PB_RP; i += kThreads) {
+            const int b = i / ((PB_CB / 8) * PB_RP), r_ = i - b * ((PB_CB / 8) * PB_RP);
+            bf16x8 z;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) z[e] = (__bf16)0.0f;
+            Ps[b][r_ / PB_RP][PB_ROWS * PB_RP + (r_ % PB_RP)] = z;
+        }
     }
     const int ncb = g.Cin / PB_CB;
     stage_load(0);
@@ -602,9 +652,15 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_patch_bf16_kernel(const f
         const bf16x8 *__restrict__ pbuf = &Ps[cb & 1][khalf][0];           // k-step ks adds 2 channel groups
         const bool more = cb + 1 < ncb;
         auto bload = [&](bf16x8 (&bv)[4], int r_, int s_, int ks) {
-            const bf16x8 *__restrict__ bp = pbuf + ks * 2 * PB_NSLOT + rowslot[r_];
+            if constexpr (FLAT) {
+                const bf16x8 *__restrict__ bp = pbuf + ks * 2 * NSLOT;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) bv[j] = bp[((j + s_ + 3) & 3) * 6 + ((j + s_ + 3) >> 2)];
+                for (int j = 0; j < 4; ++j) bv[j] = bp[fslot[r_][s_][j]];
+            } else {
+                const bf16x8 *__restrict__ bp = pbuf + ks * 2 * NSLOT + rowslot[r_];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bv[j] = bp[((j + s_ + 3) & 3) * 6 + ((j + s_ + 3) >> 2)];
+            }
         };
         bload(bfr[0], 0, 0, 0);
         __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);                 // LDS reads of sub-step 0
@@ -652,6 +708,36 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_patch_bf16_kernel(const f
         __syncthreads();
     }
 
+    if constexpr (FLAT) {
+        // the lane's pixels (0,1) and (2,3) are two pairs, each inside one row (W even): 8-byte accesses
+        const int mb = m0 + wave * 32 + 4 * khalf;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (fY[2 * h] >= NH) continue;
+            const int n_img = fY[2 * h] / g.H;
+            const size_t ob = ((size_t)n_img * g.Cout + mb) * HW + (size_t)(fY[2 * h] - n_img * g.H) * g.W + fx[2 * h];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int mo = (e & 3) + 8 * (e >> 2);
+                if (mb + mo >= g.Cout) continue;
+                const float sc = ep.scale ? ep.scale[mb + mo] : 1.0f;
+                const float bi = ep.bias ? ep.bias[mb + mo] : 0.0f;
+                const size_t o = ob + (size_t)mo * HW;
+                float v0 = acc[2 * h][e] * sc + bi, v1 = acc[2 * h + 1][e] * sc + bi;
+                if (ep.residual) {
+                    const float2 rr = *reinterpret_cast<const float2 *>(ep.residual + o);
+                    v0 += rr.x;
+                    v1 += rr.y;
+                }
+                if (ep.relu) {
+                    v0 = fmaxf(v0, 0.0f);
+                    v1 = fmaxf(v1, 0.0f);
+                }
+                *reinterpret_cast<float2 *>(y + o) = make_float2(v0, v1);
+            }
+        }
+        return;
+    }
     // ---- epilogue: the lane's quad x 16 channels (same layout as conv_bf16_fwd_kernel<128>) ----------------
     const int xo = X0 + 4 * q;
     if (Yo >= NH || xo >= g.W) return;
@@ -1349,8 +1435,10 @@ int fi_conv3x3_forward_bf16w(const float *x, const uint16_t *weight_bf16, const 
 {
     FI_REQUIRE(N >= 1 && Cin >= 1 && H >= 1 && W >= 1 && Cout >= 1, "sizes must be positive");
     FI_REQUIRE(x && weight_bf16 && y, "null pointer");
-    if (!(W % PB_TW == 0 && Cin % PB_CB == 0 && Cout > 64)) {
-        fi::set_error("fi_conv3x3_forward_bf16w needs W %% 16 == 0, Cin %% 32 == 0 and Cout > 64 (got W = %d, Cin = %d, Cout = %d)",
+    // 2-D tiles: width a multiple of 16.  Flat tiles: even widths 12..14 (the 14 x 14 RoI maps)
+    const bool flat = W % PB_TW != 0 && W < 16 && W % 2 == 0 && (W + 126) / W + 2 <= PB_ROWS_FLAT;
+    if (!((W % PB_TW == 0 || flat) && Cin % PB_CB == 0 && Cout > 64)) {
+        fi::set_error("fi_conv3x3_forward_bf16w needs W %% 16 == 0 or W in {12, 14}, Cin %% 32 == 0 and Cout > 64 (got W = %d, Cin = %d, Cout = %d)",
                       W, Cin, Cout);
         return FI_ERR_UNSUPPORTED;
     }
@@ -1360,16 +1448,20 @@ int fi_conv3x3_forward_bf16w(const float *x, const uint16_t *weight_bf16, const 
     PatchGeomB pg;
     pg.N = N; pg.Cin = Cin; pg.H = H; pg.W = W; pg.Cout = Cout;
     pg.flip = flip_taps ? 1 : 0;
-    pg.tiles_x = W / PB_TW;
-    pg.ptiles = fi::ceil_div(N * H, PB_TH) * pg.tiles_x;
+    pg.tiles_x = flat ? 1 : W / PB_TW;
+    pg.ptiles = flat ? fi::ceil_div(N * H * W, 128) : fi::ceil_div(N * H, PB_TH) * pg.tiles_x;
     pg.mtiles = fi::ceil_div(Cout, 128);
     const Epi ep = {bias, scale, residual, relu};
     hipStream_t st = (hipStream_t)stream;
     const long blocks = (long)fi::ceil_div(pg.ptiles, 8) * 8 * pg.mtiles;
     FI_REQUIRE(blocks < 2147483647L, "grid too large");
     fi::ProfScope prof(FI_K_CONV_BF16_FWD, st);
-    hipLaunchKernelGGL(conv3x3_patch_bf16_kernel<true>, dim3((unsigned)blocks), dim3(kThreads), 0, st, x,
-                       static_cast<const void *>(weight_bf16), ep, y, pg);
+    if (flat)
+        hipLaunchKernelGGL((conv3x3_patch_bf16_kernel<true, true>), dim3((unsigned)blocks), dim3(kThreads), 0, st, x,
+                           static_cast<const void *>(weight_bf16), ep, y, pg);
+    else
+        hipLaunchKernelGGL((conv3x3_patch_bf16_kernel<true, false>), dim3((unsigned)blocks), dim3(kThreads), 0, st, x,
+                           static_cast<const void *>(weight_bf16), ep, y, pg);
     FI_HIP_CHECK(hipGetLastError());
     return FI_OK;
 }

@@ -33,6 +33,11 @@ CASES = [
     (2, 64, 128, 128, 160, 3, 3, 1, 1),    # conv3x3_patch_bf16_kernel (>= 256 tiles, W % 16 == 0), partial Cout tile
     (36, 32, 20, 16, 256, 3, 3, 1, 1),     # patch kernel: tiles cross image boundaries (H = 20), one column tile
     (9, 160, 32, 32, 160, 3, 3, 1, 1),     # patch kernel for forward AND data gradient, 5 channel blocks
+    (171, 64, 14, 14, 256, 3, 3, 1, 1),    # flat patch tiles (14-wide RoI maps, odd tail tile); flat-space weight gradient
+    (90, 256, 14, 14, 272, 3, 3, 1, 1),    # flat tiles forward AND data gradient, partial third Cout tile
+    (70, 128, 12, 12, 256, 3, 3, 1, 1),    # flat tiles, 12 columns: the last staged column group lies outside the map
+    (3, 128, 20, 24, 128, 3, 3, 1, 1),     # flat-space weight gradient: groups continue on the next row, tail tile
+    (5, 64, 10, 10, 128, 1, 1, 1, 0),      # flat-space weight gradient, 1x1, 64-channel tiles, pixel tail
 ]
 
 
