@@ -126,6 +126,18 @@ def _conv_fwd(x, w, b, stride, padding, relu=False, scale=None, residual=None, o
                                                       1 if relu else 0, 1 if layout == 2 else 0, _lib.current_stream()),
                            "fi_conv3x3_forward_bf16w")
             return y
+        # 1x1 / stride 1 with whole quads and 64-channel stages: weights-in-registers kernel, bf16 weights cached
+        if (R, S) == (1, 1) and tuple(stride) == (1, 1) and tuple(padding) == (0, 0) and (H * W) % 4 == 0 and \
+                Cin % 64 == 0 and Cout > 64 and not out_channels_last and out_hw is None and \
+                ((N * H * W + 127) // 128) * ((Cout + 127) // 128) >= 256 and \
+                (residual is None or residual.data_ptr() % 16 == 0):
+            wb = _cached_bf16(w)
+            with torch.cuda.device(x.device):
+                _lib.check(L.fi_conv1x1_forward_bf16w(_lib.ptr(x), _lib.ptr(wb), _lib.ptr(b), _lib.ptr(scale),
+                                                      _lib.ptr(residual), _lib.ptr(y), N, Cin, H * W, Cout,
+                                                      1 if relu else 0, _lib.current_stream()),
+                           "fi_conv1x1_forward_bf16w")
+            return y
     with torch.cuda.device(x.device):
         _lib.check(fn(_lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(scale), _lib.ptr(residual),
                                        _lib.ptr(y), N, Cin, H, W, Cout,

@@ -768,6 +768,156 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_patch_bf16_kernel(const f
 }
 
 // ------------------------------------------------------------------------------------------------
+// 1x1 / stride 1 forward + data gradient: weights in registers, pixel tile staged 64 channels at a time
+// (the bf16 twin of conv1x1_reg_kernel in conv_igemm.hip)
+// ------------------------------------------------------------------------------------------------
+// A workgroup owns 128 consecutive pixels (H*W % 4 == 0: a quad of 4 pixels never straddles two images) x 128
+// output channels.  Per stage of 64 input channels a thread loads ONE quad of 8 channels (eight 16-byte loads, the
+// 32 lanes of a half-wavefront read 512 contiguous bytes per channel), packs it and writes four 16-byte LDS slots,
+// one per pixel = one MFMA B-fragment; slot = (pixel mod 4) * 32 + quad, so that the lanes of a wavefront -- lane
+// l31 reads pixel 4*l31 + j -- read consecutive slots.  The bf16 weights (converted once per step by the caller) go
+// straight into the MFMA A-operand: one 16-byte load per k-step.  16 MFMAs per wavefront and barrier.
+constexpr int P1_KC = 64;                         // channels per stage = 8 groups of 8
+
+struct Conv1x1GeomB {
+    int N, Cin, HW, Cout, P;                      // P = N * HW
+    int ptiles, mtiles;
+};
+
+__global__ __launch_bounds__(kThreads, 2) void conv1x1_bf16_kernel(const float *__restrict__ x,
+                                                                  const __bf16 *__restrict__ wb, Epi ep,
+                                                                  float *__restrict__ y, Conv1x1GeomB g)
+{
+    __shared__ __align__(16) bf16x8 Ps[2][P1_KC / 8][128];
+
+    // XCD-aware order: XCD c owns a contiguous band of pixel tiles, Cout tiles innermost
+    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+    const int per_xcd = (g.ptiles + 7) >> 3;
+    const int mt = local % g.mtiles;
+    const int pt = xcd * per_xcd + local / g.mtiles;
+    if (pt >= g.ptiles) return;
+    const int m0 = mt * 128, P0 = pt * 128;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, khalf = lane >> 5;
+
+    // ---- A operand: 8 consecutive channels of one output channel per k-step ----------------------------
+    const int am = min(m0 + wave * 32 + l31, g.Cout - 1);            // rows past Cout re-read the last row
+    const __bf16 *__restrict__ a_base = wb + (size_t)am * g.Cin + khalf * 8;
+    auto load_a = [&](bf16x8 (&a)[4], int cb) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) a[ks] = *reinterpret_cast<const bf16x8 *>(a_base + cb * P1_KC + ks * 16);
+    };
+
+    // ---- staging: thread = (channel group of 8, quad) ----------------------------------------------------
+    const int s_kg = tid >> 5, s_q = tid & 31;
+    const int s_p = P0 + 4 * s_q;
+    const bool s_ok = s_p < g.P;                                     // P % 4 == 0: whole quads
+    const int s_n = s_ok ? s_p / g.HW : 0;
+    const float *__restrict__ s_base =
+        s_ok ? x + ((size_t)s_n * g.Cin + s_kg * 8) * g.HW + (s_p - s_n * g.HW) : g_zero_quad;
+    const size_t s_cs = s_ok ? (size_t)g.HW : 0;                     // channel stride (0: the quad of zeros)
+    f32x4 sr0, sr1, sr2, sr3, sr4, sr5, sr6, sr7;
+    auto stage_load = [&](int cb) {
+        const float *__restrict__ p = s_base + (size_t)cb * P1_KC * s_cs;
+        sr0 = *reinterpret_cast<const f32x4 *>(p);
+        sr1 = *reinterpret_cast<const f32x4 *>(p + s_cs);
+        sr2 = *reinterpret_cast<const f32x4 *>(p + 2 * s_cs);
+        sr3 = *reinterpret_cast<const f32x4 *>(p + 3 * s_cs);
+        sr4 = *reinterpret_cast<const f32x4 *>(p + 4 * s_cs);
+        sr5 = *reinterpret_cast<const f32x4 *>(p + 5 * s_cs);
+        sr6 = *reinterpret_cast<const f32x4 *>(p + 6 * s_cs);
+        sr7 = *reinterpret_cast<const f32x4 *>(p + 7 * s_cs);
+    };
+    auto stage_store = [&](int buf) {
+        bf16x8 *__restrict__ d = &Ps[buf][s_kg][s_q];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            bf16x8 v;
+            v[0] = (__bf16)sr0[i]; v[1] = (__bf16)sr1[i]; v[2] = (__bf16)sr2[i]; v[3] = (__bf16)sr3[i];
+            v[4] = (__bf16)sr4[i]; v[5] = (__bf16)sr5[i]; v[6] = (__bf16)sr6[i]; v[7] = (__bf16)sr7[i];
+            d[i * 32] = v;
+        }
+    };
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[j][e] = 0.0f;
+
+    const int ncb = g.Cin / P1_KC;
+    bf16x8 a0[4], a1[4];                                  // weights of the even / odd stages (static register sets)
+    stage_load(0);
+    load_a(a0, 0);
+    stage_store(0);
+    __syncthreads();
+    auto stage = [&](int cb, const bf16x8 (&acur)[4], bf16x8 (&anxt)[4]) {
+        const bf16x8 *__restrict__ pbuf = &Ps[cb & 1][khalf][l31];
+        const bool more = cb + 1 < ncb;
+        // weights of the next stage, then the next pixel tile (unconditional: the last stage re-reads its own)
+        load_a(anxt, more ? cb + 1 : cb);
+        stage_load(more ? cb + 1 : cb);
+        // issue order: the 12 global loads first (left alone the compiler sinks the 8 staging loads to their use at
+        // the end of the stage), then per k-step the LDS reads of the next k-step ahead of the 4 MFMAs
+        __builtin_amdgcn_sched_barrier(0);
+        bf16x8 bv[2][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bv[0][j] = pbuf[j * 32];
+        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            if (ks + 1 < 4) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bv[(ks + 1) & 1][j] = pbuf[(ks + 1) * 2 * 128 + j * 32];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acur[ks], bv[ks & 1][j], acc[j], 0, 0, 0);
+            if (ks + 1 < 4) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        }
+        // unconditional (the last stage writes its own tile into the idle buffer): under `if (more)` the compiler
+        // sinks the staging loads into the branch, i.e. behind the MFMAs
+        stage_store((cb + 1) & 1);
+        __syncthreads();
+    };
+    for (int cb = 0; cb < ncb; cb += 2) {
+        stage(cb, a0, a1);
+        if (cb + 1 < ncb) stage(cb + 1, a1, a0);
+    }
+
+    // ---- epilogue: the lane's quad x 16 channels -----------------------------------------------------------
+    const int p = P0 + 4 * l31;
+    if (p >= g.P) return;
+    const int n_img = p / g.HW;
+    const int mb = m0 + wave * 32 + 4 * khalf;
+    const size_t obase = ((size_t)n_img * g.Cout + mb) * g.HW + (p - n_img * g.HW);
+    if (m0 + 128 <= g.Cout) {
+        if (ep.residual)
+            epilogue_full_nchw<4, true>(acc, ep, y, obase, g.HW, mb);
+        else
+            epilogue_full_nchw<4, false>(acc, ep, y, obase, g.HW, mb);
+        return;
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int m = mb + (e & 3) + 8 * (e >> 2);
+        if (m >= g.Cout) continue;
+        const float sc = ep.scale ? ep.scale[m] : 1.0f;
+        const float bi = ep.bias ? ep.bias[m] : 0.0f;
+        const size_t o = obase + (size_t)((e & 3) + 8 * (e >> 2)) * g.HW;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float v = acc[j][e] * sc + bi;
+            if (ep.residual) v += ep.residual[o + j];
+            y[o + j] = ep.relu ? fmaxf(v, 0.0f) : v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // weight gradient (tap-major dW [Cout][R*S][Cin]), stride 1 or general
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kThreads) void conv_bf16_wgrad_generic_kernel(const float *__restrict__ x,
@@ -1462,6 +1612,35 @@ int fi_conv3x3_forward_bf16w(const float *x, const uint16_t *weight_bf16, const 
     else
         hipLaunchKernelGGL((conv3x3_patch_bf16_kernel<true, false>), dim3((unsigned)blocks), dim3(kThreads), 0, st, x,
                            static_cast<const void *>(weight_bf16), ep, y, pg);
+    FI_HIP_CHECK(hipGetLastError());
+    return FI_OK;
+}
+
+int fi_conv1x1_forward_bf16w(const float *x, const uint16_t *weight_bf16, const float *bias, const float *scale,
+                             const float *residual, float *y, int N, int Cin, int HW, int Cout, int relu,
+                             fi_stream_t stream)
+{
+    FI_REQUIRE(N >= 1 && Cin >= 1 && HW >= 1 && Cout >= 1, "sizes must be positive");
+    FI_REQUIRE(x && weight_bf16 && y, "null pointer");
+    if (!(HW % 4 == 0 && Cin % P1_KC == 0 && Cout > 64)) {
+        fi::set_error("fi_conv1x1_forward_bf16w needs H*W %% 4 == 0, Cin %% 64 == 0 and Cout > 64 (got H*W = %d, Cin = %d, Cout = %d)",
+                      HW, Cin, Cout);
+        return FI_ERR_UNSUPPORTED;
+    }
+    FI_REQUIRE((uintptr_t)x % 16 == 0 && (uintptr_t)y % 16 == 0 && (uintptr_t)weight_bf16 % 16 == 0 &&
+               (residual == nullptr || (uintptr_t)residual % 16 == 0), "16-byte aligned tensors required");
+    FI_REQUIRE((long)N * Cin * HW < 2147483647L && (long)N * Cout * HW < 2147483647L, "tensor too large");
+    Conv1x1GeomB pg;
+    pg.N = N; pg.Cin = Cin; pg.HW = HW; pg.Cout = Cout; pg.P = N * HW;
+    pg.ptiles = fi::ceil_div(pg.P, 128);
+    pg.mtiles = fi::ceil_div(Cout, 128);
+    const Epi ep = {bias, scale, residual, relu};
+    hipStream_t st = (hipStream_t)stream;
+    const long blocks = (long)fi::ceil_div(pg.ptiles, 8) * 8 * pg.mtiles;
+    FI_REQUIRE(blocks < 2147483647L, "grid too large");
+    fi::ProfScope prof(FI_K_CONV_BF16_FWD, st);
+    hipLaunchKernelGGL(conv1x1_bf16_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, st, x,
+                       reinterpret_cast<const __bf16 *>(weight_bf16), ep, y, pg);
     FI_HIP_CHECK(hipGetLastError());
     return FI_OK;
 }

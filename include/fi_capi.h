@@ -301,10 +301,19 @@ int fi_conv2d_forward_bf16(const float *x, const float *weight, const float *bia
 /* 3x3 / stride 1 / pad 1 forward (flip_taps = 0) or data gradient (flip_taps = 1, weight = W^T [Cin][3][3][Cout])
  * with tap-major weights ALREADY in bf16 (uint16 bit patterns, converted once per step by the caller): the input
  * patch of a tile is staged once per 32 channels in LDS, weights go straight into the MFMA operand registers.
- * Needs W % 16 == 0, Cin % 32 == 0, Cout > 64 (FI_ERR_UNSUPPORTED otherwise); same epilogue as fi_conv2d_forward. */
+ * Needs W % 16 == 0 (8 x 16 tiles) or W in {12, 14} (flat 128-pixel tiles: the 14 x 14 RoI maps), Cin % 32 == 0,
+ * Cout > 64 (FI_ERR_UNSUPPORTED otherwise); same epilogue as fi_conv2d_forward. */
 int fi_conv3x3_forward_bf16w(const float *x, const uint16_t *weight_bf16, const float *bias, const float *scale,
                              const float *residual, float *y, int N, int Cin, int H, int W, int Cout, int relu,
                              int flip_taps, fi_stream_t stream);
+/* 1x1 / stride 1 forward, or data gradient with weight = W^T [Cin][Cout] and the channel counts swapped, with
+ * the [Cout][Cin] weights ALREADY in bf16: 128 pixels x 128 output channels per workgroup, the pixel tile staged 64
+ * channels at a time, weights straight into the MFMA operand registers (the bf16 twin of the fp32 1x1 kernel).
+ * HW = H * W.  Needs HW % 4 == 0, Cin % 64 == 0, Cout > 64 (FI_ERR_UNSUPPORTED otherwise); same epilogue as
+ * fi_conv2d_forward.  Replaces the 1x1 nn.Conv2d modules of lib/sub_module.py:38-128 on the reduced-precision path. */
+int fi_conv1x1_forward_bf16w(const float *x, const uint16_t *weight_bf16, const float *bias, const float *scale,
+                             const float *residual, float *y, int N, int Cin, int HW, int Cout, int relu,
+                             fi_stream_t stream);
 int fi_conv2d_weight_grad_bf16(const float *x, const float *dy, float *dweight, int N, int Cin,
                                int H, int W, int Cout, int R, int S, int stride_h, int stride_w,
                                int pad_h, int pad_w, int flags, fi_stream_t stream);

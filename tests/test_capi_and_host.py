@@ -66,6 +66,9 @@ def test_argument_validation_without_a_gpu():
     assert L.fi_conv3x3_forward_bf16w(16, 16, None, None, None, 16, 1, 32, 8, 20, 128, 0, 0, None) == -3
     assert b"W % 16" in L.fi_last_error()
     assert L.fi_conv3x3_forward_bf16w(None, 16, None, None, None, 16, 1, 32, 8, 16, 128, 0, 0, None) == -1
+    assert L.fi_conv1x1_forward_bf16w(16, 16, None, None, None, 16, 1, 96, 64, 128, 0, None) == -3     # Cin % 64
+    assert L.fi_conv1x1_forward_bf16w(16, 16, None, None, None, 16, 1, 64, 50, 128, 0, None) == -3     # H*W % 4
+    assert L.fi_conv1x1_forward_bf16w(None, 16, None, None, None, 16, 1, 64, 64, 128, 0, None) == -1
     assert L.fi_sgd_chunks(0) == 0 and L.fi_sgd_chunks(1) == 1 and L.fi_sgd_chunks(8193) == 2
     assert L.fi_sgd_clip_step(None, 0, 0, 1.0, None, None, None) == 0
     assert L.fi_sgd_clip_step(None, 3, 5, 1.0, None, None, None) == -1
