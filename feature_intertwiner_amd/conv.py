@@ -112,7 +112,7 @@ def _conv_fwd(x, w, b, stride, padding, relu=False, scale=None, residual=None, o
         # 3x3 / stride 1 / pad 1 on maps whose width is a multiple of 16 (or 14-wide RoI maps): patch kernel with the
         # weights converted to bf16 once per step (cached like W^T) instead of inside every workgroup
         mt = (Cout + 127) // 128
-        tiled = W % 16 == 0 and ((N * H + 7) // 8) * (W // 16) * mt >= 256
+        tiled = W % 4 == 0 and W >= 16 and ((N * H + 7) // 8) * ((W + 15) // 16) * mt >= 192
         # flat 128-pixel tiles for the 14 x 14 RoI maps (even widths below 16)
         flat = W % 16 != 0 and W < 16 and W % 2 == 0 and (W + 126) // W + 2 <= 13 and \
             ((N * H * W + 127) // 128) * mt >= 512
@@ -129,7 +129,7 @@ def _conv_fwd(x, w, b, stride, padding, relu=False, scale=None, residual=None, o
         # 1x1 / stride 1 with whole quads and 64-channel stages: weights-in-registers kernel, bf16 weights cached
         if (R, S) == (1, 1) and tuple(stride) == (1, 1) and tuple(padding) == (0, 0) and (H * W) % 4 == 0 and \
                 Cin % 64 == 0 and Cout > 64 and not out_channels_last and out_hw is None and \
-                ((N * H * W + 127) // 128) * ((Cout + 127) // 128) >= 256 and \
+                ((N * H * W + 127) // 128) * ((Cout + 127) // 128) >= 192 and \
                 (residual is None or residual.data_ptr() % 16 == 0):
             wb = _cached_bf16(w)
             with torch.cuda.device(x.device):

@@ -1542,18 +1542,18 @@ int fi_conv2d_forward_bf16(const float *x, const float *weight, const float *bia
     g.out_nhwc = output_layout == 1;
     const Epi ep = {bias, scale, residual, relu};
     hipStream_t st = (hipStream_t)stream;
-    // 3x3 / stride 1 / pad 1 on maps whose width is a multiple of 16: input patch in LDS
+    // 3x3 / stride 1 / pad 1 on maps at least 16 columns wide (whole 4-column groups): input patch in LDS
     if (!getenv("FI_NO_PATCH") && R == 3 && S == 3 && stride_h == 1 && stride_w == 1 && pad_h == 1 && pad_w == 1 &&
-        g.OH == H && g.OW == W && W % PB_TW == 0 && !g.out_nhwc && Cout > 64 && weight_layout >= 1 &&
+        g.OH == H && g.OW == W && W % 4 == 0 && W >= PB_TW && !g.out_nhwc && Cout > 64 && weight_layout >= 1 &&
         (uintptr_t)x % 16 == 0 && (uintptr_t)y % 16 == 0 && (residual == nullptr || (uintptr_t)residual % 16 == 0) &&
         (long)N * Cin * H * W < 2147483647L && (long)N * Cout * H * W < 2147483647L) {
         PatchGeomB pg;
         pg.N = N; pg.Cin = Cin; pg.H = H; pg.W = W; pg.Cout = Cout;
         pg.flip = g.flip;
-        pg.tiles_x = W / PB_TW;
+        pg.tiles_x = fi::ceil_div(W, PB_TW);                 // W % 16 != 0: the last column tile is partly empty
         pg.ptiles = fi::ceil_div(N * H, PB_TH) * pg.tiles_x;
         pg.mtiles = fi::ceil_div(Cout, 128);
-        if ((long)pg.ptiles * pg.mtiles >= 256) {
+        if ((long)pg.ptiles * pg.mtiles >= 192) {
             const long blocks = (long)fi::ceil_div(pg.ptiles, 8) * 8 * pg.mtiles;
             fi::ProfScope prof(FI_K_CONV_BF16_FWD, st);
             hipLaunchKernelGGL(conv3x3_patch_bf16_kernel<false>, dim3((unsigned)blocks), dim3(kThreads), 0, st, x,
@@ -1585,10 +1585,12 @@ int fi_conv3x3_forward_bf16w(const float *x, const uint16_t *weight_bf16, const 
 {
     FI_REQUIRE(N >= 1 && Cin >= 1 && H >= 1 && W >= 1 && Cout >= 1, "sizes must be positive");
     FI_REQUIRE(x && weight_bf16 && y, "null pointer");
-    // 2-D tiles: width a multiple of 16.  Flat tiles: even widths 12..14 (the 14 x 14 RoI maps)
-    const bool flat = W % PB_TW != 0 && W < 16 && W % 2 == 0 && (W + 126) / W + 2 <= PB_ROWS_FLAT;
-    if (!((W % PB_TW == 0 || flat) && Cin % PB_CB == 0 && Cout > 64)) {
-        fi::set_error("fi_conv3x3_forward_bf16w needs W %% 16 == 0 or W in {12, 14}, Cin %% 32 == 0 and Cout > 64 (got W = %d, Cin = %d, Cout = %d)",
+    // 2-D tiles: width a multiple of 4, at least 16 (a width that is not a multiple of 16 leaves the last column tile
+    // partly empty).  Flat tiles: even widths 12..14 (the 14 x 14 RoI maps)
+    const bool tiled = W % 4 == 0 && W >= PB_TW;
+    const bool flat = !tiled && W < 16 && W % 2 == 0 && (W + 126) / W + 2 <= PB_ROWS_FLAT;
+    if (!((tiled || flat) && Cin % PB_CB == 0 && Cout > 64)) {
+        fi::set_error("fi_conv3x3_forward_bf16w needs W %% 4 == 0 (W %% 16 == 0 for full tiles) and W >= 16, or W in {12, 14}; Cin %% 32 == 0 and Cout > 64 (got W = %d, Cin = %d, Cout = %d)",
                       W, Cin, Cout);
         return FI_ERR_UNSUPPORTED;
     }
@@ -1598,7 +1600,7 @@ int fi_conv3x3_forward_bf16w(const float *x, const uint16_t *weight_bf16, const 
     PatchGeomB pg;
     pg.N = N; pg.Cin = Cin; pg.H = H; pg.W = W; pg.Cout = Cout;
     pg.flip = flip_taps ? 1 : 0;
-    pg.tiles_x = flat ? 1 : W / PB_TW;
+    pg.tiles_x = flat ? 1 : fi::ceil_div(W, PB_TW);
     pg.ptiles = flat ? fi::ceil_div(N * H * W, 128) : fi::ceil_div(N * H, PB_TH) * pg.tiles_x;
     pg.mtiles = fi::ceil_div(Cout, 128);
     const Epi ep = {bias, scale, residual, relu};

@@ -301,7 +301,8 @@ int fi_conv2d_forward_bf16(const float *x, const float *weight, const float *bia
 /* 3x3 / stride 1 / pad 1 forward (flip_taps = 0) or data gradient (flip_taps = 1, weight = W^T [Cin][3][3][Cout])
  * with tap-major weights ALREADY in bf16 (uint16 bit patterns, converted once per step by the caller): the input
  * patch of a tile is staged once per 32 channels in LDS, weights go straight into the MFMA operand registers.
- * Needs W % 16 == 0 (8 x 16 tiles) or W in {12, 14} (flat 128-pixel tiles: the 14 x 14 RoI maps), Cin % 32 == 0,
+ * Needs W % 4 == 0 and W >= 16 (8 x 16 tiles; W % 16 == 0 for full ones) or W in {12, 14} (flat 128-pixel tiles: the
+ * 14 x 14 RoI maps), Cin % 32 == 0,
  * Cout > 64 (FI_ERR_UNSUPPORTED otherwise); same epilogue as fi_conv2d_forward. */
 int fi_conv3x3_forward_bf16w(const float *x, const uint16_t *weight_bf16, const float *bias, const float *scale,
                              const float *residual, float *y, int N, int Cin, int H, int W, int Cout, int relu,

@@ -63,8 +63,8 @@ def test_argument_validation_without_a_gpu():
     assert b"level" in L.fi_last_error()
     assert L.fi_pyramid_crop_forward_nhwc(ptrs, hs, hs, 0, 16, 16, 16, 1, 1, 64, 7, 7, 0.0, 16, None) == -1
     # bf16-weight patch convolution and the optimiser step validate before touching the device
-    assert L.fi_conv3x3_forward_bf16w(16, 16, None, None, None, 16, 1, 32, 8, 20, 128, 0, 0, None) == -3
-    assert b"W % 16" in L.fi_last_error()
+    assert L.fi_conv3x3_forward_bf16w(16, 16, None, None, None, 16, 1, 32, 8, 18, 128, 0, 0, None) == -3
+    assert b"W % 4" in L.fi_last_error()
     assert L.fi_conv3x3_forward_bf16w(None, 16, None, None, None, 16, 1, 32, 8, 16, 128, 0, 0, None) == -1
     assert L.fi_conv1x1_forward_bf16w(16, 16, None, None, None, 16, 1, 96, 64, 128, 0, None) == -3     # Cin % 64
     assert L.fi_conv1x1_forward_bf16w(16, 16, None, None, None, 16, 1, 64, 50, 128, 0, None) == -3     # H*W % 4

@@ -38,7 +38,8 @@ CASES = [
     (70, 128, 12, 12, 256, 3, 3, 1, 1),    # flat tiles, 12 columns: the last staged column group lies outside the map
     (3, 128, 20, 24, 128, 3, 3, 1, 1),     # flat-space weight gradient: groups continue on the next row, tail tile
     (5, 64, 10, 10, 128, 1, 1, 1, 0),      # flat-space weight gradient, 1x1, 64-channel tiles, pixel tail
-    (16, 64, 32, 32, 256, 1, 1, 1, 0),     # conv1x1_bf16_kernel (>= 256 tiles): one 64-channel stage
+    (14, 64, 40, 84, 160, 3, 3, 1, 1),     # patch kernel, W = 84: the sixth column tile holds 4 of 16 columns
+    (16, 64, 32, 32, 256, 1, 1, 1, 0),     # conv1x1_bf16_kernel (>= 192 tiles): one 64-channel stage
     (10, 192, 58, 58, 130, 1, 1, 1, 0),    # conv1x1_bf16_kernel: 3 stages, partial Cout tile, pixel tail, tiles across images
 ]
 
