@@ -1038,12 +1038,18 @@ __global__ __launch_bounds__(kThreads, 3) void conv1x1_reg_kernel(const float *_
     for (int cb = 0; cb < ncb; ++cb) {
         const float *__restrict__ pbuf = &Ps[cb & 1][khalf * 8][4 * l31];
         const bool more = cb + 1 < ncb;
-        if (more) stage_load(cb + 1);
         breg[0] = *reinterpret_cast<const float4 *>(pbuf);
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);          // the read of sub-step 0
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            if (h == 0) load_a(areg[1], 2 * cb + 1);
+            if (h == 0) {
+                load_a(areg[1], 2 * cb + 1);
+                // the next pixel tile is requested BEHIND the weights of the second channel group and without a
+                // branch (the last stage re-reads its own tile): at the top of the stage, or inside `if (more)`, the
+                // loads sit in front of the wait for the first group's weights and every stage starts with the
+                // memory latency
+                stage_load(more ? cb + 1 : cb);
+            }
 #pragma unroll
             for (int kk = 0; kk < 8; ++kk) {
                 const int step = h * 8 + kk;
@@ -1057,15 +1063,13 @@ __global__ __launch_bounds__(kThreads, 3) void conv1x1_reg_kernel(const float *_
                 acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv.y, acc[1], 0, 0, 0);
                 acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv.z, acc[2], 0, 0, 0);
                 acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv.w, acc[3], 0, 0, 0);
-                if (kk == 0 && h == 0) __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+                if (kk == 0 && h == 0) __builtin_amdgcn_sched_group_barrier(0x020, 6, 0);     // 2 weight + 4 staging loads
                 __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
             }
         }
-        if (more) {
-            load_a(areg[0], 2 * cb + 2);
-            stage_store((cb + 1) & 1);
-        }
+        load_a(areg[0], more ? 2 * cb + 2 : 2 * cb);         // unconditional: see above
+        if (more) stage_store((cb + 1) & 1);
         __syncthreads();
     }
 
