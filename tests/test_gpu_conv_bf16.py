@@ -160,3 +160,37 @@ def test_bf16_train_step_tracks_fp32():
     for k in ("rpn_cls", "rpn_bbox", "mrcnn_cls", "mrcnn_bbox", "mrcnn_mask"):
         a, b = float(terms["fp32"][k]), float(terms["bf16"][k])
         assert abs(a - b) <= 0.05 * abs(a) + 1e-3, (k, a, b)
+
+
+@pytest.mark.parametrize("shape", [
+    (4, 256, 256, 256, 256, 3, 1),      # P2-level 3x3 of configs[2]: 2-D patch tiles, flat-space weight gradient on 2016 workgroups
+    (2048, 256, 14, 14, 256, 3, 1),     # mask-head 3x3: flat patch tiles across 2048 RoI maps
+    (4, 1024, 64, 64, 256, 1, 0),       # C4 conv1 1x1: conv1x1_bf16_kernel, 16 stages
+])
+def test_bf16_kernels_at_full_layer_sizes_against_fp32(shape):
+    """The bf16 kernels at the layer sizes of BASELINE configs[2] (XCD-aware launches with thousands of workgroups,
+    pixel splits, tail tiles) against the exact fp32 kernels on the same inputs: the relative error of forward, data
+    gradient and weight gradient stays at the rounding of the two bf16 operands (2^-9 each, averaged down by the
+    reduction) -- a mis-mapped tile or split shows up as an O(1) error."""
+    from feature_intertwiner_amd import conv as C
+    N, Cin, H, W, Cout, R, pd = shape
+    g = torch.Generator(device=DEV).manual_seed(sum(shape))
+    x = torch.randn(N, Cin, H, W, device=DEV, generator=g)
+    w = (torch.randn(Cout, Cin, R, R, device=DEV, generator=g) / math.sqrt(Cin * R * R)).contiguous(
+        memory_format=torch.channels_last)
+    gy = torch.randn(N, Cout, H, W, device=DEV, generator=g)
+    out = {}
+    for prec in ("fp32", "bf16"):
+        C.set_conv_precision(prec)
+        try:
+            xg = x.clone().requires_grad_(True)
+            wg = w.clone(memory_format=torch.channels_last).requires_grad_(True)
+            y = C.conv2d(xg, wg, None, (1, 1), (pd, pd))
+            y.backward(gy)
+            out[prec] = (y.detach(), xg.grad, wg.grad)
+        finally:
+            C.set_conv_precision("fp32")
+    for name, a, b in zip(("y", "dx", "dw"), out["fp32"], out["bf16"]):
+        rel = ((a.double() - b.double()).norm() / a.double().norm()).item()
+        assert rel < 6e-3, (name, rel)                      # 2^-9 * sqrt(2) = 2.8e-3 for independent roundings
+        assert rel > 1e-5, (name, rel)                      # ... and the bf16 kernels really ran
