@@ -271,6 +271,71 @@ def cpu_baseline(model, batch, log_entries, shape_log=None):
             "detail_ms": {k: round(v, 1) for k, v in detail.items()}, "host_cpus": os.cpu_count()}
 
 
+def _self_launch(n):
+    """Re-run this command line under `python -m torch.distributed.run --nnodes=1 --nproc-per-node n` and
+    return the child job's JSON line."""
+    import socket
+    import subprocess
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    share = os.environ.get("FI_BENCH_SHARE_GPU") == "1"
+    have = torch.cuda.device_count()
+    if have < n and not share:
+        raise SystemExit("--gpus %d, but only %d GPU(s) are visible" % (n, have))
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: needed by RCCL between processes on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, env=env)          # stderr passes through
+    lines = [l for l in r.stdout.decode("utf-8", "replace").splitlines() if l.startswith("{")]
+    if r.returncode != 0 or not lines:
+        sys.stderr.write(r.stdout.decode("utf-8", "replace"))
+        raise SystemExit("the %d-rank job failed (exit code %d)" % (n, r.returncode))
+    return lines[-1]
+
+
+def _overlap_report(profile, steps):
+    """GradientBuckets.profile (HIP events on the main and the communication stream) -> how much of the gradient
+    exchange ran inside the backward window.  Times in ms, averaged per step."""
+    per_step, cur = [], None
+    for rec in profile:
+        if rec[0] == "backward_start":
+            cur = {"start": rec[1], "buckets": []}
+            per_step.append(cur)
+        elif cur is not None and rec[0] == "bucket":
+            cur["buckets"].append(rec[1:])
+        elif cur is not None and rec[0] in ("backward_end", "reduced"):
+            cur[rec[0]] = rec[1]
+    per_step = [st for st in per_step if "backward_end" in st and "reduced" in st and st["buckets"]]
+    if not per_step:
+        return None
+    acc = {"backward_ms": 0.0, "comm_busy_ms": 0.0, "comm_inside_backward_ms": 0.0, "exposed_after_backward_ms": 0.0,
+           "first_bucket_at_ms": 0.0}
+    for st in per_step:
+        bwd = st["start"].elapsed_time(st["backward_end"])
+        acc["backward_ms"] += bwd
+        acc["exposed_after_backward_ms"] += max(0.0, st["backward_end"].elapsed_time(st["reduced"]))
+        acc["first_bucket_at_ms"] += st["start"].elapsed_time(st["buckets"][0][2])
+        for bi, nbytes, e0, e1 in st["buckets"]:
+            t0, t1 = st["start"].elapsed_time(e0), st["start"].elapsed_time(e1)
+            acc["comm_busy_ms"] += t1 - t0
+            acc["comm_inside_backward_ms"] += max(0.0, min(t1, bwd) - min(t0, bwd))
+    n = float(len(per_step))
+    out = {k: round(v / n, 3) for k, v in acc.items()}
+    out["steps"] = len(per_step)
+    out["buckets_per_step"] = len(per_step[0]["buckets"])
+    out["bytes_per_step"] = int(sum(b[1] for b in per_step[0]["buckets"]))
+    out["frac_inside_backward"] = round(out["comm_inside_backward_ms"] / max(out["comm_busy_ms"], 1e-9), 4)
+    out["method"] = ("HIP events: backward_start / backward_end on the compute stream, one pair around every bucket's "
+                     "in-place RCCL all-reduce on the communication stream (the collective's busy time includes "
+                     "waiting for the slowest rank); exposed = compute stream idle from the end of backward until "
+                     "the last bucket is reduced")
+    return out
+
+
 def main():
     # The contract is ONE JSON line on stdout.  RCCL prints a version banner to the C-level stdout when the
     # first communicator is created, and libraries may print more: everything written to fd 1 while the
@@ -325,8 +390,12 @@ def _main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+        if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+            # `python bench.py --gpus N` without a launcher: start the N ranks ourselves, exactly as the documented
+            # command does (one process per GPU under torch.distributed.run on 127.0.0.1); rank 0 of the child job
+            # prints the JSON line, which is passed through
+            return _self_launch(args.gpus)
+        raise SystemExit("--gpus %d does not match WORLD_SIZE=%d of the launcher" % (args.gpus, world))
     # FI_BENCH_SHARE_GPU=1 (testing only): all ranks share cuda:0 over the gloo backend, to exercise
     # the multi-process code path on a single-GPU box; the real launch is one rank per GPU over RCCL
     share = os.environ.get("FI_BENCH_SHARE_GPU") == "1"
@@ -385,6 +454,12 @@ def _main():
         torch.cuda.synchronize()
         return None
 
+    if sync is not None:
+        # engine start-up, not part of the W warm-up steps: RCCL communicator + channel set-up happen at the first
+        # collective, and GradientBuckets issues its buckets from autograd hooks (overlapped) only once it has seen
+        # which parameters produce gradients for ABSENT_STEPS steps of this graph variant
+        for _ in range(sync.ABSENT_STEPS + 1):
+            step()
     for _ in range(args.warmup):
         terms = step()
     # ---- the timed region: exactly K steps, nothing recorded (no event timing, no logging) ----------
@@ -422,10 +497,28 @@ def _main():
     shape_log = ficonv.SHAPE_LOG
     ficonv.SHAPE_LOG = None
     shape_log = shape_log[:len(shape_log) // prof_steps]       # the convolutions of ONE step
+    per_rank_ms, rccl_ranks, overlap = None, None, None
+    if sync is not None and not share:
+        # a further pass with HIP events around every bucket's collective: how much of the exchange hides in backward
+        sync.profile = []
+        for _ in range(prof_steps):
+            step()
+        torch.cuda.synchronize()
+        overlap = _overlap_report(sync.profile, prof_steps)
+        sync.profile = None
     if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        mine = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        per_rank_ms = [round(float(t.item()) / args.steps * 1e3, 3) for t in every]
+        elapsed = max(float(t.item()) for t in every)                 # MAX over ranks
+        # which physical GPU every rank ran on (an all-gather of device UUIDs): N distinct devices = N RCCL ranks
+        ids = [None] * world
+        props = torch.cuda.get_device_properties(dev)
+        dist.all_gather_object(ids, {"rank": rank, "device": torch.cuda.current_device(), "name": props.name,
+                                     "uuid": str(getattr(props, "uuid", "")), "pid": os.getpid()})
+        rccl_ranks = {"backend": dist.get_backend(), "world_size": world, "ranks": ids,
+                      "distinct_devices": len(set((d["uuid"] or d["device"]) for d in ids))}
 
     if rank == 0:
         global_batch = args.batch_per_gpu * world
@@ -583,6 +676,13 @@ def _main():
                                         % (prof_steps, prof_elapsed / prof_steps * 1e3)},
             "kernels": kern,
         }
+        if world > 1 or force_dp:
+            out["data_parallel"] = {
+                "engine": "one process per GPU; gradients live in one arena per rank and every ~25 MB bucket is a "
+                          "contiguous slice of it, all-reduced IN PLACE on a side HIP stream from autograd hooks; one "
+                          "~1 MB all-reduce of the intertwiner class statistics in forward",
+                "buckets": len(sync.buckets), "bucket_bytes": sync.bucket_bytes(),
+                "ms_per_step_per_rank": per_rank_ms, "rccl_ranks": rccl_ranks, "overlap": overlap}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 entries = [e for e in log if e["pyramid"] and e["crop"] in (7, 14) and e["boxes"].size(0) ==

@@ -188,14 +188,24 @@ def require_cuda(*tensors):
 _CONST = {}
 
 
+def device_key(device):
+    """'cuda' without an index means "the current device": resolve it, so that a cache keyed on the result
+    cannot hand a tensor of another GPU to a later caller."""
+    device = torch.device(device)
+    if device.type == "cuda" and device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    return str(device)
+
+
 def const_tensor(values, device, dtype=torch.float32):
     """Small constant (python numbers / numpy array) as a device tensor, created ONCE per (values, device):
     torch.tensor(list, device=gpu) inside the step is a pageable host-to-device copy, i.e. a full stream
-    synchronisation every time."""
+    synchronisation every time.  The tensor is SHARED by every caller: read-only by contract (never the
+    target of an in-place operation)."""
     try:
-        key = (tuple(float(v) for v in values), str(device), dtype)
+        key = (tuple(float(v) for v in values), device_key(device), dtype)
     except TypeError:
-        key = ((float(values),), str(device), dtype)
+        key = ((float(values),), device_key(device), dtype)
         values = [values]
     t = _CONST.get(key)
     if t is None:

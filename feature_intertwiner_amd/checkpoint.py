@@ -26,20 +26,34 @@ def save_model(model, path, epoch, iter, loss_data=None):
                 'loss_data': [] if loss_data is None else loss_data}, path)
 
 
+def _numpy_safe_globals():
+    """Allow-list for the two ndarrays in the file.  torch matches a pickled global by the STRING
+    `module.name` stored in the file, and the reference's checkpoints were written under numpy 1.x, where
+    the array constructor pickles as 'numpy.core.multiarray._reconstruct'; numpy 2 renamed the module to
+    'numpy._core.multiarray' (the old path is a deprecated alias whose functions report the new
+    __module__), so both spellings are registered explicitly as (callable, 'full.path') pairs."""
+    try:
+        import numpy._core.multiarray as ma          # numpy >= 2
+    except ImportError:                               # numpy 1.x
+        import numpy.core.multiarray as ma
+    safe = [np.ndarray, np.dtype,
+            (ma._reconstruct, "numpy.core.multiarray._reconstruct"),
+            (ma._reconstruct, "numpy._core.multiarray._reconstruct")]
+    if hasattr(ma, "scalar"):                         # 0-d numpy scalars (e.g. an np.float64 in loss_data)
+        safe += [(ma.scalar, "numpy.core.multiarray.scalar"), (ma.scalar, "numpy._core.multiarray.scalar")]
+    # numpy >= 1.25 pickles dtypes through their per-type classes (numpy.dtypes.Float32DType ...)
+    safe += list({type(np.dtype(t)) for t in (np.float16, np.float32, np.float64, np.int8, np.uint8, np.int16,
+                                               np.int32, np.int64, np.bool_)})
+    return safe
+
+
 def _read(path, map_location, trusted):
     """The file holds tensors, python scalars/lists and two numpy arrays.  It is read with the
     restricted unpickler (weights_only=True, numpy's array reconstruction allow-listed); a
     third-party .pth that needs arbitrary pickles loads only with trusted=True."""
     if trusted:
         return torch.load(path, map_location=map_location, weights_only=False)
-    import numpy.core.multiarray as _ma        # numpy < 2 path of the same objects
-    safe = [np.ndarray, np.dtype, _ma._reconstruct]
-    try:
-        safe += [type(np.dtype(np.float32)), type(np.dtype(np.float64)), type(np.dtype(np.int64))]
-        import numpy._core.multiarray as _ma2
-        safe.append(_ma2._reconstruct)
-    except Exception:
-        pass
+    safe = _numpy_safe_globals()
     with torch.serialization.safe_globals(safe):
         return torch.load(path, map_location=map_location, weights_only=True)
 

@@ -19,7 +19,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import _lib
+from . import _lib, grad_arena
 
 # bench.py sets this to a dict to accumulate the algorithmic flops (2*N*Cout*OH*OW*Cin*R*S) of
 # every launch, keyed by the device kernel instance (see _lib.conv_kernel_key).
@@ -344,6 +344,10 @@ def _prepare_step(model, grad_on):
     dev = next(model.parameters()).device
     if dev.type != "cuda":
         return
+    if len(_WB) > 4096:
+        # bf16 copies of weights that were temporaries (the deconv's reshaped weight, transposes made on the fly)
+        # keep their source alive; inference loops never bump a parameter version, so bound the cache here
+        _WB.clear()
     plan = _PLAN.get(model)
     ptrs = tuple(p.data_ptr() for p in model.parameters())
     if plan is None or plan["ptrs"] != ptrs:
@@ -366,16 +370,18 @@ def _prepare_step(model, grad_on):
             desc[i] = (m.weight.data_ptr(), wt.data_ptr(), co, ci, r * s_, 0, base)
             base += r * s_ * ((co + 31) // 32) * ((ci + 31) // 32)
         table = torch.from_numpy(desc.view(np.uint8).copy()).to(dev) if len(tr) else None
-        slots, off = {}, 0
+        # gradient slots: the model-wide arena layout (grad_arena.py) -- every trainable parameter has one, in
+        # bucket order; the kernels' keys are the weight's / the BatchNorm gamma's address
+        layout = grad_arena.get_layout(model)
+        slots = {}
         for m in convs:
-            if m.weight.requires_grad:
-                slots[("dw", m.weight.data_ptr())] = (off, m.weight.numel())
-                off += (m.weight.numel() + 3) // 4 * 4
+            if m.weight.requires_grad and m.weight in layout.slot:
+                slots[("dw", m.weight.data_ptr())] = layout.slot[m.weight]
         for bn in [m for m in model.modules() if isinstance(m, nn.BatchNorm2d)]:
-            slots[("bn", bn.weight.data_ptr())] = (off, 3 * bn.num_features)
-            off += (3 * bn.num_features + 3) // 4 * 4
+            if bn in layout.bn_slot:
+                slots[("bn", bn.weight.data_ptr())] = (layout.bn_slot[bn], 3 * bn.num_features)
         plan = {"ptrs": tuple(p.data_ptr() for p in model.parameters()), "tr": tr, "wts": wts, "table": table,
-                "tiles": base, "slots": slots, "arena_floats": off, "versions": None}
+                "tiles": base, "slots": slots, "layout": layout, "versions": None}
         _PLAN[model] = plan
     versions = tuple(m.weight._version for m in plan["tr"])
     if plan["table"] is not None and (plan["versions"] != versions or not all(
@@ -388,8 +394,16 @@ def _prepare_step(model, grad_on):
             _WT[m.weight.data_ptr()] = (wt, m.weight._version)
         plan["versions"] = versions
         _WB.clear()          # the W^T tensors were rewritten in place (no version bump): drop their bf16 copies
-    if grad_on and plan["arena_floats"]:
-        _ARENA["buf"] = torch.zeros(plan["arena_floats"], device=dev, dtype=torch.float32)
+    layout = plan["layout"]
+    if grad_on and layout.total:
+        buf = layout.buffer(dev)
+        if layout.live_gradients(buf):
+            # gradients of an earlier backward pass are still attached (accumulation without zero_grad): they live
+            # in the arena, so it cannot be cleared -- this pass's kernels allocate their own outputs and autograd
+            # adds them to the attached gradients
+            _ARENA["buf"] = None
+        else:
+            _ARENA["buf"] = layout.zero(dev)         # ONE fill per step, same addresses every step
         _ARENA["slots"] = plan["slots"]
         _ARENA["used"] = set()
     else:
@@ -513,9 +527,11 @@ _ONES = {}
 
 
 def _ones(n, device):
-    t = _ONES.get((n, str(device)))
+    """Shared, read-only (see _lib.const_tensor)."""
+    key = (n, _lib.device_key(device))
+    t = _ONES.get(key)
     if t is None:
-        t = _ONES[(n, str(device))] = torch.ones(n, device=device, dtype=torch.float32)
+        t = _ONES[key] = torch.ones(n, device=device, dtype=torch.float32)
     return t
 
 

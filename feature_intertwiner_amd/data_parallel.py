@@ -5,9 +5,10 @@ step, gathers all outputs to GPU 0 and runs the optimizer there.
 
 Here every rank owns a full replica and its shard of the minibatch (images are
 independent through the whole detector), so the only exchanges per step are
-  1. an all-reduce (mean) of the gradients, bucketed (~25 MB flat buffers filled in
-     reverse parameter order as autograd produces the gradients) and issued from a side
-     HIP stream so that RCCL traffic over xGMI overlaps the rest of backward;
+  1. an all-reduce (mean) of the gradients, bucketed (~25 MB contiguous slices of the
+     model's gradient arena, laid out in the order autograd produces the gradients, reduced
+     IN PLACE) and issued from a side HIP stream so that RCCL traffic over xGMI overlaps
+     the rest of backward;
   2. one small all-reduce (sum) of the intertwiner class statistics (feat*cnt, cnt),
      ~1 MB -- algebraically the reference's gather-to-GPU-0 + _merge_feat_vec
      (lib/model.py:217-224).
@@ -16,6 +17,8 @@ the gloo backend (tests/test_data_parallel_gloo.py).
 """
 import torch
 import torch.distributed as dist
+
+from . import grad_arena
 
 
 class _AllReduceSumIdentityGrad(torch.autograd.Function):
@@ -59,55 +62,45 @@ def all_reduce_statistics(feat_sum, cnt_sum, group=None):
     return flat[:n].view_as(feat_sum), flat[n:].view_as(cnt_sum)
 
 
-def _mem_flat(t):
-    """1-D view of a dense tensor in MEMORY order (no copy): gradients of channels-last parameters are
-    channels-last themselves, and flattening them in logical order would cost a strided copy per tensor
-    on the way into and out of every bucket."""
-    if t.is_contiguous():
-        return t.view(-1)
-    if t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last):
-        return t.permute(0, 2, 3, 1).reshape(-1)          # a view for channels-last strides
-    return t.reshape(-1)
-
-
 class GradientBuckets(object):
-    """Bucketed, overlapped gradient all-reduce.
+    """Bucketed, overlapped gradient all-reduce, IN PLACE on the model's gradient arena.
 
         sync = GradientBuckets(model)
         ...
         sync.begin(key)      # optional: names the graph variant of this step (e.g. do_meta on/off)
         loss.backward()      # buckets launch from autograd hooks as they fill
-        sync()               # waits, writes the rank-mean gradients back into p.grad
+        sync()               # waits; p.grad (views of the arena) now hold the rank-mean gradients
+
+    Every trainable parameter owns a slot of ONE persistent buffer (grad_arena.ArenaLayout), laid out in the
+    order autograd produces gradients; a bucket is a contiguous ~25 MB slice of it.  The weight-gradient and
+    fused-BN-backward kernels accumulate straight into their slots, so for nearly all bytes there is nothing
+    to pack: when the last gradient of a bucket has arrived, the few gradients autograd allocated elsewhere
+    (library GEMMs of the head FCs, the OT module) are moved into their slots with one multi-tensor copy and
+    `.grad` is re-pointed at the slot, then the slice is all-reduced where it lies, on a side HIP stream, while
+    backward continues.  `sync()` scales the buffer by 1/world once -- no flat staging buffers, no copy back.
 
     Parameters without a gradient.  The autograd graph has static shapes and the same structure on
     every rank, so which parameters receive a gradient depends only on the graph variant `key`.
-      * A parameter whose gradient is None at the end of backward keeps `.grad is None` (it rides
-        through the collective as zeros: the bucket layout is fixed) -- SGD then applies neither weight
+      * A parameter whose gradient is None at the end of backward keeps `.grad is None` (its slot stays
+        zero and rides through the collective: the layout is fixed) -- SGD then applies neither weight
         decay nor momentum to it, exactly as on one GPU and in the reference.
       * Buckets are issued strictly in order, so a bucket holding such a parameter would stall every
-        later bucket until the end of backward.  The first step of a `key` waits for everything; later
-        steps do not wait for parameters that had no gradient under the same `key`.  A gradient that
-        shows up for a parameter that was not waited for is a programming error and raises.
+        later bucket until the end of backward.  A parameter that had no gradient in ABSENT_STEPS consecutive
+        steps of a `key` is no longer waited for under that key.  A gradient that shows up for a parameter whose
+        bucket has already been issued raises: the graph must be data-independent per key.
       * Cross-rank consistency (a parameter with a gradient on one rank and none on another) cannot be
-        acted on without a host synchronisation; one flag per parameter travels with each bucket, a
+        acted on without a host synchronisation; one flag per parameter travels at the end of each bucket, a
         device-side counter accumulates disagreements, and `check()` (tests, end of a run) raises on it.
     """
 
-    def __init__(self, module, bucket_bytes=25 * 1024 * 1024, group=None):
+    ABSENT_STEPS = 2
+
+    def __init__(self, module, bucket_bytes=None, group=None):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        params = [p for p in module.parameters() if p.requires_grad]
-        params.reverse()                      # gradients arrive roughly in reverse registration order
-        self.buckets = []
-        cur, size = [], 0
-        for p in params:
-            cur.append(p)
-            size += p.numel() * p.element_size()
-            if size >= bucket_bytes:
-                self.buckets.append(cur)
-                cur, size = [], 0
-        if cur:
-            self.buckets.append(cur)
+        self.layout = grad_arena.get_layout(module, bucket_bytes)
+        self.buckets = [b.params for b in self.layout.buckets]
+        params = self.layout.params
         self.bucket_of = {}
         for bi, b in enumerate(self.buckets):
             for p in b:
@@ -115,102 +108,164 @@ class GradientBuckets(object):
         self.device = params[0].device if params else torch.device("cpu")
         self.use_stream = self.device.type == "cuda"
         self.comm_stream = torch.cuda.Stream(device=self.device) if self.use_stream else None
+        self.stream_ordered = False  # RCCL: completion is a stream dependency; other backends: host wait in __call__
         self.launch_log = None       # set to [] to record when each bucket is issued (tests)
-        self._absent = {}            # key -> set of parameters that produced no gradient under that key
+        self.profile = None          # set to [] to record HIP events around every collective (bench.py, RCCL only)
+        self._absent_run = {}        # key -> {parameter: consecutive steps without a gradient}
         self._key = None
         self._violations = torch.zeros((), device=self.device)
         self._flag_cache = {}
+        self._flag_index = None
+        self._started = False
         self._reset()
         self.active = self.world > 1 or (dist.is_initialized() and _force_collectives())
         if self.active:
+            self.stream_ordered = self.use_stream and dist.get_backend(group) == "nccl"
+            self.arena = self.layout.buffer(self.device)
+            idx = [i for b in self.layout.buckets for i in range(b.flag_off, b.flag_off + len(b.params))]
+            self._flag_index = torch.tensor(idx, dtype=torch.long, device=self.device)
             for p in params:
                 p.register_post_accumulate_grad_hook(self._on_grad)
+
+    def bucket_bytes(self):
+        return [4 * (b.end - b.start) for b in self.layout.buckets]
 
     def begin(self, key=None):
         """Call before backward.  `key` identifies the graph variant (anything hashable)."""
         self._key = key
         self._reset()
+        self._start()
+
+    def _start(self):
+        """First touch of a backward pass: the arena must be clear (conv.prepare_step did it at the start of the
+        forward pass of a GPU model; models without that step -- the CPU tests -- are cleared here)."""
+        if self.active and not self._started:
+            self._started = True
+            self.arena = self.layout.buffer(self.device)
+            if not self.layout.fresh:
+                self.layout.zero(self.device)
+            if self.profile is not None and self.use_stream:
+                e = torch.cuda.Event(enable_timing=True)
+                e.record(torch.cuda.current_stream(self.device))
+                self.profile.append(("backward_start", e))
+
+    def _not_waited(self):
+        run = self._absent_run.get(self._key)
+        if not run:
+            return ()
+        return {p for p, n in run.items() if n >= self.ABSENT_STEPS}
 
     def _reset(self):
-        absent = self._absent.get(self._key, ())
-        self.pending = [sum(1 for p in b if p not in absent) for b in self.buckets]
+        skip = self._not_waited()
+        self._skip = skip
+        self.pending = [sum(1 for p in b if p not in skip) for b in self.buckets]
         self.next_to_launch = 0
-        self.inflight = []        # (bucket index, flat buffer, work handle, which params had a gradient)
+        self.inflight = []        # (bucket index, work handle, which params had a gradient)
         self._launched = set()
+        self._started = False
 
     def _on_grad(self, p):
+        self._start()
         bi = self.bucket_of[p]
         if bi in self._launched:
             raise RuntimeError("GradientBuckets: a gradient arrived for a parameter of bucket %d after the bucket was "
                                "issued -- the set of parameters that receive gradients changed without a new "
                                "begin(key)" % bi)
-        if p not in self._absent.get(self._key, ()):
+        if p not in self._skip:
             self.pending[bi] -= 1
         self._launch_ready()
 
+    @torch.no_grad()
     def _launch_ready(self, force=False):
         # strictly in bucket order, so every rank issues the same sequence of collectives
+        lay, buf = self.layout, self.arena
         while self.next_to_launch < len(self.buckets) and (force or self.pending[self.next_to_launch] <= 0):
             bi = self.next_to_launch
             self.next_to_launch += 1
             self._launched.add(bi)
+            b = lay.buckets[bi]
             if self.launch_log is not None:      # (bucket, gradients still to come when it was issued)
                 self.launch_log.append((bi, sum(max(n, 0) for n in self.pending[bi + 1:])))
-            # a parameter without a gradient contributes zeros (the bucket layout is fixed); one flag per
-            # parameter rides along for the cross-rank consistency counter
-            had = [p.grad is not None for p in self.buckets[bi]]
-            grads = [p.grad if h else torch.zeros_like(p) for p, h in zip(self.buckets[bi], had)]
-            # the flag vector of a (bucket, pattern) pair is built once and kept on the device: a host-to-device
-            # copy from a hook would synchronise the host with the main stream at every bucket
+            had = [p.grad is not None for p in b.params]
+            # gradients that autograd allocated outside the arena move into their slots (one multi-tensor copy);
+            # a parameter without a gradient leaves its slot zero
+            dst, src, moved = [], [], []
+            for p, h in zip(b.params, had):
+                if h and not lay.holds(p, p.grad, buf):
+                    v = lay.view(p, buf)
+                    if v is None:
+                        raise RuntimeError("GradientBuckets: parameter with unsupported strides %s" % (p.stride(),))
+                    dst.append(v)
+                    src.append(p.grad)
+                    moved.append((p, v))
+            if dst:
+                torch._foreach_copy_(dst, src)
+                for p, v in moved:
+                    p.grad = v
+            # one flag per parameter rides along for the cross-rank consistency counter; the flag vector of a
+            # (bucket, pattern) pair is built once and kept on the device: a host-to-device copy from a hook
+            # would synchronise the host with the main stream at every bucket
             fkey = (bi, tuple(had))
             flags = self._flag_cache.get(fkey)
             if flags is None:
-                flags = torch.tensor([1.0 if h else 0.0 for h in had], dtype=grads[0].dtype, device=self.device)
+                flags = torch.tensor([1.0 if h else 0.0 for h in had], dtype=torch.float32, device=self.device)
                 self._flag_cache[fkey] = flags
-            pieces = [_mem_flat(g) for g in grads] + [flags]
+            buf[b.flag_off:b.flag_off + len(had)].copy_(flags)
+            piece = buf[b.start:b.end]
             if self.use_stream:
                 self.comm_stream.wait_stream(torch.cuda.current_stream(self.device))
                 with torch.cuda.stream(self.comm_stream):
-                    flat = torch.cat(pieces)
-                    for g in grads:
-                        g.record_stream(self.comm_stream)
-                    work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                    ev = None
+                    if self.profile is not None and self.stream_ordered:
+                        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                        ev[0].record(self.comm_stream)
+                    work = dist.all_reduce(piece, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                    if self.stream_ordered:
+                        work.wait()              # RCCL: makes comm_stream wait for the collective; the host goes on
+                        work = None
+                        if ev is not None:
+                            ev[1].record(self.comm_stream)
+                            self.profile.append(("bucket", bi, 4 * (b.end - b.start), ev[0], ev[1]))
             else:
-                flat = torch.cat(pieces)
-                work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-            self.inflight.append((bi, flat, work, had, flags))
+                work = dist.all_reduce(piece, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self.inflight.append((bi, work, had))
 
+    @torch.no_grad()
     def __call__(self):
         if not self.active:
             return
-        self._launch_ready(force=True)        # whatever is left (first step of a key; trailing bucket)
-        inv = 1.0 / float(self.world)
-        absent = set()
-        for bi, flat, work, had, flags in self.inflight:
-            work.wait()
-            if self.use_stream:
-                cur = torch.cuda.current_stream(self.device)
-                cur.wait_stream(self.comm_stream)
-                flat.record_stream(cur)
-            n = len(had)
-            # some rank had a gradient where this one had none (or vice versa): replicas would diverge
-            self._violations += ((flat[-n:] > 0) & (flat[-n:] < self.world)).sum()
-            flat[:-n].mul_(inv)
-            dst, src, off = [], [], 0
+        self._start()
+        if self.profile is not None and self.use_stream:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record(torch.cuda.current_stream(self.device))
+            self.profile.append(("backward_end", e))
+        self._launch_ready(force=True)        # whatever is left (first steps of a key; trailing bucket)
+        for bi, work, had in self.inflight:
+            if work is not None:
+                work.wait()
+        if self.use_stream:
+            torch.cuda.current_stream(self.device).wait_stream(self.comm_stream)
+            if self.profile is not None:
+                e = torch.cuda.Event(enable_timing=True)
+                e.record(torch.cuda.current_stream(self.device))
+                self.profile.append(("reduced", e))
+        buf = self.arena
+        # some rank had a gradient where this one had none (or vice versa): replicas would diverge
+        f = buf[self._flag_index]
+        self._violations += ((f > 0.5) & (f < self.world - 0.5)).sum()
+        if self.world > 1:
+            buf.mul_(1.0 / float(self.world))         # ONE pass over the arena: sums -> means, in place
+        run = self._absent_run.setdefault(self._key, {})
+        for bi, work, had in self.inflight:
             for p, h in zip(self.buckets[bi], had):
-                k = p.numel()
                 if h:
-                    dst.append(_mem_flat(p.grad))             # memory order, as it was packed
-                    src.append(flat[off:off + k])
+                    run.pop(p, None)
                 else:
                     # no gradient here: .grad stays None, exactly as on one GPU
                     if p.grad is not None:
                         raise RuntimeError("GradientBuckets: gradient produced after its bucket was issued")
-                    absent.add(p)
-                off += k
-            if dst:
-                torch._foreach_copy_(dst, src)                # a few launches per bucket, not one per parameter
-        self._absent[self._key] = absent
+                    run[p] = run.get(p, 0) + 1
+        self.layout.fresh = False
         self._reset()
 
     def check(self):

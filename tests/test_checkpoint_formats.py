@@ -102,3 +102,33 @@ def test_resume_reproduces_the_next_step(tmp_path):
     other = MaskRCNN(cfg3).to(DEV)
     load_model(other, path, map_location=DEV)
     assert other.feature_buffer.buffer.shape[0] == 3 and float(other.feature_buffer.buffer_cnt.sum()) == 0
+
+
+def test_checkpoint_written_under_numpy1_loads_with_the_restricted_unpickler(tmp_path):
+    """The reference's checkpoints hold `buffer` / `buffer_cnt` as ndarrays pickled by numpy 1.x
+    (tools/utils.py:576-586): the constructor's global is spelled 'numpy.core.multiarray', not numpy 2's
+    'numpy._core.multiarray'.  The file is rewritten to the old spelling and must load with weights_only=True."""
+    import io
+    import zipfile
+    from feature_intertwiner_amd.checkpoint import _read
+    buf = np.arange(24, dtype=np.float32).reshape(1, 3, 8)
+    cnt = np.ones((1, 1, 8), dtype=np.float32)
+    src = str(tmp_path / "new.pth")
+    torch.save({'state_dict': {'w': torch.arange(4.)}, 'epoch': 3, 'iter': 7, 'buffer': buf, 'buffer_cnt': cnt,
+                'loss_data': [0.5]}, src)
+    dst = str(tmp_path / "numpy1.pth")
+    swapped = 0
+    with zipfile.ZipFile(src) as zin, zipfile.ZipFile(dst, "w", zipfile.ZIP_STORED) as zout:
+        for item in zin.infolist():
+            data = zin.read(item.filename)
+            if item.filename.endswith("data.pkl"):
+                # protocol-2 GLOBAL opcode: b"cnumpy._core.multiarray\n_reconstruct\n" -> the numpy 1.x module path
+                swapped = data.count(b"numpy._core.multiarray")
+                data = data.replace(b"numpy._core.multiarray", b"numpy.core.multiarray")
+            zout.writestr(item, data)
+    if np.lib.NumpyVersion(np.__version__) >= "2.0.0":
+        assert swapped >= 1
+    for path in (src, dst):
+        ck = _read(path, "cpu", False)
+        assert np.array_equal(ck['buffer'], buf) and np.array_equal(ck['buffer_cnt'], cnt)
+        assert (ck['epoch'], ck['iter'], ck['loss_data']) == (3, 7, [0.5]) and torch.equal(ck['state_dict']['w'], torch.arange(4.))

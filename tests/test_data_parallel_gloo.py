@@ -82,7 +82,16 @@ def _worker(rank, world, port, out, asymmetric=False):
         dist.destroy_process_group()
         return
     sync.check()                                        # every rank agreed on who got gradients
-    out[rank] = {"grads": {n: (None if p.grad is None else p.grad.detach().numpy().copy())
+    # in place: every gradient IS its slot of the arena (no flat staging buffer, no copy back), bucket b is the
+    # contiguous slice [start, end) and the buckets tile the arena in issue order
+    lay, buf = sync.layout, sync.arena
+    in_arena = all(p.grad is None or lay.holds(p, p.grad, buf) for p in net.parameters())
+    tiled = all(a.end == b.start for a, b in zip(lay.buckets, lay.buckets[1:])) and lay.buckets[0].start == 0 \
+        and lay.buckets[-1].end == lay.total
+    out[rank] = {"in_arena": in_arena and tiled, "order": [b for b, _ in sync.launch_log],
+                 "absent_flags": [float(buf[b.flag_off + i]) for b in lay.buckets for i, q in enumerate(b.params)
+                                  if q.grad is None],
+                 "grads": {n: (None if p.grad is None else p.grad.detach().numpy().copy())
                            for n, p in net.named_parameters()},
                  "s_sum": s_sum.detach().numpy().copy(), "c_sum": c_sum.detach().numpy().copy(),
                  "params": [p.data.numpy().copy() for p in net.parameters()]}
@@ -90,8 +99,11 @@ def _worker(rank, world, port, out, asymmetric=False):
     dist.destroy_process_group()
 
 
-def test_two_rank_update_equals_reference_rule():
-    world = 2
+import pytest
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_update_equals_reference_rule(world):
     mgr = mp.Manager()
     out = mgr.dict()
     mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
@@ -107,8 +119,12 @@ def test_two_rank_update_equals_reference_rule():
     ref = {n: p.grad for n, p in net.named_parameters()}
     import numpy as np
     for r in range(world):
-        assert np.allclose(out[r]["s_sum"], s_sum.detach().numpy(), rtol=1e-6, atol=1e-6)
-        assert np.array_equal(out[r]["c_sum"], np.full((1, 5), 3.0, np.float32))
+        assert out[r]["in_arena"], "gradients must be views of the arena, reduced in place"
+        assert out[r]["order"] == out[0]["order"] and len(out[r]["order"]) == 3 * len(set(out[r]["order"]))
+        assert out[r]["order"][:len(set(out[r]["order"]))] == sorted(set(out[r]["order"]))     # strictly in bucket order
+        assert out[r]["absent_flags"] and all(f == 0.0 for f in out[r]["absent_flags"])       # no rank had those gradients
+        assert np.allclose(out[r]["s_sum"], s_sum.detach().numpy(), rtol=1e-5, atol=1e-5)
+        assert np.array_equal(out[r]["c_sum"], np.full((1, 5), world * (world + 1) / 2.0, np.float32))
         for n, b in ref.items():
             a = out[r]["grads"][n]
             if b is None:
@@ -119,8 +135,9 @@ def test_two_rank_update_equals_reference_rule():
             assert np.array_equal(a, b.data.numpy())    # broadcast made the replicas identical
     assert ref["unused.weight"] is None and ref["meta.weight"] is not None and ref["rank1_only"] is None
     for n in ref:
-        a, b = out[0]["grads"][n], out[1]["grads"][n]
-        assert (a is None and b is None) or np.array_equal(a, b)      # every rank holds the same averaged gradient
+        for r in range(1, world):
+            a, b = out[0]["grads"][n], out[r]["grads"][n]
+            assert (a is None and b is None) or np.array_equal(a, b)  # every rank holds the same averaged gradient
 
 
 def test_ranks_disagreeing_on_gradient_pattern_is_detected():

@@ -47,24 +47,30 @@ VARIANTS = {
 }
 
 
-def _make(rank_for_data, variant):
+# (backbone, image size, RoIs per image, Sinkhorn iterations): the small detector of the rule tests, and the
+# per-rank workload of BASELINE configs[3] (ResNet-101-FPN, 2 x 1024^2 per rank, 512 RoIs/image, L=50)
+SIZES = {"small": ("resnet50", 256, 64, 5), "full": ("resnet101", 1024, 512, 50)}
+
+
+def _make(rank_for_data, variant, size="small"):
     """Model (identical on every caller: seed) + the data shard / hooks of rank `rank_for_data`."""
     from feature_intertwiner_amd.config import make_config
     from feature_intertwiner_amd.model import MaskRCNN
     choice, cost, _ = VARIANTS[variant]
+    backbone, img, rois, L = SIZES[size]
     torch.manual_seed(1234)
-    cfg = make_config("resnet50", 256, 2, 64, dev_switch=True, loss_choice=choice, ot_L=5, gpu_count=WORLD,
+    cfg = make_config(backbone, img, 2, rois, dev_switch=True, loss_choice=choice, ot_L=L, gpu_count=WORLD,
                       loss_fac=1000.0 if choice == "ot" else 50.0)
     model = MaskRCNN(cfg).to(DEV)
     if cost is not None:
         model.ot_loss.C_form = cost
-    return cfg, model, _shard(rank_for_data)
+    return cfg, model, _shard(rank_for_data, img)
 
 
-def _shard(rank):
+def _shard(rank, img=256):
     from feature_intertwiner_amd.synthetic import SyntheticProposals, synthetic_batch
-    batch = synthetic_batch(2, 256, device=DEV, seed=2000 + rank)
-    hook = SyntheticProposals(batch[2], 256, seed=7 + rank)
+    batch = synthetic_batch(2, img, device=DEV, seed=2000 + rank)
+    hook = SyntheticProposals(batch[2], img, seed=7 + rank)
     gen = torch.Generator(device=DEV).manual_seed(11 + rank)
     return batch, hook, gen
 
@@ -76,7 +82,7 @@ def _digest(model):
     return h.hexdigest()
 
 
-def _worker(rank, port, variant, outdir):
+def _worker(rank, port, variant, outdir, size="small"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     torch.cuda.set_device(0)
@@ -84,14 +90,14 @@ def _worker(rank, port, variant, outdir):
     from feature_intertwiner_amd.data_parallel import GradientBuckets, all_reduce_statistics, broadcast_parameters
     from feature_intertwiner_amd.workflow import compute_loss, set_optimizer
     do_meta = VARIANTS[variant][2]
-    cfg, model, (batch, hook, gen) = _make(rank, variant)
+    cfg, model, (batch, hook, gen) = _make(rank, variant, size)
     if rank == 1:
         with torch.no_grad():
             for p in model.parameters():
                 p.add_(0.01)                      # broadcast must undo this
     broadcast_parameters(model)
     opt = set_optimizer(model, cfg.TRAIN)
-    sync = GradientBuckets(model, bucket_bytes=4 << 20)
+    sync = GradientBuckets(model, bucket_bytes=(4 << 20) if size == "small" else None)
     model.proposal_hook, model.generator = hook, gen
     opt.zero_grad(set_to_none=True)
     loss, terms = compute_loss(model, list(batch), do_meta, WORLD, all_reduce_statistics)
@@ -99,6 +105,8 @@ def _worker(rank, port, variant, outdir):
     loss.backward()
     sync()
     sync.check()                  # every rank agreed on which parameters received gradients
+    # reduced in place: every gradient is a view of its slot in the rank's arena
+    assert all(p.grad is None or sync.layout.holds(p, p.grad, sync.arena) for p in model.parameters())
     grads = {n: (None if p.grad is None else p.grad.detach().cpu()) for n, p in model.named_parameters()}
     torch.nn.utils.clip_grad_norm_([p for p in model.parameters() if p.grad is not None], cfg.TRAIN.MAX_GRAD_NORM)
     opt.step()
@@ -111,18 +119,20 @@ def _worker(rank, port, variant, outdir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("variant", list(VARIANTS))
-def test_two_rank_model_step_equals_single_process_rule(variant):
+@pytest.mark.parametrize("variant,size", [(v, "small") for v in VARIANTS] + [("ot_l2cost", "full")])
+def test_two_rank_model_step_equals_single_process_rule(variant, size):
+    """size "full": the GRADIENTS (not only finiteness) of BASELINE configs[3]'s per-rank workload -- ResNet-101-FPN,
+    2 x 1024^2 per rank, 512 RoIs/image, Sinkhorn L=50 -- in two ranks against the single-process rule."""
     choice, cost, do_meta = VARIANTS[variant]
     with tempfile.TemporaryDirectory() as outdir:
-        mp.spawn(_worker, args=(_free_port(), variant, outdir), nprocs=WORLD, join=True)
+        mp.spawn(_worker, args=(_free_port(), variant, outdir, size), nprocs=WORLD, join=True)
         res = [torch.load(os.path.join(outdir, "rank%d.pt" % r), weights_only=False) for r in range(WORLD)]
 
     # ---- the single-process statement of the reference rule -----------------------------------
-    cfg, model, _ = _make(0, variant)
+    cfg, model, _ = _make(0, variant, size)
     outs = []
     for g in range(WORLD):                       # nn.DataParallel: every replica runs its shard ...
-        batch, hook, gen = _shard(g)
+        batch, hook, gen = _shard(g, SIZES[size][1])
         model.proposal_hook, model.generator = hook, gen
         outs.append(model(list(batch), 'train'))
     merged = [torch.cat([o[i] for o in outs], 0) for i in range(9)]     # ... outputs gathered on dim 0
