@@ -14,39 +14,66 @@ from .. import _lib
 LAUNCH_LOG = None
 
 
+def _is_channels_last(t):
+    """[B,C,H,W] tensor whose memory is [B,H,W,C] (and not also plain-contiguous, as when C or H*W is 1)."""
+    return t.dim() == 4 and not t.is_contiguous() and t.is_contiguous(memory_format=torch.channels_last)
+
+
 class _CropAndResize(torch.autograd.Function):
+    """Dispatches on the memory format of `image`: an NCHW-contiguous map takes the reference-shaped entry
+    point fi_crop_and_resize_forward; a map in torch.channels_last format ([B,H,W,C] in memory) is NOT
+    transposed -- it takes the channels-last kernels (fi_pyramid_crop_*_nhwc with one level), where one tap is
+    C contiguous floats, and its gradient comes back channels-last.  Results are bit-identical."""
+
     @staticmethod
     def forward(ctx, image, boxes, box_ind, crop_height, crop_width, extrapolation_value):
+        import ctypes
         _lib.require_cuda(image, boxes, box_ind)
         L = _lib.load()
-        image = image.contiguous().float()
+        cl = _is_channels_last(image) and int(crop_height) * int(crop_width) <= 220
+        image = image.float() if cl else image.contiguous().float()
         boxes_c = boxes.detach().contiguous().float()
         ind_c = box_ind.detach().contiguous().to(torch.int32)
         B, C, H, W = image.shape
         N = boxes_c.shape[0]
         crops = torch.empty((N, C, crop_height, crop_width), device=image.device, dtype=torch.float32)
         with torch.cuda.device(image.device):
-            _lib.check(L.fi_crop_and_resize_forward(
-                _lib.ptr(image), _lib.ptr(boxes_c), _lib.ptr(ind_c), N, B, C, H, W,
-                int(crop_height), int(crop_width), float(extrapolation_value), _lib.ptr(crops),
-                None, _lib.current_stream()), "fi_crop_and_resize_forward")
+            if cl:
+                _lib.check(L.fi_pyramid_crop_forward_nhwc(
+                    (ctypes.c_void_p * 1)(image.data_ptr()), (ctypes.c_int * 1)(H), (ctypes.c_int * 1)(W), 1,
+                    _lib.ptr(boxes_c), _lib.ptr(ind_c), None, N, B, C, int(crop_height), int(crop_width),
+                    float(extrapolation_value), _lib.ptr(crops), _lib.current_stream()), "fi_pyramid_crop_forward_nhwc")
+            else:
+                _lib.check(L.fi_crop_and_resize_forward(
+                    _lib.ptr(image), _lib.ptr(boxes_c), _lib.ptr(ind_c), N, B, C, H, W,
+                    int(crop_height), int(crop_width), float(extrapolation_value), _lib.ptr(crops),
+                    None, _lib.current_stream()), "fi_crop_and_resize_forward")
         ctx.im_size = (B, C, H, W)
+        ctx.channels_last = cl
         ctx.crop = (int(crop_height), int(crop_width))
         ctx.save_for_backward(boxes_c, ind_c)
         return crops
 
     @staticmethod
     def backward(ctx, grad_outputs):
+        import ctypes
         boxes_c, ind_c = ctx.saved_tensors
         L = _lib.load()
         g = grad_outputs.contiguous().float()
         B, C, H, W = ctx.im_size
-        grad_image = torch.empty((B, C, H, W), device=g.device, dtype=torch.float32)
+        grad_image = torch.empty((B, C, H, W), device=g.device, dtype=torch.float32,
+                                 memory_format=torch.channels_last if ctx.channels_last else torch.contiguous_format)
         with torch.cuda.device(g.device):
-            _lib.check(L.fi_crop_and_resize_backward(
-                _lib.ptr(g), _lib.ptr(boxes_c), _lib.ptr(ind_c), boxes_c.shape[0], B, C, H, W,
-                ctx.crop[0], ctx.crop[1], _lib.ptr(grad_image), _lib.current_stream()),
-                "fi_crop_and_resize_backward")
+            if ctx.channels_last:
+                _lib.check(L.fi_pyramid_crop_backward_nhwc(
+                    _lib.ptr(g), (ctypes.c_void_p * 1)(grad_image.data_ptr()), (ctypes.c_int * 1)(H),
+                    (ctypes.c_int * 1)(W), 1, _lib.ptr(boxes_c), _lib.ptr(ind_c), None, boxes_c.shape[0], B, C,
+                    ctx.crop[0], ctx.crop[1], _lib.current_stream()), "fi_pyramid_crop_backward_nhwc")
+            else:
+                _lib.check(L.fi_crop_and_resize_backward(
+                    _lib.ptr(g), _lib.ptr(boxes_c), _lib.ptr(ind_c), boxes_c.shape[0], B, C, H, W,
+                    ctx.crop[0], ctx.crop[1], _lib.ptr(grad_image), _lib.current_stream()),
+                    "fi_crop_and_resize_backward")
         return grad_image, None, None, None, None, None
 
 
@@ -63,11 +90,6 @@ class CropAndResizeFunction(object):
                                     self.extrapolation_value)
 
     forward = __call__
-
-
-def _is_channels_last(t):
-    """[B,C,H,W] tensor whose memory is [B,H,W,C] (and not also plain-contiguous, as when C or H*W is 1)."""
-    return t.dim() == 4 and not t.is_contiguous() and t.is_contiguous(memory_format=torch.channels_last)
 
 
 class _PyramidCrop(torch.autograd.Function):

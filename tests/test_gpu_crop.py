@@ -256,6 +256,43 @@ def test_channels_last_full_size_equals_nchw_bitwise():
         assert torch.equal(a.view(torch.int32), b.view(torch.int32))
 
 
+def test_single_level_operator_dispatches_on_memory_format(oracle):
+    """CropAndResizeFunction (the reference-shaped operator, lib/roi_align/crop_and_resize.py:14-54) handed a map in
+    torch.channels_last format does not transpose it: it runs the channels-last kernels (no NCHW crop launch is
+    timed), the forward is bit-identical to the NCHW path and to the oracle, the gradient comes back
+    channels-last."""
+    from feature_intertwiner_amd import _lib
+    from feature_intertwiner_amd.roi_align.crop_and_resize import CropAndResizeFunction
+    rs = np.random.RandomState(77)
+    B, C, H, W = 2, 64, 48, 40
+    fm = rs.standard_normal((B, C, H, W)).astype(np.float32)
+    boxes = adversarial_boxes(rs, 150, H, W)
+    ind = rs.randint(0, B, 150).astype(np.int32)
+    tb, ti = torch.from_numpy(boxes).to(DEV), torch.from_numpy(ind).to(DEV)
+    for crop in (7, 14):
+        x_nchw = torch.from_numpy(fm).to(DEV).requires_grad_(True)
+        x_cl = torch.from_numpy(fm).to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        fn = CropAndResizeFunction(crop, crop)
+        a = fn(x_nchw, tb, ti)
+        _lib.prof_reset()
+        _lib.prof_enable(True)
+        b = fn(x_cl, tb, ti)
+        torch.cuda.synchronize()
+        _lib.prof_enable(False)
+        key = {7: "7x7", 14: "14x14"}[crop]
+        assert _lib.prof_get("crop_fwd_nhwc_" + key)[0] == 1 and _lib.prof_get("crop_fwd_" + key)[0] == 0
+        exp = oracle.crop_and_resize_forward(fm, boxes, ind, crop, crop, 0.0)
+        assert np.array_equal(_bits(a.detach().cpu().numpy()), _bits(exp))
+        assert np.array_equal(_bits(b.detach().cpu().numpy()), _bits(exp))
+        G = torch.from_numpy(rs.standard_normal(exp.shape).astype(np.float32)).to(DEV)
+        a.backward(G)
+        b.backward(G)
+        assert x_cl.grad.is_contiguous(memory_format=torch.channels_last) and x_nchw.grad.is_contiguous()
+        e = oracle.crop_and_resize_backward(G.cpu().numpy(), boxes, ind, fm.shape)
+        for g in (x_nchw.grad, x_cl.grad):
+            assert np.max(np.abs(g.cpu().numpy() - e)) <= 2e-5 * (np.abs(e).max() + 1e-6)
+
+
 def test_roi_align_module_matches_oracle(oracle):
     from feature_intertwiner_amd.roi_align.roi_align import RoIAlign
     rs = np.random.RandomState(4)
