@@ -41,6 +41,10 @@ SIGNATURES = {
                                              c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p]),
     "fi_pyramid_crop_backward_nhwc": (c_int, [c_void_p, _pp, _ip, _ip, c_int, c_void_p, c_void_p,
                                               c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "fi_pyramid_crop_backward_accumulate": (c_int, [c_void_p, _pp, _ip, _ip, c_int, c_void_p, c_void_p,
+                                                    c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "fi_pyramid_crop_backward_nhwc_accumulate": (c_int, [c_void_p, _pp, _ip, _ip, c_int, c_void_p, c_void_p,
+                                                         c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "fi_roi_pool_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                                     c_int, c_float, c_void_p, c_void_p, c_void_p]),
     "fi_roi_pool_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
@@ -63,6 +67,7 @@ SIGNATURES = {
     "fi_weight_transpose_batch": (c_int, [c_void_p, c_int, ctypes.c_long, c_void_p]),
     "fi_conv3x3_forward_bf16w": (c_int, [c_void_p] * 6 + [c_int] * 7 + [c_void_p]),
     "fi_conv1x1_forward_bf16w": (c_int, [c_void_p] * 6 + [c_int] * 5 + [c_void_p]),
+    "fi_stride2_interleave": (c_int, [c_void_p] * 6 + [ctypes.c_long, c_int, c_int, c_void_p]),
     "fi_sgd_chunks": (ctypes.c_long, [ctypes.c_long]),
     "fi_sgd_clip_step": (c_int, [c_void_p, c_int, ctypes.c_long, c_float, c_void_p, c_void_p, c_void_p]),
     "fi_calib_copy": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),

@@ -185,15 +185,46 @@ def _class_taps(a, size_k, s, p):
     return r0, T, c0
 
 
-def _strided_dgrad(dz, w, in_hw, stride, padding, precision=None):
+class _Compact(object):
+    """The data gradient of a 1x1 / stride-2 convolution in COMPACT form: only the input positions (2i, 2j) can be
+    non-zero, `t` [N, Cin, ceil(H/2), ceil(W/2)] holds them.  Handed from a projection shortcut's backward to the
+    backward of the block's first convolution (same input, same stride), which adds it inside its own compact
+    data-gradient kernel before ONE interleave pass writes the full tensor."""
+    __slots__ = ("t", "hw")
+
+    def __init__(self, t, hw):
+        self.t, self.hw = t, hw
+
+    def expand(self, add=None):
+        return _interleave2({(0, 0): self.t}, add, self.t.shape[0], self.t.shape[1], self.hw[0], self.hw[1])
+
+
+def _interleave2(classes, add, N, C, H, W):
+    """dx [N,C,H,W] from the residue-class results of a stride-2 data gradient (fi_stride2_interleave): one pass,
+    every element written once; `add` [N,C,H,W] is added on the way."""
+    L = _lib.load()
+    some = next(iter(classes.values()))
+    dx = torch.empty((N, C, H, W), device=some.device, dtype=torch.float32)
+    g = lambda a, b: _lib.ptr(classes[(a, b)].contiguous()) if (a, b) in classes else None
+    keep = [classes[k].contiguous() for k in classes]      # noqa: F841  (alive until the launch is enqueued)
+    with torch.cuda.device(dx.device):
+        _lib.check(L.fi_stride2_interleave(g(0, 0), g(0, 1), g(1, 0), g(1, 1), _lib.ptr(add), _lib.ptr(dx), N * C, H, W,
+                                           _lib.current_stream()), "fi_stride2_interleave")
+    return dx
+
+
+def _strided_dgrad(dz, w, in_hw, stride, padding, precision=None, add=None):
     """Data gradient of a strided convolution WITHOUT zero-stuffing: the input positions split into
     stride_h*stride_w residue classes; each class is a stride-1 correlation of dz with the sub-kernel
-    of the taps that reach it (e.g. 3x3/stride 2/pad 1: 1, 2, 2 and 4 taps instead of 9 everywhere)."""
+    of the taps that reach it (e.g. 3x3/stride 2/pad 1: 1, 2, 2 and 4 taps instead of 9 everywhere).
+    Stride 2: the class results are interleaved (and `add` added) by one kernel; other strides: strided copies."""
     N, Cout = dz.shape[0], dz.shape[1]
     Cin, R, S = w.shape[1], w.shape[2], w.shape[3]
     H, W = in_hw
     sh, sw = stride
-    dx = dz.new_zeros(N, Cin, H, W)
+    two = (sh, sw) == (2, 2)
+    dx = None if two else dz.new_zeros(N, Cin, H, W)
+    classes = {}
     for a in range(min(sh, H)):
         r0, Th, ch0 = _class_taps(a, R, sh, padding[0])
         qa = (H - a + sh - 1) // sh
@@ -209,21 +240,34 @@ def _strided_dgrad(dz, w, in_hw, stride, padding, precision=None):
             k = w[:, :, r0:r0 + sh * (Th - 1) + 1:sh, s0:s0 + sw * (Tw - 1) + 1:sw].flip(2, 3)
             k = k.transpose(0, 1).contiguous()                                  # [Cin, Cout, Th, Tw]
             out = _conv_fwd(dz, k, None, (1, 1), (pad_h, pad_w), out_hw=(qa, qb), precision=precision)
-            dx[:, :, a::sh, b::sw] = out
-    return dx
+            if two:
+                classes[(a, b)] = out
+            else:
+                dx[:, :, a::sh, b::sw] = out
+    if two:
+        if not classes:
+            dx = dz.new_zeros(N, Cin, H, W)
+            return dx if add is None else dx + add
+        return _interleave2(classes, add, N, Cin, H, W)
+    return dx if add is None else dx + add
 
 
-def _conv_backward(ctx_needs, x, w, dz, stride, padding, want_db=False, add_to_dx=None, precision=None):
+def _conv_backward(ctx_needs, x, w, dz, stride, padding, want_db=False, add_to_dx=None, precision=None,
+                   give_compact=False):
     """dX and dW of z = conv(x, w) given dz (shared by the plain and the fused functions).
     want_db: also return sum(dz) over images and pixels (the bias gradient), accumulated by the
     weight-gradient kernel from the dY tiles it stages anyway.
-    add_to_dx: a tensor shaped like x that is added to dX inside the data-gradient kernel's epilogue
-    (the shortcut gradient of a bottleneck, instead of a separate add pass)."""
+    add_to_dx: a tensor shaped like x -- or a _Compact -- that is added to dX inside the data-gradient kernel's
+    epilogue (the shortcut gradient of a bottleneck, instead of a separate add pass).
+    give_compact: a 1x1 / stride-2 layer may return dX as a _Compact (see there) instead of the full tensor."""
     L = _lib.load()
     N, Cin, H, W = x.shape
     Cout, _, R, S = w.shape
     dx = dw = db = None
     if ctx_needs[0]:
+        if isinstance(add_to_dx, _Compact) and not (stride == (2, 2) and R * S == 1 and padding == (0, 0) and
+                                                    Cout % 16 == 0 and Cin % 16 == 0):
+            add_to_dx = add_to_dx.expand()
         if stride == (1, 1):
             if Cout % 16 == 0 and R * S <= 64:
                 # transposed weight in the kernel's tap-major layout [Cin, R, S, Cout]: re-laid-out for all
@@ -238,10 +282,25 @@ def _conv_backward(ctx_needs, x, w, dz, stride, padding, want_db=False, add_to_d
             else:
                 wt = w.flip(2, 3).transpose(0, 1).contiguous()          # [Cin, Cout, R, S]
                 dx = _conv_fwd(dz, wt, None, (1, 1), (R - 1 - padding[0], S - 1 - padding[1]), precision=precision)
+            if add_to_dx is not None:
+                dx = dx + add_to_dx
+        elif stride == (2, 2) and R * S == 1 and padding == (0, 0) and Cout % 16 == 0 and Cin % 16 == 0:
+            # 1x1 / stride 2 (the first block of C3..C5: conv1 and the projection shortcut): only the even input
+            # positions receive a gradient -- ONE 1x1 correlation with the cached W^T on the half-size map,
+            # a second compact gradient for the same input added in its epilogue, then one interleave pass
+            wt = _cached_wt(w)
+            if wt is None:
+                wt = w.permute(1, 2, 3, 0).contiguous()
+            comp = add_to_dx.t if isinstance(add_to_dx, _Compact) else None
+            c = _conv_fwd(dz, wt, None, (1, 1), (0, 0), w_tap_major=True, flip_taps=True, residual=comp,
+                          precision=precision)
+            full_add = add_to_dx if torch.is_tensor(add_to_dx) else None
+            if give_compact and full_add is None:
+                dx = _Compact(c, (H, W))
+            else:
+                dx = _interleave2({(0, 0): c}, full_add, N, Cin, H, W)
         else:
-            dx = _strided_dgrad(dz, w, (H, W), stride, padding, precision)
-        if add_to_dx is not None:
-            dx = dx + add_to_dx
+            dx = _strided_dgrad(dz, w, (H, W), stride, padding, precision, add=add_to_dx)
     if ctx_needs[1]:
         # tap-major dW ([Cout,R,S,Cin]): 128 channels of one tap per column tile, or -- same-size stride-1
         # layers with Cin == 64 (the C2 stage) -- 64 channels of two taps (mirrors wgrad_same_size())
@@ -254,10 +313,12 @@ def _conv_backward(ctx_needs, x, w, dz, stride, padding, want_db=False, add_to_d
         if bf16:
             hwc = 1
         shape = (Cout, R, S, Cin) if (hwc and R * S > 1) else (Cout, Cin, R, S)
-        # pre-zeroed slice of the step's gradient arena (one fill per step instead of one per layer)
-        dw = _arena_take(("dw", w.data_ptr()), Cout * Cin * R * S)
-        flags = _lib.OUTPUTS_ZEROED if (dw is not None and (bf16 or not want_db)) else 0
+        # pre-zeroed slice of the step's gradient arena (one fill per step instead of one per layer); a repeated
+        # use of the layer accumulates into the same slice.  (With want_db the kernel clears dW and db itself.)
+        dw, first = (None, False) if (want_db and not bf16) else _arena_take(("dw", w.data_ptr()), Cout * Cin * R * S)
+        flags = _lib.OUTPUTS_ZEROED if dw is not None else 0
         dw = dw.view(shape) if dw is not None else torch.empty(shape, device=x.device, dtype=torch.float32)
+        hand_over = first or not flags
         if want_db:
             db = dz.sum((0, 2, 3)) if bf16 else torch.empty(Cout, device=x.device, dtype=torch.float32)
         with torch.cuda.device(x.device):
@@ -274,6 +335,8 @@ def _conv_backward(ctx_needs, x, w, dz, stride, padding, want_db=False, add_to_d
                                                    _lib.ptr(db), flags, _lib.current_stream()), "fi_conv2d_weight_grad")
         if hwc and R * S > 1:
             dw = dw.permute(0, 3, 1, 2)
+        if not hand_over:
+            dw = None                 # accumulated into the slot autograd already holds
     elif want_db:
         db = dz.sum((0, 2, 3))
     return (dx, dw, db) if want_db else (dx, dw)
@@ -307,13 +370,17 @@ def _cached_wt(w):
 
 
 def _arena_take(key, numel):
-    """The zeroed slot reserved for `key` in this step's arena, once per step (a layer applied several
-    times per step -- RPN on 5 levels -- must not hand the same buffer to autograd twice)."""
+    """(slot, first): the slot reserved for `key` in this step's arena (zeroed at the start of the step) and
+    whether this is its first use in the step.  A layer applied several times per step (the RPN on 5 levels, the
+    feature extractor on small and big boxes) ACCUMULATES all its gradient contributions in the one slot -- the
+    kernels add with atomics anyway -- and hands the slot to autograd only the first time (later calls return no
+    gradient for the parameter), so there is no per-use buffer, fill and add.  (None, False): no slot."""
     slot = _ARENA["slots"].get(key)
-    if slot is None or _ARENA["buf"] is None or key in _ARENA["used"] or slot[1] != numel:
-        return None
+    if slot is None or _ARENA["buf"] is None or slot[1] != numel:
+        return None, False
+    first = key not in _ARENA["used"]
     _ARENA["used"].add(key)
-    return _ARENA["buf"][slot[0]:slot[0] + numel]
+    return _ARENA["buf"][slot[0]:slot[0] + numel], first
 
 
 def invalidate_step_state():
@@ -357,7 +424,8 @@ def _prepare_step(model, grad_on):
             if w.shape[1] % 16 == 0 and w.shape[2] * w.shape[3] > 1 and \
                     not w.is_contiguous(memory_format=torch.channels_last):
                 w.data = w.data.contiguous(memory_format=torch.channels_last)
-        tr = [m for m in convs if tuple(m.stride) == (1, 1) and m.weight.shape[0] % 16 == 0 and
+        tr = [m for m in convs if (tuple(m.stride) == (1, 1) or m.weight.shape[2] * m.weight.shape[3] == 1) and
+              m.weight.shape[0] % 16 == 0 and
               m.weight.shape[1] % 16 == 0 and m.weight.shape[2] * m.weight.shape[3] <= 64 and m.weight.requires_grad]
         import numpy as np
         desc = np.zeros(len(tr), dtype=np.dtype([("src", "<u8"), ("dst", "<u8"), ("rows", "<i4"), ("cols", "<i4"),
@@ -412,8 +480,10 @@ def _prepare_step(model, grad_on):
 
 class GradBox(object):
     """Hands a gradient from one autograd node to another: a bottleneck's last convolution leaves the
-    gradient of its identity shortcut here, and the block's first convolution -- whose data gradient flows
-    into the same tensor -- adds it inside its kernel epilogue (see Bottleneck.forward)."""
+    gradient of its identity shortcut here -- or its projection shortcut leaves its data gradient here -- and the
+    block's first convolution, whose data gradient flows into the same tensor, adds it inside its kernel
+    epilogue (see Bottleneck.forward).  The giver must run first in backward: it must be applied AFTER the
+    taker in forward (autograd executes ready nodes in reverse order of creation)."""
     __slots__ = ("value",)
 
     def __init__(self):
@@ -426,7 +496,7 @@ class _ConvBnActFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, b, gamma, beta, mean, var, eps, residual, relu, stride, padding, out_cl=False,
-                fold=None, res_grad_to=None, dx_add_from=None):
+                fold=None, res_grad_to=None, dx_add_from=None, dx_give_to=None):
         _lib.require_cuda(x, w)
         x = x.contiguous().float()
         w = _dense(w.float())
@@ -443,7 +513,7 @@ class _ConvBnActFn(torch.autograd.Function):
                       out_channels_last=out_cl)
         ctx.out_cl = bool(out_cl)
         ctx.precision = _PRECISION
-        ctx.res_grad_to, ctx.dx_add_from = res_grad_to, dx_add_from
+        ctx.res_grad_to, ctx.dx_add_from, ctx.dx_give_to = res_grad_to, dx_add_from, dx_give_to
         ctx.save_for_backward(x, w, y, scale, gamma, beta, res)
         ctx.conf = (tuple(stride), tuple(padding), b is not None, bool(relu), residual is not None, eps, mean, var)
         return y
@@ -460,10 +530,10 @@ class _ConvBnActFn(torch.autograd.Function):
         dz = torch.empty(y.shape, device=y.device, dtype=torch.float32)
         g_res = torch.empty_like(y) if (has_res and ctx.needs_input_grad[8]) else None
         # (d shift, d gamma, d conv-bias) adjacent: a slot of the step's zeroed arena, or ONE fill in the call
-        sums = _arena_take(("bn", gamma.data_ptr()), 3 * C)
+        sums, first = _arena_take(("bn", gamma.data_ptr()), 3 * C)
         flags = _lib.OUTPUTS_ZEROED if sums is not None else 0
         if sums is None:
-            sums = torch.empty(3 * C, device=y.device, dtype=torch.float32)
+            sums, first = torch.empty(3 * C, device=y.device, dtype=torch.float32), True
         dshift = sums[:C]
         dgamma = sums[C:2 * C] if ctx.needs_input_grad[3] else None
         want_db = has_bias and ctx.needs_input_grad[2]
@@ -481,9 +551,15 @@ class _ConvBnActFn(torch.autograd.Function):
         add = None
         if ctx.dx_add_from is not None:
             add, ctx.dx_add_from.value = ctx.dx_add_from.value, None
-        dx, dw = _conv_backward(ctx.needs_input_grad, x, w, dz, stride, padding, add_to_dx=add, precision=ctx.precision)
+        dx, dw = _conv_backward(ctx.needs_input_grad, x, w, dz, stride, padding, add_to_dx=add, precision=ctx.precision,
+                                give_compact=ctx.dx_give_to is not None)
+        if ctx.dx_give_to is not None and dx is not None:
+            ctx.dx_give_to.value = dx               # picked up (and added) by the backward of the block's first conv
+            dx = None
         dbeta = dshift if ctx.needs_input_grad[4] else None
-        return dx, dw, db, dgamma, dbeta, None, None, None, g_res, None, None, None, None, None, None, None
+        if not first:                 # a repeated use of the layer: accumulated into the slices autograd already holds
+            db = dgamma = dbeta = None
+        return dx, dw, db, dgamma, dbeta, None, None, None, g_res, None, None, None, None, None, None, None, None
 
 
 class _ConvBiasActFn(torch.autograd.Function):
@@ -598,7 +674,7 @@ def _invalidate_bn_folds(module=None):
 
 
 def conv_bn_act(x, conv, bn, relu=True, residual=None, channels_last_out=False, res_grad_to=None,
-                dx_add_from=None):
+                dx_add_from=None, dx_give_to=None):
     """act(bn(conv(x)) [+ residual]) for an eval-mode BatchNorm2d (the reference always evaluates
     BN with running statistics, lib/model.py:265-267).  Falls back to separate ops for a BN in
     training mode or a full-window (GEMM) convolution.  channels_last_out: return the result in
@@ -606,7 +682,8 @@ def conv_bn_act(x, conv, bn, relu=True, residual=None, channels_last_out=False, 
     R, S = conv.weight.shape[2], conv.weight.shape[3]
     gemm_path = ((x.shape[2], x.shape[3]) == (R, S) and tuple(conv.padding) == (0, 0)) or x.shape[2] * x.shape[3] == 1
     if bn.training or gemm_path or not bn.track_running_stats:
-        assert res_grad_to is None and dx_add_from is None, "gradient hand-off needs the fused conv+BN path"
+        assert res_grad_to is None and dx_add_from is None and dx_give_to is None, \
+            "gradient hand-off needs the fused conv+BN path"
         if gemm_path and not bn.training and bn.track_running_stats:
             # [N,C,1,1]: MIOpen's spatial inference BN takes ~0.4 ms on 8 MB here; the affine form is ~10 us
             scale = bn.weight * torch.rsqrt(bn.running_var + bn.eps)
@@ -621,7 +698,7 @@ def conv_bn_act(x, conv, bn, relu=True, residual=None, channels_last_out=False, 
     _FOLD_PAIRS[bn] = conv
     y = _ConvBnActFn.apply(x, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                            bn.eps, residual, relu, tuple(conv.stride), tuple(conv.padding), out_cl,
-                           _cached_fold(conv, bn), res_grad_to, dx_add_from)
+                           _cached_fold(conv, bn), res_grad_to, dx_add_from, dx_give_to)
     return y.contiguous(memory_format=torch.channels_last) if (channels_last_out and not out_cl) else y
 
 

@@ -774,9 +774,9 @@ int forward_impl(const LevelSet &ls, const float *boxes, const int32_t *box_ind,
 
 int backward_impl(const LevelSetMut &ls, const float *grads, const float *boxes,
                   const int32_t *box_ind, const int32_t *level, int num_boxes, int batch, int depth,
-                  int crop_h, int crop_w, hipStream_t st)
+                  int crop_h, int crop_w, hipStream_t st, bool clear = true)
 {
-    for (int l = 0; l < ls.n; ++l) {
+    for (int l = 0; clear && l < ls.n; ++l) {
         const size_t bytes = sizeof(float) * (size_t)batch * depth * ls.H[l] * ls.W[l];
         FI_HIP_CHECK(hipMemsetAsync(ls.img[l], 0, bytes, st));
     }
@@ -839,9 +839,9 @@ int forward_cl_impl(const LevelSet &ls, const float *boxes, const int32_t *box_i
 
 int backward_cl_impl(const LevelSetMut &ls, const float *grads, const float *boxes,
                      const int32_t *box_ind, const int32_t *level, int num_boxes, int batch, int depth,
-                     int crop_h, int crop_w, hipStream_t st)
+                     int crop_h, int crop_w, hipStream_t st, bool clear = true)
 {
-    for (int l = 0; l < ls.n; ++l) {
+    for (int l = 0; clear && l < ls.n; ++l) {
         const size_t bytes = sizeof(float) * (size_t)batch * depth * ls.H[l] * ls.W[l];
         FI_HIP_CHECK(hipMemsetAsync(ls.img[l], 0, bytes, st));
     }
@@ -970,11 +970,11 @@ int fi_pyramid_crop_forward(const float *const *level_images_host, const int *le
                         extrapolation_value, crops, nullptr, (hipStream_t)stream);
 }
 
-int fi_pyramid_crop_backward(const float *grads, float *const *level_grads_host,
-                             const int *level_h_host, const int *level_w_host, int num_levels,
-                             const float *boxes, const int32_t *box_ind, const int32_t *level,
-                             int num_boxes, int batch, int depth, int crop_h, int crop_w,
-                             fi_stream_t stream)
+static int pyramid_backward_entry(const float *grads, float *const *level_grads_host,
+                                  const int *level_h_host, const int *level_w_host, int num_levels,
+                                  const float *boxes, const int32_t *box_ind, const int32_t *level,
+                                  int num_boxes, int batch, int depth, int crop_h, int crop_w,
+                                  fi_stream_t stream, bool clear)
 {
     int rc = check_common(num_boxes, batch, depth, crop_h, crop_w);
     if (rc != FI_OK) return rc;
@@ -990,7 +990,27 @@ int fi_pyramid_crop_backward(const float *grads, float *const *level_grads_host,
         FI_REQUIRE(ls.img[l] && ls.H[l] >= 1 && ls.W[l] >= 1, "bad level entry");
     }
     return backward_impl(ls, grads, boxes, box_ind, level, num_boxes, batch, depth, crop_h, crop_w,
-                         (hipStream_t)stream);
+                         (hipStream_t)stream, clear);
+}
+
+int fi_pyramid_crop_backward(const float *grads, float *const *level_grads_host,
+                             const int *level_h_host, const int *level_w_host, int num_levels,
+                             const float *boxes, const int32_t *box_ind, const int32_t *level,
+                             int num_boxes, int batch, int depth, int crop_h, int crop_w,
+                             fi_stream_t stream)
+{
+    return pyramid_backward_entry(grads, level_grads_host, level_h_host, level_w_host, num_levels, boxes, box_ind,
+                                  level, num_boxes, batch, depth, crop_h, crop_w, stream, true);
+}
+
+int fi_pyramid_crop_backward_accumulate(const float *grads, float *const *level_grads_host,
+                                        const int *level_h_host, const int *level_w_host, int num_levels,
+                                        const float *boxes, const int32_t *box_ind, const int32_t *level,
+                                        int num_boxes, int batch, int depth, int crop_h, int crop_w,
+                                        fi_stream_t stream)
+{
+    return pyramid_backward_entry(grads, level_grads_host, level_h_host, level_w_host, num_levels, boxes, box_ind,
+                                  level, num_boxes, batch, depth, crop_h, crop_w, stream, false);
 }
 
 int fi_pyramid_crop_forward_nhwc(const float *const *level_images_host, const int *level_h_host,
@@ -1010,11 +1030,11 @@ int fi_pyramid_crop_forward_nhwc(const float *const *level_images_host, const in
                            extrapolation_value, crops, (hipStream_t)stream);
 }
 
-int fi_pyramid_crop_backward_nhwc(const float *grads, float *const *level_grads_host,
-                                  const int *level_h_host, const int *level_w_host, int num_levels,
-                                  const float *boxes, const int32_t *box_ind, const int32_t *level,
-                                  int num_boxes, int batch, int depth, int crop_h, int crop_w,
-                                  fi_stream_t stream)
+static int pyramid_backward_nhwc_entry(const float *grads, float *const *level_grads_host,
+                                       const int *level_h_host, const int *level_w_host, int num_levels,
+                                       const float *boxes, const int32_t *box_ind, const int32_t *level,
+                                       int num_boxes, int batch, int depth, int crop_h, int crop_w,
+                                       fi_stream_t stream, bool clear)
 {
     int rc = check_common(num_boxes, batch, depth, crop_h, crop_w);
     if (rc != FI_OK) return rc;
@@ -1031,7 +1051,27 @@ int fi_pyramid_crop_backward_nhwc(const float *grads, float *const *level_grads_
         ls.W[l] = lsc.W[l];
     }
     return backward_cl_impl(ls, grads, boxes, box_ind, level, num_boxes, batch, depth, crop_h, crop_w,
-                            (hipStream_t)stream);
+                            (hipStream_t)stream, clear);
+}
+
+int fi_pyramid_crop_backward_nhwc(const float *grads, float *const *level_grads_host,
+                                  const int *level_h_host, const int *level_w_host, int num_levels,
+                                  const float *boxes, const int32_t *box_ind, const int32_t *level,
+                                  int num_boxes, int batch, int depth, int crop_h, int crop_w,
+                                  fi_stream_t stream)
+{
+    return pyramid_backward_nhwc_entry(grads, level_grads_host, level_h_host, level_w_host, num_levels, boxes,
+                                       box_ind, level, num_boxes, batch, depth, crop_h, crop_w, stream, true);
+}
+
+int fi_pyramid_crop_backward_nhwc_accumulate(const float *grads, float *const *level_grads_host,
+                                             const int *level_h_host, const int *level_w_host, int num_levels,
+                                             const float *boxes, const int32_t *box_ind, const int32_t *level,
+                                             int num_boxes, int batch, int depth, int crop_h, int crop_w,
+                                             fi_stream_t stream)
+{
+    return pyramid_backward_nhwc_entry(grads, level_grads_host, level_h_host, level_w_host, num_levels, boxes,
+                                       box_ind, level, num_boxes, batch, depth, crop_h, crop_w, stream, false);
 }
 
 }  // extern "C"

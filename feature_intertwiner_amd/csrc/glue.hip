@@ -1,0 +1,86 @@
+// glue.hip -- small data-movement kernels of the training step that replace chains of framework launches.
+#include <stdint.h>
+
+#include "fi_common.h"
+
+namespace {
+
+// dx[p][h][w] = c[h & 1][w & 1][p][h >> 1][w >> 1] (0 where that residue class has no tensor) (+ add[p][h][w]):
+// the data gradient of a stride-2 convolution, assembled from the stride-1 correlations of its residue classes
+// (conv._strided_dgrad) in ONE pass that writes every element once -- instead of a zero fill plus one strided
+// scatter-copy per class (and a separate add of the second gradient that flows into the same tensor).
+template <bool VEC>
+__global__ __launch_bounds__(256) void stride2_interleave_kernel(
+    const float *__restrict__ c00, const float *__restrict__ c01, const float *__restrict__ c10,
+    const float *__restrict__ c11, const float *__restrict__ add, float *__restrict__ dx, long planes, int H,
+    int W)
+{
+    const int qw0 = (W + 1) >> 1, qw1 = W >> 1;
+    const int qh0 = (H + 1) >> 1, qh1 = H >> 1;
+    if (VEC) {
+        // W % 4 == 0: a thread writes 4 consecutive columns of one row (16-byte store), reading 2 + 2 values
+        const int wq = W >> 2;
+        const long total = planes * H * wq;
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+            const int j = (int)(i % wq);
+            const long ph = i / wq;
+            const int h = (int)(ph % H);
+            const long p = ph / H;
+            const int qh = h >> 1;
+            const float *e = (h & 1) ? c10 : c00;
+            const float *o = (h & 1) ? c11 : c01;
+            const int qhn = (h & 1) ? qh1 : qh0;
+            const long base = (p * qhn + qh) * (long)qw0 + 2 * j;
+            float2 ev = make_float2(0.f, 0.f), ov = make_float2(0.f, 0.f);
+            if (e) ev = *reinterpret_cast<const float2 *>(e + base);
+            if (o) ov = *reinterpret_cast<const float2 *>(o + base);
+            float4 r = make_float4(ev.x, ov.x, ev.y, ov.y);
+            const long off = (p * H + h) * (long)W + 4 * j;
+            if (add) {
+                const float4 a = *reinterpret_cast<const float4 *>(add + off);
+                r.x += a.x; r.y += a.y; r.z += a.z; r.w += a.w;
+            }
+            *reinterpret_cast<float4 *>(dx + off) = r;
+        }
+    } else {
+        const long total = planes * H * W;
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+            const int w = (int)(i % W);
+            const long ph = i / W;
+            const int h = (int)(ph % H);
+            const long p = ph / H;
+            const float *src = (h & 1) ? ((w & 1) ? c11 : c10) : ((w & 1) ? c01 : c00);
+            const int qhn = (h & 1) ? qh1 : qh0;
+            const int qwn = (w & 1) ? qw1 : qw0;
+            float v = src ? src[(p * qhn + (h >> 1)) * (long)qwn + (w >> 1)] : 0.0f;
+            if (add) v += add[i];
+            dx[i] = v;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int fi_stride2_interleave(const float *c00, const float *c01, const float *c10, const float *c11,
+                          const float *add, float *dx, long planes, int height, int width, fi_stream_t stream)
+{
+    FI_REQUIRE(dx && planes >= 0 && height >= 1 && width >= 1, "bad interleave arguments");
+    if (planes == 0) return FI_OK;
+    const uintptr_t all = (uintptr_t)c00 | (uintptr_t)c01 | (uintptr_t)c10 | (uintptr_t)c11;
+    const bool vec = width % 4 == 0 && all % 8 == 0 && (uintptr_t)dx % 16 == 0 && (uintptr_t)add % 16 == 0;
+    const long work = vec ? planes * height * (width / 4) : planes * height * width;
+    const long blocks = (work + 255) / 256;
+    const unsigned grid = (unsigned)(blocks < 65536 ? (blocks < 1 ? 1 : blocks) : 65536);
+    if (vec)
+        hipLaunchKernelGGL(stride2_interleave_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, c00, c01,
+                           c10, c11, add, dx, planes, height, width);
+    else
+        hipLaunchKernelGGL(stride2_interleave_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, c00, c01,
+                           c10, c11, add, dx, planes, height, width);
+    FI_HIP_CHECK(hipGetLastError());
+    return FI_OK;
+}
+
+}  // extern "C"

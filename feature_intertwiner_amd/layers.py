@@ -363,14 +363,17 @@ def compute_mrcnn_bbox_loss(target_bbox, target_class_ids, pred_bbox):
     return (l * pos).sum() / (pos.sum() * 4).clamp(min=1)
 
 
-def compute_mrcnn_mask_loss_unshuffled(target_masks, target_class_ids, pred_u):
+def compute_mrcnn_mask_loss_unshuffled(target_masks, target_class_ids, pred_u, from_logits=False):
     """compute_mrcnn_mask_loss for the mask head's un-shuffled output pred_u [b, R, 2, 2, K, h, w]
     (pred[.., k, 2y+a, 2x+b] == pred_u[.., a, b, k, y, x]): the class channel is gathered first and only
-    that [b, R, 2, 2, h, w] slice is pixel-shuffled.  Same value and gradient."""
+    that [b, R, 2, 2, h, w] slice is pixel-shuffled.  Same value and gradient.  from_logits: pred_u holds the
+    mask head's logits (Mask.forward(activate=False)) and the sigmoid is applied to the gathered slice."""
     cls = target_class_ids.long()
     b, R, _, _, K, h, w = pred_u.shape
     idx = cls.view(b, R, 1, 1, 1, 1, 1).expand(-1, -1, 2, 2, 1, h, w)
     pred = torch.gather(pred_u, 4, idx).squeeze(4)                                  # [b, R, 2, 2, h, w]
+    if from_logits:
+        pred = torch.sigmoid(pred)
     pred = pred.permute(0, 1, 4, 2, 5, 3).reshape(b, R, 2 * h, 2 * w)
     pos = (cls > 0).float().view(b, R, 1, 1)
     l = F.binary_cross_entropy(pred, target_masks, reduction='none')

@@ -138,7 +138,7 @@ class MaskRCNN(nn.Module):
             R = rois.size(1)
             pooled_mask = pooled_mask.view(bs, R, *pooled_mask.shape[1:])[:, :P].reshape(bs * P, *pooled_mask.shape[1:])
             mask_ids, mask_tgt = target_class_ids[:, :P], target_mask[:, :P]
-        mask_u = self.mask(pooled_mask, shuffled=False)                  # [bs*R', 2, 2, K, 14, 14]
+        mask_u = self.mask(pooled_mask, shuffled=False, activate=False)  # logits [bs*R', 2, 2, K, 14, 14]
         mrcnn_class_logits = mrcnn_class_logits.view(bs, -1, mrcnn_class_logits.size(1))
         mrcnn_bbox = mrcnn_bbox.view(bs, -1, mrcnn_bbox.size(1), mrcnn_bbox.size(2))
         mask_u = mask_u.view(bs, -1, *mask_u.shape[1:])
@@ -148,7 +148,7 @@ class MaskRCNN(nn.Module):
             compute_rpn_bbox_loss(target_rpn_deltas, target_rpn_match, rpn_bbox),
             compute_mrcnn_class_loss(target_class_ids, mrcnn_class_logits),
             compute_mrcnn_bbox_loss(target_deltas, target_class_ids, mrcnn_bbox),
-            compute_mrcnn_mask_loss_unshuffled(mask_tgt, mask_ids, mask_u))).view(1, 5)
+            compute_mrcnn_mask_loss_unshuffled(mask_tgt, mask_ids, mask_u, from_logits=True))).view(1, 5)
         return (losses, big_feat, big_cnt, small_feat, small_cnt, big_loss, small_output_all, small_gt_all,
                 fpn_ot_loss)
 

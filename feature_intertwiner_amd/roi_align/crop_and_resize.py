@@ -92,12 +92,23 @@ class CropAndResizeFunction(object):
     forward = __call__
 
 
+class CropGradGroup(object):
+    """Shared by the pyramid crops of ONE set of maps (the Dev stage pools 7x7 and 14x14 from the same four maps):
+    the first backward of the group allocates and clears the maps' gradients and returns them to autograd, every
+    later one ADDS into the same buffers (fi_pyramid_crop_backward*_accumulate) and returns no gradient -- instead
+    of one cleared set of buffers per crop and an add pass per level."""
+    __slots__ = ("grads",)
+
+    def __init__(self):
+        self.grads = None
+
+
 class _PyramidCrop(torch.autograd.Function):
     """All FPN levels in one launch (the callers' per-level loops, lib/layers.py:183-216 and
     lib/sub_module.py:429-662, collapse into a precomputed `level` vector)."""
 
     @staticmethod
-    def forward(ctx, boxes, box_ind, level, crop_height, crop_width, extrapolation_value, *maps):
+    def forward(ctx, boxes, box_ind, level, crop_height, crop_width, extrapolation_value, group, *maps):
         import ctypes
         _lib.require_cuda(boxes, box_ind, level, *maps)
         L = _lib.load()
@@ -122,6 +133,7 @@ class _PyramidCrop(torch.autograd.Function):
                 int(crop_height), int(crop_width), float(extrapolation_value), _lib.ptr(crops),
                 _lib.current_stream()), "fi_pyramid_crop_forward")
         ctx.channels_last = cl
+        ctx.group = group
         if _lib.TAP is not None:
             _lib.TAP("pyramid_crop", maps=maps, boxes=boxes_c, box_ind=ind_c, level=lvl_c, crops=crops,
                      crop=int(crop_height))
@@ -142,22 +154,36 @@ class _PyramidCrop(torch.autograd.Function):
         nl = len(ctx.shapes)
         B, C = ctx.shapes[0][:2]
         fmt = torch.channels_last if ctx.channels_last else torch.contiguous_format
-        grads = [torch.empty(s, device=g.device, dtype=torch.float32, memory_format=fmt) for s in ctx.shapes]
+        group = ctx.group
+        accumulate = group is not None and group.grads is not None
+        if accumulate:
+            grads = group.grads
+        else:
+            grads = [torch.empty(s, device=g.device, dtype=torch.float32, memory_format=fmt) for s in ctx.shapes]
+            if group is not None:
+                group.grads = grads
         ptrs = (ctypes.c_void_p * nl)(*[t.data_ptr() for t in grads])
         hs = (ctypes.c_int * nl)(*[s[2] for s in ctx.shapes])
         ws = (ctypes.c_int * nl)(*[s[3] for s in ctx.shapes])
-        fn = L.fi_pyramid_crop_backward_nhwc if ctx.channels_last else L.fi_pyramid_crop_backward
+        if accumulate:
+            fn = L.fi_pyramid_crop_backward_nhwc_accumulate if ctx.channels_last else L.fi_pyramid_crop_backward_accumulate
+        else:
+            fn = L.fi_pyramid_crop_backward_nhwc if ctx.channels_last else L.fi_pyramid_crop_backward
         with torch.cuda.device(g.device):
             _lib.check(fn(
                 _lib.ptr(g), ptrs, hs, ws, nl, _lib.ptr(boxes_c), _lib.ptr(ind_c), _lib.ptr(lvl_c),
                 boxes_c.shape[0], B, C, ctx.crop[0], ctx.crop[1], _lib.current_stream()),
                 "fi_pyramid_crop_backward")
-        return (None, None, None, None, None, None) + tuple(grads)
+        if accumulate:
+            return (None,) * (7 + nl)
+        return (None, None, None, None, None, None, None) + tuple(grads)
 
 
 def pyramid_crop_and_resize(feature_maps, boxes, box_ind, level, crop_height, crop_width,
-                            extrapolation_value=0.0):
+                            extrapolation_value=0.0, grad_group=None):
     """crops[i] = crop of box i from feature_maps[level[i] - 2]; rows with a level
-    outside the pyramid are zero.  Output rows are in the order of `boxes`."""
-    return _PyramidCrop.apply(boxes, box_ind, level, crop_height, crop_width, extrapolation_value,
+    outside the pyramid are zero.  Output rows are in the order of `boxes`.
+    grad_group: a CropGradGroup shared by every crop of the SAME maps (same tensors, same memory format) whose
+    results all take part in the same backward pass."""
+    return _PyramidCrop.apply(boxes, box_ind, level, crop_height, crop_width, extrapolation_value, grad_group,
                               *feature_maps)

@@ -18,7 +18,7 @@ import torch.nn.functional as F
 from . import _lib
 from .conv import Conv2d, ConvTranspose2x2, GradBox, conv2d, conv_bias_relu, conv_bn_act
 from .intertwiner import class_mean, roi_level
-from .roi_align.crop_and_resize import CropAndResizeFunction, pyramid_crop_and_resize
+from .roi_align.crop_and_resize import CropAndResizeFunction, CropGradGroup, pyramid_crop_and_resize
 from .roi_pooling.functions.roi_pool import RoIPoolFunction
 
 
@@ -108,6 +108,17 @@ class Bottleneck(nn.Module):
             out = conv_bn_act(x, self.conv1, self.bn1, relu=True, dx_add_from=box)
             out = conv_bn_act(out, self.conv2, self.bn2, relu=True)
             return conv_bn_act(out, self.conv3, self.bn3, relu=True, residual=x, res_grad_to=box)
+        if self.downsample is not None and _fused_path(x, self.bn1, self.bn3, self.downsample[1]) and \
+                x.requires_grad and torch.is_grad_enabled():
+            # projection shortcut: x receives the data gradients of conv1 and of the projection.  The projection
+            # is applied after conv1, so its backward runs first; it leaves its gradient in the box (for the
+            # stride-2 blocks in compact form: only even positions are non-zero) and conv1's backward adds it
+            # inside its own data-gradient kernel -- no zero fill, strided scatter and add over block-sized tensors.
+            box = GradBox()
+            out = conv_bn_act(x, self.conv1, self.bn1, relu=True, dx_add_from=box)
+            out = conv_bn_act(out, self.conv2, self.bn2, relu=True)
+            residual = conv_bn_act(x, self.downsample[0], self.downsample[1], relu=False, dx_give_to=box)
+            return conv_bn_act(out, self.conv3, self.bn3, relu=True, residual=residual)
         out = conv_bn_act(x, self.conv1, self.bn1, relu=True)
         out = conv_bn_act(out, self.conv2, self.bn2, relu=True)
         residual = x
@@ -312,9 +323,9 @@ class Dev(nn.Module):
         """RoIs that act as 'big' supervision at pyramid level `level` (:366-378)."""
         return roi_lvl > level if level < 5 else torch.zeros_like(roi_lvl, dtype=torch.bool)
 
-    def _crop(self, maps, boxes, box_ind, level, size):
+    def _crop(self, maps, boxes, box_ind, level, size, grad_group=None):
         if self.roi_type == 'roi_align':
-            return pyramid_crop_and_resize(maps, boxes, box_ind, level, size, size)
+            return pyramid_crop_and_resize(maps, boxes, box_ind, level, size, size, grad_group=grad_group)
         # roi_pool: per level (the RoIPool kernel takes pixel boxes and a per-level scale)
         out = boxes.new_zeros(boxes.size(0), maps[0].size(1), size, size)
         pix = self._make_roi_pool_box_input(boxes, box_ind)
@@ -363,8 +374,9 @@ class Dev(nn.Module):
             return seq(m)
         up_maps = [make_up(i, m) for i, m in enumerate(x)]
         n2, n3, n4, n5 = (int(v) for v in counts_ready().tolist())
-        pooled = self._crop(up_maps, boxes, box_ind, level, self.pool_size)
-        mask_and_feat = self._crop(up_maps, boxes, box_ind, level, self.mask_pool_size)
+        group = CropGradGroup()      # both crops' gradients accumulate in ONE set of buffers (no add pass per level)
+        pooled = self._crop(up_maps, boxes, box_ind, level, self.pool_size, group)
+        mask_and_feat = self._crop(up_maps, boxes, box_ind, level, self.mask_pool_size, group)
         if cfg.DEV.BASELINE:
             return pooled, mask_and_feat, []
 
@@ -493,10 +505,13 @@ class Mask(nn.Module):
         self.sigmoid = nn.Sigmoid()
         self.relu = nn.ReLU(inplace=True)
 
-    def forward(self, x, shuffled=True):
+    def forward(self, x, shuffled=True, activate=True):
         """shuffled=True: [N, K, 28, 28] as the reference (lib/sub_module.py:769-787).
         shuffled=False: the same values as [N, 2, 2, K, 14, 14] with out[n,k,2h+a,2w+b] = u[n,a,b,k,h,w]
-        (training: the loss gathers the class channel first and shuffles only that)."""
+        (training: the loss gathers the class channel first and shuffles only that).
+        activate=False (training, with shuffled=False): conv5's LOGITS; the sigmoid (:786) is applied by the
+        loss to the one class channel per RoI it reads (compute_mrcnn_mask_loss_unshuffled(from_logits=True)) --
+        an elementwise op commuted with a gather: same values, 1/81 of the elements."""
         x = conv_bn_act(x, self.conv1, self.bn1, relu=True)
         x = conv_bn_act(x, self.conv2, self.bn2, relu=True)
         x = conv_bn_act(x, self.conv3, self.bn3, relu=True)
@@ -505,7 +520,9 @@ class Mask(nn.Module):
         # they run before the pixel shuffle and only 81 channels are ever moved
         u = self.deconv.forward_unshuffled(x, relu=True)                 # [N, 2, 2, 256, H, W]
         n, h, w = u.shape[0], u.shape[4], u.shape[5]
-        y = self.sigmoid(self.conv5(u.view(n * 4, u.shape[3], h, w)))
+        y = self.conv5(u.view(n * 4, u.shape[3], h, w))
+        if activate:
+            y = self.sigmoid(y)
         y = y.view(n, 2, 2, y.shape[1], h, w)
         if not shuffled:
             return y

@@ -133,6 +133,23 @@ int fi_pyramid_crop_backward_nhwc(const float *grads, float *const *level_grads_
                                   int num_boxes, int batch, int depth, int crop_h,
                                   int crop_w, fi_stream_t stream);
 
+/* The two backward entry points WITHOUT the zero fill: the gradients are ADDED to what the level maps hold.
+ * A map that is cropped by two launches (the Dev stage pools 7x7 and 14x14 from the same maps,
+ * lib/sub_module.py:549-577) receives both contributions in one buffer -- the kernels add with atomics anyway --
+ * instead of two cleared buffers and an add pass per level. */
+int fi_pyramid_crop_backward_accumulate(const float *grads, float *const *level_grads_host,
+                                        const int *level_h_host, const int *level_w_host,
+                                        int num_levels, const float *boxes,
+                                        const int32_t *box_ind, const int32_t *level,
+                                        int num_boxes, int batch, int depth, int crop_h,
+                                        int crop_w, fi_stream_t stream);
+int fi_pyramid_crop_backward_nhwc_accumulate(const float *grads, float *const *level_grads_host,
+                                             const int *level_h_host, const int *level_w_host,
+                                             int num_levels, const float *boxes,
+                                             const int32_t *box_ind, const int32_t *level,
+                                             int num_boxes, int batch, int depth, int crop_h,
+                                             int crop_w, fi_stream_t stream);
+
 /* ------------------------------------------------------------------------
  * RoIPool (Caffe max pooling)
  * Replaces: roi_pooling_forward_cuda   lib/roi_pooling/src/roi_pooling_cuda.c:7-47
@@ -284,6 +301,14 @@ typedef struct {
 } FiTransposeDesc;
 int fi_weight_transpose_batch(const FiTransposeDesc *descs_dev, int n, long total_tiles,
                               fi_stream_t stream);
+
+/* Data gradient of a stride-2 convolution assembled from its residue classes in ONE pass (no counterpart in the
+ * reference: cuDNN's strided backward-data, reached through lib/sub_module.py's stride-2 Conv2d layers).
+ * dx[p][h][w] = c<h&1><w&1>[p][h>>1][w>>1] (+ add[p][h][w]); class (a, b) is [planes][ceil((H-a)/2)][ceil((W-b)/2)]
+ * or NULL (that class has no taps: zeros); add is [planes][H][W] or NULL.  Every element of dx is written. */
+int fi_stride2_interleave(const float *c00, const float *c01, const float *c10, const float *c11,
+                          const float *add, float *dx, long planes, int height, int width,
+                          fi_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * bf16-input, fp32-accumulate variants (v_mfma_f32_32x32x16_bf16) for BASELINE configs[4]'s reduced-

@@ -334,3 +334,58 @@ def test_full_size_adjoint_identities(case):
         ysum = conv2d(x.detach() + x2, w.detach(), None, (1, 1), (pd, pd))
         y2 = conv2d(x2, w.detach(), None, (1, 1), (pd, pd))
         assert float((ysum - y.detach() - y2).abs().max()) <= 2e-5 * math.sqrt(Cin * R * R) * float(ysum.abs().max())
+
+
+@pytest.mark.parametrize("inplanes,planes,stride,proj,hw", [(64, 64, 1, True, (16, 16)), (256, 128, 2, True, (16, 24)),
+                                                            (256, 128, 2, True, (15, 13)), (256, 64, 1, False, (12, 12)),
+                                                            (512, 256, 2, True, (28, 28))])
+def test_bottleneck_block_matches_torch_reference(inplanes, planes, stride, proj, hw):
+    """A whole residual block (lib/sub_module.py:84-128) incl. the gradient hand-offs between its autograd nodes:
+    identity shortcut (conv3's shortcut gradient added in conv1's data-gradient epilogue) and projection shortcut
+    (the projection's data gradient -- compact for stride 2 -- added in conv1's, one interleave pass).  Reference:
+    the same block from stock torch modules in float64."""
+    import torch.nn as nn
+    from feature_intertwiner_amd.conv import Conv2d
+    from feature_intertwiner_amd.sub_module import Bottleneck
+    torch.manual_seed(inplanes + planes + stride + hw[0])
+    ds = None
+    if proj:
+        ds = nn.Sequential(Conv2d(inplanes, planes * 4, kernel_size=1, stride=stride), nn.BatchNorm2d(planes * 4, eps=0.001))
+    blk = Bottleneck(inplanes, planes, stride, ds)
+    for m in blk.modules():
+        if isinstance(m, nn.BatchNorm2d):
+            m.weight.data.uniform_(0.5, 1.5)
+            m.bias.data.normal_(0, 0.1)
+            m.running_mean.normal_(0, 0.1)
+            m.running_var.uniform_(0.5, 1.5)
+    blk.eval()
+
+    def ref_forward(x, sd):
+        c = lambda name, inp, st=1, pd=0: F.conv2d(inp, sd[name + ".weight"], sd[name + ".bias"], stride=st, padding=pd)
+        bn = lambda name, inp, eps=0.001: F.batch_norm(inp, sd[name + ".running_mean"], sd[name + ".running_var"],
+                                                        sd[name + ".weight"], sd[name + ".bias"], False, 0.0, eps)
+        out = F.relu(bn("bn1", c("conv1", x, stride)))
+        out = F.relu(bn("bn2", c("conv2", out, 1, 1)))
+        out = bn("bn3", c("conv3", out))
+        res = bn("downsample.1", c("downsample.0", x, stride)) if proj else x
+        return F.relu(out + res)
+
+    x = torch.randn(3, inplanes, *hw)
+    pre = torch.nn.Conv2d(inplanes, inplanes, 1)          # makes the block's input a non-leaf with a consumer chain
+    sd = {k: v.detach().double().requires_grad_(v.dtype.is_floating_point and "running" not in k)
+          for k, v in blk.state_dict().items() if v.dtype.is_floating_point}
+    xd = x.double().requires_grad_(True)
+    yd = ref_forward(xd * 1.0, sd)
+    gy = torch.randn(yd.shape)
+    yd.backward(gy.double())
+
+    blk = blk.to(DEV)
+    xg = x.to(DEV).requires_grad_(True)
+    y = blk(xg * 1.0)
+    y.backward(gy.to(DEV))
+    tol = lambda ref: 3e-4 * (ref.abs().max().item() + 1e-6)
+    assert (y.detach().cpu().double() - yd.detach()).abs().max().item() <= tol(yd.detach())
+    assert (xg.grad.cpu().double() - xd.grad).abs().max().item() <= tol(xd.grad)
+    for k, p in blk.named_parameters():
+        assert p.grad is not None, k
+        assert (p.grad.cpu().double() - sd[k].grad).abs().max().item() <= tol(sd[k].grad), k

@@ -143,3 +143,22 @@ def test_unshuffled_mask_loss_equals_standard_form():
     l2.backward()
     g2 = std.grad.view(b, R, K, h, 2, w, 2).permute(0, 1, 4, 6, 2, 3, 5)
     assert torch.allclose(u.grad, g2, atol=1e-7)
+
+
+def test_mask_loss_from_logits_equals_sigmoid_before_the_gather():
+    """The training path hands the loss the mask head's LOGITS and the sigmoid (lib/sub_module.py:786) is applied
+    behind the class gather: same loss value bit for bit, same gradient w.r.t. the logits (non-target channels: 0,
+    exactly what the sigmoid -> gather chain gives them)."""
+    from feature_intertwiner_amd import layers as L
+    torch.manual_seed(1)
+    b, R, K, h, w = 2, 6, 5, 3, 4
+    z1 = torch.randn(b, R, 2, 2, K, h, w).requires_grad_(True)
+    z2 = z1.detach().clone().requires_grad_(True)
+    cls = torch.tensor([[1, 3, 0, 0, 4, 2], [2, 0, 0, 1, 1, 0]], dtype=torch.int32)
+    tgt = (torch.rand(b, R, 2 * h, 2 * w) > 0.5).float()
+    l1 = L.compute_mrcnn_mask_loss_unshuffled(tgt, cls, z1, from_logits=True)
+    l2 = L.compute_mrcnn_mask_loss_unshuffled(tgt, cls, torch.sigmoid(z2))
+    assert float(l1) == float(l2)
+    l1.backward()
+    l2.backward()
+    assert torch.allclose(z1.grad, z2.grad, atol=1e-8, rtol=1e-6)
