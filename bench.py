@@ -434,7 +434,7 @@ def _main():
     sync = GradientBuckets(model) if (world > 1 or force_dp) else None
     reduce_fn = all_reduce_statistics if (world > 1 or force_dp) else None
     batch = synthetic_batch(args.batch_per_gpu, args.image_size, device=dev, seed=2000 + rank)
-    model.proposal_hook = SyntheticProposals(batch[2], args.image_size, seed=7 + rank)
+    model.external_proposals = SyntheticProposals(batch[2], args.image_size, seed=7 + rank)
     model.generator = torch.Generator(device=dev).manual_seed(11 + rank)
 
     def step():

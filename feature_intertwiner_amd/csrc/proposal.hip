@@ -1,0 +1,288 @@
+// proposal.hip -- the pre-NMS stage of the proposal layer as ONE kernel, and the post-NMS gather as another.
+//
+// Specification: proposal_layer, lib/layers.py:71-139 of the reference: foreground scores -> the
+// PRE_NMS_LIMIT best anchors in descending score order (lib/layers.py:99-106: a full sort of all 261 888
+// anchors, then a slice) -> deltas * BBOX_STD_DEV -> apply_box_deltas (tools/box_utils.py:7-33) ->
+// clip_boxes to the image window (:36-60) -> [y1, x1, y2, x2, score] rows for NMS.  Ties between equal
+// scores are broken by the lower anchor index (a stable sort); the reference's torch.sort leaves them
+// unspecified.
+//
+// One 1024-thread workgroup per image:
+//   1. exact radix SELECT of the K-th largest score (3 passes of 11/11/10 bits over an order-preserving
+//      integer image of the float, histogram in LDS) -- no sort of the 261 888 scores;
+//   2. compaction of the K winners into LDS as 64-bit keys (~score bits : index); ties at the threshold are
+//      taken in index order;
+//   3. bitonic sort of the (<= 8192) keys in LDS: descending score, ascending index;
+//   4. decode + clip of the K boxes and the dets rows written coalesced.
+// Optional EXTERNAL candidates (`extra` [batch, E, 5] = box + score, e.g. precomputed proposals) take part
+// in the same selection; they rank before anchors at equal score.
+#include <stdint.h>
+
+#include "fi_common.h"
+
+namespace {
+
+typedef unsigned long long u64;
+constexpr int kSelThreads = 1024;
+constexpr int kSortCap = 8192;            // keys sorted in LDS (64 KB)
+constexpr int kBins = 2048;
+
+// order-preserving map float -> uint32 (larger float <=> larger integer; -0 < +0; NaN above +inf)
+__device__ __forceinline__ unsigned sortable(float f)
+{
+    const unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+struct SelectArgs {
+    const float *probs;      // [batch, A, prob_stride], foreground score at +prob_off
+    const float *deltas;     // [batch, A, 4]
+    const float *anchors;    // [A, 4] pixels (y1, x1, y2, x2)
+    const float *extra;      // [batch, E, 5] or null
+    float *dets;             // [batch, K, 5]
+    int A, E, K, prob_stride, prob_off;
+    float std0, std1, std2, std3, win_h, win_w;
+};
+
+__device__ __forceinline__ float score_of(const SelectArgs &a, int img, int i)
+{
+    if (i < a.E) return a.extra[((size_t)img * a.E + i) * 5 + 4];
+    return a.probs[((size_t)img * a.A + (i - a.E)) * a.prob_stride + a.prob_off];
+}
+
+// Block-wide: given hist[kBins] (counts per digit), find the digit d with
+//   count(digits > d) < want <= count(digits >= d); returns d and count(digits > d) through LDS.
+__device__ __forceinline__ void find_digit(int *hist, int nbins, int want, int *s_wave, int *s_out)
+{
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    // thread t owns bins [2t, 2t+1] counted from the TOP (descending digits)
+    const int hi = nbins - 1 - 2 * tid, lo = hi - 1;
+    const int c_hi = (hi >= 0) ? hist[hi] : 0;
+    const int c_lo = (lo >= 0) ? hist[lo] : 0;
+    int incl = c_hi + c_lo;                       // inclusive prefix over threads (descending digits)
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int v = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += v;
+    }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < wave; ++w) base += s_wave[w];
+    const int before = base + incl - (c_hi + c_lo);     // count of digits above this thread's pair
+    if (before < want && want <= before + c_hi + c_lo) {
+        if (want <= before + c_hi) { s_out[0] = hi; s_out[1] = before; }
+        else { s_out[0] = lo; s_out[1] = before + c_hi; }
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(kSelThreads) void proposal_select_kernel(SelectArgs a)
+{
+    extern __shared__ u64 s_keys[];                      // kSortCap keys; the histogram aliases its start
+    int *hist = reinterpret_cast<int *>(s_keys);
+    __shared__ int s_wave[kSelThreads / 64];
+    __shared__ int s_out[2];
+    __shared__ int s_cnt;
+    const int tid = threadIdx.x;
+    const int img = blockIdx.x;
+    const int total = a.A + a.E;
+    const int K = a.K;                                   // host guarantees 1 <= K <= min(total, kSortCap)
+
+    // ---- 1. radix select of the K-th largest key ---------------------------------------------------------
+    unsigned prefix = 0, prefix_mask = 0;
+    int want = K, count_eq = 0;
+    const int shifts[3] = {21, 10, 0};
+    const int widths[3] = {11, 11, 10};
+    for (int p = 0; p < 3; ++p) {
+        const int nb = 1 << widths[p];
+        for (int i = tid; i < kBins; i += kSelThreads) hist[i] = 0;
+        __syncthreads();
+        for (int i = tid; i < total; i += kSelThreads) {
+            const unsigned k = sortable(score_of(a, img, i));
+            if ((k & prefix_mask) == prefix) atomicAdd(&hist[(k >> shifts[p]) & (nb - 1)], 1);
+        }
+        __syncthreads();
+        find_digit(hist, nb, want, s_wave, s_out);
+        const int d = s_out[0];
+        want -= s_out[1];
+        count_eq = hist[d];              // after the last pass: how many keys equal the threshold key
+        prefix |= (unsigned)d << shifts[p];
+        prefix_mask |= (unsigned)(nb - 1) << shifts[p];
+        __syncthreads();
+    }
+    const unsigned T = prefix;           // the K-th largest key; `want` of the keys equal to T are still needed
+    const int need_eq = want;
+
+    // ---- 2. compaction -----------------------------------------------------------------------------------
+    __shared__ int s_cnt_eq;
+    if (tid == 0) { s_cnt = 0; s_cnt_eq = 0; }
+    __syncthreads();
+    const bool all_ties = (count_eq == need_eq);         // every key equal to T is a winner: no order needed
+    for (int i = tid; i < total; i += kSelThreads) {
+        const unsigned k = sortable(score_of(a, img, i));
+        if (k > T) {
+            const int pos = atomicAdd(&s_cnt, 1);
+            s_keys[pos] = ((u64)(~k) << 32) | (unsigned)i;
+        } else if (k == T && all_ties) {
+            const int pos = atomicAdd(&s_cnt_eq, 1);
+            s_keys[(K - need_eq) + pos] = ((u64)(~k) << 32) | (unsigned)i;
+        }
+    }
+    __syncthreads();
+    // more keys equal to T than places left: the lowest indices win -- walk the indices in order, 1024 at a time,
+    // ranks from wavefront ballots, stop as soon as the places are filled
+    if (!all_ties) {
+        int taken = 0;                                   // uniform across the block
+        for (int base = 0; base < total && taken < need_eq; base += kSelThreads) {
+            const int i = base + tid;
+            const bool is_eq = i < total && sortable(score_of(a, img, i)) == T;
+            const u64 ballot = __ballot(is_eq);
+            const int lane = tid & 63, wave = tid >> 6;
+            const int in_wave = __popcll(ballot & ((1ull << lane) - 1ull));
+            if (lane == 0) s_wave[wave] = __popcll(ballot);
+            __syncthreads();
+            int before = 0, chunk = 0;
+            for (int w = 0; w < kSelThreads / 64; ++w) {
+                const int c = s_wave[w];
+                if (w < wave) before += c;
+                chunk += c;
+            }
+            const int rank = taken + before + in_wave;
+            if (is_eq && rank < need_eq) s_keys[(K - need_eq) + rank] = ((u64)(~T) << 32) | (unsigned)i;
+            taken += chunk;
+            __syncthreads();
+        }
+    }
+    // pad to the next power of two with maximal keys
+    int n2 = 1;
+    while (n2 < K) n2 <<= 1;
+    for (int i = K + tid; i < n2; i += kSelThreads) s_keys[i] = ~0ull;
+    __syncthreads();
+
+    // ---- 3. bitonic sort, ascending u64 = descending score, ascending index ---------------------------------
+    for (int size = 2; size <= n2; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int t = tid; t < (n2 >> 1); t += kSelThreads) {
+                const int lo = ((t / stride) * stride * 2) + (t % stride);
+                const int hi = lo + stride;
+                const bool up = ((lo & size) == 0);
+                const u64 x = s_keys[lo], y = s_keys[hi];
+                if ((x > y) == up) { s_keys[lo] = y; s_keys[hi] = x; }
+            }
+            __syncthreads();
+        }
+    }
+
+    // ---- 4. decode + clip (tools/box_utils.py:7-60, each operation rounded separately) ------------------------
+    float *out = a.dets + (size_t)img * K * 5;
+    for (int r = tid; r < K; r += kSelThreads) {
+        const int i = (int)(unsigned)(s_keys[r] & 0xffffffffull);
+        float y1, x1, y2, x2, sc;
+        if (i < a.E) {
+            const float *e = a.extra + ((size_t)img * a.E + i) * 5;
+            y1 = e[0]; x1 = e[1]; y2 = e[2]; x2 = e[3]; sc = e[4];
+        } else {
+            const int an = i - a.E;
+            const float4 b = *reinterpret_cast<const float4 *>(a.anchors + 4 * (size_t)an);
+            const float4 d = *reinterpret_cast<const float4 *>(a.deltas + ((size_t)img * a.A + an) * 4);
+            sc = a.probs[((size_t)img * a.A + an) * a.prob_stride + a.prob_off];
+            const float d0 = d.x * a.std0, d1 = d.y * a.std1, d2 = d.z * a.std2, d3 = d.w * a.std3;
+            float height = b.z - b.x;
+            float width = b.w - b.y;
+            float cy = b.x + 0.5f * height;
+            float cx = b.y + 0.5f * width;
+            cy = cy + d0 * height;
+            cx = cx + d1 * width;
+            height = height * expf(d2);
+            width = width * expf(d3);
+            y1 = cy - 0.5f * height;
+            x1 = cx - 0.5f * width;
+            y2 = y1 + height;
+            x2 = x1 + width;
+        }
+        // clamp(min, max) = min(max(v, lo), hi), NaN propagates as in torch.clamp
+        y1 = fminf(fmaxf(y1, 0.0f), a.win_h);
+        x1 = fminf(fmaxf(x1, 0.0f), a.win_w);
+        y2 = fminf(fmaxf(y2, 0.0f), a.win_h);
+        x2 = fminf(fmaxf(x2, 0.0f), a.win_w);
+        out[r * 5 + 0] = y1;
+        out[r * 5 + 1] = x1;
+        out[r * 5 + 2] = y2;
+        out[r * 5 + 3] = x2;
+        out[r * 5 + 4] = sc;
+    }
+}
+
+// proposals[b][j] = j < num[b] ? dets[b][keep[b][j]][0:4] / (h, w, h, w) : 0   (lib/layers.py:131-137)
+__global__ __launch_bounds__(256) void proposal_gather_kernel(const float *__restrict__ dets, int K, int det_stride,
+                                                              const long long *__restrict__ keep, int keep_stride,
+                                                              const int *__restrict__ num, int P, float nh, float nw,
+                                                              float *__restrict__ out)
+{
+    const int img = blockIdx.y;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= P) return;
+    float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (j < num[img] && j < keep_stride) {
+        const long long k = keep[(size_t)img * keep_stride + j];
+        if (k >= 0 && k < K) {
+            const float *d = dets + ((size_t)img * K + k) * det_stride;
+            r = make_float4(d[0] / nh, d[1] / nw, d[2] / nh, d[3] / nw);
+        }
+    }
+    *reinterpret_cast<float4 *>(out + ((size_t)img * P + j) * 4) = r;
+}
+
+}  // namespace
+
+extern "C" {
+
+int fi_proposal_candidates(const float *probs, int prob_stride, int prob_offset, const float *deltas,
+                           const float *anchors, const float *extra, int batch, int num_anchors, int num_extra,
+                           int pre_nms, const float *bbox_std_host, float window_h, float window_w, float *dets,
+                           fi_stream_t stream)
+{
+    FI_REQUIRE(batch >= 0 && num_anchors >= 0 && num_extra >= 0, "sizes must be non-negative");
+    FI_REQUIRE(pre_nms >= 1 && pre_nms <= kSortCap, "1 <= pre_nms <= 8192");
+    FI_REQUIRE((long)num_anchors + num_extra >= pre_nms, "fewer candidates than pre_nms");
+    FI_REQUIRE(prob_stride >= 1 && prob_offset >= 0 && prob_offset < prob_stride, "bad score stride / offset");
+    FI_REQUIRE(bbox_std_host && dets && (num_anchors == 0 || (probs && deltas && anchors)), "null pointer");
+    FI_REQUIRE(num_extra == 0 || extra, "null extra candidates");
+    FI_REQUIRE(((uintptr_t)anchors | (uintptr_t)deltas) % 16 == 0, "anchors / deltas must be 16-byte aligned");
+    if (batch == 0) return FI_OK;
+    SelectArgs a;
+    a.probs = probs; a.deltas = deltas; a.anchors = anchors; a.extra = extra; a.dets = dets;
+    a.A = num_anchors; a.E = num_extra; a.K = pre_nms; a.prob_stride = prob_stride; a.prob_off = prob_offset;
+    a.std0 = bbox_std_host[0]; a.std1 = bbox_std_host[1]; a.std2 = bbox_std_host[2]; a.std3 = bbox_std_host[3];
+    a.win_h = window_h; a.win_w = window_w;
+    const size_t lds = sizeof(u64) * kSortCap;
+    static bool attr_set = false;
+    if (!attr_set) {
+        FI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(proposal_select_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(proposal_select_kernel, dim3(batch), dim3(kSelThreads), lds, (hipStream_t)stream, a);
+    FI_HIP_CHECK(hipGetLastError());
+    return FI_OK;
+}
+
+int fi_proposal_gather(const float *dets, int pre_nms, int det_stride, const int64_t *keep, int keep_stride,
+                       const int32_t *num, int batch, int proposal_count, float norm_h, float norm_w,
+                       float *proposals, fi_stream_t stream)
+{
+    FI_REQUIRE(batch >= 0 && pre_nms >= 0 && proposal_count >= 0 && det_stride >= 4 && keep_stride >= 0,
+               "bad sizes");
+    FI_REQUIRE(batch == 0 || proposal_count == 0 || (dets && keep && num && proposals), "null pointer");
+    FI_REQUIRE((uintptr_t)proposals % 16 == 0, "proposals must be 16-byte aligned");
+    if (batch == 0 || proposal_count == 0) return FI_OK;
+    hipLaunchKernelGGL(proposal_gather_kernel, dim3((proposal_count + 255) / 256, batch), dim3(256), 0,
+                       (hipStream_t)stream, dets, pre_nms, det_stride, (const long long *)keep, keep_stride, num,
+                       proposal_count, norm_h, norm_w, proposals);
+    FI_HIP_CHECK(hipGetLastError());
+    return FI_OK;
+}
+
+}  // extern "C"

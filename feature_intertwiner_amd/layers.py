@@ -100,35 +100,49 @@ def bbox_overlaps(boxes1, boxes2):
 # --------------------------------------------------------------------------------------
 # proposal layer (lib/layers.py:71-139)
 # --------------------------------------------------------------------------------------
-def proposal_layer(inputs, proposal_count, nms_threshold, priors, config, proposal_hook=None):
+def proposal_layer(inputs, proposal_count, nms_threshold, priors, config, extra_dets=None):
     """rpn_probs [b, A, 2], rpn_bbox [b, A, 4] -> normalised proposals [b, proposal_count, 4]
     (zero rows past each image's count) and the per-image counts [b] (int32, on the GPU).
 
+    Three launches: fi_proposal_candidates (selection of the PRE_NMS_LIMIT best foreground scores in descending
+    order -- ties: lower anchor index --, deltas * BBOX_STD_DEV, apply_box_deltas, clip_boxes: lib/layers.py:99-127
+    as one kernel, no sort of all 261 888 anchors), fi_nms_sorted, fi_proposal_gather (kept boxes / image size).
     The reference truncates every image to the shortest keep list, which needs the counts on
     the host (lib/nms/nms_wrapper.py:29-33); here shapes are static and the count
-    travels with the tensor.  `proposal_hook(boxes, scores) -> (boxes, scores)` (pixel boxes
-    [b, pre_nms, 4], scores sorted descending) lets the synthetic benchmark plant
-    object-like proposals among the random-weight RPN output; it must keep scores sorted.
+    travels with the tensor.  `extra_dets` [b, E, 5] = (y1, x1, y2, x2, score) in pixels: external proposals that
+    compete with the RPN's candidates on their scores (precomputed proposals; the synthetic benchmark's
+    object-like boxes, synthetic.SyntheticProposals) -- None in normal use.
     """
-    scores = inputs[0][:, :, 1]
-    deltas = inputs[1] * const_tensor(config.DATA.BBOX_STD_DEV, scores.device).view(1, 1, 4)
-    anchors = priors.to(scores.device)
-    pre_nms_limit = min(config.RPN.PRE_NMS_LIMIT, anchors.size(0))
-    scores, order = torch.topk(scores, pre_nms_limit, dim=1, sorted=True)
-    deltas_trim = torch.gather(deltas, 1, order.unsqueeze(2).expand(-1, -1, 4))
-    anchors_trim = anchors[order]
-    boxes = apply_box_deltas(anchors_trim, deltas_trim)
+    import ctypes
+    from . import _lib
+    probs, deltas = inputs[0].detach(), inputs[1].detach()
+    _lib.require_cuda(probs, deltas)
+    L = _lib.load()
+    probs = probs.contiguous().float()
+    deltas = deltas.contiguous().float()
+    anchors = priors.to(probs.device).contiguous().float()
+    b, A = probs.size(0), probs.size(1)
+    E = 0
+    if extra_dets is not None:
+        extra_dets = extra_dets.detach().contiguous().float()
+        E = extra_dets.size(1)
+    pre_nms_limit = min(config.RPN.PRE_NMS_LIMIT, A + E)
     height, width = float(config.DATA.IMAGE_SHAPE[0]), float(config.DATA.IMAGE_SHAPE[1])
-    boxes = clip_boxes(boxes, (0.0, 0.0, height, width))
-    if proposal_hook is not None:
-        boxes, scores = proposal_hook(boxes, scores)
-    dets = torch.cat((boxes, scores.unsqueeze(2)), 2).detach()
+    dets = torch.empty((b, pre_nms_limit, 5), device=probs.device, dtype=torch.float32)
+    std = (ctypes.c_float * 4)(*[float(v) for v in config.DATA.BBOX_STD_DEV])
+    with torch.cuda.device(probs.device):
+        _lib.check(L.fi_proposal_candidates(_lib.ptr(probs), probs.size(2), 1, _lib.ptr(deltas), _lib.ptr(anchors),
+                                            _lib.ptr(extra_dets), b, A, E, pre_nms_limit, std, height, width,
+                                            _lib.ptr(dets), _lib.current_stream()), "fi_proposal_candidates")
+    if _lib.TAP is not None:
+        _lib.TAP("proposal_candidates", probs=probs, deltas=deltas, anchors=anchors, extra=extra_dets, dets=dets)
     keep, num = nms_sorted(dets, nms_threshold, max_keep=proposal_count)
-    keep = keep[:, :proposal_count]
-    valid = torch.arange(keep.size(1), device=keep.device).unsqueeze(0) < num.unsqueeze(1)
-    boxes_keep = torch.gather(boxes, 1, keep.unsqueeze(2).expand(-1, -1, 4)) * valid.unsqueeze(2).float()
-    norm = const_tensor([height, width, height, width], boxes.device)
-    return boxes_keep / norm, num
+    out = torch.empty((b, proposal_count, 4), device=probs.device, dtype=torch.float32)
+    with torch.cuda.device(probs.device):
+        _lib.check(L.fi_proposal_gather(_lib.ptr(dets), pre_nms_limit, 5, _lib.ptr(keep), keep.size(1), _lib.ptr(num), b,
+                                        proposal_count, height, width, _lib.ptr(out), _lib.current_stream()),
+                   "fi_proposal_gather")
+    return out, num
 
 
 # --------------------------------------------------------------------------------------

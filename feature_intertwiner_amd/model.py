@@ -26,7 +26,8 @@ class MaskRCNN(nn.Module):
         self._build(config)
         self._initialize_weights()
         self.feature_buffer = None
-        self.proposal_hook = None     # synthetic-benchmark hook, see layers.proposal_layer
+        self.external_proposals = None   # optional callable -> [b, E, 5] rows that compete with the RPN's candidates
+                                         # before NMS (precomputed proposals; synthetic.SyntheticProposals)
         self.generator = None         # optional torch.Generator for target sub-sampling
 
     def _build(self, config):
@@ -108,8 +109,9 @@ class MaskRCNN(nn.Module):
         rpn_logits, rpn_probs, rpn_bbox = [torch.cat(list(o), dim=1) for o in zip(*outs)]
 
         with torch.no_grad():
+            extra = self.external_proposals() if self.external_proposals is not None else None
             proposals, num_prop = proposal_layer([rpn_probs, rpn_bbox], proposal_cnt, cfg.RPN.NMS_THRESHOLD,
-                                                 self.priors, cfg, self.proposal_hook)
+                                                 self.priors, cfg, extra)
             h, w = float(cfg.DATA.IMAGE_SHAPE[0]), float(cfg.DATA.IMAGE_SHAPE[1])
             scale = const_tensor([h, w, h, w], images.device)
             target_rpn_match, target_rpn_deltas = rpn_target_ready()
@@ -166,8 +168,9 @@ class MaskRCNN(nn.Module):
         mrcnn_maps = [p2, p3, p4, p5]
         outs = [self.rpn(p) for p in (p2, p3, p4, p5, p6)]
         _, rpn_probs, rpn_bbox = [torch.cat(list(o), dim=1) for o in zip(*outs)]
+        extra = self.external_proposals() if self.external_proposals is not None else None
         proposals, _ = proposal_layer([rpn_probs, rpn_bbox], cfg.RPN.POST_NMS_ROIS_INFERENCE,
-                                      cfg.RPN.NMS_THRESHOLD, self.priors, cfg, self.proposal_hook)
+                                      cfg.RPN.NMS_THRESHOLD, self.priors, cfg, extra)
         pooled_cls, _, feat_out = self.dev_roi(mrcnn_maps, proposals)
         small_output_all, small_gt_all = feat_out if feat_out else (None, None)
         _, mrcnn_class, mrcnn_bbox = self.classifier(pooled_cls, small_output_all, small_gt_all)

@@ -3,11 +3,12 @@ pretrained checkpoint on the GPU box, so inputs are seeded random tensors of the
 shape and the network is randomly initialised.
 
 Because a randomly initialised RPN proposes nothing object-like, `SyntheticProposals`
-plants jittered copies of the ground-truth boxes among the RPN's pre-NMS candidates, so
-that NMS sees realistically clustered boxes and the target sampler finds enough positive
-RoIs to fill TRAIN_ROIS_PER_IMAGE -- i.e. the heads, RoIAlign and the intertwiner run at
-their full configured size.  Every stage still executes (RPN convs, top-k, decode, clip,
-NMS, sampling); only the VALUES of part of the candidate boxes are synthetic.
+supplies jittered copies of the ground-truth boxes as EXTERNAL proposals that compete with
+the RPN's candidates before NMS, so that NMS sees realistically clustered boxes and the
+target sampler finds enough positive RoIs to fill TRAIN_ROIS_PER_IMAGE -- i.e. the heads,
+RoIAlign and the intertwiner run at their full configured size.  Every stage still executes
+(RPN convs, selection of the best candidates, decode, clip, NMS, sampling); only the VALUES
+of part of the candidate boxes are synthetic.
 """
 import math
 
@@ -35,8 +36,11 @@ def synthetic_batch(batch, image_size, n_gt=20, num_classes=81, mini_mask=56, de
 
 
 class SyntheticProposals(object):
-    """proposal_hook for layers.proposal_layer: overwrite the LOWEST-scoring `n_plant` of the
-    pre-NMS candidates with jittered GT copies carrying the highest scores."""
+    """External proposal source for the synthetic benchmark / tests (MaskRCNN.external_proposals): every call
+    returns `n_plant` jittered copies of the ground-truth boxes per image as rows (y1, x1, y2, x2, score) with
+    scores 2.0 .. 1.5 -- above any RPN probability -- so that they take the top of the pre-NMS ranking and the
+    best PRE_NMS_LIMIT - n_plant RPN candidates follow in their own order.  The proposal layer itself knows
+    nothing about this: it receives the rows as `extra_dets` (layers.proposal_layer)."""
 
     def __init__(self, gt_boxes, image_size, n_plant=3000, jitter=0.2, seed=7):
         self.gt_boxes = gt_boxes
@@ -45,11 +49,10 @@ class SyntheticProposals(object):
         self.jitter = jitter
         self.gen = torch.Generator(device=gt_boxes.device).manual_seed(seed)
 
-    def __call__(self, boxes, scores):
-        b, n, _ = boxes.shape
-        k = min(self.n_plant, n)
-        G = self.gt_boxes.size(1)
-        dev = boxes.device
+    def __call__(self):
+        b, G = self.gt_boxes.size(0), self.gt_boxes.size(1)
+        k = self.n_plant
+        dev = self.gt_boxes.device
         which = torch.randint(0, G, (b, k), device=dev, generator=self.gen)
         gt = torch.gather(self.gt_boxes, 1, which.unsqueeze(2).expand(-1, -1, 4))
         h = gt[..., 2] - gt[..., 0]
@@ -62,9 +65,5 @@ class SyntheticProposals(object):
         h = h * (1 + r())
         w = w * (1 + r())
         planted = torch.stack([cy - h / 2, cx - w / 2, cy + h / 2, cx + w / 2], 2).clamp(0, self.size)
-        # planted boxes take the top of the ranking; the displaced RPN candidates keep their order
-        new_boxes = torch.cat([planted, boxes[:, :n - k]], 1)
-        top = scores[:, :1].detach()
-        planted_scores = top + torch.linspace(1.0, 0.5, k, device=dev).unsqueeze(0)
-        new_scores = torch.cat([planted_scores, scores[:, :n - k]], 1)
-        return new_boxes, new_scores
+        scores = torch.linspace(2.0, 1.5, k, device=dev).view(1, k, 1).expand(b, -1, -1)
+        return torch.cat([planted, scores], 2).contiguous()

@@ -302,6 +302,26 @@ typedef struct {
 int fi_weight_transpose_batch(const FiTransposeDesc *descs_dev, int n, long total_tiles,
                               fi_stream_t stream);
 
+/* ------------------------------------------------------------------------
+ * Proposal layer around NMS.  Replaces the tensor-op chain of proposal_layer,
+ * lib/layers.py:71-139 (scores[:, :, 1] -> sort -> slice -> deltas * BBOX_STD_DEV ->
+ * tools/box_utils.py apply_box_deltas :7-33 -> clip_boxes :36-60 -> cat) with one launch per call.
+ * probs  [batch, A, prob_stride]: the foreground score of anchor a is probs[b][a][prob_offset]
+ * deltas [batch, A, 4], anchors [A, 4] pixels (y1, x1, y2, x2), both 16-byte aligned
+ * extra  [batch, E, 5] (y1, x1, y2, x2, score) external candidates that compete with the anchors, or NULL
+ * dets   [batch, pre_nms, 5]: the pre_nms best candidates, descending score (ties: extra before anchors, then
+ *        lower index), boxes decoded and clipped to [0, window_h] x [0, window_w]; pre_nms <= 8192.
+ * bbox_std_host: 4 floats on the HOST. */
+int fi_proposal_candidates(const float *probs, int prob_stride, int prob_offset, const float *deltas,
+                           const float *anchors, const float *extra, int batch, int num_anchors,
+                           int num_extra, int pre_nms, const float *bbox_std_host, float window_h,
+                           float window_w, float *dets, fi_stream_t stream);
+/* proposals[b][j] = dets[b][keep[b][j]][0:4] / (norm_h, norm_w, norm_h, norm_w) for j < num[b], zero rows after
+ * (lib/layers.py:131-137 without the host-side truncation to the shortest keep list). */
+int fi_proposal_gather(const float *dets, int pre_nms, int det_stride, const int64_t *keep, int keep_stride,
+                       const int32_t *num, int batch, int proposal_count, float norm_h, float norm_w,
+                       float *proposals, fi_stream_t stream);
+
 /* Data gradient of a stride-2 convolution assembled from its residue classes in ONE pass (no counterpart in the
  * reference: cuDNN's strided backward-data, reached through lib/sub_module.py's stride-2 Conv2d layers).
  * dx[p][h][w] = c<h&1><w&1>[p][h>>1][w>>1] (+ add[p][h][w]); class (a, b) is [planes][ceil((H-a)/2)][ceil((W-b)/2)]

@@ -353,6 +353,45 @@ class MetaLoss(object):
 IOU_EPS = np.float32(10e-20)     # tools/box_utils.py:4
 
 
+def proposal_candidates(probs, deltas, anchors, pre_nms, bbox_std, window_hw, extra=None):
+    """The pre-NMS half of proposal_layer (lib/layers.py:99-127) for ONE image: foreground scores probs[:, 1],
+    the pre_nms best in descending order -- the reference's full sort (:99-106) made deterministic: ties go to the
+    lower index, `extra` rows [E, 5] rank before anchors at equal score --, deltas * BBOX_STD_DEV (:96),
+    apply_box_deltas (tools/box_utils.py:7-33) and clip_boxes (:36-60), every operation in float32.
+    Returns (dets [pre_nms, 5], chosen [pre_nms] indices into the concatenation (extra, anchors))."""
+    f = np.float32
+    scores = np.asarray(probs, f)[:, 1]
+    E = 0 if extra is None else len(extra)
+    if E:
+        scores = np.concatenate([np.asarray(extra, f)[:, 4], scores])
+    order = np.argsort(-scores.astype(np.float64), kind="stable")[:pre_nms]
+    out = np.zeros((len(order), 5), f)
+    an = order >= E
+    a_idx = order[an] - E
+    b = np.asarray(anchors, f)[a_idx]
+    d = np.asarray(deltas, f)[a_idx] * np.asarray(bbox_std, f)[None, :]
+    h = b[:, 2] - b[:, 0]
+    w = b[:, 3] - b[:, 1]
+    cy = b[:, 0] + f(0.5) * h
+    cx = b[:, 1] + f(0.5) * w
+    cy = cy + d[:, 0] * h
+    cx = cx + d[:, 1] * w
+    h = h * np.exp(d[:, 2])
+    w = w * np.exp(d[:, 3])
+    y1 = cy - f(0.5) * h
+    x1 = cx - f(0.5) * w
+    out[an, 0], out[an, 1], out[an, 2], out[an, 3] = y1, x1, y1 + h, x1 + w
+    if E:
+        out[~an, :4] = np.asarray(extra, f)[order[~an], :4]
+    H, W = f(window_hw[0]), f(window_hw[1])
+    out[:, 0] = np.minimum(np.maximum(out[:, 0], f(0)), H)
+    out[:, 1] = np.minimum(np.maximum(out[:, 1], f(0)), W)
+    out[:, 2] = np.minimum(np.maximum(out[:, 2], f(0)), H)
+    out[:, 3] = np.minimum(np.maximum(out[:, 3], f(0)), W)
+    out[:, 4] = scores[order]
+    return out, order
+
+
 def compute_iou(boxes1, boxes2):
     """tools/box_utils.py:112-140, fp32 in the reference's operation order; [N1, N2]."""
     b1, b2 = _f32(boxes1)[:, None, :], _f32(boxes2)[None, :, :]

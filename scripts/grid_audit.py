@@ -10,7 +10,7 @@ from feature_intertwiner_amd.workflow import set_optimizer, train_step
 dev="cuda:0"; torch.manual_seed(2000)
 cfg = make_config("resnet101", 1024, 4, 512, dev_switch=True, loss_choice="ot", ot_L=50)
 m = MaskRCNN(cfg).to(dev); opt = set_optimizer(m, cfg.TRAIN)
-b = synthetic_batch(4, 1024, device=dev, seed=2000); m.proposal_hook = SyntheticProposals(b[2], 1024, seed=7)
+b = synthetic_batch(4, 1024, device=dev, seed=2000); m.external_proposals = SyntheticProposals(b[2], 1024, seed=7)
 m.generator = torch.Generator(device=dev).manual_seed(1)
 train_step(m, opt, list(b))
 C.SHAPE_LOG = []

@@ -14,7 +14,7 @@ cfg = make_config("resnet101", 1024, 4, 512, dev_switch=True, loss_choice="ot", 
 model = MaskRCNN(cfg).to(dev)
 opt = set_optimizer(model, cfg.TRAIN)
 batch = synthetic_batch(4, 1024, device=dev, seed=2000)
-model.proposal_hook = SyntheticProposals(batch[2], 1024, seed=7)
+model.external_proposals = SyntheticProposals(batch[2], 1024, seed=7)
 model.generator = torch.Generator(device=dev).manual_seed(2000)
 for _ in range(3):
     train_step(model, opt, list(batch))

@@ -29,7 +29,7 @@ model = MaskRCNN(cfg).cuda()
 print("params", sum(p.numel() for p in model.parameters()) / 1e6, "M")
 opt = set_optimizer(model, cfg.TRAIN)
 batch = synthetic_batch(a.batch, a.size)
-model.proposal_hook = SyntheticProposals(batch[2], a.size)
+model.external_proposals = SyntheticProposals(batch[2], a.size)
 for i in range(a.steps):
     torch.cuda.synchronize()
     t = time.time()

@@ -11,7 +11,7 @@ dev = "cuda:0"; torch.manual_seed(2000)
 cfg = make_config("resnet101", 1024, 4, 512, dev_switch=True, loss_choice="ot", ot_L=50,
                   conv_precision=os.environ.get("FI_SOAK_PRECISION", "fp32"))
 m = MaskRCNN(cfg).to(dev); opt = set_optimizer(m, cfg.TRAIN)
-b = synthetic_batch(4, 1024, device=dev, seed=2000); m.proposal_hook = SyntheticProposals(b[2], 1024, seed=7)
+b = synthetic_batch(4, 1024, device=dev, seed=2000); m.external_proposals = SyntheticProposals(b[2], 1024, seed=7)
 m.generator = torch.Generator(device=dev).manual_seed(1)
 t0 = time.perf_counter()
 for i in range(steps):

@@ -71,7 +71,7 @@ def test_resume_reproduces_the_next_step(tmp_path):
 
     def fresh():
         m = MaskRCNN(cfg).to(DEV)
-        m.proposal_hook = SyntheticProposals(batch[2], 256, seed=7)
+        m.external_proposals = SyntheticProposals(batch[2], 256, seed=7)
         m.generator = torch.Generator(device=DEV).manual_seed(5)
         return m
     model = fresh()
@@ -80,7 +80,7 @@ def test_resume_reproduces_the_next_step(tmp_path):
         train_step(model, opt, list(batch))
     path = str(tmp_path / "ckpt.pth")
     save_model(model, path, epoch=1, iter=2, loss_data=[1.0, 2.0])
-    hook_state = model.proposal_hook.gen.get_state()
+    hook_state = model.external_proposals.gen.get_state()
     gen_state = model.generator.get_state()
     with torch.no_grad():
         _, t_ref = compute_loss(model, list(batch))             # the next step's losses (also advances the buffer)
@@ -88,7 +88,7 @@ def test_resume_reproduces_the_next_step(tmp_path):
     resumed = fresh()
     ep, it, loss_data, missing, unexpected = load_model(resumed, path, map_location=DEV)
     assert (ep, it, loss_data) == (1, 3, [1.0, 2.0]) and not missing and not unexpected
-    resumed.proposal_hook.gen.set_state(hook_state)
+    resumed.external_proposals.gen.set_state(hook_state)
     resumed.generator.set_state(gen_state)
     with torch.no_grad():
         _, t_new = compute_loss(resumed, list(batch))

@@ -148,7 +148,7 @@ def test_bf16_train_step_tracks_fp32():
         torch.manual_seed(7)
         cfg = make_config("resnet50", 256, 2, 64, dev_switch=True, loss_choice="l2", conv_precision=mode)
         model = MaskRCNN(cfg).to(DEV)
-        model.proposal_hook = SyntheticProposals(batch[2], 256, seed=7)
+        model.external_proposals = SyntheticProposals(batch[2], 256, seed=7)
         model.generator = torch.Generator(device=DEV).manual_seed(5)
         with torch.no_grad():
             _, terms[mode] = compute_loss(model, list(batch))

@@ -98,7 +98,7 @@ def _worker(rank, port, variant, outdir, size="small"):
     broadcast_parameters(model)
     opt = set_optimizer(model, cfg.TRAIN)
     sync = GradientBuckets(model, bucket_bytes=(4 << 20) if size == "small" else None)
-    model.proposal_hook, model.generator = hook, gen
+    model.external_proposals, model.generator = hook, gen
     opt.zero_grad(set_to_none=True)
     loss, terms = compute_loss(model, list(batch), do_meta, WORLD, all_reduce_statistics)
     sync.begin(("do_meta", do_meta))
@@ -133,7 +133,7 @@ def test_two_rank_model_step_equals_single_process_rule(variant, size):
     outs = []
     for g in range(WORLD):                       # nn.DataParallel: every replica runs its shard ...
         batch, hook, gen = _shard(g, SIZES[size][1])
-        model.proposal_hook, model.generator = hook, gen
+        model.external_proposals, model.generator = hook, gen
         outs.append(model(list(batch), 'train'))
     merged = [torch.cat([o[i] for o in outs], 0) for i in range(9)]     # ... outputs gathered on dim 0
     detailed = merged[0].mean(0)
@@ -198,7 +198,7 @@ def _worker_cfg4(rank, port, outdir):
     opt = set_optimizer(model, cfg.TRAIN)
     sync = GradientBuckets(model)
     batch = synthetic_batch(2, 1024, device=DEV, seed=2000 + rank)
-    model.proposal_hook = SyntheticProposals(batch[2], 1024, seed=7 + rank)
+    model.external_proposals = SyntheticProposals(batch[2], 1024, seed=7 + rank)
     model.generator = torch.Generator(device=DEV).manual_seed(11 + rank)
     hist = []
     for _ in range(2):

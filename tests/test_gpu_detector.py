@@ -61,28 +61,96 @@ def test_det_targets_invariants():
         assert torch.all(d == 0)
 
 
-def test_proposal_layer_matches_oracle_nms(oracle):
+def _priors(cfg):
+    from feature_intertwiner_amd import layers as L
+    return torch.from_numpy(L.generate_pyramid_priors(cfg.RPN.ANCHOR_SCALES, cfg.RPN.ANCHOR_RATIOS,
+                                                      cfg.MODEL.BACKBONE_SHAPES, cfg.MODEL.BACKBONE_STRIDES, 1)).float().to(DEV)
+
+
+def _check_candidates(oracle, tap, cfg, size):
+    """fi_proposal_candidates vs the oracle restatement, per image: the SAME candidates in the SAME order (scores
+    identical, which pins the selection and the tie rule), boxes to 2 ulp of the image size (the device exp and
+    numpy's differ in the last bit)."""
+    probs, deltas, anchors, extra, dets = (tap[k] for k in ("probs", "deltas", "anchors", "extra", "dets"))
+    K = dets.shape[1]
+    for b in range(probs.shape[0]):
+        exp, order = oracle.proposal_candidates(probs[b].cpu().numpy(), deltas[b].cpu().numpy(), anchors.cpu().numpy(), K,
+                                                cfg.DATA.BBOX_STD_DEV, (size, size),
+                                                None if extra is None else extra[b].cpu().numpy())
+        got = dets[b].cpu().numpy()
+        assert np.array_equal(got[:, 4], exp[:, 4]), "selection / order differs"
+        assert np.all(np.diff(got[:, 4]) <= 0)
+        assert np.max(np.abs(got[:, :4] - exp[:, :4])) <= 3e-7 * size * 8, np.max(np.abs(got[:, :4] - exp[:, :4]))
+    return True
+
+
+def test_proposal_layer_matches_oracle(oracle):
+    """proposal_layer = fi_proposal_candidates + fi_nms_sorted + fi_proposal_gather.  Candidates vs the oracle
+    (selection exact); keep list = the oracle's NMS on the kernel's own dets (exact); gathered proposals exact."""
+    from feature_intertwiner_amd import _lib
     from feature_intertwiner_amd import layers as L
     cfg = _cfg(backbone="resnet50", image_size=256)
-    pri = torch.from_numpy(L.generate_pyramid_priors(cfg.RPN.ANCHOR_SCALES, cfg.RPN.ANCHOR_RATIOS,
-                                                     cfg.MODEL.BACKBONE_SHAPES, cfg.MODEL.BACKBONE_STRIDES, 1)).float().to(DEV)
+    pri = _priors(cfg)
     g = torch.Generator(device=DEV).manual_seed(2)
     A = pri.size(0)
     probs = torch.rand(2, A, 2, device=DEV, generator=g)
     bbox = torch.randn(2, A, 4, device=DEV, generator=g) * 0.5
-    props, num = L.proposal_layer([probs, bbox], 1000, 0.7, pri, cfg)
+    taps = {}
+    _lib.TAP = lambda name, **kw: taps.setdefault(name, kw)
+    try:
+        props, num = L.proposal_layer([probs, bbox], 1000, 0.7, pri, cfg)
+    finally:
+        _lib.TAP = None
     assert props.shape == (2, 1000, 4)
+    tap = taps["proposal_candidates"]
+    assert tap["dets"].shape == (2, min(6000, A), 5)
+    _check_candidates(oracle, tap, cfg, 256.0)
     for b in range(2):
-        sc, order = torch.sort(probs[b, :, 1], descending=True, stable=True)
-        k = min(6000, A)
-        boxes = L.clip_boxes(L.apply_box_deltas(pri[order[:k]], bbox[b, order[:k]] * torch.tensor(
-            cfg.DATA.BBOX_STD_DEV, device=DEV)), (0.0, 0.0, 256.0, 256.0))
-        dets = torch.cat([boxes, sc[:k, None]], 1).cpu().numpy()
+        dets = tap["dets"][b].cpu().numpy()
         keep = oracle.pth_nms(dets, 0.7)[:1000]
         n = int(num[b])
         assert n == len(keep)
-        assert np.allclose(props[b, :n].cpu().numpy(), dets[keep, :4] / 256.0, atol=1e-6)
+        assert np.array_equal(props[b, :n].cpu().numpy(), dets[keep, :4] / np.float32(256.0))
         assert torch.all(props[b, n:] == 0)
+
+
+@pytest.mark.parametrize("case", ["ties", "extra", "few", "all_equal", "negative_and_nan_free"])
+def test_proposal_candidates_edge_cases(oracle, case):
+    """Tie rule (lower index first; more ties at the threshold than places), external candidates merged by score
+    (before anchors at equal score), fewer candidates than PRE_NMS_LIMIT, constant scores, scores of both signs."""
+    from feature_intertwiner_amd import _lib
+    from feature_intertwiner_amd import layers as L
+    cfg = _cfg(backbone="resnet50", image_size=256)
+    pri = _priors(cfg)
+    A = pri.size(0)
+    g = torch.Generator(device=DEV).manual_seed(5)
+    probs = torch.rand(3, A, 2, device=DEV, generator=g)
+    bbox = torch.randn(3, A, 4, device=DEV, generator=g) * 0.3
+    extra = None
+    if case == "ties":
+        probs[:, :, 1] = torch.round(probs[:, :, 1] * 50) / 50          # ~51 distinct values: thousands of ties
+    elif case == "extra":
+        e_box = torch.rand(3, 700, 4, device=DEV, generator=g) * 200
+        e_sc = torch.rand(3, 700, 1, device=DEV, generator=g)
+        e_sc[:, :10, 0] = probs[:, :10, 1]                                # exact ties between extra and anchors
+        e_sc[:, 10:40] = 1.5
+        extra = torch.cat([e_box, e_sc], 2)
+    elif case == "few":
+        pri, probs, bbox = pri[:3000], probs[:, :3000], bbox[:, :3000]
+    elif case == "all_equal":
+        probs[:, :, 1] = 0.25
+    else:
+        probs[:, :, 1] = torch.randn(3, probs.size(1), device=DEV, generator=g)
+    taps = {}
+    _lib.TAP = lambda name, **kw: taps.setdefault(name, kw)
+    try:
+        props, num = L.proposal_layer([probs, bbox], 1000, 0.7, pri, cfg, extra)
+    finally:
+        _lib.TAP = None
+    tap = taps["proposal_candidates"]
+    assert tap["dets"].shape[1] == min(6000, pri.size(0) + (0 if extra is None else 700))
+    _check_candidates(oracle, tap, cfg, 256.0)
+    assert int(num.min()) >= 1
 
 
 def test_dev_stage_matches_per_level_restatement(oracle):
@@ -131,7 +199,7 @@ def test_train_step_runs_and_learns():
     model = MaskRCNN(cfg).to(DEV)
     opt = set_optimizer(model, cfg.TRAIN)
     batch = synthetic_batch(2, 256, device=DEV)
-    model.proposal_hook = SyntheticProposals(batch[2], 256)
+    model.external_proposals = SyntheticProposals(batch[2], 256)
     model.generator = torch.Generator(device=DEV).manual_seed(3)
     hist = []
     for _ in range(6):
@@ -227,7 +295,7 @@ def test_inference_path_runs():
     cfg = _cfg(backbone="resnet50", image_size=256, batch_size=2)
     model = MaskRCNN(cfg).to(DEV)
     batch = synthetic_batch(2, 256, device=DEV)
-    model.proposal_hook = SyntheticProposals(batch[2], 256)
+    model.external_proposals = SyntheticProposals(batch[2], 256)
     windows = torch.tensor([[0, 0, 256, 256], [0, 16, 256, 240]], dtype=torch.float32)
     det, masks = model([batch[0], windows], mode='inference')
     assert det.shape == (2, 100, 6) and masks.shape == (2, 100, 81, 28, 28)
@@ -255,7 +323,7 @@ def test_mask_head_on_positive_slots_is_exact():
         cfg = _cfg(backbone="resnet50", image_size=256, batch_size=2, train_rois_per_image=64, ot_L=5)
         cfg.MRCNN.MASK_HEAD_ON_POSITIVE_SLOTS = flag
         model = MaskRCNN(cfg).to(DEV)
-        model.proposal_hook = SyntheticProposals(batch[2], 256)
+        model.external_proposals = SyntheticProposals(batch[2], 256)
         model.generator = torch.Generator(device=DEV).manual_seed(3)
         loss, terms = compute_loss(model, list(batch), True, 1, None)
         loss.backward()
@@ -287,7 +355,7 @@ def test_baseline_configs_run(name, kw, size, bs):
     model = MaskRCNN(cfg).to(DEV)
     opt = set_optimizer(model, cfg.TRAIN)
     batch = synthetic_batch(bs, size, device=DEV)
-    model.proposal_hook = SyntheticProposals(batch[2], size)
+    model.external_proposals = SyntheticProposals(batch[2], size)
     model.generator = torch.Generator(device=DEV).manual_seed(3)
     first = last = None
     for _ in range(3):
@@ -337,7 +405,7 @@ def test_dev_stage_roi_pool_method_matches_oracle(oracle):
     model = MaskRCNN(cfg).to(DEV)
     opt = set_optimizer(model, cfg.TRAIN)
     batch = synthetic_batch(2, 256, device=DEV)
-    model.proposal_hook = SyntheticProposals(batch[2], 256)
+    model.external_proposals = SyntheticProposals(batch[2], 256)
     t = train_step(model, opt, list(batch))
     assert all(torch.isfinite(v) for v in t.values()), t
 
@@ -355,7 +423,7 @@ def test_meta_loss_choices_run(choice):
     assert not hasattr(model, "ot_loss")
     opt = set_optimizer(model, cfg.TRAIN)
     batch = synthetic_batch(2, 256, device=DEV)
-    model.proposal_hook = SyntheticProposals(batch[2], 256)
+    model.external_proposals = SyntheticProposals(batch[2], 256)
     model.generator = torch.Generator(device=DEV).manual_seed(3)
     for _ in range(2):
         t = train_step(model, opt, list(batch))
@@ -382,7 +450,7 @@ def test_dev_config_branches_run(tweak):
     model = MaskRCNN(cfg).to(DEV)
     opt = set_optimizer(model, cfg.TRAIN)
     batch = synthetic_batch(2, 256, device=DEV)
-    model.proposal_hook = SyntheticProposals(batch[2], 256)
+    model.external_proposals = SyntheticProposals(batch[2], 256)
     model.generator = torch.Generator(device=DEV).manual_seed(3)
     t = train_step(model, opt, list(batch), do_meta=not cfg.DEV.BASELINE)
     assert all(torch.isfinite(v) for v in t.values()), (tweak, t)
@@ -400,7 +468,7 @@ def test_fpn_ot_loss_branch_runs():
     model = MaskRCNN(cfg).to(DEV)
     opt = set_optimizer(model, cfg.TRAIN)
     batch = synthetic_batch(2, 128, device=DEV)
-    model.proposal_hook = SyntheticProposals(batch[2], 128)
+    model.external_proposals = SyntheticProposals(batch[2], 128)
     model.generator = torch.Generator(device=DEV).manual_seed(3)
     t = train_step(model, opt, list(batch))
     assert all(torch.isfinite(v) for v in t.values()), t
@@ -421,7 +489,7 @@ def test_train_step_edge_batches():
     gt_cls[1] = 0
     gt_boxes[1] = 0
     gt_masks[1] = 0
-    model.proposal_hook = hook
+    model.external_proposals = hook
     model.generator = torch.Generator(device=DEV).manual_seed(3)
     for _ in range(4):
         t = train_step(model, opt, [images, gt_cls, gt_boxes, gt_masks])

@@ -22,7 +22,7 @@ def test_configs2_full_size_two_steps_operators_vs_oracle(oracle):
     model = MaskRCNN(cfg).to(DEV)
     opt = set_optimizer(model, cfg.TRAIN)
     batch = synthetic_batch(4, 1024, device=DEV, seed=2000)
-    model.proposal_hook = SyntheticProposals(batch[2], 1024, seed=7)
+    model.external_proposals = SyntheticProposals(batch[2], 1024, seed=7)
     model.generator = torch.Generator(device=DEV).manual_seed(11)
     first = float(train_step(model, opt, list(batch))["total"])       # step 1 (fills the history buffer)
 
@@ -54,7 +54,19 @@ def test_configs2_full_size_two_steps_operators_vs_oracle(oracle):
     assert flops["conv3x3_patch"] + flops["conv3x3_patch_flat"] > 0.4 * sum(flops.values())
 
     names = [n for n, _ in taps]
-    assert names.count("nms_sorted") == 1 and names.count("sinkhorn") == 1
+    assert names.count("nms_sorted") == 1 and names.count("sinkhorn") == 1 and names.count("proposal_candidates") == 1
+    # the fused pre-NMS stage inside the step: 4 x 6000 candidates selected from 261 888 anchors + the external
+    # proposals, same rows in the same order as the oracle restatement, and they ARE what NMS received
+    cand = [t for n, t in taps if n == "proposal_candidates"][0]
+    nms_in = [t for n, t in taps if n == "nms_sorted"][0]
+    assert torch.equal(cand["dets"], nms_in["boxes"])
+    for b in range(4):
+        exp, _ = oracle.proposal_candidates(cand["probs"][b].cpu().numpy(), cand["deltas"][b].cpu().numpy(),
+                                            cand["anchors"].cpu().numpy(), 6000, cfg.DATA.BBOX_STD_DEV, (1024.0, 1024.0),
+                                            cand["extra"][b].cpu().numpy())
+        got = cand["dets"][b].cpu().numpy()
+        assert np.array_equal(got[:, 4], exp[:, 4])
+        assert np.max(np.abs(got[:, :4] - exp[:, :4])) <= 1e-3
     crops = [t for n, t in taps if n == "pyramid_crop"]
     # Dev stage: 7x7 and 14x14 over all 2048 RoIs (channels-last make-up maps) + the 'big' 14x14 crop
     kinds = sorted((c["crop"], c["boxes"].shape[0] == 2048) for c in crops)
@@ -108,7 +120,7 @@ def test_configs4_slice_full_size_bf16(oracle):
     model = MaskRCNN(cfg).to(DEV)
     opt = set_optimizer(model, cfg.TRAIN)
     batch = synthetic_batch(2, 1344, device=DEV, seed=2000)
-    model.proposal_hook = SyntheticProposals(batch[2], 1344, seed=7)
+    model.external_proposals = SyntheticProposals(batch[2], 1344, seed=7)
     model.generator = torch.Generator(device=DEV).manual_seed(11)
     first = float(train_step(model, opt, list(batch))["total"])
     taps = []

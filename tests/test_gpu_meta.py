@@ -104,7 +104,7 @@ def test_model_meta_loss_over_consecutive_steps_vs_oracle(oracle, choice, buffer
     model = MaskRCNN(cfg).to(DEV)
     opt = set_optimizer(model, cfg.TRAIN)
     batch = synthetic_batch(2, 256, device=DEV)
-    model.proposal_hook = SyntheticProposals(batch[2], 256)
+    model.external_proposals = SyntheticProposals(batch[2], 256)
     model.generator = torch.Generator(device=DEV).manual_seed(3)
     captured = {}
     inner = model.meta_loss

@@ -120,7 +120,7 @@ def test_train_step_uses_the_fused_step():
         model = MaskRCNN(cfg).to(DEV)
         opt = set_optimizer(model, cfg.TRAIN)
         batch = synthetic_batch(2, 256, device=DEV, seed=5)
-        model.proposal_hook = SyntheticProposals(batch[2], 256, seed=7)
+        model.external_proposals = SyntheticProposals(batch[2], 256, seed=7)
         model.generator = torch.Generator(device=DEV).manual_seed(11)
         old = optim.supported
         if not fused:

@@ -43,7 +43,7 @@ def _run(use_dp, out):
         reduce_fn = all_reduce_statistics
     opt = set_optimizer(model, cfg.TRAIN)
     batch = synthetic_batch(2, 256, device=DEV)
-    model.proposal_hook = SyntheticProposals(batch[2], 256, seed=7)
+    model.external_proposals = SyntheticProposals(batch[2], 256, seed=7)
     model.generator = torch.Generator(device=DEV).manual_seed(5)
     terms = train_step(model, opt, list(batch), grad_sync=sync, world_size=1, reduce_fn=reduce_fn)
     params = [p.detach().cpu().clone() for p in model.parameters()]          # after ONE update
