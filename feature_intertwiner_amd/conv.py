@@ -157,6 +157,7 @@ class _Conv2dFn(torch.autograd.Function):
         bc = b.contiguous().float() if b is not None else None
         ctx.save_for_backward(x, w)
         ctx.conf = (tuple(stride), tuple(padding), b is not None)
+        ctx.bias_ptr = b.data_ptr() if b is not None else 0
         ctx.precision = _PRECISION
         _log_shape(x, w, stride, padding)
         res = residual.contiguous().float() if residual is not None else None      # y = conv(x) + b + residual
@@ -169,7 +170,7 @@ class _Conv2dFn(torch.autograd.Function):
         dy = dy.contiguous().float()
         if has_bias and ctx.needs_input_grad[2]:
             dx, dw, db = _conv_backward(ctx.needs_input_grad, x, w, dy, stride, padding, want_db=True,
-                                        precision=ctx.precision)
+                                        precision=ctx.precision, bias_ptr=ctx.bias_ptr)
         else:
             dx, dw = _conv_backward(ctx.needs_input_grad, x, w, dy, stride, padding, precision=ctx.precision)
             db = None
@@ -253,7 +254,7 @@ def _strided_dgrad(dz, w, in_hw, stride, padding, precision=None, add=None):
 
 
 def _conv_backward(ctx_needs, x, w, dz, stride, padding, want_db=False, add_to_dx=None, precision=None,
-                   give_compact=False):
+                   give_compact=False, bias_ptr=0):
     """dX and dW of z = conv(x, w) given dz (shared by the plain and the fused functions).
     want_db: also return sum(dz) over images and pixels (the bias gradient), accumulated by the
     weight-gradient kernel from the dY tiles it stages anyway.
@@ -315,12 +316,23 @@ def _conv_backward(ctx_needs, x, w, dz, stride, padding, want_db=False, add_to_d
         shape = (Cout, R, S, Cin) if (hwc and R * S > 1) else (Cout, Cin, R, S)
         # pre-zeroed slice of the step's gradient arena (one fill per step instead of one per layer); a repeated
         # use of the layer accumulates into the same slice.  (With want_db the kernel clears dW and db itself.)
-        dw, first = (None, False) if (want_db and not bf16) else _arena_take(("dw", w.data_ptr()), Cout * Cin * R * S)
+        # With want_db the fp32 kernel accumulates the bias gradient too: both outputs must be pre-zeroed slots, or
+        # the kernel clears both itself.
+        db_slot = None
+        if want_db and not bf16:
+            db_slot, _ = _arena_take(("db", bias_ptr), Cout) if bias_ptr else (None, False)
+        if want_db and not bf16 and db_slot is None:
+            dw, first = None, False
+        else:
+            dw, first = _arena_take(("dw", w.data_ptr()), Cout * Cin * R * S)
+            if dw is None:
+                db_slot = None
         flags = _lib.OUTPUTS_ZEROED if dw is not None else 0
         dw = dw.view(shape) if dw is not None else torch.empty(shape, device=x.device, dtype=torch.float32)
         hand_over = first or not flags
         if want_db:
-            db = dz.sum((0, 2, 3)) if bf16 else torch.empty(Cout, device=x.device, dtype=torch.float32)
+            db = dz.sum((0, 2, 3)) if bf16 else (db_slot if db_slot is not None else
+                                                 torch.empty(Cout, device=x.device, dtype=torch.float32))
         with torch.cuda.device(x.device):
             if bf16:
                 _log_flops("bf16_wgrad", Cout, R, S, 2 * N * Cout * dz.shape[2] * dz.shape[3] * Cin * R * S)
@@ -337,6 +349,8 @@ def _conv_backward(ctx_needs, x, w, dz, stride, padding, want_db=False, add_to_d
             dw = dw.permute(0, 3, 1, 2)
         if not hand_over:
             dw = None                 # accumulated into the slot autograd already holds
+            if want_db and not bf16:
+                db = None
     elif want_db:
         db = dz.sum((0, 2, 3))
     return (dx, dw, db) if want_db else (dx, dw)
@@ -378,6 +392,9 @@ def _arena_take(key, numel):
     slot = _ARENA["slots"].get(key)
     if slot is None or _ARENA["buf"] is None or slot[1] != numel:
         return None, False
+    owner = slot[2]()
+    if owner is None or owner.data_ptr() != key[1]:
+        return None, False        # the model this arena belongs to is gone and its address was reused
     first = key not in _ARENA["used"]
     _ARENA["used"].add(key)
     return _ARENA["buf"][slot[0]:slot[0] + numel], first
@@ -444,10 +461,12 @@ def _prepare_step(model, grad_on):
         slots = {}
         for m in convs:
             if m.weight.requires_grad and m.weight in layout.slot:
-                slots[("dw", m.weight.data_ptr())] = layout.slot[m.weight]
+                slots[("dw", m.weight.data_ptr())] = layout.slot[m.weight] + (weakref.ref(m.weight),)
+            if m.bias is not None and m.bias.requires_grad and m.bias in layout.slot:
+                slots[("db", m.bias.data_ptr())] = layout.slot[m.bias] + (weakref.ref(m.bias),)
         for bn in [m for m in model.modules() if isinstance(m, nn.BatchNorm2d)]:
             if bn in layout.bn_slot:
-                slots[("bn", bn.weight.data_ptr())] = (layout.bn_slot[bn], 3 * bn.num_features)
+                slots[("bn", bn.weight.data_ptr())] = (layout.bn_slot[bn], 3 * bn.num_features, weakref.ref(bn.weight))
         plan = {"ptrs": tuple(p.data_ptr() for p in model.parameters()), "tr": tr, "wts": wts, "table": table,
                 "tiles": base, "slots": slots, "layout": layout, "versions": None}
         _PLAN[model] = plan
@@ -579,6 +598,7 @@ class _ConvBiasActFn(torch.autograd.Function):
         ctx.save_for_backward(x, w, y)
         ctx.precision = _PRECISION
         ctx.conf = (tuple(stride), tuple(padding), b is not None)
+        ctx.bias_ptr = b.data_ptr() if b is not None else 0
         return y
 
     @staticmethod
@@ -590,13 +610,17 @@ class _ConvBiasActFn(torch.autograd.Function):
         N, C, OH, OW = y.shape
         dz = torch.empty_like(y)
         ones = _ones(C, y.device)
-        dshift = torch.empty(C, device=y.device, dtype=torch.float32)
+        # the bias gradient accumulates in the bias's arena slot (a layer applied on 5 pyramid levels: one slot)
+        dshift, first = _arena_take(("db", ctx.bias_ptr), C) if ctx.bias_ptr else (None, False)
+        flags = _lib.OUTPUTS_ZEROED if dshift is not None else 0
+        if dshift is None:
+            dshift, first = torch.empty(C, device=y.device, dtype=torch.float32), True
         with torch.cuda.device(y.device):
             _lib.check(L.fi_bn_act_backward(_lib.ptr(dy), _lib.ptr(y), _lib.ptr(ones), None, None, None, N, C, OH * OW, 1,
-                                            _lib.ptr(dz), None, _lib.ptr(dshift), None, None, 0, 0,
+                                            _lib.ptr(dz), None, _lib.ptr(dshift), None, None, 0, flags,
                                             _lib.current_stream()), "fi_bn_act_backward")
         dx, dw = _conv_backward(ctx.needs_input_grad, x, w, dz, stride, padding, precision=ctx.precision)
-        return dx, dw, (dshift if (has_bias and ctx.needs_input_grad[2]) else None), None, None
+        return dx, dw, (dshift if (has_bias and ctx.needs_input_grad[2] and first) else None), None, None
 
 
 _ONES = {}
