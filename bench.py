@@ -371,7 +371,7 @@ def _main():
     ap.add_argument("--config", default="cfg3", choices=["cfg3", "cfg5"],
                     help="cfg3 = BASELINE configs[2], the headline (default); cfg5 = the single-GPU slice of BASELINE "
                          "configs[4]: 1333x800 padded to 1344^2, 2 images/GPU, 1000 RoIs/image + mask head, bf16 MFMA convs")
-    ap.add_argument("--conv-precision", default=None, choices=["fp32", "bf16"])
+    ap.add_argument("--conv-precision", default=None, choices=["fp32", "bf16", "fp16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 --pmc passes that fill roofline.traffic")
     ap.add_argument("--profile-steps", type=int, default=4,
@@ -653,7 +653,7 @@ def _main():
             "metric": "images/sec (train step, ResNet-101-FPN 1024^2, 512 RoIs)", "value": round(value, 4),
             "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32" if args.conv_precision == "fp32" else "bf16 (conv operands; fp32 accumulation, fp32 elsewhere)",
+            "vs_baseline": None, "dtype": "f32" if args.conv_precision == "fp32" else "%s (conv operands; fp32 accumulation, fp32 elsewhere)" % args.conv_precision,
             "data": "synthetic (seeded N(0,1)*64 images, 20 GT boxes/img, random-init weights, "
                     "GT-jittered proposals planted among RPN candidates before NMS)",
             "config": {"workload": ("BASELINE configs[2]" if args.config == "cfg3" else
@@ -666,7 +666,7 @@ def _main():
                        "variant": ("mask head on positive slots only (dead-work elimination, not the reference's "
                                    "schedule)" if args.mask_head_on_positive_slots else "reference schedule"),
                        "conv_stack": ("hand-written fp32 MFMA implicit-GEMM kernels (csrc/conv_igemm.hip)" if
-                                      args.conv_precision == "fp32" else "hand-written bf16-input / fp32-accumulate MFMA "
+                                      args.conv_precision == "fp32" else "hand-written 16-bit-operand (" + args.conv_precision + ") / fp32-accumulate MFMA "
                                       "kernels (csrc/conv_bf16.hip; layers with Cin % 32 != 0 on the fp32 kernels)") +
                                      "; full-window convs and nn.Linear on the library GEMM"},
             "losses": {k: round(float(v), 5) for k, v in terms.items()},

@@ -64,6 +64,10 @@ SIGNATURES = {
     "fi_conv2d_weight_grad": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 12 + [c_void_p, c_int, c_void_p]),
     "fi_conv2d_forward_bf16": (c_int, [c_void_p] * 6 + [c_int] * 16 + [c_void_p]),
     "fi_conv2d_weight_grad_bf16": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 12 + [c_void_p]),
+    "fi_conv2d_forward_f16": (c_int, [c_void_p] * 6 + [c_int] * 16 + [c_void_p]),
+    "fi_conv2d_weight_grad_f16": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 12 + [c_void_p]),
+    "fi_conv3x3_forward_f16w": (c_int, [c_void_p] * 6 + [c_int] * 7 + [c_void_p]),
+    "fi_conv1x1_forward_f16w": (c_int, [c_void_p] * 6 + [c_int] * 5 + [c_void_p]),
     "fi_weight_transpose_batch": (c_int, [c_void_p, c_int, ctypes.c_long, c_void_p]),
     "fi_conv3x3_forward_bf16w": (c_int, [c_void_p] * 6 + [c_int] * 7 + [c_void_p]),
     "fi_conv1x1_forward_bf16w": (c_int, [c_void_p] * 6 + [c_int] * 5 + [c_void_p]),

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(_HERE, "libfi_hip.so")
 SOURCES = ["fi_core.hip", "crop_and_resize.hip", "roi_pool.hip", "nms.hip", "sinkhorn.hip",
-           "class_mean.hip", "conv_igemm.hip", "conv_bf16.hip", "sgd.hip", "glue.hip", "proposal.hip"]
+           "class_mean.hip", "conv_igemm.hip", "conv_bf16.hip", "conv_f16.hip", "sgd.hip", "glue.hip", "proposal.hip"]
 HEADERS = ["fi_common.h", os.path.join("..", "..", "include", "fi_capi.h")]
 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -40,7 +40,8 @@ def build_hip(force=False, verbose=False):
     objs = []
     for s in srcs:
         o = s[:-4] + ".o"
-        if force or _stale(o, [s] + hdrs):
+        deps = [s] + hdrs + ([os.path.join(CSRC, "conv_bf16.hip")] if s.endswith("conv_f16.hip") else [])
+        if force or _stale(o, deps):
             cmd = [HIPCC] + FLAGS + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd))

@@ -29,21 +29,29 @@ FLOP_LOG = None
 SHAPE_LOG = None
 
 
-# Arithmetic of the MFMA convolutions: "fp32" (exact, v_mfma_f32_32x32x2_f32 -- the headline) or "bf16"
-# (operands rounded to bf16, fp32 accumulation, v_mfma_f32_32x32x16_bf16 -- BASELINE configs[4]'s reduced-
+# Arithmetic of the MFMA convolutions: "fp32" (exact, v_mfma_f32_32x32x2_f32 -- the headline), "bf16" or "fp16"
+# (operands rounded to the 16-bit type, fp32 accumulation, v_mfma_f32_32x32x16_{bf16,f16} -- BASELINE configs[4]'s reduced-
 # precision conv path).  Read when a forward pass runs; the backward of that pass uses the same setting.
 _PRECISION = "fp32"
 
 
 def set_conv_precision(mode):
     global _PRECISION
-    if mode not in ("fp32", "bf16"):
-        raise ValueError("conv precision must be 'fp32' or 'bf16'")
+    if mode not in ("fp32", "bf16", "fp16"):
+        raise ValueError("conv precision must be 'fp32', 'bf16' or 'fp16'")
     _PRECISION = mode
 
 
 def conv_precision():
     return _PRECISION
+
+
+_LOWP = {"bf16": ("bf16", torch.bfloat16), "fp16": ("f16", torch.float16)}     # precision -> (entry-point suffix, dtype)
+
+
+def _lowp_fn(L, stem, precision, tail=""):
+    """fi_<stem>_{bf16,f16}<tail> of the loaded library."""
+    return getattr(L, "fi_%s_%s%s" % (stem, _LOWP[precision][0], tail))
 
 
 def _log_shape(x, w, stride, padding):
@@ -97,7 +105,8 @@ def _conv_fwd(x, w, b, stride, padding, relu=False, scale=None, residual=None, o
     OW = (W + 2 * padding[1] - S) // stride[1] + 1
     if out_hw is not None:
         OH, OW = out_hw
-    if not ((_PRECISION == "bf16" if precision is None else precision == "bf16") and layout >= 1 and Cin % 32 == 0):
+    prec = _PRECISION if precision is None else precision
+    if not (prec in _LOWP and layout >= 1 and Cin % 32 == 0):
         _log_flops("fwd", Cout, R, S, 2 * N * Cout * OH * OW * Cin * R * S, N * OH * OW,
                    patch=(_lib.patch_mode(N, Cin, H, W, Cout, R, S, stride, padding, layout >= 1,
                                           (OH, OW) == (H, W), out_channels_last) or
@@ -105,8 +114,8 @@ def _conv_fwd(x, w, b, stride, padding, relu=False, scale=None, residual=None, o
                    if FLOP_LOG is not None else 0)
     y = torch.empty((N, Cout, OH, OW), device=x.device, dtype=torch.float32,
                     memory_format=torch.channels_last if out_channels_last else torch.contiguous_format)
-    bf16 = (_PRECISION == "bf16" if precision is None else precision == "bf16") and layout >= 1 and Cin % 32 == 0
-    fn = L.fi_conv2d_forward_bf16 if bf16 else L.fi_conv2d_forward
+    bf16 = prec in _LOWP and layout >= 1 and Cin % 32 == 0          # "bf16" here and below: either 16-bit operand type
+    fn = _lowp_fn(L, "conv2d_forward", prec) if bf16 else L.fi_conv2d_forward
     if bf16:
         _log_flops("bf16_fwd", Cout, R, S, 2 * N * Cout * OH * OW * Cin * R * S)
         # 3x3 / stride 1 / pad 1 on maps whose width is a multiple of 16 (or 14-wide RoI maps): patch kernel with the
@@ -119,9 +128,9 @@ def _conv_fwd(x, w, b, stride, padding, relu=False, scale=None, residual=None, o
         if (R, S) == (3, 3) and tuple(stride) == (1, 1) and tuple(padding) == (1, 1) and (OH, OW) == (H, W) and \
                 (tiled or flat) and Cout > 64 and not out_channels_last and out_hw is None and \
                 (residual is None or residual.data_ptr() % 16 == 0):
-            wb = _cached_bf16(w)
+            wb = _cached_bf16(w, _LOWP[prec][1])
             with torch.cuda.device(x.device):
-                _lib.check(L.fi_conv3x3_forward_bf16w(_lib.ptr(x), _lib.ptr(wb), _lib.ptr(b), _lib.ptr(scale),
+                _lib.check(_lowp_fn(L, "conv3x3_forward", prec, "w")(_lib.ptr(x), _lib.ptr(wb), _lib.ptr(b), _lib.ptr(scale),
                                                       _lib.ptr(residual), _lib.ptr(y), N, Cin, H, W, Cout,
                                                       1 if relu else 0, 1 if layout == 2 else 0, _lib.current_stream()),
                            "fi_conv3x3_forward_bf16w")
@@ -131,9 +140,9 @@ def _conv_fwd(x, w, b, stride, padding, relu=False, scale=None, residual=None, o
                 Cin % 64 == 0 and Cout > 64 and not out_channels_last and out_hw is None and \
                 ((N * H * W + 127) // 128) * ((Cout + 127) // 128) >= 192 and \
                 (residual is None or residual.data_ptr() % 16 == 0):
-            wb = _cached_bf16(w)
+            wb = _cached_bf16(w, _LOWP[prec][1])
             with torch.cuda.device(x.device):
-                _lib.check(L.fi_conv1x1_forward_bf16w(_lib.ptr(x), _lib.ptr(wb), _lib.ptr(b), _lib.ptr(scale),
+                _lib.check(_lowp_fn(L, "conv1x1_forward", prec, "w")(_lib.ptr(x), _lib.ptr(wb), _lib.ptr(b), _lib.ptr(scale),
                                                       _lib.ptr(residual), _lib.ptr(y), N, Cin, H * W, Cout,
                                                       1 if relu else 0, _lib.current_stream()),
                            "fi_conv1x1_forward_bf16w")
@@ -310,7 +319,7 @@ def _conv_backward(ctx_needs, x, w, dz, stride, padding, want_db=False, add_to_d
                 x.data_ptr() % 16 == 0 and dz.data_ptr() % 16 == 0)
         hwc = 1 if (Cin % 128 == 0 or (Cin == 64 and same)) else 0
         # bf16 weight gradient: always tap-major, so the parameter must be stored that way (or be 1x1)
-        bf16 = precision == "bf16" and (R * S == 1 or (Cin % 16 == 0 and w.is_contiguous(memory_format=torch.channels_last)))
+        bf16 = precision in _LOWP and (R * S == 1 or (Cin % 16 == 0 and w.is_contiguous(memory_format=torch.channels_last)))
         if bf16:
             hwc = 1
         shape = (Cout, R, S, Cin) if (hwc and R * S > 1) else (Cout, Cin, R, S)
@@ -336,7 +345,7 @@ def _conv_backward(ctx_needs, x, w, dz, stride, padding, want_db=False, add_to_d
         with torch.cuda.device(x.device):
             if bf16:
                 _log_flops("bf16_wgrad", Cout, R, S, 2 * N * Cout * dz.shape[2] * dz.shape[3] * Cin * R * S)
-                _lib.check(L.fi_conv2d_weight_grad_bf16(_lib.ptr(x), _lib.ptr(dz), _lib.ptr(dw), N, Cin, H, W, Cout,
+                _lib.check(_lowp_fn(L, "conv2d_weight_grad", precision)(_lib.ptr(x), _lib.ptr(dz), _lib.ptr(dw), N, Cin, H, W, Cout,
                                                         R, S, stride[0], stride[1], padding[0], padding[1], flags,
                                                         _lib.current_stream()), "fi_conv2d_weight_grad_bf16")
             else:
@@ -365,13 +374,13 @@ _PLAN = weakref.WeakKeyDictionary()      # model -> cached layer lists / descrip
 _WB = {}           # tap-major fp32 weight data_ptr -> (bf16 copy, version, shape): refreshed once per step
 
 
-def _cached_bf16(w):
-    """bf16 copy of a tap-major fp32 weight, made once per (tensor, version).  The entry keeps `w` alive, so its
+def _cached_bf16(w, dtype=torch.bfloat16):
+    """16-bit copy of a tap-major fp32 weight, made once per (tensor, version).  The entry keeps `w` alive, so its
     address cannot be handed to another tensor while the entry exists."""
     e = _WB.get(w.data_ptr())
-    if e is not None and e[1] == w._version and e[2] == tuple(w.shape):
+    if e is not None and e[1] == w._version and e[2] == tuple(w.shape) and e[0].dtype == dtype:
         return e[0]
-    wb = w.to(torch.bfloat16)
+    wb = w.to(dtype)
     _WB[w.data_ptr()] = (wb, w._version, tuple(w.shape), w)
     return wb
 

@@ -26,14 +26,27 @@
 
 #include "fi_common.h"
 
+#ifdef FI_E16_HALF
+#define E16 _Float16
+#define MFMA16 __builtin_amdgcn_mfma_f32_32x32x16_f16
+#define FI16(stem, tail) stem##_f16##tail
+#else
+#define E16 __bf16
+#define MFMA16 __builtin_amdgcn_mfma_f32_32x32x16_bf16
+#define FI16(stem, tail) stem##_bf16##tail
+#endif
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef f32x4 f32x4_a4 __attribute__((aligned(4)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+// The 16-bit operand type of this translation unit.  conv_f16.hip includes this file with FI_E16_HALF defined and
+// gets the same kernels on IEEE half (v_mfma_f32_32x32x16_f16) under the *_f16 entry-point names -- BASELINE
+// configs[4] names an fp16 path; bf16 has fp32's exponent range and needs no loss scaling, so it is the default.
+typedef E16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef E16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef E16 bf16x2 __attribute__((ext_vector_type(2)));
 
 constexpr int kThreads = 256;
 constexpr int TN = 128;      // pixel tile (forward) / (tap, ci) tile (weight gradient)
@@ -55,8 +68,8 @@ struct Epi {
 __device__ __forceinline__ bf16x2 pack2(float a, float b)
 {
     bf16x2 r;
-    r.x = (__bf16)a;
-    r.y = (__bf16)b;
+    r.x = (E16)a;
+    r.y = (E16)b;
     return r;
 }
 
@@ -128,8 +141,8 @@ __global__ __launch_bounds__(kThreads, 2) void conv_bf16_fwd_kernel(const float 
     // lane then owns all 4 pixels of its quad (see the row permutation of the B tile), so the epilogue
     // stores 16 bytes per lane; BM = 64: 2 x 2 (two adjacent pixels per lane).
     constexpr int WM = BM / 32, WN = 4 / WM, NT = (TN / WN) / 32;
-    __shared__ __align__(16) __bf16 As[2][BM][LP];
-    __shared__ __align__(16) __bf16 Bs[2][TN][LP];
+    __shared__ __align__(16) E16 As[2][BM][LP];
+    __shared__ __align__(16) E16 Bs[2][TN][LP];
 
     // XCD-aware tile order: block b runs on XCD b % 8; the Cout tiles of one pixel tile follow each other on
     // the same XCD, so the activation tile is fetched into ONE L2 and re-read there
@@ -274,10 +287,10 @@ __global__ __launch_bounds__(kThreads, 2) void conv_bf16_fwd_kernel(const float 
             bf16x8 lo, hi;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                lo[e] = (__bf16)R.a[0][e];
-                lo[4 + e] = (__bf16)R.a[1][e];
-                hi[e] = (__bf16)R.a[2][e];
-                hi[4 + e] = (__bf16)R.a[3][e];
+                lo[e] = (E16)R.a[0][e];
+                lo[4 + e] = (E16)R.a[1][e];
+                hi[e] = (E16)R.a[2][e];
+                hi[4 + e] = (E16)R.a[3][e];
             }
             *reinterpret_cast<bf16x8 *>(&As[buf][a_row][a_half * 16]) = lo;
             *reinterpret_cast<bf16x8 *>(&As[buf][a_row][a_half * 16 + 8]) = hi;
@@ -320,7 +333,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_bf16_fwd_kernel(const float 
                 bfr[j] = *reinterpret_cast<const bf16x8 *>(&Bs[cur][wn * (TN / WN) + j * 32 + l31][ks * 16 + lh * 8]);
 #pragma unroll
             for (int j = 0; j < NT; ++j)
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr[j], acc[j], 0, 0, 0);
+                acc[j] = MFMA16(af, bfr[j], acc[j], 0, 0, 0);
         }
     };
 
@@ -475,8 +488,8 @@ struct PatchGeomB {
 __device__ __forceinline__ bf16x8 pack8(const f32x4 &lo, const f32x4 &hi)
 {
     bf16x8 r;
-    r[0] = (__bf16)lo.x; r[1] = (__bf16)lo.y; r[2] = (__bf16)lo.z; r[3] = (__bf16)lo.w;
-    r[4] = (__bf16)hi.x; r[5] = (__bf16)hi.y; r[6] = (__bf16)hi.z; r[7] = (__bf16)hi.w;
+    r[0] = (E16)lo.x; r[1] = (E16)lo.y; r[2] = (E16)lo.z; r[3] = (E16)lo.w;
+    r[4] = (E16)hi.x; r[5] = (E16)hi.y; r[6] = (E16)hi.z; r[7] = (E16)hi.w;
     return r;
 }
 
@@ -492,7 +505,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_patch_bf16_kernel(const f
     constexpr int NSLOT = FLAT ? PB_NSLOT_FLAT : PB_NSLOT;
     constexpr int SGRP = FLAT ? 4 : 6;            // staged 4-column groups per patch row (flat: columns 0..15 only)
     const float *__restrict__ w = static_cast<const float *>(wv);
-    const __bf16 *__restrict__ wb = static_cast<const __bf16 *>(wv);
+    const E16 *__restrict__ wb = static_cast<const E16 *>(wv);
     __shared__ __align__(16) bf16x8 Ps[2][PB_CB / 8][NSLOT];
 
     const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
@@ -514,7 +527,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_patch_bf16_kernel(const f
     // ---- A operand ------------------------------------------------------------------------------------
     const int am = min(m0 + wave * 32 + l31, g.Cout - 1);
     const float *__restrict__ a_base = w + (size_t)am * 9 * g.Cin + khalf * 8;
-    const __bf16 *__restrict__ ab_base = wb + (size_t)am * 9 * g.Cin + khalf * 8;
+    const E16 *__restrict__ ab_base = wb + (size_t)am * 9 * g.Cin + khalf * 8;
     auto load_a_raw = [&](f32x4 (&raw)[4], int tap, int cb) {          // both k-steps of a tap
         const float *__restrict__ p = a_base + (size_t)(g.flip ? 8 - tap : tap) * g.Cin + cb * PB_CB;
         raw[0] = *reinterpret_cast<const f32x4 *>(p);
@@ -523,7 +536,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_patch_bf16_kernel(const f
         raw[3] = *reinterpret_cast<const f32x4 *>(p + 20);
     };
     auto load_a_b16 = [&](bf16x8 (&pk)[2], int tap, int cb) {
-        const __bf16 *__restrict__ p = ab_base + (size_t)(g.flip ? 8 - tap : tap) * g.Cin + cb * PB_CB;
+        const E16 *__restrict__ p = ab_base + (size_t)(g.flip ? 8 - tap : tap) * g.Cin + cb * PB_CB;
         pk[0] = *reinterpret_cast<const bf16x8 *>(p);
         pk[1] = *reinterpret_cast<const bf16x8 *>(p + 16);
     };
@@ -599,8 +612,8 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_patch_bf16_kernel(const f
 #pragma unroll
         for (int i = 0; i < 4; ++i) {                          // pixel i of the group: column c = 4*grp + i -> slot i*6 + grp
             bf16x8 v;
-            v[0] = (__bf16)sr0[i]; v[1] = (__bf16)sr1[i]; v[2] = (__bf16)sr2[i]; v[3] = (__bf16)sr3[i];
-            v[4] = (__bf16)sr4[i]; v[5] = (__bf16)sr5[i]; v[6] = (__bf16)sr6[i]; v[7] = (__bf16)sr7[i];
+            v[0] = (E16)sr0[i]; v[1] = (E16)sr1[i]; v[2] = (E16)sr2[i]; v[3] = (E16)sr3[i];
+            v[4] = (E16)sr4[i]; v[5] = (E16)sr5[i]; v[6] = (E16)sr6[i]; v[7] = (E16)sr7[i];
             d[i * 6] = v;
         }
     };
@@ -615,7 +628,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_patch_bf16_kernel(const f
     if constexpr (FLAT) {
         bf16x8 z;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) z[e] = (__bf16)0.0f;
+        for (int e = 0; e < 8; ++e) z[e] = (E16)0.0f;
         bf16x8 *__restrict__ pz = &Ps[0][0][0];
         for (int i = tid; i < 2 * (PB_CB / 8) * NSLOT; i += kThreads) pz[i] = z;
         __syncthreads();
@@ -624,7 +637,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_patch_bf16_kernel(const f
             const int b = i / ((PB_CB / 8) * PB_RP), r_ = i - b * ((PB_CB / 8) * PB_RP);
             bf16x8 z;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) z[e] = (__bf16)0.0f;
+            for (int e = 0; e < 8; ++e) z[e] = (E16)0.0f;
             Ps[b][r_ / PB_RP][PB_ROWS * PB_RP + (r_ % PB_RP)] = z;
         }
     }
@@ -687,7 +700,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_patch_bf16_kernel(const f
                 const bf16x8 av = apk[t % 3][ks];
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bfr[step & 1][j], acc[j], 0, 0, 0);
+                    acc[j] = MFMA16(av, bfr[step & 1][j], acc[j], 0, 0, 0);
             }
             // fp32 weights: tap t+1 (of this stage or the first of the next) was loaded one tap ago, packed now
             if (!WB16 && (t + 1 < 9 || more)) {
@@ -785,7 +798,7 @@ struct Conv1x1GeomB {
 };
 
 __global__ __launch_bounds__(kThreads, 2) void conv1x1_bf16_kernel(const float *__restrict__ x,
-                                                                  const __bf16 *__restrict__ wb, Epi ep,
+                                                                  const E16 *__restrict__ wb, Epi ep,
                                                                   float *__restrict__ y, Conv1x1GeomB g)
 {
     __shared__ __align__(16) bf16x8 Ps[2][P1_KC / 8][128];
@@ -804,7 +817,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv1x1_bf16_kernel(const float *
 
     // ---- A operand: 8 consecutive channels of one output channel per k-step ----------------------------
     const int am = min(m0 + wave * 32 + l31, g.Cout - 1);            // rows past Cout re-read the last row
-    const __bf16 *__restrict__ a_base = wb + (size_t)am * g.Cin + khalf * 8;
+    const E16 *__restrict__ a_base = wb + (size_t)am * g.Cin + khalf * 8;
     auto load_a = [&](bf16x8 (&a)[4], int cb) {
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) a[ks] = *reinterpret_cast<const bf16x8 *>(a_base + cb * P1_KC + ks * 16);
@@ -835,8 +848,8 @@ __global__ __launch_bounds__(kThreads, 2) void conv1x1_bf16_kernel(const float *
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             bf16x8 v;
-            v[0] = (__bf16)sr0[i]; v[1] = (__bf16)sr1[i]; v[2] = (__bf16)sr2[i]; v[3] = (__bf16)sr3[i];
-            v[4] = (__bf16)sr4[i]; v[5] = (__bf16)sr5[i]; v[6] = (__bf16)sr6[i]; v[7] = (__bf16)sr7[i];
+            v[0] = (E16)sr0[i]; v[1] = (E16)sr1[i]; v[2] = (E16)sr2[i]; v[3] = (E16)sr3[i];
+            v[4] = (E16)sr4[i]; v[5] = (E16)sr5[i]; v[6] = (E16)sr6[i]; v[7] = (E16)sr7[i];
             d[i * 32] = v;
         }
     };
@@ -874,7 +887,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv1x1_bf16_kernel(const float *
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acur[ks], bv[ks & 1][j], acc[j], 0, 0, 0);
+                acc[j] = MFMA16(acur[ks], bv[ks & 1][j], acc[j], 0, 0, 0);
             if (ks + 1 < 4) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
         }
@@ -927,8 +940,8 @@ __global__ __launch_bounds__(kThreads) void conv_bf16_wgrad_generic_kernel(const
                                                                    int chunk_pixels)
 {
     constexpr int BM = 128;
-    __shared__ __align__(16) __bf16 As[2][BM][LP];      // dY  [cout][pixel]
-    __shared__ __align__(16) __bf16 Bs[2][TN][LP];      // X   [ci][pixel]   (for one tap)
+    __shared__ __align__(16) E16 As[2][BM][LP];      // dY  [cout][pixel]
+    __shared__ __align__(16) E16 Bs[2][TN][LP];      // X   [ci][pixel]   (for one tap)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -1014,14 +1027,14 @@ __global__ __launch_bounds__(kThreads) void conv_bf16_wgrad_generic_kernel(const
         bf16x8 a0, a1, b0, b1;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            a0[e] = (__bf16)ra[0][e];
-            a0[4 + e] = (__bf16)ra[1][e];
-            a1[e] = (__bf16)ra[2][e];
-            a1[4 + e] = (__bf16)ra[3][e];
-            b0[e] = (__bf16)rb[0][e];
-            b0[4 + e] = (__bf16)rb[1][e];
-            b1[e] = (__bf16)rb[2][e];
-            b1[4 + e] = (__bf16)rb[3][e];
+            a0[e] = (E16)ra[0][e];
+            a0[4 + e] = (E16)ra[1][e];
+            a1[e] = (E16)ra[2][e];
+            a1[4 + e] = (E16)ra[3][e];
+            b0[e] = (E16)rb[0][e];
+            b0[4 + e] = (E16)rb[1][e];
+            b1[e] = (E16)rb[2][e];
+            b1[4 + e] = (E16)rb[3][e];
         }
         *reinterpret_cast<bf16x8 *>(&As[buf][row][half * 16]) = a0;
         *reinterpret_cast<bf16x8 *>(&As[buf][row][half * 16 + 8]) = a1;
@@ -1050,7 +1063,7 @@ __global__ __launch_bounds__(kThreads) void conv_bf16_wgrad_generic_kernel(const
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = MFMA16(af[i], bfr[j], acc[i][j], 0, 0, 0);
         }
         if (!have_next) break;
         store_tile(cur ^ 1);
@@ -1091,8 +1104,8 @@ __global__ __launch_bounds__(kThreads, 2) void conv_bf16_wgrad_kernel(const floa
     constexpr int MT = BM / 64, NT = BNC / 64;
     constexpr int AV = BM / 32, BV = BNC / 32;          // row passes of the loaders
     constexpr int NL = SWT;                             // 16-byte loads per X row and quad (column stride 1 or 2)
-    __shared__ __align__(16) __bf16 As[2][BM][LP];       // dY  [cout][pixel]
-    __shared__ __align__(16) __bf16 Bs[2][BNC][LP];      // X   [ci][pixel]   (for one tap)
+    __shared__ __align__(16) E16 As[2][BM][LP];       // dY  [cout][pixel]
+    __shared__ __align__(16) E16 Bs[2][BNC][LP];      // X   [ci][pixel]   (for one tap)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -1192,7 +1205,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_bf16_wgrad_kernel(const floa
             if (R.da != 0) t = shifted(t, R.da);
             bf16x4 o;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) o[j] = (__bf16)t[j];
+            for (int j = 0; j < 4; ++j) o[j] = (E16)t[j];
             *reinterpret_cast<bf16x4 *>(&As[buf][r0 + 32 * v][4 * q]) = o;
         }
 #pragma unroll
@@ -1210,7 +1223,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_bf16_wgrad_kernel(const floa
             }
             bf16x4 o;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) o[j] = (__bf16)t[j];
+            for (int j = 0; j < 4; ++j) o[j] = (E16)t[j];
             *reinterpret_cast<bf16x4 *>(&Bs[buf][r0 + 32 * v][4 * q]) = o;
         }
     };
@@ -1236,7 +1249,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_bf16_wgrad_kernel(const floa
             for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int j = 0; j < NT; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = MFMA16(af[i], bfr[j], acc[i][j], 0, 0, 0);
         }
     };
 
@@ -1304,8 +1317,8 @@ __global__ __launch_bounds__(kThreads, 2) void conv_bf16_wgrad_flat_kernel(const
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     constexpr int MT = BM / 64, NT = BNC / 64;
     constexpr int AV = BM / 16, BV = BNC / 16;          // row passes of the loaders: thread = (group tid & 15, row tid >> 4)
-    __shared__ __align__(16) __bf16 As[2][BM][FLP];      // dY  [cout][pixel]
-    __shared__ __align__(16) __bf16 Bs[2][BNC][FLP];     // X   [ci][pixel]   (one tap)
+    __shared__ __align__(16) E16 As[2][BM][FLP];      // dY  [cout][pixel]
+    __shared__ __align__(16) E16 Bs[2][BNC][FLP];     // X   [ci][pixel]   (one tap)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -1414,10 +1427,10 @@ __global__ __launch_bounds__(kThreads, 2) void conv_bf16_wgrad_flat_kernel(const
     };
     auto cvt4 = [](const u32x4 &v) {
         bf16x4 o;
-        o[0] = (__bf16)__uint_as_float(v.x);
-        o[1] = (__bf16)__uint_as_float(v.y);
-        o[2] = (__bf16)__uint_as_float(v.z);
-        o[3] = (__bf16)__uint_as_float(v.w);
+        o[0] = (E16)__uint_as_float(v.x);
+        o[1] = (E16)__uint_as_float(v.y);
+        o[2] = (E16)__uint_as_float(v.z);
+        o[3] = (E16)__uint_as_float(v.w);
         return o;
     };
     auto store_tile = [&](int buf, Regs &R) {
@@ -1468,7 +1481,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_bf16_wgrad_flat_kernel(const
             for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int j = 0; j < NT; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = MFMA16(af[i], bfr[j], acc[i][j], 0, 0, 0);
         }
     };
 
@@ -1521,7 +1534,7 @@ int make_geom(Geom &g, int N, int Cin, int H, int W, int Cout, int R, int S, int
 
 extern "C" {
 
-int fi_conv2d_forward_bf16(const float *x, const float *weight, const float *bias, const float *scale,
+int FI16(fi_conv2d_forward, )(const float *x, const float *weight, const float *bias, const float *scale,
                            const float *residual, float *y, int N, int Cin, int H, int W, int Cout, int R,
                            int S, int stride_h, int stride_w, int pad_h, int pad_w, int relu,
                            int weight_layout, int out_h, int out_w, int output_layout, fi_stream_t stream)
@@ -1579,7 +1592,7 @@ int fi_conv2d_forward_bf16(const float *x, const float *weight, const float *bia
     return FI_OK;
 }
 
-int fi_conv3x3_forward_bf16w(const float *x, const uint16_t *weight_bf16, const float *bias, const float *scale,
+int FI16(fi_conv3x3_forward, w)(const float *x, const uint16_t *weight_bf16, const float *bias, const float *scale,
                              const float *residual, float *y, int N, int Cin, int H, int W, int Cout, int relu,
                              int flip_taps, fi_stream_t stream)
 {
@@ -1618,7 +1631,7 @@ int fi_conv3x3_forward_bf16w(const float *x, const uint16_t *weight_bf16, const 
     return FI_OK;
 }
 
-int fi_conv1x1_forward_bf16w(const float *x, const uint16_t *weight_bf16, const float *bias, const float *scale,
+int FI16(fi_conv1x1_forward, w)(const float *x, const uint16_t *weight_bf16, const float *bias, const float *scale,
                              const float *residual, float *y, int N, int Cin, int HW, int Cout, int relu,
                              fi_stream_t stream)
 {
@@ -1642,12 +1655,12 @@ int fi_conv1x1_forward_bf16w(const float *x, const uint16_t *weight_bf16, const 
     FI_REQUIRE(blocks < 2147483647L, "grid too large");
     fi::ProfScope prof(FI_K_CONV_BF16_FWD, st);
     hipLaunchKernelGGL(conv1x1_bf16_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, st, x,
-                       reinterpret_cast<const __bf16 *>(weight_bf16), ep, y, pg);
+                       reinterpret_cast<const E16 *>(weight_bf16), ep, y, pg);
     FI_HIP_CHECK(hipGetLastError());
     return FI_OK;
 }
 
-int fi_conv2d_weight_grad_bf16(const float *x, const float *dy, float *dweight, int N, int Cin, int H, int W,
+int FI16(fi_conv2d_weight_grad, )(const float *x, const float *dy, float *dweight, int N, int Cin, int H, int W,
                                int Cout, int R, int S, int stride_h, int stride_w, int pad_h, int pad_w,
                                int flags, fi_stream_t stream)
 {

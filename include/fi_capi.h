@@ -364,6 +364,24 @@ int fi_conv2d_weight_grad_bf16(const float *x, const float *dy, float *dweight, 
                                int H, int W, int Cout, int R, int S, int stride_h, int stride_w,
                                int pad_h, int pad_w, int flags, fi_stream_t stream);
 
+/* The same four entry points on IEEE half operands (v_mfma_f32_32x32x16_f16, fp32 accumulation) -- BASELINE
+ * configs[4] names an "fp16 MFMA conv path".  Identical arguments, tiles and epilogues; weight_f16 holds half bit
+ * patterns.  Operands beyond 65504 round to infinity (no loss scaling inside the library). */
+int fi_conv2d_forward_f16(const float *x, const float *weight, const float *bias,
+                          const float *scale, const float *residual, float *y, int N, int Cin,
+                          int H, int W, int Cout, int R, int S, int stride_h, int stride_w,
+                          int pad_h, int pad_w, int relu, int weight_layout, int out_h, int out_w,
+                          int output_layout, fi_stream_t stream);
+int fi_conv3x3_forward_f16w(const float *x, const uint16_t *weight_f16, const float *bias, const float *scale,
+                            const float *residual, float *y, int N, int Cin, int H, int W, int Cout, int relu,
+                            int flip_taps, fi_stream_t stream);
+int fi_conv1x1_forward_f16w(const float *x, const uint16_t *weight_f16, const float *bias, const float *scale,
+                            const float *residual, float *y, int N, int Cin, int HW, int Cout, int relu,
+                            fi_stream_t stream);
+int fi_conv2d_weight_grad_f16(const float *x, const float *dy, float *dweight, int N, int Cin,
+                              int H, int W, int Cout, int R, int S, int stride_h, int stride_w,
+                              int pad_h, int pad_w, int flags, fi_stream_t stream);
+
 /* ------------------------------------------------------------------------
  * In-library kernel timing (HIP events recorded on the launch stream around
  * each kernel launch while enabled).  Used by bench.py for the roofline object;

@@ -21,12 +21,14 @@ bf16 = "--bf16" in sys.argv
 target = float(sys.argv[sys.argv.index("--target") + 1]) if "--target" in sys.argv else (600.0 if bf16 else 135.0)
 dev = "cuda:0"
 torch.manual_seed(2000)
-cfg = make_config("resnet101", 1024, 4, 512, dev_switch=True, loss_choice="ot", ot_L=50,
+cfg5 = "--cfg5" in sys.argv          # the single-GPU slice of BASELINE configs[4]: 2 x 1344^2, 1000 RoIs/image
+SIZE, BATCH, ROIS = (1344, 2, 1000) if cfg5 else (1024, 4, 512)
+cfg = make_config("resnet101", SIZE, BATCH, ROIS, dev_switch=True, loss_choice="ot", ot_L=50,
                   conv_precision="bf16" if bf16 else "fp32")
 model = MaskRCNN(cfg).to(dev)
 opt = set_optimizer(model, cfg.TRAIN)
-batch = synthetic_batch(4, 1024, device=dev, seed=2000)
-model.external_proposals = SyntheticProposals(batch[2], 1024, seed=7)
+batch = synthetic_batch(BATCH, SIZE, device=dev, seed=2000)
+model.external_proposals = SyntheticProposals(batch[2], SIZE, seed=7)
 model.generator = torch.Generator(device=dev).manual_seed(11)
 for _ in range(3):
     train_step(model, opt, list(batch))

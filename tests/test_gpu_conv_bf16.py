@@ -44,14 +44,18 @@ CASES = [
 ]
 
 
-def _bf(t):
-    return t.to(torch.bfloat16).double()
+# the two 16-bit operand types: (torch dtype, operand rounding 2^-(significand bits + 1)); bf16 is csrc/conv_bf16.hip,
+# fp16 the same kernels on v_mfma_f32_32x32x16_f16 (csrc/conv_f16.hip, BASELINE configs[4]'s "fp16 MFMA conv path")
+LOWP = {"bf16": (torch.bfloat16, 2.0 ** -9), "fp16": (torch.float16, 2.0 ** -12)}
 
 
+@pytest.mark.parametrize("precision", ["bf16", "fp16"])
 @pytest.mark.parametrize("case", CASES)
-def test_bf16_conv_forward_backward(case):
+def test_bf16_conv_forward_backward(case, precision):
     from feature_intertwiner_amd import conv as C
     N, Cin, H, W, Cout, R, S, st, pd = case
+    dtype, ulp = LOWP[precision]
+    _bf = lambda t: t.to(dtype).double()
     g = torch.Generator().manual_seed(sum(case))
     x = torch.randn(N, Cin, H, W, generator=g)
     w = torch.randn(Cout, Cin, R, S, generator=g) / math.sqrt(Cin * R * S)
@@ -70,7 +74,7 @@ def test_bf16_conv_forward_backward(case):
     F.conv2d(xd, wd, None, stride=st, padding=pd).backward(_bf(gy))
     y_full = F.conv2d(x.double(), w.double(), b.double(), stride=st, padding=pd)
 
-    C.set_conv_precision("bf16")
+    C.set_conv_precision(precision)
     try:
         xg = x.to(DEV).requires_grad_(True)
         wg = w.to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)   # as parameters are stored
@@ -96,8 +100,8 @@ def test_bf16_conv_forward_backward(case):
     P = N * gy.shape[2] * gy.shape[3]
     assert (wg.grad.cpu().double() - wd.grad).abs().max().item() <= tight(wd.grad, P)
     assert (bg.grad.cpu().double() - gy.double().sum((0, 2, 3))).abs().max().item() <= tight(gy.double().sum((0, 2, 3)), P)
-    # the documented cost of bf16 operands
-    loose = 1.6e-2 * math.sqrt(K) * x.double().pow(2).mean().sqrt().item() * w.double().pow(2).mean().sqrt().item()
+    # the documented cost of 16-bit operands (1.6e-2 = 8 * 2^-9 for bf16)
+    loose = 8 * ulp * math.sqrt(K) * x.double().pow(2).mean().sqrt().item() * w.double().pow(2).mean().sqrt().item()
     assert (y.detach().cpu().double() - y_full).abs().max().item() <= loose
 
 
