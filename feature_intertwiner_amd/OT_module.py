@@ -51,7 +51,11 @@ class _SinkhornLoss(torch.autograd.Function):
     def backward(ctx, grad_loss):
         x, y, plan = ctx.saved_tensors
         g = grad_loss.view(-1, 1, 1)
-        if ctx.cost_mode == 2:
+        if ctx.cost_mode == 2 and x.size(2) == 1:
+            # D = 1 (the model's 1-D form): the two plan-vector products as broadcast multiply + row / column sums
+            gx = -(plan * y.transpose(1, 2)).sum(2, keepdim=True) * g
+            gy = -(plan * x).sum(1).unsqueeze(2) * g
+        elif ctx.cost_mode == 2:
             gx = -torch.bmm(plan, y) * g
             gy = -torch.bmm(plan.transpose(1, 2), x) * g
         else:

@@ -735,14 +735,95 @@ def conv_bn_act(x, conv, bn, relu=True, residual=None, channels_last_out=False, 
     return y.contiguous(memory_format=torch.channels_last) if (channels_last_out and not out_cl) else y
 
 
+
+# ---- fully connected layers on the convolution kernels -----------------------------------------------------------
+# The heads' full-window 7x7 "fc" convolutions (lib/sub_module.py:707, :333), their 1x1 convolutions on 1x1 maps,
+# the class / box nn.Linear layers (:744-747) and the OT module's centre-tap Conv1d (lib/OT_module.py:37-41) are
+# plain matrix products y = x W^T.  They run on the library's own fp32 MFMA kernels (no vendor GEMM):
+#   y  [M,N] = x [M,K] . W[N,K]^T   both operands contiguous along the reduction  -> the weight-gradient kernel
+#              (dW[co][ci] = sum_p dz[co][p] x[ci][p] with co = m, ci = n, p = k), split over K, fp32 atomics;
+#   dx [M,K] = dy[M,N] . W[N,K]     reduction over rows of W                       -> the 1x1 convolution kernel
+#              (Y[co][p] = sum_ci A[co][ci] X[ci][p] with A = dy, X = W, p = k);
+#   dW [N,K] = dy^T[N,M] . x[M,K]   reduction over rows of x                       -> the 1x1 convolution kernel
+#              with A = dy^T (a small transposed copy), X = x.
+# The kernels want the reduction length of the second and third product (N, M) to be a multiple of 32 and the
+# output columns of the first (N) a multiple of 128: N is padded with zero rows of W / zero columns of dy (small
+# copies), M by zero rows of x and dy (only when M % 32 != 0: the callers keep M a multiple of 32).
+def _pad_rows(t, rows):
+    if t.shape[0] == rows:
+        return t.contiguous()
+    out = t.new_zeros((rows,) + tuple(t.shape[1:]))
+    out[:t.shape[0]] = t
+    return out
+
+
+def _gemm_nt(a, b):
+    """a [M,K] . b[N,K]^T -> [M,N]; N % 128 == 0, K % 4 == 0, 16-byte aligned rows."""
+    L = _lib.load()
+    M, K = a.shape
+    N = b.shape[0]
+    y = torch.empty((M, N), device=a.device, dtype=torch.float32)
+    _log_flops("wgrad", M, 1, 1, 2.0 * M * N * K, K, N)
+    with torch.cuda.device(a.device):
+        _lib.check(L.fi_conv2d_weight_grad(_lib.ptr(b), _lib.ptr(a), _lib.ptr(y), 1, N, 1, K, M, 1, 1, 1, 1, 0, 0, 1,
+                                           None, 0, _lib.current_stream()), "fi_conv2d_weight_grad (gemm)")
+    return y
+
+
+def _gemm_nn(a, b):
+    """a [M,R] . b [R,K] -> [M,K]; R % 32 == 0, K % 4 == 0."""
+    M, R = a.shape
+    K = b.shape[1]
+    return _conv_fwd(b.view(1, R, 1, K), a.view(M, R, 1, 1), None, (1, 1), (0, 0), precision="fp32").view(M, K)
+
+
+class _LinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b):
+        _lib.require_cuda(x, w)
+        M, K = x.shape
+        N = w.shape[0]
+        Mp, Np = (M + 31) // 32 * 32, (N + 127) // 128 * 128
+        xp = _pad_rows(x.float(), Mp)
+        wp = _pad_rows(w.float(), Np)
+        y = _gemm_nt(xp, wp)[:M, :N]
+        ctx.save_for_backward(xp, wp)
+        ctx.dims = (M, N, K, b is not None)
+        return y + b if b is not None else y.contiguous()
+
+    @staticmethod
+    def backward(ctx, dy):
+        xp, wp = ctx.saved_tensors
+        M, N, K, has_b = ctx.dims
+        Mp, Np = xp.shape[0], wp.shape[0]
+        dy = dy.float()
+        dyp = dy.new_zeros((Mp, Np))
+        dyp[:M, :N] = dy
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = _gemm_nn(dyp, wp)[:M]                       # reduction over the padded N (zero columns x zero rows)
+        if ctx.needs_input_grad[1]:
+            dw = _gemm_nn(dyp.t().contiguous(), xp)[:N]      # reduction over the padded M
+        db = dy.sum(0) if (has_b and ctx.needs_input_grad[2]) else None
+        return dx, dw, db
+
+
+def linear(x, weight, bias=None):
+    """F.linear(x [M,K], weight [N,K], bias) on the library's MFMA kernels (see above).  Shapes the kernels do not
+    take (K % 4 != 0, a CPU tensor) fall back to F.linear."""
+    if x.dim() != 2 or not x.is_cuda or x.shape[1] % 4 != 0 or x.shape[0] == 0 or x.dtype != torch.float32:
+        return F.linear(x, weight, bias)
+    return _LinearFn.apply(x, weight, bias)
+
+
 def conv2d(x, weight, bias=None, stride=(1, 1), padding=(0, 0), residual=None):
-    """Functional form: conv(x) + bias [+ residual, added in the kernel epilogue].  Full-window kernels become
-    one library GEMM."""
+    """Functional form: conv(x) + bias [+ residual, added in the kernel epilogue].  Full-window kernels are
+    matrix products (linear() above)."""
     R, S = weight.shape[2], weight.shape[3]
     gemm = ((x.shape[2], x.shape[3]) == (R, S) and tuple(padding) == (0, 0) and R * S > 1) or \
         (x.shape[2] * x.shape[3] == 1 and R * S == 1)
     if gemm:
-        y = F.linear(x.reshape(x.shape[0], -1), weight.reshape(weight.shape[0], -1), bias)
+        y = linear(x.reshape(x.shape[0], -1), weight.reshape(weight.shape[0], -1), bias)
         y = y.view(x.shape[0], weight.shape[0], 1, 1)
         return y if residual is None else y + residual
     return _Conv2dFn.apply(x, weight, bias, tuple(stride), tuple(padding), residual)
@@ -796,5 +877,5 @@ class Conv1d(nn.Conv1d):
     def forward(self, x):
         if x.size(2) == 1 and self.kernel_size == (3,) and self.padding == (1,) and self.stride == (1,) \
                 and self.dilation == (1,) and self.groups == 1:
-            return F.linear(x[:, :, 0], self.weight[:, :, 1], self.bias).unsqueeze(2)
+            return linear(x[:, :, 0].contiguous(), self.weight[:, :, 1], self.bias).unsqueeze(2)
         return super(Conv1d, self).forward(x)

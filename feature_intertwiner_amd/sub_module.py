@@ -16,7 +16,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import _lib
-from .conv import Conv2d, ConvTranspose2x2, GradBox, conv2d, conv_bias_relu, conv_bn_act
+from .conv import Conv2d, ConvTranspose2x2, GradBox, conv2d, conv_bias_relu, conv_bn_act, linear
 from .intertwiner import class_mean, roi_level
 from .roi_align.crop_and_resize import CropAndResizeFunction, CropGradGroup, pyramid_crop_and_resize
 from .roi_pooling.functions.roi_pool import RoIPoolFunction
@@ -384,21 +384,26 @@ class Dev(nn.Module):
         # level-major like the reference's small_output_all / small_gt_all (:583-598): a stable sort by
         # level puts them first, in (level, original index) order
         n_small = n2 + n3 + n4
-        order = torch.sort(level, stable=True)[1][:n_small]
+        total_box = bs * R
+        # The feature extractor's fully connected stages are matrix products over the rows fed to it; their kernels
+        # take row counts that are multiples of 32, so up to 31 further RoIs (the first level-5 ones in the sorted
+        # order) ride along.  Their outputs are never read: every use below is restricted to the first n_small rows
+        # or masked by level.
+        n_rows = min((n_small + 31) // 32 * 32, total_box)
+        order = torch.sort(level, stable=True)[1][:n_rows]
         small_output = self._feat_extract(mask_and_feat[order])
         if cfg.DEV.LOSS_CHOICE != 'ot':
             small_output = self.last_op(small_output)
-        small_output = small_output.view(n_small, -1)
-        total_box = bs * R
+        small_output = small_output.view(n_rows, -1)
         small_output_all = small_output.new_zeros(total_box, small_output.size(1))
-        small_output_all[:n_small] = small_output
+        small_output_all[:n_small] = small_output[:n_small]
         small_gt_all = small_output.new_zeros(total_box)
         if not train_phase:
             small_gt_all[:n_small] = 1
             return pooled, mask_and_feat, [small_output_all, small_gt_all]
 
         gt = roi_cls_gt.reshape(-1).to(torch.int32)
-        small_gt_all[:n_small] = gt[order].float()
+        small_gt_all[:n_small] = gt[order[:n_small]].float()
         lvl_o = level[order]
         gt_o = gt[order]
         K = self.num_classs
@@ -416,6 +421,13 @@ class Dev(nn.Module):
             idx = torch.nonzero_static(level > lvl, size=n_big[lvl]).view(-1)
             big_sel.append(idx)
             big_lvl.append(torch.full_like(idx, lvl, dtype=torch.int32))
+        n_big_rows = sum(n_big.values())
+        n_pad = (-n_big_rows) % 32
+        if n_big_rows and n_pad:
+            # row count of the big branch rounded up to a multiple of 32 (see above): the filler rows carry level 0,
+            # which no pyramid level matches -- zero crops, no statistics, no loss
+            big_sel.append(torch.zeros(n_pad, dtype=big_sel[0].dtype, device=level.device))
+            big_lvl.append(torch.zeros(n_pad, dtype=torch.int32, device=level.device))
         big_idx = torch.cat(big_sel)
         big_level = torch.cat(big_lvl)
         big_loss = []
@@ -433,7 +445,8 @@ class Dev(nn.Module):
                 big_out = big_raw = small_output.new_zeros(0, small_output.size(1))
             big_gt = gt[big_idx]
             if cfg.DEV.BIG_SUPERVISE:
-                ce = F.cross_entropy(self.big_fc_layer(big_raw), big_gt.long(), reduction='none') \
+                ce = F.cross_entropy(linear(big_raw, self.big_fc_layer.weight, self.big_fc_layer.bias), big_gt.long(),
+                                     reduction='none') \
                     if big_idx.numel() else big_raw.new_zeros(0)
             for i, lvl in enumerate((2, 3, 4)):
                 # a level without small boxes contributes no big statistics either (:456-467)
@@ -484,9 +497,9 @@ class Classifier(nn.Module):
                 x = (1 - wgt) * x + wgt * small_feat_input.view(x.size(0), x.size(1), 1, 1)
         x = conv_bn_act(x, self.conv2, self.bn2, relu=True)
         x = x.view(-1, 1024)
-        logits = self.linear_class(x)
+        logits = linear(x, self.linear_class.weight, self.linear_class.bias)
         probs = self.softmax(logits)
-        bbox = self.linear_bbox(x)
+        bbox = linear(x, self.linear_bbox.weight, self.linear_bbox.bias)
         bbox = bbox.view(bbox.size(0), -1, 4)
         return [logits, probs, bbox]
 

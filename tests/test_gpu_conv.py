@@ -389,3 +389,39 @@ def test_bottleneck_block_matches_torch_reference(inplanes, planes, stride, proj
     for k, p in blk.named_parameters():
         assert p.grad is not None, k
         assert (p.grad.cpu().double() - sd[k].grad).abs().max().item() <= tol(sd[k].grad), k
+
+
+@pytest.mark.parametrize("M,K,N,bias", [(64, 1024, 1024, True), (2048, 12544, 1024, True), (96, 1024, 81, True),
+                                       (50, 1024, 324, False), (224, 25088, 1024, True), (7, 256, 130, True)])
+def test_linear_on_the_library_kernels_matches_float64(M, K, N, bias):
+    """conv.linear = F.linear on the library's own fp32 MFMA kernels (no vendor GEMM): y = x W^T through the
+    weight-gradient kernel (split over K), dx and dW through the 1x1 convolution kernel; rows / columns that are not
+    multiples of 32 / 128 are padded.  The head FCs of lib/sub_module.py:698-747 and :333."""
+    from feature_intertwiner_amd import _lib
+    from feature_intertwiner_amd.conv import linear
+    g = torch.Generator().manual_seed(M + K + N)
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / math.sqrt(K)
+    b = torch.randn(N, generator=g) if bias else None
+    gy = torch.randn(M, N, generator=g)
+    xd, wd = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    bd = b.double().requires_grad_(True) if bias else None
+    yd = F.linear(xd, wd, bd)
+    yd.backward(gy.double())
+    xg, wg = x.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True)
+    bg = b.to(DEV).requires_grad_(True) if bias else None
+    _lib.prof_reset()
+    _lib.prof_enable(True)
+    y = linear(xg, wg, bg)
+    y.backward(gy.to(DEV))
+    torch.cuda.synchronize()
+    _lib.prof_enable(False)
+    ran = sum(_lib.prof_get(k)[0] for k in _lib.KERNEL_IDS if k.startswith("conv_"))
+    assert ran >= 3, "forward, dx and dW must run on the library's kernels"
+    tol = lambda ref, k: 2e-5 * math.sqrt(k) * (ref.abs().max().item() + 1e-6)
+    assert y.shape == (M, N)
+    assert (y.detach().cpu().double() - yd.detach()).abs().max().item() <= tol(yd.detach(), K)
+    assert (xg.grad.cpu().double() - xd.grad).abs().max().item() <= tol(xd.grad, N)
+    assert (wg.grad.cpu().double() - wd.grad).abs().max().item() <= tol(wd.grad, M)
+    if bias:
+        assert (bg.grad.cpu().double() - bd.grad).abs().max().item() <= tol(bd.grad, M)
