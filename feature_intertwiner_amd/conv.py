@@ -757,16 +757,17 @@ def _pad_rows(t, rows):
     return out
 
 
-def _gemm_nt(a, b):
-    """a [M,K] . b[N,K]^T -> [M,N]; N % 128 == 0, K % 4 == 0, 16-byte aligned rows."""
+def _gemm_nt(a, b, bias=None, relu=False):
+    """act(a [M,K] . b[N,K]^T + bias) -> [M,N] (fi_gemm_nt: deterministic split over K); N % 128 == 0, K % 4 == 0."""
     L = _lib.load()
     M, K = a.shape
     N = b.shape[0]
     y = torch.empty((M, N), device=a.device, dtype=torch.float32)
+    ws = torch.empty((int(L.fi_gemm_nt_workspace_bytes(M, N, K)) + 3) // 4, device=a.device, dtype=torch.float32)
     _log_flops("wgrad", M, 1, 1, 2.0 * M * N * K, K, N)
     with torch.cuda.device(a.device):
-        _lib.check(L.fi_conv2d_weight_grad(_lib.ptr(b), _lib.ptr(a), _lib.ptr(y), 1, N, 1, K, M, 1, 1, 1, 1, 0, 0, 1,
-                                           None, 0, _lib.current_stream()), "fi_conv2d_weight_grad (gemm)")
+        _lib.check(L.fi_gemm_nt(_lib.ptr(a), _lib.ptr(b), _lib.ptr(bias), _lib.ptr(y), M, N, K, 1 if relu else 0,
+                                _lib.ptr(ws), _lib.current_stream()), "fi_gemm_nt")
     return y
 
 
@@ -786,10 +787,11 @@ class _LinearFn(torch.autograd.Function):
         Mp, Np = (M + 31) // 32 * 32, (N + 127) // 128 * 128
         xp = _pad_rows(x.float(), Mp)
         wp = _pad_rows(w.float(), Np)
-        y = _gemm_nt(xp, wp)[:M, :N]
+        bp = _pad_rows(b.float(), Np) if b is not None else None
+        y = _gemm_nt(xp, wp, bp)[:M, :N]                      # bias added by the split reduction
         ctx.save_for_backward(xp, wp)
         ctx.dims = (M, N, K, b is not None)
-        return y + b if b is not None else y.contiguous()
+        return y.contiguous()
 
     @staticmethod
     def backward(ctx, dy):

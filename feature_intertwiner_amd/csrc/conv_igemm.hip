@@ -72,6 +72,8 @@ struct ConvGeom {
     unsigned mul_ohw, sft_ohw, mul_ow, sft_ow;   // magic numbers: n / d == umulhi(n, mul) >> sft
     const float *zero;   // device address of g_zero_page (a kernel argument: no GOT load inside the K loop)
     int wg_gx, wg_gy, wg_splits;   // weight gradient with swz: logical grid (column tiles, Cout tiles, pixel splits) of a 1-D launch
+    long dw_slab; // weight gradient: 0 = all pixel splits add into ONE dW (atomics); > 0 = split s STORES its partial
+                  // sums at dw + s * dw_slab (one writer per element: deterministic; the caller reduces the slabs)
 };
 
 // Out-of-image taps of the tap-major gather read this instead of being masked after the load:
@@ -1651,7 +1653,12 @@ __global__ __launch_bounds__(kThreads, 4) void conv_wgrad_vec_kernel(const float
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int m = m0 + wm * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * khalf;
-                if (m < g.Cout) atomicAdd(dw + (size_t)m * K + k, acc[i][j][e]);
+                if (m < g.Cout) {
+                    if (g.dw_slab)
+                        dw[(size_t)bz * g.dw_slab + (size_t)m * K + k] = acc[i][j][e];
+                    else
+                        atomicAdd(dw + (size_t)m * K + k, acc[i][j][e]);
+                }
             }
     }
     if (do_bias) {                 // the 4 lanes that share `lr` hold the 16 pixels of a K-step
@@ -1730,6 +1737,7 @@ int make_geom(ConvGeom &g, int N, int Cin, int H, int W, int Cout, int R, int S,
     g.out_nhwc = 0;
     g.flip = 0;
     g.swz = 0;
+    g.dw_slab = 0;
     g.vec_out = 0;
     g.zero = nullptr;      // set by the entry points once the arguments are validated (needs the device)
     g.p_base = 0;
@@ -2313,6 +2321,88 @@ int fi_conv2d_weight_grad(const float *x, const float *dy, float *dweight, int N
         launch_wgrad<64>(g, x, dy, dweight, splits, pps, hwc, dbias, st);
     else
         launch_wgrad<128>(g, x, dy, dweight, splits, pps, hwc, dbias, st);
+    FI_HIP_CHECK(hipGetLastError());
+    return FI_OK;
+}
+
+// c[i] = act(sum_s slab_s[i] + bias[i % N]): the ordered reduction of fi_gemm_nt's split-K partial sums
+__global__ __launch_bounds__(256) void gemm_slab_reduce_kernel(const float *__restrict__ ws, int splits, long slab,
+                                                               const float *__restrict__ bias, int N, int relu,
+                                                               float *__restrict__ c, long total4)
+{
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long)gridDim.x * 256) {
+        float4 a = *reinterpret_cast<const float4 *>(ws + 4 * i);
+        for (int sidx = 1; sidx < splits; ++sidx) {
+            const float4 v = *reinterpret_cast<const float4 *>(ws + (size_t)sidx * slab + 4 * i);
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        }
+        if (bias) {
+            const float4 b = *reinterpret_cast<const float4 *>(bias + (4 * i) % N);
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        }
+        if (relu) {
+            a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f);
+        }
+        *reinterpret_cast<float4 *>(c + 4 * i) = a;
+    }
+}
+
+static void gemm_nt_plan(int M, int N, int K, int *bm, int *splits, int *pps)
+{
+    // the tile / split choice of fi_conv2d_weight_grad with Cout = M, Cin = N, pixels = K
+    const long max_splits0 = ((long)K + 511) / 512;
+    const long tiles128 = (long)fi::ceil_div(N, BN) * fi::ceil_div(M, 128);
+    const long per = 1024 / tiles128 < 1 ? 1 : 1024 / tiles128;
+    const long reach128 = tiles128 * (per < max_splits0 ? per : max_splits0);
+    *bm = (M <= 64 || reach128 < 768) ? 64 : 128;
+    const long tiles = (long)fi::ceil_div(N, BN) * fi::ceil_div(M, *bm);
+    long want = 1024 / tiles;
+    long sp = want < 1 ? 1 : (want > max_splits0 ? max_splits0 : want);
+    int p = fi::ceil_div(K, (int)sp);
+    p = fi::ceil_div(p, BK) * BK;
+    *pps = p;
+    *splits = fi::ceil_div(K, p);
+}
+
+size_t fi_gemm_nt_workspace_bytes(int M, int N, int K)
+{
+    if (M < 1 || N < 1 || K < 1) return 0;
+    int bm, splits, pps;
+    gemm_nt_plan(M, N, K, &bm, &splits, &pps);
+    return sizeof(float) * (size_t)splits * (size_t)M * (size_t)N;
+}
+
+int fi_gemm_nt(const float *a, const float *b, const float *bias, float *c, int M, int N, int K, int relu,
+               float *workspace, fi_stream_t stream)
+{
+    FI_REQUIRE(a && b && c && workspace, "null pointer");
+    FI_REQUIRE(M >= 1 && N >= 1 && K >= 4, "sizes must be positive");
+    FI_REQUIRE(N % BN == 0 && K % 4 == 0, "fi_gemm_nt needs N % 128 == 0 and K % 4 == 0");
+    FI_REQUIRE((((uintptr_t)a | (uintptr_t)b | (uintptr_t)c | (uintptr_t)workspace | (uintptr_t)bias) & 15) == 0,
+               "fi_gemm_nt needs 16-byte aligned operands");
+    FI_REQUIRE((long)M * K * 4 < 0x7fffff00L && (long)N * K * 4 < 0x7fffff00L, "operand larger than 2 GB");
+    ConvGeom g;
+    int rc = make_geom(g, 1, N, 1, K, M, 1, 1, 1, 1, 0, 0);
+    if (rc != FI_OK) return rc;
+    g.zero = zero_page();
+    FI_REQUIRE(g.zero != nullptr, "zero page lookup failed (no HIP device?)");
+    FI_REQUIRE(wgrad_same_size(g, b, a), "operands do not meet the row-major kernel's alignment rules");
+    int bm, splits, pps;
+    gemm_nt_plan(M, N, K, &bm, &splits, &pps);
+    g.dw_slab = (long)M * N;
+    hipStream_t st = (hipStream_t)stream;
+    {
+        fi::ProfScope prof(FI_K_CONV_WGRAD + (bm == 64 ? 0 : 4) + window_class(1, 1), st);
+        if (bm == 64)
+            launch_wgrad<64>(g, b, a, workspace, splits, pps, true, nullptr, st);
+        else
+            launch_wgrad<128>(g, b, a, workspace, splits, pps, true, nullptr, st);
+        FI_HIP_CHECK(hipGetLastError());
+    }
+    const long total4 = (long)M * N / 4;
+    const long blocks = (total4 + 255) / 256;
+    hipLaunchKernelGGL(gemm_slab_reduce_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, st, workspace,
+                       splits, g.dw_slab, bias, N, relu, c, total4);
     FI_HIP_CHECK(hipGetLastError());
     return FI_OK;
 }

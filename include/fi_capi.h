@@ -289,6 +289,19 @@ int fi_conv2d_weight_grad(const float *x, const float *dy, float *dweight, int N
                           int H, int W, int Cout, int R, int S, int stride_h, int stride_w,
                           int pad_h, int pad_w, int weight_layout, float *dbias, int flags,
                           fi_stream_t stream);
+/* Fully connected layers (the heads' full-window 7x7 "fc" convolutions lib/sub_module.py:707, :333, their nn.Linear
+ * layers :744-747, the OT module's centre-tap Conv1d lib/OT_module.py:37-41):
+ *     c [M,N] = act(a [M,K] . b [N,K]^T + bias [N])        (torch: F.linear; the reference: cuBLAS through torch)
+ * on the row-major weight-gradient kernel (both operands contiguous along the reduction), the reduction split over
+ * workgroups that each STORE their partial sums in their own slab of `workspace`
+ * (fi_gemm_nt_workspace_bytes(M, N, K) bytes), reduced in a fixed order by a second kernel that adds the bias and
+ * applies the ReLU -- deterministic, unlike an atomic split-K.  N % 128 == 0, K % 4 == 0, 16-byte aligned operands.
+ * The two backward products (reductions over rows) are 1x1 convolutions: fi_conv2d_forward with the weight-like
+ * operand [M,R] as `weight` and the [R,K] operand as a [1,R,1,K] input. */
+size_t fi_gemm_nt_workspace_bytes(int M, int N, int K);
+int fi_gemm_nt(const float *a, const float *b, const float *bias, float *c, int M, int N, int K, int relu,
+               float *workspace, fi_stream_t stream);
+
 /* All layers' W^T for the data-gradient kernel in one launch: for every descriptor, src is
  * [rows][taps][cols] (a weight stored [Cout][R][S][Cin]) and dst becomes [cols][taps][rows]
  * ([Cin][R][S][Cout]).  tile_base = number of 32x32 tiles of all earlier descriptors
