@@ -416,7 +416,7 @@ def test_linear_on_the_library_kernels_matches_float64(M, K, N, bias):
     y.backward(gy.to(DEV))
     torch.cuda.synchronize()
     _lib.prof_enable(False)
-    ran = sum(_lib.prof_get(k)[0] for k in _lib.KERNEL_IDS if k.startswith("conv_"))
+    ran = sum(_lib.prof_get(k)[0] for k in _lib.KERNEL_IDS if k.startswith("conv"))
     assert ran >= 3, "forward, dx and dW must run on the library's kernels"
     tol = lambda ref, k: 2e-5 * math.sqrt(k) * (ref.abs().max().item() + 1e-6)
     assert y.shape == (M, N)
