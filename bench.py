@@ -169,12 +169,12 @@ def pmc_traffic(kernel_substrings, extra_args, timeout_s=170):
     return out
 
 
-def cpu_conv_stack_seconds(shape_log, budget_s=40.0):
+def cpu_conv_stack_seconds(shape_log, top=5, budget_s=30.0):
     """The step's convolutions (forward + input/weight gradients) on the host CPU through torch /
-    oneDNN -- which is how the reference runs them on its CPU path.  Every distinct layer shape is
-    timed ONCE on a reduced batch (1 image of the 4, 32 RoIs of the 2048) and scaled by batch ratio
-    and multiplicity; shapes are taken largest-first and the loop stops at `budget_s`, the remainder
-    being extrapolated from the measured seconds per flop."""
+    oneDNN -- which is how the reference runs them on its CPU path.  The `top` layer shapes that carry the most
+    flops (multiplicity included) are timed at their FULL batch, forward + backward, TWICE -- the first run pays
+    oneDNN's primitive creation and the page faults of fresh buffers and is discarded --; the remaining shapes are
+    priced at the seconds per flop measured on those.  Stops early (and extrapolates more) after `budget_s`."""
     import collections
     import torch.nn.functional as F
     counts = collections.Counter(shape_log)
@@ -183,24 +183,27 @@ def cpu_conv_stack_seconds(shape_log, budget_s=40.0):
     todo = sorted(counts.items(), key=lambda kv: -flops(kv[0]) * kv[1])
     total, timed_flops, timed_s, rest_flops = 0.0, 0.0, 0.0, 0.0
     t_start = time.time()
+    n_timed = 0
     for k, cnt in todo:
         N, Cin, H, W, Cout, R, S, st, pd = k
-        if time.time() - t_start > budget_s:
+        if n_timed >= top or time.time() - t_start > budget_s:
             rest_flops += 3.0 * flops(k) * cnt
             continue
-        n_s = max(1, N // 4) if N <= 16 else 32
-        x = torch.randn(n_s, Cin, H, W, requires_grad=True)
+        x = torch.randn(N, Cin, H, W, requires_grad=True)
         w = torch.randn(Cout, Cin, R, S, requires_grad=True)
-        t = time.time()
-        y = F.conv2d(x, w, None, st, pd)
-        y.backward(torch.ones_like(y))
-        dt = (time.time() - t) * (N / n_s)
+        dt = None
+        for _ in range(2):
+            t = time.time()
+            y = F.conv2d(x, w, None, st, pd)
+            y.backward(torch.ones_like(y))
+            dt = time.time() - t
+        n_timed += 1
         total += dt * cnt
         timed_s += dt * cnt
         timed_flops += 3.0 * flops(k) * cnt
     if rest_flops and timed_flops:
         total += rest_flops * (timed_s / timed_flops)
-    return total, len(todo), (timed_flops / max(timed_flops + rest_flops, 1.0))
+    return total, n_timed, (timed_flops / max(timed_flops + rest_flops, 1.0))
 
 
 def cpu_baseline(model, batch, log_entries, shape_log=None):
@@ -263,9 +266,9 @@ def cpu_baseline(model, batch, log_entries, shape_log=None):
         detail["operators_ms"] = t_total * 1e3
         t_total += conv_s
         unit = "images/sec (operators on the CPU oracle + conv stack on torch CPU/oneDNN)"
-        sample += ("; conv stack: %d distinct layer shapes, each timed once fwd+bwd with torch on %d threads on a "
-                   "reduced batch (1 of 4 images / 32 of 2048 RoIs) and scaled; %.0f%% of the conv flops timed, "
-                   "the rest extrapolated" % (n_shapes, torch.get_num_threads(), 100 * frac))
+        sample += ("; conv stack: the %d layer shapes with the most flops timed fwd+bwd at full batch with torch on %d "
+                   "threads (second of two runs), = %.0f%% of the conv flops; the other shapes priced at the measured "
+                   "seconds per flop" % (n_shapes, torch.get_num_threads(), 100 * frac))
     return {"value": bs / t_total, "unit": unit,
             "cores": O.num_threads(), "kind": "port", "sample": sample,
             "detail_ms": {k: round(v, 1) for k, v in detail.items()}, "host_cpus": os.cpu_count()}

@@ -167,9 +167,15 @@ def test_two_rank_model_step_equals_single_process_rule(variant, size):
             assert (got - ref).abs().max().item() <= 1e-4 * gmax, n      # both are ~0 next to the detector gradients
             continue
         ratio[n] = (float((got * ref).sum() / (ref * ref).sum().clamp(min=1e-30)), err)
-    bad = {n: v for n, v in ratio.items() if v[1] > 2e-3}
-    # fp32 atomics (weight gradient splits, RoIAlign backward) and a different summation order of the two
-    # shards; the W x error this test exists for would show as a ratio of 2 and err ~ 1
+    # Bars (measured: 3e-7 .. 8e-7 without the OT term; 7e-5 .. 3e-4 on the detector and 6e-4 .. 1.1e-3 on ot_loss.*
+    # with it).  Without the OT term the only differences are fp32 atomics (weight-gradient splits, RoIAlign
+    # backward) and the summation order of the two shards: 5e-6.  Through the Sinkhorn plan (a detached 50-iteration
+    # fixed point of exp(-C)) a last-bit difference of the merged statistics is amplified: 1e-3 on what the OT
+    # gradient reaches, 2e-3 on the OT module's own parameters.  The W x error this test exists for would show as a
+    # ratio of 2 and a deviation of ~1.
+    through_ot = choice == "ot" and do_meta
+    bar_of = lambda n: (2e-3 if n.startswith("ot_loss") else 1e-3) if through_ot else 5e-6
+    bad = {n: v for n, v in ratio.items() if v[1] > bar_of(n)}
     assert not bad, ("(least-squares ratio got/ref, max relative deviation) per parameter", bad)
     if choice == "ot":
         has_ot = any(n.startswith("ot_loss") and p.grad is not None for n, p in model.named_parameters())
