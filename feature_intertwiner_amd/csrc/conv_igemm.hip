@@ -2301,16 +2301,18 @@ int fi_conv2d_weight_grad(const float *x, const float *dy, float *dweight, int N
     }
     // 64-row tiles for narrow layers, and when 128-row tiles x the admissible splits (>= 512 pixels each)
     // would fill less than 3/4 of the resident slots (C4/C5 1x1 layers at batch 4)
-    const long max_splits0 = (g.P + 511) / 512;
+    static const int min_pix = getenv("FI_WG_MINPIX") ? atoi(getenv("FI_WG_MINPIX")) : 512;      // tuning knobs (scripts/)
+    static const int force_bm = getenv("FI_WG_BM") ? atoi(getenv("FI_WG_BM")) : 0;
+    const long max_splits0 = (g.P + min_pix - 1) / min_pix;
     const long tiles128 = (long)fi::ceil_div(g.K, BN) * fi::ceil_div(Cout, 128);
     const long reach128 = tiles128 * (1024 / tiles128 < max_splits0 ? (1024 / tiles128 < 1 ? 1 : 1024 / tiles128) : max_splits0);
-    const int BMsel = (Cout <= 64 || reach128 < 768) ? 64 : 128;
+    const int BMsel = force_bm ? (Cout <= 64 ? 64 : force_bm) : ((Cout <= 64 || reach128 < 768) ? 64 : 128);
     const long tiles = (long)fi::ceil_div(g.K, BN) * fi::ceil_div(Cout, BMsel);
     // Split the pixel range so that tiles x splits fills the 1024 resident workgroup slots (256 CUs x 4)
     // in ONE round: every workgroup has the same amount of work, so 1044 workgroups on 1024 slots take
     // two rounds (the first version rounded UP and paid exactly that).  At least 512 pixels per split.
     long want = 1024 / tiles;
-    long max_splits = (g.P + 511) / 512;
+    long max_splits = (g.P + min_pix - 1) / min_pix;
     int splits = (int)(want < 1 ? 1 : (want > max_splits ? max_splits : want));
     if (splits < 1) splits = 1;
     int pps = fi::ceil_div(g.P, splits);

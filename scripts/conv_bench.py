@@ -26,6 +26,10 @@ SHAPES = [
     ("C2 conv3 1x1", 4, 64, 256, 256, 256, 1, 1, 0),
     ("mask deconv as 1x1", 2048, 256, 14, 14, 1024, 1, 1, 0),
     ("stem 7x7 s2", 4, 3, 1024, 1024, 64, 7, 2, 3),
+    ("C3 conv1 1x1", 4, 512, 128, 128, 128, 1, 1, 0),
+    ("C3 conv3 1x1", 4, 128, 128, 128, 512, 1, 1, 0),
+    ("C5 conv1 1x1", 4, 2048, 32, 32, 512, 1, 1, 0),
+    ("C5 conv3 1x1", 4, 512, 32, 32, 2048, 1, 1, 0),
 ]
 
 
