@@ -276,9 +276,14 @@ def run_on_side_stream(fn, *args):
     def wait():
         now = torch.cuda.current_stream(dev)
         now.wait_event(done)
-        for t in (out if isinstance(out, (tuple, list)) else (out,)):
-            if torch.is_tensor(t):
-                t.record_stream(now)      # allocated from the side stream's pool, consumed here
+        def mark(o):
+            if torch.is_tensor(o):
+                if o.is_cuda:
+                    o.record_stream(now)  # allocated from the side stream's pool, consumed here
+            elif isinstance(o, (tuple, list)):
+                for e in o:
+                    mark(e)
+        mark(out)
         return out
     return wait
 

@@ -114,12 +114,28 @@ class MaskRCNN(nn.Module):
                                                  self.priors, cfg, extra)
             h, w = float(cfg.DATA.IMAGE_SHAPE[0]), float(cfg.DATA.IMAGE_SHAPE[1])
             scale = const_tensor([h, w, h, w], images.device)
+            # detection targets (IoU matching, sampling, mask-target crops: ~130 small kernels) on the second stream;
+            # the Dev stage's make-up convolutions below do not depend on the RoIs and run meanwhile
+            def targets_and_levels(*a):
+                t = prepare_det_target(*a)
+                level, counts_ready = self.dev_roi.level_info(t[0])      # starts the one host read of the RoI stage
+                return t + (level,), counts_ready
+
+            gtb = gt_boxes / scale
+            if images.is_cuda:
+                side = _lib.run_on_side_stream(targets_and_levels, proposals, num_prop, gt_class_ids, gtb, gt_masks,
+                                               cfg, self.generator)
+            else:
+                side = (lambda r=targets_and_levels(proposals, num_prop, gt_class_ids, gtb, gt_masks, cfg,
+                                                    self.generator): r)
+        up_maps = self.dev_roi.make_up_maps(mrcnn_maps) if (cfg.DEV.SWITCH and images.is_cuda) else None
+        with torch.no_grad():
+            (rois, target_class_ids, target_deltas, target_mask, roi_lvl), counts_ready = side()
             target_rpn_match, target_rpn_deltas = rpn_target_ready()
-            rois, target_class_ids, target_deltas, target_mask = prepare_det_target(
-                proposals, num_prop, gt_class_ids, gt_boxes / scale, gt_masks, cfg, self.generator)
 
         K = cfg.DATASET.NUM_CLASSES
-        pooled_cls, pooled_mask, feat_out = self.dev_roi(mrcnn_maps, rois, target_class_ids)
+        pooled_cls, pooled_mask, feat_out = self.dev_roi(mrcnn_maps, rois, target_class_ids, up_maps=up_maps,
+                                                         level_info=(roi_lvl, counts_ready))
         scale_num = 3
         if cfg.DEV.SWITCH and not cfg.DEV.BASELINE:
             big_feat, big_cnt, small_feat, small_cnt, big_loss, small_output_all, small_gt_all = feat_out

@@ -339,13 +339,40 @@ class Dev(nn.Module):
         b = boxes * float(self.image_shape[0])      # square images only
         return torch.stack([box_ind.float(), b[:, 1], b[:, 0], b[:, 3], b[:, 2]], dim=1)
 
-    def forward(self, x, rois, roi_cls_gt=None):
+    def make_up_maps(self, x):
+        """The make-up layer (lib/sub_module.py:308-325, applied at :549-557) on every pyramid level.  It does not
+        depend on the RoIs, so the caller may run it while the RoIs are still being generated."""
         cfg = self.config
-        base = cfg.ROIS.ASSIGN_ANCHOR_BASE
+
+        def make_up(i, m):
+            seq = self.upsample[i if cfg.DEV.MULTI_UPSAMPLER else 0]
+            if isinstance(seq[0], Conv2d):
+                # these maps feed only the two crops of forward(): written channels-last by the conv epilogue so
+                # that RoIAlign reads (and its backward adds) whole cache lines per tap
+                return conv_bn_act(m, seq[0], seq[1], relu=True, channels_last_out=(self.roi_type == 'roi_align'))
+            return seq(m)
+        return [make_up(i, m) for i, m in enumerate(x)]
+
+    def level_info(self, rois):
+        """(level [bs*R] int, counts_ready): the pyramid level of every RoI (lib/sub_module.py:405-410) and a
+        function returning the RoI counts of levels 2..5 on the HOST -- the only data-dependent SHAPES of the stage
+        (how many 'small' rows feed feat_extract, how many 'big' boxes each level sees).  They come back in ONE small
+        read; the copy is started here on a side stream and awaited in forward() only after work that does not
+        depend on it has been enqueued, so the device keeps working while the host waits.  (The reference
+        synchronises per level: nonzero / .any() at lib/sub_module.py:456, 475, 483, 541.)"""
+        boxes = rois.reshape(-1, 4)
+        level = roi_level(boxes, float(self.image_shape[0] * self.image_shape[1]), self.config.ROIS.ASSIGN_ANCHOR_BASE)
+        lv = torch.arange(2, 6, device=level.device, dtype=level.dtype)
+        per_level = (level.unsqueeze(0) == lv.unsqueeze(1)).sum(1)                 # [n2, n3, n4, n5]
+        counts_ready = _lib.async_host_read(per_level) if level.is_cuda else (lambda: per_level)
+        return level, counts_ready
+
+    def forward(self, x, rois, roi_cls_gt=None, up_maps=None, level_info=None):
+        cfg = self.config
         bs, R = rois.size(0), rois.size(1)
         boxes = rois.reshape(-1, 4)
         box_ind = torch.arange(bs, device=rois.device, dtype=torch.int32).repeat_interleave(R)
-        level = roi_level(boxes, float(self.image_shape[0] * self.image_shape[1]), base)
+        level, counts_ready = level_info if level_info is not None else self.level_info(rois)
 
         if not self.use_dev:
             pooled = self._crop(x, boxes, box_ind, level, self.pool_size)
@@ -355,24 +382,9 @@ class Dev(nn.Module):
             raise NotImplementedError("only DEV.STRUCTURE='beta' executes in the reference (SURVEY Q9)")
 
         train_phase = roi_cls_gt is not None
-        # The only data-dependent SHAPES of the stage are how many RoIs sit on levels 2..4 ('small' rows fed
-        # to feat_extract) and how many 'big' boxes each level sees.  All of them come back in ONE small
-        # read; the copy runs on a side stream and is awaited only after the make-up convolutions (which do
-        # not depend on the RoIs) have been enqueued, so the device keeps working while the host waits.
-        # (The reference synchronises per level: nonzero / .any() at lib/sub_module.py:456, 475, 483, 541.)
-        lv = torch.arange(2, 6, device=level.device, dtype=level.dtype)
-        per_level = (level.unsqueeze(0) == lv.unsqueeze(1)).sum(1)                 # [n2, n3, n4, n5]
-        counts_ready = _lib.async_host_read(per_level) if level.is_cuda else (lambda: per_level)
-
-        # make-up layer on every level, then ONE launch per crop size over all levels
-        def make_up(i, m):
-            seq = self.upsample[i if cfg.DEV.MULTI_UPSAMPLER else 0]
-            if isinstance(seq[0], Conv2d):
-                # these maps feed only the two crops below: written channels-last by the conv epilogue so
-                # that RoIAlign reads (and its backward adds) whole cache lines per tap
-                return conv_bn_act(m, seq[0], seq[1], relu=True, channels_last_out=(self.roi_type == 'roi_align'))
-            return seq(m)
-        up_maps = [make_up(i, m) for i, m in enumerate(x)]
+        # make-up layer on every level (unless the caller already ran it), then ONE launch per crop size over all levels
+        if up_maps is None:
+            up_maps = self.make_up_maps(x)
         n2, n3, n4, n5 = (int(v) for v in counts_ready().tolist())
         group = CropGradGroup()      # both crops' gradients accumulate in ONE set of buffers (no add pass per level)
         pooled = self._crop(up_maps, boxes, box_ind, level, self.pool_size, group)

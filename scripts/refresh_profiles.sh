@@ -26,4 +26,16 @@ python scripts/trace_groups.py $f conv 7 | head -70 > $O/${R}_conv_layers.txt
 python scripts/trace_groups.py $f bn_act 7 > $O/${R}_bn_bwd_layers.txt
 timeout 200 python scripts/conv_bench.py > $O/${R}_conv_bench.txt 2>&1
 timeout 200 python scripts/conv_bench.py --bf16 > $O/${R}_conv_bench_bf16.txt 2>&1
-ls -la $O | tail -20
+# round 3 additions
+timeout 200 python scripts/step_attrib.py > $O/${R}_step_attrib.txt 2>&1
+timeout 200 python scripts/conv_shapes.py > $O/${R}_conv_shapes_fp32.txt 2>&1
+timeout 200 python scripts/conv_shapes.py --bf16 --cfg5 > $O/${R}_conv_shapes_cfg5_bf16.txt 2>&1
+( cd /tmp && timeout 400 python $GRAFT_REPO_ROOT/bench.py --config cfg5 --conv-precision fp16 --no-cpu-baseline --no-pmc > $O/${R}_bench_cfg5_fp16.json 2>/dev/null )
+# the data-parallel engine on RCCL with ONE rank (all a 1-GPU box can host): bucket sizes, in-place reduction, overlap object
+( cd /tmp && FI_DP_FORCE=1 timeout 400 python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-pmc > $O/${R}_bench_dp_force_1rank_rccl.json 2>/dev/null )
+# `python bench.py --gpus 2` WITHOUT a launcher (self-launch), two ranks sharing the GPU over gloo (test mode)
+( cd /tmp && FI_BENCH_SHARE_GPU=1 timeout 600 python $GRAFT_REPO_ROOT/bench.py --gpus 2 --steps 6 --no-cpu-baseline --no-pmc > $O/${R}_bench_gpus2_selflaunch_shared_gpu.json 2>/dev/null )
+# RoIAlign NCHW: kernel variants and overhead probes at the north-star shape, and the TCP / TCC / SQ counters of the library kernel
+timeout 200 scripts/micro/bin/crop_var > $O/${R}_crop_nchw_variants.txt 2>&1
+bash scripts/micro/crop_pmc.sh library > /dev/null 2>&1; cp $O/crop_pmc/summary.txt $O/${R}_crop_nchw_pmc.txt
+ls -la $O | tail -30
