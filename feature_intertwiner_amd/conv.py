@@ -746,9 +746,11 @@ def conv_bn_act(x, conv, bn, relu=True, residual=None, channels_last_out=False, 
 #              (Y[co][p] = sum_ci A[co][ci] X[ci][p] with A = dy, X = W, p = k);
 #   dW [N,K] = dy^T[N,M] . x[M,K]   reduction over rows of x                       -> the 1x1 convolution kernel
 #              with A = dy^T (a small transposed copy), X = x.
-# The kernels want the reduction length of the second and third product (N, M) to be a multiple of 32 and the
-# output columns of the first (N) a multiple of 128: N is padded with zero rows of W / zero columns of dy (small
-# copies), M by zero rows of x and dy (only when M % 32 != 0: the callers keep M a multiple of 32).
+# The kernels want the reduction length of the second and third product (N, M) to be a multiple of 32 (64 on the
+# 16-bit kernels) and the output columns of the first (N) a multiple of 128: N is padded with zero rows of W / zero
+# columns of dy (small copies), M by zero rows of x and dy (only when needed: the callers keep M a multiple of 64).
+# With MODEL.CONV_PRECISION 'bf16' / 'fp16' the three products run on the 16-bit MFMA kernels like every other
+# convolution of the step (the full-window "fc" layers ARE convolutions in the reference).
 def _pad_rows(t, rows):
     if t.shape[0] == rows:
         return t.contiguous()
@@ -757,11 +759,23 @@ def _pad_rows(t, rows):
     return out
 
 
-def _gemm_nt(a, b, bias=None, relu=False):
-    """act(a [M,K] . b[N,K]^T + bias) -> [M,N] (fi_gemm_nt: deterministic split over K); N % 128 == 0, K % 4 == 0."""
+def _gemm_nt(a, b, bias=None, relu=False, precision="fp32"):
+    """act(a [M,K] . b[N,K]^T + bias) -> [M,N]; N % 128 == 0, K % 4 == 0.  fp32: fi_gemm_nt (deterministic split over
+    K).  16-bit precisions: the 16-bit weight-gradient kernel (operands rounded on their way into LDS, fp32 atomics
+    over the split) when M % 64 == 0, then bias / ReLU."""
     L = _lib.load()
     M, K = a.shape
     N = b.shape[0]
+    if precision in _LOWP and M % 64 == 0 and K >= 64:
+        y = torch.empty((M, N), device=a.device, dtype=torch.float32)
+        _log_flops("bf16_wgrad", M, 1, 1, 2.0 * M * N * K)
+        with torch.cuda.device(a.device):
+            _lib.check(_lowp_fn(L, "conv2d_weight_grad", precision)(_lib.ptr(b), _lib.ptr(a), _lib.ptr(y), 1, N, 1, K, M,
+                                                                    1, 1, 1, 1, 0, 0, 0, _lib.current_stream()),
+                       "fi_conv2d_weight_grad_16 (gemm)")
+        if bias is not None:
+            y = y + bias
+        return torch.relu_(y) if relu else y
     y = torch.empty((M, N), device=a.device, dtype=torch.float32)
     ws = torch.empty((int(L.fi_gemm_nt_workspace_bytes(M, N, K)) + 3) // 4, device=a.device, dtype=torch.float32)
     _log_flops("wgrad", M, 1, 1, 2.0 * M * N * K, K, N)
@@ -771,11 +785,11 @@ def _gemm_nt(a, b, bias=None, relu=False):
     return y
 
 
-def _gemm_nn(a, b):
+def _gemm_nn(a, b, precision="fp32"):
     """a [M,R] . b [R,K] -> [M,K]; R % 32 == 0, K % 4 == 0."""
     M, R = a.shape
     K = b.shape[1]
-    return _conv_fwd(b.view(1, R, 1, K), a.view(M, R, 1, 1), None, (1, 1), (0, 0), precision="fp32").view(M, K)
+    return _conv_fwd(b.view(1, R, 1, K), a.view(M, R, 1, 1), None, (1, 1), (0, 0), precision=precision).view(M, K)
 
 
 class _LinearFn(torch.autograd.Function):
@@ -784,13 +798,16 @@ class _LinearFn(torch.autograd.Function):
         _lib.require_cuda(x, w)
         M, K = x.shape
         N = w.shape[0]
-        Mp, Np = (M + 31) // 32 * 32, (N + 127) // 128 * 128
+        prec = _PRECISION
+        rows = 64 if prec in _LOWP else 32
+        Mp, Np = (M + rows - 1) // rows * rows, (N + 127) // 128 * 128
         xp = _pad_rows(x.float(), Mp)
         wp = _pad_rows(w.float(), Np)
         bp = _pad_rows(b.float(), Np) if b is not None else None
-        y = _gemm_nt(xp, wp, bp)[:M, :N]                      # bias added by the split reduction
+        y = _gemm_nt(xp, wp, bp, precision=prec)[:M, :N]      # bias added by the split reduction
         ctx.save_for_backward(xp, wp)
         ctx.dims = (M, N, K, b is not None)
+        ctx.precision = prec
         return y.contiguous()
 
     @staticmethod
@@ -803,9 +820,9 @@ class _LinearFn(torch.autograd.Function):
         dyp[:M, :N] = dy
         dx = dw = None
         if ctx.needs_input_grad[0]:
-            dx = _gemm_nn(dyp, wp)[:M]                       # reduction over the padded N (zero columns x zero rows)
+            dx = _gemm_nn(dyp, wp, ctx.precision)[:M]        # reduction over the padded N (zero columns x zero rows)
         if ctx.needs_input_grad[1]:
-            dw = _gemm_nn(dyp.t().contiguous(), xp)[:N]      # reduction over the padded M
+            dw = _gemm_nn(dyp.t().contiguous(), xp, ctx.precision)[:N]      # reduction over the padded M
         db = dy.sum(0) if (has_b and ctx.needs_input_grad[2]) else None
         return dx, dw, db
 

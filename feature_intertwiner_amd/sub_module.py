@@ -398,10 +398,10 @@ class Dev(nn.Module):
         n_small = n2 + n3 + n4
         total_box = bs * R
         # The feature extractor's fully connected stages are matrix products over the rows fed to it; their kernels
-        # take row counts that are multiples of 32, so up to 31 further RoIs (the first level-5 ones in the sorted
+        # take row counts that are multiples of 64, so up to 63 further RoIs (the first level-5 ones in the sorted
         # order) ride along.  Their outputs are never read: every use below is restricted to the first n_small rows
         # or masked by level.
-        n_rows = min((n_small + 31) // 32 * 32, total_box)
+        n_rows = min((n_small + 63) // 64 * 64, total_box)
         order = torch.sort(level, stable=True)[1][:n_rows]
         small_output = self._feat_extract(mask_and_feat[order])
         if cfg.DEV.LOSS_CHOICE != 'ot':
@@ -434,9 +434,9 @@ class Dev(nn.Module):
             big_sel.append(idx)
             big_lvl.append(torch.full_like(idx, lvl, dtype=torch.int32))
         n_big_rows = sum(n_big.values())
-        n_pad = (-n_big_rows) % 32
+        n_pad = (-n_big_rows) % 64
         if n_big_rows and n_pad:
-            # row count of the big branch rounded up to a multiple of 32 (see above): the filler rows carry level 0,
+            # row count of the big branch rounded up to a multiple of 64 (see above): the filler rows carry level 0,
             # which no pyramid level matches -- zero crops, no statistics, no loss
             big_sel.append(torch.zeros(n_pad, dtype=big_sel[0].dtype, device=level.device))
             big_lvl.append(torch.zeros(n_pad, dtype=torch.int32, device=level.device))

@@ -198,3 +198,38 @@ def test_bf16_kernels_at_full_layer_sizes_against_fp32(shape):
         rel = ((a.double() - b.double()).norm() / a.double().norm()).item()
         assert rel < 6e-3, (name, rel)                      # 2^-9 * sqrt(2) = 2.8e-3 for independent roundings
         assert rel > 1e-5, (name, rel)                      # ... and the bf16 kernels really ran
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp16"])
+@pytest.mark.parametrize("M,K,N", [(128, 1024, 1024), (2000, 12544, 1024), (192, 25088, 1024), (96, 1024, 81)])
+def test_linear_on_the_16bit_kernels(M, K, N, precision):
+    """conv.linear under MODEL.CONV_PRECISION bf16 / fp16: the three products of a head FC (y = x W^T, dX, dW) on the
+    16-bit MFMA kernels.  Tight bar against float64 on operands rounded to the 16-bit type (what each product's
+    kernel rounds), as for the convolutions above."""
+    from feature_intertwiner_amd import conv as C
+    dtype, ulp = LOWP[precision]
+    r = lambda t: t.to(dtype).double()
+    g = torch.Generator().manual_seed(M + K + N)
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / math.sqrt(K)
+    b = torch.randn(N, generator=g)
+    gy = torch.randn(M, N, generator=g)
+    y_t = r(x) @ r(w).t() + b.double()
+    dx_t = r(gy) @ r(w)
+    dw_t = r(gy).t() @ r(x)
+    C.set_conv_precision(precision)
+    try:
+        C.FLOP_LOG = {}
+        xg, wg, bg = x.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
+        y = C.linear(xg, wg, bg)
+        y.backward(gy.to(DEV))
+        used = dict(C.FLOP_LOG)
+    finally:
+        C.set_conv_precision("fp32")
+        C.FLOP_LOG = None
+    assert "conv_bf16_fwd" in used and "conv_bf16_wgrad" in used, used
+    tight = lambda ref, k: 2e-5 * math.sqrt(k) * (ref.abs().max().item() + 1e-6)
+    assert (y.detach().cpu().double() - y_t).abs().max().item() <= tight(y_t, K)
+    assert (xg.grad.cpu().double() - dx_t).abs().max().item() <= tight(dx_t, N)
+    assert (wg.grad.cpu().double() - dw_t).abs().max().item() <= tight(dw_t, M)
+    assert (bg.grad.cpu().double() - gy.double().sum(0)).abs().max().item() <= tight(gy.double().sum(0), M)
