@@ -13,6 +13,7 @@ csrc/conv_igemm.hip:
 7x7 crops, lib/sub_module.py:707; the 7x7 conv of feat_extract on 7x7 maps, :333) are
 plain matrix products and go to the library GEMM.
 """
+import contextlib
 import weakref
 
 import torch
@@ -274,6 +275,13 @@ def _conv_backward(ctx_needs, x, w, dz, stride, padding, want_db=False, add_to_d
     N, Cin, H, W = x.shape
     Cout, _, R, S = w.shape
     dx = dw = db = None
+    dz_ready = None
+    if ctx_needs[0] and ctx_needs[1] and WGRAD_SIDE_STREAM_MAX_PIXELS and \
+            N * dz.shape[2] * dz.shape[3] <= WGRAD_SIDE_STREAM_MAX_PIXELS and precision not in _LOWP:
+        # the weight gradient may run on the second stream (below): it depends on dz as it is NOW, not on the data
+        # gradient that is enqueued first
+        dz_ready = torch.cuda.Event()
+        dz_ready.record(torch.cuda.current_stream(x.device))
     if ctx_needs[0]:
         if isinstance(add_to_dx, _Compact) and not (stride == (2, 2) and R * S == 1 and padding == (0, 0) and
                                                     Cout % 16 == 0 and Cin % 16 == 0):
@@ -342,7 +350,14 @@ def _conv_backward(ctx_needs, x, w, dz, stride, padding, want_db=False, add_to_d
         if want_db:
             db = dz.sum((0, 2, 3)) if bf16 else (db_slot if db_slot is not None else
                                                  torch.empty(Cout, device=x.device, dtype=torch.float32))
-        with torch.cuda.device(x.device):
+        side = None
+        if flags and dz_ready is not None and not bf16:
+            main = torch.cuda.current_stream(x.device)
+            side = _wgrad_side_stream(x.device)
+            side.wait_event(dz_ready)                      # dz (and x) were complete on the main stream there
+            x.record_stream(side)
+            dz.record_stream(side)
+        with torch.cuda.device(x.device), (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
             if bf16:
                 _log_flops("bf16_wgrad", Cout, R, S, 2 * N * Cout * dz.shape[2] * dz.shape[3] * Cin * R * S)
                 _lib.check(_lowp_fn(L, "conv2d_weight_grad", precision)(_lib.ptr(x), _lib.ptr(dz), _lib.ptr(dw), N, Cin, H, W, Cout,
@@ -354,6 +369,8 @@ def _conv_backward(ctx_needs, x, w, dz, stride, padding, want_db=False, add_to_d
                 _lib.check(L.fi_conv2d_weight_grad(_lib.ptr(x), _lib.ptr(dz), _lib.ptr(dw), N, Cin, H, W, Cout,
                                                    R, S, stride[0], stride[1], padding[0], padding[1], hwc,
                                                    _lib.ptr(db), flags, _lib.current_stream()), "fi_conv2d_weight_grad")
+        if side is not None:
+            _queue_wgrad_join(main, side)
         if hwc and R * S > 1:
             dw = dw.permute(0, 3, 1, 2)
         if not hand_over:
@@ -363,6 +380,46 @@ def _conv_backward(ctx_needs, x, w, dz, stride, padding, want_db=False, add_to_d
     elif want_db:
         db = dz.sum((0, 2, 3))
     return (dx, dw, db) if want_db else (dx, dw)
+
+
+# ---- weight gradients of small layers on a second stream ---------------------------------------------------------
+# The data gradient and the weight gradient of a layer are independent (both read dz).  For layers whose grids are a
+# single round of workgroups (the C3..C5 stages at batch 4) each kernel leaves the chip part-empty while its
+# workgroups start up and while they drain (prologue, short K loops, atomic epilogue); issued on two streams the
+# tail of one kernel overlaps the head of the other.  Only for gradients that land in the persistent arena (no
+# allocator involvement); the main stream re-joins at the end of the backward pass (an autograd engine callback) and
+# data_parallel.GradientBuckets waits for this stream before it reduces a bucket.
+import os as _os
+WGRAD_SIDE_STREAM_MAX_PIXELS = int(_os.environ.get("FI_WGRAD_SIDE_PIXELS", str(1 << 30)))   # largest layer (pixels) that takes the second stream; 0 disables
+_WG_STREAM = {}
+_WG_JOIN_QUEUED = [False]
+
+
+def wgrad_stream(device):
+    """The second stream weight gradients may run on (None before first use)."""
+    return _WG_STREAM.get(_lib.device_key(device))
+
+
+def _wgrad_side_stream(dev):
+    key = _lib.device_key(dev)
+    st = _WG_STREAM.get(key)
+    if st is None:
+        st = _WG_STREAM[key] = torch.cuda.Stream(device=dev)
+    return st
+
+
+def _queue_wgrad_join(main, side):
+    if _WG_JOIN_QUEUED[0]:
+        return
+
+    def join():
+        _WG_JOIN_QUEUED[0] = False
+        main.wait_stream(side)
+    try:
+        torch.autograd.Variable._execution_engine.queue_callback(join)
+        _WG_JOIN_QUEUED[0] = True
+    except RuntimeError:          # not inside a backward pass: join right away
+        main.wait_stream(side)
 
 
 # ---- per-step derived state: W^T for the data gradient, zeroed gradient arena ---------------------
@@ -375,11 +432,13 @@ _WB = {}           # tap-major fp32 weight data_ptr -> (bf16 copy, version, shap
 
 
 def _cached_bf16(w, dtype=torch.bfloat16):
-    """16-bit copy of a tap-major fp32 weight, made once per (tensor, version).  The entry keeps `w` alive, so its
-    address cannot be handed to another tensor while the entry exists."""
+    """16-bit copy of a (contiguous, tap-major) fp32 weight, made once per (tensor, version).  Model weights and
+    their W^T are converted for ALL layers by one multi-tensor copy per step (_prepare_step fills the cache); anything
+    else (temporaries) is converted here.  The entry keeps `w` alive, so its address cannot be handed to another
+    tensor while the entry exists."""
     e = _WB.get(w.data_ptr())
-    if e is not None and e[1] == w._version and e[2] == tuple(w.shape) and e[0].dtype == dtype:
-        return e[0]
+    if e is not None and e[1] == w._version and e[0].numel() == w.numel() and e[0].dtype == dtype:
+        return e[0].view(w.shape) if e[0].shape != w.shape else e[0]
     wb = w.to(dtype)
     _WB[w.data_ptr()] = (wb, w._version, tuple(w.shape), w)
     return wb
@@ -477,7 +536,7 @@ def _prepare_step(model, grad_on):
             if bn in layout.bn_slot:
                 slots[("bn", bn.weight.data_ptr())] = (layout.bn_slot[bn], 3 * bn.num_features, weakref.ref(bn.weight))
         plan = {"ptrs": tuple(p.data_ptr() for p in model.parameters()), "tr": tr, "wts": wts, "table": table,
-                "tiles": base, "slots": slots, "layout": layout, "versions": None}
+                "tiles": base, "slots": slots, "layout": layout, "versions": None, "convs": convs}
         _PLAN[model] = plan
     versions = tuple(m.weight._version for m in plan["tr"])
     if plan["table"] is not None and (plan["versions"] != versions or not all(
@@ -490,6 +549,26 @@ def _prepare_step(model, grad_on):
             _WT[m.weight.data_ptr()] = (wt, m.weight._version)
         plan["versions"] = versions
         _WB.clear()          # the W^T tensors were rewritten in place (no version bump): drop their bf16 copies
+    if _PRECISION in _LOWP:
+        # 16-bit copies of every layer's weight and W^T for this step: one multi-tensor copy (per-layer .to() calls were
+        # ~190 launches / 0.8 ms of the bf16 step)
+        dtype = _LOWP[_PRECISION][1]
+        lw = plan.get("lowp")
+        if lw is None or lw["dtype"] != dtype:
+            srcs = [m.weight for m in plan["convs"] if m.weight.shape[1] % 32 == 0] + list(plan["wts"])
+            lw = plan["lowp"] = {"dtype": dtype, "srcs": srcs, "versions": None,
+                                 "dsts": [torch.empty(t.numel(), device=dev, dtype=dtype) for t in srcs]}
+        vers = tuple(t._version for t in lw["srcs"]) + (plan["versions"],)
+        stale = lw["versions"] != vers or any(_WB.get(t.data_ptr(), (None,))[0] is not d
+                                               for t, d in zip(lw["srcs"][:1], lw["dsts"][:1]))
+        if stale and lw["srcs"]:
+            # memory order of a channels-last parameter IS the tap-major [Cout][R][S][Cin] order the kernels read
+            flat = [t.permute(0, 2, 3, 1).reshape(-1) if (t.dim() == 4 and not t.is_contiguous()) else t.reshape(-1)
+                    for t in lw["srcs"]]
+            torch._foreach_copy_(lw["dsts"], flat)
+            for t, d in zip(lw["srcs"], lw["dsts"]):
+                _WB[t.data_ptr()] = (d, t._version, tuple(t.shape), t)
+            lw["versions"] = vers
     layout = plan["layout"]
     if grad_on and layout.total:
         buf = layout.buffer(dev)

@@ -21,6 +21,11 @@ import torch.distributed as dist
 from . import grad_arena
 
 
+def conv_wgrad_stream(device):
+    from .conv import wgrad_stream          # (conv imports nothing from here; late import keeps CPU-only use light)
+    return wgrad_stream(device)
+
+
 class _AllReduceSumIdentityGrad(torch.autograd.Function):
     """y = sum over ranks of x; backward returns world_size * g.
 
@@ -214,6 +219,9 @@ class GradientBuckets(object):
             piece = buf[b.start:b.end]
             if self.use_stream:
                 self.comm_stream.wait_stream(torch.cuda.current_stream(self.device))
+                wg = conv_wgrad_stream(self.device)        # weight gradients of small layers run on their own stream
+                if wg is not None:
+                    self.comm_stream.wait_stream(wg)
                 with torch.cuda.stream(self.comm_stream):
                     ev = None
                     if self.profile is not None and self.stream_ordered:
