@@ -255,17 +255,6 @@ def async_host_read(t):
 
 _SIDE = {}
 _SIDE2 = {}
-_BRANCH = {}
-
-
-def branch_stream(device):
-    """A stream for a branch of the network that is independent of what the current stream runs next."""
-    key = device_key(device)
-    st = _BRANCH.get(key)
-    if st is None:
-        st = _BRANCH[key] = torch.cuda.Stream(device=device)
-    return st
-
 
 def run_on_side_stream(fn, *args):
     """Run fn(*args) (network-independent small kernels, e.g. RPN target generation) on a second stream so that

@@ -2,8 +2,6 @@
 Counterpart of lib/model.py of the reference (train path; same sub-module names, so
 state dicts line up: fpn.*, rpn.*, dev_roi.*, ot_loss.*, classifier.*, mask.*).
 """
-import os
-
 import numpy as np
 import torch
 import torch.nn as nn
@@ -19,7 +17,6 @@ from .OT_module import OptTrans
 from .sub_module import FPN, RPN, Classifier, Dev, Mask, ResNet
 
 EPS = 1e-20
-_BRANCH_STREAMS = os.environ.get("FI_BRANCH_STREAMS", "0") == "1"     # box head on its own stream: measured neutral, off
 
 
 class MaskRCNN(nn.Module):
@@ -148,20 +145,7 @@ class MaskRCNN(nn.Module):
             big_cnt, small_cnt = z(1, scale_num, 1, K), z(1, scale_num, 1, K)
             big_loss, small_output_all, small_gt_all = z(1, scale_num, 1), z(1, 1024), z(1)
 
-        # The box head (three small matrix products and a 1x1 layer) and the mask head (four 3x3 layers on 2048 RoI maps)
-        # are independent: with FI_BRANCH_STREAMS=1 the box head runs on a second stream, forward AND backward (autograd
-        # runs a node's backward on the stream of its forward).  Measured neutral (155.9 vs 156.3 ms/step in one box,
-        # within run-to-run noise): the mask head's kernels fill the chip by themselves.  Off by default.
-        branch = _lib.branch_stream(images.device) if (images.is_cuda and _BRANCH_STREAMS) else None
-        if branch is not None:
-            cur = torch.cuda.current_stream(images.device)
-            branch.wait_stream(cur)
-            with torch.cuda.stream(branch):
-                mrcnn_class_logits, _, mrcnn_bbox = self.classifier(pooled_cls, small_output_all, small_gt_all)
-            for t in (pooled_cls, small_output_all, small_gt_all):
-                t.record_stream(branch)
-        else:
-            mrcnn_class_logits, _, mrcnn_bbox = self.classifier(pooled_cls, small_output_all, small_gt_all)
+        mrcnn_class_logits, _, mrcnn_bbox = self.classifier(pooled_cls, small_output_all, small_gt_all)
         mask_ids, mask_tgt = target_class_ids, target_mask
         if cfg.MRCNN.MASK_HEAD_ON_POSITIVE_SLOTS:
             # The reference runs the mask head on every RoI (lib/model.py:442) although only positive
@@ -173,10 +157,6 @@ class MaskRCNN(nn.Module):
             pooled_mask = pooled_mask.view(bs, R, *pooled_mask.shape[1:])[:, :P].reshape(bs * P, *pooled_mask.shape[1:])
             mask_ids, mask_tgt = target_class_ids[:, :P], target_mask[:, :P]
         mask_u = self.mask(pooled_mask, shuffled=False, activate=False)  # logits [bs*R', 2, 2, K, 14, 14]
-        if branch is not None:
-            cur.wait_stream(branch)
-            mrcnn_class_logits.record_stream(cur)
-            mrcnn_bbox.record_stream(cur)
         mrcnn_class_logits = mrcnn_class_logits.view(bs, -1, mrcnn_class_logits.size(1))
         mrcnn_bbox = mrcnn_bbox.view(bs, -1, mrcnn_bbox.size(1), mrcnn_bbox.size(2))
         mask_u = mask_u.view(bs, -1, *mask_u.shape[1:])
