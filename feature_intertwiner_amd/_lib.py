@@ -97,6 +97,7 @@ KERNEL_IDS = {
     "crop_fwd_nhwc_7x7": 31, "crop_fwd_nhwc_14x14": 32, "crop_fwd_nhwc_generic": 33,
     "crop_bwd_nhwc_7x7": 34, "crop_bwd_nhwc_14x14": 35, "crop_bwd_nhwc_generic": 36,
     "conv_bf16_fwd": 37, "conv_bf16_wgrad": 38, "conv3x3_patch": 39, "conv3x3_patch_flat": 40, "conv1x1_reg": 41,
+    "proposal_select": 42, "proposal_gather": 43, "stride2_interleave": 44, "gemm_reduce": 45,
 }
 for _i, _bm in enumerate((64, 128)):
     for _j, _w in enumerate(("1x1", "3x3", "7x7", "other")):

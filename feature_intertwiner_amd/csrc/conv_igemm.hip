@@ -2403,6 +2403,7 @@ int fi_gemm_nt(const float *a, const float *b, const float *bias, float *c, int 
     }
     const long total4 = (long)M * N / 4;
     const long blocks = (total4 + 255) / 256;
+    fi::ProfScope prof2(FI_K_GEMM_REDUCE, st);
     hipLaunchKernelGGL(gemm_slab_reduce_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, st, workspace,
                        splits, g.dw_slab, bias, N, relu, c, total4);
     FI_HIP_CHECK(hipGetLastError());

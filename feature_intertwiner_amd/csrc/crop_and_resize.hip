@@ -233,6 +233,104 @@ __global__ __launch_bounds__(kThreads) void crop_fwd_kernel(
     }
 }
 
+// -------------------------------------------------------------------------------------
+// Table-free forward for small crops (7 x 7): a thread owns ONE bin of one RoI for CG consecutive channels.
+// No LDS, no barrier, no per-workgroup header chain: the flat thread index runs over (channel group, RoI, bin),
+// the two sampling coordinates are computed per thread (two make_tap() -- ~70 VALU amortised over CG outputs), the
+// 2 x CG gathers of the bin are all in flight before the first lerp, and the stores of one channel are the 49
+// consecutive floats of a (RoI, channel) crop.  XCD-aware like crop_fwd_kernel: workgroup b runs on XCD b % 8 and
+// XCD x owns the channel groups g with g % 8 == x, each for ALL RoIs, so that a group's planes stay in one L2
+// (without this order the same kernel takes 63-69 us instead of 29.5 at 512 x 256 x 7 x 7: scripts/micro/
+// crop_nchw_variants.hip).  Bit-identical to crop_fwd_kernel (same make_tap, same lerp order).
+// -------------------------------------------------------------------------------------
+template <int CH, int CW, int CG>
+__global__ __launch_bounds__(kThreads) void crop_fwd_flat_kernel(
+    LevelSet ls, const float *__restrict__ boxes, const int *__restrict__ box_ind,
+    const int *__restrict__ level, int num_boxes, int batch, int depth, float extrap, int groups_per_xcd,
+    float *__restrict__ crops, int *__restrict__ status)
+{
+    constexpr int bins = CH * CW;
+    const int xcd = blockIdx.x & 7;
+    const long seq = (long)(blockIdx.x >> 3) * kThreads + threadIdx.x;      // index within this XCD's items
+    const long per_group = (long)num_boxes * bins;
+    const int gi = (int)(seq / per_group);
+    if (gi >= groups_per_xcd) return;
+    const long rem = seq - (long)gi * per_group;
+    const int box = (int)(rem / bins);
+    const int bin = (int)(rem - (long)box * bins);
+    const int g = gi * 8 + xcd;
+    const int y = bin / CW, x = bin - y * CW;
+    float *__restrict__ out = crops + ((size_t)box * depth + (size_t)g * CG) * bins + bin;
+
+    const int lvl = level ? (level[box] - 2) : 0;
+    const int img = box_ind[box];
+    // per-lane level record (lanes of a wavefront may sit on different RoIs): a select chain over the (few) levels
+    const float *__restrict__ base = nullptr;
+    int H = 1, W = 1;
+#pragma unroll
+    for (int l = 0; l < kMaxLevels; ++l)
+        if (l < ls.n && l == lvl) {
+            base = ls.img[l];
+            H = ls.H[l];
+            W = ls.W[l];
+        }
+    if (base == nullptr || img < 0 || img >= batch) {
+#pragma unroll
+        for (int k = 0; k < CG; ++k) out[(size_t)k * bins] = 0.0f;
+        if (status && bin == 0 && g == 0) atomicOr(status, 1);
+        return;
+    }
+    const float *b = boxes + 4 * (size_t)box;          // scalar-width loads: no alignment demand on callers
+    const Tap ty = make_tap(b[0], b[2], H, CH, y);
+    const Tap tx = make_tap(b[1], b[3], W, CW, x);
+    if (!(ty.valid & tx.valid)) {
+#pragma unroll
+        for (int k = 0; k < CG; ++k) out[(size_t)k * bins] = extrap;
+        return;
+    }
+    const size_t plane = (size_t)H * W;
+    const float *__restrict__ p0 = base + ((size_t)img * depth + (size_t)g * CG) * plane;
+    if (W >= 2) {
+        // left / right taps are adjacent floats: ONE (4-byte aligned) 8-byte load per row at column min(x0, W - 2)
+        const int xb = min(tx.i0, W - 2);
+        const bool sl = tx.i0 != xb, sr = tx.i1 != xb;
+        const float *__restrict__ pt = p0 + (size_t)ty.i0 * W + xb;
+        const float *__restrict__ pb = p0 + (size_t)ty.i1 * W + xb;
+        pair_f32 vt[CG], vb[CG];
+#pragma unroll
+        for (int k = 0; k < CG; ++k) {
+            vt[k] = *reinterpret_cast<const pair_f32_a4 *>(pt + (size_t)k * plane);
+            vb[k] = *reinterpret_cast<const pair_f32_a4 *>(pb + (size_t)k * plane);
+        }
+#pragma unroll
+        for (int k = 0; k < CG; ++k) {
+            const float tl = sl ? vt[k].y : vt[k].x;
+            const float tr = sr ? vt[k].y : vt[k].x;
+            const float bl = sl ? vb[k].y : vb[k].x;
+            const float br = sr ? vb[k].y : vb[k].x;
+            const float dt = tr - tl;
+            const float top = tl + dt * tx.frac;
+            const float db = br - bl;
+            const float bot = bl + db * tx.frac;
+            const float dv = bot - top;
+            out[(size_t)k * bins] = top + dv * ty.frac;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < CG; ++k) {
+            const float *__restrict__ p = p0 + (size_t)k * plane;
+            const float tl = p[(size_t)ty.i0 * W + tx.i0], tr = p[(size_t)ty.i0 * W + tx.i1];
+            const float bl = p[(size_t)ty.i1 * W + tx.i0], br = p[(size_t)ty.i1 * W + tx.i1];
+            const float dt = tr - tl;
+            const float top = tl + dt * tx.frac;
+            const float db = br - bl;
+            const float bot = bl + db * tx.frac;
+            const float dv = bot - top;
+            out[(size_t)k * bins] = top + dv * ty.frac;
+        }
+    }
+}
+
 template <int CH, int CW>
 __global__ __launch_bounds__(kThreads) void crop_bwd_kernel(
     LevelSetMut ls, const float *__restrict__ grads, const float *__restrict__ boxes,
@@ -761,6 +859,18 @@ int forward_impl(const LevelSet &ls, const float *boxes, const int32_t *box_ind,
                  float extrap, float *crops, int32_t *status, hipStream_t st)
 {
     if (num_boxes == 0) return FI_OK;
+    constexpr int kFlatCG = 8;
+    if (crop_h == 7 && crop_w == 7 && depth % (8 * kFlatCG) == 0 && !getenv("FI_CROP_NO_FLAT")) {
+        // 7 x 7: table-free kernel, 8 channels per thread (-9 % against the table kernel at the north-star shape)
+        const int groups_per_xcd = depth / (8 * kFlatCG);
+        const long per_xcd = ((long)num_boxes * groups_per_xcd * 49 + kThreads - 1) / kThreads;
+        FI_REQUIRE(per_xcd * 8 < 2147483647L, "grid too large");
+        fi::ProfScope prof(FI_K_CROP_FWD_7X7, st);
+        hipLaunchKernelGGL((crop_fwd_flat_kernel<7, 7, kFlatCG>), dim3((unsigned)(per_xcd * 8)), dim3(kThreads), 0, st, ls,
+                           boxes, box_ind, level, num_boxes, batch, depth, extrap, groups_per_xcd, crops, status);
+        FI_HIP_CHECK(hipGetLastError());
+        return FI_OK;
+    }
     int cpb, chunks;
     pick_fwd_chunks(depth, &cpb, &chunks);
     const long nblk = (long)num_boxes * fi::ceil_div(chunks, 8) * 8;

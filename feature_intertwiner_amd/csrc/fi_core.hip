@@ -136,7 +136,7 @@ int fi_prof_get(int kernel_id, int *launches, float *total_ms)
 const char *fi_prof_kernel_name(int kernel_id)
 {
     static const char *names[FI_K_COUNT] = {
-        "crop_fwd_kernel<7, 7>",   "crop_fwd_kernel<14, 14>", "crop_fwd_kernel<28, 28>",
+        "crop_fwd_flat_kernel<7, 7, 8>", "crop_fwd_kernel<14, 14>", "crop_fwd_kernel<28, 28>",   /* slot 0: depth % 64 != 0 runs crop_fwd_kernel<7, 7> */
         "crop_fwd_kernel<0, 0>",   "crop_bwd_kernel<7, 7>",   "crop_bwd_kernel<14, 14>",
         "crop_bwd_kernel<28, 28>", "crop_bwd_kernel<0, 0>",   "roi_pool_fwd_kernel",
         "roi_pool_bwd_kernel",     "nms_mask_kernel",         "nms_scan_kernel",
@@ -150,7 +150,8 @@ const char *fi_prof_kernel_name(int kernel_id)
         "crop_fwd_cl_kernel<7, 7>", "crop_fwd_cl_kernel<14, 14>", "crop_fwd_cl_kernel<0, 0>",
         "crop_bwd_cl_kernel<7, 7>", "crop_bwd_cl_kernel<14, 14>", "crop_bwd_cl_kernel<0, 0>",
         "conv_bf16_fwd_kernel", "conv_bf16_wgrad_kernel",
-        "conv3x3_patch_kernel<false>", "conv3x3_patch_kernel<true>", "conv1x1_reg_kernel"};
+        "conv3x3_patch_kernel<false>", "conv3x3_patch_kernel<true>", "conv1x1_reg_kernel",
+        "proposal_select_kernel", "proposal_gather_kernel", "stride2_interleave_kernel", "gemm_slab_reduce_kernel"};
     if (kernel_id < 0 || kernel_id >= FI_K_COUNT) return "?";
     return names[kernel_id];
 }

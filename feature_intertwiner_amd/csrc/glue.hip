@@ -73,6 +73,7 @@ int fi_stride2_interleave(const float *c00, const float *c01, const float *c10, 
     const long work = vec ? planes * height * (width / 4) : planes * height * width;
     const long blocks = (work + 255) / 256;
     const unsigned grid = (unsigned)(blocks < 65536 ? (blocks < 1 ? 1 : blocks) : 65536);
+    fi::ProfScope prof(FI_K_STRIDE2_INTERLEAVE, (hipStream_t)stream);
     if (vec)
         hipLaunchKernelGGL(stride2_interleave_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, c00, c01,
                            c10, c11, add, dx, planes, height, width);

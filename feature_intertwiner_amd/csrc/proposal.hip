@@ -264,6 +264,7 @@ int fi_proposal_candidates(const float *probs, int prob_stride, int prob_offset,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
+    fi::ProfScope prof(FI_K_PROPOSAL_SELECT, (hipStream_t)stream);
     hipLaunchKernelGGL(proposal_select_kernel, dim3(batch), dim3(kSelThreads), lds, (hipStream_t)stream, a);
     FI_HIP_CHECK(hipGetLastError());
     return FI_OK;
@@ -278,6 +279,7 @@ int fi_proposal_gather(const float *dets, int pre_nms, int det_stride, const int
     FI_REQUIRE(batch == 0 || proposal_count == 0 || (dets && keep && num && proposals), "null pointer");
     FI_REQUIRE((uintptr_t)proposals % 16 == 0, "proposals must be 16-byte aligned");
     if (batch == 0 || proposal_count == 0) return FI_OK;
+    fi::ProfScope prof(FI_K_PROPOSAL_GATHER, (hipStream_t)stream);
     hipLaunchKernelGGL(proposal_gather_kernel, dim3((proposal_count + 255) / 256, batch), dim3(256), 0,
                        (hipStream_t)stream, dets, pre_nms, det_stride, (const long long *)keep, keep_stride, num,
                        proposal_count, norm_h, norm_w, proposals);

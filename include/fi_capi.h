@@ -433,7 +433,11 @@ enum {
     FI_K_CONV3X3_PATCH = 39,         /* 3x3/s1/p1 forward + data gradient, input patch in LDS: 2-D tiles */
     FI_K_CONV3X3_PATCH_FLAT = 40,    /* ... flat 128-pixel tiles (14 x 14 RoI maps) */
     FI_K_CONV1X1_REG = 41,           /* 1x1/s1 forward + data gradient, weights in registers */
-    FI_K_COUNT = 42
+    FI_K_PROPOSAL_SELECT = 42,       /* fused pre-NMS stage of the proposal layer */
+    FI_K_PROPOSAL_GATHER = 43,
+    FI_K_STRIDE2_INTERLEAVE = 44,
+    FI_K_GEMM_REDUCE = 45,           /* ordered reduction of fi_gemm_nt's split-K slabs (+ bias / ReLU) */
+    FI_K_COUNT = 46
 };
 /* ------------------------------------------------------------------------
  * Optimiser step of the training iteration: torch.nn.utils.clip_grad_norm_(params, max_norm) followed by

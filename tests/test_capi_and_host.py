@@ -39,7 +39,7 @@ def test_ctypes_binding_covers_the_header_and_loads():
     assert L.fi_version().startswith(b"fi_hip")
     assert L.fi_nms_workspace_bytes(4, 6000) == 4 * 6000 * 94 * 8
     assert L.fi_nms_workspace_bytes(1, 64) == 64 * 8
-    assert L.fi_prof_kernel_name(0) == b"crop_fwd_kernel<7, 7>"
+    assert L.fi_prof_kernel_name(0) == b"crop_fwd_flat_kernel<7, 7, 8>" and L.fi_prof_kernel_name(45) == b"gemm_slab_reduce_kernel"
 
 
 def test_argument_validation_without_a_gpu():
