@@ -77,6 +77,7 @@ SIGNATURES = {
                                        ctypes.POINTER(c_float), c_float, c_float, c_void_p, c_void_p]),
     "fi_proposal_gather": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_float, c_float,
                                    c_void_p, c_void_p]),
+    "fi_bn_fold_batch": (c_int, [c_void_p, c_int, c_int, c_void_p]),
     "fi_stride2_interleave": (c_int, [c_void_p] * 6 + [ctypes.c_long, c_int, c_int, c_void_p]),
     "fi_sgd_chunks": (ctypes.c_long, [ctypes.c_long]),
     "fi_sgd_clip_step": (c_int, [c_void_p, c_int, ctypes.c_long, c_float, c_void_p, c_void_p, c_void_p]),

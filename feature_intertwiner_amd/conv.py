@@ -745,26 +745,49 @@ def _cached_fold(conv, bn):
     return None
 
 
+_FOLD_TABLE = {"key": None}      # descriptor table of fi_bn_fold_batch for the current set of (conv, bn) pairs
+
+
 @torch.no_grad()
 def refresh_bn_folds():
     """Recompute scale = gamma/sqrt(var+eps), shift = beta + (conv_bias - mean)*scale for every
-    eval-mode (conv, bn) pair seen so far.  Call once per step before the forward pass."""
-    pairs = [(c, b) for b, c in _FOLD_PAIRS.items()
-             if not b.training and b.weight.is_cuda and _cached_fold(c, b) is None]
+    eval-mode (conv, bn) pair seen so far whose parameters changed.  Call once per step before the forward pass.
+    ONE launch (fi_bn_fold_batch) over a descriptor table that is rebuilt only when the set of pairs or an address
+    changes; the outputs are persistent per BatchNorm."""
+    pairs, keys = [], []
+    for b, c in _FOLD_PAIRS.items():
+        if b.training or not b.weight.is_cuda:
+            continue
+        fk = _fold_key(c, b)
+        cur = getattr(b, "_fi_fold", None)
+        if cur is None or cur[2] != fk:
+            pairs.append((c, b))
+            keys.append(fk)
     if not pairs:
         return
-    gam = [b.weight for _, b in pairs]
-    inv = torch._foreach_add([b.running_var for _, b in pairs], [float(b.eps) for _, b in pairs])
-    torch._foreach_rsqrt_(inv)
-    scale = torch._foreach_mul(gam, inv)
-    shift = torch._foreach_mul([b.running_mean for _, b in pairs], scale)
-    shift = torch._foreach_sub([b.bias for _, b in pairs], shift)
-    wb = [i for i, (c, _) in enumerate(pairs) if c.bias is not None]
-    if wb:
-        torch._foreach_add_([shift[i] for i in wb],
-                            torch._foreach_mul([pairs[i][0].bias for i in wb], [scale[i] for i in wb]))
-    for (c, b), sc, sh in zip(pairs, scale, shift):
-        b._fi_fold = (sc, sh, _fold_key(c, b))
+    import numpy as np
+    L = _lib.load()
+    dev = pairs[0][1].weight.device
+    key = tuple((id(b), fk[-1]) for (_, b), fk in zip(pairs, keys))
+    t = _FOLD_TABLE
+    if t["key"] != key:
+        desc = np.zeros(len(pairs), dtype=np.dtype([("gamma", "<u8"), ("beta", "<u8"), ("mean", "<u8"), ("var", "<u8"),
+                                                    ("cb", "<u8"), ("scale", "<u8"), ("shift", "<u8"), ("ch", "<i4"),
+                                                    ("eps", "<f4")]))
+        outs = []
+        for i, (c, b) in enumerate(pairs):
+            C = b.num_features
+            sc = torch.empty(C, device=dev, dtype=torch.float32)
+            sh = torch.empty(C, device=dev, dtype=torch.float32)
+            outs.append((sc, sh))
+            desc[i] = (b.weight.data_ptr(), b.bias.data_ptr(), b.running_mean.data_ptr(), b.running_var.data_ptr(),
+                       0 if c.bias is None else c.bias.data_ptr(), sc.data_ptr(), sh.data_ptr(), C, float(b.eps))
+        t.update(key=key, outs=outs, n=len(pairs), maxc=max(b.num_features for _, b in pairs),
+                 table=torch.from_numpy(desc.view(np.uint8).copy()).to(dev))
+    with torch.cuda.device(dev):
+        _lib.check(L.fi_bn_fold_batch(_lib.ptr(t["table"]), t["n"], t["maxc"], _lib.current_stream()), "fi_bn_fold_batch")
+    for (c, b), (sc, sh), fk in zip(pairs, t["outs"], keys):
+        b._fi_fold = (sc, sh, fk)
 
 
 def invalidate_bn_folds(module=None):

@@ -59,9 +59,42 @@ __global__ __launch_bounds__(256) void stride2_interleave_kernel(
     }
 }
 
+// scale[c] = gamma[c] * rsqrt(var[c] + eps), shift[c] = beta[c] - mean[c] * scale[c] (+ conv_bias[c] * scale[c]) for EVERY
+// (convolution, eval-mode BatchNorm) pair of the model in one launch: the per-step refresh of the folded BatchNorms
+// (conv.refresh_bn_folds) was five multi-tensor framework launches over ~100 tensors each -- 2.5 ms of HOST time at
+// the step boundary, where the device has nothing queued.  One workgroup per (pair, block of 256 channels).
+__global__ __launch_bounds__(256) void bn_fold_kernel(const FiBnFoldDesc *__restrict__ descs, int n)
+{
+    const int pair = blockIdx.x, c = blockIdx.y * 256 + threadIdx.x;
+    if (pair >= n) return;
+    const FiBnFoldDesc d = descs[pair];
+    if (c >= d.channels) return;
+    const float *gamma = static_cast<const float *>(d.gamma), *beta = static_cast<const float *>(d.beta);
+    const float *mean = static_cast<const float *>(d.mean), *var = static_cast<const float *>(d.var);
+    const float *cb = static_cast<const float *>(d.conv_bias);
+    const float inv = rsqrtf(var[c] + d.eps);
+    const float sc = gamma[c] * inv;
+    float sh = beta[c] - mean[c] * sc;
+    if (cb) sh = sh + cb[c] * sc;
+    static_cast<float *>(d.scale)[c] = sc;
+    static_cast<float *>(d.shift)[c] = sh;
+}
+
 }  // namespace
 
 extern "C" {
+
+int fi_bn_fold_batch(const FiBnFoldDesc *descs_dev, int n, int max_channels, fi_stream_t stream)
+{
+    FI_REQUIRE(n >= 0 && max_channels >= 0, "bad sizes");
+    if (n == 0 || max_channels == 0) return FI_OK;
+    FI_REQUIRE(descs_dev != nullptr, "null descriptor table");
+    hipLaunchKernelGGL(bn_fold_kernel, dim3((unsigned)n, (unsigned)((max_channels + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, descs_dev, n);
+    FI_HIP_CHECK(hipGetLastError());
+    return FI_OK;
+}
+
 
 int fi_stride2_interleave(const float *c00, const float *c01, const float *c10, const float *c11,
                           const float *add, float *dx, long planes, int height, int width, fi_stream_t stream)

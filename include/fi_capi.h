@@ -335,6 +335,17 @@ int fi_proposal_gather(const float *dets, int pre_nms, int det_stride, const int
                        const int32_t *num, int batch, int proposal_count, float norm_h, float norm_w,
                        float *proposals, fi_stream_t stream);
 
+/* Eval-mode BatchNorm folded into the preceding convolution's epilogue (the reference always evaluates BN with running
+ * statistics, lib/model.py:265-267): scale = gamma * rsqrt(var + eps), shift = beta - mean * scale (+ conv_bias * scale)
+ * for every (conv, bn) pair of the model in ONE launch; the table lives in device memory. */
+typedef struct {
+    const void *gamma, *beta, *mean, *var, *conv_bias;   /* conv_bias may be NULL */
+    void *scale, *shift;                                 /* outputs, [channels] each */
+    int channels;
+    float eps;
+} FiBnFoldDesc;
+int fi_bn_fold_batch(const FiBnFoldDesc *descs_dev, int n, int max_channels, fi_stream_t stream);
+
 /* Data gradient of a stride-2 convolution assembled from its residue classes in ONE pass (no counterpart in the
  * reference: cuDNN's strided backward-data, reached through lib/sub_module.py's stride-2 Conv2d layers).
  * dx[p][h][w] = c<h&1><w&1>[p][h>>1][w>>1] (+ add[p][h][w]); class (a, b) is [planes][ceil((H-a)/2)][ceil((W-b)/2)]

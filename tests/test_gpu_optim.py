@@ -136,3 +136,49 @@ def test_train_step_uses_the_fused_step():
     for (n, p), (_, q) in zip(models[0].named_parameters(), models[1].named_parameters()):
         worst = max(worst, float((p - q).detach().abs().max()) / (float(q.detach().abs().max()) + 1e-12))
     assert worst <= 1e-5, worst
+
+
+def test_static_table_path_with_persistent_gradients():
+    """Gradients that stay where they were (the gradient arena): the descriptor table is reused, and every change the
+    fast path has to notice -- a learning-rate change, a replaced momentum buffer, a gradient dropped, a gradient
+    re-allocated -- still produces torch's result."""
+    from feature_intertwiner_amd import optim
+    a, b = _params(4), _params(4)
+    oa, ob = _make(a), _make(b)
+    _set_grads(a, 1, 1.0)
+    _set_grads(b, 1, 1.0)
+    slots = [p.grad for p in a]
+    tables = []
+    for step in range(7):
+        g = torch.Generator(device="cpu").manual_seed(200 + step)
+        for i, (p, q) in enumerate(zip(a, b)):
+            t = torch.randn(p.shape, generator=g).to(DEV) * (3.0 if step % 2 else 0.01)
+            q.grad = t.contiguous(memory_format=torch.channels_last) if (p.dim() == 4 and not p.is_contiguous()) else t
+            if step == 4 and i == 2:
+                p.grad = None                                   # dropped this step
+                q.grad = None
+            elif step == 6 and i == 1:
+                p.grad = q.grad.clone()                         # re-allocated elsewhere
+            else:
+                slots[i].copy_(q.grad)
+                p.grad = slots[i].view_as(slots[i])             # a NEW tensor object over the same memory, like an arena view
+        if step == 2:
+            for o in (oa, ob):
+                o.param_groups[1]["lr"] = 0.004
+        if step == 3:
+            oa.state[a[5]]["momentum_buffer"] = oa.state[a[5]]["momentum_buffer"].clone()
+        versions = [p._version for p in a]
+        optim.clip_and_step(oa, 5.0)
+        tables.append(optim._CACHE[oa]["table"].data_ptr())
+        torch.nn.utils.clip_grad_norm_([q for q in b if q.grad is not None], 5.0)
+        ob.step()
+        for i, (p, q) in enumerate(zip(a, b)):
+            if q.grad is None:
+                continue
+            assert p._version > versions[i]
+            assert float((p - q).detach().abs().max()) <= 2e-6 * float(q.detach().abs().max()) + 1e-9, (step, i)
+            ba, bb = oa.state[p]["momentum_buffer"], ob.state[q]["momentum_buffer"]
+            assert float((ba - bb).abs().max()) <= 4e-6 * float(bb.abs().max() + q.grad.abs().max()) + 1e-12, (step, i)
+    # same table for steps 0-1; rebuilt at 2 (lr), 3 (buffer), 4 (gradient dropped), 5 (it is back); patched in place at 6 (moved)
+    assert tables[0] == tables[1] and tables[5] == tables[6]
+    torch.cuda.synchronize()
