@@ -77,6 +77,9 @@ SIGNATURES = {
                                        ctypes.POINTER(c_float), c_float, c_float, c_void_p, c_void_p]),
     "fi_proposal_gather": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_float, c_float,
                                    c_void_p, c_void_p]),
+    "fi_conv2d_forward_gated": (c_int, [c_void_p] * 7 + [c_int] * 16 + [c_void_p]),
+    "fi_relu_mask": (c_int, [c_void_p, c_void_p, c_void_p, ctypes.c_long, c_void_p]),
+    "fi_bn_fold_grad": (c_int, [c_void_p] * 6 + [ctypes.c_float] + [c_void_p] * 3 + [c_int] * 5 + [c_void_p]),
     "fi_bn_fold_batch": (c_int, [c_void_p, c_int, c_int, c_void_p]),
     "fi_stride2_interleave": (c_int, [c_void_p] * 6 + [ctypes.c_long, c_int, c_int, c_void_p]),
     "fi_sgd_chunks": (ctypes.c_long, [ctypes.c_long]),

@@ -82,7 +82,7 @@ def _dense(w):
 
 
 def _conv_fwd(x, w, b, stride, padding, relu=False, scale=None, residual=None, out_hw=None,
-              out_channels_last=False, w_tap_major=False, flip_taps=False, precision=None):
+              out_channels_last=False, w_tap_major=False, flip_taps=False, precision=None, gate=None):
     """w is [Cout, Cin, R, S].  When Cin % 16 == 0 the kernel's tap-major fast path is used: the
     weight is handed over channels-last ([Cout, R, S, Cin]; a copy of at most a few MB).
     out_channels_last: y is returned in torch.channels_last memory format ([N,OH,OW,Cout] in
@@ -116,6 +116,16 @@ def _conv_fwd(x, w, b, stride, padding, relu=False, scale=None, residual=None, o
     y = torch.empty((N, Cout, OH, OW), device=x.device, dtype=torch.float32,
                     memory_format=torch.channels_last if out_channels_last else torch.contiguous_format)
     bf16 = prec in _LOWP and layout >= 1 and Cin % 32 == 0          # "bf16" here and below: either 16-bit operand type
+    if gate is not None:
+        # y * (gate > 0) in the epilogue (fp32 kernels): the data gradient of a layer whose input is a ReLU output
+        assert not bf16 and not out_channels_last and gate.shape == y.shape and gate.is_contiguous()
+        with torch.cuda.device(x.device):
+            _lib.check(L.fi_conv2d_forward_gated(_lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(scale), _lib.ptr(residual),
+                                                 _lib.ptr(gate), _lib.ptr(y), N, Cin, H, W, Cout, R, S, stride[0], stride[1],
+                                                 padding[0], padding[1], 1 if relu else 0, layout,
+                                                 OH if out_hw is not None else 0, OW if out_hw is not None else 0, 0,
+                                                 _lib.current_stream()), "fi_conv2d_forward_gated")
+        return y
     fn = _lowp_fn(L, "conv2d_forward", prec) if bf16 else L.fi_conv2d_forward
     if bf16:
         _log_flops("bf16_fwd", Cout, R, S, 2 * N * Cout * OH * OW * Cin * R * S)
@@ -263,14 +273,29 @@ def _strided_dgrad(dz, w, in_hw, stride, padding, precision=None, add=None):
     return dx if add is None else dx + add
 
 
+def _relu_mask(dy, y, out=None):
+    """dy * (y > 0) (fi_relu_mask); out may be dy itself."""
+    out = torch.empty_like(dy) if out is None else out
+    with torch.cuda.device(dy.device):
+        _lib.check(_lib.load().fi_relu_mask(_lib.ptr(dy), _lib.ptr(y), _lib.ptr(out), dy.numel(), _lib.current_stream()),
+                   "fi_relu_mask")
+    return out
+
+
 def _conv_backward(ctx_needs, x, w, dz, stride, padding, want_db=False, add_to_dx=None, precision=None,
-                   give_compact=False, bias_ptr=0):
+                   give_compact=False, bias_ptr=0, gate=None, w_scale=None, db_into=None, after_wgrad=None):
     """dX and dW of z = conv(x, w) given dz (shared by the plain and the fused functions).
     want_db: also return sum(dz) over images and pixels (the bias gradient), accumulated by the
     weight-gradient kernel from the dY tiles it stages anyway.
     add_to_dx: a tensor shaped like x -- or a _Compact -- that is added to dX inside the data-gradient kernel's
     epilogue (the shortcut gradient of a bottleneck, instead of a separate add pass).
-    give_compact: a 1x1 / stride-2 layer may return dX as a _Compact (see there) instead of the full tensor."""
+    give_compact: a 1x1 / stride-2 layer may return dX as a _Compact (see there) instead of the full tensor.
+    gate: a tensor shaped like x; dX (with add_to_dx) is multiplied by (gate > 0) -- inside the data-gradient kernel's
+    epilogue where that kernel has one, by a separate pass otherwise.
+    w_scale [Cout]: the data gradient uses W * w_scale[co] (conv + eval-BatchNorm given the UNSCALED masked gradient:
+    _ConvBnActFn.backward); the weight gradient is the caller's to scale (after_wgrad).
+    db_into: where sum(dz) is accumulated (a zeroed [Cout] tensor) instead of the bias's arena slot.
+    after_wgrad(dw_flat, tap_major): called right after the weight-gradient launch, on the stream it ran on."""
     L = _lib.load()
     N, Cin, H, W = x.shape
     Cout, _, R, S = w.shape
@@ -286,19 +311,28 @@ def _conv_backward(ctx_needs, x, w, dz, stride, padding, want_db=False, add_to_d
         if isinstance(add_to_dx, _Compact) and not (stride == (2, 2) and R * S == 1 and padding == (0, 0) and
                                                     Cout % 16 == 0 and Cin % 16 == 0):
             add_to_dx = add_to_dx.expand()
+        scaled = w_scale is not None
+        weff = None            # W * w_scale, made on demand where no cached transposed copy exists
+
+        def w_eff():
+            return w * w_scale.view(-1, 1, 1, 1) if scaled else w
+        gate_in_kernel = gate is not None and precision not in _LOWP and gate.is_contiguous()
         if stride == (1, 1):
             if Cout % 16 == 0 and R * S <= 64:
                 # transposed weight in the kernel's tap-major layout [Cin, R, S, Cout]: re-laid-out for all
                 # layers by one launch per step (prepare_step); otherwise one copy here.  The tap flip is
                 # done by the kernel's weight indexing (weight_layout 2)
-                wt = _cached_wt(w)
+                wt = _cached_wt(w, scaled)
                 if wt is None:
-                    wt = w.permute(1, 2, 3, 0).contiguous()
+                    wt = w_eff().permute(1, 2, 3, 0).contiguous()
                 dx = _conv_fwd(dz, wt, None, (1, 1), (R - 1 - padding[0], S - 1 - padding[1]), w_tap_major=True,
-                               flip_taps=True, residual=add_to_dx, precision=precision)
+                               flip_taps=True, residual=add_to_dx, precision=precision,
+                               gate=gate if gate_in_kernel else None)
                 add_to_dx = None
+                if gate_in_kernel:
+                    gate = None
             else:
-                wt = w.flip(2, 3).transpose(0, 1).contiguous()          # [Cin, Cout, R, S]
+                wt = w_eff().flip(2, 3).transpose(0, 1).contiguous()          # [Cin, Cout, R, S]
                 dx = _conv_fwd(dz, wt, None, (1, 1), (R - 1 - padding[0], S - 1 - padding[1]), precision=precision)
             if add_to_dx is not None:
                 dx = dx + add_to_dx
@@ -306,9 +340,9 @@ def _conv_backward(ctx_needs, x, w, dz, stride, padding, want_db=False, add_to_d
             # 1x1 / stride 2 (the first block of C3..C5: conv1 and the projection shortcut): only the even input
             # positions receive a gradient -- ONE 1x1 correlation with the cached W^T on the half-size map,
             # a second compact gradient for the same input added in its epilogue, then one interleave pass
-            wt = _cached_wt(w)
+            wt = _cached_wt(w, scaled)
             if wt is None:
-                wt = w.permute(1, 2, 3, 0).contiguous()
+                wt = w_eff().permute(1, 2, 3, 0).contiguous()
             comp = add_to_dx.t if isinstance(add_to_dx, _Compact) else None
             c = _conv_fwd(dz, wt, None, (1, 1), (0, 0), w_tap_major=True, flip_taps=True, residual=comp,
                           precision=precision)
@@ -318,7 +352,11 @@ def _conv_backward(ctx_needs, x, w, dz, stride, padding, want_db=False, add_to_d
             else:
                 dx = _interleave2({(0, 0): c}, full_add, N, Cin, H, W)
         else:
-            dx = _strided_dgrad(dz, w, (H, W), stride, padding, precision, add=add_to_dx)
+            dx = _strided_dgrad(dz, w_eff(), (H, W), stride, padding, precision, add=add_to_dx)
+        if gate is not None:
+            if isinstance(dx, _Compact):
+                dx = dx.expand()
+            dx = _relu_mask(dx, gate.contiguous(), dx)
     if ctx_needs[1]:
         # tap-major dW ([Cout,R,S,Cin]): 128 channels of one tap per column tile, or -- same-size stride-1
         # layers with Cin == 64 (the C2 stage) -- 64 channels of two taps (mirrors wgrad_same_size())
@@ -337,13 +375,20 @@ def _conv_backward(ctx_needs, x, w, dz, stride, padding, want_db=False, add_to_d
         # the kernel clears both itself.
         db_slot = None
         if want_db and not bf16:
-            db_slot, _ = _arena_take(("db", bias_ptr), Cout) if bias_ptr else (None, False)
+            if db_into is not None:
+                db_slot = db_into
+            else:
+                db_slot, _ = _arena_take(("db", bias_ptr), Cout) if bias_ptr else (None, False)
         if want_db and not bf16 and db_slot is None:
             dw, first = None, False
         else:
             dw, first = _arena_take(("dw", w.data_ptr()), Cout * Cin * R * S)
             if dw is None:
                 db_slot = None
+            elif after_wgrad is not None and not first:
+                # a repeated use of the layer would add unscaled sums onto the scaled ones of the first use:
+                # _ConvBnActFn.backward routes repeated uses to the path that has no after_wgrad
+                raise _lib.FiError("after_wgrad on a layer applied more than once per step")
         flags = _lib.OUTPUTS_ZEROED if dw is not None else 0
         dw = dw.view(shape) if dw is not None else torch.empty(shape, device=x.device, dtype=torch.float32)
         hand_over = first or not flags
@@ -351,7 +396,10 @@ def _conv_backward(ctx_needs, x, w, dz, stride, padding, want_db=False, add_to_d
             db = dz.sum((0, 2, 3)) if bf16 else (db_slot if db_slot is not None else
                                                  torch.empty(Cout, device=x.device, dtype=torch.float32))
         side = None
-        if flags and dz_ready is not None and not bf16:
+        # second stream only if autograd will ADOPT dw as the parameter's gradient: a dw whose memory order differs
+        # from the parameter's is cloned by AccumulateGrad, on the main stream, while the kernel may still be running
+        adopt = R * S == 1 or bool(hwc) == (not w.is_contiguous())
+        if flags and dz_ready is not None and not bf16 and adopt:
             main = torch.cuda.current_stream(x.device)
             side = _wgrad_side_stream(x.device)
             side.wait_event(dz_ready)                      # dz (and x) were complete on the main stream there
@@ -369,6 +417,8 @@ def _conv_backward(ctx_needs, x, w, dz, stride, padding, want_db=False, add_to_d
                 _lib.check(L.fi_conv2d_weight_grad(_lib.ptr(x), _lib.ptr(dz), _lib.ptr(dw), N, Cin, H, W, Cout,
                                                    R, S, stride[0], stride[1], padding[0], padding[1], hwc,
                                                    _lib.ptr(db), flags, _lib.current_stream()), "fi_conv2d_weight_grad")
+            if after_wgrad is not None:
+                after_wgrad(dw, db, bool(hwc and R * S > 1))
         if side is not None:
             _queue_wgrad_join(main, side)
         if hwc and R * S > 1:
@@ -442,9 +492,12 @@ def _cached_bf16(w, dtype=torch.bfloat16):
     return wb
 
 
-def _cached_wt(w):
+def _cached_wt(w, scaled=False):
+    """This step's W^T [Cin][R][S][Cout] (prepare_step); scaled: the copy with the layer's eval-BatchNorm scale folded
+    in (W^T[...][co] * scale[co]) -- a layer has one or the other."""
     e = _WT.get(w.data_ptr())
-    if e is not None and e[1] == w._version and e[0].shape == (w.shape[1], w.shape[2], w.shape[3], w.shape[0]):
+    if e is not None and e[1] == w._version and e[2] == bool(scaled) and \
+            e[0].shape == (w.shape[1], w.shape[2], w.shape[3], w.shape[0]):
         return e[0]
     return None
 
@@ -464,6 +517,11 @@ def _arena_take(key, numel):
     first = key not in _ARENA["used"]
     _ARENA["used"].add(key)
     return _ARENA["buf"][slot[0]:slot[0] + numel], first
+
+
+import numpy as _np
+_TR_DESC = _np.dtype([("src", "<u8"), ("dst", "<u8"), ("rows", "<i4"), ("cols", "<i4"), ("taps", "<i4"), ("pad", "<i4"),
+                      ("tile_base", "<i8"), ("row_scale", "<u8")])      # FiTransposeDesc
 
 
 def invalidate_step_state():
@@ -511,14 +569,13 @@ def _prepare_step(model, grad_on):
               m.weight.shape[0] % 16 == 0 and
               m.weight.shape[1] % 16 == 0 and m.weight.shape[2] * m.weight.shape[3] <= 64 and m.weight.requires_grad]
         import numpy as np
-        desc = np.zeros(len(tr), dtype=np.dtype([("src", "<u8"), ("dst", "<u8"), ("rows", "<i4"), ("cols", "<i4"),
-                                                 ("taps", "<i4"), ("pad", "<i4"), ("tile_base", "<i8")]))
+        desc = np.zeros(len(tr), dtype=_TR_DESC)
         wts, base = [], 0
         for i, m in enumerate(tr):
             co, ci, r, s_ = m.weight.shape
             wt = torch.empty((ci, r, s_, co), device=dev, dtype=torch.float32)
             wts.append(wt)
-            desc[i] = (m.weight.data_ptr(), wt.data_ptr(), co, ci, r * s_, 0, base)
+            desc[i] = (m.weight.data_ptr(), wt.data_ptr(), co, ci, r * s_, 0, base, 0)
             base += r * s_ * ((co + 31) // 32) * ((ci + 31) // 32)
         table = torch.from_numpy(desc.view(np.uint8).copy()).to(dev) if len(tr) else None
         # gradient slots: the model-wide arena layout (grad_arena.py) -- every trainable parameter has one, in
@@ -534,17 +591,35 @@ def _prepare_step(model, grad_on):
             if bn in layout.bn_slot:
                 slots[("bn", bn.weight.data_ptr())] = (layout.bn_slot[bn], 3 * bn.num_features, weakref.ref(bn.weight))
         plan = {"ptrs": tuple(p.data_ptr() for p in model.parameters()), "tr": tr, "wts": wts, "table": table,
-                "tiles": base, "slots": slots, "layout": layout, "versions": None, "convs": convs}
+                "desc": desc, "tiles": base, "slots": slots, "layout": layout, "versions": None, "convs": convs,
+                "scales": None}
         _PLAN[model] = plan
-    versions = tuple(m.weight._version for m in plan["tr"])
+    # fp32 training: W^T of a layer that is followed by an eval-mode BatchNorm carries the BatchNorm's scale
+    # (_ConvBnActFn.backward feeds the data-gradient kernel the unscaled masked gradient); the 16-bit kernels keep the
+    # plain W^T.  The pairs are known after the first forward pass (conv_bn_act registers them).
+    scales = [None] * len(plan["tr"])
+    if grad_on and _PRECISION not in _LOWP and _FOLD_PAIRS and plan["table"] is not None:
+        by_conv = {c: b for b, c in _FOLD_PAIRS.items()}
+        for i, m in enumerate(plan["tr"]):
+            b = by_conv.get(m)
+            if b is not None and not b.training and getattr(b, "_fi_fold", None) is not None:
+                scales[i] = b
+    sig = tuple(0 if b is None else b._fi_fold[0].data_ptr() for b in scales)
+    if plan["table"] is not None and plan["scales"] != sig:
+        desc = plan["desc"]
+        desc["row_scale"] = sig
+        plan["table"] = torch.from_numpy(desc.view(_np.uint8).copy()).to(dev)
+        plan["scales"] = sig
+        plan["versions"] = None
+    versions = tuple(m.weight._version for m in plan["tr"]) + tuple(b._fi_fold[2] for b in scales if b is not None)
     if plan["table"] is not None and (plan["versions"] != versions or not all(
-            _cached_wt(m.weight) is not None for m in plan["tr"][:1])):
+            _cached_wt(m.weight, sig[0] != 0) is not None for m in plan["tr"][:1])):
         L = _lib.load()
         with torch.cuda.device(dev):
             _lib.check(L.fi_weight_transpose_batch(_lib.ptr(plan["table"]), len(plan["tr"]), plan["tiles"],
                                                    _lib.current_stream()), "fi_weight_transpose_batch")
-        for m, wt in zip(plan["tr"], plan["wts"]):
-            _WT[m.weight.data_ptr()] = (wt, m.weight._version)
+        for m, wt, sp in zip(plan["tr"], plan["wts"], sig):
+            _WT[m.weight.data_ptr()] = (wt, m.weight._version, sp != 0)
         plan["versions"] = versions
         _WB.clear()          # the W^T tensors were rewritten in place (no version bump): drop their bf16 copies
     if _PRECISION in _LOWP:
@@ -583,6 +658,9 @@ def _prepare_step(model, grad_on):
         _ARENA["buf"] = None
 
 
+_UNSCALED_BACKWARD = not _os.environ.get("FI_BN_BWD_OLD")      # A/B switch (scripts/ab_env.sh)
+
+
 class GradBox(object):
     """Hands a gradient from one autograd node to another: a bottleneck's last convolution leaves the
     gradient of its identity shortcut here -- or its projection shortcut leaves its data gradient here -- and the
@@ -595,13 +673,33 @@ class GradBox(object):
         self.value = None
 
 
+class Gate(object):
+    """Travels with the output y of a fused conv + BN + ReLU (attribute `_fi_gate` of the tensor).  A consumer that is
+    told it is y's ONLY reader (conv_bn_act(gate_dx=True)) claims it: its data gradient -- together with whatever it
+    adds through a GradBox -- leaves its kernel multiplied by (y > 0), and the producer's backward skips its own
+    masking pass over (dy, y)."""
+    __slots__ = ("claimed",)
+
+    def __init__(self):
+        self.claimed = False
+
+
 class _ConvBnActFn(torch.autograd.Function):
-    """y = act(BN_eval(conv(x)) [+ residual]) in ONE kernel launch; backward = one fused
-    elementwise/reduction pass (fi_bn_act_backward) + the conv dgrad/wgrad kernels."""
+    """y = act(BN_eval(conv(x)) [+ residual]) in ONE kernel launch.
+
+    Backward, fp32 kernels (round 3): with g = dy * (y > 0) the UNSCALED masked gradient,
+        dX  = conv_T(g, W * scale[co])            W^T with the scale folded in: one transpose launch per step
+        dW' = g (x) patches(x), s = sum_p g       the weight-gradient kernel and its bias sums
+        dW = scale * dW', d beta = s, d gamma = inv_std * (<W, dW'> + (bias - mean) * s), d bias = scale * s
+                                                  (fi_bn_fold_grad: sum_p g * conv(x, W) = <W, dW'>)
+    so no pass over the activations computes the BatchNorm sums, the shortcut gradient of a bottleneck IS g, and g
+    itself arrives ready-made when the consumer of y claimed its Gate (otherwise: one fi_relu_mask pass).
+    16-bit kernels, channels-last outputs and layers applied more than once per step keep the older form: one fused
+    elementwise/reduction pass (fi_bn_act_backward) producing dz = g * scale and the sums, then dgrad / wgrad on dz."""
 
     @staticmethod
     def forward(ctx, x, w, b, gamma, beta, mean, var, eps, residual, relu, stride, padding, out_cl=False,
-                fold=None, res_grad_to=None, dx_add_from=None, dx_give_to=None):
+                fold=None, res_grad_to=None, dx_add_from=None, dx_give_to=None, dx_gate=False, out_gate=None):
         _lib.require_cuda(x, w)
         x = x.contiguous().float()
         w = _dense(w.float())
@@ -619,13 +717,70 @@ class _ConvBnActFn(torch.autograd.Function):
         ctx.out_cl = bool(out_cl)
         ctx.precision = _PRECISION
         ctx.res_grad_to, ctx.dx_add_from, ctx.dx_give_to = res_grad_to, dx_add_from, dx_give_to
-        ctx.save_for_backward(x, w, y, scale, gamma, beta, res)
+        ctx.dx_gate, ctx.out_gate = bool(dx_gate), out_gate
+        ctx.save_for_backward(x, w, y, scale, gamma, beta, res, b)
         ctx.conf = (tuple(stride), tuple(padding), b is not None, bool(relu), residual is not None, eps, mean, var)
         return y
 
     @staticmethod
+    def _backward_unscaled(ctx, dy):
+        """The fp32 form of the class docstring; None if this use of the layer has to take the older form."""
+        x, w, y, scale, gamma, beta, res, b = ctx.saved_tensors
+        stride, padding, has_bias, relu, has_res, eps, mean, var = ctx.conf
+        N, C, OH, OW = y.shape
+        if not ctx.needs_input_grad[1]:
+            return None                          # frozen weights: no weight gradient to take the sums from
+        sums, first = _arena_take(("bn", gamma.data_ptr()), 3 * C)
+        if sums is not None and not first:
+            return None                          # applied more than once this step: sums and dW accumulate
+        L = _lib.load()
+        dy = dy.contiguous().float()
+        if sums is None:
+            sums = torch.zeros(3 * C, device=y.device, dtype=torch.float32)
+        premasked = ctx.out_gate is not None and ctx.out_gate.claimed
+        g = _relu_mask(dy, y) if (relu and not premasked) else dy
+        g_res = g if (has_res and ctx.needs_input_grad[8]) else None
+        if g_res is not None and ctx.res_grad_to is not None:
+            ctx.res_grad_to.value = g_res           # picked up by the block's first convolution
+            g_res = None
+        add = None
+        if ctx.dx_add_from is not None:
+            add, ctx.dx_add_from.value = ctx.dx_add_from.value, None
+        want_gamma, want_beta = ctx.needs_input_grad[3], ctx.needs_input_grad[4]
+        want_db = has_bias and ctx.needs_input_grad[2]
+        out = {}
+
+        def finish(dw_flat, s, tap_major):
+            Cin, R, S = w.shape[1], w.shape[2], w.shape[3]
+            w_tap_major = R * S > 1 and not w.is_contiguous()       # _dense(): contiguous or channels-last
+            out["s"] = s
+            here = torch.cuda.current_stream(sums.device)                  # the weight gradient's stream
+            sums.record_stream(here)
+            scale.record_stream(here)       # folded in-layer (first step, no prepare_step): a temporary of the forward
+            _lib.check(L.fi_bn_fold_grad(_lib.ptr(dw_flat), _lib.ptr(w), _lib.ptr(s), _lib.ptr(scale), _lib.ptr(mean),
+                                         _lib.ptr(var), float(eps), _lib.ptr(b) if has_bias else None,
+                                         _lib.ptr(sums[C:2 * C]) if want_gamma else None,
+                                         _lib.ptr(sums[2 * C:]) if want_db else None, C, Cin, R * S,
+                                         1 if tap_major else 0, 1 if w_tap_major else 0, _lib.current_stream()),
+                       "fi_bn_fold_grad")
+        dx, dw, _ = _conv_backward(ctx.needs_input_grad, x, w, g, stride, padding, want_db=True, add_to_dx=add,
+                                   precision="fp32", give_compact=ctx.dx_give_to is not None,
+                                   gate=x if ctx.dx_gate else None, w_scale=scale, db_into=sums[:C],
+                                   after_wgrad=finish)
+        dbeta = out["s"] if want_beta else None
+        if ctx.dx_give_to is not None and dx is not None:
+            ctx.dx_give_to.value = dx               # picked up (and added) by the backward of the block's first conv
+            dx = None
+        return (dx, dw, sums[2 * C:] if want_db else None, sums[C:2 * C] if want_gamma else None,
+                dbeta if want_beta else None, None, None, None, g_res) + (None,) * 10
+
+    @staticmethod
     def backward(ctx, dy):
-        x, w, y, scale, gamma, beta, res = ctx.saved_tensors
+        if ctx.precision not in _LOWP and not ctx.out_cl and _UNSCALED_BACKWARD:
+            r = _ConvBnActFn._backward_unscaled(ctx, dy)
+            if r is not None:
+                return r
+        x, w, y, scale, gamma, beta, res, _b = ctx.saved_tensors
         stride, padding, has_bias, relu, has_res, eps, mean, var = ctx.conf
         L = _lib.load()
         # channels-last output: the gradient comes back channels-last from the RoIAlign backward and is
@@ -657,14 +812,14 @@ class _ConvBnActFn(torch.autograd.Function):
         if ctx.dx_add_from is not None:
             add, ctx.dx_add_from.value = ctx.dx_add_from.value, None
         dx, dw = _conv_backward(ctx.needs_input_grad, x, w, dz, stride, padding, add_to_dx=add, precision=ctx.precision,
-                                give_compact=ctx.dx_give_to is not None)
+                                give_compact=ctx.dx_give_to is not None, gate=x if ctx.dx_gate else None)
         if ctx.dx_give_to is not None and dx is not None:
             ctx.dx_give_to.value = dx               # picked up (and added) by the backward of the block's first conv
             dx = None
         dbeta = dshift if ctx.needs_input_grad[4] else None
         if not first:                 # a repeated use of the layer: accumulated into the slices autograd already holds
             db = dgamma = dbeta = None
-        return dx, dw, db, dgamma, dbeta, None, None, None, g_res, None, None, None, None, None, None, None, None
+        return (dx, dw, db, dgamma, dbeta, None, None, None, g_res) + (None,) * 10
 
 
 class _ConvBiasActFn(torch.autograd.Function):
@@ -745,7 +900,7 @@ def _cached_fold(conv, bn):
     return None
 
 
-_FOLD_TABLE = {"key": None}      # descriptor table of fi_bn_fold_batch for the current set of (conv, bn) pairs
+_FOLD_TABLE = {"key": None, "refs": []}      # descriptor table of fi_bn_fold_batch for the current set of (conv, bn) pairs
 
 
 @torch.no_grad()
@@ -770,19 +925,27 @@ def refresh_bn_folds():
     dev = pairs[0][1].weight.device
     key = tuple((id(b), fk[-1]) for (_, b), fk in zip(pairs, keys))
     t = _FOLD_TABLE
-    if t["key"] != key:
+    # ids and addresses are reused once a model is freed: the table also remembers (weakly) WHICH modules it is for
+    same = t["key"] == key and all(r() is b for r, (_, b) in zip(t["refs"], pairs))
+    if not same:
         desc = np.zeros(len(pairs), dtype=np.dtype([("gamma", "<u8"), ("beta", "<u8"), ("mean", "<u8"), ("var", "<u8"),
                                                     ("cb", "<u8"), ("scale", "<u8"), ("shift", "<u8"), ("ch", "<i4"),
                                                     ("eps", "<f4")]))
         outs = []
         for i, (c, b) in enumerate(pairs):
             C = b.num_features
-            sc = torch.empty(C, device=dev, dtype=torch.float32)
-            sh = torch.empty(C, device=dev, dtype=torch.float32)
+            # one (scale, shift) pair per BatchNorm for its lifetime: this step's W^T table (prepare_step) holds
+            # the address of the scale
+            keep = getattr(b, "_fi_fold_out", None)
+            if keep is None or keep[0].device != dev or keep[0].numel() != C:
+                keep = b._fi_fold_out = (torch.empty(C, device=dev, dtype=torch.float32),
+                                         torch.empty(C, device=dev, dtype=torch.float32))
+            sc, sh = keep
             outs.append((sc, sh))
             desc[i] = (b.weight.data_ptr(), b.bias.data_ptr(), b.running_mean.data_ptr(), b.running_var.data_ptr(),
                        0 if c.bias is None else c.bias.data_ptr(), sc.data_ptr(), sh.data_ptr(), C, float(b.eps))
         t.update(key=key, outs=outs, n=len(pairs), maxc=max(b.num_features for _, b in pairs),
+                 refs=[weakref.ref(b) for _, b in pairs],
                  table=torch.from_numpy(desc.view(np.uint8).copy()).to(dev))
     with torch.cuda.device(dev):
         _lib.check(L.fi_bn_fold_batch(_lib.ptr(t["table"]), t["n"], t["maxc"], _lib.current_stream()), "fi_bn_fold_batch")
@@ -807,11 +970,14 @@ def _invalidate_bn_folds(module=None):
 
 
 def conv_bn_act(x, conv, bn, relu=True, residual=None, channels_last_out=False, res_grad_to=None,
-                dx_add_from=None, dx_give_to=None):
+                dx_add_from=None, dx_give_to=None, gate_dx=False):
     """act(bn(conv(x)) [+ residual]) for an eval-mode BatchNorm2d (the reference always evaluates
     BN with running statistics, lib/model.py:265-267).  Falls back to separate ops for a BN in
     training mode or a full-window (GEMM) convolution.  channels_last_out: return the result in
-    torch.channels_last memory format (for maps that only the channels-last RoIAlign reads)."""
+    torch.channels_last memory format (for maps that only the channels-last RoIAlign reads).
+    gate_dx: the caller's promise that NOTHING else reads x (or that every other gradient into x reaches this layer
+    through dx_add_from).  If x is the output of a fused conv + BN + ReLU, this layer's data-gradient kernel then
+    applies that ReLU's mask in its epilogue and the producer skips its masking pass (see Gate)."""
     R, S = conv.weight.shape[2], conv.weight.shape[3]
     gemm_path = ((x.shape[2], x.shape[3]) == (R, S) and tuple(conv.padding) == (0, 0)) or x.shape[2] * x.shape[3] == 1
     if bn.training or gemm_path or not bn.track_running_stats:
@@ -829,9 +995,16 @@ def conv_bn_act(x, conv, bn, relu=True, residual=None, channels_last_out=False, 
         return y.contiguous(memory_format=torch.channels_last) if channels_last_out else y
     out_cl = bool(channels_last_out) and residual is None and conv.weight.shape[0] % 4 == 0
     _FOLD_PAIRS[bn] = conv
+    track = torch.is_grad_enabled() and x.is_cuda
+    claim = getattr(x, "_fi_gate", None) if (gate_dx and track and x.requires_grad) else None
+    if claim is not None:
+        claim.claimed = True
+    out_gate = Gate() if (relu and track and not out_cl) else None
     y = _ConvBnActFn.apply(x, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                            bn.eps, residual, relu, tuple(conv.stride), tuple(conv.padding), out_cl,
-                           _cached_fold(conv, bn), res_grad_to, dx_add_from, dx_give_to)
+                           _cached_fold(conv, bn), res_grad_to, dx_add_from, dx_give_to, claim is not None, out_gate)
+    if out_gate is not None:
+        y._fi_gate = out_gate
     return y.contiguous(memory_format=torch.channels_last) if (channels_last_out and not out_cl) else y
 
 

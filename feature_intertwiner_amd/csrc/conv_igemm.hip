@@ -53,11 +53,14 @@ constexpr int PAD = 2;   // row pitch = 2 (mod 32) banks: the transposed tile st
 
 // epilogue: y = acc * scale[m] + bias[m] (+ residual) (ReLU) -- scale/bias carry an eval-mode
 // BatchNorm folded by the caller, residual the bottleneck shortcut
+// gate (optional, shaped like y): the result is multiplied by (gate > 0) -- the data gradient of a layer whose input
+// is a ReLU output leaves the kernel already masked (the separate masking pass of that ReLU's backward disappears)
 struct Epilogue {
     const float *bias;
     const float *scale;
     const float *residual;
     int relu;
+    const float *gate;
 };
 
 struct ConvGeom {
@@ -129,7 +132,7 @@ __device__ __forceinline__ void mma_tile(const float (*__restrict__ As)[BM + PAD
 // 48 dependent round trips per lane -- which on the short-K 1x1 layers, where all resident workgroups reach
 // the epilogue together, cost 10..15 % of the kernel.)  Absent scale / bias are read from a dummy page and
 // dropped by a select, so that the arithmetic stays exactly `acc [*scale] [+bias] [+shortcut] [relu]`.
-template <int BM, int BNT, bool HAS_RES>
+template <int BM, int BNT, bool HAS_RES, bool HAS_GATE>
 __device__ __forceinline__ void conv_epilogue_full(const f32x16 (&acc)[BM / 64][BNT / 64], const Epilogue &ep,
                                                    float *__restrict__ y, const ConvGeom &g, int m0, int p0,
                                                    int wm, int wn, int l31, int khalf,
@@ -162,11 +165,16 @@ __device__ __forceinline__ void conv_epilogue_full(const f32x16 (&acc)[BM / 64][
         const size_t obase = (size_t)on * g.Cout * OHW + (pp - on * OHW) + (size_t)mrow * OHW;
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
-            float4 r[4];
+            float4 r[4], gt[4];
             if (HAS_RES) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
                     r[q] = *reinterpret_cast<const float4 *>(ep.residual + obase + (size_t)(i * 32 + 8 * q) * OHW);
+            }
+            if (HAS_GATE) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    gt[q] = *reinterpret_cast<const float4 *>(ep.gate + obase + (size_t)(i * 32 + 8 * q) * OHW);
             }
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
@@ -189,6 +197,10 @@ __device__ __forceinline__ void conv_epilogue_full(const f32x16 (&acc)[BM / 64][
                     }
                     v.x = relu ? fmaxf(v.x, 0.0f) : v.x; v.y = relu ? fmaxf(v.y, 0.0f) : v.y;
                     v.z = relu ? fmaxf(v.z, 0.0f) : v.z; v.w = relu ? fmaxf(v.w, 0.0f) : v.w;
+                    if (HAS_GATE) {
+                        v.x = gt[q].x > 0.0f ? v.x : 0.0f; v.y = gt[q].y > 0.0f ? v.y : 0.0f;
+                        v.z = gt[q].z > 0.0f ? v.z : 0.0f; v.w = gt[q].w > 0.0f ? v.w : 0.0f;
+                    }
                     *reinterpret_cast<float4 *>(y + obase + (size_t)(i * 32 + 8 * q) * OHW) = v;
                 }
             }
@@ -207,10 +219,15 @@ __device__ __forceinline__ void conv_epilogue(const f32x16 (&acc)[BM / 64][BNT /
     constexpr int NT = BNT / 64;
     const int OHW = g.OH * g.OW;
     if (!ONHWC && g.vec_out && p0 + BNT <= g.P && m0 + BM <= g.Cout) {
-        if (ep.residual)
-            conv_epilogue_full<BM, BNT, true>(acc, ep, y, g, m0, p0, wm, wn, l31, khalf, scratch);
+        if (ep.gate) {
+            if (ep.residual)
+                conv_epilogue_full<BM, BNT, true, true>(acc, ep, y, g, m0, p0, wm, wn, l31, khalf, scratch);
+            else
+                conv_epilogue_full<BM, BNT, false, true>(acc, ep, y, g, m0, p0, wm, wn, l31, khalf, scratch);
+        } else if (ep.residual)
+            conv_epilogue_full<BM, BNT, true, false>(acc, ep, y, g, m0, p0, wm, wn, l31, khalf, scratch);
         else
-            conv_epilogue_full<BM, BNT, false>(acc, ep, y, g, m0, p0, wm, wn, l31, khalf, scratch);
+            conv_epilogue_full<BM, BNT, false, false>(acc, ep, y, g, m0, p0, wm, wn, l31, khalf, scratch);
         return;
     }
     if (!ONHWC && g.vec_out) {
@@ -262,6 +279,11 @@ __device__ __forceinline__ void conv_epilogue(const f32x16 (&acc)[BM / 64][BNT /
                             if (ep.relu) {
                                 v.x = fmaxf(v.x, 0.0f); v.y = fmaxf(v.y, 0.0f);
                                 v.z = fmaxf(v.z, 0.0f); v.w = fmaxf(v.w, 0.0f);
+                            }
+                            if (ep.gate) {
+                                const float4 t4 = *reinterpret_cast<const float4 *>(ep.gate + o);
+                                v.x = t4.x > 0.0f ? v.x : 0.0f; v.y = t4.y > 0.0f ? v.y : 0.0f;
+                                v.z = t4.z > 0.0f ? v.z : 0.0f; v.w = t4.w > 0.0f ? v.w : 0.0f;
                             }
                             *reinterpret_cast<float4 *>(y + o) = v;
                         }
@@ -329,6 +351,7 @@ __device__ __forceinline__ void conv_epilogue(const f32x16 (&acc)[BM / 64][BNT /
                     if (ep.bias) v += bi;
                     if (ep.residual) v += ep.residual[o];
                     if (ep.relu) v = fmaxf(v, 0.0f);
+                    if (ep.gate) v = ep.gate[o] > 0.0f ? v : 0.0f;
                     y[o] = v;
                 }
             }
@@ -581,7 +604,7 @@ struct PatchGeom {
 };
 
 // predicate-free NCHW epilogue of conv3x3_patch_kernel<false>: the loads of a group of 4 rows are issued together
-template <bool HAS_RES>
+template <bool HAS_RES, bool HAS_GATE>
 __device__ __forceinline__ void patch_epilogue_vec(const f32x16 (&acc)[4], const Epilogue &ep, float *__restrict__ y,
                                                    size_t obase, size_t HW, int mb, const float *__restrict__ sp,
                                                    const float *__restrict__ bp, int smul, int bmul, bool has_sc,
@@ -590,13 +613,14 @@ __device__ __forceinline__ void patch_epilogue_vec(const f32x16 (&acc)[4], const
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         float sc[4], bi[4];
-        float4 rr[4];
+        float4 rr[4], gt[4];
 #pragma unroll
         for (int e4 = 0; e4 < 4; ++e4) {
             const int m = mb + 8 * q + e4;
             sc[e4] = sp[m * smul];
             bi[e4] = bp[m * bmul];
             if (HAS_RES) rr[e4] = *reinterpret_cast<const float4 *>(ep.residual + obase + (size_t)(8 * q + e4) * HW);
+            if (HAS_GATE) gt[e4] = *reinterpret_cast<const float4 *>(ep.gate + obase + (size_t)(8 * q + e4) * HW);
         }
 #pragma unroll
         for (int e4 = 0; e4 < 4; ++e4) {
@@ -613,6 +637,10 @@ __device__ __forceinline__ void patch_epilogue_vec(const f32x16 (&acc)[4], const
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) t[j] = relu ? fmaxf(t[j], 0.0f) : t[j];
+            if (HAS_GATE) {
+                t[0] = gt[e4].x > 0.0f ? t[0] : 0.0f; t[1] = gt[e4].y > 0.0f ? t[1] : 0.0f;
+                t[2] = gt[e4].z > 0.0f ? t[2] : 0.0f; t[3] = gt[e4].w > 0.0f ? t[3] : 0.0f;
+            }
             *reinterpret_cast<float4 *>(y + obase + (size_t)(8 * q + e4) * HW) = make_float4(t[0], t[1], t[2], t[3]);
         }
     }
@@ -620,7 +648,7 @@ __device__ __forceinline__ void patch_epilogue_vec(const f32x16 (&acc)[4], const
 
 // flat tiles: the lane's pixels (0,1) and (2,3) are two pairs, each inside one row (W even): 8-byte accesses.
 // Loads are unconditional (clamped rows / pixels), only the stores are predicated.
-template <bool HAS_RES>
+template <bool HAS_RES, bool HAS_GATE>
 __device__ __forceinline__ void patch_epilogue_pairs(const f32x16 (&acc)[4], const Epilogue &ep, float *__restrict__ y,
                                                      const size_t (&opair)[2], const bool (&okp)[2], size_t HW, int mb,
                                                      int Cout, const float *__restrict__ sp,
@@ -630,7 +658,7 @@ __device__ __forceinline__ void patch_epilogue_pairs(const f32x16 (&acc)[4], con
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         float sc[4], bi[4];
-        float2 rr[4][2];
+        float2 rr[4][2], gt[4][2];
         int mrow[4];
 #pragma unroll
         for (int e4 = 0; e4 < 4; ++e4) {
@@ -640,6 +668,10 @@ __device__ __forceinline__ void patch_epilogue_pairs(const f32x16 (&acc)[4], con
             if (HAS_RES) {
                 rr[e4][0] = *reinterpret_cast<const float2 *>(ep.residual + opair[0] + (size_t)mrow[e4] * HW);
                 rr[e4][1] = *reinterpret_cast<const float2 *>(ep.residual + opair[1] + (size_t)mrow[e4] * HW);
+            }
+            if (HAS_GATE) {
+                gt[e4][0] = *reinterpret_cast<const float2 *>(ep.gate + opair[0] + (size_t)mrow[e4] * HW);
+                gt[e4][1] = *reinterpret_cast<const float2 *>(ep.gate + opair[1] + (size_t)mrow[e4] * HW);
             }
         }
 #pragma unroll
@@ -657,6 +689,10 @@ __device__ __forceinline__ void patch_epilogue_pairs(const f32x16 (&acc)[4], con
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) t[j] = relu ? fmaxf(t[j], 0.0f) : t[j];
+            if (HAS_GATE) {
+                t[0] = gt[e4][0].x > 0.0f ? t[0] : 0.0f; t[1] = gt[e4][0].y > 0.0f ? t[1] : 0.0f;
+                t[2] = gt[e4][1].x > 0.0f ? t[2] : 0.0f; t[3] = gt[e4][1].y > 0.0f ? t[3] : 0.0f;
+            }
             const bool row_ok = mb + 8 * q + e4 < Cout;
             if (row_ok && okp[0]) *reinterpret_cast<float2 *>(y + opair[0] + (size_t)mrow[e4] * HW) = make_float2(t[0], t[1]);
             if (row_ok && okp[1]) *reinterpret_cast<float2 *>(y + opair[1] + (size_t)mrow[e4] * HW) = make_float2(t[2], t[3]);
@@ -886,10 +922,15 @@ __global__ __launch_bounds__(kThreads, 3) void conv3x3_patch_kernel(const float 
             const int n_img = Yc / g.H;
             opair[h] = ((size_t)n_img * g.Cout + mb) * HW + (size_t)(Yc - n_img * g.H) * g.W + xj[2 * h];
         }
-        if (ep.residual)
-            patch_epilogue_pairs<true>(acc, ep, y, opair, okp, HW, mb, g.Cout, sp, bp, smul, bmul, has_sc, has_bi, relu);
+        if (ep.gate) {
+            if (ep.residual)
+                patch_epilogue_pairs<true, true>(acc, ep, y, opair, okp, HW, mb, g.Cout, sp, bp, smul, bmul, has_sc, has_bi, relu);
+            else
+                patch_epilogue_pairs<false, true>(acc, ep, y, opair, okp, HW, mb, g.Cout, sp, bp, smul, bmul, has_sc, has_bi, relu);
+        } else if (ep.residual)
+            patch_epilogue_pairs<true, false>(acc, ep, y, opair, okp, HW, mb, g.Cout, sp, bp, smul, bmul, has_sc, has_bi, relu);
         else
-            patch_epilogue_pairs<false>(acc, ep, y, opair, okp, HW, mb, g.Cout, sp, bp, smul, bmul, has_sc, has_bi, relu);
+            patch_epilogue_pairs<false, false>(acc, ep, y, opair, okp, HW, mb, g.Cout, sp, bp, smul, bmul, has_sc, has_bi, relu);
         return;
     }
     const int Yo = Yj[0], xo = xj[0];
@@ -924,10 +965,15 @@ __global__ __launch_bounds__(kThreads, 3) void conv3x3_patch_kernel(const float 
     const int n_img = Yo / g.H;
     const size_t obase = ((size_t)n_img * g.Cout + mb) * HW + (size_t)(Yo - n_img * g.H) * g.W + xo;
     if (g.vec4 && m0 + 128 <= g.Cout) {      // xo % 4 == 0 and W % 4 == 0: the quad is inside the row
-        if (ep.residual)
-            patch_epilogue_vec<true>(acc, ep, y, obase, HW, mb, sp, bp, smul, bmul, has_sc, has_bi, relu);
+        if (ep.gate) {
+            if (ep.residual)
+                patch_epilogue_vec<true, true>(acc, ep, y, obase, HW, mb, sp, bp, smul, bmul, has_sc, has_bi, relu);
+            else
+                patch_epilogue_vec<false, true>(acc, ep, y, obase, HW, mb, sp, bp, smul, bmul, has_sc, has_bi, relu);
+        } else if (ep.residual)
+            patch_epilogue_vec<true, false>(acc, ep, y, obase, HW, mb, sp, bp, smul, bmul, has_sc, has_bi, relu);
         else
-            patch_epilogue_vec<false>(acc, ep, y, obase, HW, mb, sp, bp, smul, bmul, has_sc, has_bi, relu);
+            patch_epilogue_vec<false, false>(acc, ep, y, obase, HW, mb, sp, bp, smul, bmul, has_sc, has_bi, relu);
         return;
     }
     // general: rows past Cout and columns past W are skipped; 4-byte accesses
@@ -944,7 +990,9 @@ __global__ __launch_bounds__(kThreads, 3) void conv3x3_patch_kernel(const float 
             v = has_sc ? v * sc : v;
             v = has_bi ? v + bi : v;
             if (ep.residual) v += ep.residual[o + j];
-            y[o + j] = relu ? fmaxf(v, 0.0f) : v;
+            v = relu ? fmaxf(v, 0.0f) : v;
+            if (ep.gate) v = ep.gate[o + j] > 0.0f ? v : 0.0f;
+            y[o + j] = v;
         }
     }
 }
@@ -1087,10 +1135,15 @@ __global__ __launch_bounds__(kThreads, 3) void conv1x1_reg_kernel(const float *_
     const float *__restrict__ bpp = has_bi ? ep.bias : g.zero;
     const int smul = has_sc ? 1 : 0, bmul = has_bi ? 1 : 0;
     if (g.vec4 && m0 + 128 <= g.Cout) {
-        if (ep.residual)
-            patch_epilogue_vec<true>(acc, ep, y, obase, HW, mb, spp, bpp, smul, bmul, has_sc, has_bi, relu);
+        if (ep.gate) {
+            if (ep.residual)
+                patch_epilogue_vec<true, true>(acc, ep, y, obase, HW, mb, spp, bpp, smul, bmul, has_sc, has_bi, relu);
+            else
+                patch_epilogue_vec<false, true>(acc, ep, y, obase, HW, mb, spp, bpp, smul, bmul, has_sc, has_bi, relu);
+        } else if (ep.residual)
+            patch_epilogue_vec<true, false>(acc, ep, y, obase, HW, mb, spp, bpp, smul, bmul, has_sc, has_bi, relu);
         else
-            patch_epilogue_vec<false>(acc, ep, y, obase, HW, mb, spp, bpp, smul, bmul, has_sc, has_bi, relu);
+            patch_epilogue_vec<false, false>(acc, ep, y, obase, HW, mb, spp, bpp, smul, bmul, has_sc, has_bi, relu);
         return;
     }
 #pragma unroll
@@ -1105,7 +1158,9 @@ __global__ __launch_bounds__(kThreads, 3) void conv1x1_reg_kernel(const float *_
             v = has_sc ? v * sc : v;
             v = has_bi ? v + bi : v;
             if (ep.residual) v += ep.residual[o + j];
-            y[o + j] = relu ? fmaxf(v, 0.0f) : v;
+            v = relu ? fmaxf(v, 0.0f) : v;
+            if (ep.gate) v = ep.gate[o + j] > 0.0f ? v : 0.0f;
+            y[o + j] = v;
         }
     }
 }
@@ -1773,7 +1828,8 @@ void launch_fwd(const ConvGeom &g_in, const float *x, const float *w, const Epil
 {
     ConvGeom g = g_in;
     g.vec_out = (!g.out_nhwc && (g.OH * g.OW) % 4 == 0 && ((uintptr_t)y % 16 == 0) &&
-                 (ep.residual == nullptr || (uintptr_t)ep.residual % 16 == 0)) ? 1 : 0;
+                 (ep.residual == nullptr || (uintptr_t)ep.residual % 16 == 0) &&
+                 (ep.gate == nullptr || (uintptr_t)ep.gate % 16 == 0)) ? 1 : 0;
     // 64-pixel tiles when even 64-row tiles leave fewer than 4 workgroups per CU (C4/C5 of the backbone
     // at batch 4): twice the workgroups, so that 4 wavefronts share each SIMD's MFMA pipe
     if constexpr (BM == 64) {
@@ -2130,12 +2186,14 @@ __global__ __launch_bounds__(256) void weight_transpose_kernel(const FiTranspose
         const float *__restrict__ src = (const float *)d.src + (size_t)tap * d.cols;           // [rows][taps][cols]
         float *__restrict__ dst = (float *)d.dst + (size_t)tap * d.rows;                       // [cols][taps][rows]
         const size_t src_pitch = (size_t)d.taps * d.cols, dst_pitch = (size_t)d.taps * d.rows;
+        const float *__restrict__ rs = (const float *)d.row_scale;
         const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int r = r0 + ty + 8 * k, c = c0 + tx;
-            if (r < d.rows && c < d.cols) s_t[ty + 8 * k][tx] = src[(size_t)r * src_pitch + c];
+            if (r < d.rows && c < d.cols)
+                s_t[ty + 8 * k][tx] = rs ? src[(size_t)r * src_pitch + c] * rs[r] : src[(size_t)r * src_pitch + c];
         }
         __syncthreads();
 #pragma unroll
@@ -2155,14 +2213,23 @@ int fi_conv2d_forward(const float *x, const float *weight, const float *bias, co
                       int S, int stride_h, int stride_w, int pad_h, int pad_w, int relu,
                       int weight_layout, int out_h, int out_w, int output_layout, fi_stream_t stream)
 {
+    return fi_conv2d_forward_gated(x, weight, bias, scale, residual, nullptr, y, N, Cin, H, W, Cout, R, S, stride_h,
+                                   stride_w, pad_h, pad_w, relu, weight_layout, out_h, out_w, output_layout, stream);
+}
+
+int fi_conv2d_forward_gated(const float *x, const float *weight, const float *bias, const float *scale,
+                            const float *residual, const float *gate, float *y, int N, int Cin, int H, int W,
+                            int Cout, int R, int S, int stride_h, int stride_w, int pad_h, int pad_w, int relu,
+                            int weight_layout, int out_h, int out_w, int output_layout, fi_stream_t stream)
+{
     ConvGeom g;
     int rc = make_geom(g, N, Cin, H, W, Cout, R, S, stride_h, stride_w, pad_h, pad_w, out_h, out_w);
     if (rc != FI_OK) return rc;
     FI_REQUIRE(x && weight && y, "null pointer");
     FI_REQUIRE(output_layout == 0 || output_layout == 1, "output_layout: 0 = [N][Cout][OH][OW], 1 = [N][OH][OW][Cout]");
     if (output_layout == 1) {
-        FI_REQUIRE(Cout % 4 == 0 && residual == nullptr && (uintptr_t)y % 16 == 0,
-                   "channels-last output needs Cout % 4 == 0, a 16-byte aligned y and no fused residual");
+        FI_REQUIRE(Cout % 4 == 0 && residual == nullptr && gate == nullptr && (uintptr_t)y % 16 == 0,
+                   "channels-last output needs Cout % 4 == 0, a 16-byte aligned y and no fused residual / gate");
         FI_REQUIRE(Cin % BK == 0 && R * S <= 64 && (weight_layout >= 1 || R * S == 1),
                    "channels-last output is implemented on the tap-major path (Cin % 16 == 0, weight_layout 1)");
         g.out_nhwc = 1;
@@ -2176,10 +2243,11 @@ int fi_conv2d_forward(const float *x, const float *weight, const float *bias, co
     g.zero = zero_page();
     FI_REQUIRE(g.zero != nullptr, "zero page lookup failed (no HIP device?)");
     hipStream_t st = (hipStream_t)stream;
-    const Epilogue ep = {bias, scale, residual, relu};
+    const Epilogue ep = {bias, scale, residual, relu, gate};
     const bool bm64 = use_bm64(Cout, g.P);
     // 3x3 / stride 1 / pad 1 layers with enough tiles to fill the chip: input patch in LDS (conv3x3_patch_kernel)
-    const int patch_mode = getenv("FI_NO_PATCH") ? 0 : patch_eligible(g, hwc, weight_layout, x, y, residual);
+    int patch_mode = getenv("FI_NO_PATCH") ? 0 : patch_eligible(g, hwc, weight_layout, x, y, residual);
+    if (patch_mode == 2 && gate != nullptr && (uintptr_t)gate % 8 != 0) patch_mode = 0;
     // 1x1 / stride 1 layers: weights in registers, pixel tile staged 32 channels at a time (conv1x1_reg_kernel);
     // layers with fewer than 128 input channels are bound by their output stream and measured faster on
     // conv_fwd_kernel (4 workgroups per CU)
@@ -2195,7 +2263,8 @@ int fi_conv2d_forward(const float *x, const float *weight, const float *bias, co
         cg.N = N; cg.Cin = Cin; cg.HW = H * W; cg.Cout = Cout;
         cg.ptiles = fi::ceil_div(N * H * W, 128);
         cg.mtiles = fi::ceil_div(Cout, 128);
-        cg.vec4 = ((uintptr_t)y % 16 == 0 && (residual == nullptr || (uintptr_t)residual % 16 == 0)) ? 1 : 0;
+        cg.vec4 = ((uintptr_t)y % 16 == 0 && (residual == nullptr || (uintptr_t)residual % 16 == 0) &&
+                   (gate == nullptr || (uintptr_t)gate % 16 == 0)) ? 1 : 0;
         cg.zero = g.zero;
         const long blocks = (long)fi::ceil_div(cg.ptiles, 8) * 8 * cg.mtiles;
         hipLaunchKernelGGL(conv1x1_reg_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, st, x, weight, ep, y, cg);
@@ -2209,7 +2278,8 @@ int fi_conv2d_forward(const float *x, const float *weight, const float *bias, co
         pg.tiles_x = fi::ceil_div(W, PT_TW);
         pg.ptiles = patch_mode == 2 ? fi::ceil_div(N * H * W, 128) : fi::ceil_div(N * H, PT_TH) * pg.tiles_x;
         pg.mtiles = fi::ceil_div(Cout, 128);
-        pg.vec4 = (W % 4 == 0 && (uintptr_t)y % 16 == 0 && (residual == nullptr || (uintptr_t)residual % 16 == 0)) ? 1 : 0;
+        pg.vec4 = (W % 4 == 0 && (uintptr_t)y % 16 == 0 && (residual == nullptr || (uintptr_t)residual % 16 == 0) &&
+                   (gate == nullptr || (uintptr_t)gate % 16 == 0)) ? 1 : 0;
         pg.out_nhwc = g.out_nhwc;
         pg.zero = g.zero;
         const long blocks = (long)fi::ceil_div(pg.ptiles, 8) * 8 * pg.mtiles;

@@ -1,6 +1,8 @@
 // glue.hip -- small data-movement kernels of the training step that replace chains of framework launches.
 #include <stdint.h>
 
+#include <algorithm>
+
 #include "fi_common.h"
 
 namespace {
@@ -80,9 +82,102 @@ __global__ __launch_bounds__(256) void bn_fold_kernel(const FiBnFoldDesc *__rest
     static_cast<float *>(d.shift)[c] = sh;
 }
 
+__global__ __launch_bounds__(256) void relu_mask_kernel(const float *__restrict__ dy, const float *__restrict__ y,
+                                                        float *__restrict__ out, long n4, long n)
+{
+    const long stride = (long)gridDim.x * 256;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+        const float4 d = reinterpret_cast<const float4 *>(dy)[i];
+        const float4 v = reinterpret_cast<const float4 *>(y)[i];
+        float4 o;
+        o.x = v.x > 0.0f ? d.x : 0.0f; o.y = v.y > 0.0f ? d.y : 0.0f;
+        o.z = v.z > 0.0f ? d.z : 0.0f; o.w = v.w > 0.0f ? d.w : 0.0f;
+        reinterpret_cast<float4 *>(out)[i] = o;
+    }
+    for (long i = n4 * 4 + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) out[i] = y[i] > 0.0f ? dy[i] : 0.0f;
+}
+
+// one workgroup per output channel: <W[co], dW'[co]> while dW'[co] is scaled in place (see fi_capi.h)
+__global__ __launch_bounds__(256) void bn_fold_grad_kernel(float *__restrict__ dw, const float *__restrict__ w,
+                                                           const float *__restrict__ s, const float *__restrict__ scale,
+                                                           const float *__restrict__ mean, const float *__restrict__ var,
+                                                           float eps, const float *__restrict__ conv_bias,
+                                                           float *__restrict__ dgamma, float *__restrict__ dbias, int Cin,
+                                                           int taps, int vec, int same_order, int dw_tap_major)
+{
+    __shared__ float part[4];
+    const int co = blockIdx.x, K = Cin * taps;
+    float *__restrict__ drow = dw + (size_t)co * K;
+    const float *__restrict__ wrow = w + (size_t)co * K;
+    const float sc = scale[co];
+    float dot = 0.0f;
+    if (vec) {
+        for (int k = threadIdx.x * 4; k < K; k += 1024) {
+            float4 d = *reinterpret_cast<float4 *>(drow + k);
+            const float4 v = *reinterpret_cast<const float4 *>(wrow + k);
+            dot += (d.x * v.x + d.y * v.y) + (d.z * v.z + d.w * v.w);
+            d.x *= sc; d.y *= sc; d.z *= sc; d.w *= sc;
+            *reinterpret_cast<float4 *>(drow + k) = d;
+        }
+    } else {
+        for (int k = threadIdx.x; k < K; k += 256) {
+            int kw = k;
+            if (!same_order) {
+                // k indexes dW'; the same (ci, tap) element of W sits at the other order's index
+                const int ci = dw_tap_major ? k % Cin : k / taps, tap = dw_tap_major ? k / Cin : k % taps;
+                kw = dw_tap_major ? ci * taps + tap : tap * Cin + ci;
+            }
+            const float d = drow[k];
+            dot += d * wrow[kw];
+            drow[k] = d * sc;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) dot += __shfl_xor(dot, off, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = dot;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float total = (part[0] + part[1]) + (part[2] + part[3]);
+        const float sv = s[co];
+        const float inv = rsqrtf(var[co] + eps);
+        const float cb = conv_bias ? conv_bias[co] : 0.0f;
+        // atomics: a layer applied twice per step has its other use accumulate here from another stream
+        if (dgamma) atomicAdd(dgamma + co, inv * (total + (cb - mean[co]) * sv));
+        if (dbias) atomicAdd(dbias + co, sc * sv);
+    }
+}
+
 }  // namespace
 
 extern "C" {
+
+int fi_relu_mask(const float *dy, const float *y, float *out, long n, fi_stream_t stream)
+{
+    FI_REQUIRE(n >= 0, "bad size");
+    if (n == 0) return FI_OK;
+    FI_REQUIRE(dy && y && out, "null pointer");
+    const bool vec = ((uintptr_t)dy % 16 == 0) && ((uintptr_t)y % 16 == 0) && ((uintptr_t)out % 16 == 0);
+    const long n4 = vec ? n / 4 : 0;
+    const long blocks = std::min<long>(std::max<long>((std::max<long>(n4, 1) + 511) / 512, 1), 256L * 16);
+    hipLaunchKernelGGL(relu_mask_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dy, y, out, n4, n);
+    FI_HIP_CHECK(hipGetLastError());
+    return FI_OK;
+}
+
+int fi_bn_fold_grad(float *dw, const float *w, const float *s, const float *scale, const float *mean,
+                    const float *var, float eps, const float *conv_bias, float *dgamma, float *dbias, int Cout,
+                    int Cin, int taps, int dw_tap_major, int w_tap_major, fi_stream_t stream)
+{
+    FI_REQUIRE(Cout > 0 && Cin > 0 && taps > 0, "bad sizes");
+    FI_REQUIRE(dw && w && s && scale && mean && var, "null pointer");
+    const int same_order = (taps == 1 || (dw_tap_major != 0) == (w_tap_major != 0)) ? 1 : 0;
+    // 16-byte accesses need aligned rows; otherwise the scalar loop (with the index map when the orders differ)
+    const int vec = (same_order && ((long)Cin * taps) % 4 == 0 && (uintptr_t)dw % 16 == 0 && (uintptr_t)w % 16 == 0) ? 1 : 0;
+    hipLaunchKernelGGL(bn_fold_grad_kernel, dim3((unsigned)Cout), dim3(256), 0, (hipStream_t)stream, dw, w, s, scale, mean,
+                       var, eps, conv_bias, dgamma, dbias, Cin, taps, vec, same_order, dw_tap_major);
+    FI_HIP_CHECK(hipGetLastError());
+    return FI_OK;
+}
 
 int fi_bn_fold_batch(const FiBnFoldDesc *descs_dev, int n, int max_channels, fi_stream_t stream)
 {

@@ -96,6 +96,7 @@ class Bottleneck(nn.Module):
         self.relu = nn.ReLU(inplace=True)
         self.downsample = downsample
         self.stride = stride
+        self.input_sole = False       # True: nothing but this block reads its input (the inner blocks of a stage)
 
     def forward(self, x):
         # conv + eval-BN (+ shortcut) + ReLU are one kernel launch each (conv.conv_bn_act)
@@ -104,10 +105,14 @@ class Bottleneck(nn.Module):
             # shortcut gradient (produced by conv3's backward, which always runs first) is handed to
             # conv1's backward and added inside its data-gradient kernel, instead of a separate pass over
             # two block-sized tensors (33 blocks in ResNet-101).
+            # gate_dx: conv2 / conv3 are the only readers of their inputs, and with `input_sole` (set by
+            # ResNet.make_layer for the blocks after the first of a stage) this block is the only reader of x --
+            # conv1's kernel sees x's whole gradient (its own + the shortcut's through the box): the ReLU masks of
+            # the three producing layers are applied in these layers' data-gradient epilogues (conv.Gate).
             box = GradBox()
-            out = conv_bn_act(x, self.conv1, self.bn1, relu=True, dx_add_from=box)
-            out = conv_bn_act(out, self.conv2, self.bn2, relu=True)
-            return conv_bn_act(out, self.conv3, self.bn3, relu=True, residual=x, res_grad_to=box)
+            out = conv_bn_act(x, self.conv1, self.bn1, relu=True, dx_add_from=box, gate_dx=self.input_sole)
+            out = conv_bn_act(out, self.conv2, self.bn2, relu=True, gate_dx=True)
+            return conv_bn_act(out, self.conv3, self.bn3, relu=True, residual=x, res_grad_to=box, gate_dx=True)
         if self.downsample is not None and _fused_path(x, self.bn1, self.bn3, self.downsample[1]) and \
                 x.requires_grad and torch.is_grad_enabled():
             # projection shortcut: x receives the data gradients of conv1 and of the projection.  The projection
@@ -116,15 +121,15 @@ class Bottleneck(nn.Module):
             # inside its own data-gradient kernel -- no zero fill, strided scatter and add over block-sized tensors.
             box = GradBox()
             out = conv_bn_act(x, self.conv1, self.bn1, relu=True, dx_add_from=box)
-            out = conv_bn_act(out, self.conv2, self.bn2, relu=True)
+            out = conv_bn_act(out, self.conv2, self.bn2, relu=True, gate_dx=True)
             residual = conv_bn_act(x, self.downsample[0], self.downsample[1], relu=False, dx_give_to=box)
-            return conv_bn_act(out, self.conv3, self.bn3, relu=True, residual=residual)
+            return conv_bn_act(out, self.conv3, self.bn3, relu=True, residual=residual, gate_dx=True)
         out = conv_bn_act(x, self.conv1, self.bn1, relu=True)
-        out = conv_bn_act(out, self.conv2, self.bn2, relu=True)
+        out = conv_bn_act(out, self.conv2, self.bn2, relu=True, gate_dx=True)
         residual = x
         if self.downsample is not None:
             residual = conv_bn_act(x, self.downsample[0], self.downsample[1], relu=False)
-        return conv_bn_act(out, self.conv3, self.bn3, relu=True, residual=residual)
+        return conv_bn_act(out, self.conv3, self.bn3, relu=True, residual=residual, gate_dx=True)
 
 
 class ResNet(nn.Module):
@@ -157,6 +162,8 @@ class ResNet(nn.Module):
             project = nn.Sequential(Conv2d(self.inplanes, out_ch, kernel_size=1, stride=stride), _bn(out_ch))
         chain = [block(self.inplanes, planes, stride, project)]
         chain += [block(out_ch, planes) for _ in range(blocks - 1)]
+        for b in chain[1:]:
+            b.input_sole = True       # nn.Sequential: the previous block's output goes to this block only
         self.inplanes = out_ch
         return nn.Sequential(*chain)
 
@@ -538,9 +545,9 @@ class Mask(nn.Module):
         loss to the one class channel per RoI it reads (compute_mrcnn_mask_loss_unshuffled(from_logits=True)) --
         an elementwise op commuted with a gather: same values, 1/81 of the elements."""
         x = conv_bn_act(x, self.conv1, self.bn1, relu=True)
-        x = conv_bn_act(x, self.conv2, self.bn2, relu=True)
-        x = conv_bn_act(x, self.conv3, self.bn3, relu=True)
-        x = conv_bn_act(x, self.conv4, self.bn4, relu=True)
+        x = conv_bn_act(x, self.conv2, self.bn2, relu=True, gate_dx=True)      # each layer is the only reader of the
+        x = conv_bn_act(x, self.conv3, self.bn3, relu=True, gate_dx=True)      # previous one's output (conv.Gate)
+        x = conv_bn_act(x, self.conv4, self.bn4, relu=True, gate_dx=True)
         # deconv(k2,s2) = 1x1 conv to (a, b, c) channels; ReLU, conv5 (1x1) and sigmoid are per pixel, so
         # they run before the pixel shuffle and only 81 channels are ever moved
         u = self.deconv.forward_unshuffled(x, relu=True)                 # [N, 2, 2, 256, H, W]

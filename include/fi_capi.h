@@ -271,6 +271,27 @@ int fi_conv2d_forward(const float *x, const float *weight, const float *bias,
                       int H, int W, int Cout, int R, int S, int stride_h, int stride_w,
                       int pad_h, int pad_w, int relu, int weight_layout, int out_h, int out_w,
                       int output_layout, fi_stream_t stream);
+/* fi_conv2d_forward with one more epilogue operand: gate [N,Cout,OH,OW] (or NULL), y = (...) * (gate > 0).
+ * The data gradient of a layer whose input is a ReLU output that nothing else reads leaves the kernel already
+ * multiplied by that ReLU's mask (output_layout 0 only). */
+int fi_conv2d_forward_gated(const float *x, const float *weight, const float *bias, const float *scale,
+                            const float *residual, const float *gate, float *y, int N, int Cin, int H, int W,
+                            int Cout, int R, int S, int stride_h, int stride_w, int pad_h, int pad_w, int relu,
+                            int weight_layout, int out_h, int out_w, int output_layout, fi_stream_t stream);
+/* out = dy * (y > 0), n elements (out may alias dy): the ReLU part of the backward below on its own. */
+int fi_relu_mask(const float *dy, const float *y, float *out, long n, fi_stream_t stream);
+/* Gradients of conv + eval-mode BatchNorm from the weight gradient of the UNSCALED masked gradient g
+ * (y = act(conv(x, W) * scale + shift), scale = gamma * inv_std, g = dy * (y > 0)):
+ *     dW'[co] = sum_p g[co] (x) patches(x)   (fi_conv2d_weight_grad on g),   s[co] = sum_p g[co] = d beta
+ *     dW[co]      = scale[co] * dW'[co]                                (in place)
+ *     d gamma[co] += inv_std[co] * (<W[co], dW'[co]> + (conv_bias[co] - mean[co]) * s[co])
+ *     d conv_bias[co] += scale[co] * s[co]
+ * because sum_p g * conv(x, W) = <W, dW'>: no second pass over the activations.  dw [Cout][K] in tap-major
+ * (dw_tap_major: k = tap*Cin + ci) or channel-major (k = ci*taps + tap) order, w likewise (w_tap_major).
+ * dgamma / dbias may be NULL; conv_bias NULL = no bias. */
+int fi_bn_fold_grad(float *dw, const float *w, const float *s, const float *scale, const float *mean,
+                    const float *var, float eps, const float *conv_bias, float *dgamma, float *dbias, int Cout,
+                    int Cin, int taps, int dw_tap_major, int w_tap_major, fi_stream_t stream);
 /* Backward of that fused epilogue (eval-mode BatchNorm folded into scale/shift, optional ReLU):
  * g = dy * (y > 0 | 1); dz = g * scale[c]; dshift[c] = sum g; dgamma[c] = sum g*(y-beta[c])/gamma[c].
  * layout 1: dy and y are channels-last [N,HW,C] (dz is still written [N,C,HW]; no residual/g_out).
@@ -311,6 +332,8 @@ typedef struct {
     void *dst;
     int rows, cols, taps, pad_;
     long tile_base;
+    const void *row_scale;   /* [rows] or NULL: dst[col][tap][row] = src[row][tap][col] * row_scale[row] -- the data
+                              * gradient of conv + eval-BatchNorm reads W^T with the BatchNorm scale folded in */
 } FiTransposeDesc;
 int fi_weight_transpose_batch(const FiTransposeDesc *descs_dev, int n, long total_tiles,
                               fi_stream_t stream);

@@ -425,3 +425,136 @@ def test_linear_on_the_library_kernels_matches_float64(M, K, N, bias):
     assert (wg.grad.cpu().double() - wd.grad).abs().max().item() <= tol(wd.grad, M)
     if bias:
         assert (bg.grad.cpu().double() - bd.grad).abs().max().item() <= tol(bd.grad, M)
+
+
+@pytest.mark.parametrize("case", [
+    # N, Cin, H, W, Cout, k, residual -- which forward kernel serves the (data-gradient shaped) call
+    (4, 256, 64, 64, 128, 1, True),      # conv1x1_reg_kernel, full tiles, shortcut + gate
+    (4, 256, 64, 64, 128, 1, False),
+    (2, 128, 64, 64, 128, 3, False),     # conv3x3_patch_kernel<false> (8 x 16 tiles)
+    (2, 128, 64, 64, 128, 3, True),
+    (640, 128, 14, 14, 128, 3, False),   # conv3x3_patch_kernel<true> (flat tiles, the RoI maps)
+    (3, 48, 13, 11, 40, 3, True),        # conv_fwd_kernel, ragged tile, scalar epilogue
+    (2, 64, 32, 32, 64, 1, True),        # conv_fwd_kernel, 16-byte epilogue
+    (2, 128, 20, 12, 256, 1, False),     # 1x1, pixel count not a multiple of the tile
+])
+def test_gated_epilogue_matches_masked_reference(case):
+    """fi_conv2d_forward_gated: y = (conv(x, w) [+ residual]) * (gate > 0) in every forward kernel's epilogue."""
+    from feature_intertwiner_amd.conv import _conv_fwd
+    N, Cin, H, W, Cout, k, res = case
+    g = torch.Generator(device="cpu").manual_seed(N + Cin + H + k)
+    x = torch.randn(N, Cin, H, W, generator=g).to(DEV)
+    w = (torch.randn(Cout, Cin, k, k, generator=g) * (1.0 / (Cin * k * k) ** 0.5)).to(DEV)
+    r = torch.randn(N, Cout, H, W, generator=g).to(DEV) if res else None
+    gate = torch.randn(N, Cout, H, W, generator=g).to(DEV)
+    gate[gate.abs() < 0.2] = 0.0                                       # exact zeros are closed gates
+    wt = w.permute(0, 2, 3, 1).contiguous() if Cin % 16 == 0 else None
+    if wt is not None:
+        y = _conv_fwd(x, wt, None, (1, 1), (k // 2, k // 2), residual=r, w_tap_major=True, gate=gate, precision="fp32")
+        plain = _conv_fwd(x, wt, None, (1, 1), (k // 2, k // 2), residual=r, w_tap_major=True, precision="fp32")
+    else:
+        y = _conv_fwd(x, w, None, (1, 1), (k // 2, k // 2), residual=r, gate=gate, precision="fp32")
+        plain = _conv_fwd(x, w, None, (1, 1), (k // 2, k // 2), residual=r, precision="fp32")
+    assert torch.equal(y, plain * (gate > 0))                          # the same arithmetic, then a select
+    ref = F.conv2d(x.double(), w.double(), padding=k // 2)
+    if res:
+        ref = ref + r.double()
+    ref = ref * (gate > 0)
+    assert float((y.double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max()) * (Cin * k * k) ** 0.5
+
+
+@pytest.mark.parametrize("cin,cout,k,cl_weight,bias", [(128, 64, 3, False, True), (128, 64, 3, True, False),
+                                                      (48, 40, 3, True, True), (64, 256, 1, False, True),
+                                                      (20, 24, 3, False, True)])
+def test_batchnorm_gradients_from_the_weight_gradient(cin, cout, k, cl_weight, bias):
+    """The fp32 backward of conv + eval-BN + ReLU takes d gamma from <W, dW'> (fi_bn_fold_grad) instead of a pass over
+    the activations: every gradient against float64 autograd, for both memory orders of W and of dW'."""
+    from feature_intertwiner_amd import conv as C
+    torch.manual_seed(cin + cout + k)
+    conv = C.Conv2d(cin, cout, k, padding=k // 2, bias=bias).to(DEV)
+    if cl_weight:
+        conv.weight.data = conv.weight.data.contiguous(memory_format=torch.channels_last)
+    bn = torch.nn.BatchNorm2d(cout, eps=0.001).to(DEV).eval()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5); bn.bias.normal_(0, 0.3)
+        bn.running_mean.normal_(0, 0.5); bn.running_var.uniform_(0.5, 2.0)
+        bn.weight[3] = 0.0                       # a dead channel: d beta and d gamma must still be exact
+    x = torch.randn(4, cin, 16, 12, device=DEV)
+    xg = x.clone().requires_grad_(True)
+    y = C.conv_bn_act(xg, conv, bn, relu=True)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    rc = torch.nn.Conv2d(cin, cout, k, padding=k // 2, bias=bias).double()
+    rb = torch.nn.BatchNorm2d(cout, eps=0.001).double().eval()
+    rc.load_state_dict({n: v.cpu().double() for n, v in conv.state_dict().items()})
+    rb.load_state_dict({n: v.cpu().double() if v.dtype.is_floating_point else v.cpu() for n, v in bn.state_dict().items()})
+    xd = x.cpu().double().requires_grad_(True)
+    yd = torch.relu(rb(rc(xd)))
+    yd.backward(gy.cpu().double())
+    pairs = [("dx", xg.grad, xd.grad), ("dw", conv.weight.grad, rc.weight.grad), ("dgamma", bn.weight.grad, rb.weight.grad),
+             ("dbeta", bn.bias.grad, rb.bias.grad)]
+    if bias:
+        pairs.append(("dbias", conv.bias.grad, rc.bias.grad))
+    for name, a, b in pairs:
+        assert float((a.cpu().double() - b).abs().max()) <= 2e-4 * float(b.abs().max()) + 1e-9, name
+
+
+def test_stage_of_bottlenecks_with_gated_data_gradients():
+    """A stage as ResNet.make_layer builds it (projection block + identity blocks in an nn.Sequential): the blocks after
+    the first are the only readers of their inputs, so every ReLU mask inside the stage is applied in the consuming
+    layer's data-gradient epilogue (conv.Gate) -- values and ALL gradients against the same stage in float64, with and
+    without the gradient arena of a model-level prepare_step."""
+    import torch.nn as nn
+    from feature_intertwiner_amd import conv as C
+    from feature_intertwiner_amd.sub_module import ResNet
+    torch.manual_seed(5)
+    net = ResNet("resnet50")
+    net.inplanes = 64
+    stage = net.make_layer(net.block, 32, 3, stride=2)
+    for m in stage.modules():
+        if isinstance(m, nn.BatchNorm2d):
+            m.weight.data.uniform_(0.5, 1.5)
+            m.bias.data.normal_(0, 0.1)
+            m.running_mean.normal_(0, 0.1)
+            m.running_var.uniform_(0.5, 1.5)
+    stage.eval()
+    assert [b.input_sole for b in stage] == [False, True, True]
+
+    def ref_block(x, sd, p, stride, proj):
+        c = lambda name, inp, st=1, pd=0: F.conv2d(inp, sd[p + name + ".weight"], sd[p + name + ".bias"], stride=st, padding=pd)
+        bn = lambda name, inp: F.batch_norm(inp, sd[p + name + ".running_mean"], sd[p + name + ".running_var"],
+                                            sd[p + name + ".weight"], sd[p + name + ".bias"], False, 0.0, 0.001)
+        out = F.relu(bn("bn1", c("conv1", x, stride)))
+        out = F.relu(bn("bn2", c("conv2", out, 1, 1)))
+        out = bn("bn3", c("conv3", out))
+        res = bn("downsample.1", c("downsample.0", x, stride)) if proj else x
+        return F.relu(out + res)
+
+    x = torch.randn(2, 64, 32, 48)
+    sd = {k: v.detach().double().requires_grad_("running" not in k) for k, v in stage.state_dict().items()
+          if v.dtype.is_floating_point}
+    xd = x.double().requires_grad_(True)
+    yd = xd * 1.0
+    for i in range(3):
+        yd = ref_block(yd, sd, "%d." % i, 2 if i == 0 else 1, i == 0)
+    gy = torch.randn(yd.shape)
+    yd.backward(gy.double())
+    stage = stage.to(DEV)
+    tol = lambda ref: 3e-4 * (ref.abs().max().item() + 1e-6)
+    for arena in (False, True):
+        for p in stage.parameters():
+            p.grad = None
+        if arena:
+            C.prepare_step(stage)
+            C.prepare_step(stage)          # the second call knows the (conv, bn) pairs: scaled W^T from the batched transpose
+        xg = x.to(DEV).requires_grad_(True)
+        y = stage(xg * 1.0)
+        claimed = [getattr(t, "claimed", None) for t in ()]
+        y.backward(gy.to(DEV))
+        torch.cuda.synchronize()
+        assert (y.detach().cpu().double() - yd.detach()).abs().max().item() <= tol(yd.detach())
+        assert (xg.grad.cpu().double() - xd.grad).abs().max().item() <= tol(xd.grad), arena
+        for k, p in stage.named_parameters():
+            assert p.grad is not None, k
+            assert (p.grad.cpu().double() - sd[k].grad).abs().max().item() <= tol(sd[k].grad), (k, arena)
+    C.invalidate_step_state()
