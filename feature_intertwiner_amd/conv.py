@@ -170,12 +170,13 @@ def _conv_fwd(x, w, b, stride, padding, relu=False, scale=None, residual=None, o
 
 class _Conv2dFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, b, stride, padding, residual=None):
+    def forward(ctx, x, w, b, stride, padding, residual=None, dx_gate=False):
         _lib.require_cuda(x, w)
         x = x.contiguous().float()
         w = _dense(w.float())
         bc = b.contiguous().float() if b is not None else None
         ctx.save_for_backward(x, w)
+        ctx.dx_gate = bool(dx_gate)
         ctx.conf = (tuple(stride), tuple(padding), b is not None)
         ctx.bias_ptr = b.data_ptr() if b is not None else 0
         ctx.precision = _PRECISION
@@ -190,11 +191,12 @@ class _Conv2dFn(torch.autograd.Function):
         dy = dy.contiguous().float()
         if has_bias and ctx.needs_input_grad[2]:
             dx, dw, db = _conv_backward(ctx.needs_input_grad, x, w, dy, stride, padding, want_db=True,
-                                        precision=ctx.precision, bias_ptr=ctx.bias_ptr)
+                                        precision=ctx.precision, bias_ptr=ctx.bias_ptr, gate=x if ctx.dx_gate else None)
         else:
-            dx, dw = _conv_backward(ctx.needs_input_grad, x, w, dy, stride, padding, precision=ctx.precision)
+            dx, dw = _conv_backward(ctx.needs_input_grad, x, w, dy, stride, padding, precision=ctx.precision,
+                                    gate=x if ctx.dx_gate else None)
             db = None
-        return dx, dw, db, None, None, (dy if ctx.needs_input_grad[5] else None)
+        return dx, dw, db, None, None, (dy if ctx.needs_input_grad[5] else None), None
 
 
 def _class_taps(a, size_k, s, p):
@@ -333,7 +335,11 @@ def _conv_backward(ctx_needs, x, w, dz, stride, padding, want_db=False, add_to_d
                     gate = None
             else:
                 wt = w_eff().flip(2, 3).transpose(0, 1).contiguous()          # [Cin, Cout, R, S]
-                dx = _conv_fwd(dz, wt, None, (1, 1), (R - 1 - padding[0], S - 1 - padding[1]), precision=precision)
+                fuse = gate_in_kernel and (add_to_dx is None or torch.is_tensor(add_to_dx))
+                dx = _conv_fwd(dz, wt, None, (1, 1), (R - 1 - padding[0], S - 1 - padding[1]), precision=precision,
+                               residual=add_to_dx if fuse else None, gate=gate if fuse else None)
+                if fuse:
+                    add_to_dx = gate = None
             if add_to_dx is not None:
                 dx = dx + add_to_dx
         elif stride == (2, 2) and R * S == 1 and padding == (0, 0) and Cout % 16 == 0 and Cin % 16 == 0:
@@ -829,7 +835,7 @@ class _ConvBiasActFn(torch.autograd.Function):
     together (instead of threshold_backward + a separate reduction)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, stride, padding):
+    def forward(ctx, x, w, b, stride, padding, out_gate=None):
         _lib.require_cuda(x, w)
         x = x.contiguous().float()
         w = _dense(w.float())
@@ -838,6 +844,7 @@ class _ConvBiasActFn(torch.autograd.Function):
         y = _conv_fwd(x, w, bc, stride, padding, relu=True)
         ctx.save_for_backward(x, w, y)
         ctx.precision = _PRECISION
+        ctx.out_gate = out_gate
         ctx.conf = (tuple(stride), tuple(padding), b is not None)
         ctx.bias_ptr = b.data_ptr() if b is not None else 0
         return y
@@ -848,6 +855,15 @@ class _ConvBiasActFn(torch.autograd.Function):
         stride, padding, has_bias = ctx.conf
         L = _lib.load()
         dy = dy.contiguous().float()
+        if ctx.out_gate is not None and ctx.out_gate.claimed and ctx.precision not in _LOWP:
+            # the only reader of y applied the ReLU mask in its data-gradient epilogue (Gate): dy IS the masked
+            # gradient; the bias gradient comes out of the weight-gradient kernel's pass over it
+            if has_bias and ctx.needs_input_grad[2] and ctx.needs_input_grad[1]:
+                return _conv_backward(ctx.needs_input_grad, x, w, dy, stride, padding, want_db=True,
+                                      precision=ctx.precision, bias_ptr=ctx.bias_ptr) + (None, None, None)
+            dx, dw = _conv_backward(ctx.needs_input_grad, x, w, dy, stride, padding, precision=ctx.precision)
+            db = dy.sum((0, 2, 3)) if (has_bias and ctx.needs_input_grad[2]) else None
+            return dx, dw, db, None, None, None
         N, C, OH, OW = y.shape
         dz = torch.empty_like(y)
         ones = _ones(C, y.device)
@@ -861,7 +877,7 @@ class _ConvBiasActFn(torch.autograd.Function):
                                             _lib.ptr(dz), None, _lib.ptr(dshift), None, None, 0, flags,
                                             _lib.current_stream()), "fi_bn_act_backward")
         dx, dw = _conv_backward(ctx.needs_input_grad, x, w, dz, stride, padding, precision=ctx.precision)
-        return dx, dw, (dshift if (has_bias and ctx.needs_input_grad[2] and first) else None), None, None
+        return dx, dw, (dshift if (has_bias and ctx.needs_input_grad[2] and first) else None), None, None, None
 
 
 _ONES = {}
@@ -877,8 +893,24 @@ def _ones(n, device):
 
 
 def conv_bias_relu(x, weight, bias=None, stride=(1, 1), padding=(0, 0)):
-    """relu(conv2d(x, weight, bias)) fused (weight [Cout, Cin, R, S])."""
-    return _ConvBiasActFn.apply(x, weight, bias, tuple(stride), tuple(padding))
+    """relu(conv2d(x, weight, bias)) fused (weight [Cout, Cin, R, S]).  The result carries a Gate (see there)."""
+    gate = Gate() if (torch.is_grad_enabled() and x.is_cuda) else None
+    y = _ConvBiasActFn.apply(x, weight, bias, tuple(stride), tuple(padding), gate)
+    if gate is not None:
+        y._fi_gate = gate
+    return y
+
+
+def _claim_gate(x, gate_dx):
+    """gate_dx: True (x itself carries the Gate) or the Gate of the tensor x is a view of.  Claims it; returns whether
+    this layer has to apply the mask (x > 0) to its data gradient."""
+    if not gate_dx or not (torch.is_grad_enabled() and x.is_cuda and x.requires_grad):
+        return False
+    tok = gate_dx if isinstance(gate_dx, Gate) else getattr(x, "_fi_gate", None)
+    if tok is None:
+        return False
+    tok.claimed = True
+    return True
 
 
 # ---- eval-BN fold (scale, shift) for every (conv, bn) pair, refreshed once per step ------------
@@ -996,13 +1028,11 @@ def conv_bn_act(x, conv, bn, relu=True, residual=None, channels_last_out=False, 
     out_cl = bool(channels_last_out) and residual is None and conv.weight.shape[0] % 4 == 0
     _FOLD_PAIRS[bn] = conv
     track = torch.is_grad_enabled() and x.is_cuda
-    claim = getattr(x, "_fi_gate", None) if (gate_dx and track and x.requires_grad) else None
-    if claim is not None:
-        claim.claimed = True
+    claimed = _claim_gate(x, gate_dx)
     out_gate = Gate() if (relu and track and not out_cl) else None
     y = _ConvBnActFn.apply(x, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                            bn.eps, residual, relu, tuple(conv.stride), tuple(conv.padding), out_cl,
-                           _cached_fold(conv, bn), res_grad_to, dx_add_from, dx_give_to, claim is not None, out_gate)
+                           _cached_fold(conv, bn), res_grad_to, dx_add_from, dx_give_to, claimed, out_gate)
     if out_gate is not None:
         y._fi_gate = out_gate
     return y.contiguous(memory_format=torch.channels_last) if (channels_last_out and not out_cl) else y
@@ -1108,9 +1138,9 @@ def linear(x, weight, bias=None):
     return _LinearFn.apply(x, weight, bias)
 
 
-def conv2d(x, weight, bias=None, stride=(1, 1), padding=(0, 0), residual=None):
+def conv2d(x, weight, bias=None, stride=(1, 1), padding=(0, 0), residual=None, gate_dx=False):
     """Functional form: conv(x) + bias [+ residual, added in the kernel epilogue].  Full-window kernels are
-    matrix products (linear() above)."""
+    matrix products (linear() above).  gate_dx: as conv_bn_act's (True, or the Gate of the tensor x is a view of)."""
     R, S = weight.shape[2], weight.shape[3]
     gemm = ((x.shape[2], x.shape[3]) == (R, S) and tuple(padding) == (0, 0) and R * S > 1) or \
         (x.shape[2] * x.shape[3] == 1 and R * S == 1)
@@ -1118,7 +1148,7 @@ def conv2d(x, weight, bias=None, stride=(1, 1), padding=(0, 0), residual=None):
         y = linear(x.reshape(x.shape[0], -1), weight.reshape(weight.shape[0], -1), bias)
         y = y.view(x.shape[0], weight.shape[0], 1, 1)
         return y if residual is None else y + residual
-    return _Conv2dFn.apply(x, weight, bias, tuple(stride), tuple(padding), residual)
+    return _Conv2dFn.apply(x, weight, bias, tuple(stride), tuple(padding), residual, _claim_gate(x, gate_dx))
 
 
 class Conv2d(nn.Conv2d):
@@ -1158,7 +1188,10 @@ class ConvTranspose2x2(nn.ConvTranspose2d):
         w = self.weight.permute(2, 3, 1, 0).reshape(4 * cout, cin, 1, 1)       # output channels ordered (a, b, c)
         b = self.bias.repeat(4) if self.bias is not None else None
         y = conv_bias_relu(x, w, b) if relu else conv2d(x, w, b)
-        return y.view(x.shape[0], 2, 2, cout, x.shape[2], x.shape[3])
+        u = y.view(x.shape[0], 2, 2, cout, x.shape[2], x.shape[3])
+        if getattr(y, "_fi_gate", None) is not None:
+            u._fi_gate = y._fi_gate           # a view of y: its only reader may claim the Gate (conv2d(gate_dx=...))
+        return u
 
 
 class Conv1d(nn.Conv1d):

@@ -257,7 +257,7 @@ class RPN(nn.Module):
         # weight gradient, and autograd has no two data gradients to add
         ncls = self.conv_class.weight.shape[0]
         both = conv2d(x, torch.cat((self.conv_class.weight, self.conv_bbox.weight), 0),
-                      torch.cat((self.conv_class.bias, self.conv_bbox.bias), 0))
+                      torch.cat((self.conv_class.bias, self.conv_bbox.bias), 0), gate_dx=True)    # x's only reader
         logits = both[:, :ncls].permute(0, 2, 3, 1).contiguous().view(x.size(0), -1, 2)
         probs = self.softmax(logits)
         bbox = both[:, ncls:].permute(0, 2, 3, 1).contiguous().view(x.size(0), -1, 4)
@@ -564,7 +564,7 @@ class Mask(nn.Module):
             pad = (-K) % 16
             w5 = torch.cat((self.conv5.weight, self.conv5.weight.new_zeros(pad, *self.conv5.weight.shape[1:])), 0)
             b5 = torch.cat((self.conv5.bias, self.conv5.bias.new_zeros(pad))) if self.conv5.bias is not None else None
-            y = conv2d(u.view(n * 4, u.shape[3], h, w), w5, b5)
+            y = conv2d(u.view(n * 4, u.shape[3], h, w), w5, b5, gate_dx=getattr(u, "_fi_gate", None))    # u's only reader
         if activate:
             y = self.sigmoid(y)
         y = y.view(n, 2, 2, y.shape[1], h, w)

@@ -558,3 +558,34 @@ def test_stage_of_bottlenecks_with_gated_data_gradients():
             assert p.grad is not None, k
             assert (p.grad.cpu().double() - sd[k].grad).abs().max().item() <= tol(sd[k].grad), (k, arena)
     C.invalidate_step_state()
+
+
+def test_gate_between_conv_bias_relu_and_its_only_reader():
+    """conv + bias + ReLU whose output feeds ONE plain convolution (the RPN's shared conv -> stacked heads, the mask
+    head's deconv -> conv5 through a view): the reader masks its data gradient, the producer takes the bias gradient
+    from its weight-gradient kernel.  Against float64 autograd, single use and a layer applied twice (two pyramid levels)."""
+    from feature_intertwiner_amd import conv as C
+    torch.manual_seed(9)
+    shared = C.Conv2d(32, 64, 3, padding=1).to(DEV)
+    head = C.Conv2d(64, 18, 1).to(DEV)
+    rs, rh = torch.nn.Conv2d(32, 64, 3, padding=1).double(), torch.nn.Conv2d(64, 18, 1).double()
+    rs.load_state_dict({k: v.cpu().double() for k, v in shared.state_dict().items()})
+    rh.load_state_dict({k: v.cpu().double() for k, v in head.state_dict().items()})
+    xs = [torch.randn(2, 32, 24, 16), torch.randn(2, 32, 12, 8)]
+    xg = [x.to(DEV).requires_grad_(True) for x in xs]
+    xd = [x.double().requires_grad_(True) for x in xs]
+    tot, totd, gates = 0.0, 0.0, []
+    for a, b in zip(xg, xd):
+        y = C.conv_bias_relu(a, shared.weight, shared.bias, (1, 1), (1, 1))
+        gates.append(y._fi_gate)
+        o = C.conv2d(y.view(y.shape), head.weight, head.bias, gate_dx=y._fi_gate)       # through a view, like the mask head
+        gy = torch.randn(o.shape)
+        tot = tot + (o * gy.to(DEV)).sum()
+        totd = totd + (rh(torch.relu(rs(b))) * gy.double()).sum()
+    assert all(g.claimed for g in gates)
+    tot.backward()
+    totd.backward()
+    pairs = [(xg[0].grad, xd[0].grad), (xg[1].grad, xd[1].grad), (shared.weight.grad, rs.weight.grad),
+             (shared.bias.grad, rs.bias.grad), (head.weight.grad, rh.weight.grad), (head.bias.grad, rh.bias.grad)]
+    for i, (a, b) in enumerate(pairs):
+        assert float((a.cpu().double() - b).abs().max()) <= 2e-4 * float(b.abs().max()) + 1e-9, i
