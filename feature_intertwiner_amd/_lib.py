@@ -62,6 +62,14 @@ SIGNATURES = {
     "fi_conv2d_forward": (c_int, [c_void_p] * 6 + [c_int] * 16 + [c_void_p]),
     "fi_bn_act_backward": (c_int, [c_void_p] * 6 + [c_int] * 4 + [c_void_p] * 5 + [c_int, c_int, c_void_p]),
     "fi_conv2d_weight_grad": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 12 + [c_void_p, c_int, c_void_p]),
+    "fi_conv2d_forward_gated_bf16": (c_int, [c_void_p] * 7 + [c_int] * 16 + [c_void_p]),
+    "fi_conv3x3_forward_gated_bf16w": (c_int, [c_void_p] * 7 + [c_int] * 7 + [c_void_p]),
+    "fi_conv1x1_forward_gated_bf16w": (c_int, [c_void_p] * 7 + [c_int] * 5 + [c_void_p]),
+    "fi_conv2d_weight_grad_db_bf16": (c_int, [c_void_p] * 4 + [c_int] * 12 + [c_void_p]),
+    "fi_conv2d_forward_gated_f16": (c_int, [c_void_p] * 7 + [c_int] * 16 + [c_void_p]),
+    "fi_conv3x3_forward_gated_f16w": (c_int, [c_void_p] * 7 + [c_int] * 7 + [c_void_p]),
+    "fi_conv1x1_forward_gated_f16w": (c_int, [c_void_p] * 7 + [c_int] * 5 + [c_void_p]),
+    "fi_conv2d_weight_grad_db_f16": (c_int, [c_void_p] * 4 + [c_int] * 12 + [c_void_p]),
     "fi_conv2d_forward_bf16": (c_int, [c_void_p] * 6 + [c_int] * 16 + [c_void_p]),
     "fi_conv2d_weight_grad_bf16": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 12 + [c_void_p]),
     "fi_conv2d_forward_f16": (c_int, [c_void_p] * 6 + [c_int] * 16 + [c_void_p]),

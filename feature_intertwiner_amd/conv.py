@@ -117,16 +117,9 @@ def _conv_fwd(x, w, b, stride, padding, relu=False, scale=None, residual=None, o
                     memory_format=torch.channels_last if out_channels_last else torch.contiguous_format)
     bf16 = prec in _LOWP and layout >= 1 and Cin % 32 == 0          # "bf16" here and below: either 16-bit operand type
     if gate is not None:
-        # y * (gate > 0) in the epilogue (fp32 kernels): the data gradient of a layer whose input is a ReLU output
-        assert not bf16 and not out_channels_last and gate.shape == y.shape and gate.is_contiguous()
-        with torch.cuda.device(x.device):
-            _lib.check(L.fi_conv2d_forward_gated(_lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(scale), _lib.ptr(residual),
-                                                 _lib.ptr(gate), _lib.ptr(y), N, Cin, H, W, Cout, R, S, stride[0], stride[1],
-                                                 padding[0], padding[1], 1 if relu else 0, layout,
-                                                 OH if out_hw is not None else 0, OW if out_hw is not None else 0, 0,
-                                                 _lib.current_stream()), "fi_conv2d_forward_gated")
-        return y
-    fn = _lowp_fn(L, "conv2d_forward", prec) if bf16 else L.fi_conv2d_forward
+        # y * (gate > 0) in the epilogue: the data gradient of a layer whose input is a ReLU output
+        assert not out_channels_last and gate.shape == y.shape and gate.is_contiguous()
+    fn = _lowp_fn(L, "conv2d_forward_gated", prec) if bf16 else L.fi_conv2d_forward_gated
     if bf16:
         _log_flops("bf16_fwd", Cout, R, S, 2 * N * Cout * OH * OW * Cin * R * S)
         # 3x3 / stride 1 / pad 1 on maps whose width is a multiple of 16 (or 14-wide RoI maps): patch kernel with the
@@ -138,11 +131,11 @@ def _conv_fwd(x, w, b, stride, padding, relu=False, scale=None, residual=None, o
             ((N * H * W + 127) // 128) * mt >= 512
         if (R, S) == (3, 3) and tuple(stride) == (1, 1) and tuple(padding) == (1, 1) and (OH, OW) == (H, W) and \
                 (tiled or flat) and Cout > 64 and not out_channels_last and out_hw is None and \
-                (residual is None or residual.data_ptr() % 16 == 0):
+                (residual is None or residual.data_ptr() % 16 == 0) and (gate is None or gate.data_ptr() % 16 == 0):
             wb = _cached_bf16(w, _LOWP[prec][1])
             with torch.cuda.device(x.device):
-                _lib.check(_lowp_fn(L, "conv3x3_forward", prec, "w")(_lib.ptr(x), _lib.ptr(wb), _lib.ptr(b), _lib.ptr(scale),
-                                                      _lib.ptr(residual), _lib.ptr(y), N, Cin, H, W, Cout,
+                _lib.check(_lowp_fn(L, "conv3x3_forward_gated", prec, "w")(_lib.ptr(x), _lib.ptr(wb), _lib.ptr(b), _lib.ptr(scale),
+                                                      _lib.ptr(residual), _lib.ptr(gate), _lib.ptr(y), N, Cin, H, W, Cout,
                                                       1 if relu else 0, 1 if layout == 2 else 0, _lib.current_stream()),
                            "fi_conv3x3_forward_bf16w")
             return y
@@ -150,16 +143,16 @@ def _conv_fwd(x, w, b, stride, padding, relu=False, scale=None, residual=None, o
         if (R, S) == (1, 1) and tuple(stride) == (1, 1) and tuple(padding) == (0, 0) and (H * W) % 4 == 0 and \
                 Cin % 64 == 0 and Cout > 64 and not out_channels_last and out_hw is None and \
                 ((N * H * W + 127) // 128) * ((Cout + 127) // 128) >= 192 and \
-                (residual is None or residual.data_ptr() % 16 == 0):
+                (residual is None or residual.data_ptr() % 16 == 0) and (gate is None or gate.data_ptr() % 16 == 0):
             wb = _cached_bf16(w, _LOWP[prec][1])
             with torch.cuda.device(x.device):
-                _lib.check(_lowp_fn(L, "conv1x1_forward", prec, "w")(_lib.ptr(x), _lib.ptr(wb), _lib.ptr(b), _lib.ptr(scale),
-                                                      _lib.ptr(residual), _lib.ptr(y), N, Cin, H * W, Cout,
+                _lib.check(_lowp_fn(L, "conv1x1_forward_gated", prec, "w")(_lib.ptr(x), _lib.ptr(wb), _lib.ptr(b), _lib.ptr(scale),
+                                                      _lib.ptr(residual), _lib.ptr(gate), _lib.ptr(y), N, Cin, H * W, Cout,
                                                       1 if relu else 0, _lib.current_stream()),
                            "fi_conv1x1_forward_bf16w")
             return y
     with torch.cuda.device(x.device):
-        _lib.check(fn(_lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(scale), _lib.ptr(residual),
+        _lib.check(fn(_lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(scale), _lib.ptr(residual), _lib.ptr(gate),
                                        _lib.ptr(y), N, Cin, H, W, Cout,
                                        R, S, stride[0], stride[1], padding[0], padding[1], 1 if relu else 0,
                                        layout, OH if out_hw is not None else 0, OW if out_hw is not None else 0,
@@ -318,7 +311,7 @@ def _conv_backward(ctx_needs, x, w, dz, stride, padding, want_db=False, add_to_d
 
         def w_eff():
             return w * w_scale.view(-1, 1, 1, 1) if scaled else w
-        gate_in_kernel = gate is not None and precision not in _LOWP and gate.is_contiguous()
+        gate_in_kernel = gate is not None and gate.is_contiguous()
         if stride == (1, 1):
             if Cout % 16 == 0 and R * S <= 64:
                 # transposed weight in the kernel's tap-major layout [Cin, R, S, Cout]: re-laid-out for all
@@ -380,12 +373,12 @@ def _conv_backward(ctx_needs, x, w, dz, stride, padding, want_db=False, add_to_d
         # With want_db the fp32 kernel accumulates the bias gradient too: both outputs must be pre-zeroed slots, or
         # the kernel clears both itself.
         db_slot = None
-        if want_db and not bf16:
+        if want_db:
             if db_into is not None:
                 db_slot = db_into
             else:
                 db_slot, _ = _arena_take(("db", bias_ptr), Cout) if bias_ptr else (None, False)
-        if want_db and not bf16 and db_slot is None:
+        if want_db and db_slot is None:
             dw, first = None, False
         else:
             dw, first = _arena_take(("dw", w.data_ptr()), Cout * Cin * R * S)
@@ -399,8 +392,7 @@ def _conv_backward(ctx_needs, x, w, dz, stride, padding, want_db=False, add_to_d
         dw = dw.view(shape) if dw is not None else torch.empty(shape, device=x.device, dtype=torch.float32)
         hand_over = first or not flags
         if want_db:
-            db = dz.sum((0, 2, 3)) if bf16 else (db_slot if db_slot is not None else
-                                                 torch.empty(Cout, device=x.device, dtype=torch.float32))
+            db = db_slot if db_slot is not None else torch.empty(Cout, device=x.device, dtype=torch.float32)
         side = None
         # second stream only if autograd will ADOPT dw as the parameter's gradient: a dw whose memory order differs
         # from the parameter's is cloned by AccumulateGrad, on the main stream, while the kernel may still be running
@@ -414,7 +406,8 @@ def _conv_backward(ctx_needs, x, w, dz, stride, padding, want_db=False, add_to_d
         with torch.cuda.device(x.device), (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
             if bf16:
                 _log_flops("bf16_wgrad", Cout, R, S, 2 * N * Cout * dz.shape[2] * dz.shape[3] * Cin * R * S)
-                _lib.check(_lowp_fn(L, "conv2d_weight_grad", precision)(_lib.ptr(x), _lib.ptr(dz), _lib.ptr(dw), N, Cin, H, W, Cout,
+                _lib.check(_lowp_fn(L, "conv2d_weight_grad_db", precision)(_lib.ptr(x), _lib.ptr(dz), _lib.ptr(dw), _lib.ptr(db),
+                                                        N, Cin, H, W, Cout,
                                                         R, S, stride[0], stride[1], padding[0], padding[1], flags,
                                                         _lib.current_stream()), "fi_conv2d_weight_grad_bf16")
             else:
@@ -424,14 +417,14 @@ def _conv_backward(ctx_needs, x, w, dz, stride, padding, want_db=False, add_to_d
                                                    R, S, stride[0], stride[1], padding[0], padding[1], hwc,
                                                    _lib.ptr(db), flags, _lib.current_stream()), "fi_conv2d_weight_grad")
             if after_wgrad is not None:
-                after_wgrad(dw, db, bool(hwc and R * S > 1))
+                after_wgrad(dw, db, bool(hwc and R * S > 1))        # (the 16-bit kernels write tap-major: hwc is set)
         if side is not None:
             _queue_wgrad_join(main, side)
         if hwc and R * S > 1:
             dw = dw.permute(0, 3, 1, 2)
         if not hand_over:
             dw = None                 # accumulated into the slot autograd already holds
-            if want_db and not bf16:
+            if want_db:
                 db = None
     elif want_db:
         db = dz.sum((0, 2, 3))
@@ -604,7 +597,7 @@ def _prepare_step(model, grad_on):
     # (_ConvBnActFn.backward feeds the data-gradient kernel the unscaled masked gradient); the 16-bit kernels keep the
     # plain W^T.  The pairs are known after the first forward pass (conv_bn_act registers them).
     scales = [None] * len(plan["tr"])
-    if grad_on and _PRECISION not in _LOWP and _FOLD_PAIRS and plan["table"] is not None:
+    if grad_on and _FOLD_PAIRS and plan["table"] is not None:
         by_conv = {c: b for b, c in _FOLD_PAIRS.items()}
         for i, m in enumerate(plan["tr"]):
             b = by_conv.get(m)
@@ -770,7 +763,7 @@ class _ConvBnActFn(torch.autograd.Function):
                                          1 if tap_major else 0, 1 if w_tap_major else 0, _lib.current_stream()),
                        "fi_bn_fold_grad")
         dx, dw, _ = _conv_backward(ctx.needs_input_grad, x, w, g, stride, padding, want_db=True, add_to_dx=add,
-                                   precision="fp32", give_compact=ctx.dx_give_to is not None,
+                                   precision=ctx.precision, give_compact=ctx.dx_give_to is not None,
                                    gate=x if ctx.dx_gate else None, w_scale=scale, db_into=sums[:C],
                                    after_wgrad=finish)
         dbeta = out["s"] if want_beta else None
@@ -782,7 +775,7 @@ class _ConvBnActFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        if ctx.precision not in _LOWP and not ctx.out_cl and _UNSCALED_BACKWARD:
+        if not ctx.out_cl and _UNSCALED_BACKWARD:
             r = _ConvBnActFn._backward_unscaled(ctx, dy)
             if r is not None:
                 return r
@@ -855,7 +848,7 @@ class _ConvBiasActFn(torch.autograd.Function):
         stride, padding, has_bias = ctx.conf
         L = _lib.load()
         dy = dy.contiguous().float()
-        if ctx.out_gate is not None and ctx.out_gate.claimed and ctx.precision not in _LOWP:
+        if ctx.out_gate is not None and ctx.out_gate.claimed:
             # the only reader of y applied the ReLU mask in its data-gradient epilogue (Gate): dy IS the masked
             # gradient; the bias gradient comes out of the weight-gradient kernel's pass over it
             if has_bias and ctx.needs_input_grad[2] and ctx.needs_input_grad[1]:

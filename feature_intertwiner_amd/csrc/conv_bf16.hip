@@ -22,6 +22,7 @@
 //   is split across workgroups and accumulated with fp32 atomics (as the fp32 kernel does).
 #include <stdint.h>
 
+#include <algorithm>
 #include <type_traits>
 
 #include "fi_common.h"
@@ -63,6 +64,7 @@ struct Geom {
 struct Epi {
     const float *bias, *scale, *residual;
     int relu;
+    const float *gate;      // shaped like y, or null: y *= (gate > 0) (conv_igemm.hip's Epilogue::gate)
 };
 
 __device__ __forceinline__ bf16x2 pack2(float a, float b)
@@ -93,7 +95,7 @@ __device__ __forceinline__ float pick4(const f32x4 &v, int i)
 // group of 4 rows are issued together instead of one dependent round trip each (the general path's ISA is a
 // chain of `global_load; s_waitcnt vmcnt(0)`: +40 % on a fused 1x1 layer).  Absent scale / bias are dropped by
 // a select so the arithmetic stays `acc [*scale] [+bias] [+shortcut] [relu]`.
-template <int NT, bool HAS_RES>
+template <int NT, bool HAS_RES, bool HAS_GATE>
 __device__ __forceinline__ void epilogue_full_nchw(const f32x16 (&acc)[NT], const Epi &ep, float *__restrict__ y,
                                                    size_t obase, int OHW, int mb)
 {
@@ -106,12 +108,13 @@ __device__ __forceinline__ void epilogue_full_nchw(const f32x16 (&acc)[NT], cons
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         float sc[4], bi[4];
-        f32xN rr[4];
+        f32xN rr[4], gg[4];
 #pragma unroll
         for (int e4 = 0; e4 < 4; ++e4) {
             sc[e4] = sp[(8 * q + e4) * smul];
             bi[e4] = bp[(8 * q + e4) * bmul];
             if (HAS_RES) rr[e4] = *reinterpret_cast<const f32xN_a4 *>(ep.residual + obase + (size_t)(8 * q + e4) * OHW);
+            if (HAS_GATE) gg[e4] = *reinterpret_cast<const f32xN_a4 *>(ep.gate + obase + (size_t)(8 * q + e4) * OHW);
         }
 #pragma unroll
         for (int e4 = 0; e4 < 4; ++e4) {
@@ -122,7 +125,9 @@ __device__ __forceinline__ void epilogue_full_nchw(const f32x16 (&acc)[NT], cons
                 t = has_sc ? t * sc[e4] : t;
                 t = has_bi ? t + bi[e4] : t;
                 if (HAS_RES) t += rr[e4][j];
-                v[j] = relu ? fmaxf(t, 0.0f) : t;
+                t = relu ? fmaxf(t, 0.0f) : t;
+                if (HAS_GATE) t = gg[e4][j] > 0.0f ? t : 0.0f;
+                v[j] = t;
             }
             *reinterpret_cast<f32xN_a4 *>(y + obase + (size_t)(8 * q + e4) * OHW) = v;
         }
@@ -377,10 +382,15 @@ __global__ __launch_bounds__(kThreads, 2) void conv_bf16_fwd_kernel(const float 
         const bool full = !g.out_nhwc && (g.OW & 3) == 0 && p0 + TN <= PV && m0 + BM <= g.Cout;
         if (full) {
             const size_t obase = ((size_t)n * g.Cout + mb) * OHW + rem;
-            if (ep.residual)
-                epilogue_full_nchw<NT, true>(acc, ep, y, obase, OHW, mb);
+            if (ep.gate) {
+                if (ep.residual)
+                    epilogue_full_nchw<NT, true, true>(acc, ep, y, obase, OHW, mb);
+                else
+                    epilogue_full_nchw<NT, false, true>(acc, ep, y, obase, OHW, mb);
+            } else if (ep.residual)
+                epilogue_full_nchw<NT, true, false>(acc, ep, y, obase, OHW, mb);
             else
-                epilogue_full_nchw<NT, false>(acc, ep, y, obase, OHW, mb);
+                epilogue_full_nchw<NT, false, false>(acc, ep, y, obase, OHW, mb);
             return;
         }
         if (nvalid > 0) {
@@ -425,6 +435,11 @@ __global__ __launch_bounds__(kThreads, 2) void conv_bf16_fwd_kernel(const float 
                             f32x4 v;
 #pragma unroll
                             for (int j = 0; j < 4; ++j) v[j] = ep.relu ? fmaxf(t[j], 0.0f) : t[j];
+                            if (ep.gate) {
+                                const f32x4 gg = *reinterpret_cast<const f32x4_a4 *>(ep.gate + o);
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) v[j] = gg[j] > 0.0f ? v[j] : 0.0f;
+                            }
                             *reinterpret_cast<f32x4_a4 *>(y + o) = v;
                         } else {
                             typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -437,6 +452,11 @@ __global__ __launch_bounds__(kThreads, 2) void conv_bf16_fwd_kernel(const float 
                             f32x2 v;
                             v.x = ep.relu ? fmaxf(t[0], 0.0f) : t[0];
                             v.y = ep.relu ? fmaxf(t[1], 0.0f) : t[1];
+                            if (ep.gate) {
+                                const f32x2 gg = *reinterpret_cast<const f32x2_a4 *>(ep.gate + o);
+                                v.x = gg.x > 0.0f ? v.x : 0.0f;
+                                v.y = gg.y > 0.0f ? v.y : 0.0f;
+                            }
                             *reinterpret_cast<f32x2_a4 *>(y + o) = v;
                         }
                     } else {
@@ -445,7 +465,9 @@ __global__ __launch_bounds__(kThreads, 2) void conv_bf16_fwd_kernel(const float 
                             if (j >= nvalid) continue;
                             float u = t[j];
                             if (ep.residual) u += ep.residual[o + j];
-                            y[o + j] = ep.relu ? fmaxf(u, 0.0f) : u;
+                            u = ep.relu ? fmaxf(u, 0.0f) : u;
+                            if (ep.gate) u = ep.gate[o + j] > 0.0f ? u : 0.0f;
+                            y[o + j] = u;
                         }
                     }
                 }
@@ -746,6 +768,11 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_patch_bf16_kernel(const f
                     v0 = fmaxf(v0, 0.0f);
                     v1 = fmaxf(v1, 0.0f);
                 }
+                if (ep.gate) {
+                    const float2 gg = *reinterpret_cast<const float2 *>(ep.gate + o);
+                    v0 = gg.x > 0.0f ? v0 : 0.0f;
+                    v1 = gg.y > 0.0f ? v1 : 0.0f;
+                }
                 *reinterpret_cast<float2 *>(y + o) = make_float2(v0, v1);
             }
         }
@@ -758,10 +785,15 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_patch_bf16_kernel(const f
     const int mb = m0 + wave * 32 + 4 * khalf;
     const size_t obase = ((size_t)n_img * g.Cout + mb) * HW + (size_t)yo * g.W + xo;
     if (m0 + 128 <= g.Cout) {
-        if (ep.residual)
-            epilogue_full_nchw<4, true>(acc, ep, y, obase, (int)HW, mb);
+        if (ep.gate) {
+            if (ep.residual)
+                epilogue_full_nchw<4, true, true>(acc, ep, y, obase, (int)HW, mb);
+            else
+                epilogue_full_nchw<4, false, true>(acc, ep, y, obase, (int)HW, mb);
+        } else if (ep.residual)
+            epilogue_full_nchw<4, true, false>(acc, ep, y, obase, (int)HW, mb);
         else
-            epilogue_full_nchw<4, false>(acc, ep, y, obase, (int)HW, mb);
+            epilogue_full_nchw<4, false, false>(acc, ep, y, obase, (int)HW, mb);
         return;
     }
 #pragma unroll
@@ -775,7 +807,9 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_patch_bf16_kernel(const f
         for (int j = 0; j < 4; ++j) {
             float v = acc[j][e] * sc + bi;
             if (ep.residual) v += ep.residual[o + j];
-            y[o + j] = ep.relu ? fmaxf(v, 0.0f) : v;
+            v = ep.relu ? fmaxf(v, 0.0f) : v;
+            if (ep.gate) v = ep.gate[o + j] > 0.0f ? v : 0.0f;
+            y[o + j] = v;
         }
     }
 }
@@ -908,10 +942,15 @@ __global__ __launch_bounds__(kThreads, 2) void conv1x1_bf16_kernel(const float *
     const int mb = m0 + wave * 32 + 4 * khalf;
     const size_t obase = ((size_t)n_img * g.Cout + mb) * g.HW + (p - n_img * g.HW);
     if (m0 + 128 <= g.Cout) {
-        if (ep.residual)
-            epilogue_full_nchw<4, true>(acc, ep, y, obase, g.HW, mb);
+        if (ep.gate) {
+            if (ep.residual)
+                epilogue_full_nchw<4, true, true>(acc, ep, y, obase, g.HW, mb);
+            else
+                epilogue_full_nchw<4, false, true>(acc, ep, y, obase, g.HW, mb);
+        } else if (ep.residual)
+            epilogue_full_nchw<4, true, false>(acc, ep, y, obase, g.HW, mb);
         else
-            epilogue_full_nchw<4, false>(acc, ep, y, obase, g.HW, mb);
+            epilogue_full_nchw<4, false, false>(acc, ep, y, obase, g.HW, mb);
         return;
     }
 #pragma unroll
@@ -925,7 +964,9 @@ __global__ __launch_bounds__(kThreads, 2) void conv1x1_bf16_kernel(const float *
         for (int j = 0; j < 4; ++j) {
             float v = acc[j][e] * sc + bi;
             if (ep.residual) v += ep.residual[o + j];
-            y[o + j] = ep.relu ? fmaxf(v, 0.0f) : v;
+            v = ep.relu ? fmaxf(v, 0.0f) : v;
+            if (ep.gate) v = ep.gate[o + j] > 0.0f ? v : 0.0f;
+            y[o + j] = v;
         }
     }
 }
@@ -1312,7 +1353,8 @@ template <int BM, int BNC, bool K3>
 __global__ __launch_bounds__(kThreads, 2) void conv_bf16_wgrad_flat_kernel(const float *__restrict__ x,
                                                                            const float *__restrict__ dy,
                                                                            float *__restrict__ dw, Geom g, int cin_tiles,
-                                                                           int p_per_split, int mtiles, int splits)
+                                                                           int p_per_split, int mtiles, int splits,
+                                                                           float *__restrict__ dbias)
 {
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     constexpr int MT = BM / 64, NT = BNC / 64;
@@ -1433,9 +1475,21 @@ __global__ __launch_bounds__(kThreads, 2) void conv_bf16_wgrad_flat_kernel(const
         o[3] = (E16)__uint_as_float(v.w);
         return o;
     };
+    // dbias[m] = sum over pixels of dy[m]: the workgroups of (tap 0, ci tile 0) add up the fp32 dY values they stage
+    // anyway (every pixel split has exactly one such workgroup per Cout tile)
+    const bool bias_sums = dbias != nullptr && by == 0;
+    float bsum[AV];
+#pragma unroll
+    for (int i = 0; i < AV; ++i) bsum[i] = 0.0f;
     auto store_tile = [&](int buf, Regs &R) {
 #pragma unroll
         for (int i = 0; i < AV; ++i) *reinterpret_cast<bf16x4 *>(&As[buf][lr + 16 * i][4 * gq]) = cvt4(R.a[i]);
+        if (bias_sums) {
+#pragma unroll
+            for (int i = 0; i < AV; ++i)
+                bsum[i] += (__uint_as_float(R.a[i].x) + __uint_as_float(R.a[i].y)) +
+                           (__uint_as_float(R.a[i].z) + __uint_as_float(R.a[i].w));
+        }
         if (K3 && R.mk != 0xFu) {                               // a row end / image edge inside the group: rare
             const unsigned mk = R.mk;
             if (neg_block && R.bo < 0 && R.bo > -16) {          // loaded from offset 0: element e holds x[e], wanted x[e - k]
@@ -1498,6 +1552,17 @@ __global__ __launch_bounds__(kThreads, 2) void conv_bf16_wgrad_flat_kernel(const
         __syncthreads();
     }
 
+    if (bias_sums) {
+#pragma unroll
+        for (int i = 0; i < AV; ++i) {
+            float v = bsum[i];                      // the 16 threads of a row (gq = lane & 15) hold its pixel groups
+            v += __shfl_xor(v, 8, 64);
+            v += __shfl_xor(v, 4, 64);
+            v += __shfl_xor(v, 2, 64);
+            v += __shfl_xor(v, 1, 64);
+            if (gq == 0) atomicAdd(dbias + m0 + lr + 16 * i, v);
+        }
+    }
     // dW[m][tap][ci]: lanes run over ci (contiguous) -> coalesced fp32 atomics
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
@@ -1512,6 +1577,24 @@ __global__ __launch_bounds__(kThreads, 2) void conv_bf16_wgrad_flat_kernel(const
             }
         }
     }
+}
+
+// dbias[c] += sum over images and pixels of dy[n][c][p] for the layers the flat weight-gradient kernel does not serve
+__global__ __launch_bounds__(256) void channel_sum_kernel(const float *__restrict__ dy, float *__restrict__ dbias, int N,
+                                                          int C, int HW)
+{
+    __shared__ float part[4];
+    const int c = blockIdx.x;
+    float s = 0.0f;
+    for (int n = blockIdx.y; n < N; n += gridDim.y) {
+        const float *__restrict__ p = dy + ((size_t)n * C + c) * HW;
+        for (int i = threadIdx.x; i < HW; i += 256) s += p[i];
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(dbias + c, (part[0] + part[1]) + (part[2] + part[3]));
 }
 
 int make_geom(Geom &g, int N, int Cin, int H, int W, int Cout, int R, int S, int sh, int sw, int ph, int pw,
@@ -1539,6 +1622,16 @@ int FI16(fi_conv2d_forward, )(const float *x, const float *weight, const float *
                            int S, int stride_h, int stride_w, int pad_h, int pad_w, int relu,
                            int weight_layout, int out_h, int out_w, int output_layout, fi_stream_t stream)
 {
+    return FI16(fi_conv2d_forward_gated, )(x, weight, bias, scale, residual, nullptr, y, N, Cin, H, W, Cout, R, S, stride_h,
+                                           stride_w, pad_h, pad_w, relu, weight_layout, out_h, out_w, output_layout,
+                                           stream);
+}
+
+int FI16(fi_conv2d_forward_gated, )(const float *x, const float *weight, const float *bias, const float *scale,
+                                 const float *residual, const float *gate, float *y, int N, int Cin, int H, int W,
+                                 int Cout, int R, int S, int stride_h, int stride_w, int pad_h, int pad_w, int relu,
+                                 int weight_layout, int out_h, int out_w, int output_layout, fi_stream_t stream)
+{
     Geom g;
     int rc = make_geom(g, N, Cin, H, W, Cout, R, S, stride_h, stride_w, pad_h, pad_w, out_h, out_w);
     if (rc != FI_OK) return rc;
@@ -1548,18 +1641,18 @@ int FI16(fi_conv2d_forward, )(const float *x, const float *weight, const float *
                       weight_layout);
         return FI_ERR_UNSUPPORTED;
     }
-    FI_REQUIRE(output_layout == 0 || (Cout % 4 == 0 && residual == nullptr && (uintptr_t)y % 16 == 0),
-               "channels-last output needs Cout % 4 == 0, a 16-byte aligned y and no fused residual");
+    FI_REQUIRE(output_layout == 0 || (Cout % 4 == 0 && residual == nullptr && gate == nullptr && (uintptr_t)y % 16 == 0),
+               "channels-last output needs Cout % 4 == 0, a 16-byte aligned y and no fused residual / gate");
     FI_REQUIRE(((uintptr_t)weight % 16) == 0, "weights must be 16-byte aligned");
     g.flip = weight_layout == 2;
     g.out_nhwc = output_layout == 1;
-    const Epi ep = {bias, scale, residual, relu};
+    const Epi ep = {bias, scale, residual, relu, gate};
     hipStream_t st = (hipStream_t)stream;
     // 3x3 / stride 1 / pad 1 on maps at least 16 columns wide (whole 4-column groups): input patch in LDS
     if (!getenv("FI_NO_PATCH") && R == 3 && S == 3 && stride_h == 1 && stride_w == 1 && pad_h == 1 && pad_w == 1 &&
         g.OH == H && g.OW == W && W % 4 == 0 && W >= PB_TW && !g.out_nhwc && Cout > 64 && weight_layout >= 1 &&
         (uintptr_t)x % 16 == 0 && (uintptr_t)y % 16 == 0 && (residual == nullptr || (uintptr_t)residual % 16 == 0) &&
-        (long)N * Cin * H * W < 2147483647L && (long)N * Cout * H * W < 2147483647L) {
+        (gate == nullptr || (uintptr_t)gate % 16 == 0) && (long)N * Cin * H * W < 2147483647L && (long)N * Cout * H * W < 2147483647L) {
         PatchGeomB pg;
         pg.N = N; pg.Cin = Cin; pg.H = H; pg.W = W; pg.Cout = Cout;
         pg.flip = g.flip;
@@ -1596,6 +1689,14 @@ int FI16(fi_conv3x3_forward, w)(const float *x, const uint16_t *weight_bf16, con
                              const float *residual, float *y, int N, int Cin, int H, int W, int Cout, int relu,
                              int flip_taps, fi_stream_t stream)
 {
+    return FI16(fi_conv3x3_forward_gated, w)(x, weight_bf16, bias, scale, residual, nullptr, y, N, Cin, H, W, Cout, relu,
+                                             flip_taps, stream);
+}
+
+int FI16(fi_conv3x3_forward_gated, w)(const float *x, const uint16_t *weight_bf16, const float *bias, const float *scale,
+                                   const float *residual, const float *gate, float *y, int N, int Cin, int H, int W,
+                                   int Cout, int relu, int flip_taps, fi_stream_t stream)
+{
     FI_REQUIRE(N >= 1 && Cin >= 1 && H >= 1 && W >= 1 && Cout >= 1, "sizes must be positive");
     FI_REQUIRE(x && weight_bf16 && y, "null pointer");
     // 2-D tiles: width a multiple of 4, at least 16 (a width that is not a multiple of 16 leaves the last column tile
@@ -1608,7 +1709,8 @@ int FI16(fi_conv3x3_forward, w)(const float *x, const uint16_t *weight_bf16, con
         return FI_ERR_UNSUPPORTED;
     }
     FI_REQUIRE((uintptr_t)x % 16 == 0 && (uintptr_t)y % 16 == 0 && (uintptr_t)weight_bf16 % 16 == 0 &&
-               (residual == nullptr || (uintptr_t)residual % 16 == 0), "16-byte aligned tensors required");
+               (residual == nullptr || (uintptr_t)residual % 16 == 0) && (gate == nullptr || (uintptr_t)gate % 16 == 0),
+               "16-byte aligned tensors required");
     FI_REQUIRE((long)N * Cin * H * W < 2147483647L && (long)N * Cout * H * W < 2147483647L, "tensor too large");
     PatchGeomB pg;
     pg.N = N; pg.Cin = Cin; pg.H = H; pg.W = W; pg.Cout = Cout;
@@ -1616,7 +1718,7 @@ int FI16(fi_conv3x3_forward, w)(const float *x, const uint16_t *weight_bf16, con
     pg.tiles_x = flat ? 1 : fi::ceil_div(W, PB_TW);
     pg.ptiles = flat ? fi::ceil_div(N * H * W, 128) : fi::ceil_div(N * H, PB_TH) * pg.tiles_x;
     pg.mtiles = fi::ceil_div(Cout, 128);
-    const Epi ep = {bias, scale, residual, relu};
+    const Epi ep = {bias, scale, residual, relu, gate};
     hipStream_t st = (hipStream_t)stream;
     const long blocks = (long)fi::ceil_div(pg.ptiles, 8) * 8 * pg.mtiles;
     FI_REQUIRE(blocks < 2147483647L, "grid too large");
@@ -1635,6 +1737,13 @@ int FI16(fi_conv1x1_forward, w)(const float *x, const uint16_t *weight_bf16, con
                              const float *residual, float *y, int N, int Cin, int HW, int Cout, int relu,
                              fi_stream_t stream)
 {
+    return FI16(fi_conv1x1_forward_gated, w)(x, weight_bf16, bias, scale, residual, nullptr, y, N, Cin, HW, Cout, relu, stream);
+}
+
+int FI16(fi_conv1x1_forward_gated, w)(const float *x, const uint16_t *weight_bf16, const float *bias, const float *scale,
+                                   const float *residual, const float *gate, float *y, int N, int Cin, int HW, int Cout,
+                                   int relu, fi_stream_t stream)
+{
     FI_REQUIRE(N >= 1 && Cin >= 1 && HW >= 1 && Cout >= 1, "sizes must be positive");
     FI_REQUIRE(x && weight_bf16 && y, "null pointer");
     if (!(HW % 4 == 0 && Cin % P1_KC == 0 && Cout > 64)) {
@@ -1643,13 +1752,14 @@ int FI16(fi_conv1x1_forward, w)(const float *x, const uint16_t *weight_bf16, con
         return FI_ERR_UNSUPPORTED;
     }
     FI_REQUIRE((uintptr_t)x % 16 == 0 && (uintptr_t)y % 16 == 0 && (uintptr_t)weight_bf16 % 16 == 0 &&
-               (residual == nullptr || (uintptr_t)residual % 16 == 0), "16-byte aligned tensors required");
+               (residual == nullptr || (uintptr_t)residual % 16 == 0) && (gate == nullptr || (uintptr_t)gate % 16 == 0),
+               "16-byte aligned tensors required");
     FI_REQUIRE((long)N * Cin * HW < 2147483647L && (long)N * Cout * HW < 2147483647L, "tensor too large");
     Conv1x1GeomB pg;
     pg.N = N; pg.Cin = Cin; pg.HW = HW; pg.Cout = Cout; pg.P = N * HW;
     pg.ptiles = fi::ceil_div(pg.P, 128);
     pg.mtiles = fi::ceil_div(Cout, 128);
-    const Epi ep = {bias, scale, residual, relu};
+    const Epi ep = {bias, scale, residual, relu, gate};
     hipStream_t st = (hipStream_t)stream;
     const long blocks = (long)fi::ceil_div(pg.ptiles, 8) * 8 * pg.mtiles;
     FI_REQUIRE(blocks < 2147483647L, "grid too large");
@@ -1664,14 +1774,24 @@ int FI16(fi_conv2d_weight_grad, )(const float *x, const float *dy, float *dweigh
                                int Cout, int R, int S, int stride_h, int stride_w, int pad_h, int pad_w,
                                int flags, fi_stream_t stream)
 {
+    return FI16(fi_conv2d_weight_grad_db, )(x, dy, dweight, nullptr, N, Cin, H, W, Cout, R, S, stride_h, stride_w, pad_h,
+                                            pad_w, flags, stream);
+}
+
+int FI16(fi_conv2d_weight_grad_db, )(const float *x, const float *dy, float *dweight, float *dbias, int N, int Cin, int H,
+                                  int W, int Cout, int R, int S, int stride_h, int stride_w, int pad_h, int pad_w,
+                                  int flags, fi_stream_t stream)
+{
     Geom g;
     int rc = make_geom(g, N, Cin, H, W, Cout, R, S, stride_h, stride_w, pad_h, pad_w, 0, 0);
     if (rc != FI_OK) return rc;
     FI_REQUIRE(x && dy && dweight, "null pointer");
     hipStream_t st = (hipStream_t)stream;
     const int RS = R * S;
-    if (!(flags & FI_OUTPUTS_ZEROED))
+    if (!(flags & FI_OUTPUTS_ZEROED)) {
         FI_HIP_CHECK(hipMemsetAsync(dweight, 0, sizeof(float) * (size_t)Cout * RS * Cin, st));
+        if (dbias) FI_HIP_CHECK(hipMemsetAsync(dbias, 0, sizeof(float) * (size_t)Cout, st));
+    }
     const int OHW = g.OH * g.OW;
     fi::ProfScope prof(FI_K_CONV_BF16_WGRAD, st);
     // same-size stride-1 layers with whole channel tiles: flat pixel space (conv_bf16_wgrad_flat_kernel)
@@ -1700,10 +1820,15 @@ int FI16(fi_conv2d_weight_grad, )(const float *x, const float *dy, float *dweigh
                                      : (bnc == 128 ? conv_bf16_wgrad_flat_kernel<64, 128, true> : conv_bf16_wgrad_flat_kernel<64, 64, true>))
                         : (bm == 128 ? (bnc == 128 ? conv_bf16_wgrad_flat_kernel<128, 128, false> : conv_bf16_wgrad_flat_kernel<128, 64, false>)
                                      : (bnc == 128 ? conv_bf16_wgrad_flat_kernel<64, 128, false> : conv_bf16_wgrad_flat_kernel<64, 64, false>));
-            hipLaunchKernelGGL(k, grid, dim3(kThreads), 0, st, x, dy, dweight, g, cin_tiles, per * FK, mt, (int)z);
+            hipLaunchKernelGGL(k, grid, dim3(kThreads), 0, st, x, dy, dweight, g, cin_tiles, per * FK, mt, (int)z, dbias);
             FI_HIP_CHECK(hipGetLastError());
             return FI_OK;
         }
+    }
+    if (dbias) {
+        const int chunks = std::max(1, std::min(N, 2048 / std::max(1, Cout)));
+        hipLaunchKernelGGL(channel_sum_kernel, dim3((unsigned)Cout, (unsigned)chunks), dim3(256), 0, st, dy, dbias, N, Cout, OHW);
+        FI_HIP_CHECK(hipGetLastError());
     }
     if ((stride_w == 1 || stride_w == 2) && g.OW >= 4 && W >= 4 * stride_w) {
         const int bm = Cout <= 64 ? 64 : 128, bnc = Cin <= 64 ? 64 : 128;

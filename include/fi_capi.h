@@ -410,6 +410,22 @@ int fi_conv1x1_forward_bf16w(const float *x, const uint16_t *weight_bf16, const 
 int fi_conv2d_weight_grad_bf16(const float *x, const float *dy, float *dweight, int N, int Cin,
                                int H, int W, int Cout, int R, int S, int stride_h, int stride_w,
                                int pad_h, int pad_w, int flags, fi_stream_t stream);
+/* The same kernels with the additions of fi_conv2d_forward_gated (epilogue operand gate, y *= (gate > 0)) and of
+ * fi_conv2d_weight_grad's dbias (sum of dy over images and pixels, accumulated by the flat weight-gradient kernel from
+ * the tiles it stages, by a channel-sum kernel for the other layers). */
+int fi_conv2d_forward_gated_bf16(const float *x, const float *weight, const float *bias, const float *scale,
+                                 const float *residual, const float *gate, float *y, int N, int Cin, int H, int W,
+                                 int Cout, int R, int S, int stride_h, int stride_w, int pad_h, int pad_w, int relu,
+                                 int weight_layout, int out_h, int out_w, int output_layout, fi_stream_t stream);
+int fi_conv3x3_forward_gated_bf16w(const float *x, const uint16_t *weight_bf16, const float *bias, const float *scale,
+                                   const float *residual, const float *gate, float *y, int N, int Cin, int H, int W,
+                                   int Cout, int relu, int flip_taps, fi_stream_t stream);
+int fi_conv1x1_forward_gated_bf16w(const float *x, const uint16_t *weight_bf16, const float *bias, const float *scale,
+                                   const float *residual, const float *gate, float *y, int N, int Cin, int HW, int Cout,
+                                   int relu, fi_stream_t stream);
+int fi_conv2d_weight_grad_db_bf16(const float *x, const float *dy, float *dweight, float *dbias, int N, int Cin, int H,
+                                  int W, int Cout, int R, int S, int stride_h, int stride_w, int pad_h, int pad_w,
+                                  int flags, fi_stream_t stream);
 
 /* The same four entry points on IEEE half operands (v_mfma_f32_32x32x16_f16, fp32 accumulation) -- BASELINE
  * configs[4] names an "fp16 MFMA conv path".  Identical arguments, tiles and epilogues; weight_f16 holds half bit
@@ -428,6 +444,19 @@ int fi_conv1x1_forward_f16w(const float *x, const uint16_t *weight_f16, const fl
 int fi_conv2d_weight_grad_f16(const float *x, const float *dy, float *dweight, int N, int Cin,
                               int H, int W, int Cout, int R, int S, int stride_h, int stride_w,
                               int pad_h, int pad_w, int flags, fi_stream_t stream);
+int fi_conv2d_forward_gated_f16(const float *x, const float *weight, const float *bias, const float *scale,
+                                const float *residual, const float *gate, float *y, int N, int Cin, int H, int W,
+                                int Cout, int R, int S, int stride_h, int stride_w, int pad_h, int pad_w, int relu,
+                                int weight_layout, int out_h, int out_w, int output_layout, fi_stream_t stream);
+int fi_conv3x3_forward_gated_f16w(const float *x, const uint16_t *weight_f16, const float *bias, const float *scale,
+                                  const float *residual, const float *gate, float *y, int N, int Cin, int H, int W,
+                                  int Cout, int relu, int flip_taps, fi_stream_t stream);
+int fi_conv1x1_forward_gated_f16w(const float *x, const uint16_t *weight_f16, const float *bias, const float *scale,
+                                  const float *residual, const float *gate, float *y, int N, int Cin, int HW, int Cout,
+                                  int relu, fi_stream_t stream);
+int fi_conv2d_weight_grad_db_f16(const float *x, const float *dy, float *dweight, float *dbias, int N, int Cin, int H,
+                                 int W, int Cout, int R, int S, int stride_h, int stride_w, int pad_h, int pad_w,
+                                 int flags, fi_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * In-library kernel timing (HIP events recorded on the launch stream around

@@ -233,3 +233,82 @@ def test_linear_on_the_16bit_kernels(M, K, N, precision):
     assert (xg.grad.cpu().double() - dx_t).abs().max().item() <= tight(dx_t, N)
     assert (wg.grad.cpu().double() - dw_t).abs().max().item() <= tight(dw_t, M)
     assert (bg.grad.cpu().double() - gy.double().sum(0)).abs().max().item() <= tight(gy.double().sum(0), M)
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp16"])
+@pytest.mark.parametrize("case", [
+    (4, 256, 64, 64, 128, 1, True),      # conv1x1 weights-in-registers kernel
+    (2, 128, 64, 64, 128, 3, False),     # 3x3 patch kernel, 8 x 16 tiles
+    (640, 128, 14, 14, 128, 3, True),    # 3x3 patch kernel, flat tiles (RoI maps)
+    (3, 64, 13, 11, 40, 3, True),        # general kernel, ragged rows
+    (2, 64, 32, 32, 64, 1, False),       # general kernel, full tiles
+])
+def test_gated_epilogue_of_the_16bit_kernels(case, precision):
+    """fi_conv*_forward_gated_{bf16,f16}: the gate is a select after the unchanged arithmetic."""
+    from feature_intertwiner_amd import conv as C
+    N, Cin, H, W, Cout, k, res = case
+    g = torch.Generator(device="cpu").manual_seed(N + Cin + H + k)
+    x = torch.randn(N, Cin, H, W, generator=g).to(DEV)
+    w = (torch.randn(Cout, Cin, k, k, generator=g) * (1.0 / (Cin * k * k) ** 0.5)).to(DEV)
+    r = torch.randn(N, Cout, H, W, generator=g).to(DEV) if res else None
+    gate = torch.randn(N, Cout, H, W, generator=g).to(DEV)
+    gate[gate.abs() < 0.2] = 0.0
+    wt = w.permute(0, 2, 3, 1).contiguous()
+    y = C._conv_fwd(x, wt, None, (1, 1), (k // 2, k // 2), residual=r, w_tap_major=True, gate=gate, precision=precision)
+    plain = C._conv_fwd(x, wt, None, (1, 1), (k // 2, k // 2), residual=r, w_tap_major=True, precision=precision)
+    assert torch.equal(y, plain * (gate > 0))
+    ref = F.conv2d(x.double(), w.double(), padding=k // 2) + (r.double() if res else 0.0)
+    assert float((plain.double() - ref).abs().max()) <= 2e-2 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp16"])
+def test_stage_gradients_on_the_16bit_kernels_track_fp32(precision):
+    """The unscaled-gradient backward (scaled W^T, gates, BatchNorm sums from the weight gradient, bias sums inside the
+    16-bit weight-gradient kernel) on a ResNet stage against the fp32 run and against the older form of the backward
+    (fi_bn_act_backward) on the same 16-bit kernels."""
+    import torch.nn as nn
+    from feature_intertwiner_amd import conv as C
+    from feature_intertwiner_amd.sub_module import ResNet
+    torch.manual_seed(5)
+    net = ResNet("resnet50")
+    net.inplanes = 128
+    stage = net.make_layer(net.block, 64, 3, stride=2)
+    for m in stage.modules():
+        if isinstance(m, nn.BatchNorm2d):
+            m.weight.data.uniform_(0.5, 1.5)
+            m.bias.data.normal_(0, 0.1)
+            m.running_mean.normal_(0, 0.1)
+            m.running_var.uniform_(0.5, 1.5)
+    stage = stage.eval().to(DEV)
+    x = torch.randn(2, 128, 32, 48, device=DEV)
+    gy = None
+    grads = {}
+    try:
+        for name, prec, unscaled in (("fp32", "fp32", True), ("new", precision, True), ("old", precision, False)):
+            C.set_conv_precision(prec)
+            C._UNSCALED_BACKWARD = unscaled
+            for p in stage.parameters():
+                p.grad = None
+            C.prepare_step(stage)
+            C.prepare_step(stage)
+            xg = x.clone().requires_grad_(True)
+            y = stage(xg * 1.0)
+            gy = torch.randn_like(y) if gy is None else gy
+            y.backward(gy)
+            torch.cuda.synchronize()
+            grads[name] = {"x": xg.grad.clone(), **{k: p.grad.clone() for k, p in stage.named_parameters()}}
+    finally:
+        C.set_conv_precision("fp32")
+        C._UNSCALED_BACKWARD = True
+        C.invalidate_step_state()
+    # 16-bit operands through 9 layers forward and backward: ~0.1 (bf16) / ~0.06 (fp16) of the largest element away from
+    # fp32, in EITHER form of the backward; the two forms differ from each other by much less (where the BatchNorm scale
+    # is rounded into the operands), and neither is biased
+    far = 0.15 if precision == "bf16" else 0.09
+    for k, ref in grads["fp32"].items():
+        new, old = grads["new"][k], grads["old"][k]
+        top = float(ref.abs().max()) + 1e-6
+        assert float((new - ref).abs().max()) <= far * top, k
+        assert float((new - old).abs().max()) <= 0.4 * far * top, k
+        ratio = float((new * ref).sum() / (ref * ref).sum().clamp(min=1e-30))
+        assert abs(ratio - 1.0) < 3e-2, (k, ratio)
