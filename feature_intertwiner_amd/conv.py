@@ -828,7 +828,7 @@ class _ConvBiasActFn(torch.autograd.Function):
     together (instead of threshold_backward + a separate reduction)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, stride, padding, out_gate=None):
+    def forward(ctx, x, w, b, stride, padding, out_gate=None, dx_gate=False):
         _lib.require_cuda(x, w)
         x = x.contiguous().float()
         w = _dense(w.float())
@@ -837,7 +837,7 @@ class _ConvBiasActFn(torch.autograd.Function):
         y = _conv_fwd(x, w, bc, stride, padding, relu=True)
         ctx.save_for_backward(x, w, y)
         ctx.precision = _PRECISION
-        ctx.out_gate = out_gate
+        ctx.out_gate, ctx.dx_gate = out_gate, bool(dx_gate)
         ctx.conf = (tuple(stride), tuple(padding), b is not None)
         ctx.bias_ptr = b.data_ptr() if b is not None else 0
         return y
@@ -853,10 +853,12 @@ class _ConvBiasActFn(torch.autograd.Function):
             # gradient; the bias gradient comes out of the weight-gradient kernel's pass over it
             if has_bias and ctx.needs_input_grad[2] and ctx.needs_input_grad[1]:
                 return _conv_backward(ctx.needs_input_grad, x, w, dy, stride, padding, want_db=True,
-                                      precision=ctx.precision, bias_ptr=ctx.bias_ptr) + (None, None, None)
-            dx, dw = _conv_backward(ctx.needs_input_grad, x, w, dy, stride, padding, precision=ctx.precision)
+                                      precision=ctx.precision, bias_ptr=ctx.bias_ptr,
+                                      gate=x if ctx.dx_gate else None) + (None, None, None, None)
+            dx, dw = _conv_backward(ctx.needs_input_grad, x, w, dy, stride, padding, precision=ctx.precision,
+                                    gate=x if ctx.dx_gate else None)
             db = dy.sum((0, 2, 3)) if (has_bias and ctx.needs_input_grad[2]) else None
-            return dx, dw, db, None, None, None
+            return dx, dw, db, None, None, None, None
         N, C, OH, OW = y.shape
         dz = torch.empty_like(y)
         ones = _ones(C, y.device)
@@ -869,8 +871,9 @@ class _ConvBiasActFn(torch.autograd.Function):
             _lib.check(L.fi_bn_act_backward(_lib.ptr(dy), _lib.ptr(y), _lib.ptr(ones), None, None, None, N, C, OH * OW, 1,
                                             _lib.ptr(dz), None, _lib.ptr(dshift), None, None, 0, flags,
                                             _lib.current_stream()), "fi_bn_act_backward")
-        dx, dw = _conv_backward(ctx.needs_input_grad, x, w, dz, stride, padding, precision=ctx.precision)
-        return dx, dw, (dshift if (has_bias and ctx.needs_input_grad[2] and first) else None), None, None, None
+        dx, dw = _conv_backward(ctx.needs_input_grad, x, w, dz, stride, padding, precision=ctx.precision,
+                                gate=x if ctx.dx_gate else None)
+        return dx, dw, (dshift if (has_bias and ctx.needs_input_grad[2] and first) else None), None, None, None, None
 
 
 _ONES = {}
@@ -885,10 +888,11 @@ def _ones(n, device):
     return t
 
 
-def conv_bias_relu(x, weight, bias=None, stride=(1, 1), padding=(0, 0)):
-    """relu(conv2d(x, weight, bias)) fused (weight [Cout, Cin, R, S]).  The result carries a Gate (see there)."""
+def conv_bias_relu(x, weight, bias=None, stride=(1, 1), padding=(0, 0), gate_dx=False):
+    """relu(conv2d(x, weight, bias)) fused (weight [Cout, Cin, R, S]).  The result carries a Gate (see there);
+    gate_dx as conv_bn_act's."""
     gate = Gate() if (torch.is_grad_enabled() and x.is_cuda) else None
-    y = _ConvBiasActFn.apply(x, weight, bias, tuple(stride), tuple(padding), gate)
+    y = _ConvBiasActFn.apply(x, weight, bias, tuple(stride), tuple(padding), gate, _claim_gate(x, gate_dx))
     if gate is not None:
         y._fi_gate = gate
     return y
@@ -1170,7 +1174,7 @@ class ConvTranspose2x2(nn.ConvTranspose2d):
         b = self.bias.repeat_interleave(4) if self.bias is not None else None
         return F.pixel_shuffle(conv2d(x, w, b), 2)
 
-    def forward_unshuffled(self, x, relu=False):
+    def forward_unshuffled(self, x, relu=False, gate_dx=False):
         """The same values BEFORE the pixel shuffle, as [N, 2, 2, Cout, H, W] with
         out[n, c, 2h+a, 2w+b] == u[n, a, b, c, h, w] (optionally with ReLU fused into the 1x1 conv).
         A following 1x1 convolution / elementwise op can consume u viewed as [N*4, Cout, H, W] and
@@ -1180,7 +1184,7 @@ class ConvTranspose2x2(nn.ConvTranspose2d):
         cin, cout = self.weight.shape[0], self.weight.shape[1]
         w = self.weight.permute(2, 3, 1, 0).reshape(4 * cout, cin, 1, 1)       # output channels ordered (a, b, c)
         b = self.bias.repeat(4) if self.bias is not None else None
-        y = conv_bias_relu(x, w, b) if relu else conv2d(x, w, b)
+        y = conv_bias_relu(x, w, b, gate_dx=gate_dx) if relu else conv2d(x, w, b, gate_dx=gate_dx)
         u = y.view(x.shape[0], 2, 2, cout, x.shape[2], x.shape[3])
         if getattr(y, "_fi_gate", None) is not None:
             u._fi_gate = y._fi_gate           # a view of y: its only reader may claim the Gate (conv2d(gate_dx=...))

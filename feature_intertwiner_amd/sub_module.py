@@ -550,7 +550,7 @@ class Mask(nn.Module):
         x = conv_bn_act(x, self.conv4, self.bn4, relu=True, gate_dx=True)
         # deconv(k2,s2) = 1x1 conv to (a, b, c) channels; ReLU, conv5 (1x1) and sigmoid are per pixel, so
         # they run before the pixel shuffle and only 81 channels are ever moved
-        u = self.deconv.forward_unshuffled(x, relu=True)                 # [N, 2, 2, 256, H, W]
+        u = self.deconv.forward_unshuffled(x, relu=True, gate_dx=True)   # [N, 2, 2, 256, H, W]; conv4's only reader
         n, h, w = u.shape[0], u.shape[4], u.shape[5]
         K = self.conv5.weight.shape[0]
         if activate or K % 16 == 0 or not u.is_cuda:

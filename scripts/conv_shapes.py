@@ -11,6 +11,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("FI_WGRAD_SIDE_PIXELS", "0")      # weight gradients on the main stream: the events bracket the kernel
 from feature_intertwiner_amd import _lib  # noqa: E402
 from feature_intertwiner_amd.config import make_config  # noqa: E402
 from feature_intertwiner_amd.model import MaskRCNN  # noqa: E402
@@ -68,7 +69,9 @@ _lib._lib = L
 
 def describe(name, a):
     v = [x for x in a if x is not None]
-    if name in ("fi_conv2d_forward", "fi_conv2d_forward_bf16"):
+    gated = "_gated" in name
+    name = name.replace("_gated", "")
+    if name in ("fi_conv2d_forward", "fi_conv2d_forward_bf16", "fi_conv2d_forward_f16"):
         N, Cin, H, W, Cout, R, S, sh, sw, ph, pw, relu, layout, oh, ow, ocl = v[:16]
         OH = oh or (H + 2 * ph - R) // sh + 1
         OW = ow or (W + 2 * pw - S) // sw + 1
@@ -81,6 +84,7 @@ def describe(name, a):
     if name in ("fi_conv1x1_forward_bf16w",):
         N, Cin, HW, Cout = v[:4]
         return "fwd_bf16w1x1 N%d HW%d Cin%d->Cout%d" % (N, HW, Cin, Cout), 2.0 * N * Cout * HW * Cin
+    name = name.replace("_db_", "_")
     if name in ("fi_conv2d_weight_grad", "fi_conv2d_weight_grad_bf16"):
         N, Cin, H, W, Cout, R, S, sh, sw, ph, pw = v[:11]
         OH = (H + 2 * ph - R) // sh + 1
