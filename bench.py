@@ -487,11 +487,18 @@ def _main():
     car.LAUNCH_LOG = []
     ficonv.FLOP_LOG = {}
     ficonv.SHAPE_LOG = []
+    # EXCLUSIVE kernel durations: in the timed region the weight gradients run on a second stream next to the data
+    # gradients (conv.WGRAD_SIDE_STREAM_MAX_PIXELS) and two kernels that share the chip each take longer than alone;
+    # the roofline objects price a kernel against the whole chip, so this pass keeps everything on one stream
+    # (`exclusive_ms_per_step` in the JSON is what that costs; `value` comes from the timed region above)
+    side_pixels = ficonv.WGRAD_SIDE_STREAM_MAX_PIXELS
+    ficonv.WGRAD_SIDE_STREAM_MAX_PIXELS = 0
     t1 = time.perf_counter()
     for _ in range(prof_steps):
         step()
     torch.cuda.synchronize()
     prof_elapsed = time.perf_counter() - t1
+    ficonv.WGRAD_SIDE_STREAM_MAX_PIXELS = side_pixels
     _lib.prof_enable(False)
     log = car.LAUNCH_LOG
     car.LAUNCH_LOG = None
@@ -675,8 +682,10 @@ def _main():
             "losses": {k: round(float(v), 5) for k, v in terms.items()},
             "roofline": roof, "roofline_roialign": roof_roi, "conv_stack": conv_stack, "nms": nms_obj, "sinkhorn": sk_obj,
             "timing": {"timed_region": "%d steps, no event recording / logging" % args.steps,
-                       "profiled_pass": "%d further steps with HIP-event timing of every library kernel: %.2f ms/step"
-                                        % (prof_steps, prof_elapsed / prof_steps * 1e3)},
+                       "profiled_pass": "%d further steps with HIP-event timing of every library kernel, weight gradients "
+                                        "on the main stream so that every duration is the kernel alone on the chip (the "
+                                        "timed region overlaps them with the data gradients on a second stream): "
+                                        "%.2f ms/step" % (prof_steps, prof_elapsed / prof_steps * 1e3)},
             "kernels": kern,
         }
         if world > 1 or force_dp:

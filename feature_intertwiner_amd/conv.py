@@ -277,6 +277,33 @@ def _relu_mask(dy, y, out=None):
     return out
 
 
+class _Upsample2xFn(torch.autograd.Function):
+    """F.interpolate(x, scale_factor=2, mode='nearest') whose backward is ONE pass (fi_sum2x2: the framework's kernel
+    takes 0.5 ms per step on the FPN's three top-down maps, 5x the time of reading them)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return F.interpolate(x, scale_factor=2, mode='nearest')
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = dy.contiguous().float()
+        N, C, H2, W2 = dy.shape
+        if not dy.is_cuda or (W2 // 2) % 2 or dy.data_ptr() % 16:
+            return dy.view(N, C, H2 // 2, 2, W2 // 2, 2).sum((3, 5))
+        out = torch.empty((N, C, H2 // 2, W2 // 2), device=dy.device, dtype=torch.float32)
+        with torch.cuda.device(dy.device):
+            _lib.check(_lib.load().fi_sum2x2(_lib.ptr(dy), _lib.ptr(out), N * C, H2 // 2, W2 // 2, _lib.current_stream()),
+                       "fi_sum2x2")
+        return out
+
+
+def upsample2x(x):
+    """x2 nearest-neighbour upsampling (the FPN's top-down path)."""
+    return _Upsample2xFn.apply(x) if (x.is_cuda and x.requires_grad and torch.is_grad_enabled()) else \
+        F.interpolate(x, scale_factor=2, mode='nearest')
+
+
 def _conv_backward(ctx_needs, x, w, dz, stride, padding, want_db=False, add_to_dx=None, precision=None,
                    give_compact=False, bias_ptr=0, gate=None, w_scale=None, db_into=None, after_wgrad=None):
     """dX and dW of z = conv(x, w) given dz (shared by the plain and the fused functions).

@@ -82,6 +82,29 @@ __global__ __launch_bounds__(256) void bn_fold_kernel(const FiBnFoldDesc *__rest
     static_cast<float *>(d.shift)[c] = sh;
 }
 
+// out[p][h][w] = ((dy[p][2h][2w] + dy[p][2h][2w+1]) + dy[p][2h+1][2w]) + dy[p][2h+1][2w+1]: the backward of a x2
+// nearest-neighbour upsampling (the FPN's top-down path, lib/sub_module.py:172-200), in the summation order of the
+// framework's kernel (rows, then columns of the 2 x 2 source window).  A thread makes 2 adjacent outputs from two
+// 16-byte loads.
+__global__ __launch_bounds__(256) void sum2x2_kernel(const float *__restrict__ dy, float *__restrict__ out, long planes,
+                                                     int H, int W)
+{
+    const int wp = W >> 1;                                  // output pairs per row (W even)
+    const long total = planes * H * wp;
+    const int W2 = 2 * W;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int j = (int)(i % wp);
+        const long ph = i / wp;                             // p * H + h
+        const float *__restrict__ r0 = dy + (ph * 2) * W2 + 4 * j;
+        const float4 a = *reinterpret_cast<const float4 *>(r0);
+        const float4 b = *reinterpret_cast<const float4 *>(r0 + W2);
+        float2 o;
+        o.x = ((a.x + a.y) + b.x) + b.y;
+        o.y = ((a.z + a.w) + b.z) + b.w;
+        *reinterpret_cast<float2 *>(out + ph * W + 2 * j) = o;
+    }
+}
+
 __global__ __launch_bounds__(256) void relu_mask_kernel(const float *__restrict__ dy, const float *__restrict__ y,
                                                         float *__restrict__ out, long n4, long n)
 {
@@ -150,6 +173,20 @@ __global__ __launch_bounds__(256) void bn_fold_grad_kernel(float *__restrict__ d
 }  // namespace
 
 extern "C" {
+
+int fi_sum2x2(const float *dy, float *out, long planes, int height, int width, fi_stream_t stream)
+{
+    FI_REQUIRE(planes >= 0 && height >= 1 && width >= 2 && width % 2 == 0, "out is [planes][height][width], width even");
+    if (planes == 0) return FI_OK;
+    FI_REQUIRE(dy && out, "null pointer");
+    FI_REQUIRE((uintptr_t)dy % 16 == 0 && (uintptr_t)out % 8 == 0, "dy must be 16-byte, out 8-byte aligned");
+    const long total = planes * height * (width / 2);
+    const long blocks = std::min<long>((total + 255) / 256, 256L * 32);
+    hipLaunchKernelGGL(sum2x2_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dy, out, planes, height,
+                       width);
+    FI_HIP_CHECK(hipGetLastError());
+    return FI_OK;
+}
 
 int fi_relu_mask(const float *dy, const float *y, float *out, long n, fi_stream_t stream)
 {

@@ -16,7 +16,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import _lib
-from .conv import Conv2d, ConvTranspose2x2, GradBox, conv2d, conv_bias_relu, conv_bn_act, linear
+from .conv import Conv2d, ConvTranspose2x2, GradBox, conv2d, conv_bias_relu, conv_bn_act, linear, upsample2x
 from .intertwiner import class_mean, roi_level
 from .roi_align.crop_and_resize import CropAndResizeFunction, CropGradGroup, pyramid_crop_and_resize
 from .roi_pooling.functions.roi_pool import RoIPoolFunction
@@ -208,7 +208,7 @@ class FPN(nn.Module):
         c4 = self.C4(c3)
         c5 = self.C5(c4)
         p5 = self.P5_conv1(c5)
-        up = lambda t: F.interpolate(t, scale_factor=2, mode='nearest')
+        up = upsample2x
         if self.ot and mode == 'train':
             t4 = self.P4_conv1(c4)
             l0 = self.p4_ot(p5, t4)

@@ -278,6 +278,10 @@ int fi_conv2d_forward_gated(const float *x, const float *weight, const float *bi
                             const float *residual, const float *gate, float *y, int N, int Cin, int H, int W,
                             int Cout, int R, int S, int stride_h, int stride_w, int pad_h, int pad_w, int relu,
                             int weight_layout, int out_h, int out_w, int output_layout, fi_stream_t stream);
+/* Backward of a x2 nearest-neighbour upsampling (F.interpolate(scale_factor=2, mode='nearest') in the FPN's top-down
+ * path, lib/sub_module.py:172-200): out [planes][height][width] = the 2 x 2 block sums of dy [planes][2*height][2*width],
+ * summed rows first like the framework's kernel.  width even. */
+int fi_sum2x2(const float *dy, float *out, long planes, int height, int width, fi_stream_t stream);
 /* out = dy * (y > 0), n elements (out may alias dy): the ReLU part of the backward below on its own. */
 int fi_relu_mask(const float *dy, const float *y, float *out, long n, fi_stream_t stream);
 /* Gradients of conv + eval-mode BatchNorm from the weight gradient of the UNSCALED masked gradient g

@@ -589,3 +589,19 @@ def test_gate_between_conv_bias_relu_and_its_only_reader():
              (shared.bias.grad, rs.bias.grad), (head.weight.grad, rh.weight.grad), (head.bias.grad, rh.bias.grad)]
     for i, (a, b) in enumerate(pairs):
         assert float((a.cpu().double() - b).abs().max()) <= 2e-4 * float(b.abs().max()) + 1e-9, i
+
+
+@pytest.mark.parametrize("shape", [(4, 256, 64, 64), (2, 3, 5, 6), (1, 16, 33, 128)])
+def test_upsample2x_backward_is_bit_identical_to_the_framework(shape):
+    """conv.upsample2x: F.interpolate(scale 2, nearest) forward; backward fi_sum2x2 adds the 2 x 2 source window in the
+    order of the framework's kernel -- same bits."""
+    from feature_intertwiner_amd.conv import upsample2x
+    torch.manual_seed(shape[1])
+    x = torch.randn(*shape, device=DEV)
+    a, b = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    ya, yb = upsample2x(a), F.interpolate(b, scale_factor=2, mode="nearest")
+    assert torch.equal(ya, yb)
+    gy = torch.randn_like(ya)
+    ya.backward(gy)
+    yb.backward(gy)
+    assert torch.equal(a.grad, b.grad)
