@@ -298,6 +298,45 @@ class _Upsample2xFn(torch.autograd.Function):
         return out
 
 
+class _MaxPool3x3s2Fn(torch.autograd.Function):
+    """The stem's max-pooling (3 x 3, stride 2, windows clipped at the border) without an index tensor: backward
+    recomputes the arg-max from the input, which the stem keeps anyway (fi_maxpool3x3s2_*).  masked: the input is a
+    ReLU output whose Gate this op claimed -- the gradient leaves multiplied by (x > 0)."""
+
+    @staticmethod
+    def forward(ctx, x, masked):
+        N, C, H, W = x.shape
+        y = torch.empty((N, C, (H - 2) // 2 + 1, (W - 2) // 2 + 1), device=x.device, dtype=torch.float32)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.load().fi_maxpool3x3s2_forward(_lib.ptr(x), _lib.ptr(y), N * C, H, W, _lib.current_stream()),
+                       "fi_maxpool3x3s2_forward")
+        ctx.save_for_backward(x)
+        ctx.masked = bool(masked)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, = ctx.saved_tensors
+        N, C, H, W = x.shape
+        dy = dy.contiguous().float()
+        dx = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.load().fi_maxpool3x3s2_backward(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(dx), N * C, H, W,
+                                                            1 if ctx.masked else 0, _lib.current_stream()),
+                       "fi_maxpool3x3s2_backward")
+        return dx, None
+
+
+def maxpool3x3s2(x):
+    """max_pool2d(x, 3, 2, ceil_mode=True) for a contiguous fp32 CUDA map whose width is a multiple of 4 (None if x
+    is something else: the caller falls back to the framework).  Claims x's Gate (the pooling is the stem's only
+    reader)."""
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous() and x.shape[3] % 4 == 0 and
+            x.shape[2] >= 3 and x.data_ptr() % 16 == 0):
+        return None
+    return _MaxPool3x3s2Fn.apply(x, _claim_gate(x, True))
+
+
 def upsample2x(x):
     """x2 nearest-neighbour upsampling (the FPN's top-down path)."""
     return _Upsample2xFn.apply(x) if (x.is_cuda and x.requires_grad and torch.is_grad_enabled()) else \

@@ -105,6 +105,125 @@ __global__ __launch_bounds__(256) void sum2x2_kernel(const float *__restrict__ d
     }
 }
 
+// ---- 3 x 3 / stride 2 max-pooling of the stem (ceil_mode, no padding: windows clipped at the border) -----------------
+// The framework's pair of kernels stores an int64 index per output (forward: 0.23 ms) and reads it back in a gather
+// over all windows of every input element (backward: 0.45 ms for 268 MB of gradient); the input is at hand in backward
+// (it is the stem's ReLU output, kept for the stem's own backward), so the arg-max is recomputed instead, with the
+// framework's rule: scan rows then columns, take v if (v > best || isnan(v)) -- the FIRST maximum.
+__device__ __forceinline__ bool pool_better(float v, float best) { return v > best || v != v; }
+
+// a thread makes 2 adjacent outputs from 3 rows x (one 16-byte + one 4-byte) loads
+__global__ __launch_bounds__(256) void maxpool3s2_fwd_kernel(const float *__restrict__ x, float *__restrict__ y, long planes,
+                                                             int H, int W, int OH, int OW)
+{
+    const int op = (OW + 1) >> 1;
+    const long total = planes * OH * op;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int j = (int)(i % op);
+        const long po = i / op;
+        const int oh = (int)(po % OH);
+        const long p = po / OH;
+        const float *__restrict__ base = x + (p * H + 2 * oh) * W + 4 * j;
+        float b0 = 0.0f, b1 = 0.0f;
+        bool first = true;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            if (2 * oh + r >= H) break;
+            const float4 v = *reinterpret_cast<const float4 *>(base + (long)r * W);      // W % 4 == 0
+            const bool more = 4 * j + 4 < W;
+            const float e = more ? base[(long)r * W + 4] : 0.0f;
+            if (first) { b0 = v.x; b1 = v.z; first = false; } else { b0 = pool_better(v.x, b0) ? v.x : b0; b1 = pool_better(v.z, b1) ? v.z : b1; }
+            b0 = pool_better(v.y, b0) ? v.y : b0;
+            b0 = pool_better(v.z, b0) ? v.z : b0;
+            b1 = pool_better(v.w, b1) ? v.w : b1;
+            if (more) b1 = pool_better(e, b1) ? e : b1;
+        }
+        float *__restrict__ o = y + po * OW + 2 * j;
+        o[0] = b0;
+        if (2 * j + 1 < OW) o[1] = b1;
+    }
+}
+
+// a thread owns rows (2m, 2m+1) x columns 4t .. 4t+3 of the input gradient: the windows that can select one of its
+// elements are (m-1, m) x (2t-1, 2t, 2t+1); contributions are added in the framework's order (window rows, then columns).
+// positive_only: the result is multiplied by (x > 0) -- x is a ReLU output whose mask its producer then skips (Gate).
+__global__ __launch_bounds__(256) void maxpool3s2_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ x,
+                                                             float *__restrict__ dx, long planes, int H, int W, int OH,
+                                                             int OW, int positive_only)
+{
+    const int tq = W >> 2, mh = (H + 1) >> 1;
+    const long total = planes * mh * tq;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int t = (int)(i % tq);
+        const long pm = i / tq;
+        const int m = (int)(pm % mh);
+        const long p = pm / mh;
+        const float *__restrict__ xp = x + p * H * W;
+        const float *__restrict__ dyp = dy + p * OH * OW;
+        // x rows 2m-2 .. 2m+2, columns 4t-2 .. 4t+4 (absent ones are never read below)
+        float xv[5][7];
+#pragma unroll
+        for (int r = 0; r < 5; ++r) {
+            const int h = 2 * m - 2 + r;
+#pragma unroll
+            for (int c = 0; c < 7; ++c) xv[r][c] = 0.0f;
+            if (h < 0 || h >= H) continue;
+            const float *__restrict__ row = xp + (long)h * W + 4 * t;
+            const float4 v = *reinterpret_cast<const float4 *>(row);
+            xv[r][2] = v.x; xv[r][3] = v.y; xv[r][4] = v.z; xv[r][5] = v.w;
+            if (t > 0) {
+                const float2 l = *reinterpret_cast<const float2 *>(row - 2);
+                xv[r][0] = l.x; xv[r][1] = l.y;
+            }
+            if (4 * t + 4 < W) xv[r][6] = row[4];
+        }
+        float acc[2][4];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc[a][b] = 0.0f;
+#pragma unroll
+        for (int wr = 0; wr < 2; ++wr) {                      // window row oh = m - 1 + wr: local x rows 2*wr .. 2*wr+2
+            const int oh = m - 1 + wr;
+            if (oh < 0 || oh >= OH) continue;
+#pragma unroll
+            for (int wc = 0; wc < 3; ++wc) {                  // window column ow = 2t - 1 + wc: local x columns 2*wc .. 2*wc+2
+                const int ow = 2 * t - 1 + wc;
+                if (ow < 0 || ow >= OW) continue;
+                float best = 0.0f;
+                int br = -1, bc = -1;
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    if (2 * oh + r >= H) continue;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        if (2 * ow + c >= W) continue;
+                        const float v = xv[2 * wr + r][2 * wc + c];
+                        if (br < 0 || pool_better(v, best)) { best = v; br = 2 * wr + r; bc = 2 * wc + c; }
+                    }
+                }
+                const float g = dyp[(long)oh * OW + ow];
+                // own elements: local rows 2, 3 (input rows 2m, 2m+1), local columns 2 .. 5
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) acc[a][b] += (br == 2 + a && bc == 2 + b) ? g : 0.0f;
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const int h = 2 * m + a;
+            if (h >= H) continue;
+            float4 o = make_float4(acc[a][0], acc[a][1], acc[a][2], acc[a][3]);
+            if (positive_only) {
+                o.x = xv[2 + a][2] > 0.0f ? o.x : 0.0f; o.y = xv[2 + a][3] > 0.0f ? o.y : 0.0f;
+                o.z = xv[2 + a][4] > 0.0f ? o.z : 0.0f; o.w = xv[2 + a][5] > 0.0f ? o.w : 0.0f;
+            }
+            *reinterpret_cast<float4 *>(dx + (p * H + h) * W + 4 * t) = o;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void relu_mask_kernel(const float *__restrict__ dy, const float *__restrict__ y,
                                                         float *__restrict__ out, long n4, long n)
 {
@@ -173,6 +292,37 @@ __global__ __launch_bounds__(256) void bn_fold_grad_kernel(float *__restrict__ d
 }  // namespace
 
 extern "C" {
+
+int fi_maxpool3x3s2_forward(const float *x, float *y, long planes, int height, int width, fi_stream_t stream)
+{
+    FI_REQUIRE(planes >= 0 && height >= 3 && width >= 4 && width % 4 == 0, "x is [planes][height][width], width % 4 == 0");
+    if (planes == 0) return FI_OK;
+    FI_REQUIRE(x && y, "null pointer");
+    FI_REQUIRE((uintptr_t)x % 16 == 0, "x must be 16-byte aligned");
+    const int OH = (height - 2) / 2 + 1, OW = (width - 2) / 2 + 1;          // ceil((n - 3) / 2) + 1, last window starts inside
+    const long total = planes * OH * ((OW + 1) / 2);
+    const long blocks = std::min<long>((total + 255) / 256, 256L * 32);
+    hipLaunchKernelGGL(maxpool3s2_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, y, planes, height,
+                       width, OH, OW);
+    FI_HIP_CHECK(hipGetLastError());
+    return FI_OK;
+}
+
+int fi_maxpool3x3s2_backward(const float *dy, const float *x, float *dx, long planes, int height, int width,
+                             int positive_only, fi_stream_t stream)
+{
+    FI_REQUIRE(planes >= 0 && height >= 3 && width >= 4 && width % 4 == 0, "x is [planes][height][width], width % 4 == 0");
+    if (planes == 0) return FI_OK;
+    FI_REQUIRE(dy && x && dx, "null pointer");
+    FI_REQUIRE((uintptr_t)x % 16 == 0 && (uintptr_t)dx % 16 == 0, "x and dx must be 16-byte aligned");
+    const int OH = (height - 2) / 2 + 1, OW = (width - 2) / 2 + 1;
+    const long total = planes * ((height + 1) / 2) * (width / 4);
+    const long blocks = std::min<long>((total + 255) / 256, 256L * 64);
+    hipLaunchKernelGGL(maxpool3s2_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dy, x, dx, planes,
+                       height, width, OH, OW, positive_only);
+    FI_HIP_CHECK(hipGetLastError());
+    return FI_OK;
+}
 
 int fi_sum2x2(const float *dy, float *out, long planes, int height, int width, fi_stream_t stream)
 {

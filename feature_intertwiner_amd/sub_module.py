@@ -16,7 +16,8 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import _lib
-from .conv import Conv2d, ConvTranspose2x2, GradBox, conv2d, conv_bias_relu, conv_bn_act, linear, upsample2x
+from .conv import (Conv2d, ConvTranspose2x2, GradBox, conv2d, conv_bias_relu, conv_bn_act, linear, maxpool3x3s2,
+                   upsample2x)
 from .intertwiner import class_mean, roi_level
 from .roi_align.crop_and_resize import CropAndResizeFunction, CropGradGroup, pyramid_crop_and_resize
 from .roi_pooling.functions.roi_pool import RoIPoolFunction
@@ -57,6 +58,10 @@ def _pad_maxpool(x, pad, pool):
     l, r, t, b = pad.pads(x.size(2), x.size(3))
     k, s_ = nn.modules.utils._pair(pool.kernel_size), nn.modules.utils._pair(pool.stride)
     if l == 0 and t == 0 and r < k[1] and b < k[0] and tuple(nn.modules.utils._pair(pool.padding)) == (0, 0):
+        if k == (3, 3) and s_ == (2, 2):
+            y = maxpool3x3s2(x)            # own kernels: no index tensor, the stem's ReLU mask applied on the way back
+            if y is not None and y.shape[2] == (x.size(2) + b - 3) // 2 + 1 and y.shape[3] == (x.size(3) + r - 3) // 2 + 1:
+                return y
         y = F.max_pool2d(x, k, s_, 0, ceil_mode=True)
         if y.shape[2] == (x.size(2) + b - k[0]) // s_[0] + 1 and y.shape[3] == (x.size(3) + r - k[1]) // s_[1] + 1:
             return y

@@ -278,6 +278,13 @@ int fi_conv2d_forward_gated(const float *x, const float *weight, const float *bi
                             const float *residual, const float *gate, float *y, int N, int Cin, int H, int W,
                             int Cout, int R, int S, int stride_h, int stride_w, int pad_h, int pad_w, int relu,
                             int weight_layout, int out_h, int out_w, int output_layout, fi_stream_t stream);
+/* The stem's max-pooling (lib/sub_module.py:44-45: SamePad2d + MaxPool2d(3, 2) == 3 x 3 / stride 2 windows clipped at
+ * the right / bottom border, i.e. ceil_mode): y [planes][OH][OW], OH = (height - 2) / 2 + 1.  Backward recomputes the
+ * arg-max from x with the framework's first-maximum rule and adds the gradients of the (up to 4) windows that select
+ * an element in the framework's order; positive_only multiplies the result by (x > 0).  width % 4 == 0. */
+int fi_maxpool3x3s2_forward(const float *x, float *y, long planes, int height, int width, fi_stream_t stream);
+int fi_maxpool3x3s2_backward(const float *dy, const float *x, float *dx, long planes, int height, int width,
+                             int positive_only, fi_stream_t stream);
 /* Backward of a x2 nearest-neighbour upsampling (F.interpolate(scale_factor=2, mode='nearest') in the FPN's top-down
  * path, lib/sub_module.py:172-200): out [planes][height][width] = the 2 x 2 block sums of dy [planes][2*height][2*width],
  * summed rows first like the framework's kernel.  width even. */

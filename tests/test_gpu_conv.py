@@ -605,3 +605,26 @@ def test_upsample2x_backward_is_bit_identical_to_the_framework(shape):
     ya.backward(gy)
     yb.backward(gy)
     assert torch.equal(a.grad, b.grad)
+
+
+@pytest.mark.parametrize("shape", [(2, 8, 64, 64), (1, 3, 13, 12), (2, 4, 9, 8), (1, 2, 512, 512), (3, 5, 16, 20)])
+def test_stem_maxpool_kernels_match_the_framework_bit_for_bit(shape):
+    """fi_maxpool3x3s2_*: max_pool2d(3, 2, ceil_mode) without an index tensor.  Inputs with MANY exact ties (a ReLU
+    output is mostly zeros; values drawn from a small set) pin the first-maximum rule and the order in which the
+    overlapping windows' gradients are added; `masked` = the gradient times (x > 0)."""
+    from feature_intertwiner_amd.conv import _MaxPool3x3s2Fn
+    g = torch.Generator(device="cpu").manual_seed(shape[2])
+    x = torch.relu(torch.randint(-3, 4, shape, generator=g).float() * 0.5).to(DEV)          # ties everywhere
+    x2 = torch.relu(torch.randn(shape, generator=g)).to(DEV)
+    for inp in (x, x2):
+        a, b = inp.clone().requires_grad_(True), inp.clone().requires_grad_(True)
+        ya = _MaxPool3x3s2Fn.apply(a, False)
+        yb = F.max_pool2d(b, 3, 2, 0, ceil_mode=True)
+        assert ya.shape == yb.shape and torch.equal(ya, yb)
+        gy = torch.randn(ya.shape, generator=g).to(DEV)
+        ya.backward(gy)
+        yb.backward(gy)
+        assert torch.equal(a.grad, b.grad)
+        c = inp.clone().requires_grad_(True)
+        _MaxPool3x3s2Fn.apply(c, True).backward(gy)
+        assert torch.equal(c.grad, b.grad * (inp > 0))
