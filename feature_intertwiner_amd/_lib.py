@@ -93,6 +93,7 @@ SIGNATURES = {
     "fi_bn_fold_grad": (c_int, [c_void_p] * 6 + [ctypes.c_float] + [c_void_p] * 3 + [c_int] * 5 + [c_void_p]),
     "fi_bn_fold_batch": (c_int, [c_void_p, c_int, c_int, c_void_p]),
     "fi_stride2_interleave": (c_int, [c_void_p] * 6 + [ctypes.c_long, c_int, c_int, c_void_p]),
+    "fi_stride2_interleave_gated": (c_int, [c_void_p] * 7 + [ctypes.c_long, c_int, c_int, c_void_p]),
     "fi_sgd_chunks": (ctypes.c_long, [ctypes.c_long]),
     "fi_sgd_clip_step": (c_int, [c_void_p, c_int, ctypes.c_long, c_float, c_void_p, c_void_p, c_void_p]),
     "fi_calib_copy": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),

@@ -163,13 +163,14 @@ def _conv_fwd(x, w, b, stride, padding, relu=False, scale=None, residual=None, o
 
 class _Conv2dFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, b, stride, padding, residual=None, dx_gate=False):
+    def forward(ctx, x, w, b, stride, padding, residual=None, dx_gate=False, dx_give_to=None):
         _lib.require_cuda(x, w)
         x = x.contiguous().float()
         w = _dense(w.float())
         bc = b.contiguous().float() if b is not None else None
         ctx.save_for_backward(x, w)
         ctx.dx_gate = bool(dx_gate)
+        ctx.dx_give_to = dx_give_to
         ctx.conf = (tuple(stride), tuple(padding), b is not None)
         ctx.bias_ptr = b.data_ptr() if b is not None else 0
         ctx.precision = _PRECISION
@@ -189,7 +190,10 @@ class _Conv2dFn(torch.autograd.Function):
             dx, dw = _conv_backward(ctx.needs_input_grad, x, w, dy, stride, padding, precision=ctx.precision,
                                     gate=x if ctx.dx_gate else None)
             db = None
-        return dx, dw, db, None, None, (dy if ctx.needs_input_grad[5] else None), None
+        if ctx.dx_give_to is not None and dx is not None:
+            ctx.dx_give_to.value = dx         # added (and masked) inside the data-gradient kernel of x's other reader
+            dx = None
+        return dx, dw, db, None, None, (dy if ctx.needs_input_grad[5] else None), None, None
 
 
 def _class_taps(a, size_k, s, p):
@@ -215,17 +219,18 @@ class _Compact(object):
         return _interleave2({(0, 0): self.t}, add, self.t.shape[0], self.t.shape[1], self.hw[0], self.hw[1])
 
 
-def _interleave2(classes, add, N, C, H, W):
+def _interleave2(classes, add, N, C, H, W, gate=None):
     """dx [N,C,H,W] from the residue-class results of a stride-2 data gradient (fi_stride2_interleave): one pass,
-    every element written once; `add` [N,C,H,W] is added on the way."""
+    every element written once; `add` [N,C,H,W] is added on the way, the result multiplied by (gate > 0)."""
     L = _lib.load()
     some = next(iter(classes.values()))
     dx = torch.empty((N, C, H, W), device=some.device, dtype=torch.float32)
     g = lambda a, b: _lib.ptr(classes[(a, b)].contiguous()) if (a, b) in classes else None
     keep = [classes[k].contiguous() for k in classes]      # noqa: F841  (alive until the launch is enqueued)
     with torch.cuda.device(dx.device):
-        _lib.check(L.fi_stride2_interleave(g(0, 0), g(0, 1), g(1, 0), g(1, 1), _lib.ptr(add), _lib.ptr(dx), N * C, H, W,
-                                           _lib.current_stream()), "fi_stride2_interleave")
+        _lib.check(L.fi_stride2_interleave_gated(g(0, 0), g(0, 1), g(1, 0), g(1, 1), _lib.ptr(add), _lib.ptr(gate),
+                                                 _lib.ptr(dx), N * C, H, W, _lib.current_stream()),
+                   "fi_stride2_interleave")
     return dx
 
 
@@ -369,8 +374,17 @@ def _conv_backward(ctx_needs, x, w, dz, stride, padding, want_db=False, add_to_d
         dz_ready = torch.cuda.Event()
         dz_ready.record(torch.cuda.current_stream(x.device))
     if ctx_needs[0]:
-        if isinstance(add_to_dx, _Compact) and not (stride == (2, 2) and R * S == 1 and padding == (0, 0) and
-                                                    Cout % 16 == 0 and Cin % 16 == 0):
+        compact_path = stride == (2, 2) and R * S == 1 and padding == (0, 0) and Cout % 16 == 0 and Cin % 16 == 0
+        if isinstance(add_to_dx, tuple):
+            # (compact or None, full tensor or None): two gradients handed over (the projection shortcut's and the FPN
+            # lateral's); only the compact 1x1 / stride-2 path takes both inside its kernels
+            cpt, full = add_to_dx
+            if compact_path:
+                add_to_dx = (cpt, full) if (cpt is not None and full is not None) else (cpt if cpt is not None else full)
+            else:
+                parts = [t.expand() if isinstance(t, _Compact) else t for t in (cpt, full) if t is not None]
+                add_to_dx = parts[0] + parts[1] if len(parts) == 2 else (parts[0] if parts else None)
+        if isinstance(add_to_dx, _Compact) and not compact_path:
             add_to_dx = add_to_dx.expand()
         scaled = w_scale is not None
         weff = None            # W * w_scale, made on demand where no cached transposed copy exists
@@ -408,14 +422,19 @@ def _conv_backward(ctx_needs, x, w, dz, stride, padding, want_db=False, add_to_d
             wt = _cached_wt(w, scaled)
             if wt is None:
                 wt = w_eff().permute(1, 2, 3, 0).contiguous()
-            comp = add_to_dx.t if isinstance(add_to_dx, _Compact) else None
+            both = add_to_dx if isinstance(add_to_dx, tuple) else (add_to_dx if isinstance(add_to_dx, _Compact) else None,
+                                                                    add_to_dx if torch.is_tensor(add_to_dx) else None)
+            comp = both[0].t if both[0] is not None else None
             c = _conv_fwd(dz, wt, None, (1, 1), (0, 0), w_tap_major=True, flip_taps=True, residual=comp,
                           precision=precision)
-            full_add = add_to_dx if torch.is_tensor(add_to_dx) else None
-            if give_compact and full_add is None:
+            full_add = both[1]
+            if give_compact and full_add is None and gate is None:
                 dx = _Compact(c, (H, W))
             else:
-                dx = _interleave2({(0, 0): c}, full_add, N, Cin, H, W)
+                dx = _interleave2({(0, 0): c}, full_add, N, Cin, H, W,
+                                  gate=gate if (gate is not None and gate.is_contiguous()) else None)
+                if gate is not None and gate.is_contiguous():
+                    gate = None
         else:
             dx = _strided_dgrad(dz, w_eff(), (H, W), stride, padding, precision, add=add_to_dx)
         if gate is not None:
@@ -732,10 +751,36 @@ class GradBox(object):
     block's first convolution, whose data gradient flows into the same tensor, adds it inside its kernel
     epilogue (see Bottleneck.forward).  The giver must run first in backward: it must be applied AFTER the
     taker in forward (autograd executes ready nodes in reverse order of creation)."""
-    __slots__ = ("value",)
+    __slots__ = ("value", "taker")
 
     def __init__(self):
         self.value = None
+        self.taker = False      # set by the layer that WILL pick the value up (a giver must not give otherwise)
+
+
+def _take_boxes(boxes):
+    """The value(s) left in a GradBox, or in a pair of them (the second gradient then becomes the second element of a
+    (compact, full) tuple for _conv_backward); the boxes are emptied."""
+    if boxes is None:
+        return None
+    if isinstance(boxes, GradBox):
+        v, boxes.value = boxes.value, None
+        return v
+    vals = []
+    for b in boxes:
+        v, b.value = b.value, None
+        if v is not None:
+            vals.append(v)
+    if not vals:
+        return None
+    if len(vals) == 1:
+        return vals[0]
+    cpt = [v for v in vals if isinstance(v, _Compact)]
+    full = [v for v in vals if not isinstance(v, _Compact)]
+    if len(cpt) > 1 or len(full) > 1:
+        parts = [v.expand() if isinstance(v, _Compact) else v for v in vals]
+        return parts[0] + parts[1]
+    return (cpt[0] if cpt else None, full[0] if full else None)
 
 
 class Gate(object):
@@ -808,9 +853,7 @@ class _ConvBnActFn(torch.autograd.Function):
         if g_res is not None and ctx.res_grad_to is not None:
             ctx.res_grad_to.value = g_res           # picked up by the block's first convolution
             g_res = None
-        add = None
-        if ctx.dx_add_from is not None:
-            add, ctx.dx_add_from.value = ctx.dx_add_from.value, None
+        add = _take_boxes(ctx.dx_add_from)
         want_gamma, want_beta = ctx.needs_input_grad[3], ctx.needs_input_grad[4]
         want_db = has_bias and ctx.needs_input_grad[2]
         out = {}
@@ -873,9 +916,7 @@ class _ConvBnActFn(torch.autograd.Function):
         if g_res is not None and ctx.res_grad_to is not None:
             ctx.res_grad_to.value = g_res           # picked up by the block's first convolution
             g_res = None
-        add = None
-        if ctx.dx_add_from is not None:
-            add, ctx.dx_add_from.value = ctx.dx_add_from.value, None
+        add = _take_boxes(ctx.dx_add_from)
         dx, dw = _conv_backward(ctx.needs_input_grad, x, w, dz, stride, padding, add_to_dx=add, precision=ctx.precision,
                                 give_compact=ctx.dx_give_to is not None, gate=x if ctx.dx_gate else None)
         if ctx.dx_give_to is not None and dx is not None:
@@ -1201,9 +1242,11 @@ def linear(x, weight, bias=None):
     return _LinearFn.apply(x, weight, bias)
 
 
-def conv2d(x, weight, bias=None, stride=(1, 1), padding=(0, 0), residual=None, gate_dx=False):
+def conv2d(x, weight, bias=None, stride=(1, 1), padding=(0, 0), residual=None, gate_dx=False, dx_give_to=None):
     """Functional form: conv(x) + bias [+ residual, added in the kernel epilogue].  Full-window kernels are
-    matrix products (linear() above).  gate_dx: as conv_bn_act's (True, or the Gate of the tensor x is a view of)."""
+    matrix products (linear() above).  gate_dx: as conv_bn_act's (True, or the Gate of the tensor x is a view of).
+    dx_give_to: a GradBox whose taker flag is set -- the data gradient goes there instead of to autograd (the taker,
+    another reader of x whose backward runs later, adds it inside its own data-gradient kernel)."""
     R, S = weight.shape[2], weight.shape[3]
     gemm = ((x.shape[2], x.shape[3]) == (R, S) and tuple(padding) == (0, 0) and R * S > 1) or \
         (x.shape[2] * x.shape[3] == 1 and R * S == 1)
@@ -1211,7 +1254,8 @@ def conv2d(x, weight, bias=None, stride=(1, 1), padding=(0, 0), residual=None, g
         y = linear(x.reshape(x.shape[0], -1), weight.reshape(weight.shape[0], -1), bias)
         y = y.view(x.shape[0], weight.shape[0], 1, 1)
         return y if residual is None else y + residual
-    return _Conv2dFn.apply(x, weight, bias, tuple(stride), tuple(padding), residual, _claim_gate(x, gate_dx))
+    give = dx_give_to if (dx_give_to is not None and dx_give_to.taker and x.is_cuda and torch.is_grad_enabled()) else None
+    return _Conv2dFn.apply(x, weight, bias, tuple(stride), tuple(padding), residual, _claim_gate(x, gate_dx), give)
 
 
 class Conv2d(nn.Conv2d):

@@ -14,8 +14,8 @@ namespace {
 template <bool VEC>
 __global__ __launch_bounds__(256) void stride2_interleave_kernel(
     const float *__restrict__ c00, const float *__restrict__ c01, const float *__restrict__ c10,
-    const float *__restrict__ c11, const float *__restrict__ add, float *__restrict__ dx, long planes, int H,
-    int W)
+    const float *__restrict__ c11, const float *__restrict__ add, const float *__restrict__ gate,
+    float *__restrict__ dx, long planes, int H, int W)
 {
     const int qw0 = (W + 1) >> 1, qw1 = W >> 1;
     const int qh0 = (H + 1) >> 1, qh1 = H >> 1;
@@ -42,6 +42,11 @@ __global__ __launch_bounds__(256) void stride2_interleave_kernel(
                 const float4 a = *reinterpret_cast<const float4 *>(add + off);
                 r.x += a.x; r.y += a.y; r.z += a.z; r.w += a.w;
             }
+            if (gate) {          // dx * (gate > 0): the layer's input is a ReLU output that nothing else reads (conv.Gate)
+                const float4 g4 = *reinterpret_cast<const float4 *>(gate + off);
+                r.x = g4.x > 0.0f ? r.x : 0.0f; r.y = g4.y > 0.0f ? r.y : 0.0f;
+                r.z = g4.z > 0.0f ? r.z : 0.0f; r.w = g4.w > 0.0f ? r.w : 0.0f;
+            }
             *reinterpret_cast<float4 *>(dx + off) = r;
         }
     } else {
@@ -56,6 +61,7 @@ __global__ __launch_bounds__(256) void stride2_interleave_kernel(
             const int qwn = (w & 1) ? qw1 : qw0;
             float v = src ? src[(p * qhn + (h >> 1)) * (long)qwn + (w >> 1)] : 0.0f;
             if (add) v += add[i];
+            if (gate) v = gate[i] > 0.0f ? v : 0.0f;
             dx[i] = v;
         }
     }
@@ -381,20 +387,28 @@ int fi_bn_fold_batch(const FiBnFoldDesc *descs_dev, int n, int max_channels, fi_
 int fi_stride2_interleave(const float *c00, const float *c01, const float *c10, const float *c11,
                           const float *add, float *dx, long planes, int height, int width, fi_stream_t stream)
 {
+    return fi_stride2_interleave_gated(c00, c01, c10, c11, add, nullptr, dx, planes, height, width, stream);
+}
+
+int fi_stride2_interleave_gated(const float *c00, const float *c01, const float *c10, const float *c11,
+                                const float *add, const float *gate, float *dx, long planes, int height, int width,
+                                fi_stream_t stream)
+{
     FI_REQUIRE(dx && planes >= 0 && height >= 1 && width >= 1, "bad interleave arguments");
     if (planes == 0) return FI_OK;
     const uintptr_t all = (uintptr_t)c00 | (uintptr_t)c01 | (uintptr_t)c10 | (uintptr_t)c11;
-    const bool vec = width % 4 == 0 && all % 8 == 0 && (uintptr_t)dx % 16 == 0 && (uintptr_t)add % 16 == 0;
+    const bool vec = width % 4 == 0 && all % 8 == 0 && (uintptr_t)dx % 16 == 0 && (uintptr_t)add % 16 == 0 &&
+                     (uintptr_t)gate % 16 == 0;
     const long work = vec ? planes * height * (width / 4) : planes * height * width;
     const long blocks = (work + 255) / 256;
     const unsigned grid = (unsigned)(blocks < 65536 ? (blocks < 1 ? 1 : blocks) : 65536);
     fi::ProfScope prof(FI_K_STRIDE2_INTERLEAVE, (hipStream_t)stream);
     if (vec)
         hipLaunchKernelGGL(stride2_interleave_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, c00, c01,
-                           c10, c11, add, dx, planes, height, width);
+                           c10, c11, add, gate, dx, planes, height, width);
     else
         hipLaunchKernelGGL(stride2_interleave_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, c00, c01,
-                           c10, c11, add, dx, planes, height, width);
+                           c10, c11, add, gate, dx, planes, height, width);
     FI_HIP_CHECK(hipGetLastError());
     return FI_OK;
 }

@@ -102,6 +102,7 @@ class Bottleneck(nn.Module):
         self.downsample = downsample
         self.stride = stride
         self.input_sole = False       # True: nothing but this block reads its input (the inner blocks of a stage)
+        self.lateral_box = None       # set for ONE forward call by FPN.forward on the first block of C3..C5
 
     def forward(self, x):
         # conv + eval-BN (+ shortcut) + ReLU are one kernel launch each (conv.conv_bn_act)
@@ -124,8 +125,15 @@ class Bottleneck(nn.Module):
             # is applied after conv1, so its backward runs first; it leaves its gradient in the box (for the
             # stride-2 blocks in compact form: only even positions are non-zero) and conv1's backward adds it
             # inside its own data-gradient kernel -- no zero fill, strided scatter and add over block-sized tensors.
+            # `lateral_box` (FPN.forward): x -- the previous stage's output -- has a third reader, the FPN's lateral
+            # convolution, whose backward runs before this block's.  It leaves its data gradient in that box too, conv1's
+            # interleave pass adds both and, now that it sees x's WHOLE gradient, applies x's ReLU mask (gate_dx).
             box = GradBox()
-            out = conv_bn_act(x, self.conv1, self.bn1, relu=True, dx_add_from=box)
+            lateral, self.lateral_box = self.lateral_box, None
+            if lateral is not None:
+                lateral.taker = True
+            out = conv_bn_act(x, self.conv1, self.bn1, relu=True, dx_add_from=box if lateral is None else (box, lateral),
+                              gate_dx=lateral is not None)
             out = conv_bn_act(out, self.conv2, self.bn2, relu=True, gate_dx=True)
             residual = conv_bn_act(x, self.downsample[0], self.downsample[1], relu=False, dx_give_to=box)
             return conv_bn_act(out, self.conv3, self.bn3, relu=True, residual=residual, gate_dx=True)
@@ -208,10 +216,20 @@ class FPN(nn.Module):
         ot_loss = x.new_zeros(bs, 3)
         x = conv_bn_act(x, self.C1[0], self.C1[1], relu=True)       # C1 = conv, bn, relu, pad, maxpool
         x = _pad_maxpool(x, self.C1[3], self.C1[4])
+        # c2..c4 are read by the next stage AND by their lateral convolution: the lateral hands its data gradient to the
+        # next stage's first block (GradBox; see Bottleneck.forward), which is the only one left talking to autograd
+        fuse = mode == 'train' and not self.ot and x.is_cuda and torch.is_grad_enabled()
+        boxes = {}
         c2 = self.C2(x)
-        c3 = self.C3(c2)
-        c4 = self.C4(c3)
-        c5 = self.C5(c4)
+        c = {2: c2}
+        for lvl, stage in ((3, self.C3), (4, self.C4), (5, self.C5)):
+            first = stage[0] if (fuse and stage is not None and len(stage)) else None
+            if isinstance(first, Bottleneck) and first.downsample is not None and tuple(first.conv1.stride) == (2, 2):
+                boxes[lvl - 1] = first.lateral_box = GradBox()
+            c[lvl] = stage(c[lvl - 1])
+            if first is not None:
+                first.lateral_box = None           # not picked up (the block took another path): nothing is given
+        c3, c4, c5 = c[3], c[4], c[5]
         p5 = self.P5_conv1(c5)
         up = upsample2x
         if self.ot and mode == 'train':
@@ -227,10 +245,11 @@ class FPN(nn.Module):
             ot_loss = torch.stack((l0, l1, l2), 1)
         else:
             # lateral 1x1 conv + top-down map in the conv epilogue (no separate add pass)
-            lat = lambda m, c, top: conv2d(c, m.weight, m.bias, m.stride, m.padding, residual=up(top))
-            p4 = lat(self.P4_conv1, c4, p5)
-            p3 = lat(self.P3_conv1, c3, p4)
-            p2 = lat(self.P2_conv1, c2, p3)
+            lat = lambda m, c, top, box: conv2d(c, m.weight, m.bias, m.stride, m.padding, residual=up(top),
+                                                dx_give_to=box)
+            p4 = lat(self.P4_conv1, c4, p5, boxes.get(4))
+            p3 = lat(self.P3_conv1, c3, p4, boxes.get(3))
+            p2 = lat(self.P2_conv1, c2, p3, boxes.get(2))
         p5 = self.P5_conv2(p5)
         p4 = self.P4_conv2(p4)
         p3 = self.P3_conv2(p3)

@@ -387,6 +387,10 @@ int fi_bn_fold_batch(const FiBnFoldDesc *descs_dev, int n, int max_channels, fi_
 int fi_stride2_interleave(const float *c00, const float *c01, const float *c10, const float *c11,
                           const float *add, float *dx, long planes, int height, int width,
                           fi_stream_t stream);
+/* ... with the result multiplied by (gate > 0), gate [planes][H][W] or NULL (see fi_conv2d_forward_gated). */
+int fi_stride2_interleave_gated(const float *c00, const float *c01, const float *c10, const float *c11,
+                                const float *add, const float *gate, float *dx, long planes, int height, int width,
+                                fi_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * bf16-input, fp32-accumulate variants (v_mfma_f32_32x32x16_bf16) for BASELINE configs[4]'s reduced-
