@@ -83,6 +83,45 @@ def test_argument_validation_without_a_gpu():
     assert L.fi_bn_act_backward(16, 16, 16, None, None, None, 1, 8, 16, 1, 16, None, 16, None, None, 3, 0, None) == -1
 
 
+def test_round3_entry_points_validate_and_gradient_handoffs_on_the_host():
+    """The entry points added for the unscaled-gradient backward reject bad arguments before any HIP call, and the
+    host-side hand-off logic (GradBox pairs, Gate claims) behaves on CPU tensors: nothing is claimed, nothing is given."""
+    import torch
+    from feature_intertwiner_amd import _lib, conv as C
+    L = _lib.load()
+    a = [16, 16, None, None, None, 32, 16]                   # x, w, bias, scale, residual, gate, y
+    assert L.fi_conv2d_forward_gated(*a, 1, 32, 8, 8, 64, 1, 1, 1, 1, 0, 0, 0, 1, 0, 0, 1, None) == -1      # gate + NHWC output
+    assert b"gate" in L.fi_last_error()
+    assert L.fi_relu_mask(None, None, None, -1, None) == -1
+    assert L.fi_relu_mask(None, None, None, 0, None) == 0
+    assert L.fi_relu_mask(None, 16, 16, 8, None) == -1
+    assert L.fi_bn_fold_grad(None, 16, 16, 16, 16, 16, 0.001, None, None, None, 8, 8, 1, 0, 0, None) == -1
+    assert L.fi_bn_fold_grad(16, 16, 16, 16, 16, 16, 0.001, None, None, None, 0, 8, 1, 0, 0, None) == -1
+    assert L.fi_bn_fold_batch(None, 0, 0, None) == 0 and L.fi_bn_fold_batch(None, 3, 64, None) == -1
+    assert L.fi_sum2x2(16, 16, 1, 4, 5, None) == -1                                   # odd width
+    assert L.fi_sum2x2(None, None, 0, 4, 4, None) == 0
+    assert L.fi_maxpool3x3s2_forward(16, 16, 1, 8, 6, None) == -1                     # width % 4
+    assert L.fi_maxpool3x3s2_backward(16, 16, 16, 1, 2, 8, 0, None) == -1             # height < 3
+    assert L.fi_stride2_interleave_gated(None, None, None, None, None, None, None, 1, 4, 4, None) == -1
+    # GradBox pairs: (compact, full) for the compact 1x1 / stride-2 path, one value alone, nothing -> None
+    b1, b2 = C.GradBox(), C.GradBox()
+    assert C._take_boxes(None) is None and C._take_boxes((b1, b2)) is None
+    t = torch.ones(1, 2, 4, 4)
+    cp = C._Compact(torch.ones(1, 2, 2, 2), (4, 4))
+    b1.value = cp
+    assert C._take_boxes((b1, b2)) is cp and b1.value is None
+    b1.value, b2.value = cp, t
+    got = C._take_boxes((b1, b2))
+    assert isinstance(got, tuple) and got[0] is cp and got[1] is t and b1.value is None and b2.value is None
+    b1.value = t
+    assert C._take_boxes(b1) is t
+    # a Gate is only ever claimed for a CUDA tensor that requires grad, and only a taker's box is given to
+    x = torch.ones(1, 2, 4, 4, requires_grad=True)
+    x._fi_gate = C.Gate()
+    assert C._claim_gate(x, True) is False and not x._fi_gate.claimed
+    assert C.GradBox().taker is False
+
+
 def test_reference_shaped_python_surface():
     import inspect
     from feature_intertwiner_amd.roi_align.crop_and_resize import CropAndResizeFunction
