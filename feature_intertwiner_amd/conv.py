@@ -743,6 +743,9 @@ def _prepare_step(model, grad_on):
 
 
 _UNSCALED_BACKWARD = not _os.environ.get("FI_BN_BWD_OLD")      # A/B switch (scripts/ab_env.sh)
+# Gates and the FPN-lateral hand-off on / off.  Off + _UNSCALED_BACKWARD off = the round-2 form of the backward pass, kept
+# as the differential reference of tests/test_gpu_detector.py::test_detector_gradients_agree_between_backward_forms
+GATES = True
 
 
 class GradBox(object):
@@ -1008,7 +1011,7 @@ def conv_bias_relu(x, weight, bias=None, stride=(1, 1), padding=(0, 0), gate_dx=
 def _claim_gate(x, gate_dx):
     """gate_dx: True (x itself carries the Gate) or the Gate of the tensor x is a view of.  Claims it; returns whether
     this layer has to apply the mask (x > 0) to its data gradient."""
-    if not gate_dx or not (torch.is_grad_enabled() and x.is_cuda and x.requires_grad):
+    if not GATES or not gate_dx or not (torch.is_grad_enabled() and x.is_cuda and x.requires_grad):
         return False
     tok = gate_dx if isinstance(gate_dx, Gate) else getattr(x, "_fi_gate", None)
     if tok is None:

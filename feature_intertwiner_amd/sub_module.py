@@ -16,6 +16,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import _lib
+from . import conv as _conv
 from .conv import (Conv2d, ConvTranspose2x2, GradBox, conv2d, conv_bias_relu, conv_bn_act, linear, maxpool3x3s2,
                    upsample2x)
 from .intertwiner import class_mean, roi_level
@@ -218,7 +219,7 @@ class FPN(nn.Module):
         x = _pad_maxpool(x, self.C1[3], self.C1[4])
         # c2..c4 are read by the next stage AND by their lateral convolution: the lateral hands its data gradient to the
         # next stage's first block (GradBox; see Bottleneck.forward), which is the only one left talking to autograd
-        fuse = mode == 'train' and not self.ot and x.is_cuda and torch.is_grad_enabled()
+        fuse = mode == 'train' and not self.ot and x.is_cuda and torch.is_grad_enabled() and _conv.GATES
         boxes = {}
         c2 = self.C2(x)
         c = {2: c2}
