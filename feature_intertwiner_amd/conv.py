@@ -938,7 +938,7 @@ class _ConvBiasActFn(torch.autograd.Function):
     together (instead of threshold_backward + a separate reduction)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, stride, padding, out_gate=None, dx_gate=False):
+    def forward(ctx, x, w, b, stride, padding, out_gate=None, dx_gate=False, dx_add_from=None):
         _lib.require_cuda(x, w)
         x = x.contiguous().float()
         w = _dense(w.float())
@@ -947,7 +947,7 @@ class _ConvBiasActFn(torch.autograd.Function):
         y = _conv_fwd(x, w, bc, stride, padding, relu=True)
         ctx.save_for_backward(x, w, y)
         ctx.precision = _PRECISION
-        ctx.out_gate, ctx.dx_gate = out_gate, bool(dx_gate)
+        ctx.out_gate, ctx.dx_gate, ctx.dx_add_from = out_gate, bool(dx_gate), dx_add_from
         ctx.conf = (tuple(stride), tuple(padding), b is not None)
         ctx.bias_ptr = b.data_ptr() if b is not None else 0
         return y
@@ -958,17 +958,18 @@ class _ConvBiasActFn(torch.autograd.Function):
         stride, padding, has_bias = ctx.conf
         L = _lib.load()
         dy = dy.contiguous().float()
+        add = _take_boxes(ctx.dx_add_from)          # another reader's gradient for x: added in the data-gradient epilogue
         if ctx.out_gate is not None and ctx.out_gate.claimed:
             # the only reader of y applied the ReLU mask in its data-gradient epilogue (Gate): dy IS the masked
             # gradient; the bias gradient comes out of the weight-gradient kernel's pass over it
             if has_bias and ctx.needs_input_grad[2] and ctx.needs_input_grad[1]:
                 return _conv_backward(ctx.needs_input_grad, x, w, dy, stride, padding, want_db=True,
-                                      precision=ctx.precision, bias_ptr=ctx.bias_ptr,
-                                      gate=x if ctx.dx_gate else None) + (None, None, None, None)
+                                      precision=ctx.precision, bias_ptr=ctx.bias_ptr, add_to_dx=add,
+                                      gate=x if ctx.dx_gate else None) + (None, None, None, None, None)
             dx, dw = _conv_backward(ctx.needs_input_grad, x, w, dy, stride, padding, precision=ctx.precision,
-                                    gate=x if ctx.dx_gate else None)
+                                    add_to_dx=add, gate=x if ctx.dx_gate else None)
             db = dy.sum((0, 2, 3)) if (has_bias and ctx.needs_input_grad[2]) else None
-            return dx, dw, db, None, None, None, None
+            return dx, dw, db, None, None, None, None, None
         N, C, OH, OW = y.shape
         dz = torch.empty_like(y)
         ones = _ones(C, y.device)
@@ -982,8 +983,8 @@ class _ConvBiasActFn(torch.autograd.Function):
                                             _lib.ptr(dz), None, _lib.ptr(dshift), None, None, 0, flags,
                                             _lib.current_stream()), "fi_bn_act_backward")
         dx, dw = _conv_backward(ctx.needs_input_grad, x, w, dz, stride, padding, precision=ctx.precision,
-                                gate=x if ctx.dx_gate else None)
-        return dx, dw, (dshift if (has_bias and ctx.needs_input_grad[2] and first) else None), None, None, None, None
+                                add_to_dx=add, gate=x if ctx.dx_gate else None)
+        return dx, dw, (dshift if (has_bias and ctx.needs_input_grad[2] and first) else None), None, None, None, None, None
 
 
 _ONES = {}
@@ -998,11 +999,16 @@ def _ones(n, device):
     return t
 
 
-def conv_bias_relu(x, weight, bias=None, stride=(1, 1), padding=(0, 0), gate_dx=False):
+def conv_bias_relu(x, weight, bias=None, stride=(1, 1), padding=(0, 0), gate_dx=False, dx_add_from=None):
     """relu(conv2d(x, weight, bias)) fused (weight [Cout, Cin, R, S]).  The result carries a Gate (see there);
-    gate_dx as conv_bn_act's."""
+    gate_dx as conv_bn_act's.  dx_add_from: a GradBox another reader of x (applied LATER in forward) leaves its data
+    gradient in; this layer becomes the box's taker and adds the value inside its data-gradient kernel."""
     gate = Gate() if (torch.is_grad_enabled() and x.is_cuda) else None
-    y = _ConvBiasActFn.apply(x, weight, bias, tuple(stride), tuple(padding), gate, _claim_gate(x, gate_dx))
+    take = dx_add_from if (dx_add_from is not None and GATES and torch.is_grad_enabled() and x.is_cuda and
+                           x.requires_grad) else None
+    if take is not None:
+        take.taker = True
+    y = _ConvBiasActFn.apply(x, weight, bias, tuple(stride), tuple(padding), gate, _claim_gate(x, gate_dx), take)
     if gate is not None:
         y._fi_gate = gate
     return y

@@ -7,6 +7,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
+from . import conv as _conv
 from ._lib import const_tensor
 from .conv import conv_precision, prepare_step, set_conv_precision
 from .intertwiner import FeatureBuffer, meta_loss
@@ -105,7 +106,13 @@ class MaskRCNN(nn.Module):
         p2, p3, p4, p5, p6, fpn_ot_loss = self.fpn(images, mode=mode)
         rpn_maps = [p2, p3, p4, p5, p6]
         mrcnn_maps = [p2, p3, p4, p5]
-        outs = [self.rpn(p) for p in rpn_maps]
+        # P2..P5 have three readers -- the RPN, the Dev make-up layer and (raw) the Dev stage's big-box crop.  Backward
+        # visits them in the reverse order; each leaves its gradient for the map with the next one, whose data-gradient
+        # kernel adds it, and only the RPN's shared convolution reports to autograd (conv.GradBox; off with conv.GATES)
+        chain = bool(cfg.DEV.SWITCH) and images.is_cuda and torch.is_grad_enabled() and _conv.GATES
+        to_rpn = [_conv.GradBox() if chain else None for _ in mrcnn_maps]
+        to_make_up = [_conv.GradBox() if chain else None for _ in mrcnn_maps]
+        outs = [self.rpn(p, to_rpn[i] if i < len(to_rpn) else None) for i, p in enumerate(rpn_maps)]
         rpn_logits, rpn_probs, rpn_bbox = [torch.cat(list(o), dim=1) for o in zip(*outs)]
 
         with torch.no_grad():
@@ -128,14 +135,16 @@ class MaskRCNN(nn.Module):
             else:
                 side = (lambda r=targets_and_levels(proposals, num_prop, gt_class_ids, gtb, gt_masks, cfg,
                                                     self.generator): r)
-        up_maps = self.dev_roi.make_up_maps(mrcnn_maps) if (cfg.DEV.SWITCH and images.is_cuda) else None
+        up_maps = self.dev_roi.make_up_maps(mrcnn_maps, give_to=to_rpn, take_from=to_make_up) \
+            if (cfg.DEV.SWITCH and images.is_cuda) else None
         with torch.no_grad():
             (rois, target_class_ids, target_deltas, target_mask, roi_lvl), counts_ready = side()
             target_rpn_match, target_rpn_deltas = rpn_target_ready()
 
         K = cfg.DATASET.NUM_CLASSES
         pooled_cls, pooled_mask, feat_out = self.dev_roi(mrcnn_maps, rois, target_class_ids, up_maps=up_maps,
-                                                         level_info=(roi_lvl, counts_ready))
+                                                         level_info=(roi_lvl, counts_ready),
+                                                         raw_grad_boxes=to_make_up if chain else None)
         scale_num = 3
         if cfg.DEV.SWITCH and not cfg.DEV.BASELINE:
             big_feat, big_cnt, small_feat, small_cnt, big_loss, small_output_all, small_gt_all = feat_out

@@ -97,10 +97,13 @@ class CropGradGroup(object):
     the first backward of the group allocates and clears the maps' gradients and returns them to autograd, every
     later one ADDS into the same buffers (fi_pyramid_crop_backward*_accumulate) and returns no gradient -- instead
     of one cleared set of buffers per crop and an add pass per level."""
-    __slots__ = ("grads",)
+    __slots__ = ("grads", "give_to")
 
-    def __init__(self):
+    def __init__(self, give_to=None):
         self.grads = None
+        # give_to: per map, a conv.GradBox (or None): the map's gradient is left there for another reader of the map,
+        # whose data-gradient kernel adds it, instead of going to autograd (only boxes whose taker flag is set)
+        self.give_to = give_to
 
 
 class _PyramidCrop(torch.autograd.Function):
@@ -176,7 +179,12 @@ class _PyramidCrop(torch.autograd.Function):
                 "fi_pyramid_crop_backward")
         if accumulate:
             return (None,) * (7 + nl)
-        return (None, None, None, None, None, None, None) + tuple(grads)
+        out = list(grads)
+        if group is not None and group.give_to:
+            for i, box in enumerate(group.give_to):
+                if box is not None and box.taker:
+                    box.value, out[i] = out[i], None
+        return (None, None, None, None, None, None, None) + tuple(out)
 
 
 def pyramid_crop_and_resize(feature_maps, boxes, box_ind, level, crop_height, crop_width,

@@ -274,9 +274,13 @@ class RPN(nn.Module):
         self.softmax = nn.Softmax(dim=2)
         self.conv_bbox = Conv2d(512, 4 * anchors_per_location, kernel_size=1, stride=1)
 
-    def forward(self, x):
+    def forward(self, x, grad_box=None):
+        """grad_box: a GradBox in which a later reader of x (the Dev make-up layer) leaves ITS data gradient for x;
+        the shared convolution's data-gradient kernel adds it (only when the padding is folded: x itself is read)."""
         c = self.conv_shared
-        x = conv_bias_relu(self.padding(x), c.weight, c.bias, c.stride, c.padding)      # conv + bias + ReLU, one launch
+        xp = self.padding(x)
+        x = conv_bias_relu(xp, c.weight, c.bias, c.stride, c.padding,
+                           dx_add_from=grad_box if xp is x else None)                    # conv + bias + ReLU, one launch
         # the two 1x1 heads as ONE convolution over their stacked filters (every output channel is computed
         # exactly as before): the 512-channel map is read once instead of twice in forward, data gradient and
         # weight gradient, and autograd has no two data gradients to add
@@ -371,9 +375,12 @@ class Dev(nn.Module):
         b = boxes * float(self.image_shape[0])      # square images only
         return torch.stack([box_ind.float(), b[:, 1], b[:, 0], b[:, 3], b[:, 2]], dim=1)
 
-    def make_up_maps(self, x):
+    def make_up_maps(self, x, give_to=None, take_from=None):
         """The make-up layer (lib/sub_module.py:308-325, applied at :549-557) on every pyramid level.  It does not
-        depend on the RoIs, so the caller may run it while the RoIs are still being generated."""
+        depend on the RoIs, so the caller may run it while the RoIs are still being generated.
+        give_to / take_from: per level, GradBoxes of the level map's other readers (MaskRCNN.forward): the layer's data
+        gradient for the map -- plus what the big-box crop of forward() left in take_from -- goes to give_to's taker
+        (the RPN's shared convolution) instead of to autograd: one kernel writes the map's whole gradient."""
         cfg = self.config
 
         def make_up(i, m):
@@ -381,7 +388,14 @@ class Dev(nn.Module):
             if isinstance(seq[0], Conv2d):
                 # these maps feed only the two crops of forward(): written channels-last by the conv epilogue so
                 # that RoIAlign reads (and its backward adds) whole cache lines per tap
-                return conv_bn_act(m, seq[0], seq[1], relu=True, channels_last_out=(self.roi_type == 'roi_align'))
+                fused = m.is_cuda and not seq[1].training and seq[1].track_running_stats and m.requires_grad and \
+                    torch.is_grad_enabled() and m.shape[2] * m.shape[3] > 1
+                give = give_to[i] if (give_to and fused and give_to[i] is not None and give_to[i].taker) else None
+                take = take_from[i] if (take_from and fused and take_from[i] is not None) else None
+                if take is not None:
+                    take.taker = True
+                return conv_bn_act(m, seq[0], seq[1], relu=True, channels_last_out=(self.roi_type == 'roi_align'),
+                                   dx_add_from=take, dx_give_to=give)
             return seq(m)
         return [make_up(i, m) for i, m in enumerate(x)]
 
@@ -399,7 +413,9 @@ class Dev(nn.Module):
         counts_ready = _lib.async_host_read(per_level) if level.is_cuda else (lambda: per_level)
         return level, counts_ready
 
-    def forward(self, x, rois, roi_cls_gt=None, up_maps=None, level_info=None):
+    def forward(self, x, rois, roi_cls_gt=None, up_maps=None, level_info=None, raw_grad_boxes=None):
+        """raw_grad_boxes: per level, the GradBox make_up_maps(take_from=...) takes from -- the big-box crop of the RAW
+        level maps leaves its map gradients there."""
         cfg = self.config
         bs, R = rois.size(0), rois.size(1)
         boxes = rois.reshape(-1, 4)
@@ -480,7 +496,8 @@ class Dev(nn.Module):
         with torch.set_grad_enabled(torch.is_grad_enabled() and
                                     (not cfg.DEV.BIG_FEAT_DETACH or cfg.DEV.BIG_SUPERVISE)):
             if big_idx.numel():
-                big_pooled = self._crop(x, boxes[big_idx], box_ind[big_idx], big_level, self.feat_pool_size)
+                big_pooled = self._crop(x, boxes[big_idx], box_ind[big_idx], big_level, self.feat_pool_size,
+                                        CropGradGroup(give_to=raw_grad_boxes) if raw_grad_boxes else None)
                 big_raw = self._feat_extract(big_pooled)
                 big_out = self.last_op(big_raw) if cfg.DEV.LOSS_CHOICE != 'ot' else big_raw
                 big_out = big_out.view(big_idx.numel(), -1)
