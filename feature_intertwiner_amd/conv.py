@@ -342,6 +342,57 @@ def maxpool3x3s2(x):
     return _MaxPool3x3s2Fn.apply(x, _claim_gate(x, True))
 
 
+class _TakeRowsFn(torch.autograd.Function):
+    """x[index] along dim 0 for a tensor with a second reader: backward adds dy's rows INTO the gradient that reader
+    left in the GradBox (one index_add) instead of zeros + index_put followed by autograd's accumulation pass."""
+
+    @staticmethod
+    def _fast(x, index):
+        n = x[0].numel() if x.shape[0] else 0
+        return (x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and index.dtype == torch.int64 and
+                index.is_contiguous() and n >= 4 and n % 4 == 0 and 0 < index.numel() <= 65535 and x.data_ptr() % 16 == 0)
+
+    @staticmethod
+    def forward(ctx, x, index, box):
+        ctx.save_for_backward(index)
+        ctx.shape, ctx.box = tuple(x.shape), box
+        if not _TakeRowsFn._fast(x, index):
+            return x.index_select(0, index)
+        out = torch.empty((index.numel(),) + tuple(x.shape[1:]), device=x.device, dtype=torch.float32)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.load().fi_rows_gather(_lib.ptr(x), _lib.ptr(index), _lib.ptr(out), index.numel(),
+                                                  x[0].numel(), _lib.current_stream()), "fi_rows_gather")
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        index, = ctx.saved_tensors
+        base = _take_boxes(ctx.box)
+        if not (torch.is_tensor(base) and tuple(base.shape) == ctx.shape and base.is_contiguous() and
+                base.dtype == dy.dtype):
+            extra, base = base, torch.zeros(ctx.shape, device=dy.device, dtype=dy.dtype)
+            if torch.is_tensor(extra):
+                base += extra
+        dy = dy.contiguous()
+        if _TakeRowsFn._fast(base, index) and dy.dtype == torch.float32 and dy.data_ptr() % 16 == 0:
+            # the index is a prefix of a permutation (distinct rows): plain read-modify-write
+            with torch.cuda.device(dy.device):
+                _lib.check(_lib.load().fi_rows_scatter_add(_lib.ptr(dy), _lib.ptr(index), _lib.ptr(base), index.numel(),
+                                                           base[0].numel(), _lib.current_stream()), "fi_rows_scatter_add")
+        else:
+            base.index_add_(0, index, dy)
+        return base, None, None
+
+
+def take_rows(x, index, grad_box=None):
+    """x.index_select(0, index) for an index vector with DISTINCT entries; grad_box: a GradBox in which x's OTHER reader (applied later in forward) leaves its
+    gradient for x -- this op becomes the box's taker and returns the sum to autograd."""
+    if grad_box is not None and GATES and x.is_cuda and x.requires_grad and torch.is_grad_enabled():
+        grad_box.taker = True
+        return _TakeRowsFn.apply(x, index, grad_box)
+    return x.index_select(0, index)
+
+
 def upsample2x(x):
     """x2 nearest-neighbour upsampling (the FPN's top-down path)."""
     return _Upsample2xFn.apply(x) if (x.is_cuda and x.requires_grad and torch.is_grad_enabled()) else \

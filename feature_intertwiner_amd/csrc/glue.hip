@@ -230,6 +230,32 @@ __global__ __launch_bounds__(256) void maxpool3s2_bwd_kernel(const float *__rest
     }
 }
 
+// Row gather / scatter-add of a [rows][row_len] tensor by an index vector whose entries are DISTINCT (a permutation
+// prefix): dst[i] = src[index[i]]  /  dst[index[i]] += src[i].  One workgroup column per row, 16-byte accesses; the
+// framework's index kernels handle arbitrary (repeating) indices and run at a third of the copy rate here.
+__global__ __launch_bounds__(256) void rows_gather_kernel(const float *__restrict__ src, const long *__restrict__ index,
+                                                          float *__restrict__ dst, long row_len4)
+{
+    const long row = blockIdx.y;
+    const float4 *__restrict__ s4 = reinterpret_cast<const float4 *>(src) + index[row] * row_len4;
+    float4 *__restrict__ d4 = reinterpret_cast<float4 *>(dst) + row * row_len4;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < row_len4; i += (long)gridDim.x * 256) d4[i] = s4[i];
+}
+
+__global__ __launch_bounds__(256) void rows_scatter_add_kernel(const float *__restrict__ src, const long *__restrict__ index,
+                                                               float *__restrict__ dst, long row_len4)
+{
+    const long row = blockIdx.y;
+    const float4 *__restrict__ s4 = reinterpret_cast<const float4 *>(src) + row * row_len4;
+    float4 *__restrict__ d4 = reinterpret_cast<float4 *>(dst) + index[row] * row_len4;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < row_len4; i += (long)gridDim.x * 256) {
+        float4 a = d4[i];
+        const float4 b = s4[i];
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        d4[i] = a;
+    }
+}
+
 __global__ __launch_bounds__(256) void relu_mask_kernel(const float *__restrict__ dy, const float *__restrict__ y,
                                                         float *__restrict__ out, long n4, long n)
 {
@@ -298,6 +324,32 @@ __global__ __launch_bounds__(256) void bn_fold_grad_kernel(float *__restrict__ d
 }  // namespace
 
 extern "C" {
+
+int fi_rows_gather(const float *src, const int64_t *index, float *dst, long n_index, long row_len, fi_stream_t stream)
+{
+    FI_REQUIRE(n_index >= 0 && row_len >= 4 && row_len % 4 == 0, "row_len must be a positive multiple of 4");
+    if (n_index == 0) return FI_OK;
+    FI_REQUIRE(src && index && dst, "null pointer");
+    FI_REQUIRE((uintptr_t)src % 16 == 0 && (uintptr_t)dst % 16 == 0 && n_index <= 65535, "16-byte aligned tensors, <= 65535 rows");
+    const long per = std::min<long>(std::max<long>((row_len / 4 + 1023) / 1024, 1), 64);
+    hipLaunchKernelGGL(rows_gather_kernel, dim3((unsigned)per, (unsigned)n_index), dim3(256), 0, (hipStream_t)stream, src,
+                       reinterpret_cast<const long *>(index), dst, row_len / 4);
+    FI_HIP_CHECK(hipGetLastError());
+    return FI_OK;
+}
+
+int fi_rows_scatter_add(const float *src, const int64_t *index, float *dst, long n_index, long row_len, fi_stream_t stream)
+{
+    FI_REQUIRE(n_index >= 0 && row_len >= 4 && row_len % 4 == 0, "row_len must be a positive multiple of 4");
+    if (n_index == 0) return FI_OK;
+    FI_REQUIRE(src && index && dst, "null pointer");
+    FI_REQUIRE((uintptr_t)src % 16 == 0 && (uintptr_t)dst % 16 == 0 && n_index <= 65535, "16-byte aligned tensors, <= 65535 rows");
+    const long per = std::min<long>(std::max<long>((row_len / 4 + 1023) / 1024, 1), 64);
+    hipLaunchKernelGGL(rows_scatter_add_kernel, dim3((unsigned)per, (unsigned)n_index), dim3(256), 0, (hipStream_t)stream,
+                       src, reinterpret_cast<const long *>(index), dst, row_len / 4);
+    FI_HIP_CHECK(hipGetLastError());
+    return FI_OK;
+}
 
 int fi_maxpool3x3s2_forward(const float *x, float *y, long planes, int height, int width, fi_stream_t stream)
 {

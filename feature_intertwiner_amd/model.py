@@ -112,6 +112,8 @@ class MaskRCNN(nn.Module):
         chain = bool(cfg.DEV.SWITCH) and images.is_cuda and torch.is_grad_enabled() and _conv.GATES
         to_rpn = [_conv.GradBox() if chain else None for _ in mrcnn_maps]
         to_make_up = [_conv.GradBox() if chain else None for _ in mrcnn_maps]
+        # (the 14 x 14 crops likewise: mask head -> the row gather in front of the Dev stage's feature extractor)
+        mask_box = _conv.GradBox() if (chain and not cfg.MRCNN.MASK_HEAD_ON_POSITIVE_SLOTS) else None
         outs = [self.rpn(p, to_rpn[i] if i < len(to_rpn) else None) for i, p in enumerate(rpn_maps)]
         rpn_logits, rpn_probs, rpn_bbox = [torch.cat(list(o), dim=1) for o in zip(*outs)]
 
@@ -144,7 +146,8 @@ class MaskRCNN(nn.Module):
         K = cfg.DATASET.NUM_CLASSES
         pooled_cls, pooled_mask, feat_out = self.dev_roi(mrcnn_maps, rois, target_class_ids, up_maps=up_maps,
                                                          level_info=(roi_lvl, counts_ready),
-                                                         raw_grad_boxes=to_make_up if chain else None)
+                                                         raw_grad_boxes=to_make_up if chain else None,
+                                                         mask_grad_box=mask_box)
         scale_num = 3
         if cfg.DEV.SWITCH and not cfg.DEV.BASELINE:
             big_feat, big_cnt, small_feat, small_cnt, big_loss, small_output_all, small_gt_all = feat_out
@@ -165,7 +168,8 @@ class MaskRCNN(nn.Module):
             R = rois.size(1)
             pooled_mask = pooled_mask.view(bs, R, *pooled_mask.shape[1:])[:, :P].reshape(bs * P, *pooled_mask.shape[1:])
             mask_ids, mask_tgt = target_class_ids[:, :P], target_mask[:, :P]
-        mask_u = self.mask(pooled_mask, shuffled=False, activate=False)  # logits [bs*R', 2, 2, K, 14, 14]
+        mask_u = self.mask(pooled_mask, shuffled=False, activate=False,    # logits [bs*R', 2, 2, K, 14, 14]
+                           input_grad_box=mask_box)
         mrcnn_class_logits = mrcnn_class_logits.view(bs, -1, mrcnn_class_logits.size(1))
         mrcnn_bbox = mrcnn_bbox.view(bs, -1, mrcnn_bbox.size(1), mrcnn_bbox.size(2))
         mask_u = mask_u.view(bs, -1, *mask_u.shape[1:])

@@ -18,7 +18,7 @@ import torch.nn.functional as F
 from . import _lib
 from . import conv as _conv
 from .conv import (Conv2d, ConvTranspose2x2, GradBox, conv2d, conv_bias_relu, conv_bn_act, linear, maxpool3x3s2,
-                   upsample2x)
+                   take_rows, upsample2x)
 from .intertwiner import class_mean, roi_level
 from .roi_align.crop_and_resize import CropAndResizeFunction, CropGradGroup, pyramid_crop_and_resize
 from .roi_pooling.functions.roi_pool import RoIPoolFunction
@@ -413,9 +413,11 @@ class Dev(nn.Module):
         counts_ready = _lib.async_host_read(per_level) if level.is_cuda else (lambda: per_level)
         return level, counts_ready
 
-    def forward(self, x, rois, roi_cls_gt=None, up_maps=None, level_info=None, raw_grad_boxes=None):
+    def forward(self, x, rois, roi_cls_gt=None, up_maps=None, level_info=None, raw_grad_boxes=None, mask_grad_box=None):
         """raw_grad_boxes: per level, the GradBox make_up_maps(take_from=...) takes from -- the big-box crop of the RAW
-        level maps leaves its map gradients there."""
+        level maps leaves its map gradients there.  mask_grad_box: the mask head (the second reader of the 14 x 14
+        crops, applied after this stage) leaves its input gradient there; the row gather in front of the feature
+        extractor adds its own rows into it (conv.take_rows)."""
         cfg = self.config
         bs, R = rois.size(0), rois.size(1)
         boxes = rois.reshape(-1, 4)
@@ -451,7 +453,7 @@ class Dev(nn.Module):
         # or masked by level.
         n_rows = min((n_small + 63) // 64 * 64, total_box)
         order = torch.sort(level, stable=True)[1][:n_rows]
-        small_output = self._feat_extract(mask_and_feat[order])
+        small_output = self._feat_extract(take_rows(mask_and_feat, order, mask_grad_box))
         if cfg.DEV.LOSS_CHOICE != 'ot':
             small_output = self.last_op(small_output)
         small_output = small_output.view(n_rows, -1)
@@ -579,14 +581,16 @@ class Mask(nn.Module):
         self.sigmoid = nn.Sigmoid()
         self.relu = nn.ReLU(inplace=True)
 
-    def forward(self, x, shuffled=True, activate=True):
+    def forward(self, x, shuffled=True, activate=True, input_grad_box=None):
         """shuffled=True: [N, K, 28, 28] as the reference (lib/sub_module.py:769-787).
         shuffled=False: the same values as [N, 2, 2, K, 14, 14] with out[n,k,2h+a,2w+b] = u[n,a,b,k,h,w]
         (training: the loss gathers the class channel first and shuffles only that).
         activate=False (training, with shuffled=False): conv5's LOGITS; the sigmoid (:786) is applied by the
         loss to the one class channel per RoI it reads (compute_mrcnn_mask_loss_unshuffled(from_logits=True)) --
         an elementwise op commuted with a gather: same values, 1/81 of the elements."""
-        x = conv_bn_act(x, self.conv1, self.bn1, relu=True)
+        # input_grad_box: x has another reader whose backward runs later and takes the gradient from there (Dev.forward)
+        give = input_grad_box if (input_grad_box is not None and input_grad_box.taker and _fused_path(x, self.bn1)) else None
+        x = conv_bn_act(x, self.conv1, self.bn1, relu=True, dx_give_to=give)
         x = conv_bn_act(x, self.conv2, self.bn2, relu=True, gate_dx=True)      # each layer is the only reader of the
         x = conv_bn_act(x, self.conv3, self.bn3, relu=True, gate_dx=True)      # previous one's output (conv.Gate)
         x = conv_bn_act(x, self.conv4, self.bn4, relu=True, gate_dx=True)

@@ -278,6 +278,11 @@ int fi_conv2d_forward_gated(const float *x, const float *weight, const float *bi
                             const float *residual, const float *gate, float *y, int N, int Cin, int H, int W,
                             int Cout, int R, int S, int stride_h, int stride_w, int pad_h, int pad_w, int relu,
                             int weight_layout, int out_h, int out_w, int output_layout, fi_stream_t stream);
+/* dst[i][:] = src[index[i]][:] and dst[index[i]][:] += src[i][:] for [rows][row_len] fp32 tensors and an int64 index
+ * vector with DISTINCT entries (the Dev stage hands the feature extractor the 14 x 14 crops of its "small" RoIs in
+ * level-major order, lib/sub_module.py:583-598; the backward adds their gradients into the crops' gradient). */
+int fi_rows_gather(const float *src, const int64_t *index, float *dst, long n_index, long row_len, fi_stream_t stream);
+int fi_rows_scatter_add(const float *src, const int64_t *index, float *dst, long n_index, long row_len, fi_stream_t stream);
 /* The stem's max-pooling (lib/sub_module.py:44-45: SamePad2d + MaxPool2d(3, 2) == 3 x 3 / stride 2 windows clipped at
  * the right / bottom border, i.e. ceil_mode): y [planes][OH][OW], OH = (height - 2) / 2 + 1.  Backward recomputes the
  * arg-max from x with the framework's first-maximum rule and adds the gradients of the (up to 4) windows that select

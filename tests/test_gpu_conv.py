@@ -628,3 +628,27 @@ def test_stem_maxpool_kernels_match_the_framework_bit_for_bit(shape):
         c = inp.clone().requires_grad_(True)
         _MaxPool3x3s2Fn.apply(c, True).backward(gy)
         assert torch.equal(c.grad, b.grad * (inp > 0))
+
+
+def test_take_rows_gathers_and_hands_the_second_gradient_over():
+    """conv.take_rows: rows of a tensor with a second reader (the Dev stage's 14 x 14 crops: feature extractor + mask
+    head).  Values and gradients against plain indexing, with and without the GradBox hand-off."""
+    from feature_intertwiner_amd import conv as C
+    torch.manual_seed(4)
+    x = torch.randn(40, 8, 6, 6, device=DEV)
+    order = torch.randperm(40, device=DEV)[:25]
+    w = torch.randn(25, 8, 6, 6, device=DEV)
+    v = torch.randn(40, 8, 6, 6, device=DEV)
+    a = x.clone().requires_grad_(True)
+    (a[order] * w).sum().backward()
+    ref_alone = a.grad.clone()
+    for with_box in (False, True):
+        b = x.clone().requires_grad_(True)
+        box = C.GradBox() if with_box else None
+        rows = C.take_rows(b, order, box)
+        assert torch.equal(rows, x[order])
+        if with_box:
+            assert box.taker
+            box.value = v.clone()                 # what the second reader's backward would leave
+        (rows * w).sum().backward()
+        assert torch.equal(b.grad, ref_alone + v if with_box else ref_alone)
