@@ -342,6 +342,51 @@ def maxpool3x3s2(x):
     return _MaxPool3x3s2Fn.apply(x, _claim_gate(x, True))
 
 
+class _Conv1x1ClassRowsFn(torch.autograd.Function):
+    """out[n] = conv1x1(x, W, b)[n, cls[n]]  ([N, H, W] from x [N, C, H, W]): the 1x1 convolution is computed for ALL
+    output channels (the reference's schedule: lib/sub_module.py:783-786 evaluates every class's mask), the caller reads
+    one of them per row.  Backward exploits what that implies -- the output gradient has one non-zero channel per row --
+    instead of running the dense data- and weight-gradient kernels over K - 1 channels of zeros
+    (fi_class_row_conv1x1_backward: same gradients, one pass over x and one over dx)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, cls, gated):
+        _lib.require_cuda(x, w)
+        x = x.contiguous().float()
+        w2 = w.reshape(w.shape[0], -1).contiguous().float()
+        y = _conv_fwd(x, w2.view(w.shape[0], x.shape[1], 1, 1), b.contiguous().float() if b is not None else None,
+                      (1, 1), (0, 0))
+        cls = cls.to(torch.int64).contiguous()
+        ctx.save_for_backward(x, w2, cls)
+        ctx.gated, ctx.has_bias, ctx.wshape = bool(gated), b is not None, tuple(w.shape)
+        return y[torch.arange(x.shape[0], device=x.device), cls]
+
+    @staticmethod
+    def backward(ctx, d):
+        x, w2, cls = ctx.saved_tensors
+        N, C, H, W = x.shape
+        K = w2.shape[0]
+        d = d.contiguous().float()
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dw = torch.zeros_like(w2) if ctx.needs_input_grad[1] else None
+        db = torch.zeros(K, device=x.device, dtype=torch.float32) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        L = _lib.load()
+        ws = torch.empty(int(L.fi_class_row_conv1x1_workspace_bytes(N, C)) // 4, device=x.device, dtype=torch.float32)
+        with torch.cuda.device(x.device):
+            _lib.check(L.fi_class_row_conv1x1_backward(_lib.ptr(d), _lib.ptr(x), _lib.ptr(w2), _lib.ptr(cls),
+                                                       _lib.ptr(dx), _lib.ptr(dw), _lib.ptr(db), N, C, H * W, K,
+                                                       1 if ctx.gated else 0, _lib.ptr(ws), _lib.current_stream()),
+                       "fi_class_row_conv1x1_backward")
+        return dx, (dw.view(ctx.wshape) if dw is not None else None), db, None, None
+
+
+def conv1x1_class_rows(x, weight, bias, cls, gate_dx=False):
+    """conv2d(x, weight [K, C, 1, 1], bias)[n, cls[n]] for every row n -> [N, H, W]; gate_dx as conv2d's."""
+    if weight.shape[0] > 240:          # the backward keeps a [K][64] table in LDS: dense path beyond that
+        return conv2d(x, weight, bias, gate_dx=gate_dx)[torch.arange(x.shape[0], device=x.device), cls.long()]
+    return _Conv1x1ClassRowsFn.apply(x, weight, bias, cls, _claim_gate(x, gate_dx))
+
+
 class _TakeRowsFn(torch.autograd.Function):
     """x[index] along dim 0 for a tensor with a second reader: backward adds dy's rows INTO the gradient that reader
     left in the GradBox (one index_add) instead of zeros + index_put followed by autograd's accumulation pass."""

@@ -256,6 +256,125 @@ __global__ __launch_bounds__(256) void rows_scatter_add_kernel(const float *__re
     }
 }
 
+// Backward of a 1x1 convolution whose output gradient has ONE non-zero channel per image row: dy[n][cls[n]][p] = d[n][p],
+// zero elsewhere (the mask head's conv5 under the mask loss, lib/layers.py:905-934: only the target class's mask of a
+// RoI enters the loss).  The dense kernels would multiply 80 of 81 channels of zeros:
+//     dx[n][c][p]  = W[cls[n]][c] * d[n][p]      (* (x > 0) when gated: x is the ReLU output of the deconv)
+//     dW[k][c] += sum over rows n of class k, pixels p of d[n][p] * x[n][c][p]        db[k] += sum of d[n][p]
+// Phase 1, one workgroup per (row n, block of 64 channels): a wavefront owns a channel at a time, lanes run over pixels
+// (the plane's HW floats are contiguous); the per-row sums go to a workspace v[n][c], t[n].  Rows whose d is all zero
+// (RoIs that are not positives: three quarters of them) write zeros without reading x.  Phase 2, one workgroup per
+// (class, 64 channels): the rows of the class are summed in row order -- no atomics (thousands of rows share one
+// class: atomics on dW[k][c] serialise), deterministic.
+__global__ __launch_bounds__(256) void class_row_conv1x1_bwd_kernel(const float *__restrict__ d, const float *__restrict__ x,
+                                                                    const float *__restrict__ w, const long *__restrict__ cls,
+                                                                    float *__restrict__ dx, float *__restrict__ v,
+                                                                    float *__restrict__ t, float *__restrict__ live, int C,
+                                                                    int HW, int gated)
+{
+    extern __shared__ float s_d[];                   // d[n][0 .. HW)
+    __shared__ int s_any;
+    const long n = blockIdx.x;
+    const int c0 = blockIdx.y * 64;
+    const long k = cls[n];
+    const float *__restrict__ dn = d + n * HW;
+    if (threadIdx.x == 0) s_any = 0;
+    __syncthreads();
+    bool any = false;
+    for (int p = threadIdx.x; p < HW; p += 256) {
+        const float q = dn[p];
+        s_d[p] = q;
+        any |= q != 0.0f;
+    }
+    if (any) s_any = 1;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int cend = min(c0 + 64, C);
+    if (!s_any) {                                    // workgroup-uniform: a row that is not a positive RoI
+        if (blockIdx.y == 0 && threadIdx.x == 0) live[n] = 0.0f;
+        if (dx) {
+            float *__restrict__ op = dx + (n * C + c0) * (long)HW;
+            const long len = (long)(cend - c0) * HW;
+            if ((len & 3) == 0 && ((uintptr_t)op & 15) == 0) {
+                const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (long i = threadIdx.x; i < (len >> 2); i += 256) reinterpret_cast<float4 *>(op)[i] = z;
+            } else {
+                for (long i = threadIdx.x; i < len; i += 256) op[i] = 0.0f;
+            }
+        }
+        return;
+    }
+    if (blockIdx.y == 0 && wave == 0) {
+        float s = 0.0f;
+        for (int p = lane; p < HW; p += 64) s += s_d[p];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+        if (lane == 0) {
+            t[n] = s;
+            live[n] = 1.0f;
+        }
+    }
+    // two channels per trip (c and c + 4): their loads are in flight together
+    for (int c = c0 + wave; c < cend; c += 8) {
+        const bool two = c + 4 < cend;
+        const int cb = two ? c + 4 : c;
+        const float wa = w[k * C + c], wb = w[k * C + cb];
+        const float *__restrict__ xa = x + (n * C + c) * (long)HW;
+        const float *__restrict__ xb = x + (n * C + cb) * (long)HW;
+        float acca = 0.0f, accb = 0.0f;
+        for (int p = lane; p < HW; p += 64) {
+            const float va = xa[p], vb = xb[p], dv = s_d[p];
+            acca += dv * va;
+            accb += dv * vb;
+            if (dx) {
+                dx[(n * C + c) * (long)HW + p] = (!gated || va > 0.0f) ? wa * dv : 0.0f;
+                if (two) dx[(n * C + cb) * (long)HW + p] = (!gated || vb > 0.0f) ? wb * dv : 0.0f;
+            }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            acca += __shfl_xor(acca, off, 64);
+            accb += __shfl_xor(accb, off, 64);
+        }
+        if (lane == 0) {
+            v[n * C + c] = acca;
+            if (two) v[n * C + cb] = accb;
+        }
+    }
+}
+
+// Phase 2: (block of 64 channels, chunk of 256 rows) workgroups add their live rows into a [K][64] LDS table (ds_add_f32:
+// rows of one class meet inside the workgroup, not in memory) and flush the classes they saw with one global atomic per
+// (class, channel) -- 32 per address for 8192 rows, whatever the class distribution.
+__global__ __launch_bounds__(256) void class_row_reduce_kernel(const float *__restrict__ v, const float *__restrict__ t,
+                                                               const float *__restrict__ live, const long *__restrict__ cls,
+                                                               float *__restrict__ dw, float *__restrict__ db, long N, int C,
+                                                               int K)
+{
+    extern __shared__ float s_acc[];                 // [K][64], then [K] for the bias sums
+    float *s_t = s_acc + (size_t)K * 64;
+    for (int i = threadIdx.x; i < K * 65; i += 256) s_acc[i] = 0.0f;
+    __syncthreads();
+    const int cc = threadIdx.x & 63, slice = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cc;
+    const long n0 = (long)blockIdx.y * 256;
+    for (long n = n0 + slice; n < min(N, n0 + 256); n += 4) {
+        if (live[n] == 0.0f) continue;               // wavefront-uniform (a wavefront = one slice)
+        const long k = cls[n];
+        if (c < C) atomicAdd(&s_acc[k * 64 + cc], v[n * C + c]);
+        if (blockIdx.x == 0 && cc == 0) atomicAdd(&s_t[k], t[n]);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < K * 64; i += 256) {
+        const int k = i >> 6, ch = blockIdx.x * 64 + (i & 63);
+        const float a = s_acc[i];
+        if (a != 0.0f && ch < C && dw) atomicAdd(dw + (size_t)k * C + ch, a);
+    }
+    if (blockIdx.x == 0 && db)
+        for (int k = threadIdx.x; k < K; k += 256)
+            if (s_t[k] != 0.0f) atomicAdd(db + k, s_t[k]);
+}
+
 __global__ __launch_bounds__(256) void relu_mask_kernel(const float *__restrict__ dy, const float *__restrict__ y,
                                                         float *__restrict__ out, long n4, long n)
 {
@@ -324,6 +443,34 @@ __global__ __launch_bounds__(256) void bn_fold_grad_kernel(float *__restrict__ d
 }  // namespace
 
 extern "C" {
+
+size_t fi_class_row_conv1x1_workspace_bytes(long N, int C) { return (size_t)(N > 0 ? N : 0) * (size_t)(C + 2) * sizeof(float); }
+
+int fi_class_row_conv1x1_backward(const float *d, const float *x, const float *weight, const int64_t *cls, float *dx,
+                                  float *dweight, float *dbias, long N, int C, int HW, int num_classes, int gated,
+                                  float *workspace, fi_stream_t stream)
+{
+    FI_REQUIRE(N >= 0 && C >= 1 && HW >= 1 && HW <= 16384 && num_classes >= 1, "bad sizes (HW <= 16384)");
+    if (N == 0) return FI_OK;
+    FI_REQUIRE(d && x && weight && cls && workspace, "null pointer");
+    FI_REQUIRE(N <= 2147483647L, "too many rows");
+    if (num_classes > 240) {
+        fi::set_error("fi_class_row_conv1x1_backward keeps a [num_classes][64] table in LDS: num_classes <= 240 (got %d)", num_classes);
+        return FI_ERR_UNSUPPORTED;
+    }
+    float *v = workspace, *t = workspace + (size_t)N * C, *live = t + N;
+    hipLaunchKernelGGL(class_row_conv1x1_bwd_kernel, dim3((unsigned)N, (unsigned)((C + 63) / 64)), dim3(256),
+                       (size_t)HW * sizeof(float), (hipStream_t)stream, d, x, weight, reinterpret_cast<const long *>(cls), dx,
+                       v, t, live, C, HW, gated);
+    FI_HIP_CHECK(hipGetLastError());
+    if (dweight || dbias) {
+        hipLaunchKernelGGL(class_row_reduce_kernel, dim3((unsigned)((C + 63) / 64), (unsigned)((N + 255) / 256)), dim3(256),
+                           (size_t)num_classes * 65 * sizeof(float), (hipStream_t)stream, v, t, live,
+                           reinterpret_cast<const long *>(cls), dweight, dbias, N, C, num_classes);
+        FI_HIP_CHECK(hipGetLastError());
+    }
+    return FI_OK;
+}
 
 int fi_rows_gather(const float *src, const int64_t *index, float *dst, long n_index, long row_len, fi_stream_t stream)
 {

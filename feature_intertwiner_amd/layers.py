@@ -394,6 +394,18 @@ def compute_mrcnn_mask_loss_unshuffled(target_masks, target_class_ids, pred_u, f
     return (l * pos).sum() / (pos.sum() * 4 * h * w).clamp(min=1)
 
 
+def compute_mrcnn_mask_loss_selected(target_masks, target_class_ids, logits):
+    """compute_mrcnn_mask_loss for logits [b, R, 2, 2, h, w] that ALREADY are the target class's channel of the mask
+    head's un-shuffled output (Mask.forward(select_class=...)): sigmoid, pixel shuffle, BCE on the positives.  Same
+    value and gradient as compute_mrcnn_mask_loss_unshuffled(from_logits=True) on the full output."""
+    cls = target_class_ids.long()
+    b, R, _, _, h, w = logits.shape
+    pred = torch.sigmoid(logits).permute(0, 1, 4, 2, 5, 3).reshape(b, R, 2 * h, 2 * w)
+    pos = (cls > 0).float().view(b, R, 1, 1)
+    l = F.binary_cross_entropy(pred, target_masks, reduction='none')
+    return (l * pos).sum() / (pos.sum() * 4 * h * w).clamp(min=1)
+
+
 def compute_mrcnn_mask_loss(target_masks, target_class_ids, pred_masks):
     """pred_masks [b, R, num_classes, h, w] probabilities: positives only, class-specific mask."""
     cls = target_class_ids.long()

@@ -11,7 +11,8 @@ from . import conv as _conv
 from ._lib import const_tensor
 from .conv import conv_precision, prepare_step, set_conv_precision
 from .intertwiner import FeatureBuffer, meta_loss
-from .layers import (compute_mrcnn_bbox_loss, compute_mrcnn_class_loss, compute_mrcnn_mask_loss_unshuffled,
+from .layers import (compute_mrcnn_bbox_loss, compute_mrcnn_class_loss, compute_mrcnn_mask_loss_selected,
+                     compute_mrcnn_mask_loss_unshuffled,
                      compute_rpn_bbox_loss, compute_rpn_class_loss, detection_layer, generate_pyramid_priors,
                      prepare_det_target, prepare_rpn_target, proposal_layer)
 from .OT_module import OptTrans
@@ -168,8 +169,10 @@ class MaskRCNN(nn.Module):
             R = rois.size(1)
             pooled_mask = pooled_mask.view(bs, R, *pooled_mask.shape[1:])[:, :P].reshape(bs * P, *pooled_mask.shape[1:])
             mask_ids, mask_tgt = target_class_ids[:, :P], target_mask[:, :P]
-        mask_u = self.mask(pooled_mask, shuffled=False, activate=False,    # logits [bs*R', 2, 2, K, 14, 14]
-                           input_grad_box=mask_box)
+        # logits of every RoI's TARGET class [bs*R', 2, 2, 14, 14] (all K classes are evaluated; see Mask.forward), or of
+        # all classes [bs*R', 2, 2, K, 14, 14] on a CPU tensor / with conv.GATES off
+        mask_u = self.mask(pooled_mask, shuffled=False, activate=False, input_grad_box=mask_box,
+                           select_class=mask_ids.reshape(-1))
         mrcnn_class_logits = mrcnn_class_logits.view(bs, -1, mrcnn_class_logits.size(1))
         mrcnn_bbox = mrcnn_bbox.view(bs, -1, mrcnn_bbox.size(1), mrcnn_bbox.size(2))
         mask_u = mask_u.view(bs, -1, *mask_u.shape[1:])
@@ -179,6 +182,7 @@ class MaskRCNN(nn.Module):
             compute_rpn_bbox_loss(target_rpn_deltas, target_rpn_match, rpn_bbox),
             compute_mrcnn_class_loss(target_class_ids, mrcnn_class_logits),
             compute_mrcnn_bbox_loss(target_deltas, target_class_ids, mrcnn_bbox),
+            compute_mrcnn_mask_loss_selected(mask_tgt, mask_ids, mask_u) if mask_u.dim() == 6 else
             compute_mrcnn_mask_loss_unshuffled(mask_tgt, mask_ids, mask_u, from_logits=True))).view(1, 5)
         return (losses, big_feat, big_cnt, small_feat, small_cnt, big_loss, small_output_all, small_gt_all,
                 fpn_ot_loss)

@@ -17,8 +17,8 @@ import torch.nn.functional as F
 
 from . import _lib
 from . import conv as _conv
-from .conv import (Conv2d, ConvTranspose2x2, GradBox, conv2d, conv_bias_relu, conv_bn_act, linear, maxpool3x3s2,
-                   take_rows, upsample2x)
+from .conv import (Conv2d, ConvTranspose2x2, GradBox, conv1x1_class_rows, conv2d, conv_bias_relu, conv_bn_act, linear,
+                   maxpool3x3s2, take_rows, upsample2x)
 from .intertwiner import class_mean, roi_level
 from .roi_align.crop_and_resize import CropAndResizeFunction, CropGradGroup, pyramid_crop_and_resize
 from .roi_pooling.functions.roi_pool import RoIPoolFunction
@@ -581,13 +581,16 @@ class Mask(nn.Module):
         self.sigmoid = nn.Sigmoid()
         self.relu = nn.ReLU(inplace=True)
 
-    def forward(self, x, shuffled=True, activate=True, input_grad_box=None):
+    def forward(self, x, shuffled=True, activate=True, input_grad_box=None, select_class=None):
         """shuffled=True: [N, K, 28, 28] as the reference (lib/sub_module.py:769-787).
         shuffled=False: the same values as [N, 2, 2, K, 14, 14] with out[n,k,2h+a,2w+b] = u[n,a,b,k,h,w]
         (training: the loss gathers the class channel first and shuffles only that).
         activate=False (training, with shuffled=False): conv5's LOGITS; the sigmoid (:786) is applied by the
         loss to the one class channel per RoI it reads (compute_mrcnn_mask_loss_unshuffled(from_logits=True)) --
-        an elementwise op commuted with a gather: same values, 1/81 of the elements."""
+        an elementwise op commuted with a gather: same values, 1/81 of the elements.
+        select_class [N] (training, with shuffled=False and activate=False): return only the logits of class
+        select_class[n] for RoI n, [N, 2, 2, 14, 14] -- conv5 still evaluates every class (the reference's schedule), but
+        its backward then knows that the gradient has one non-zero channel per RoI (conv.conv1x1_class_rows)."""
         # input_grad_box: x has another reader whose backward runs later and takes the gradient from there (Dev.forward)
         give = input_grad_box if (input_grad_box is not None and input_grad_box.taker and _fused_path(x, self.bn1)) else None
         x = conv_bn_act(x, self.conv1, self.bn1, relu=True, dx_give_to=give)
@@ -599,6 +602,11 @@ class Mask(nn.Module):
         u = self.deconv.forward_unshuffled(x, relu=True, gate_dx=True)   # [N, 2, 2, 256, H, W]; conv4's only reader
         n, h, w = u.shape[0], u.shape[4], u.shape[5]
         K = self.conv5.weight.shape[0]
+        if select_class is not None and not activate and not shuffled and u.is_cuda and _conv.GATES:
+            cls4 = select_class.reshape(-1, 1).expand(-1, 4).reshape(-1)             # rows of u are (RoI, a, b)
+            sel = conv1x1_class_rows(u.view(n * 4, u.shape[3], h, w), self.conv5.weight, self.conv5.bias, cls4,
+                                     gate_dx=getattr(u, "_fi_gate", None))           # u's only reader
+            return sel.view(n, 2, 2, h, w)
         if activate or K % 16 == 0 or not u.is_cuda:
             y = self.conv5(u.view(n * 4, u.shape[3], h, w))
         else:

@@ -278,6 +278,18 @@ int fi_conv2d_forward_gated(const float *x, const float *weight, const float *bi
                             const float *residual, const float *gate, float *y, int N, int Cin, int H, int W,
                             int Cout, int R, int S, int stride_h, int stride_w, int pad_h, int pad_w, int relu,
                             int weight_layout, int out_h, int out_w, int output_layout, fi_stream_t stream);
+/* Backward of a 1x1 convolution y [N,K,HW] = W [K,C] . x [N,C,HW] + b whose output gradient has ONE non-zero channel
+ * per row n: dy[n][cls[n]] = d[n] (d is [N,HW]), zeros elsewhere -- the mask head's conv5 under the mask loss
+ * (lib/layers.py:905-934 reads the target class's mask of a RoI and nothing else):
+ *     dx[n][c] = W[cls[n]][c] * d[n]  (times (x > 0) if gated),   dweight[cls[n]][c] += <d[n], x[n][c]>,
+ *     dbias[cls[n]] += sum d[n]
+ * dx may be NULL; dweight / dbias (may be NULL) are ACCUMULATED into (rows pre-summed per class in LDS, then fp32
+ * atomics); cls int64 in [0, num_classes), num_classes <= 240 (FI_ERR_UNSUPPORTED otherwise); workspace:
+ * fi_class_row_conv1x1_workspace_bytes(N, C). */
+size_t fi_class_row_conv1x1_workspace_bytes(long N, int C);
+int fi_class_row_conv1x1_backward(const float *d, const float *x, const float *weight, const int64_t *cls, float *dx,
+                                  float *dweight, float *dbias, long N, int C, int HW, int num_classes, int gated,
+                                  float *workspace, fi_stream_t stream);
 /* dst[i][:] = src[index[i]][:] and dst[index[i]][:] += src[i][:] for [rows][row_len] fp32 tensors and an int64 index
  * vector with DISTINCT entries (the Dev stage hands the feature extractor the 14 x 14 crops of its "small" RoIs in
  * level-major order, lib/sub_module.py:583-598; the backward adds their gradients into the crops' gradient). */

@@ -652,3 +652,39 @@ def test_take_rows_gathers_and_hands_the_second_gradient_over():
             box.value = v.clone()                 # what the second reader's backward would leave
         (rows * w).sum().backward()
         assert torch.equal(b.grad, ref_alone + v if with_box else ref_alone)
+
+
+@pytest.mark.parametrize("N,C,K,hw,gated", [(64, 256, 81, 14, True), (37, 48, 5, 7, False), (16, 256, 81, 14, False)])
+def test_class_row_conv1x1_matches_the_dense_backward(N, C, K, hw, gated):
+    """conv.conv1x1_class_rows: the mask head's conv5 + the loss's class gather.  Forward = the dense 1x1 convolution's
+    channel cls[n]; backward (fi_class_row_conv1x1_backward) = what the dense data- and weight-gradient produce for a
+    gradient that is zero outside channel cls[n] -- against float64 autograd of the dense formulation; `gated`: x is a
+    ReLU output whose mask the layer applies to dx (conv.Gate)."""
+    from feature_intertwiner_amd import conv as C_
+    torch.manual_seed(N + K)
+    pre = torch.randn(N, C, hw, hw, device=DEV)
+    w = (torch.randn(K, C, 1, 1, device=DEV) * 0.1).requires_grad_(True)
+    b = torch.randn(K, device=DEV).requires_grad_(True)
+    cls = torch.randint(0, K, (N,), device=DEV)
+    gy = torch.randn(N, hw, hw, device=DEV)
+    # library path: x = relu(pre) produced by a fused conv so that it carries a Gate when `gated`
+    x_leaf = pre.clone().requires_grad_(True)
+    if gated:
+        eye = torch.eye(C, device=DEV).view(C, C, 1, 1)
+        x = C_.conv_bias_relu(x_leaf, eye, None)                      # relu(x_leaf), with a Gate
+        out = C_.conv1x1_class_rows(x, w, b, cls, gate_dx=True)
+        assert x._fi_gate.claimed
+    else:
+        x = x_leaf
+        out = C_.conv1x1_class_rows(x, w, b, cls)
+    out.backward(gy)
+    # float64 dense reference
+    xd = pre.double().cpu().requires_grad_(True)
+    wd, bd = w.detach().double().cpu().requires_grad_(True), b.detach().double().cpu().requires_grad_(True)
+    xin = torch.relu(xd) if gated else xd
+    y = F.conv2d(xin, wd, bd)
+    ref = y[torch.arange(N), cls.cpu()]
+    ref.backward(gy.double().cpu())
+    assert float((out.detach().cpu().double() - ref.detach()).abs().max()) <= 1e-4 * float(ref.abs().max())
+    for name, got, want in (("dx", x_leaf.grad, xd.grad), ("dw", w.grad, wd.grad), ("db", b.grad, bd.grad)):
+        assert float((got.cpu().double() - want).abs().max()) <= 2e-5 * float(want.abs().max()) + 1e-9, name
