@@ -355,6 +355,27 @@ def compute_rpn_class_loss(target_rpn_match, rpn_class_logits):
     return _masked_mean(ce, (target_rpn_match != 0).reshape(-1).float())
 
 
+def select_rpn_rows(target_rpn_match, rows_per_image):
+    """(image [R], anchor [R], valid [R]), R = b * rows_per_image: the anchors with target_rpn_match != 0 in (image,
+    anchor) order, padded with invalid rows -- prepare_rpn_target samples at most RPN.TRAIN_ANCHORS_PER_IMAGE of them
+    per image, so the shape is static and nothing is read back."""
+    b = target_rpn_match.size(0)
+    sel = torch.nonzero_static(target_rpn_match != 0, size=b * rows_per_image, fill_value=-1)
+    return sel[:, 0], sel[:, 1], sel[:, 0] >= 0
+
+
+def compute_rpn_losses_on_rows(target_rpn_match, target_rpn_deltas, image, anchor, valid, logits, bbox):
+    """compute_rpn_class_loss and compute_rpn_bbox_loss on the rows of select_rpn_rows (every anchor with a non-zero
+    match is one of them, every other anchor contributes exactly zero to either loss): same values."""
+    i, a = image.clamp(min=0), anchor.clamp(min=0)
+    match = torch.where(valid, target_rpn_match[i, a], torch.zeros_like(target_rpn_match[i, a]))
+    ce = F.cross_entropy(logits, (match == 1).long(), reduction='none')
+    cls_loss = _masked_mean(ce, (match != 0).float())
+    pos = (match == 1).float().unsqueeze(1)
+    l = F.smooth_l1_loss(bbox, target_rpn_deltas[i, a], reduction='none')
+    return cls_loss, (l * pos).sum() / (pos.sum() * 4).clamp(min=1)
+
+
 def compute_rpn_bbox_loss(target_rpn_deltas, target_rpn_match, rpn_bbox):
     pos = (target_rpn_match == 1).float().unsqueeze(2)
     l = F.smooth_l1_loss(rpn_bbox, target_rpn_deltas, reduction='none')

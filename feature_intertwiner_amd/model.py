@@ -13,8 +13,8 @@ from .conv import conv_precision, prepare_step, set_conv_precision
 from .intertwiner import FeatureBuffer, meta_loss
 from .layers import (compute_mrcnn_bbox_loss, compute_mrcnn_class_loss, compute_mrcnn_mask_loss_selected,
                      compute_mrcnn_mask_loss_unshuffled,
-                     compute_rpn_bbox_loss, compute_rpn_class_loss, detection_layer, generate_pyramid_priors,
-                     prepare_det_target, prepare_rpn_target, proposal_layer)
+                     compute_rpn_bbox_loss, compute_rpn_class_loss, compute_rpn_losses_on_rows, detection_layer,
+                     generate_pyramid_priors, prepare_det_target, prepare_rpn_target, proposal_layer, select_rpn_rows)
 from .OT_module import OptTrans
 from .sub_module import FPN, RPN, Classifier, Dev, Mask, ResNet
 
@@ -115,7 +115,21 @@ class MaskRCNN(nn.Module):
         to_make_up = [_conv.GradBox() if chain else None for _ in mrcnn_maps]
         # (the 14 x 14 crops likewise: mask head -> the row gather in front of the Dev stage's feature extractor)
         mask_box = _conv.GradBox() if (chain and not cfg.MRCNN.MASK_HEAD_ON_POSITIVE_SLOTS) else None
-        outs = [self.rpn(p, to_rpn[i] if i < len(to_rpn) else None) for i, p in enumerate(rpn_maps)]
+        # The RPN losses read RPN.TRAIN_ANCHORS_PER_IMAGE sampled anchors per image: with conv.GATES the dense RPN runs
+        # without a graph (the proposal layer needs every anchor) and the losses' graph is RPN.forward_rows on those rows
+        rows = images.is_cuda and torch.is_grad_enabled() and _conv.GATES and self.rpn.anchor_stride == 1
+        if rows:
+            with torch.no_grad():
+                outs = [self.rpn(p) for p in rpn_maps]
+                target_rpn_match, target_rpn_deltas = rpn_target_ready()
+                r_img, r_anchor, r_valid = select_rpn_rows(target_rpn_match, cfg.RPN.TRAIN_ANCHORS_PER_IMAGE)
+            for b_ in to_rpn:
+                if b_ is not None:
+                    b_.taker = True                     # _PatchRowsFn takes what the make-up layer leaves
+            row_logits, row_bbox = self.rpn.forward_rows(rpn_maps, r_img, r_anchor, r_valid,
+                                                         grad_boxes=list(to_rpn) + [None] * (len(rpn_maps) - len(to_rpn)))
+        else:
+            outs = [self.rpn(p, to_rpn[i] if i < len(to_rpn) else None) for i, p in enumerate(rpn_maps)]
         rpn_logits, rpn_probs, rpn_bbox = [torch.cat(list(o), dim=1) for o in zip(*outs)]
 
         with torch.no_grad():
@@ -142,7 +156,8 @@ class MaskRCNN(nn.Module):
             if (cfg.DEV.SWITCH and images.is_cuda) else None
         with torch.no_grad():
             (rois, target_class_ids, target_deltas, target_mask, roi_lvl), counts_ready = side()
-            target_rpn_match, target_rpn_deltas = rpn_target_ready()
+            if not rows:
+                target_rpn_match, target_rpn_deltas = rpn_target_ready()
 
         K = cfg.DATASET.NUM_CLASSES
         pooled_cls, pooled_mask, feat_out = self.dev_roi(mrcnn_maps, rois, target_class_ids, up_maps=up_maps,
@@ -177,9 +192,15 @@ class MaskRCNN(nn.Module):
         mrcnn_bbox = mrcnn_bbox.view(bs, -1, mrcnn_bbox.size(1), mrcnn_bbox.size(2))
         mask_u = mask_u.view(bs, -1, *mask_u.shape[1:])
 
+        if rows:
+            rpn_cls_loss, rpn_box_loss = compute_rpn_losses_on_rows(target_rpn_match, target_rpn_deltas, r_img, r_anchor,
+                                                                    r_valid, row_logits, row_bbox)
+        else:
+            rpn_cls_loss = compute_rpn_class_loss(target_rpn_match, rpn_logits)
+            rpn_box_loss = compute_rpn_bbox_loss(target_rpn_deltas, target_rpn_match, rpn_bbox)
         losses = torch.stack((
-            compute_rpn_class_loss(target_rpn_match, rpn_logits),
-            compute_rpn_bbox_loss(target_rpn_deltas, target_rpn_match, rpn_bbox),
+            rpn_cls_loss,
+            rpn_box_loss,
             compute_mrcnn_class_loss(target_class_ids, mrcnn_class_logits),
             compute_mrcnn_bbox_loss(target_deltas, target_class_ids, mrcnn_bbox),
             compute_mrcnn_mask_loss_selected(mask_tgt, mask_ids, mask_u) if mask_u.dim() == 6 else

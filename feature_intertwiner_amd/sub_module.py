@@ -259,6 +259,58 @@ class FPN(nn.Module):
         return [p2, p3, p4, p5, p6, ot_loss]
 
 
+class _PatchRowsFn(torch.autograd.Function):
+    """rows[r] = the 3 x 3 x C patch (tap-major: (dy, dx, c)) around pixel (h_r, w_r) of image n_r on pyramid level
+    lvl_r -- zeros outside the map and for invalid rows.  The training path of the RPN reads the pyramid ONLY here
+    (RPN.forward_rows): backward adds the patch gradients into the level maps' gradients (a few thousand atomics) instead
+    of running dense convolution gradients over maps whose output gradient is zero except at the sampled anchors.
+    boxes[l] (a conv.GradBox or None): another reader of level l (the Dev make-up layer) leaves ITS gradient for the
+    map there; this op is the taker and returns the sum to autograd."""
+
+    @staticmethod
+    def _index(n, h, w, use, H, W):
+        dy = torch.tensor([-1, -1, -1, 0, 0, 0, 1, 1, 1], device=n.device)
+        dx = torch.tensor([-1, 0, 1, -1, 0, 1, -1, 0, 1], device=n.device)
+        hh, ww = h.unsqueeze(1) + dy, w.unsqueeze(1) + dx                       # [R, 9]
+        inside = (hh >= 0) & (hh < H) & (ww >= 0) & (ww < W) & use.unsqueeze(1)
+        # taps that do not exist (outside the map, rows of another level, padding rows) read / add zeros SOMEWHERE: spread
+        # them over the map (slot id modulo the map) -- parked on one pixel their atomic adds would serialise
+        slot = torch.arange(n.numel() * 9, device=n.device).view(-1, 9)
+        hh = torch.where(inside, hh, (slot // W) % H)
+        ww = torch.where(inside, ww, slot % W)
+        return n.unsqueeze(1).expand(-1, 9), hh, ww, inside
+
+    @staticmethod
+    def forward(ctx, n, lvl, h, w, valid, boxes, *maps):
+        R, C = n.numel(), maps[0].shape[1]
+        out = maps[0].new_zeros(R, 9, C)
+        for l, m in enumerate(maps):
+            nn_, hc, wc, inside = _PatchRowsFn._index(n, h, w, valid & (lvl == l), m.shape[2], m.shape[3])
+            out += m.permute(0, 2, 3, 1)[nn_, hc, wc] * inside.unsqueeze(2)
+        ctx.save_for_backward(n, lvl, h, w, valid)
+        ctx.shapes, ctx.boxes = [tuple(m.shape) for m in maps], boxes
+        return out.view(R, 9 * C)
+
+    @staticmethod
+    def backward(ctx, d):
+        n, lvl, h, w, valid = ctx.saved_tensors
+        R = n.numel()
+        d = d.reshape(R, 9, -1)
+        grads = []
+        for l, shape in enumerate(ctx.shapes):
+            base = None
+            if ctx.boxes is not None and ctx.boxes[l] is not None:
+                base, ctx.boxes[l].value = ctx.boxes[l].value, None
+            if not (torch.is_tensor(base) and tuple(base.shape) == shape and base.is_contiguous()):
+                extra, base = base, d.new_zeros(shape)
+                if torch.is_tensor(extra):
+                    base += extra
+            nn_, hc, wc, inside = _PatchRowsFn._index(n, h, w, valid & (lvl == l), shape[2], shape[3])
+            base.permute(0, 2, 3, 1).index_put_((nn_, hc, wc), d * inside.unsqueeze(2), accumulate=True)
+            grads.append(base)
+        return (None,) * 6 + tuple(grads)
+
+
 class RPN(nn.Module):
     """Returns [rpn_class_logits [b, anchors, 2], rpn_probs, rpn_bbox [b, anchors, 4]]."""
 
@@ -291,6 +343,42 @@ class RPN(nn.Module):
         probs = self.softmax(logits)
         bbox = both[:, ncls:].permute(0, 2, 3, 1).contiguous().view(x.size(0), -1, 4)
         return [logits, probs, bbox]
+
+    def forward_rows(self, maps, image, anchor, valid, grad_boxes=None):
+        """The RPN's outputs at SELECTED anchors only: (logits [R, 2], bbox [R, 4]) for rows (image[r], anchor[r]) of the
+        level-major anchor list (lib/layers.py:41-44), zeros where valid[r] is False.
+
+        The RPN losses read 256 sampled anchors per image out of ~262 000 (lib/layers.py:808-861), so the gradient of
+        the dense outputs is zero everywhere else and the dense backward of the shared 3x3 convolution -- the largest
+        convolution of the step next to the mask head's -- multiplies zeros (13 of 151 ms).  The dense forward still runs
+        (under no_grad: the proposal layer needs every anchor's score); for the losses the same two layers are evaluated
+        on the selected pixels' 3 x 3 patches as matrix products (conv.linear: [R, 9*256] . W_shared^T -> ReLU -> . W_heads^T),
+        whose backward IS the convolution's backward restricted to the rows that have a gradient; the patch gather's
+        backward scatters the input gradient into the level maps (_PatchRowsFn)."""
+        assert self.anchor_stride == 1, "row form: stride-1 RPN only"
+        per_loc = self.conv_class.weight.shape[0] // 2
+        sizes = [m.shape[2] * m.shape[3] * per_loc for m in maps]
+        starts = torch.tensor([sum(sizes[:i]) for i in range(len(maps))], device=anchor.device)
+        widths = torch.tensor([m.shape[3] for m in maps], device=anchor.device)
+        a = anchor.clamp(min=0)
+        lvl = (a.unsqueeze(1) >= starts.unsqueeze(0)).sum(1) - 1
+        local = a - starts[lvl]
+        k = local % per_loc
+        pix = local // per_loc
+        wl = widths[lvl]
+        h, w = pix // wl, pix % wl
+        patches = _PatchRowsFn.apply(image.clamp(min=0), lvl, h, w, valid, grad_boxes, *maps)
+        cs = self.conv_shared
+        ws = cs.weight.permute(0, 2, 3, 1).reshape(cs.weight.shape[0], -1)           # [512, 9*256]: a view of the
+        y = torch.relu(linear(patches, ws, cs.bias))                                  # channels-last parameter
+        heads = linear(y, torch.cat((self.conv_class.weight, self.conv_bbox.weight), 0).flatten(1),
+                       torch.cat((self.conv_class.bias, self.conv_bbox.bias), 0))     # [R, 2*per_loc + 4*per_loc]
+        ncls = 2 * per_loc
+        col = torch.arange(2, device=a.device).unsqueeze(0)
+        logits = torch.gather(heads, 1, 2 * k.unsqueeze(1) + col)
+        bbox = torch.gather(heads, 1, ncls + 4 * k.unsqueeze(1) + torch.arange(4, device=a.device).unsqueeze(0))
+        keep = valid.unsqueeze(1).float()
+        return logits * keep, bbox * keep
 
 
 class Dev(nn.Module):

@@ -549,8 +549,9 @@ def test_detector_gradients_agree_between_backward_forms(precision):
     BatchNorm scale in W^T, BatchNorm sums from the weight gradient, FPN-lateral / shortcut gradients handed through
     GradBoxes, stem pooling and top-down upsampling on own kernels -- against the round-2 form (one fused
     elementwise/reduction pass per layer, autograd accumulating every multi-reader gradient).  The forward passes are
-    the same kernels on the same inputs, so every mask is identical and the two gradients may differ only by summation
-    order and by where the BatchNorm scale is multiplied in: 2e-5 of each parameter's largest gradient element in fp32
+    the same kernels on the same inputs (the RPN's sampled anchors apart, see below), so every mask is identical and the
+    two gradients may differ only by summation order and by where the BatchNorm scale is multiplied in: 2e-5 of each
+    parameter's largest gradient element in fp32
     (the 16-bit kernels round the scale into different operands: the bar of test_gpu_conv_bf16's stage test)."""
     from feature_intertwiner_amd import conv as C
     from feature_intertwiner_amd.model import MaskRCNN
@@ -580,10 +581,9 @@ def test_detector_gradients_agree_between_backward_forms(precision):
         C._UNSCALED_BACKWARD = C.GATES = True
         C.set_conv_precision("fp32")
         C.invalidate_step_state()
-    if precision == "fp32":
-        assert losses["round3"] == losses["round2"]             # same forward, bit for bit
-    else:                                                       # the 16-bit head FCs reduce with fp32 atomics
-        assert abs(losses["round3"] - losses["round2"]) <= 1e-5 * abs(losses["round2"])
+    # the same forward kernels on the same inputs, except the RPN's outputs at the sampled anchors, which the round-3 form
+    # evaluates as matrix products on the anchors' 3 x 3 patches (RPN.forward_rows: another summation order)
+    assert abs(losses["round3"] - losses["round2"]) <= (1e-6 if precision == "fp32" else 1e-5) * abs(losses["round2"])
     assert grads["round3"].keys() == grads["round2"].keys()
     bar = 2e-5 if precision == "fp32" else 6e-2
     gmax = max(float(g.abs().max()) for g in grads["round2"].values())
