@@ -88,6 +88,8 @@ SIGNATURES = {
     "fi_conv2d_forward_gated": (c_int, [c_void_p] * 7 + [c_int] * 16 + [c_void_p]),
     "fi_class_row_conv1x1_workspace_bytes": (ctypes.c_size_t, [ctypes.c_long, c_int]),
     "fi_class_row_conv1x1_backward": (c_int, [c_void_p] * 7 + [ctypes.c_long, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "fi_pyramid_patch_rows_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, ctypes.c_long, c_int, c_void_p, c_void_p]),
+    "fi_pyramid_patch_rows_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, ctypes.c_long, c_int, c_void_p]),
     "fi_rows_gather": (c_int, [c_void_p, c_void_p, c_void_p, ctypes.c_long, ctypes.c_long, c_void_p]),
     "fi_rows_scatter_add": (c_int, [c_void_p, c_void_p, c_void_p, ctypes.c_long, ctypes.c_long, c_void_p]),
     "fi_maxpool3x3s2_forward": (c_int, [c_void_p, c_void_p, ctypes.c_long, c_int, c_int, c_void_p]),

@@ -375,6 +375,69 @@ __global__ __launch_bounds__(256) void class_row_reduce_kernel(const float *__re
             if (s_t[k] != 0.0f) atomicAdd(db + k, s_t[k]);
 }
 
+// ---- 3 x 3 patches of pyramid maps at selected anchors (the RPN's training path, sub_module.RPN.forward_rows) -------
+// Row r = (image[r], anchor[r]) of the level-major anchor list: level l holds H_l * W_l * per_loc anchors starting at
+// start[l]; anchor a of level l sits on pixel (a - start[l]) / per_loc.  out[r][tap][c] = map_l[image][c][h + dy][w + dx]
+// (zero outside the map and for rows with image[r] < 0); backward adds d[r][tap][c] into the level's gradient map.
+struct PatchLevels {
+    const float *map[8];
+    float *grad[8];
+    int H[8], W[8];
+    long start[8];
+    int levels, per_loc;
+};
+
+__device__ __forceinline__ bool patch_locate(const PatchLevels &lv, long img, long a, int &l, int &h, int &w)
+{
+    if (img < 0 || a < 0) return false;
+    l = 0;
+    while (l + 1 < lv.levels && a >= lv.start[l + 1]) ++l;
+    const long pix = (a - lv.start[l]) / lv.per_loc;
+    h = (int)(pix / lv.W[l]);
+    w = (int)(pix - (long)h * lv.W[l]);
+    return h < lv.H[l];
+}
+
+// one workgroup per (row, tap): lanes over channels (stride H*W in the NCHW map, contiguous in the output)
+__global__ __launch_bounds__(256) void patch_rows_fwd_kernel(PatchLevels lv, const long *__restrict__ image,
+                                                             const long *__restrict__ anchor, float *__restrict__ out, int C)
+{
+    const long r = blockIdx.x;
+    const int tap = blockIdx.y;
+    int l, h, w;
+    float *__restrict__ o = out + (r * 9 + tap) * (long)C;
+    bool ok = patch_locate(lv, image[r], anchor[r], l, h, w);
+    if (ok) {
+        h += tap / 3 - 1;
+        w += tap % 3 - 1;
+        ok = h >= 0 && h < lv.H[l] && w >= 0 && w < lv.W[l];
+    }
+    if (!ok) {
+        for (int c = threadIdx.x; c < C; c += 256) o[c] = 0.0f;
+        return;
+    }
+    const long HW = (long)lv.H[l] * lv.W[l];
+    const float *__restrict__ src = lv.map[l] + image[r] * C * HW + (long)h * lv.W[l] + w;
+    for (int c = threadIdx.x; c < C; c += 256) o[c] = src[c * HW];
+}
+
+__global__ __launch_bounds__(256) void patch_rows_bwd_kernel(PatchLevels lv, const long *__restrict__ image,
+                                                             const long *__restrict__ anchor, const float *__restrict__ d,
+                                                             int C)
+{
+    const long r = blockIdx.x;
+    const int tap = blockIdx.y;
+    int l, h, w;
+    if (!patch_locate(lv, image[r], anchor[r], l, h, w)) return;
+    h += tap / 3 - 1;
+    w += tap % 3 - 1;
+    if (h < 0 || h >= lv.H[l] || w < 0 || w >= lv.W[l]) return;
+    const long HW = (long)lv.H[l] * lv.W[l];
+    float *__restrict__ dst = lv.grad[l] + image[r] * C * HW + (long)h * lv.W[l] + w;
+    const float *__restrict__ src = d + (r * 9 + tap) * (long)C;
+    for (int c = threadIdx.x; c < C; c += 256) atomicAdd(dst + c * HW, src[c]);
+}
+
 __global__ __launch_bounds__(256) void relu_mask_kernel(const float *__restrict__ dy, const float *__restrict__ y,
                                                         float *__restrict__ out, long n4, long n)
 {
@@ -469,6 +532,58 @@ int fi_class_row_conv1x1_backward(const float *d, const float *x, const float *w
                            reinterpret_cast<const long *>(cls), dweight, dbias, N, C, num_classes);
         FI_HIP_CHECK(hipGetLastError());
     }
+    return FI_OK;
+}
+
+static int patch_levels(PatchLevels &lv, const void *const *maps, void *const *grads, const int *heights, const int *widths,
+                        int levels, int per_loc)
+{
+    FI_REQUIRE(levels >= 1 && levels <= 8 && per_loc >= 1, "1..8 pyramid levels");
+    long start = 0;
+    for (int l = 0; l < levels; ++l) {
+        FI_REQUIRE(heights[l] >= 1 && widths[l] >= 1, "bad map size");
+        lv.map[l] = maps ? static_cast<const float *>(maps[l]) : nullptr;
+        lv.grad[l] = grads ? static_cast<float *>(grads[l]) : nullptr;
+        FI_REQUIRE((maps && lv.map[l]) || (grads && lv.grad[l]), "null level map");
+        lv.H[l] = heights[l];
+        lv.W[l] = widths[l];
+        lv.start[l] = start;
+        start += (long)heights[l] * widths[l] * per_loc;
+    }
+    lv.levels = levels;
+    lv.per_loc = per_loc;
+    return FI_OK;
+}
+
+int fi_pyramid_patch_rows_forward(const void *const *maps, const int *heights, const int *widths, int levels,
+                                  int anchors_per_location, const int64_t *image, const int64_t *anchor, long rows,
+                                  int channels, float *out, fi_stream_t stream)
+{
+    FI_REQUIRE(rows >= 0 && channels >= 1, "bad sizes");
+    if (rows == 0) return FI_OK;
+    FI_REQUIRE(maps && heights && widths && image && anchor && out, "null pointer");
+    PatchLevels lv = {};
+    const int rc = patch_levels(lv, maps, nullptr, heights, widths, levels, anchors_per_location);
+    if (rc != FI_OK) return rc;
+    hipLaunchKernelGGL(patch_rows_fwd_kernel, dim3((unsigned)rows, 9), dim3(256), 0, (hipStream_t)stream, lv,
+                       reinterpret_cast<const long *>(image), reinterpret_cast<const long *>(anchor), out, channels);
+    FI_HIP_CHECK(hipGetLastError());
+    return FI_OK;
+}
+
+int fi_pyramid_patch_rows_backward(const float *d, void *const *grads, const int *heights, const int *widths, int levels,
+                                   int anchors_per_location, const int64_t *image, const int64_t *anchor, long rows,
+                                   int channels, fi_stream_t stream)
+{
+    FI_REQUIRE(rows >= 0 && channels >= 1, "bad sizes");
+    if (rows == 0) return FI_OK;
+    FI_REQUIRE(d && grads && heights && widths && image && anchor, "null pointer");
+    PatchLevels lv = {};
+    const int rc = patch_levels(lv, nullptr, grads, heights, widths, levels, anchors_per_location);
+    if (rc != FI_OK) return rc;
+    hipLaunchKernelGGL(patch_rows_bwd_kernel, dim3((unsigned)rows, 9), dim3(256), 0, (hipStream_t)stream, lv,
+                       reinterpret_cast<const long *>(image), reinterpret_cast<const long *>(anchor), d, channels);
+    FI_HIP_CHECK(hipGetLastError());
     return FI_OK;
 }
 

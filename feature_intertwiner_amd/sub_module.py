@@ -260,55 +260,63 @@ class FPN(nn.Module):
 
 
 class _PatchRowsFn(torch.autograd.Function):
-    """rows[r] = the 3 x 3 x C patch (tap-major: (dy, dx, c)) around pixel (h_r, w_r) of image n_r on pyramid level
-    lvl_r -- zeros outside the map and for invalid rows.  The training path of the RPN reads the pyramid ONLY here
-    (RPN.forward_rows): backward adds the patch gradients into the level maps' gradients (a few thousand atomics) instead
-    of running dense convolution gradients over maps whose output gradient is zero except at the sampled anchors.
-    boxes[l] (a conv.GradBox or None): another reader of level l (the Dev make-up layer) leaves ITS gradient for the
-    map there; this op is the taker and returns the sum to autograd."""
+    """rows[r] = the 3 x 3 x C patch (tap-major: (dy, dx, c)) around the pixel of anchor (image[r], anchor[r]) on its
+    pyramid level -- zeros outside the map and for padding rows (image[r] < 0): fi_pyramid_patch_rows_forward.  The
+    training path of the RPN reads the pyramid ONLY here (RPN.forward_rows): backward adds the patch gradients into the
+    level maps' gradients (a few thousand atomics per level) instead of running dense convolution gradients over maps
+    whose output gradient is zero except at the sampled anchors.
+    boxes[l] (a conv.GradBox or None): another reader of level l (the Dev make-up layer) leaves ITS gradient for the map
+    there; this op is the taker and returns the sum to autograd."""
 
     @staticmethod
-    def _index(n, h, w, use, H, W):
-        dy = torch.tensor([-1, -1, -1, 0, 0, 0, 1, 1, 1], device=n.device)
-        dx = torch.tensor([-1, 0, 1, -1, 0, 1, -1, 0, 1], device=n.device)
-        hh, ww = h.unsqueeze(1) + dy, w.unsqueeze(1) + dx                       # [R, 9]
-        inside = (hh >= 0) & (hh < H) & (ww >= 0) & (ww < W) & use.unsqueeze(1)
-        # taps that do not exist (outside the map, rows of another level, padding rows) read / add zeros SOMEWHERE: spread
-        # them over the map (slot id modulo the map) -- parked on one pixel their atomic adds would serialise
-        slot = torch.arange(n.numel() * 9, device=n.device).view(-1, 9)
-        hh = torch.where(inside, hh, (slot // W) % H)
-        ww = torch.where(inside, ww, slot % W)
-        return n.unsqueeze(1).expand(-1, 9), hh, ww, inside
+    def _levels(shapes):
+        import ctypes
+        n = len(shapes)
+        return (ctypes.c_int * n)(*[s[2] for s in shapes]), (ctypes.c_int * n)(*[s[3] for s in shapes])
 
     @staticmethod
-    def forward(ctx, n, lvl, h, w, valid, boxes, *maps):
-        R, C = n.numel(), maps[0].shape[1]
-        out = maps[0].new_zeros(R, 9, C)
-        for l, m in enumerate(maps):
-            nn_, hc, wc, inside = _PatchRowsFn._index(n, h, w, valid & (lvl == l), m.shape[2], m.shape[3])
-            out += m.permute(0, 2, 3, 1)[nn_, hc, wc] * inside.unsqueeze(2)
-        ctx.save_for_backward(n, lvl, h, w, valid)
-        ctx.shapes, ctx.boxes = [tuple(m.shape) for m in maps], boxes
-        return out.view(R, 9 * C)
+    def forward(ctx, image, anchor, per_loc, boxes, *maps):
+        import ctypes
+        _lib.require_cuda(image, anchor, *maps)
+        maps = [m.contiguous().float() for m in maps]
+        image, anchor = image.to(torch.int64).contiguous(), anchor.to(torch.int64).contiguous()
+        R, C = image.numel(), maps[0].shape[1]
+        out = torch.empty((R, 9 * C), device=image.device, dtype=torch.float32)
+        shapes = [tuple(m.shape) for m in maps]
+        hs, ws = _PatchRowsFn._levels(shapes)
+        ptrs = (ctypes.c_void_p * len(maps))(*[m.data_ptr() for m in maps])
+        with torch.cuda.device(image.device):
+            _lib.check(_lib.load().fi_pyramid_patch_rows_forward(ptrs, hs, ws, len(maps), int(per_loc), _lib.ptr(image),
+                                                                 _lib.ptr(anchor), R, C, _lib.ptr(out),
+                                                                 _lib.current_stream()), "fi_pyramid_patch_rows_forward")
+        ctx.save_for_backward(image, anchor)
+        ctx.shapes, ctx.boxes, ctx.per_loc = shapes, boxes, int(per_loc)
+        return out
 
     @staticmethod
     def backward(ctx, d):
-        n, lvl, h, w, valid = ctx.saved_tensors
-        R = n.numel()
-        d = d.reshape(R, 9, -1)
+        import ctypes
+        image, anchor = ctx.saved_tensors
+        d = d.contiguous().float()
         grads = []
         for l, shape in enumerate(ctx.shapes):
             base = None
             if ctx.boxes is not None and ctx.boxes[l] is not None:
                 base, ctx.boxes[l].value = ctx.boxes[l].value, None
-            if not (torch.is_tensor(base) and tuple(base.shape) == shape and base.is_contiguous()):
+            if not (torch.is_tensor(base) and tuple(base.shape) == shape and base.is_contiguous() and
+                    base.dtype == torch.float32):
                 extra, base = base, d.new_zeros(shape)
                 if torch.is_tensor(extra):
                     base += extra
-            nn_, hc, wc, inside = _PatchRowsFn._index(n, h, w, valid & (lvl == l), shape[2], shape[3])
-            base.permute(0, 2, 3, 1).index_put_((nn_, hc, wc), d * inside.unsqueeze(2), accumulate=True)
             grads.append(base)
-        return (None,) * 6 + tuple(grads)
+        hs, ws = _PatchRowsFn._levels(ctx.shapes)
+        ptrs = (ctypes.c_void_p * len(grads))(*[g.data_ptr() for g in grads])
+        with torch.cuda.device(d.device):
+            _lib.check(_lib.load().fi_pyramid_patch_rows_backward(_lib.ptr(d), ptrs, hs, ws, len(grads), ctx.per_loc,
+                                                                  _lib.ptr(image), _lib.ptr(anchor), image.numel(),
+                                                                  ctx.shapes[0][1], _lib.current_stream()),
+                       "fi_pyramid_patch_rows_backward")
+        return (None,) * 4 + tuple(grads)
 
 
 class RPN(nn.Module):
@@ -357,17 +365,10 @@ class RPN(nn.Module):
         backward scatters the input gradient into the level maps (_PatchRowsFn)."""
         assert self.anchor_stride == 1, "row form: stride-1 RPN only"
         per_loc = self.conv_class.weight.shape[0] // 2
-        sizes = [m.shape[2] * m.shape[3] * per_loc for m in maps]
-        starts = torch.tensor([sum(sizes[:i]) for i in range(len(maps))], device=anchor.device)
-        widths = torch.tensor([m.shape[3] for m in maps], device=anchor.device)
-        a = anchor.clamp(min=0)
-        lvl = (a.unsqueeze(1) >= starts.unsqueeze(0)).sum(1) - 1
-        local = a - starts[lvl]
-        k = local % per_loc
-        pix = local // per_loc
-        wl = widths[lvl]
-        h, w = pix // wl, pix % wl
-        patches = _PatchRowsFn.apply(image.clamp(min=0), lvl, h, w, valid, grad_boxes, *maps)
+        rows_image = torch.where(valid, image, torch.full_like(image, -1))
+        patches = _PatchRowsFn.apply(rows_image, anchor.clamp(min=0), per_loc, grad_boxes, *maps)
+        k = anchor.clamp(min=0) % per_loc          # every level's first anchor index is a multiple of per_loc
+        a = anchor
         cs = self.conv_shared
         ws = cs.weight.permute(0, 2, 3, 1).reshape(cs.weight.shape[0], -1)           # [512, 9*256]: a view of the
         y = torch.relu(linear(patches, ws, cs.bias))                                  # channels-last parameter

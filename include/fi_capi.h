@@ -290,6 +290,18 @@ size_t fi_class_row_conv1x1_workspace_bytes(long N, int C);
 int fi_class_row_conv1x1_backward(const float *d, const float *x, const float *weight, const int64_t *cls, float *dx,
                                   float *dweight, float *dbias, long N, int C, int HW, int num_classes, int gated,
                                   float *workspace, fi_stream_t stream);
+/* The RPN's training path on SELECTED anchors (lib/layers.py:808-861 reads RPN.TRAIN_ANCHORS_PER_IMAGE sampled anchors
+ * per image; lib/sub_module.py:256-280 is then two matrix products on those anchors' 3 x 3 patches).  Row r =
+ * (image[r], anchor[r]) of the level-major anchor list (level l: heights[l] * widths[l] * anchors_per_location anchors,
+ * anchor a on pixel a / anchors_per_location); image[r] < 0 marks a padding row.
+ *   forward:  out [rows][9][channels], out[r][tap][c] = maps[l][image][c][h + tap/3 - 1][w + tap%3 - 1] or 0 outside
+ *   backward: grads[l][image][c][h + ..][w + ..] += d[r][tap][c]   (fp32 atomics; the maps are [B][channels][H][W]) */
+int fi_pyramid_patch_rows_forward(const void *const *maps, const int *heights, const int *widths, int levels,
+                                  int anchors_per_location, const int64_t *image, const int64_t *anchor, long rows,
+                                  int channels, float *out, fi_stream_t stream);
+int fi_pyramid_patch_rows_backward(const float *d, void *const *grads, const int *heights, const int *widths, int levels,
+                                   int anchors_per_location, const int64_t *image, const int64_t *anchor, long rows,
+                                   int channels, fi_stream_t stream);
 /* dst[i][:] = src[index[i]][:] and dst[index[i]][:] += src[i][:] for [rows][row_len] fp32 tensors and an int64 index
  * vector with DISTINCT entries (the Dev stage hands the feature extractor the 14 x 14 crops of its "small" RoIs in
  * level-major order, lib/sub_module.py:583-598; the backward adds their gradients into the crops' gradient). */

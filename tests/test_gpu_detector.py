@@ -601,3 +601,59 @@ def test_detector_gradients_agree_between_backward_forms(precision):
         if err > bar:
             worst[n] = err
     assert not worst, sorted(worst.items(), key=lambda kv: -kv[1])[:8]
+
+
+def test_rpn_row_form_equals_the_dense_rpn_at_the_selected_anchors():
+    """RPN.forward_rows (3 x 3 patches of the selected anchors' pixels -> conv.linear x 2) against the dense RPN read at
+    the same anchors: outputs, and the gradients of every weight and of every pyramid level -- including a level whose
+    gradient box already holds another reader's gradient, anchors on map borders and padding rows."""
+    from feature_intertwiner_amd import conv as C
+    from feature_intertwiner_amd.sub_module import RPN
+    torch.manual_seed(11)
+    rpn = RPN(3, 1, 256).to(DEV)
+    shapes = [(2, 256, 16, 16), (2, 256, 8, 8), (2, 256, 4, 4)]
+    maps = [torch.randn(s, device=DEV) for s in shapes]
+    A = sum(s[2] * s[3] * 3 for s in shapes)
+    R = 96
+    g = torch.Generator(device="cpu").manual_seed(3)
+    image = torch.randint(0, 2, (R,), generator=g).to(DEV)
+    anchor = torch.randint(0, A, (R,), generator=g).to(DEV)
+    anchor[:6] = torch.tensor([0, 2, 16 * 16 * 3 - 1, 16 * 16 * 3, A - 1, 15 * 3], device=DEV)      # corners / level starts
+    valid = torch.ones(R, dtype=torch.bool, device=DEV)
+    valid[-7:] = False
+    image_p, anchor_p = image.clone(), anchor.clone()
+    image_p[-7:] = -1
+    anchor_p[-7:] = -1
+    w_l, w_b = torch.randn(R, 2, device=DEV), torch.randn(R, 4, device=DEV)
+    extra = torch.randn(shapes[1], device=DEV)                      # what another reader left for level 1
+
+    def run(row_form):
+        for p in rpn.parameters():
+            p.grad = None
+        ms = [m.clone().requires_grad_(True) for m in maps]
+        if row_form:
+            boxes = [None, C.GradBox(), None]
+            boxes[1].taker = True
+            boxes[1].value = extra.clone()
+            logits, bbox = rpn.forward_rows(ms, image_p, anchor_p, valid, grad_boxes=boxes)
+        else:
+            outs = [rpn(m) for m in ms]
+            lg = torch.cat([o[0] for o in outs], 1)
+            bb = torch.cat([o[2] for o in outs], 1)
+            logits = lg[image, anchor] * valid.unsqueeze(1)
+            bbox = bb[image, anchor] * valid.unsqueeze(1)
+        ((logits * w_l).sum() + (bbox * w_b).sum()).backward()
+        gm = [m.grad.clone() for m in ms]
+        if not row_form:
+            gm[1] = gm[1] + extra
+        return logits.detach(), bbox.detach(), gm, {n: p.grad.clone() for n, p in rpn.named_parameters()}
+
+    dl, db, dgm, dgp = run(False)
+    rl, rb, rgm, rgp = run(True)
+    close = lambda a, b: float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 1e-7
+    assert close(rl, dl) and close(rb, db)
+    assert torch.equal(rl[-7:], torch.zeros_like(rl[-7:]))
+    for a, b in zip(rgm, dgm):
+        assert close(a, b)
+    for n in dgp:
+        assert close(rgp[n], dgp[n]), n
