@@ -114,7 +114,12 @@ class MaskRCNN(nn.Module):
         to_rpn = [_conv.GradBox() if chain else None for _ in mrcnn_maps]
         to_make_up = [_conv.GradBox() if chain else None for _ in mrcnn_maps]
         # (the 14 x 14 crops likewise: mask head -> the row gather in front of the Dev stage's feature extractor)
-        mask_box = _conv.GradBox() if (chain and not cfg.MRCNN.MASK_HEAD_ON_POSITIVE_SLOTS) else None
+        # Only the positive RoIs' masks enter the mask loss, and prepare_det_target puts an image's positives in its first
+        # int(R * ROI_POSITIVE_RATIO) slots: with conv.GATES the mask head runs as two batches -- those slots WITH a graph,
+        # the other slots without one (their outputs are computed, as the reference does, and their gradient is zero)
+        split_mask = images.is_cuda and torch.is_grad_enabled() and _conv.GATES and \
+            not cfg.MRCNN.MASK_HEAD_ON_POSITIVE_SLOTS
+        mask_box = None if (split_mask or cfg.MRCNN.MASK_HEAD_ON_POSITIVE_SLOTS or not chain) else _conv.GradBox()
         # The RPN losses read RPN.TRAIN_ANCHORS_PER_IMAGE sampled anchors per image: with conv.GATES the dense RPN runs
         # without a graph (the proposal layer needs every anchor) and the losses' graph is RPN.forward_rows on those rows
         rows = images.is_cuda and torch.is_grad_enabled() and _conv.GATES and self.rpn.anchor_stride == 1
@@ -175,14 +180,22 @@ class MaskRCNN(nn.Module):
 
         mrcnn_class_logits, _, mrcnn_bbox = self.classifier(pooled_cls, small_output_all, small_gt_all)
         mask_ids, mask_tgt = target_class_ids, target_mask
-        if cfg.MRCNN.MASK_HEAD_ON_POSITIVE_SLOTS:
+        if cfg.MRCNN.MASK_HEAD_ON_POSITIVE_SLOTS or split_mask:
             # The reference runs the mask head on every RoI (lib/model.py:442) although only positive
             # RoIs enter the mask loss (lib/layers.py:905-934).  prepare_det_target puts the positives
             # of an image in its first slots, at most ROI_POSITIVE_RATIO * R of them, so the head's
-            # output on the other slots is never read: same loss, same gradients, 1/3 of the work.
+            # output on the other slots is never read.  MASK_HEAD_ON_POSITIVE_SLOTS (not the reference's schedule) drops
+            # them: same loss, same gradients, 1/3 of the work.  The default evaluates them too, in a second batch that
+            # builds no graph: every RoI's masks are computed exactly as before (the layers act per RoI), and the
+            # backward pass of the head -- the largest convolutions of the step -- covers the third of the RoIs whose
+            # gradient is not identically zero.
             P = int(cfg.ROIS.TRAIN_ROIS_PER_IMAGE * cfg.ROIS.ROI_POSITIVE_RATIO)
             R = rois.size(1)
-            pooled_mask = pooled_mask.view(bs, R, *pooled_mask.shape[1:])[:, :P].reshape(bs * P, *pooled_mask.shape[1:])
+            per_image = pooled_mask.view(bs, R, *pooled_mask.shape[1:])
+            if split_mask and P < R:
+                with torch.no_grad():
+                    self.mask(per_image[:, P:].reshape(bs * (R - P), *pooled_mask.shape[1:]), shuffled=False, activate=False)
+            pooled_mask = per_image[:, :P].reshape(bs * P, *pooled_mask.shape[1:])
             mask_ids, mask_tgt = target_class_ids[:, :P], target_mask[:, :P]
         # logits of every RoI's TARGET class [bs*R', 2, 2, 14, 14] (all K classes are evaluated; see Mask.forward), or of
         # all classes [bs*R', 2, 2, K, 14, 14] on a CPU tensor / with conv.GATES off
