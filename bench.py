@@ -376,6 +376,10 @@ def _main():
                          "configs[4]: 1333x800 padded to 1344^2, 2 images/GPU, 1000 RoIs/image + mask head, bf16 MFMA convs")
     ap.add_argument("--conv-precision", default=None, choices=["fp32", "bf16", "fp16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dense-backward", action="store_true",
+                    help="the backward pass in its dense (round-2) form: dense RPN and mask-head gradients over the "
+                         "anchors / RoIs whose gradient is identically zero, one elementwise pass per BatchNorm layer, "
+                         "autograd accumulating every multi-reader gradient (conv.GATES = conv._UNSCALED_BACKWARD = False)")
     ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 --pmc passes that fill roofline.traffic")
     ap.add_argument("--profile-steps", type=int, default=4,
                     help="extra steps AFTER the timed region, run with in-library HIP-event timing for the roofline objects")
@@ -431,6 +435,8 @@ def _main():
     cfg = make_config(args.backbone, args.image_size, args.batch_per_gpu, args.rois, dev_switch=True,
                       loss_choice="ot", ot_L=args.ot_L, gpu_count=world, conv_precision=args.conv_precision)
     cfg.MRCNN.MASK_HEAD_ON_POSITIVE_SLOTS = bool(args.mask_head_on_positive_slots)
+    if args.dense_backward:
+        ficonv.GATES = ficonv._UNSCALED_BACKWARD = False
     model = MaskRCNN(cfg).to(dev)
     broadcast_parameters(model)
     opt = set_optimizer(model, cfg.TRAIN)
@@ -637,6 +643,8 @@ def _main():
                      args.conv_precision]
             if args.mask_head_on_positive_slots:
                 child.append("--mask-head-on-positive-slots")
+            if args.dense_backward:
+                child.append("--dense-backward")
             subs = [roof["kernel"].split("<")[0] + "<" + roof["kernel"].split("<")[1].rstrip(">")]
             if roof_roi is not None:
                 subs.append(roof_roi["kernel"].rstrip(">"))
@@ -674,7 +682,13 @@ def _main():
                                       args.ot_L),
                        "global_batch": global_batch, "parallelism": "dp%d" % world,
                        "variant": ("mask head on positive slots only (dead-work elimination, not the reference's "
-                                   "schedule)" if args.mask_head_on_positive_slots else "reference schedule"),
+                                   "schedule)" if args.mask_head_on_positive_slots else
+                                   ("reference schedule, dense backward (round-2 form)" if args.dense_backward else
+                                    "reference schedule: every forward result of the reference is computed (all anchors' RPN "
+                                    "outputs, every RoI's masks of every class); the backward pass computes the same "
+                                    "gradients and skips the parts that are identically zero -- the RPN losses read 256 "
+                                    "sampled anchors per image, the mask loss the positive RoIs' target-class masks "
+                                    "(DESIGN.md section 3; --dense-backward runs the dense form)")),
                        "conv_stack": ("hand-written fp32 MFMA implicit-GEMM kernels (csrc/conv_igemm.hip)" if
                                       args.conv_precision == "fp32" else "hand-written 16-bit-operand (" + args.conv_precision + ") / fp32-accumulate MFMA "
                                       "kernels (csrc/conv_bf16.hip; layers with Cin % 32 != 0 on the fp32 kernels)") +

@@ -42,6 +42,6 @@ timeout 200 scripts/micro/bin/crop_var > $O/${R}_crop_nchw_variants.txt 2>&1
 bash scripts/micro/crop_pmc.sh library > /dev/null 2>&1; cp $O/crop_pmc/summary.txt $O/${R}_crop_nchw_pmc.txt
 ls -la $O | tail -30
 # conv + eval-BN backward: the older form (fi_bn_act_backward passes) against the unscaled-gradient form, same box, interleaved
-( cd $GRAFT_REPO_ROOT && bash scripts/ab_env.sh "FI_BN_BWD_OLD=1" "FI_BN_BWD_NEW=1" 2>&1 | grep -v amdgpu > $O/${R}_ab_bn_backward.txt; bash scripts/ab_env.sh "FI_BN_BWD_OLD=1" "FI_BN_BWD_NEW=1" --config cfg5 2>&1 | grep -v amdgpu >> $O/${R}_ab_bn_backward.txt )
+( cd $GRAFT_REPO_ROOT && bash scripts/ab_env.sh "FI_BN_BWD_OLD=1" "FI_BN_BWD_NEW=1" 2>&1 | grep -v amdgpu > $O/${R}_ab_bn_backward.txt; bash scripts/ab_env.sh "FI_BN_BWD_OLD=1" "FI_BN_BWD_NEW=1" --config cfg5 2>&1 | grep -v amdgpu >> $O/${R}_ab_bn_backward.txt; bash scripts/ab_dense.sh > $O/${R}_ab_dense_backward.txt 2>&1 )
 timeout 200 python scripts/host_time.py 2>&1 | grep -v amdgpu | tail -8 > $O/${R}_host_time.txt
 ls -la $O | tail -40
