@@ -279,6 +279,15 @@ def async_host_read(t):
 _SIDE = {}
 _SIDE2 = {}
 
+def side_stream(device=None):
+    """The second stream of run_on_side_stream (created on first use)."""
+    dev = torch.cuda.current_device() if device is None else torch.device(device).index
+    side = _SIDE2.get(dev)
+    if side is None:
+        side = _SIDE2[dev] = torch.cuda.Stream(device=dev)
+    return side
+
+
 def run_on_side_stream(fn, *args):
     """Run fn(*args) (network-independent small kernels, e.g. RPN target generation) on a second stream so that
     its launch-latency-bound kernels interleave with the convolutions of the current stream.  Returns a

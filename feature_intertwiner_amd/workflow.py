@@ -63,6 +63,10 @@ def train_step(model, optimizer, inputs, do_meta=True, grad_sync=None, world_siz
     if grad_sync is not None and hasattr(grad_sync, "begin"):
         grad_sync.begin(("do_meta", bool(do_meta)))     # the graph variant decides which parameters get gradients
     loss.backward()
+    join = getattr(model, "_side_join", None)
+    if join is not None:          # work of the forward pass that nothing reads (MaskRCNN.forward) ends before the weights move
+        model._side_join = None
+        join()
     if grad_sync is not None:
         grad_sync()
     if optim.supported(optimizer):
