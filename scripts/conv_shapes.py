@@ -11,6 +11,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("FI_DEAD_SIDE", "0")
 os.environ.setdefault("FI_WGRAD_SIDE_PIXELS", "0")      # weight gradients on the main stream: the events bracket the kernel
 from feature_intertwiner_amd import _lib  # noqa: E402
 from feature_intertwiner_amd.config import make_config  # noqa: E402

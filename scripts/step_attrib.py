@@ -12,6 +12,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("FI_DEAD_SIDE", "0")
 os.environ.setdefault("FI_WGRAD_SIDE_PIXELS", "0")      # one stream: kernel durations are exclusive and add up to the step
 from torch.profiler import ProfilerActivity, profile, record_function  # noqa: E402
 
