@@ -376,6 +376,8 @@ def _main():
                          "configs[4]: 1333x800 padded to 1344^2, 2 images/GPU, 1000 RoIs/image + mask head, bf16 MFMA convs")
     ap.add_argument("--conv-precision", default=None, choices=["fp32", "bf16", "fp16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-dense-reference", action="store_true",
+                    help="skip the 8 extra steps (after the timed region) that time the dense form of the backward pass")
     ap.add_argument("--dense-backward", action="store_true",
                     help="the backward pass in its dense (round-2) form: dense RPN and mask-head gradients over the "
                          "anchors / RoIs whose gradient is identically zero, one elementwise pass per BatchNorm layer, "
@@ -517,6 +519,26 @@ def _main():
     shape_log = ficonv.SHAPE_LOG
     ficonv.SHAPE_LOG = None
     shape_log = shape_log[:len(shape_log) // prof_steps]       # the convolutions of ONE step
+    # ---- the same step with the backward pass in its dense form, for reference (outside the timed region) ----------
+    dense_ref = None
+    if world == 1 and not args.dense_backward and not args.no_dense_reference:
+        keep = (ficonv.GATES, ficonv._UNSCALED_BACKWARD)
+        ficonv.GATES = ficonv._UNSCALED_BACKWARD = False
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        for _ in range(6):
+            step()
+        torch.cuda.synchronize()
+        dense_ms = (time.perf_counter() - t2) / 6 * 1e3
+        ficonv.GATES, ficonv._UNSCALED_BACKWARD = keep
+        step()                                  # back to the default form (plans, W^T tables)
+        torch.cuda.synchronize()
+        dense_ref = {"ms_per_step": round(dense_ms, 3), "value": round(args.batch_per_gpu * 1e3 / dense_ms, 4), "steps": 6,
+                     "what": "python bench.py --dense-backward: dense RPN / mask-head gradients over anchors and RoIs whose "
+                             "gradient is identically zero, one elementwise pass per BatchNorm layer, autograd accumulating "
+                             "multi-reader gradients -- the same forward results and the same gradients as the default"}
     per_rank_ms, rccl_ranks, overlap = None, None, None
     if sync is not None and not share:
         # a further pass with HIP events around every bucket's collective: how much of the exchange hides in backward
@@ -698,6 +720,7 @@ def _main():
                                       "kernels (csrc/conv_bf16.hip; layers with Cin % 32 != 0 on the fp32 kernels)") +
                                      "; full-window convs and nn.Linear on the library GEMM"},
             "losses": {k: round(float(v), 5) for k, v in terms.items()},
+            "dense_backward_reference": dense_ref,
             "roofline": roof, "roofline_roialign": roof_roi, "conv_stack": conv_stack, "nms": nms_obj, "sinkhorn": sk_obj,
             "timing": {"timed_region": "%d steps, no event recording / logging" % args.steps,
                        "profiled_pass": "%d further steps with HIP-event timing of every library kernel, weight gradients "

@@ -8,7 +8,7 @@ O=$GRAFT_REPO_ROOT/gpurun_out
 # rocprofv3 per-kernel summary of the same command (headline flags, fewer steps; no nested PMC passes)
 # (FI_WGRAD_SIDE_PIXELS=0: weight gradients on the main stream, as in bench.py's profiled pass -- kernel durations are
 # exclusive; with the second stream two kernels share the chip and each row's average is longer than the kernel alone)
-rm -rf /tmp/prof7; ( cd /tmp && FI_WGRAD_SIDE_PIXELS=0 FI_DEAD_SIDE=0 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof7 -o b -- python $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 2 --profile-steps 1 --no-cpu-baseline --no-pmc > $O/${R}_bench_n1_under_rocprof.json 2>/dev/null )
+rm -rf /tmp/prof7; ( cd /tmp && FI_WGRAD_SIDE_PIXELS=0 FI_DEAD_SIDE=0 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof7 -o b -- python $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 2 --profile-steps 1 --no-cpu-baseline --no-pmc --no-dense-reference > $O/${R}_bench_n1_under_rocprof.json 2>/dev/null )
 f=$(find /tmp/prof7 -name 'b_kernel_stats.csv' | head -1)
 ( head -81 $f; grep -E "crop_|nms_|sinkhorn|roi_pool|class_mean|weight_transpose" $f ) | awk '!seen[$0]++' > $O/${R}_bench_n1_kernel_stats.csv
 # operator micro-benchmarks, and the rocprofv3 summary of the RoI operators in that run
@@ -22,7 +22,7 @@ timeout 200 python scripts/roipool_probe.py > $O/${R}_roipool_probe.txt 2>&1
 ( cd /tmp && timeout 400 python $GRAFT_REPO_ROOT/bench.py --config cfg5 --no-cpu-baseline --no-pmc > $O/${R}_bench_cfg5_bf16.json 2>/dev/null )
 ( cd /tmp && timeout 400 python $GRAFT_REPO_ROOT/bench.py --conv-precision bf16 --no-cpu-baseline --no-pmc > $O/${R}_bench_cfg3_bf16.json 2>/dev/null )
 # per-layer view of the step's kernels (grid size = layer shape) from a kernel trace of the headline command
-rm -rf /tmp/prof9; ( cd /tmp && FI_WGRAD_SIDE_PIXELS=0 FI_DEAD_SIDE=0 timeout 400 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof9 -o kt -- python $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 2 --profile-steps 0 --no-cpu-baseline --no-pmc > /dev/null 2>&1 )
+rm -rf /tmp/prof9; ( cd /tmp && FI_WGRAD_SIDE_PIXELS=0 FI_DEAD_SIDE=0 timeout 400 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof9 -o kt -- python $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 2 --profile-steps 0 --no-cpu-baseline --no-pmc --no-dense-reference > /dev/null 2>&1 )
 f=$(find /tmp/prof9 -name 'kt_kernel_trace.csv' | head -1)
 python scripts/trace_groups.py $f conv 7 | head -70 > $O/${R}_conv_layers.txt
 python scripts/trace_groups.py $f bn_act 7 > $O/${R}_bn_bwd_layers.txt
