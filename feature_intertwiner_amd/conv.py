@@ -738,7 +738,7 @@ def _prepare_step(model, grad_on):
         _WB.clear()
     plan = _PLAN.get(model)
     ptrs = tuple(p.data_ptr() for p in model.parameters())
-    if plan is None or plan["ptrs"] != ptrs:
+    if plan is None or plan["ptrs"] != ptrs or plan["layout"].superseded:
         convs = [m for m in model.modules() if isinstance(m, Conv2d) and not m.full_window]
         for m in convs:
             w = m.weight

@@ -146,8 +146,18 @@ class GradientBuckets(object):
         forward pass of a GPU model; models without that step -- the CPU tests -- are cleared here)."""
         if self.active and not self._started:
             self._started = True
+            if self.layout.superseded:
+                # grad_arena.get_layout() replaced the layout (another bucket size, a changed trainable set): the
+                # kernels and the optimiser follow the new one, so must the buckets
+                raise RuntimeError("GradientBuckets: the model's gradient layout was rebuilt after this object was "
+                                   "created; construct a new GradientBuckets")
             self.arena = self.layout.buffer(self.device)
-            if not self.layout.fresh:
+            # Gradients of an earlier backward pass that are still attached LIVE in the arena (accumulation over
+            # micro-batches without zero_grad; zero_grad(set_to_none=False) with no begin(), where AccumulateGrad
+            # has already added into the slot when the first hook runs): clearing would discard them.  The reduced
+            # means of the earlier passes are identical on every rank, so summing them again over the ranks and
+            # dividing by the world size in __call__ leaves them unchanged.
+            if not self.layout.fresh and not self.layout.live_gradients(self.arena):
                 self.layout.zero(self.device)
             if self.profile is not None and self.use_stream:
                 e = torch.cuda.Event(enable_timing=True)

@@ -97,6 +97,7 @@ class ArenaLayout(object):
         self.params = [p for b in self.buckets for p in b.params]
         self._buf = {}              # device -> tensor
         self.fresh = False          # zeroed and not yet consumed by a gradient exchange
+        self.superseded = False     # get_layout() built a newer layout for the same module: holders must re-fetch
 
     def buffer(self, device):
         device = torch.device(device)
@@ -154,6 +155,8 @@ def get_layout(module, bucket_bytes=None):
             all(p in lay.slot for p in module.parameters() if p.requires_grad)
         if same_params and (bucket_bytes is None or int(bucket_bytes) == lay.bucket_bytes):
             return lay
+    if lay is not None:
+        lay.superseded = True       # conv._prepare_step / GradientBuckets compare and rebuild (or refuse)
     lay = ArenaLayout(module, DEFAULT_BUCKET_BYTES if bucket_bytes is None else bucket_bytes)
     _LAYOUTS[module] = lay
     return lay
