@@ -539,6 +539,20 @@ def _main():
                      "what": "python bench.py --dense-backward: dense RPN / mask-head gradients over anchors and RoIs whose "
                              "gradient is identically zero, one elementwise pass per BatchNorm layer, autograd accumulating "
                              "multi-reader gradients -- the same forward results and the same gradients as the default"}
+    # ---- the default backward pass against its dense form on the SAME weights / inputs / draws (outside the timed region)
+    backward_check = None
+    if world == 1 and not args.dense_backward and not args.no_dense_reference:
+        from feature_intertwiner_amd.workflow import compare_backward_forms
+        lowp = args.conv_precision != "fp32"
+        r = compare_backward_forms(model, batch, skip=(lambda n: n.startswith("ot_loss") or
+                                                       n.startswith("dev_roi.feat_extract")) if lowp else None)
+        backward_check = {"max_rel_dev": float("%.3g" % r["max_rel_dev"]), "worst": r["worst"], "params": r["params"],
+                          "loss_rel": float("%.3g" % r["loss_rel"]), "none_sets_equal": r["none_sets_equal"],
+                          "what": "one backward pass in the default form and one in the dense form "
+                                  "(workflow.compare_backward_forms) after the timed steps: max over parameters of "
+                                  "max|g - g_dense| / max|g_dense|"}
+        step()                                  # plans / W^T tables back in the default form
+        torch.cuda.synchronize()
     per_rank_ms, rccl_ranks, overlap = None, None, None
     if sync is not None and not share:
         # a further pass with HIP events around every bucket's collective: how much of the exchange hides in backward
@@ -721,6 +735,7 @@ def _main():
                                      "; full-window convs and nn.Linear on the library GEMM"},
             "losses": {k: round(float(v), 5) for k, v in terms.items()},
             "dense_backward_reference": dense_ref,
+            "backward_check": backward_check,
             "roofline": roof, "roofline_roialign": roof_roi, "conv_stack": conv_stack, "nms": nms_obj, "sinkhorn": sk_obj,
             "timing": {"timed_region": "%d steps, no event recording / logging" % args.steps,
                        "profiled_pass": "%d further steps with HIP-event timing of every library kernel, weight gradients "

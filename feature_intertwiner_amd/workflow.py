@@ -78,3 +78,72 @@ def train_step(model, optimizer, inputs, do_meta=True, grad_sync=None, world_siz
                                        cfg.TRAIN.MAX_GRAD_NORM)
     optimizer.step()
     return terms
+
+
+def compare_backward_forms(model, inputs, do_meta=True, generator_seed=3, skip=None):
+    """Differential check of the default backward pass against its DENSE form on the same weights, the same inputs and
+    the same random draws (no optimiser step; the intertwiner history buffer is restored between the two passes).
+
+    Default form: ReLU masks in the readers' data-gradient epilogues, BatchNorm scale in W^T,
+    gradients that are identically zero not computed (the RPN's graph on the sampled anchors, the mask head's on the
+    slots that can hold positives -- lib/layers.py:808-934, lib/model.py:442).  Dense form (`conv.GATES =
+    conv._UNSCALED_BACKWARD = False`): what the reference's autograd does -- dense RPN / mask-head gradients, one
+    elementwise pass per BatchNorm layer, autograd accumulating every multi-reader gradient.
+
+    Returns {"loss": (default, dense), "loss_rel": |difference| / |dense|, "max_rel_dev": the largest, over parameters,
+    of max|g_default - g_dense| / max|g_dense|, "worst": its parameter, "params": parameters compared,
+    "none_sets_equal": the same parameters have no gradient in both forms}.  skip(name) -> True leaves a parameter out
+    of max_rel_dev."""
+    from . import conv as C
+    keep = (C.GATES, C._UNSCALED_BACKWARD)
+    fb = model.feature_buffer
+    saved_fb = None if fb is None else (fb.buffer.clone(), fb.buffer_cnt.clone())
+    saved_gen = model.generator
+    # a stateful external proposal source (synthetic.SyntheticProposals draws new jitter at every call) must hand both
+    # passes the same rows
+    ext_gen = getattr(getattr(model, "external_proposals", None), "gen", None)
+    ext_state = ext_gen.get_state() if ext_gen is not None else None
+    dev = next(model.parameters()).device
+    out = {}
+    try:
+        for form in ("default", "dense"):
+            C.GATES = C._UNSCALED_BACKWARD = (form == "default")
+            if model.feature_buffer is not None and saved_fb is not None:
+                model.feature_buffer.buffer, model.feature_buffer.buffer_cnt = saved_fb[0].clone(), saved_fb[1].clone()
+            elif saved_fb is None:
+                model.feature_buffer = None
+            model.generator = torch.Generator(device=dev).manual_seed(generator_seed)
+            if ext_state is not None:
+                ext_gen.set_state(ext_state)
+            for p in model.parameters():
+                p.grad = None
+            loss, _ = compute_loss(model, list(inputs), do_meta, 1, None)
+            loss.backward()
+            join = getattr(model, "_side_join", None)
+            if join is not None:
+                model._side_join = None
+                join()
+            if dev.type == "cuda":
+                torch.cuda.synchronize(dev)
+            out[form] = (float(loss.detach()),
+                         {n: (None if p.grad is None else p.grad.detach().clone()) for n, p in model.named_parameters()})
+    finally:
+        C.GATES, C._UNSCALED_BACKWARD = keep
+        model.generator = saved_gen
+        if saved_fb is not None and model.feature_buffer is not None:
+            model.feature_buffer.buffer, model.feature_buffer.buffer_cnt = saved_fb
+        for p in model.parameters():
+            p.grad = None
+    (l_a, g_a), (l_b, g_b) = out["default"], out["dense"]
+    worst, worst_name, n = 0.0, None, 0
+    for name, ref in g_b.items():
+        got = g_a[name]
+        if ref is None or got is None or (skip is not None and skip(name)):
+            continue
+        n += 1
+        dev_rel = float((got - ref).abs().max()) / (float(ref.abs().max()) + 1e-30)
+        if dev_rel > worst:
+            worst, worst_name = dev_rel, name
+    none_equal = {k for k, v in g_a.items() if v is None} == {k for k, v in g_b.items() if v is None}
+    return {"loss": (l_a, l_b), "loss_rel": abs(l_a - l_b) / (abs(l_b) + 1e-30), "max_rel_dev": worst,
+            "worst": worst_name, "params": n, "none_sets_equal": none_equal}

@@ -108,6 +108,60 @@ def test_configs2_full_size_two_steps_operators_vs_oracle(oracle):
     torch.cuda.empty_cache()
 
 
+def test_configs2_backward_forms_agree_at_full_size():
+    """The headline rests on the backward pass that skips structural zeros: at BASELINE configs[2]
+    itself -- R101, 23 C4 blocks, 4 x 1024^2, 512 RoIs per image (170 positive slots), L = 50, 261 888 anchors with the
+    border / level-start anchors at real scale -- one backward pass in the default form and one in the dense form
+    (conv.GATES = conv._UNSCALED_BACKWARD = False) from identical weights, inputs and random draws: losses equal to
+    1e-6, every parameter's gradient within 2e-5 of its largest element, the same parameters without a gradient.
+    lib/layers.py:808-934 (which rows the losses read), lib/model.py:442 (the mask head on all RoIs)."""
+    from feature_intertwiner_amd.config import make_config
+    from feature_intertwiner_amd.model import MaskRCNN
+    from feature_intertwiner_amd.synthetic import SyntheticProposals, synthetic_batch
+    from feature_intertwiner_amd.workflow import compare_backward_forms, set_optimizer, train_step
+    torch.manual_seed(2000)
+    cfg = make_config("resnet101", 1024, 4, 512, dev_switch=True, loss_choice="ot", ot_L=50)
+    model = MaskRCNN(cfg).to(DEV)
+    opt = set_optimizer(model, cfg.TRAIN)
+    batch = synthetic_batch(4, 1024, device=DEV, seed=2000)
+    model.external_proposals = SyntheticProposals(batch[2], 1024, seed=7)
+    model.generator = torch.Generator(device=DEV).manual_seed(11)
+    for _ in range(2):                       # two real steps first: history buffer filled, weights off their initial values
+        train_step(model, opt, list(batch))
+    r = compare_backward_forms(model, batch)
+    assert r["none_sets_equal"], r
+    assert r["params"] > 400, r
+    assert r["loss_rel"] <= 1e-6, r
+    assert r["max_rel_dev"] <= 2e-5, r
+    del model, opt
+    torch.cuda.empty_cache()
+
+
+def test_configs4_slice_backward_forms_agree_bf16():
+    """The same differential check on the configs[4] slice (R101, 2 x 1344^2, 1000 RoIs, bf16 MFMA convolutions) at the
+    16-bit bar of tests/test_gpu_detector.py::test_detector_gradients_agree_between_backward_forms: the two forms round
+    the BatchNorm scale into different operands, and the 1-D cosine OT gradient is numerically degenerate,
+    so parameters reached only through it are compared against the largest detector gradient."""
+    from feature_intertwiner_amd.config import make_config
+    from feature_intertwiner_amd.model import MaskRCNN
+    from feature_intertwiner_amd.synthetic import SyntheticProposals, synthetic_batch
+    from feature_intertwiner_amd.workflow import compare_backward_forms, set_optimizer, train_step
+    torch.manual_seed(2000)
+    cfg = make_config("resnet101", 1344, 2, 1000, dev_switch=True, loss_choice="ot", ot_L=50, conv_precision="bf16")
+    model = MaskRCNN(cfg).to(DEV)
+    opt = set_optimizer(model, cfg.TRAIN)
+    batch = synthetic_batch(2, 1344, device=DEV, seed=2000)
+    model.external_proposals = SyntheticProposals(batch[2], 1344, seed=7)
+    model.generator = torch.Generator(device=DEV).manual_seed(11)
+    train_step(model, opt, list(batch))
+    r = compare_backward_forms(model, batch, skip=lambda n: n.startswith("ot_loss") or n.startswith("dev_roi.feat_extract"))
+    assert r["none_sets_equal"], r
+    assert r["loss_rel"] <= 1e-5, r
+    assert r["max_rel_dev"] <= 6e-2, r
+    del model, opt
+    torch.cuda.empty_cache()
+
+
 def test_configs4_slice_full_size_bf16(oracle):
     """The single-GPU slice of BASELINE configs[4]: ResNet-101-FPN, 1333x800 padded to 1344^2,
     2 images per GPU, 1000 RoIs per image with the mask head, bf16-input MFMA convolutions.  Two full train
