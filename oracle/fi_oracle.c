@@ -21,9 +21,10 @@
  *     execution.  The reference C sources need <TH/TH.h> (PyTorch 0.3 headers,
  *     absent from this image) and its .cu files need CUDA, so no reference build
  *     exists here; the reference ships no tests or golden vectors.  These
- *     restatements are pinned only by hand-derived known-answer vectors
- *     (tests/golden/kat_*.json) and cross-checks against independent formulations
- *     (torch grid_sample, brute-force NMS), which the tests state explicitly.
+ *     restatements are pinned only by hand-derived known-answer cases (written
+ *     inline in tests/test_oracle_kat.py) and cross-checks against independent
+ *     formulations (torch grid_sample, float64 brute-force NMS, max_pool2d for
+ *     aligned RoIPool windows), which the tests state explicitly.
  */
 #include <math.h>
 #include <float.h>
