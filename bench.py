@@ -343,6 +343,32 @@ def _self_launch(n):
     return lines[-1]
 
 
+def _preflight(rank, world, dev, share):
+    """Fail with a readable message BEFORE the model is built if the job cannot be what the JSON line will claim: every
+    rank on its own physical GPU (an all-gather of device UUIDs over the store, no GPU traffic) and a 1-element
+    all-reduce through the backend that will carry the gradients (RCCL communicator set-up, xGMI / dmabuf IPC)."""
+    props = torch.cuda.get_device_properties(dev)
+    ids = [None] * world
+    dist.all_gather_object(ids, (rank, str(getattr(props, "uuid", "")) or "device-%d" % torch.cuda.current_device()))
+    distinct = len(set(u for _, u in ids))
+    if distinct < world and not share:
+        raise SystemExit("bench.py preflight: %d ranks but only %d distinct GPUs (%s) -- one process per GPU is required; "
+                         "check --nproc-per-node, LOCAL_RANK and HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES"
+                         % (world, distinct, sorted(set(u for _, u in ids))))
+    try:
+        t = torch.ones(1, device=dev)
+        dist.all_reduce(t)
+        torch.cuda.synchronize()
+        got = float(t.item())
+    except Exception as ex:
+        raise SystemExit("bench.py preflight: the first all-reduce over backend '%s' failed on rank %d: %r "
+                         "(HSA_ENABLE_IPC_MODE_LEGACY=%s; RCCL needs dmabuf IPC on this driver: export "
+                         "HSA_ENABLE_IPC_MODE_LEGACY=0)" % (dist.get_backend(), rank, ex,
+                                                            os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")))
+    if got != float(world):
+        raise SystemExit("bench.py preflight: all-reduce of ones over %d ranks returned %r" % (world, got))
+
+
 def _overlap_report(profile, steps):
     """GradientBuckets.profile (HIP events on the main and the communication stream) -> how much of the gradient
     exchange ran inside the backward window.  Times in ms, averaged per step."""
@@ -465,6 +491,8 @@ def _main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if world > 1:
+            _preflight(rank, world, dev, share)
 
     from feature_intertwiner_amd import _lib
     from feature_intertwiner_amd.config import make_config
@@ -605,6 +633,35 @@ def _main():
         torch.cuda.synchronize()
         overlap = _overlap_report(sync.profile, prof_steps)
         sync.profile = None
+    configs3 = None
+    if world > 1 and args.config == "cfg3" and args.batch_per_gpu != 2:
+        # BASELINE configs[3] quotes 2 images per GPU: the same model and engine on a 2-image shard, after the timed
+        # region (2 warm-up + 6 timed steps, barrier + synchronize on both sides, MAX over ranks)
+        batch2 = synthetic_batch(2, args.image_size, device=dev, seed=3000 + rank)
+        keep_ext = model.external_proposals
+        model.external_proposals = SyntheticProposals(batch2[2], args.image_size, seed=17 + rank)
+
+        def step2():
+            return train_step(model, opt, list(batch2), do_meta=True, grad_sync=sync, world_size=world, reduce_fn=reduce_fn)
+        for _ in range(2):
+            step2()
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t3 = time.perf_counter()
+        for _ in range(6):
+            step2()
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        mine2 = torch.tensor([time.perf_counter() - t3], device=dev, dtype=torch.float64)
+        dist.all_reduce(mine2, op=dist.ReduceOp.MAX)
+        ms2 = float(mine2.item()) / 6 * 1e3
+        configs3 = {"workload": "BASELINE configs[3]: 2 images per GPU, otherwise as config.workload", "images_per_gpu": 2,
+                    "global_batch": 2 * world, "steps": 6, "ms_per_step": round(ms2, 3),
+                    "value": round(2 * world * 1e3 / ms2, 4), "unit": "images/sec"}
+        model.external_proposals = keep_ext
+        del batch2
     if world > 1:
         mine = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         every = [torch.zeros_like(mine) for _ in range(world)]
@@ -804,7 +861,8 @@ def _main():
                           "contiguous slice of it, all-reduced IN PLACE on a side HIP stream from autograd hooks; one "
                           "~1 MB all-reduce of the intertwiner class statistics in forward",
                 "buckets": len(sync.buckets), "bucket_bytes": sync.bucket_bytes(),
-                "ms_per_step_per_rank": per_rank_ms, "rccl_ranks": rccl_ranks, "overlap": overlap}
+                "ms_per_step_per_rank": per_rank_ms, "rccl_ranks": rccl_ranks, "overlap": overlap,
+                "configs3_shape": configs3}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 entries = [e for e in log if e["pyramid"] and e["crop"] in (7, 14) and e["boxes"].size(0) ==

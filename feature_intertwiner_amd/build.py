@@ -24,7 +24,7 @@ FLAGS = [
     # hardware fp32 atomic add (global_atomic_add_f32) for the scatter kernels
     "-munsafe-fp-atomics",
     "-Wall", "-Wno-unused-function",
-]
+] + os.environ.get("FI_EXTRA_HIPCC_FLAGS", "").split()          # e.g. -DFI_PROBE_1X1 (scripts/c4_probe.sh)
 
 
 def _stale(target, deps):

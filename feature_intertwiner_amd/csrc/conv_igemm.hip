@@ -1075,7 +1075,12 @@ __global__ __launch_bounds__(kThreads, 3) void conv1x1_reg_kernel(const float *_
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[j][e] = 0.0f;
 
+#ifdef FI_PROBE_1X1
+    if (ep.relu & (1 << 21)) return;                      // probe: empty launch
+    const int ncb = (ep.relu & (1 << 22)) ? 1 : g.Cin / P1_CB;      // probe: one stage only
+#else
     const int ncb = g.Cin / P1_CB;
+#endif
     stage_load(0);
     stage_store(0);
     __syncthreads();
@@ -1099,6 +1104,10 @@ __global__ __launch_bounds__(kThreads, 3) void conv1x1_reg_kernel(const float *_
                 // loads sit in front of the wait for the first group's weights and every stage starts with the
                 // memory latency
                 stage_load(more ? cb + 1 : cb);
+            } else {
+                // the first channel group of the NEXT stage: its register set is free from here on (at the end of the
+                // stage the loads sat 0 MFMAs in front of their first use: one exposed L2 round trip per stage)
+                load_a(areg[0], more ? 2 * cb + 2 : 2 * cb);
             }
 #pragma unroll
             for (int kk = 0; kk < 8; ++kk) {
@@ -1114,11 +1123,11 @@ __global__ __launch_bounds__(kThreads, 3) void conv1x1_reg_kernel(const float *_
                 acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv.z, acc[2], 0, 0, 0);
                 acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv.w, acc[3], 0, 0, 0);
                 if (kk == 0 && h == 0) __builtin_amdgcn_sched_group_barrier(0x020, 6, 0);     // 2 weight + 4 staging loads
+                if (kk == 0 && h == 1) __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);     // 2 weight loads
                 __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
             }
         }
-        load_a(areg[0], more ? 2 * cb + 2 : 2 * cb);         // unconditional: see above
         if (more) stage_store((cb + 1) & 1);
         __syncthreads();
     }
@@ -1130,7 +1139,10 @@ __global__ __launch_bounds__(kThreads, 3) void conv1x1_reg_kernel(const float *_
     const int mb = m0 + wave * 32 + 4 * khalf;
     const size_t HW = (size_t)g.HW;
     const size_t obase = ((size_t)n_img * g.Cout + mb) * HW + (po - n_img * g.HW);
-    const bool has_sc = ep.scale != nullptr, has_bi = ep.bias != nullptr, relu = ep.relu != 0;
+    const bool has_sc = ep.scale != nullptr, has_bi = ep.bias != nullptr, relu = (ep.relu & 1) != 0;
+#ifdef FI_PROBE_1X1
+    if (ep.relu & (1 << 20)) return;       // probe: no epilogue at all
+#endif
     const float *__restrict__ spp = has_sc ? ep.scale : g.zero;
     const float *__restrict__ bpp = has_bi ? ep.bias : g.zero;
     const int smul = has_sc ? 1 : 0, bmul = has_bi ? 1 : 0;
@@ -2243,6 +2255,9 @@ int fi_conv2d_forward_gated(const float *x, const float *weight, const float *bi
     g.zero = zero_page();
     FI_REQUIRE(g.zero != nullptr, "zero page lookup failed (no HIP device?)");
     hipStream_t st = (hipStream_t)stream;
+#ifdef FI_PROBE_1X1
+    if (getenv("FI_DBG_1X1")) relu |= (int)strtol(getenv("FI_DBG_1X1"), nullptr, 0);
+#endif
     const Epilogue ep = {bias, scale, residual, relu, gate};
     const bool bm64 = use_bm64(Cout, g.P);
     // 3x3 / stride 1 / pad 1 layers with enough tiles to fill the chip: input patch in LDS (conv3x3_patch_kernel)

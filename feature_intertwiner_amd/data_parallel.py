@@ -105,11 +105,12 @@ class GradientBuckets(object):
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.layout = grad_arena.get_layout(module, bucket_bytes)
         self.buckets = [b.params for b in self.layout.buckets]
+        self.waits = [b.wait for b in self.layout.buckets]      # == params, except for the pieces of one large parameter
         params = self.layout.params
-        self.bucket_of = {}
-        for bi, b in enumerate(self.buckets):
-            for p in b:
-                self.bucket_of[p] = bi
+        self.buckets_of = {}
+        for bi, w in enumerate(self.waits):
+            for p in w:
+                self.buckets_of.setdefault(p, []).append(bi)
         self.device = params[0].device if params else torch.device("cpu")
         self.use_stream = self.device.type == "cuda"
         self.comm_stream = torch.cuda.Stream(device=self.device) if self.use_stream else None
@@ -173,7 +174,7 @@ class GradientBuckets(object):
     def _reset(self):
         skip = self._not_waited()
         self._skip = skip
-        self.pending = [sum(1 for p in b if p not in skip) for b in self.buckets]
+        self.pending = [sum(1 for p in w if p not in skip) for w in self.waits]
         self.next_to_launch = 0
         self.inflight = []        # (bucket index, work handle, which params had a gradient)
         self._launched = set()
@@ -181,13 +182,13 @@ class GradientBuckets(object):
 
     def _on_grad(self, p):
         self._start()
-        bi = self.bucket_of[p]
-        if bi in self._launched:
-            raise RuntimeError("GradientBuckets: a gradient arrived for a parameter of bucket %d after the bucket was "
-                               "issued -- the set of parameters that receive gradients changed without a new "
-                               "begin(key)" % bi)
-        if p not in self._skip:
-            self.pending[bi] -= 1
+        for bi in self.buckets_of[p]:
+            if bi in self._launched:
+                raise RuntimeError("GradientBuckets: a gradient arrived for a parameter of bucket %d after the bucket was "
+                                   "issued -- the set of parameters that receive gradients changed without a new "
+                                   "begin(key)" % bi)
+            if p not in self._skip:
+                self.pending[bi] -= 1
         self._launch_ready()
 
     @torch.no_grad()
@@ -203,9 +204,11 @@ class GradientBuckets(object):
                 self.launch_log.append((bi, sum(max(n, 0) for n in self.pending[bi + 1:])))
             had = [p.grad is not None for p in b.params]
             # gradients that autograd allocated outside the arena move into their slots (one multi-tensor copy);
-            # a parameter without a gradient leaves its slot zero
+            # a parameter without a gradient leaves its slot zero.  (b.wait: a piece of a split parameter moves the
+            # whole parameter in before the first piece leaves)
             dst, src, moved = [], [], []
-            for p, h in zip(b.params, had):
+            for p in b.wait:
+                h = p.grad is not None
                 if h and not lay.holds(p, p.grad, buf):
                     v = lay.view(p, buf)
                     if v is None:

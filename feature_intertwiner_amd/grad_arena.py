@@ -30,10 +30,14 @@ def _align4(n):
 
 
 class Bucket(object):
-    __slots__ = ("params", "start", "end", "flag_off")
+    """[start, end) of the arena (floats).  `params`: the parameters whose slots END in this bucket -- their "had a
+    gradient" flags ride at flag_off.  `wait`: the parameters whose gradient must have arrived before the slice may
+    be reduced -- `params` plus, for a bucket that is a piece of ONE large parameter (split_large), that parameter."""
+    __slots__ = ("params", "start", "end", "flag_off", "wait")
 
-    def __init__(self, params, start, end, flag_off):
+    def __init__(self, params, start, end, flag_off, wait=None):
         self.params, self.start, self.end, self.flag_off = params, start, end, flag_off
+        self.wait = list(params) if wait is None else wait
 
 
 class ArenaLayout(object):
@@ -67,6 +71,25 @@ class ArenaLayout(object):
             nonlocal off, start, cur
             flag_off = off
             off = _align4(off + len(cur))
+            # A bucket boundary may fall INSIDE a parameter (the slice is contiguous either way): a parameter larger
+            # than ~1.5 buckets (the heads' two full-window convolutions: 103 MB and 51 MB of gradient) is cut into
+            # bucket-sized pieces, each its own collective, so that the exchange of the first piece starts while
+            # the later ones are still queued and no single 100 MB all-reduce sits at the end of backward.  The
+            # pieces wait for the same gradient; the flags ride in the last piece.
+            piece = self.bucket_bytes // 4
+            last = cur[-1] if cur else None
+            lo, n = self.slot.get(last, (0, 0)) if last is not None else (0, 0)
+            if n > piece + piece // 2 and lo + _align4(n) == flag_off:      # the oversize is the LAST unit, a plain parameter
+                cut = start
+                while flag_off - cut > piece + piece // 2:
+                    nxt = _align4(max(cut + piece, lo + 4))
+                    if nxt >= flag_off:
+                        break
+                    self.buckets.append(Bucket([], cut, nxt, nxt, wait=list(cur)))      # no flags of its own
+                    cut = nxt
+                self.buckets.append(Bucket(cur, cut, off, flag_off))
+                start, cur = off, []
+                return
             self.buckets.append(Bucket(cur, start, off, flag_off))
             start, cur = off, []
 

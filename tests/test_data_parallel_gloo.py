@@ -50,6 +50,11 @@ def _worker(rank, world, port, out, asymmetric=False):
     broadcast_parameters(net)
     sync = GradientBuckets(net, bucket_bytes=300)      # tiny buckets: several collectives
     assert len(sync.buckets) > 2
+    # the 16 x 16 weight (1 KB of gradient) is larger than 1.5 buckets: it is cut into bucket-sized pieces, each its own
+    # collective, all waiting for the one gradient; the flags ride in the last piece
+    pieces = [b for b in sync.layout.buckets if not b.params]
+    assert pieces and all(any(q is net.body[2].weight for q in b.wait) for b in pieces[:2])
+    assert max(4 * (b.end - b.start) for b in pieces) <= 300 * 1.5
     sync.launch_log = []
     g = torch.Generator().manual_seed(100)
     x_all = torch.randn(world * 3, 6, generator=g)
