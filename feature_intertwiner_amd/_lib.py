@@ -288,17 +288,36 @@ def side_stream(device=None):
     return side
 
 
-def run_on_side_stream(fn, *args):
+_SIDE3 = {}
+
+
+def side_stream3(device=None):
+    """The third stream (run_on_side_stream(after=...)), created on first use."""
+    dev = torch.cuda.current_device() if device is None else torch.device(device).index
+    side = _SIDE3.get(dev)
+    if side is None:
+        side = _SIDE3[dev] = torch.cuda.Stream(device=dev)
+    return side
+
+
+def run_on_side_stream(fn, *args, after=None):
     """Run fn(*args) (network-independent small kernels, e.g. RPN target generation) on a second stream so that
     its launch-latency-bound kernels interleave with the convolutions of the current stream.  Returns a
     function that makes the current stream wait for the result and returns it (a tuple/list of tensors or a
-    tensor).  Inputs must already be complete on the current stream when this is called."""
+    tensor).  Inputs must already be complete on the current stream when this is called -- or, with `after` (an
+    event recorded on the current stream EARLIER), at that event: the work then starts there, next to whatever the
+    current stream has queued behind the event (a third stream, so that it does not queue behind run_on_side_stream
+    work either)."""
     dev = torch.cuda.current_device()
     cur = torch.cuda.current_stream(dev)
-    side = _SIDE2.get(dev)
+    pool = _SIDE2 if after is None else _SIDE3
+    side = pool.get(dev)
     if side is None:
-        side = _SIDE2[dev] = torch.cuda.Stream(device=dev)
-    side.wait_stream(cur)
+        side = pool[dev] = torch.cuda.Stream(device=dev)
+    if after is None:
+        side.wait_stream(cur)
+    else:
+        side.wait_event(after)
     with torch.cuda.stream(side):
         out = fn(*args)
     done = torch.cuda.Event()
@@ -316,6 +335,7 @@ def run_on_side_stream(fn, *args):
                     mark(e)
         mark(out)
         return out
+    wait.out, wait.done = out, done          # for consumers on the SAME side stream (ordered there): no wait needed
     return wait
 
 

@@ -11,6 +11,8 @@ from . import conv as _conv
 import os as _os
 # the mask head's batch whose results nothing reads runs on the second stream (same-box A/B 120.3 -> 117.2 ms/step)
 _DEAD_SIDE = _os.environ.get('FI_DEAD_SIDE', '1') != '0'
+# the proposal layer on the second stream, under the Dev stage's make-up convolutions (A/B switch)
+_PROPOSAL_SIDE = _os.environ.get('FI_PROPOSAL_SIDE', '1') != '0'
 from ._lib import const_tensor
 from .conv import conv_precision, prepare_step, set_conv_precision
 from .intertwiner import FeatureBuffer, meta_loss
@@ -144,25 +146,29 @@ class MaskRCNN(nn.Module):
         rpn_logits, rpn_probs, rpn_bbox = [torch.cat(list(o), dim=1) for o in zip(*outs)]
 
         with torch.no_grad():
-            extra = self.external_proposals() if self.external_proposals is not None else None
-            proposals, num_prop = proposal_layer([rpn_probs, rpn_bbox], proposal_cnt, cfg.RPN.NMS_THRESHOLD,
-                                                 self.priors, cfg, extra)
             h, w = float(cfg.DATA.IMAGE_SHAPE[0]), float(cfg.DATA.IMAGE_SHAPE[1])
             scale = const_tensor([h, w, h, w], images.device)
-            # detection targets (IoU matching, sampling, mask-target crops: ~130 small kernels) on the second stream;
-            # the Dev stage's make-up convolutions below do not depend on the RoIs and run meanwhile
-            def targets_and_levels(*a):
-                t = prepare_det_target(*a)
+            # The proposal layer (candidate selection, NMS: a chain of latency-bound kernels on a handful of CUs, ~0.7 ms)
+            # and the detection targets (IoU matching, sampling, mask-target crops: ~130 small kernels) on the second
+            # stream; the Dev stage's make-up convolutions below do not depend on the RoIs and run meanwhile
+            def propose(probs, bbox):
+                extra = self.external_proposals() if self.external_proposals is not None else None
+                return proposal_layer([probs, bbox], proposal_cnt, cfg.RPN.NMS_THRESHOLD, self.priors, cfg, extra)
+            early = None if _PROPOSAL_SIDE else propose(rpn_probs, rpn_bbox)      # A/B: on the main stream
+
+            def proposals_targets_levels(probs, bbox, *a):
+                proposals, num_prop = early if early is not None else propose(probs, bbox)
+                t = prepare_det_target(proposals, num_prop, *a)
                 level, counts_ready = self.dev_roi.level_info(t[0])      # starts the one host read of the RoI stage
                 return t + (level,), counts_ready
 
             gtb = gt_boxes / scale
             if images.is_cuda:
-                side = _lib.run_on_side_stream(targets_and_levels, proposals, num_prop, gt_class_ids, gtb, gt_masks,
-                                               cfg, self.generator)
+                side = _lib.run_on_side_stream(proposals_targets_levels, rpn_probs, rpn_bbox, gt_class_ids, gtb,
+                                               gt_masks, cfg, self.generator)
             else:
-                side = (lambda r=targets_and_levels(proposals, num_prop, gt_class_ids, gtb, gt_masks, cfg,
-                                                    self.generator): r)
+                side = (lambda r=proposals_targets_levels(rpn_probs, rpn_bbox, gt_class_ids, gtb, gt_masks, cfg,
+                                                          self.generator): r)
         up_maps = self.dev_roi.make_up_maps(mrcnn_maps, give_to=to_rpn, take_from=to_make_up) \
             if (cfg.DEV.SWITCH and images.is_cuda) else None
         with torch.no_grad():
@@ -175,6 +181,12 @@ class MaskRCNN(nn.Module):
                                                          level_info=(roi_lvl, counts_ready),
                                                          raw_grad_boxes=to_make_up if chain else None,
                                                          mask_grad_box=mask_box)
+        # the statistics the meta loss reads are complete here: workflow.compute_loss evaluates it on another stream from
+        # this point on, next to the box and mask heads (its ~70 small kernels and the Sinkhorn launch are latency bound)
+        self._stats_ready = None
+        if images.is_cuda:
+            self._stats_ready = torch.cuda.Event()
+            self._stats_ready.record(torch.cuda.current_stream(images.device))
         scale_num = 3
         if cfg.DEV.SWITCH and not cfg.DEV.BASELINE:
             big_feat, big_cnt, small_feat, small_cnt, big_loss, small_output_all, small_gt_all = feat_out
@@ -232,6 +244,14 @@ class MaskRCNN(nn.Module):
             compute_mrcnn_bbox_loss(target_deltas, target_class_ids, mrcnn_bbox),
             compute_mrcnn_mask_loss_selected(mask_tgt, mask_ids, mask_u) if mask_u.dim() == 6 else
             compute_mrcnn_mask_loss_unshuffled(mask_tgt, mask_ids, mask_u, from_logits=True))).view(1, 5)
+        big_done = getattr(self.dev_roi, "big_done", None)
+        if big_done is not None:
+            # the Dev stage's big branch ran on the third stream: joined here, behind the heads (it finished long ago in
+            # device time), so that whatever reads the statistics on this stream is ordered behind it
+            cur = torch.cuda.current_stream(images.device)
+            cur.wait_event(big_done)
+            for t in (big_feat, big_cnt, big_loss):
+                t.record_stream(cur)
         return (losses, big_feat, big_cnt, small_feat, small_cnt, big_loss, small_output_all, small_gt_all,
                 fpn_ot_loss)
 

@@ -24,6 +24,9 @@ from .roi_align.crop_and_resize import CropAndResizeFunction, CropGradGroup, pyr
 from .roi_pooling.functions.roi_pool import RoIPoolFunction
 
 
+import os as _os
+_BIG_SIDE = _os.environ.get('FI_BIG_SIDE', '1') != '0'      # the graph-less big branch of the Dev stage on the third stream (A/B switch)
+
 class SamePad2d(nn.Module):
     """TensorFlow 'SAME' padding (lib/sub_module.py:9-33).  `folded=True` means the following
     convolution carries the (symmetric) padding itself, so no padded copy is materialised."""
@@ -565,59 +568,80 @@ class Dev(nn.Module):
             small_cnt.append(c)
         # 'big' boxes: RoIs of higher levels pooled 14x14 from the RAW level map (:498-507); level l sees
         # the RoIs of every higher level, so an RoI of level 5 appears three times
-        n_big = {2: n3 + n4 + n5, 3: n4 + n5, 4: n5}
-        has_small = {2: n2 > 0, 3: n3 > 0, 4: n4 > 0}
-        big_sel, big_lvl = [], []
-        for lvl in (2, 3, 4):
-            idx = torch.nonzero_static(level > lvl, size=n_big[lvl]).view(-1)
-            big_sel.append(idx)
-            big_lvl.append(torch.full_like(idx, lvl, dtype=torch.int32))
-        n_big_rows = sum(n_big.values())
-        n_pad = (-n_big_rows) % 64
-        if n_big_rows and n_pad:
-            # row count of the big branch rounded up to a multiple of 64 (see above): the filler rows carry level 0,
-            # which no pyramid level matches -- zero crops, no statistics, no loss
-            big_sel.append(torch.zeros(n_pad, dtype=big_sel[0].dtype, device=level.device))
-            big_lvl.append(torch.zeros(n_pad, dtype=torch.int32, device=level.device))
-        big_idx = torch.cat(big_sel)
-        big_level = torch.cat(big_lvl)
-        big_loss = []
-        # the big branch needs a graph only when its class means are not detached or when it is
-        # supervised by its own classifier (:531-535: the CE loss reaches feat_extract either way)
-        with torch.set_grad_enabled(torch.is_grad_enabled() and
-                                    (not cfg.DEV.BIG_FEAT_DETACH or cfg.DEV.BIG_SUPERVISE)):
-            if big_idx.numel():
-                big_pooled = self._crop(x, boxes[big_idx], box_ind[big_idx], big_level, self.feat_pool_size,
-                                        CropGradGroup(give_to=raw_grad_boxes) if raw_grad_boxes else None)
-                big_raw = self._feat_extract(big_pooled)
-                big_out = self.last_op(big_raw) if cfg.DEV.LOSS_CHOICE != 'ot' else big_raw
-                big_out = big_out.view(big_idx.numel(), -1)
-                big_raw = big_raw.view(big_idx.numel(), -1)
-            else:
-                big_out = big_raw = small_output.new_zeros(0, small_output.size(1))
-            big_gt = gt[big_idx]
-            if cfg.DEV.BIG_SUPERVISE:
-                ce = F.cross_entropy(linear(big_raw, self.big_fc_layer.weight, self.big_fc_layer.bias), big_gt.long(),
-                                     reduction='none') \
-                    if big_idx.numel() else big_raw.new_zeros(0)
-            for i, lvl in enumerate((2, 3, 4)):
-                # a level without small boxes contributes no big statistics either (:456-467)
-                at_lvl = big_level == lvl
-                g = torch.where(at_lvl, big_gt, torch.zeros_like(big_gt)) if has_small[lvl] else torch.zeros_like(big_gt)
-                f, c = class_mean(big_out, g, K)
-                big_feat.append(f)
-                big_cnt.append(c)
-                if cfg.DEV.BIG_SUPERVISE and has_small[lvl]:     # mean CE over the level's big boxes (:531-535)
-                    w = at_lvl.float()
-                    big_loss.append(((ce * w).sum() / w.sum().clamp(min=1)).view(1))
+        def big_branch():
+            big_feat, big_cnt = [], []
+            n_big = {2: n3 + n4 + n5, 3: n4 + n5, 4: n5}
+            has_small = {2: n2 > 0, 3: n3 > 0, 4: n4 > 0}
+            big_sel, big_lvl = [], []
+            for lvl in (2, 3, 4):
+                idx = torch.nonzero_static(level > lvl, size=n_big[lvl]).view(-1)
+                big_sel.append(idx)
+                big_lvl.append(torch.full_like(idx, lvl, dtype=torch.int32))
+            n_big_rows = sum(n_big.values())
+            n_pad = (-n_big_rows) % 64
+            if n_big_rows and n_pad:
+                # row count of the big branch rounded up to a multiple of 64 (see above): the filler rows carry level 0,
+                # which no pyramid level matches -- zero crops, no statistics, no loss
+                big_sel.append(torch.zeros(n_pad, dtype=big_sel[0].dtype, device=level.device))
+                big_lvl.append(torch.zeros(n_pad, dtype=torch.int32, device=level.device))
+            big_idx = torch.cat(big_sel)
+            big_level = torch.cat(big_lvl)
+            big_loss = []
+            # the big branch needs a graph only when its class means are not detached or when it is
+            # supervised by its own classifier (:531-535: the CE loss reaches feat_extract either way)
+            with torch.set_grad_enabled(torch.is_grad_enabled() and
+                                        (not cfg.DEV.BIG_FEAT_DETACH or cfg.DEV.BIG_SUPERVISE)):
+                if big_idx.numel():
+                    big_pooled = self._crop(x, boxes[big_idx], box_ind[big_idx], big_level, self.feat_pool_size,
+                                            CropGradGroup(give_to=raw_grad_boxes) if raw_grad_boxes else None)
+                    big_raw = self._feat_extract(big_pooled)
+                    big_out = self.last_op(big_raw) if cfg.DEV.LOSS_CHOICE != 'ot' else big_raw
+                    big_out = big_out.view(big_idx.numel(), -1)
+                    big_raw = big_raw.view(big_idx.numel(), -1)
                 else:
-                    big_loss.append(small_output.new_zeros(1))
-        bf = torch.stack(big_feat).unsqueeze(0)
-        if cfg.DEV.BIG_FEAT_DETACH:
-            bf = bf.detach()
-        feat_out = [bf, torch.stack(big_cnt).unsqueeze(0),
+                    big_out = big_raw = small_output.new_zeros(0, small_output.size(1))
+                big_gt = gt[big_idx]
+                if cfg.DEV.BIG_SUPERVISE:
+                    ce = F.cross_entropy(linear(big_raw, self.big_fc_layer.weight, self.big_fc_layer.bias), big_gt.long(),
+                                         reduction='none') \
+                        if big_idx.numel() else big_raw.new_zeros(0)
+                for i, lvl in enumerate((2, 3, 4)):
+                    # a level without small boxes contributes no big statistics either (:456-467)
+                    at_lvl = big_level == lvl
+                    g = torch.where(at_lvl, big_gt, torch.zeros_like(big_gt)) if has_small[lvl] else torch.zeros_like(big_gt)
+                    f, c = class_mean(big_out, g, K)
+                    big_feat.append(f)
+                    big_cnt.append(c)
+                    if cfg.DEV.BIG_SUPERVISE and has_small[lvl]:     # mean CE over the level's big boxes (:531-535)
+                        w = at_lvl.float()
+                        big_loss.append(((ce * w).sum() / w.sum().clamp(min=1)).view(1))
+                    else:
+                        big_loss.append(small_output.new_zeros(1))
+            bf = torch.stack(big_feat).unsqueeze(0)
+            if cfg.DEV.BIG_FEAT_DETACH:
+                bf = bf.detach()
+            return bf, torch.stack(big_cnt).unsqueeze(0), torch.stack(big_loss).unsqueeze(0)
+
+        # The big branch builds no graph when its class means are detached and it has no classifier of its own (the
+        # defaults): nothing on the main stream reads it before the meta loss, so it runs on the third stream, next to
+        # the small branch, the box head and the mask head (crop + feat_extract on ~1300 rows: ~3 ms of kernels).
+        # workflow.compute_loss evaluates the meta loss on that same stream, behind it; a consumer on another stream
+        # waits for self.big_done.
+        self.big_done = None
+        if _BIG_SIDE and level.is_cuda and cfg.DEV.BIG_FEAT_DETACH and not cfg.DEV.BIG_SUPERVISE:
+            fork = torch.cuda.Event()
+            fork.record(torch.cuda.current_stream(level.device))
+            side3 = _lib.side_stream3(level.device)
+            for t in (boxes, box_ind, level, gt):
+                t.record_stream(side3)
+            ready = _lib.run_on_side_stream(big_branch, after=fork)
+            bf, bcnt, bloss = ready.out
+            self.big_done = ready.done
+        else:
+            bf, bcnt, bloss = big_branch()
+        feat_out = [bf, bcnt,
                     torch.stack(small_feat).unsqueeze(0), torch.stack(small_cnt).unsqueeze(0),
-                    torch.stack(big_loss).unsqueeze(0), small_output_all, small_gt_all]
+                    bloss, small_output_all, small_gt_all]
         return pooled, mask_and_feat, feat_out
 
 

@@ -4,8 +4,13 @@ clipping, SGD step.  The reference's epoch/stage loops, logging, visdom and chec
 are out of scope (SURVEY 2.1 #8)."""
 import torch
 
+import os
+
 from . import optim
 from ._lib import const_tensor
+from ._lib import run_on_side_stream as _run_on_side_stream
+
+META_SIDE_STREAM = os.environ.get("FI_META_SIDE", "1") != "0"      # A/B switch (scripts/ab_env.sh)
 
 
 def set_optimizer(net, opt):
@@ -35,8 +40,20 @@ def compute_loss(model, inputs, do_meta=True, world_size=1, reduce_fn=None):
             # torch.sum's backward does not look at values, so their gradients still flow -- mirrored
             off = const_tensor([0., 1., 0., 1., 1.], detailed.device)
             detailed = detailed - detailed.detach() * off
-        meta = model.meta_loss([big_feat, big_cnt, small_feat, small_cnt, small_output_all, small_gt_all],
-                               reduce_fn=reduce_fn)
+        feats = [big_feat, big_cnt, small_feat, small_cnt, small_output_all, small_gt_all]
+        fork = getattr(model, "_stats_ready", None)
+        if fork is not None and META_SIDE_STREAM and reduce_fn is None and big_feat.is_cuda:
+            # latency-bound (~70 small kernels + one Sinkhorn launch) and independent of the box / mask heads the main
+            # stream still has queued: evaluated from the point where the statistics were complete (autograd runs the
+            # backward of these ops on the stream their forward ran on, with the joins it needs).  Data parallel: the
+            # statistics all-reduce is a rendezvous of all ranks and stays on the main stream.
+            model._stats_ready = None
+            meta = _run_on_side_stream(lambda: model.meta_loss(feats, reduce_fn=None), after=fork)()
+        else:
+            big_done = getattr(getattr(model, "dev_roi", None), "big_done", None)
+            if big_done is not None:          # the big branch ran on the third stream (Dev.forward)
+                torch.cuda.current_stream(big_feat.device).wait_event(big_done)
+            meta = model.meta_loss(feats, reduce_fn=reduce_fn)
         meta = torch.where(meta < 0, torch.zeros_like(meta), meta)       # workflow.py:196-200
         meta = meta * cfg.DEV.LOSS_FAC if do_meta else torch.zeros_like(meta)
     else:
