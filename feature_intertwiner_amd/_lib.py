@@ -62,6 +62,7 @@ SIGNATURES = {
     "fi_conv2d_forward": (c_int, [c_void_p] * 6 + [c_int] * 16 + [c_void_p]),
     "fi_bn_act_backward": (c_int, [c_void_p] * 6 + [c_int] * 4 + [c_void_p] * 5 + [c_int, c_int, c_void_p]),
     "fi_conv2d_weight_grad": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 12 + [c_void_p, c_int, c_void_p]),
+    "fi_conv2d_weight_grad_batch": (c_int, [c_void_p] * 4 + [c_int] * 14 + [c_void_p]),
     "fi_conv2d_forward_gated_bf16": (c_int, [c_void_p] * 7 + [c_int] * 16 + [c_void_p]),
     "fi_conv3x3_forward_gated_bf16w": (c_int, [c_void_p] * 7 + [c_int] * 7 + [c_void_p]),
     "fi_conv1x1_forward_gated_bf16w": (c_int, [c_void_p] * 7 + [c_int] * 5 + [c_void_p]),
@@ -151,7 +152,7 @@ def reg1x1_mode(N, Cin, H, W, Cout, R, S, stride, padding, out_channels_last):
             ((N * H * W + 127) // 128) * ((Cout + 127) // 128) >= 256)
 
 
-def conv_kernel_key(kind, cout, R, S, pixels=None, cin=None):
+def conv_kernel_key(kind, cout, R, S, pixels=None, cin=None, batch=1):
     """Name (KERNEL_IDS key) of the device kernel instance a convolution launch uses (mirrors
     use_bm64() and the tile choice of fi_conv2d_weight_grad in csrc/conv_igemm.hip: 64-row tiles for
     narrow layers and under-filled grids)."""
@@ -162,7 +163,7 @@ def conv_kernel_key(kind, cout, R, S, pixels=None, cin=None):
     if kind == "wgrad" and not bm64 and pixels is not None and cin is not None:
         tiles128 = ((cin * R * S + 127) // 128) * ((cout + 127) // 128)
         max_splits = (pixels + 511) // 512
-        bm64 = tiles128 * min(max(1, 1024 // tiles128), max_splits) < 768
+        bm64 = batch * tiles128 * min(max(1, 1024 // tiles128), max_splits) < 768      # batch: fi_conv2d_weight_grad_batch
     return "conv_%s_bm%d_%s" % (kind, 64 if bm64 else 128, w)
 
 

@@ -61,12 +61,12 @@ def _log_shape(x, w, stride, padding):
                           tuple(stride), tuple(padding)))
 
 
-def _log_flops(kind, cout, R, S, flops, pixels=None, cin=None, patch=0):
+def _log_flops(kind, cout, R, S, flops, pixels=None, cin=None, patch=0, batch=1):
     if FLOP_LOG is not None:
         if patch:
             k = {1: "conv3x3_patch", 2: "conv3x3_patch_flat", 3: "conv1x1_reg"}[patch]
         else:
-            k = ("conv_" + kind) if kind.startswith("bf16") else _lib.conv_kernel_key(kind, cout, R, S, pixels, cin)
+            k = ("conv_" + kind) if kind.startswith("bf16") else _lib.conv_kernel_key(kind, cout, R, S, pixels, cin, batch)
         e = FLOP_LOG.setdefault(k, [0, 0])
         e[0] += 1
         e[1] += flops
@@ -584,8 +584,18 @@ def _conv_backward(ctx_needs, x, w, dz, stride, padding, want_db=False, add_to_d
             side.wait_event(dz_ready)                      # dz (and x) were complete on the main stream there
             x.record_stream(side)
             dz.record_stream(side)
+        if side is not None and WGRAD_BATCH > 1 and hwc and same and Cin % 128 == 0 and \
+                N * dz.shape[2] * dz.shape[3] <= WGRAD_BATCH_MAX_PIXELS and _defer_wgrad(
+                    (N, Cin, H, W, Cout, R, S, padding, want_db and db is not None),
+                    x, dz, dw, db if want_db else None, after_wgrad, bool(hwc and R * S > 1), dz_ready, main, side):
+            side = None                    # queued: launched with the other layers of its geometry (_flush_wgrads)
+            deferred = True
+        else:
+            deferred = False
         with torch.cuda.device(x.device), (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
-            if bf16:
+            if deferred:
+                pass
+            elif bf16:
                 _log_flops("bf16_wgrad", Cout, R, S, 2 * N * Cout * dz.shape[2] * dz.shape[3] * Cin * R * S)
                 _lib.check(_lowp_fn(L, "conv2d_weight_grad_db", precision)(_lib.ptr(x), _lib.ptr(dz), _lib.ptr(dw), _lib.ptr(db),
                                                         N, Cin, H, W, Cout,
@@ -597,10 +607,11 @@ def _conv_backward(ctx_needs, x, w, dz, stride, padding, want_db=False, add_to_d
                 _lib.check(L.fi_conv2d_weight_grad(_lib.ptr(x), _lib.ptr(dz), _lib.ptr(dw), N, Cin, H, W, Cout,
                                                    R, S, stride[0], stride[1], padding[0], padding[1], hwc,
                                                    _lib.ptr(db), flags, _lib.current_stream()), "fi_conv2d_weight_grad")
-            if after_wgrad is not None:
+            if after_wgrad is not None and not deferred:
                 after_wgrad(dw, db, bool(hwc and R * S > 1))        # (the 16-bit kernels write tap-major: hwc is set)
         if side is not None:
             _queue_wgrad_join(main, side)
+        _age_wgrad_queues()
         if hwc and R * S > 1:
             dw = dw.permute(0, 3, 1, 2)
         if not hand_over:
@@ -648,6 +659,92 @@ def _queue_wgrad_join(main, side):
         torch.autograd.Variable._execution_engine.queue_callback(join)
     except RuntimeError:          # not inside a backward pass: join right away
         join()
+
+
+# ---- weight gradients of identical layers in ONE launch ---------------------------------------------------------------
+# A layer of the C4 stage at batch 4 ([4, 256|1024, 64, 64]) gives the weight-gradient kernel 16..36 tiles: to fill the
+# chip it is cut into up to 64 pixel splits, one round of short workgroups whose fixed cost -- prologue, atomic epilogue of
+# 64 KB per workgroup -- is a third of the launch (86..95 us for 8.6 GFLOP whatever the shape; scripts/wg_batch_probe.py:
+# the same arithmetic with 4x / 23x the pixels per launch runs at 123 / 130 TFLOP/s instead of 90..98).  ResNet-101 has 23
+# such blocks in a row.  Their weight gradients already run on the second stream and nothing reads them before the
+# optimiser, so they are QUEUED per geometry and launched WGRAD_BATCH at a time (fi_conv2d_weight_grad_batch: the operand
+# pointers travel in the kernel arguments), each problem with fewer, longer splits.  A queue is also flushed when its
+# geometry has not been seen for WGRAD_BATCH_AGE convolution backward calls (the stage is over), when a data-parallel
+# bucket is about to be reduced (data_parallel.GradientBuckets), and at the end of the backward pass.
+WGRAD_BATCH = int(_os.environ.get("FI_WGRAD_BATCH", "12"))              # problems per launch; <= 1 disables the queue
+WGRAD_BATCH_AGE = 9
+WGRAD_BATCH_MAX_PIXELS = 65536                                         # larger layers fill the chip on their own
+_WGQ = {"queues": {}, "tick": 0, "armed": False, "streams": {}}
+
+
+def _defer_wgrad(key, x, dz, dw, db, after, tap_major, ev, main, side):
+    """Queue one weight gradient (True), or decline (False: not inside a backward pass -- nobody would flush)."""
+    q = _WGQ
+    if not q["armed"]:
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(_finish_wgrads)
+        except RuntimeError:
+            return False
+        q["armed"] = True
+    q["streams"][(id(main), id(side))] = (main, side)
+    e = q["queues"].setdefault(key, {"items": [], "last": 0, "main": main, "side": side})
+    # (an alias of dw: AccumulateGrad adopts a gradient only while nobody else holds the tensor it was handed -- a second
+    # reference to that very object makes it clone the still-empty slot)
+    e["items"].append((x, dz, dw.view(dw.shape), None if db is None else db.view(db.shape), after, tap_major, ev))
+    e["last"] = q["tick"]
+    if len(e["items"]) >= min(WGRAD_BATCH, 24):
+        _flush_wgrads(key)
+    return True
+
+
+def _age_wgrad_queues():
+    q = _WGQ
+    q["tick"] += 1
+    if q["queues"]:
+        for key in [k for k, e in q["queues"].items() if q["tick"] - e["last"] >= WGRAD_BATCH_AGE]:
+            _flush_wgrads(key)
+
+
+def _flush_wgrads(key):
+    import ctypes
+    e = _WGQ["queues"].pop(key, None)
+    if not e or not e["items"]:
+        return
+    items, side = e["items"], e["side"]
+    N, Cin, H, W, Cout, R, S, padding, has_db = key
+    n = len(items)
+    L = _lib.load()
+    side.wait_event(items[-1][6])          # the events were recorded on one stream, in order: the last covers all
+    arr = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])
+    xs, dzs, dws = [it[0] for it in items], [it[1] for it in items], [it[2] for it in items]
+    for t in xs + dzs:
+        t.record_stream(side)
+    with torch.cuda.device(xs[0].device), torch.cuda.stream(side):
+        _log_flops("wgrad", Cout, R, S, 2.0 * n * N * H * W * Cout * Cin * R * S, N * H * W, Cin, batch=n)
+        _lib.check(L.fi_conv2d_weight_grad_batch(arr(xs), arr(dzs), arr(dws),
+                                                 arr([it[3] for it in items]) if has_db else None, n, N, Cin, H, W, Cout,
+                                                 R, S, 1, 1, padding[0], padding[1], 1, _lib.OUTPUTS_ZEROED,
+                                                 _lib.current_stream()), "fi_conv2d_weight_grad_batch")
+        for x, dz, dw, db, after, tap_major, ev in items:
+            if after is not None:
+                after(dw, db, tap_major)
+
+
+def flush_deferred_wgrads():
+    """Launch every queued weight gradient now (on the weight-gradient stream)."""
+    for key in list(_WGQ["queues"].keys()):
+        _flush_wgrads(key)
+
+
+def _finish_wgrads():
+    """Engine callback at the end of the backward pass that queued something: flush, then re-join the streams."""
+    q = _WGQ
+    q["armed"] = False
+    flush_deferred_wgrads()
+    joins, q["streams"] = list(q["streams"].values()), {}
+    for main, side in joins:
+        main.wait_stream(side)
+        torch.cuda.current_stream(side.device).wait_stream(side)
 
 
 # ---- per-step derived state: W^T for the data gradient, zeroed gradient arena ---------------------
@@ -732,6 +829,11 @@ def _prepare_step(model, grad_on):
     dev = next(model.parameters()).device
     if dev.type != "cuda":
         return
+    if _WGQ["queues"] or _WGQ["armed"]:
+        # leftovers of a backward pass that raised before its end-of-pass callback ran: their slots are about to be cleared
+        _WGQ["queues"].clear()
+        _WGQ["streams"].clear()
+        _WGQ["armed"] = False
     if len(_WB) > 4096:
         # bf16 copies of weights that were temporaries (the deconv's reshaped weight, transposes made on the fly)
         # keep their source alive; inference loops never bump a parameter version, so bound the cache here
@@ -974,7 +1076,8 @@ class _ConvBnActFn(torch.autograd.Function):
                                    precision=ctx.precision, give_compact=ctx.dx_give_to is not None,
                                    gate=x if ctx.dx_gate else None, w_scale=scale, db_into=sums[:C],
                                    after_wgrad=finish)
-        dbeta = out["s"] if want_beta else None
+        # the weight-gradient kernel's bias sums: what finish() was handed, or -- the launch is still queued -- db_into
+        dbeta = out.get("s", sums[:C]) if want_beta else None
         if ctx.dx_give_to is not None and dx is not None:
             ctx.dx_give_to.value = dx               # picked up (and added) by the backward of the block's first conv
             dx = None

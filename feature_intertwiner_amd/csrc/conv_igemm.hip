@@ -79,6 +79,17 @@ struct ConvGeom {
                   // sums at dw + s * dw_slab (one writer per element: deterministic; the caller reduces the slabs)
 };
 
+// Several weight gradients of ONE geometry in one launch (fi_conv2d_weight_grad_batch): the operand pointers of every
+// problem travel by value in the kernel arguments -- no device-side table, no host-to-device copy per launch.
+constexpr int kWgBatchMax = FI_WGRAD_BATCH_MAX;
+struct WgradBatch {
+    int n;                                   // 0: a plain launch (the kernel's own x / dy / dw / dbias arguments)
+    const float *x[kWgBatchMax];
+    const float *dy[kWgBatchMax];
+    float *dw[kWgBatchMax];
+    float *db[kWgBatchMax];
+};
+
 // Out-of-image taps of the tap-major gather read this instead of being masked after the load:
 // the loaded registers go to LDS untouched (no per-value select in the K loop).
 __device__ __attribute__((aligned(16))) float g_zero_page[64];
@@ -1381,11 +1392,16 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(const float *__res
 // K-step cost 8 % on this kernel), so every vector instruction removed from the K loop is MFMA time: the general
 // path spends ~80 of them per 32 MFMAs on per-lane pixel bookkeeping and halo masks, this one ~15.
 template <int BM, int TR, int TS, bool HALF = false, bool U16 = false>
-__global__ __launch_bounds__(kThreads, 4) void conv_wgrad_vec_kernel(const float *__restrict__ x,
-                                                                     const float *__restrict__ dy,
-                                                                     float *__restrict__ dw, ConvGeom g,
-                                                                     int p_per_split, float *__restrict__ dbias)
+__global__ __launch_bounds__(kThreads, 4) void conv_wgrad_vec_kernel(const float *__restrict__ x_arg,
+                                                                     const float *__restrict__ dy_arg,
+                                                                     float *__restrict__ dw_arg, ConvGeom g,
+                                                                     int p_per_split, float *__restrict__ dbias_arg,
+                                                                     WgradBatch wb)
 {
+    const float *__restrict__ x = x_arg;
+    const float *__restrict__ dy = dy_arg;
+    float *__restrict__ dw = dw_arg;
+    float *__restrict__ dbias = dbias_arg;
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     constexpr int MT = BM / 64;
     constexpr int PITCH = BK + 4;
@@ -1406,10 +1422,21 @@ __global__ __launch_bounds__(kThreads, 4) void conv_wgrad_vec_kernel(const float
     int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
     if (g.swz) {
         const int tiles = g.wg_gx * g.wg_gy;
-        const int nblk = tiles * g.wg_splits;
+        const int nblk1 = tiles * g.wg_splits;                   // workgroups of one problem
+        const int nblk = wb.n ? nblk1 * wb.n : nblk1;
         const int per_xcd = (nblk + 7) >> 3;
-        const int idx = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+        int idx = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
         if (idx >= nblk) return;
+        if (wb.n) {
+            // batched launch: (problem, pixel split, tile) order, cut into the 8 XCD bands like a single problem --
+            // a problem's operands stay in one L2
+            const int prob = idx / nblk1;
+            idx -= prob * nblk1;
+            x = wb.x[prob];
+            dy = wb.dy[prob];
+            dw = wb.dw[prob];
+            dbias = wb.db[prob];
+        }
         bz = idx / tiles;
         const int t = idx - bz * tiles;
         by = t / g.wg_gx;
@@ -1927,46 +1954,49 @@ bool wgrad_same_size(const ConvGeom &g, const float *x, const float *dy)
 
 template <int BM>
 void launch_wgrad(const ConvGeom &g, const float *x, const float *dy, float *dw, int splits,
-                  int p_per_split, bool hwc, float *dbias, hipStream_t st)
+                  int p_per_split, bool hwc, float *dbias, hipStream_t st, const WgradBatch *batch = nullptr)
 {
     dim3 grid(fi::ceil_div(g.K, BN), fi::ceil_div(g.Cout, BM), splits);
     const bool same = wgrad_same_size(g, x, dy);
+    WgradBatch wbatch;
+    wbatch.n = 0;
+    if (batch) wbatch = *batch;              // (only the row-major kernel below reads it; checked by the caller)
     if (hwc && same && g.Cin == 64) {            // two taps per 128-column tile
         if (g.R == 3 && g.S == 3)
             if (g.OW % BK == 0)
-                hipLaunchKernelGGL((conv_wgrad_vec_kernel<BM, 3, 3, true, true>), grid, dim3(kThreads), 0, st, x, dy, dw, g, p_per_split, dbias);
+                hipLaunchKernelGGL((conv_wgrad_vec_kernel<BM, 3, 3, true, true>), grid, dim3(kThreads), 0, st, x, dy, dw, g, p_per_split, dbias, wbatch);
             else
-                hipLaunchKernelGGL((conv_wgrad_vec_kernel<BM, 3, 3, true>), grid, dim3(kThreads), 0, st, x, dy, dw, g, p_per_split, dbias);
+                hipLaunchKernelGGL((conv_wgrad_vec_kernel<BM, 3, 3, true>), grid, dim3(kThreads), 0, st, x, dy, dw, g, p_per_split, dbias, wbatch);
         else if (g.R == 1 && g.S == 1)
             if (g.OW % BK == 0)
-                hipLaunchKernelGGL((conv_wgrad_vec_kernel<BM, 1, 1, true, true>), grid, dim3(kThreads), 0, st, x, dy, dw, g, p_per_split, dbias);
+                hipLaunchKernelGGL((conv_wgrad_vec_kernel<BM, 1, 1, true, true>), grid, dim3(kThreads), 0, st, x, dy, dw, g, p_per_split, dbias, wbatch);
             else
-                hipLaunchKernelGGL((conv_wgrad_vec_kernel<BM, 1, 1, true>), grid, dim3(kThreads), 0, st, x, dy, dw, g, p_per_split, dbias);
+                hipLaunchKernelGGL((conv_wgrad_vec_kernel<BM, 1, 1, true>), grid, dim3(kThreads), 0, st, x, dy, dw, g, p_per_split, dbias, wbatch);
         else
-            hipLaunchKernelGGL((conv_wgrad_vec_kernel<BM, 0, 0, true>), grid, dim3(kThreads), 0, st, x, dy, dw, g, p_per_split, dbias);
+            hipLaunchKernelGGL((conv_wgrad_vec_kernel<BM, 0, 0, true>), grid, dim3(kThreads), 0, st, x, dy, dw, g, p_per_split, dbias, wbatch);
         return;
     }
     if (hwc && same) {
         ConvGeom gs = g;
         dim3 vgrid = grid;
-        if (g.P >= 32768 && !getenv("FI_NO_WG_SWZ")) {       // XCD-aware 1-D launch (see the kernel)
+        if ((g.P >= 32768 && !getenv("FI_NO_WG_SWZ")) || wbatch.n) {       // XCD-aware 1-D launch (see the kernel)
             gs.swz = 1;
             gs.wg_gx = (int)grid.x; gs.wg_gy = (int)grid.y; gs.wg_splits = splits;
-            const long nblk = (long)grid.x * grid.y * splits;
+            const long nblk = (long)grid.x * grid.y * splits * (wbatch.n ? wbatch.n : 1);
             vgrid = dim3((unsigned)(((nblk + 7) / 8) * 8), 1, 1);
         }
         if (g.R == 3 && g.S == 3)
             if (g.OW % BK == 0)
-                hipLaunchKernelGGL((conv_wgrad_vec_kernel<BM, 3, 3, false, true>), vgrid, dim3(kThreads), 0, st, x, dy, dw, gs, p_per_split, dbias);
+                hipLaunchKernelGGL((conv_wgrad_vec_kernel<BM, 3, 3, false, true>), vgrid, dim3(kThreads), 0, st, x, dy, dw, gs, p_per_split, dbias, wbatch);
             else
-                hipLaunchKernelGGL((conv_wgrad_vec_kernel<BM, 3, 3>), vgrid, dim3(kThreads), 0, st, x, dy, dw, gs, p_per_split, dbias);
+                hipLaunchKernelGGL((conv_wgrad_vec_kernel<BM, 3, 3>), vgrid, dim3(kThreads), 0, st, x, dy, dw, gs, p_per_split, dbias, wbatch);
         else if (g.R == 1 && g.S == 1)
             if (g.OW % BK == 0)
-                hipLaunchKernelGGL((conv_wgrad_vec_kernel<BM, 1, 1, false, true>), vgrid, dim3(kThreads), 0, st, x, dy, dw, gs, p_per_split, dbias);
+                hipLaunchKernelGGL((conv_wgrad_vec_kernel<BM, 1, 1, false, true>), vgrid, dim3(kThreads), 0, st, x, dy, dw, gs, p_per_split, dbias, wbatch);
             else
-                hipLaunchKernelGGL((conv_wgrad_vec_kernel<BM, 1, 1>), vgrid, dim3(kThreads), 0, st, x, dy, dw, gs, p_per_split, dbias);
+                hipLaunchKernelGGL((conv_wgrad_vec_kernel<BM, 1, 1>), vgrid, dim3(kThreads), 0, st, x, dy, dw, gs, p_per_split, dbias, wbatch);
         else
-            hipLaunchKernelGGL((conv_wgrad_vec_kernel<BM, 0, 0>), vgrid, dim3(kThreads), 0, st, x, dy, dw, gs, p_per_split, dbias);
+            hipLaunchKernelGGL((conv_wgrad_vec_kernel<BM, 0, 0>), vgrid, dim3(kThreads), 0, st, x, dy, dw, gs, p_per_split, dbias, wbatch);
         return;
     }
     if (hwc) {
@@ -2362,9 +2392,69 @@ int fi_bn_act_backward(const float *dy, const float *y, const float *scale, cons
     return FI_OK;
 }
 
+// 1: this geometry runs on conv_wgrad_vec_kernel's plain (non-HALF) instantiation -- the one that takes a WgradBatch
+static bool wgrad_batchable(const ConvGeom &g, const float *x, const float *dy, int weight_layout)
+{
+    const bool hwc = (g.Cin % BN == 0) && (weight_layout == 1 || g.R * g.S == 1);
+    return hwc && wgrad_same_size(g, x, dy);
+}
+
+static int wgrad_impl(const float *x, const float *dy, float *dweight, int N, int Cin, int H,
+                      int W, int Cout, int R, int S, int stride_h, int stride_w, int pad_h,
+                      int pad_w, int weight_layout, float *dbias, int flags, fi_stream_t stream, const WgradBatch *batch);
+
 int fi_conv2d_weight_grad(const float *x, const float *dy, float *dweight, int N, int Cin, int H,
                           int W, int Cout, int R, int S, int stride_h, int stride_w, int pad_h,
                           int pad_w, int weight_layout, float *dbias, int flags, fi_stream_t stream)
+{
+    return wgrad_impl(x, dy, dweight, N, Cin, H, W, Cout, R, S, stride_h, stride_w, pad_h, pad_w, weight_layout, dbias,
+                      flags, stream, nullptr);
+}
+
+int fi_conv2d_weight_grad_batch(const float *const *x, const float *const *dy, float *const *dweight,
+                                float *const *dbias, int n, int N, int Cin, int H, int W, int Cout, int R, int S,
+                                int stride_h, int stride_w, int pad_h, int pad_w, int weight_layout, int flags,
+                                fi_stream_t stream)
+{
+    FI_REQUIRE(n >= 1 && x && dy && dweight, "empty batch / null pointer table");
+    ConvGeom g;
+    int rc = make_geom(g, N, Cin, H, W, Cout, R, S, stride_h, stride_w, pad_h, pad_w);
+    if (rc != FI_OK) return rc;
+    bool ok = true, any_db = false, all_db = true;
+    for (int i = 0; i < n; ++i) {
+        FI_REQUIRE(x[i] && dy[i] && dweight[i], "null pointer in the batch");
+        ok = ok && wgrad_batchable(g, x[i], dy[i], weight_layout);
+        const bool has = dbias && dbias[i];
+        any_db = any_db || has;
+        all_db = all_db && has;
+    }
+    // one launch only for the row-major kernel, with the outputs pre-zeroed by the caller and uniform bias use;
+    // anything else: one launch per problem (same results)
+    if (!ok || n == 1 || !(flags & FI_OUTPUTS_ZEROED) || (any_db && !all_db)) {
+        for (int i = 0; i < n; ++i) {
+            rc = wgrad_impl(x[i], dy[i], dweight[i], N, Cin, H, W, Cout, R, S, stride_h, stride_w, pad_h, pad_w,
+                            weight_layout, dbias ? dbias[i] : nullptr, flags, stream, nullptr);
+            if (rc != FI_OK) return rc;
+        }
+        return FI_OK;
+    }
+    for (int i0 = 0; i0 < n; i0 += kWgBatchMax) {
+        WgradBatch wb;
+        wb.n = n - i0 < kWgBatchMax ? n - i0 : kWgBatchMax;
+        for (int i = 0; i < kWgBatchMax; ++i) {
+            const int j = i0 + (i < wb.n ? i : 0);
+            wb.x[i] = x[j]; wb.dy[i] = dy[j]; wb.dw[i] = dweight[j]; wb.db[i] = all_db ? dbias[j] : nullptr;
+        }
+        rc = wgrad_impl(wb.x[0], wb.dy[0], wb.dw[0], N, Cin, H, W, Cout, R, S, stride_h, stride_w, pad_h, pad_w,
+                        weight_layout, wb.db[0], flags, stream, &wb);
+        if (rc != FI_OK) return rc;
+    }
+    return FI_OK;
+}
+
+static int wgrad_impl(const float *x, const float *dy, float *dweight, int N, int Cin, int H,
+                      int W, int Cout, int R, int S, int stride_h, int stride_w, int pad_h,
+                      int pad_w, int weight_layout, float *dbias, int flags, fi_stream_t stream, const WgradBatch *batch)
 {
     ConvGeom g;
     int rc = make_geom(g, N, Cin, H, W, Cout, R, S, stride_h, stride_w, pad_h, pad_w);
@@ -2390,13 +2480,16 @@ int fi_conv2d_weight_grad(const float *x, const float *dy, float *dweight, int N
     static const int force_bm = getenv("FI_WG_BM") ? atoi(getenv("FI_WG_BM")) : 0;
     const long max_splits0 = (g.P + min_pix - 1) / min_pix;
     const long tiles128 = (long)fi::ceil_div(g.K, BN) * fi::ceil_div(Cout, 128);
-    const long reach128 = tiles128 * (1024 / tiles128 < max_splits0 ? (1024 / tiles128 < 1 ? 1 : 1024 / tiles128) : max_splits0);
+    const long reach128 = (batch ? batch->n : 1) * tiles128 * (1024 / tiles128 < max_splits0 ? (1024 / tiles128 < 1 ? 1 : 1024 / tiles128) : max_splits0);
     const int BMsel = force_bm ? (Cout <= 64 ? 64 : force_bm) : ((Cout <= 64 || reach128 < 768) ? 64 : 128);
     const long tiles = (long)fi::ceil_div(g.K, BN) * fi::ceil_div(Cout, BMsel);
     // Split the pixel range so that tiles x splits fills the 1024 resident workgroup slots (256 CUs x 4)
     // in ONE round: every workgroup has the same amount of work, so 1044 workgroups on 1024 slots take
     // two rounds (the first version rounded UP and paid exactly that).  At least 512 pixels per split.
-    long want = 1024 / tiles;
+    // (a batch of nb problems fills the slots together: fewer, longer pixel splits per problem -- the fixed cost of a
+    // workgroup, prologue and atomic epilogue, is paid per split)
+    const int nb = batch ? batch->n : 1;
+    long want = 1024 / (tiles * nb);
     long max_splits = (g.P + min_pix - 1) / min_pix;
     int splits = (int)(want < 1 ? 1 : (want > max_splits ? max_splits : want));
     if (splits < 1) splits = 1;
@@ -2405,9 +2498,9 @@ int fi_conv2d_weight_grad(const float *x, const float *dy, float *dweight, int N
     splits = fi::ceil_div(g.P, pps);
     fi::ProfScope prof(FI_K_CONV_WGRAD + (BMsel == 64 ? 0 : 4) + window_class(R, S), st);
     if (BMsel == 64)
-        launch_wgrad<64>(g, x, dy, dweight, splits, pps, hwc, dbias, st);
+        launch_wgrad<64>(g, x, dy, dweight, splits, pps, hwc, dbias, st, batch);
     else
-        launch_wgrad<128>(g, x, dy, dweight, splits, pps, hwc, dbias, st);
+        launch_wgrad<128>(g, x, dy, dweight, splits, pps, hwc, dbias, st, batch);
     FI_HIP_CHECK(hipGetLastError());
     return FI_OK;
 }

@@ -232,6 +232,8 @@ class GradientBuckets(object):
             piece = buf[b.start:b.end]
             if self.use_stream:
                 self.comm_stream.wait_stream(torch.cuda.current_stream(self.device))
+                from .conv import flush_deferred_wgrads
+                flush_deferred_wgrads()                    # queued (batched) weight gradients of this bucket's layers
                 wg = conv_wgrad_stream(self.device)        # weight gradients of small layers run on their own stream
                 if wg is not None:
                     self.comm_stream.wait_stream(wg)

@@ -350,6 +350,18 @@ int fi_conv2d_weight_grad(const float *x, const float *dy, float *dweight, int N
                           int H, int W, int Cout, int R, int S, int stride_h, int stride_w,
                           int pad_h, int pad_w, int weight_layout, float *dbias, int flags,
                           fi_stream_t stream);
+/* n weight gradients of ONE geometry (the identical residual blocks of a ResNet stage: 23 in C4 of ResNet-101,
+ * lib/sub_module.py:103-116) in one launch: x[i], dy[i], dweight[i], dbias[i] (dbias NULL, or one pointer per problem)
+ * are HOST arrays of device pointers.  A layer of the C4 stage at batch 4 is a single round of short workgroups whose
+ * fixed cost (prologue, atomic epilogue) is a third of its time; n layers together take fewer, longer pixel splits
+ * per layer.  Same sums as n calls of fi_conv2d_weight_grad (fp32 atomics: the order of the partial sums differs).
+ * One launch needs FI_OUTPUTS_ZEROED, tap-major / 1x1 weights with Cin % 128 == 0 and a same-size stride-1 layer;
+ * otherwise the call loops over the problems.  At most FI_WGRAD_BATCH_MAX problems travel in one launch. */
+#define FI_WGRAD_BATCH_MAX 24
+int fi_conv2d_weight_grad_batch(const float *const *x, const float *const *dy, float *const *dweight,
+                                float *const *dbias, int n, int N, int Cin, int H, int W, int Cout, int R, int S,
+                                int stride_h, int stride_w, int pad_h, int pad_w, int weight_layout, int flags,
+                                fi_stream_t stream);
 /* Fully connected layers (the heads' full-window 7x7 "fc" convolutions lib/sub_module.py:707, :333, their nn.Linear
  * layers :744-747, the OT module's centre-tap Conv1d lib/OT_module.py:37-41):
  *     c [M,N] = act(a [M,K] . b [N,K]^T + bias [N])        (torch: F.linear; the reference: cuBLAS through torch)

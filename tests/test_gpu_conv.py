@@ -688,3 +688,44 @@ def test_class_row_conv1x1_matches_the_dense_backward(N, C, K, hw, gated):
     assert float((out.detach().cpu().double() - ref.detach()).abs().max()) <= 1e-4 * float(ref.abs().max())
     for name, got, want in (("dx", x_leaf.grad, xd.grad), ("dw", w.grad, wd.grad), ("db", b.grad, bd.grad)):
         assert float((got.cpu().double() - want).abs().max()) <= 2e-5 * float(want.abs().max()) + 1e-9, name
+
+
+def test_weight_grad_batch_equals_separate_launches():
+    """fi_conv2d_weight_grad_batch (n problems of one geometry in ONE launch, operand pointers in the kernel arguments)
+    against n calls of fi_conv2d_weight_grad and against float64: the C4-stage shapes of ResNet-101 (1x1 256 -> 1024,
+    1x1 1024 -> 256, 3x3 256 -> 256 on 64 x 64 maps), with and without the bias sums, incl. a batch larger than
+    FI_WGRAD_BATCH_MAX and a geometry the one-launch path does not take (falls back to a loop)."""
+    import ctypes
+    from feature_intertwiner_amd import _lib
+    L = _lib.load()
+    torch.manual_seed(3)
+    cases = [(2, 256, 16, 16, 512, 1, 5, True), (2, 512, 16, 16, 128, 1, 3, False), (2, 128, 16, 16, 128, 3, 4, True),
+             (1, 128, 8, 8, 128, 3, 26, True), (2, 64, 16, 16, 64, 3, 3, False)]
+    for N, Cin, H, W, Cout, R, n, with_db in cases:
+        pad = R // 2
+        xs = [torch.randn(N, Cin, H, W, device=DEV) for _ in range(n)]
+        dys = [torch.randn(N, Cout, H, W, device=DEV) for _ in range(n)]
+        lay = 1 if Cin % 128 == 0 else 0
+        shape = (Cout, R, R, Cin) if lay else (Cout, Cin, R, R)
+        got = [torch.zeros(shape, device=DEV) for _ in range(n)]
+        gdb = [torch.zeros(Cout, device=DEV) for _ in range(n)]
+        arr = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])
+        _lib.check(L.fi_conv2d_weight_grad_batch(arr(xs), arr(dys), arr(got), arr(gdb) if with_db else None, n, N, Cin, H, W,
+                                                 Cout, R, R, 1, 1, pad, pad, lay, _lib.OUTPUTS_ZEROED,
+                                                 _lib.current_stream()), "batch")
+        for i in range(n):
+            one = torch.zeros(shape, device=DEV)
+            odb = torch.zeros(Cout, device=DEV)
+            _lib.check(L.fi_conv2d_weight_grad(_lib.ptr(xs[i]), _lib.ptr(dys[i]), _lib.ptr(one), N, Cin, H, W, Cout, R, R,
+                                               1, 1, pad, pad, lay, _lib.ptr(odb) if with_db else None,
+                                               _lib.OUTPUTS_ZEROED, _lib.current_stream()), "single")
+            ref = torch.nn.grad.conv2d_weight(xs[i].double(), (Cout, Cin, R, R), dys[i].double(), padding=pad)
+            g = got[i].permute(0, 3, 1, 2) if lay else got[i]
+            o = one.permute(0, 3, 1, 2) if lay else one
+            bar = 2e-5 * (N * H * W) ** 0.5 * float(ref.abs().max())
+            assert float((g.double() - ref).abs().max()) <= bar, (N, Cin, Cout, R, i)
+            assert float((g - o).abs().max()) <= bar
+            if with_db:
+                rdb = dys[i].double().sum((0, 2, 3))
+                assert float((gdb[i].double() - rdb).abs().max()) <= 2e-5 * (N * H * W) ** 0.5 * float(rdb.abs().max()) + 1e-4
+                assert float((gdb[i] - odb).abs().max()) <= 1e-3
