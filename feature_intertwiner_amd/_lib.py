@@ -93,6 +93,7 @@ SIGNATURES = {
     "fi_pyramid_patch_rows_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, ctypes.c_long, c_int, c_void_p]),
     "fi_rows_gather": (c_int, [c_void_p, c_void_p, c_void_p, ctypes.c_long, ctypes.c_long, c_void_p]),
     "fi_rows_scatter_add": (c_int, [c_void_p, c_void_p, c_void_p, ctypes.c_long, ctypes.c_long, c_void_p]),
+    "fi_rows_combine": (c_int, [c_void_p, ctypes.c_long, c_void_p, c_void_p, c_void_p, ctypes.c_long, ctypes.c_long, c_void_p]),
     "fi_maxpool3x3s2_forward": (c_int, [c_void_p, c_void_p, ctypes.c_long, c_int, c_int, c_void_p]),
     "fi_maxpool3x3s2_backward": (c_int, [c_void_p, c_void_p, c_void_p, ctypes.c_long, c_int, c_int, c_int, c_void_p]),
     "fi_sum2x2": (c_int, [c_void_p, c_void_p, ctypes.c_long, c_int, c_int, c_void_p]),

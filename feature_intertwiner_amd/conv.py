@@ -413,12 +413,28 @@ class _TakeRowsFn(torch.autograd.Function):
     def backward(ctx, dy):
         index, = ctx.saved_tensors
         base = _take_boxes(ctx.box)
+        dy = dy.contiguous()
+        if (base is None or (torch.is_tensor(base) and base.dim() == len(ctx.shape) and base.shape[0] < ctx.shape[0] and
+                             tuple(base.shape[1:]) == ctx.shape[1:] and base.is_contiguous() and
+                             base.dtype == torch.float32)) and \
+                dy.is_cuda and dy.dtype == torch.float32 and index.dtype == torch.int64 and 0 < ctx.shape[0] <= 65535 and \
+                dy[0].numel() % 4 == 0 and dy.data_ptr() % 16 == 0 and (base is None or base.data_ptr() % 16 == 0):
+            # the other reader took the FIRST rows of x as a view (the mask head's graph batch) or nothing at all: the
+            # whole gradient in one pass (fi_rows_combine)
+            rows = ctx.shape[0]
+            pos = torch.full((rows,), -1, device=dy.device, dtype=torch.int64)
+            pos[index] = torch.arange(index.numel(), device=dy.device, dtype=torch.int64)
+            out = torch.empty(ctx.shape, device=dy.device, dtype=torch.float32)
+            with torch.cuda.device(dy.device):
+                _lib.check(_lib.load().fi_rows_combine(_lib.ptr(base), 0 if base is None else base.shape[0], _lib.ptr(dy),
+                                                       _lib.ptr(pos), _lib.ptr(out), rows, dy[0].numel(),
+                                                       _lib.current_stream()), "fi_rows_combine")
+            return out, None, None
         if not (torch.is_tensor(base) and tuple(base.shape) == ctx.shape and base.is_contiguous() and
                 base.dtype == dy.dtype):
             extra, base = base, torch.zeros(ctx.shape, device=dy.device, dtype=dy.dtype)
             if torch.is_tensor(extra):
-                base += extra
-        dy = dy.contiguous()
+                base[:extra.shape[0]] += extra
         if _TakeRowsFn._fast(base, index) and dy.dtype == torch.float32 and dy.data_ptr() % 16 == 0:
             # the index is a prefix of a permutation (distinct rows): plain read-modify-write
             with torch.cuda.device(dy.device):

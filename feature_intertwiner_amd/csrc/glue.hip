@@ -256,6 +256,28 @@ __global__ __launch_bounds__(256) void rows_scatter_add_kernel(const float *__re
     }
 }
 
+// dst[r] = (r < n_front ? front[r] : 0) + (src_row[r] >= 0 ? src[src_row[r]] : 0): the gradient of a [rows][row_len] tensor
+// with two readers -- one took its first n_front rows as a view, the other a set of distinct rows -- written once.
+__global__ __launch_bounds__(256) void rows_combine_kernel(const float *__restrict__ front, long n_front,
+                                                           const float *__restrict__ src, const long *__restrict__ src_row,
+                                                           float *__restrict__ dst, long row_len4)
+{
+    const long row = blockIdx.y;
+    const long sr = src_row[row];
+    const float4 *__restrict__ f4 = reinterpret_cast<const float4 *>(front) + row * row_len4;
+    const float4 *__restrict__ s4 = reinterpret_cast<const float4 *>(src) + (sr >= 0 ? sr : 0) * row_len4;
+    float4 *__restrict__ d4 = reinterpret_cast<float4 *>(dst) + row * row_len4;
+    const bool hf = row < n_front, hs = sr >= 0;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < row_len4; i += (long)gridDim.x * 256) {
+        float4 a = hf ? f4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (hs) {
+            const float4 b = s4[i];
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        }
+        d4[i] = a;
+    }
+}
+
 // Backward of a 1x1 convolution whose output gradient has ONE non-zero channel per image row: dy[n][cls[n]][p] = d[n][p],
 // zero elsewhere (the mask head's conv5 under the mask loss, lib/layers.py:905-934: only the target class's mask of a
 // RoI enters the loss).  The dense kernels would multiply 80 of 81 channels of zeros:
@@ -609,6 +631,22 @@ int fi_rows_scatter_add(const float *src, const int64_t *index, float *dst, long
     const long per = std::min<long>(std::max<long>((row_len / 4 + 1023) / 1024, 1), 64);
     hipLaunchKernelGGL(rows_scatter_add_kernel, dim3((unsigned)per, (unsigned)n_index), dim3(256), 0, (hipStream_t)stream,
                        src, reinterpret_cast<const long *>(index), dst, row_len / 4);
+    FI_HIP_CHECK(hipGetLastError());
+    return FI_OK;
+}
+
+int fi_rows_combine(const float *front, long n_front, const float *src, const int64_t *src_row, float *dst, long rows,
+                    long row_len, fi_stream_t stream)
+{
+    FI_REQUIRE(rows >= 0 && n_front >= 0 && n_front <= rows && row_len >= 4 && row_len % 4 == 0,
+               "row_len must be a positive multiple of 4, n_front <= rows");
+    if (rows == 0) return FI_OK;
+    FI_REQUIRE(src_row && dst && (front || n_front == 0), "null pointer");
+    FI_REQUIRE((uintptr_t)dst % 16 == 0 && (uintptr_t)src % 16 == 0 && (uintptr_t)front % 16 == 0 && rows <= 65535,
+               "16-byte aligned tensors, <= 65535 rows");
+    const long per = std::min<long>(std::max<long>((row_len / 4 + 1023) / 1024, 1), 64);
+    hipLaunchKernelGGL(rows_combine_kernel, dim3((unsigned)per, (unsigned)rows), dim3(256), 0, (hipStream_t)stream, front,
+                       n_front, src, reinterpret_cast<const long *>(src_row), dst, row_len / 4);
     FI_HIP_CHECK(hipGetLastError());
     return FI_OK;
 }

@@ -13,6 +13,8 @@ import os as _os
 _DEAD_SIDE = _os.environ.get('FI_DEAD_SIDE', '1') != '0'
 # the proposal layer on the second stream, under the Dev stage's make-up convolutions (A/B switch)
 _PROPOSAL_SIDE = _os.environ.get('FI_PROPOSAL_SIDE', '1') != '0'
+# the 14 x 14 crops come back with the positive RoI slots first: the mask head's two batches are views (A/B switch)
+_MASK_FRONT = _os.environ.get('FI_MASK_FRONT', '1') != '0'
 from ._lib import const_tensor
 from .conv import conv_precision, prepare_step, set_conv_precision
 from .intertwiner import FeatureBuffer, meta_loss
@@ -127,7 +129,12 @@ class MaskRCNN(nn.Module):
         # the other slots without one (their outputs are computed, as the reference does, and their gradient is zero)
         split_mask = images.is_cuda and torch.is_grad_enabled() and _conv.GATES and \
             not cfg.MRCNN.MASK_HEAD_ON_POSITIVE_SLOTS
-        mask_box = None if (split_mask or cfg.MRCNN.MASK_HEAD_ON_POSITIVE_SLOTS or not chain) else _conv.GradBox()
+        P_front = int(cfg.ROIS.TRAIN_ROIS_PER_IMAGE * cfg.ROIS.ROI_POSITIVE_RATIO)
+        # with the split, the Dev stage returns the 14 x 14 crops with the positive slots first (Dev.forward(mask_front)):
+        # both batches are views, and the graph batch's input gradient (the first rows) goes through the box as well
+        front = P_front if (split_mask and chain and _MASK_FRONT and 0 < P_front < cfg.ROIS.TRAIN_ROIS_PER_IMAGE) else None
+        mask_box = None if ((split_mask and not front) or cfg.MRCNN.MASK_HEAD_ON_POSITIVE_SLOTS or not chain) \
+            else _conv.GradBox()
         # The RPN losses read RPN.TRAIN_ANCHORS_PER_IMAGE sampled anchors per image: with conv.GATES the dense RPN runs
         # without a graph (the proposal layer needs every anchor) and the losses' graph is RPN.forward_rows on those rows
         rows = images.is_cuda and torch.is_grad_enabled() and _conv.GATES and self.rpn.anchor_stride == 1
@@ -180,7 +187,7 @@ class MaskRCNN(nn.Module):
         pooled_cls, pooled_mask, feat_out = self.dev_roi(mrcnn_maps, rois, target_class_ids, up_maps=up_maps,
                                                          level_info=(roi_lvl, counts_ready),
                                                          raw_grad_boxes=to_make_up if chain else None,
-                                                         mask_grad_box=mask_box)
+                                                         mask_grad_box=mask_box, mask_front=front)
         # the statistics the meta loss reads are complete here: workflow.compute_loss evaluates it on another stream from
         # this point on, next to the box and mask heads (its ~70 small kernels and the Sinkhorn launch are latency bound)
         self._stats_ready = None
@@ -209,10 +216,10 @@ class MaskRCNN(nn.Module):
             # gradient is not identically zero.
             P = int(cfg.ROIS.TRAIN_ROIS_PER_IMAGE * cfg.ROIS.ROI_POSITIVE_RATIO)
             R = rois.size(1)
-            per_image = pooled_mask.view(bs, R, *pooled_mask.shape[1:])
+            per_image = pooled_mask.view(bs, R, *pooled_mask.shape[1:]) if not front else None
             if split_mask and P < R:
                 with torch.no_grad():
-                    rest = per_image[:, P:].reshape(bs * (R - P), *pooled_mask.shape[1:])
+                    rest = pooled_mask[bs * P:] if front else per_image[:, P:].reshape(bs * (R - P), *pooled_mask.shape[1:])
                     if _DEAD_SIDE:
                         # nothing reads these masks: the batch runs on the second stream next to the rest of the step
                         # and is joined before the optimiser touches the weights (workflow.train_step: join_side_work)
@@ -221,7 +228,7 @@ class MaskRCNN(nn.Module):
                         rest.record_stream(_lib.side_stream(rest.device))
                     else:
                         self.mask(rest, shuffled=False, activate=False)
-            pooled_mask = per_image[:, :P].reshape(bs * P, *pooled_mask.shape[1:])
+            pooled_mask = pooled_mask[:bs * P] if front else per_image[:, :P].reshape(bs * P, *pooled_mask.shape[1:])
             mask_ids, mask_tgt = target_class_ids[:, :P], target_mask[:, :P]
         # logits of every RoI's TARGET class [bs*R', 2, 2, 14, 14] (all K classes are evaluated; see Mask.forward), or of
         # all classes [bs*R', 2, 2, K, 14, 14] on a CPU tensor / with conv.GATES off

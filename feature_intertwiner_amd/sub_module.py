@@ -505,7 +505,23 @@ class Dev(nn.Module):
         counts_ready = _lib.async_host_read(per_level) if level.is_cuda else (lambda: per_level)
         return level, counts_ready
 
-    def forward(self, x, rois, roi_cls_gt=None, up_maps=None, level_info=None, raw_grad_boxes=None, mask_grad_box=None):
+    _PERM = {}
+
+    @classmethod
+    def _front_permutation(cls, bs, R, P, device):
+        """(perm, inv): RoI slots (b, s < P) of every image first -- in (b, s) order --, then the others; inv[perm[j]] = j."""
+        key = (bs, R, P, str(device))
+        t = cls._PERM.get(key)
+        if t is None:
+            slot = torch.arange(bs * R).view(bs, R)
+            perm = torch.cat((slot[:, :P].reshape(-1), slot[:, P:].reshape(-1)))
+            inv = torch.empty_like(perm)
+            inv[perm] = torch.arange(bs * R)
+            t = cls._PERM[key] = (perm.to(device), inv.to(device))
+        return t
+
+    def forward(self, x, rois, roi_cls_gt=None, up_maps=None, level_info=None, raw_grad_boxes=None, mask_grad_box=None,
+                mask_front=None):
         """raw_grad_boxes: per level, the GradBox make_up_maps(take_from=...) takes from -- the big-box crop of the RAW
         level maps leaves its map gradients there.  mask_grad_box: the mask head (the second reader of the 14 x 14
         crops, applied after this stage) leaves its input gradient there; the row gather in front of the feature
@@ -515,6 +531,10 @@ class Dev(nn.Module):
         boxes = rois.reshape(-1, 4)
         box_ind = torch.arange(bs, device=rois.device, dtype=torch.int32).repeat_interleave(R)
         level, counts_ready = level_info if level_info is not None else self.level_info(rois)
+        # mask_front = P: the 14 x 14 crops are RETURNED with the RoI slots s < P of every image first (rows b*P + s), the
+        # other slots behind them: the mask head's two batches (MaskRCNN.forward) are then two contiguous views of the
+        # crop tensor instead of two strided copies of it (and of a zero-filled, copied gradient on the way back)
+        front = mask_front if (mask_front and self.use_dev and 0 < mask_front < R and rois.is_cuda) else None
 
         if not self.use_dev:
             pooled = self._crop(x, boxes, box_ind, level, self.pool_size)
@@ -530,7 +550,12 @@ class Dev(nn.Module):
         n2, n3, n4, n5 = (int(v) for v in counts_ready().tolist())
         group = CropGradGroup()      # both crops' gradients accumulate in ONE set of buffers (no add pass per level)
         pooled = self._crop(up_maps, boxes, box_ind, level, self.pool_size, group)
-        mask_and_feat = self._crop(up_maps, boxes, box_ind, level, self.mask_pool_size, group)
+        if front:
+            perm, inv = self._front_permutation(bs, R, front, rois.device)
+            mask_and_feat = self._crop(up_maps, boxes[perm], box_ind[perm], level[perm], self.mask_pool_size, group)
+        else:
+            inv = None
+            mask_and_feat = self._crop(up_maps, boxes, box_ind, level, self.mask_pool_size, group)
         if cfg.DEV.BASELINE:
             return pooled, mask_and_feat, []
 
@@ -545,7 +570,7 @@ class Dev(nn.Module):
         # or masked by level.
         n_rows = min((n_small + 63) // 64 * 64, total_box)
         order = torch.sort(level, stable=True)[1][:n_rows]
-        small_output = self._feat_extract(take_rows(mask_and_feat, order, mask_grad_box))
+        small_output = self._feat_extract(take_rows(mask_and_feat, order if inv is None else inv[order], mask_grad_box))
         if cfg.DEV.LOSS_CHOICE != 'ot':
             small_output = self.last_op(small_output)
         small_output = small_output.view(n_rows, -1)

@@ -307,6 +307,11 @@ int fi_pyramid_patch_rows_backward(const float *d, void *const *grads, const int
  * level-major order, lib/sub_module.py:583-598; the backward adds their gradients into the crops' gradient). */
 int fi_rows_gather(const float *src, const int64_t *index, float *dst, long n_index, long row_len, fi_stream_t stream);
 int fi_rows_scatter_add(const float *src, const int64_t *index, float *dst, long n_index, long row_len, fi_stream_t stream);
+/* dst[r][:] = (r < n_front ? front[r][:] : 0) + (src_row[r] >= 0 ? src[src_row[r]][:] : 0) for r < rows: the gradient of the
+ * 14 x 14 crops when the mask head read the first n_front rows (a view) and the feature extractor the gathered rows --
+ * one pass instead of fill + copy + scatter-add.  front may be NULL when n_front == 0. */
+int fi_rows_combine(const float *front, long n_front, const float *src, const int64_t *src_row, float *dst, long rows,
+                    long row_len, fi_stream_t stream);
 /* The stem's max-pooling (lib/sub_module.py:44-45: SamePad2d + MaxPool2d(3, 2) == 3 x 3 / stride 2 windows clipped at
  * the right / bottom border, i.e. ceil_mode): y [planes][OH][OW], OH = (height - 2) / 2 + 1.  Backward recomputes the
  * arg-max from x with the framework's first-maximum rule and adds the gradients of the (up to 4) windows that select

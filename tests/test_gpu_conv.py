@@ -729,3 +729,28 @@ def test_weight_grad_batch_equals_separate_launches():
                 rdb = dys[i].double().sum((0, 2, 3))
                 assert float((gdb[i].double() - rdb).abs().max()) <= 2e-5 * (N * H * W) ** 0.5 * float(rdb.abs().max()) + 1e-4
                 assert float((gdb[i] - odb).abs().max()) <= 1e-3
+
+
+def test_take_rows_with_a_front_block_in_the_box():
+    """conv.take_rows whose GradBox holds the gradient of the FIRST rows only (the mask head's graph batch reads the
+    14 x 14 crops [: bs * P] as a view, Dev.forward(mask_front)): one fi_rows_combine pass must equal zeros + front block +
+    index_add; also with an empty box."""
+    from feature_intertwiner_amd import conv as C
+    torch.manual_seed(0)
+    x = torch.randn(40, 8, 6, 6, device=DEV)
+    idx = torch.randperm(40, device=DEV)[:24]
+    gy = torch.randn(24, 8, 6, 6, device=DEV)
+    front = torch.randn(16, 8, 6, 6, device=DEV)
+    for with_front in (True, False):
+        xg = x.clone().requires_grad_(True)
+        box = C.GradBox()
+        y = C.take_rows(xg, idx, box)
+        assert torch.equal(y, x[idx])
+        if with_front:
+            box.value = front.clone()
+        y.backward(gy)
+        ref = torch.zeros_like(x)
+        if with_front:
+            ref[:16] = front
+        ref.index_add_(0, idx, gy)
+        assert torch.equal(xg.grad, ref)
