@@ -149,6 +149,42 @@ def north_star_roialign(dev):
     return out
 
 
+def configs4_slice(dev, steps=6, warmup=3):
+    """The single-GPU slice of BASELINE configs[4] (`python bench.py --config cfg5`: ResNet-101-FPN, 1333 x 800 padded to
+    1344^2, 2 images per GPU, 1000 RoIs per image + mask head, 16-bit MFMA convolutions) for a few steps after the
+    headline's timed region, so that the driver's record carries a number for it."""
+    from feature_intertwiner_amd import conv as ficonv
+    from feature_intertwiner_amd.config import make_config
+    from feature_intertwiner_amd.model import MaskRCNN
+    from feature_intertwiner_amd.synthetic import SyntheticProposals, synthetic_batch
+    from feature_intertwiner_amd.workflow import set_optimizer, train_step
+    torch.manual_seed(2000)
+    cfg = make_config("resnet101", 1344, 2, 1000, dev_switch=True, loss_choice="ot", ot_L=50, conv_precision="bf16")
+    model = MaskRCNN(cfg).to(dev)
+    opt = set_optimizer(model, cfg.TRAIN)
+    batch = synthetic_batch(2, 1344, device=dev, seed=2000)
+    model.external_proposals = SyntheticProposals(batch[2], 1344, seed=7)
+    model.generator = torch.Generator(device=dev).manual_seed(11)
+    for _ in range(warmup):
+        terms = train_step(model, opt, list(batch))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        terms = train_step(model, opt, list(batch))
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    out = {"workload": "single-GPU slice of BASELINE configs[4]: resnet101-FPN, 1344x1344 (1333x800 padded, SURVEY Q8), "
+                       "2 images/GPU, 1000 RoIs/image + mask head, OT intertwiner on, full train step",
+           "dtype": "bf16 conv operands, fp32 accumulation, fp32 elsewhere", "steps": steps, "warmup": warmup,
+           "ms_per_step": round(ms, 3), "value": round(2 * 1e3 / ms, 4), "unit": "images/sec",
+           "finite_losses": bool(all(torch.isfinite(v) for v in terms.values())),
+           "command": "python bench.py --config cfg5 (its own roofline / conv_stack objects: profiles/)"}
+    del model, opt, batch
+    ficonv.invalidate_step_state()
+    torch.cuda.empty_cache()
+    return out
+
+
 def pmc_traffic(kernel_substrings, extra_args, timeout_s=170):
     """HBM-side bytes per launch of the named kernels from rocprofv3's FETCH_SIZE / WRITE_SIZE, collected as
     MI355X_MICROARCH.md prescribes: each counter in its OWN `--pmc` pass (with --kernel-trace only), values in
@@ -624,6 +660,14 @@ def _main():
                                   "max|g - g_dense| / max|g_dense|"}
         step()                                  # plans / W^T tables back in the default form
         torch.cuda.synchronize()
+    # ---- BASELINE configs[4], single-GPU slice, on the driver's record too (outside the timed region) -----------------
+    cfg4_slice = None
+    if world == 1 and args.config == "cfg3" and not args.no_dense_reference and not args.dense_backward and \
+            args.conv_precision == "fp32":
+        try:
+            cfg4_slice = configs4_slice(dev)
+        except Exception as ex:          # never takes the headline down
+            cfg4_slice = {"error": repr(ex)}
     per_rank_ms, rccl_ranks, overlap = None, None, None
     if sync is not None and not share:
         # a further pass with HIP events around every bucket's collective: how much of the exchange hides in backward
@@ -847,6 +891,7 @@ def _main():
             "losses": {k: round(float(v), 5) for k, v in terms.items()},
             "dense_backward_reference": dense_ref,
             "backward_check": backward_check,
+            "configs4_slice": cfg4_slice,
             "roofline": roof, "roofline_roialign": roof_roi, "conv_stack": conv_stack, "nms": nms_obj, "sinkhorn": sk_obj,
             "timing": {"timed_region": "%d steps, no event recording / logging" % args.steps,
                        "profiled_pass": "%d further steps with HIP-event timing of every library kernel, weight gradients "

@@ -214,11 +214,10 @@ def detection_layer(rois, probs, deltas, windows, config, feature=None):
 # --------------------------------------------------------------------------------------
 # RPN targets (lib/layers.py:439-658), batched
 # --------------------------------------------------------------------------------------
-def _random_subset(mask, limit, kmax, generator=None):
-    """Keep at most limit[b] of the True entries of mask [b, n], uniformly at random.
-    limit: python int or int tensor [b]; kmax: static upper bound of limit."""
+def _random_subset(mask, limit, kmax, key):
+    """Keep at most limit[b] of the True entries of mask [b, n], uniformly at random: the entries with the largest
+    `key` [b, n] (uniform in [1, 2)).  limit: python int or int tensor [b]; kmax: static upper bound of limit."""
     b, n = mask.shape
-    key = torch.rand(mask.shape, device=mask.device, generator=generator) + 1.0
     key = torch.where(mask, key, torch.zeros_like(key))
     k = min(n, int(kmax))
     top, idx = torch.topk(key, k, dim=1, sorted=True)
@@ -229,14 +228,66 @@ def _random_subset(mask, limit, kmax, generator=None):
     return out
 
 
+import os as _os
+# CUDA: fi_rpn_targets / fi_detection_targets (csrc/targets.hip); False: the tensor formulation (A/B switch)
+TARGET_KERNELS = _os.environ.get('FI_TARGET_KERNELS', '1') != '0'
+
+
 def prepare_rpn_target(anchors, gt_class_ids, gt_boxes, config, generator=None):
     """anchors [A,4] pixels; gt_class_ids [b,G] (0 = padding, <0 = crowd); gt_boxes [b,G,4]
     pixels.  Returns target_rpn_match [b,A] in {1,-1,0} and target_rpn_deltas [b,A,4] (the
     refinement of every anchor towards its best GT, already divided by BBOX_STD_DEV; only
     rows with match == 1 are used).  The reference packs the positives' deltas into
     [b, 256, 4] in anchor order (:599-604) and the loss re-aligns them (:854-861); keeping
-    them per anchor is the same pairing without the packing."""
+    them per anchor is the same pairing without the packing.
+    The random sub-samples are drawn as one uniform key per anchor (positives first, then negatives: two draws from
+    `generator`); which anchors are kept is a function of the keys (rpn_target_from_keys)."""
     anchors = anchors.to(gt_boxes.device)
+    b, A = gt_class_ids.size(0), anchors.size(0)
+    key_pos = torch.rand((b, A), device=gt_boxes.device, generator=generator) + 1.0
+    key_neg = torch.rand((b, A), device=gt_boxes.device, generator=generator) + 1.0
+    return rpn_target_from_keys(anchors, gt_class_ids, gt_boxes, config, key_pos, key_neg)
+
+
+def rpn_target_from_keys(anchors, gt_class_ids, gt_boxes, config, key_pos, key_neg, kernels=None):
+    """prepare_rpn_target given the sampling keys.  CUDA: two kernels (fi_rpn_targets) instead of ~140 framework
+    launches; the tensor formulation below is the CPU path and the kernels' test reference (same results bit for bit
+    when no two candidate keys tie at a selection boundary)."""
+    use = TARGET_KERNELS if kernels is None else kernels
+    G = gt_class_ids.size(1)
+    if use and gt_boxes.is_cuda and G <= 256 and 2 <= config.RPN.TRAIN_ANCHORS_PER_IMAGE <= 4096:
+        return _rpn_target_kernels(anchors, gt_class_ids, gt_boxes, config, key_pos, key_neg)
+    return _rpn_target_tensors(anchors, gt_class_ids, gt_boxes, config, key_pos, key_neg)
+
+
+def _rpn_target_kernels(anchors, gt_class_ids, gt_boxes, config, key_pos, key_neg):
+    import ctypes
+    from . import _lib
+    L = _lib.load()
+    dev = gt_boxes.device
+    b, G = gt_class_ids.shape
+    A = anchors.size(0)
+    n_total = int(config.RPN.TRAIN_ANCHORS_PER_IMAGE)
+    anchors = anchors.contiguous().float()
+    ids = gt_class_ids.to(torch.int64).contiguous()
+    boxes = gt_boxes.contiguous().float()
+    match = torch.empty((b, A), device=dev, dtype=torch.float32)
+    deltas = torch.empty((b, A, 4), device=dev, dtype=torch.float32)
+    row_image = torch.empty((b * n_total,), device=dev, dtype=torch.int64)
+    row_anchor = torch.empty((b * n_total,), device=dev, dtype=torch.int64)
+    ws = torch.empty((int(L.fi_rpn_targets_workspace_bytes(b, A, G)) + 3) // 4, device=dev, dtype=torch.float32)
+    std = (ctypes.c_float * 4)(*[float(v) for v in config.DATA.BBOX_STD_DEV])
+    with torch.cuda.device(dev):
+        _lib.check(L.fi_rpn_targets(_lib.ptr(anchors), _lib.ptr(ids), _lib.ptr(boxes), _lib.ptr(key_pos.contiguous()),
+                                    _lib.ptr(key_neg.contiguous()), b, A, G, float(config.RPN.TARGET_NEG_THRES),
+                                    float(config.RPN.TARGET_POS_THRES), n_total, std, _lib.ptr(match), _lib.ptr(deltas),
+                                    _lib.ptr(row_image), _lib.ptr(row_anchor), _lib.ptr(ws), _lib.current_stream()),
+                   "fi_rpn_targets")
+    match._fi_rows = (n_total, row_image, row_anchor)        # select_rpn_rows: the kernel has listed them already
+    return match, deltas
+
+
+def _rpn_target_tensors(anchors, gt_class_ids, gt_boxes, config, key_pos, key_neg):
     b, G = gt_class_ids.shape
     A = anchors.size(0)
     valid_gt = gt_class_ids > 0
@@ -259,9 +310,9 @@ def prepare_rpn_target(anchors, gt_class_ids, gt_boxes, config, generator=None):
     match = torch.where(iou_max >= config.RPN.TARGET_POS_THRES, torch.ones_like(match), match)
     # balance: at most half positives, negatives fill the rest (:512-548)
     n_total = config.RPN.TRAIN_ANCHORS_PER_IMAGE
-    pos = _random_subset(match == 1, n_total // 2, n_total // 2, generator)
+    pos = _random_subset(match == 1, n_total // 2, n_total // 2, key_pos)
     n_pos = pos.sum(1)
-    neg = _random_subset(match == -1, (n_total - n_pos).clamp(min=0), n_total, generator)
+    neg = _random_subset(match == -1, (n_total - n_pos).clamp(min=0), n_total, key_neg)
     match = pos.float() - neg.float()
     gt_for_anchor = torch.gather(gt_boxes, 1, iou_argmax.unsqueeze(2).expand(-1, -1, 4))
     deltas = box_refinement(anchors.unsqueeze(0).expand(b, -1, -1), gt_for_anchor)
@@ -277,12 +328,51 @@ def prepare_det_target(proposals, num_proposals, gt_class_ids, gt_boxes, gt_mask
     """proposals [b,P,4] normalised (zero rows past num_proposals[b]); gt_* zero padded,
     gt_boxes normalised, gt_masks [b,G,56,56] mini-masks.
     Returns rois [b,R,4], target_class_ids [b,R] int32, target_deltas [b,R,4],
-    target_mask [b,R,28,28] -- positives first, then negatives, then zero padding."""
+    target_mask [b,R,28,28] -- positives first, then negatives, then zero padding.
+    The two random rankings are one uniform key per proposal each (positives, then negatives: two draws from
+    `generator`); see det_target_from_keys."""
+    b, P, _ = proposals.shape
+    key_pos = torch.rand((b, P), device=proposals.device, generator=generator) + 1.0
+    key_neg = torch.rand((b, P), device=proposals.device, generator=generator) + 1.0
+    return det_target_from_keys(proposals, num_proposals, gt_class_ids, gt_boxes, gt_masks, config, key_pos, key_neg)
+
+
+def det_target_from_keys(proposals, num_proposals, gt_class_ids, gt_boxes, gt_masks, config, key_pos, key_neg, kernels=None):
+    """prepare_det_target given the ranking keys.  CUDA: one kernel (fi_detection_targets: IoU, ranking by an LDS sort,
+    slots, class ids, refinements, mask-crop boxes) + the mask-target crop, instead of ~130 framework launches."""
     b, P, _ = proposals.shape
     G = gt_class_ids.size(1)
     dev = proposals.device
     R = config.ROIS.TRAIN_ROIS_PER_IMAGE
     mh, mw = config.MRCNN.MASK_SHAPE
+    use = TARGET_KERNELS if kernels is None else kernels
+    pos_cap = int(R * config.ROIS.ROI_POSITIVE_RATIO)
+    ratio = 1.0 / config.ROIS.ROI_POSITIVE_RATIO
+    if use and proposals.is_cuda and P <= 2048 and G <= 256:
+        import ctypes
+        from . import _lib
+        L = _lib.load()
+        rois = torch.empty((b, R, 4), device=dev, dtype=torch.float32)
+        target_class_ids = torch.empty((b, R), device=dev, dtype=torch.int32)
+        target_deltas = torch.empty((b, R, 4), device=dev, dtype=torch.float32)
+        boxes = torch.empty((b, R, 4), device=dev, dtype=torch.float32)
+        box_ids = torch.empty((b, R), device=dev, dtype=torch.int32)
+        is_pos_f = torch.empty((b, R), device=dev, dtype=torch.float32)
+        std = (ctypes.c_float * 4)(*[float(v) for v in config.DATA.BBOX_STD_DEV])
+        props = proposals.contiguous().float()
+        with torch.cuda.device(dev):
+            _lib.check(L.fi_detection_targets(_lib.ptr(props), _lib.ptr(num_proposals.to(torch.int64).contiguous()),
+                                              _lib.ptr(gt_class_ids.to(torch.int64).contiguous()),
+                                              _lib.ptr(gt_boxes.contiguous().float()), _lib.ptr(key_pos.contiguous()),
+                                              _lib.ptr(key_neg.contiguous()), b, P, G, R, pos_cap, ratio,
+                                              1 if config.MRCNN.USE_MINI_MASK else 0, std, _lib.ptr(rois),
+                                              _lib.ptr(target_class_ids), _lib.ptr(target_deltas), _lib.ptr(boxes),
+                                              _lib.ptr(box_ids), _lib.ptr(is_pos_f), _lib.current_stream()),
+                       "fi_detection_targets")
+        masks = CropAndResizeFunction(mh, mw)(gt_masks.reshape(b * G, 1, gt_masks.size(2), gt_masks.size(3)).float(),
+                                              boxes.reshape(-1, 4), box_ids.reshape(-1))
+        target_mask = torch.round(masks.view(b, R, mh, mw)) * is_pos_f.view(b, R, 1, 1)
+        return rois, target_class_ids, target_deltas, target_mask
     valid_prop = torch.arange(P, device=dev).unsqueeze(0) < num_proposals.unsqueeze(1)
     valid_gt = gt_class_ids > 0
     crowd = gt_class_ids < 0
@@ -293,19 +383,15 @@ def prepare_det_target(proposals, num_proposals, gt_class_ids, gt_boxes, gt_mask
     pos_bool = (roi_iou_max >= 0.5) & valid_prop
     neg_bool = (roi_iou_max < 0.5) & no_crowd & valid_prop
 
-    pos_cap = int(R * config.ROIS.ROI_POSITIVE_RATIO)
-    ratio = 1.0 / config.ROIS.ROI_POSITIVE_RATIO
-
-    def ranked(mask, k):
-        key = torch.rand(mask.shape, device=dev, generator=generator) + 1.0
+    def ranked(mask, k, key):
         key = torch.where(mask, key, torch.zeros_like(key))
         top, idx = torch.topk(key, min(k, P), dim=1, sorted=True)
         return idx, (top > 0).sum(1)
 
-    pos_idx, n_pos_avail = ranked(pos_bool, pos_cap)
+    pos_idx, n_pos_avail = ranked(pos_bool, pos_cap, key_pos)
     pos_cnt = n_pos_avail.clamp(max=pos_cap)
     neg_want = torch.floor(ratio * pos_cnt.double() - pos_cnt.double()).long()     # int(r*pos - pos)
-    neg_idx, n_neg_avail = ranked(neg_bool, R)
+    neg_idx, n_neg_avail = ranked(neg_bool, R, key_neg)
     neg_cnt = torch.minimum(neg_want, n_neg_avail).clamp(max=R)
     neg_cnt = torch.minimum(neg_cnt, (R - pos_cnt))
 
@@ -360,6 +446,9 @@ def select_rpn_rows(target_rpn_match, rows_per_image):
     anchor) order, padded with invalid rows -- prepare_rpn_target samples at most RPN.TRAIN_ANCHORS_PER_IMAGE of them
     per image, so the shape is static and nothing is read back."""
     b = target_rpn_match.size(0)
+    rows = getattr(target_rpn_match, "_fi_rows", None)
+    if rows is not None and rows[0] == rows_per_image:          # fi_rpn_targets listed them (per image, -1 padded)
+        return rows[1], rows[2], rows[1] >= 0
     sel = torch.nonzero_static(target_rpn_match != 0, size=b * rows_per_image, fill_value=-1)
     return sel[:, 0], sel[:, 1], sel[:, 0] >= 0
 

@@ -439,6 +439,35 @@ int fi_stride2_interleave_gated(const float *c00, const float *c01, const float 
                                 fi_stream_t stream);
 
 /* ------------------------------------------------------------------------
+ * Target generation of one training step.
+ * fi_rpn_targets: lib/layers.py:439-604 (generate_target) for a whole minibatch -- IoU of every anchor with the image's
+ * ground-truth boxes (gt_class_ids [batch][max_gt] int64: > 0 object, < 0 COCO crowd box, 0 padding; gt_boxes pixels),
+ * negatives IoU < neg_thres and not on a crowd box, positives IoU >= pos_thres plus every object's best anchor, at most
+ * n_total / 2 positives and negatives up to n_total, sub-sampled at random: key_pos / key_neg [batch][anchors] hold one
+ * uniform key in [1, 2) per anchor and "keep k at random" keeps the k largest keys (ties: lower anchor index).
+ * match [batch][anchors] in {1, -1, 0}; deltas [batch][anchors][4] = refinement of the kept positives towards their best
+ * object, divided by bbox_std_dev (HOST array of 4), zero elsewhere; row_image / row_anchor (optional, [batch][n_total]
+ * int64): the anchors with a non-zero match in anchor order, -1 padded per image.  Workspace:
+ * fi_rpn_targets_workspace_bytes.  max_gt <= 256.
+ * fi_detection_targets: lib/layers.py:224-376 (generate_roi) -- proposals [batch][n_proposals][4] normalised, the first
+ * num_proposals[b] (int64) of them real; positives IoU >= 0.5, negatives < 0.5 off crowd boxes; positive_cap =
+ * int(rois_per_image * ROI_POSITIVE_RATIO) positives in descending key order first, then
+ * min(floor(negatives_per_positive * pos - pos), available, rois_per_image - pos) negatives, then zero rows.  Outputs per
+ * slot: rois, target_class_ids (int32), target_deltas (/ bbox_std_dev), mask_boxes = the RoI in the assigned object's
+ * mini-mask frame (:301-322; the RoI itself when use_mini_mask == 0) and mask_box_ids = image * max_gt + object for the
+ * crop_and_resize launch that cuts the mask targets, is_positive (1 / 0).  n_proposals <= 2048. */
+size_t fi_rpn_targets_workspace_bytes(int batch, int anchors, int max_gt);
+int fi_rpn_targets(const float *anchors, const int64_t *gt_class_ids, const float *gt_boxes, const float *key_pos,
+                   const float *key_neg, int batch, int n_anchors, int max_gt, float neg_thres, float pos_thres,
+                   int n_total, const float *bbox_std_dev, float *match, float *deltas, int64_t *row_image,
+                   int64_t *row_anchor, void *workspace, fi_stream_t stream);
+int fi_detection_targets(const float *proposals, const int64_t *num_proposals, const int64_t *gt_class_ids,
+                         const float *gt_boxes, const float *key_pos, const float *key_neg, int batch, int n_proposals,
+                         int max_gt, int rois_per_image, int positive_cap, double negatives_per_positive, int use_mini_mask,
+                         const float *bbox_std_dev, float *rois, int32_t *target_class_ids, float *target_deltas,
+                         float *mask_boxes, int32_t *mask_box_ids, float *is_positive, fi_stream_t stream);
+
+/* ------------------------------------------------------------------------
  * bf16-input, fp32-accumulate variants (v_mfma_f32_32x32x16_bf16) for BASELINE configs[4]'s reduced-
  * precision conv path.  Same tensors as above (fp32 in memory, operands rounded to bf16 on their way into
  * LDS); selected by configuration, never by the fp32 headline.  fi_conv2d_forward_bf16 takes the
