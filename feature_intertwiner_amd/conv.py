@@ -600,10 +600,11 @@ def _conv_backward(ctx_needs, x, w, dz, stride, padding, want_db=False, add_to_d
             side.wait_event(dz_ready)                      # dz (and x) were complete on the main stream there
             x.record_stream(side)
             dz.record_stream(side)
-        if side is not None and WGRAD_BATCH > 1 and hwc and same and Cin % 128 == 0 and \
+        if flags and adopt and not bf16 and WGRAD_BATCH > 1 and hwc and same and Cin % 128 == 0 and \
                 N * dz.shape[2] * dz.shape[3] <= WGRAD_BATCH_MAX_PIXELS and _defer_wgrad(
                     (N, Cin, H, W, Cout, R, S, padding, want_db and db is not None),
-                    x, dz, dw, db if want_db else None, after_wgrad, bool(hwc and R * S > 1), dz_ready, main, side):
+                    x, dz, dw, db if want_db else None, after_wgrad, bool(hwc and R * S > 1), dz_ready,
+                    torch.cuda.current_stream(x.device), side):
             side = None                    # queued: launched with the other layers of its geometry (_flush_wgrads)
             deferred = True
         else:
@@ -702,7 +703,8 @@ def _defer_wgrad(key, x, dz, dw, db, after, tap_major, ev, main, side):
         except RuntimeError:
             return False
         q["armed"] = True
-    q["streams"][(id(main), id(side))] = (main, side)
+    if side is not None:
+        q["streams"][(id(main), id(side))] = (main, side)
     e = q["queues"].setdefault(key, {"items": [], "last": 0, "main": main, "side": side})
     # (an alias of dw: AccumulateGrad adopts a gradient only while nobody else holds the tensor it was handed -- a second
     # reference to that very object makes it clone the still-empty slot)
@@ -730,12 +732,13 @@ def _flush_wgrads(key):
     N, Cin, H, W, Cout, R, S, padding, has_db = key
     n = len(items)
     L = _lib.load()
-    side.wait_event(items[-1][6])          # the events were recorded on one stream, in order: the last covers all
     arr = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])
     xs, dzs, dws = [it[0] for it in items], [it[1] for it in items], [it[2] for it in items]
-    for t in xs + dzs:
-        t.record_stream(side)
-    with torch.cuda.device(xs[0].device), torch.cuda.stream(side):
+    if side is not None:                   # (None: no second stream for weight gradients -- launched where we are)
+        side.wait_event(items[-1][6])      # the events were recorded on one stream, in order: the last covers all
+        for t in xs + dzs:
+            t.record_stream(side)
+    with torch.cuda.device(xs[0].device), (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
         _log_flops("wgrad", Cout, R, S, 2.0 * n * N * H * W * Cout * Cin * R * S, N * H * W, Cin, batch=n)
         _lib.check(L.fi_conv2d_weight_grad_batch(arr(xs), arr(dzs), arr(dws),
                                                  arr([it[3] for it in items]) if has_db else None, n, N, Cin, H, W, Cout,

@@ -2493,6 +2493,21 @@ static int wgrad_impl(const float *x, const float *dy, float *dweight, int N, in
     long max_splits = (g.P + min_pix - 1) / min_pix;
     int splits = (int)(want < 1 ? 1 : (want > max_splits ? max_splits : want));
     if (splits < 1) splits = 1;
+    if (nb > 1) {
+        // a batch rarely fits ONE round exactly (12 layers x 36 tiles x 2 splits = 864 of 1024 slots): take the split
+        // count that minimises rounds x (pixels per split + the fixed cost of a workgroup, ~256 pixels' worth)
+        long best_cost = -1;
+        const long smax = max_splits < 64 ? max_splits : 64;
+        for (long sp = 1; sp <= smax; ++sp) {
+            const long total = tiles * nb * sp;
+            const long rounds = (total + 1023) / 1024;
+            const long cost = rounds * ((g.P + sp - 1) / sp + 256);
+            if (best_cost < 0 || cost < best_cost) {
+                best_cost = cost;
+                splits = (int)sp;
+            }
+        }
+    }
     int pps = fi::ceil_div(g.P, splits);
     pps = fi::ceil_div(pps, BK) * BK;
     splits = fi::ceil_div(g.P, pps);
