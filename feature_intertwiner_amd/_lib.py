@@ -62,6 +62,9 @@ SIGNATURES = {
     "fi_conv2d_forward": (c_int, [c_void_p] * 6 + [c_int] * 16 + [c_void_p]),
     "fi_bn_act_backward": (c_int, [c_void_p] * 6 + [c_int] * 4 + [c_void_p] * 5 + [c_int, c_int, c_void_p]),
     "fi_conv2d_weight_grad": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 12 + [c_void_p, c_int, c_void_p]),
+    "fi_detector_losses_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "fi_detector_losses": (c_int, [c_void_p] * 6 + [c_int, c_int] + [c_void_p] * 4 + [c_int, c_int] + [c_void_p] * 3 +
+                           [c_int, c_int, c_int] + [c_void_p] * 7 + [c_void_p]),
     "fi_rpn_targets_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "fi_rpn_targets": (c_int, [c_void_p] * 5 + [c_int, c_int, c_int, c_float, c_float, c_int, ctypes.POINTER(c_float)] +
                        [c_void_p] * 5 + [c_void_p]),

@@ -524,3 +524,62 @@ def compute_mrcnn_mask_loss(target_masks, target_class_ids, pred_masks):
     pred = torch.gather(pred_masks, 2, cls.view(b, R, 1, 1, 1).expand(-1, -1, 1, h, w)).squeeze(2)
     l = F.binary_cross_entropy(pred, target_masks, reduction='none')
     return (l * pos).sum() / (pos.sum() * h * w).clamp(min=1)
+
+
+# --------------------------------------------------------------------------------------
+# the five losses in one pass (csrc/losses.hip)
+# --------------------------------------------------------------------------------------
+LOSS_KERNEL = _os.environ.get('FI_LOSS_KERNEL', '1') != '0'      # A/B switch
+
+
+class _DetectorLossesFn(torch.autograd.Function):
+    """[rpn_class, rpn_bbox, mrcnn_class, mrcnn_bbox, mrcnn_mask] (fi_detector_losses): the kernel leaves every loss's
+    gradient with respect to its network output up to a factor 1 / count, so backward is one scaling per tensor."""
+
+    @staticmethod
+    def forward(ctx, row_logits, row_bbox, cls_logits, roi_bbox, mask_logits, rpn_match, rpn_deltas, row_image, row_anchor,
+                roi_cls, roi_deltas, mask_cls, mask_targets):
+        from . import _lib
+        L = _lib.load()
+        dev = cls_logits.device
+        c = lambda t: t.contiguous().float()
+        row_logits, row_bbox, cls_logits, roi_bbox, mask_logits = (c(row_logits), c(row_bbox), c(cls_logits), c(roi_bbox),
+                                                                   c(mask_logits))
+        Rr, N, K = row_logits.size(0), cls_logits.size(0), cls_logits.size(1)
+        Nm, h, w = mask_logits.size(0), mask_logits.size(-2), mask_logits.size(-1)
+        grads = [torch.empty_like(t) for t in (row_logits, row_bbox, cls_logits, roi_bbox, mask_logits)]
+        out = torch.empty(10, device=dev, dtype=torch.float32)
+        ws = torch.empty((int(L.fi_detector_losses_workspace_bytes(Rr, N, Nm)) + 3) // 4, device=dev, dtype=torch.float32)
+        with torch.cuda.device(dev):
+            _lib.check(L.fi_detector_losses(_lib.ptr(c(rpn_match)), _lib.ptr(c(rpn_deltas)),
+                                            _lib.ptr(row_image.to(torch.int64).contiguous()),
+                                            _lib.ptr(row_anchor.to(torch.int64).contiguous()), _lib.ptr(row_logits),
+                                            _lib.ptr(row_bbox), Rr, rpn_match.size(1),
+                                            _lib.ptr(roi_cls.to(torch.int32).contiguous()), _lib.ptr(cls_logits),
+                                            _lib.ptr(c(roi_deltas)), _lib.ptr(roi_bbox), N, K,
+                                            _lib.ptr(mask_cls.to(torch.int32).contiguous()), _lib.ptr(mask_logits),
+                                            _lib.ptr(c(mask_targets)), Nm, h, w, *[_lib.ptr(g) for g in grads],
+                                            _lib.ptr(out), _lib.ptr(ws), _lib.current_stream()), "fi_detector_losses")
+        ctx.save_for_backward(out, *grads)
+        return out[:5].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        out, g0, g1, g2, g3, g4 = ctx.saved_tensors
+        f = g.float() * out[5:]                                   # [5]
+        need = ctx.needs_input_grad
+        return tuple((G * f[k]) if need[k] else None for k, G in enumerate((g0, g1, g2, g3, g4))) + (None,) * 8
+
+
+def detector_losses(row_logits, row_bbox, r_img, r_anchor, target_rpn_match, target_rpn_deltas, class_logits, roi_bbox,
+                    target_class_ids, target_deltas, mask_logits, mask_ids, mask_targets):
+    """The five losses [5] of compute_rpn_losses_on_rows / compute_mrcnn_class_loss / compute_mrcnn_bbox_loss /
+    compute_mrcnn_mask_loss_selected in ONE kernel pass (CUDA; None when the inputs do not fit it).  class_logits
+    [b, R, K], roi_bbox [b, R, K, 4], mask_logits [b, P, 2, 2, h, w] (target-class channel), mask_targets [b, P, 2h, 2w]."""
+    if not (LOSS_KERNEL and class_logits.is_cuda and mask_logits.dim() == 6 and row_logits.dim() == 2):
+        return None
+    K = class_logits.size(-1)
+    return _DetectorLossesFn.apply(row_logits, row_bbox, class_logits.reshape(-1, K), roi_bbox.reshape(-1, K, 4),
+                                   mask_logits.reshape(-1, *mask_logits.shape[2:]), target_rpn_match, target_rpn_deltas,
+                                   r_img, r_anchor, target_class_ids.reshape(-1), target_deltas.reshape(-1, 4),
+                                   mask_ids.reshape(-1), mask_targets.reshape(-1, *mask_targets.shape[2:]))

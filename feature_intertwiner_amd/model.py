@@ -20,7 +20,7 @@ from .conv import conv_precision, prepare_step, set_conv_precision
 from .intertwiner import FeatureBuffer, meta_loss
 from .layers import (compute_mrcnn_bbox_loss, compute_mrcnn_class_loss, compute_mrcnn_mask_loss_selected,
                      compute_mrcnn_mask_loss_unshuffled,
-                     compute_rpn_bbox_loss, compute_rpn_class_loss, compute_rpn_losses_on_rows, detection_layer,
+                     compute_rpn_bbox_loss, compute_rpn_class_loss, compute_rpn_losses_on_rows, detection_layer, detector_losses,
                      generate_pyramid_priors, prepare_det_target, prepare_rpn_target, proposal_layer, select_rpn_rows)
 from .OT_module import OptTrans
 from .sub_module import FPN, RPN, Classifier, Dev, Mask, ResNet
@@ -238,6 +238,18 @@ class MaskRCNN(nn.Module):
         mrcnn_bbox = mrcnn_bbox.view(bs, -1, mrcnn_bbox.size(1), mrcnn_bbox.size(2))
         mask_u = mask_u.view(bs, -1, *mask_u.shape[1:])
 
+        fused = detector_losses(row_logits, row_bbox, r_img, r_anchor, target_rpn_match, target_rpn_deltas,
+                                mrcnn_class_logits, mrcnn_bbox, target_class_ids, target_deltas, mask_u, mask_ids,
+                                mask_tgt) if rows else None
+        if fused is not None:
+            big_done = getattr(self.dev_roi, "big_done", None)
+            if big_done is not None:
+                cur = torch.cuda.current_stream(images.device)
+                cur.wait_event(big_done)
+                for t in (big_feat, big_cnt, big_loss):
+                    t.record_stream(cur)
+            return (fused.view(1, 5), big_feat, big_cnt, small_feat, small_cnt, big_loss, small_output_all, small_gt_all,
+                    fpn_ot_loss)
         if rows:
             rpn_cls_loss, rpn_box_loss = compute_rpn_losses_on_rows(target_rpn_match, target_rpn_deltas, r_img, r_anchor,
                                                                     r_valid, row_logits, row_bbox)

@@ -467,6 +467,24 @@ int fi_detection_targets(const float *proposals, const int64_t *num_proposals, c
                          const float *bbox_std_dev, float *rois, int32_t *target_class_ids, float *target_deltas,
                          float *mask_boxes, int32_t *mask_box_ids, float *is_positive, fi_stream_t stream);
 
+/* The five detector losses (lib/layers.py:808-934) and their gradients in one pass: the RPN class / box losses on the
+ * rows fi_rpn_targets listed (row_image / row_anchor [rpn_rows], -1 = no row; row_logits [rows][2], row_bbox [rows][4];
+ * rpn_match [b][anchors], rpn_deltas [b][anchors][4]), the box head's class loss (soft-max cross entropy over all `rois`
+ * rows, zero when the batch has no foreground) and box loss (smooth L1 on the positive RoIs' target-class row of
+ * roi_bbox [rois][K][4]), the mask loss (sigmoid + binary cross entropy on the positive rows of mask_logits
+ * [mask_rows][2][2][h][w] -- the target class's channel, BEFORE the pixel shuffle -- against mask_targets
+ * [mask_rows][2h][2w]).  losses_and_factors[0..4] = rpn_class, rpn_bbox, mrcnn_class, mrcnn_bbox, mrcnn_mask;
+ * [5..9] = d loss_k / d (stored gradient): grad_* hold each loss's gradient with respect to the network output up to
+ * that factor (so backward is one scaling per tensor).  Partial sums are added in a fixed order: deterministic. */
+size_t fi_detector_losses_workspace_bytes(int rpn_rows, int rois, int mask_rows);
+int fi_detector_losses(const float *rpn_match, const float *rpn_deltas, const int64_t *row_image, const int64_t *row_anchor,
+                       const float *row_logits, const float *row_bbox, int rpn_rows, int anchors,
+                       const int32_t *roi_class_ids, const float *class_logits, const float *roi_deltas,
+                       const float *roi_bbox, int rois, int num_classes, const int32_t *mask_class_ids,
+                       const float *mask_logits, const float *mask_targets, int mask_rows, int mask_h, int mask_w,
+                       float *grad_row_logits, float *grad_row_bbox, float *grad_class_logits, float *grad_roi_bbox,
+                       float *grad_mask_logits, float *losses_and_factors, void *workspace, fi_stream_t stream);
+
 /* ------------------------------------------------------------------------
  * bf16-input, fp32-accumulate variants (v_mfma_f32_32x32x16_bf16) for BASELINE configs[4]'s reduced-
  * precision conv path.  Same tensors as above (fp32 in memory, operands rounded to bf16 on their way into

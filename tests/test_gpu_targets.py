@@ -125,3 +125,57 @@ def test_detection_target_kernel_equals_the_tensor_formulation(P, R, crowd, ties
         rois, ids = got[0].cpu().numpy(), got[1].cpu().numpy()
         pc = int(R * cfg.ROIS.ROI_POSITIVE_RATIO)
         assert ((ids > 0).sum(1) <= pc).all() and (ids[:, pc:] == 0).all()
+
+
+@pytest.mark.parametrize("with_fg", [True, False])
+def test_detector_losses_kernel_matches_the_loss_functions(with_fg):
+    """fi_detector_losses (the five losses and their gradients in one pass) against the loss functions of layers.py --
+    which tests/test_reference_goldens.py holds to the reference's outputs -- values to 2e-6 relative, gradients with
+    respect to every network output to 1e-6 of their largest element; also a batch without any foreground (the class
+    loss is then switched off, lib/layers.py:866-870)."""
+    from feature_intertwiner_amd import layers as L
+    torch.manual_seed(4)
+    b, A, R, K, P, h = 2, 3000, 64, 81, 21, 14
+    n_total = 256
+    match = torch.zeros(b, A, device=DEV)
+    deltas = torch.zeros(b, A, 4, device=DEV)
+    rows_i, rows_a = [], []
+    for i in range(b):
+        idx = torch.randperm(A)[:200 + 30 * i].sort()[0].to(DEV)
+        match[i, idx[:60]] = 1.0
+        match[i, idx[60:]] = -1.0
+        deltas[i, idx[:60]] = torch.randn(60, 4, device=DEV)
+        pad = n_total - idx.numel()
+        rows_i.append(torch.cat((torch.full((idx.numel(),), i, device=DEV), torch.full((pad,), -1, device=DEV))))
+        rows_a.append(torch.cat((idx, torch.full((pad,), -1, device=DEV))))
+    r_img, r_anchor = torch.cat(rows_i).long(), torch.cat(rows_a).long()
+    r_valid = r_img >= 0
+    ids = torch.zeros(b, R, dtype=torch.int32, device=DEV)
+    if with_fg:
+        ids[0, :15] = torch.randint(1, K, (15,), dtype=torch.int32).to(DEV)
+        ids[1, :7] = torch.randint(1, K, (7,), dtype=torch.int32).to(DEV)
+    tdel = torch.randn(b, R, 4, device=DEV) * (ids > 0).unsqueeze(2)
+    tmask = (torch.rand(b, P, 2 * h, 2 * h, device=DEV) > 0.5).float()
+    mk = lambda *s: (torch.randn(*s, device=DEV) * 2).requires_grad_(True)
+    outs = {}
+    for form in ("kernel", "functions"):
+        torch.manual_seed(7)
+        row_logits, row_bbox = mk(b * n_total, 2), mk(b * n_total, 4)
+        cls_logits, roi_bbox, mask_logits = mk(b, R, K), mk(b, R, K, 4), mk(b, P, 2, 2, h, h)
+        if form == "kernel":
+            five = L.detector_losses(row_logits, row_bbox, r_img, r_anchor, match, deltas, cls_logits, roi_bbox, ids, tdel,
+                                     mask_logits, ids[:, :P], tmask)
+        else:
+            rc, rb = L.compute_rpn_losses_on_rows(match, deltas, r_img, r_anchor, r_valid, row_logits, row_bbox)
+            five = torch.stack((rc, rb, L.compute_mrcnn_class_loss(ids, cls_logits),
+                                L.compute_mrcnn_bbox_loss(tdel, ids, roi_bbox),
+                                L.compute_mrcnn_mask_loss_selected(tmask, ids[:, :P], mask_logits)))
+        wts = torch.tensor([1.0, 0.7, 1.3, 0.9, 1.1], device=DEV)
+        (five * wts).sum().backward()
+        outs[form] = (five.detach(), [t.grad for t in (row_logits, row_bbox, cls_logits, roi_bbox, mask_logits)])
+    a, r = outs["kernel"], outs["functions"]
+    assert float((a[0] - r[0]).abs().max()) <= 2e-6 * float(r[0].abs().max()) + 1e-9, (a[0], r[0])
+    if not with_fg:
+        assert float(a[0][2]) == 0.0 and float(a[0][3]) == 0.0 and float(a[0][4]) == 0.0
+    for name, ga, gr in zip(("rpn logits", "rpn bbox", "class logits", "roi bbox", "mask logits"), a[1], r[1]):
+        assert float((ga - gr).abs().max()) <= 1e-6 * float(gr.abs().max()) + 1e-12, name
