@@ -71,6 +71,8 @@ SIGNATURES = {
     "fi_detection_targets": (c_int, [c_void_p] * 6 + [c_int] * 5 + [ctypes.c_double, c_int, ctypes.POINTER(c_float)] +
                              [c_void_p] * 6 + [c_void_p]),
     "fi_conv2d_weight_grad_batch": (c_int, [c_void_p] * 4 + [c_int] * 14 + [c_void_p]),
+    "fi_conv2d_weight_grad_batch_bf16": (c_int, [c_void_p] * 4 + [c_int] * 14 + [c_void_p]),
+    "fi_conv2d_weight_grad_batch_f16": (c_int, [c_void_p] * 4 + [c_int] * 14 + [c_void_p]),
     "fi_conv2d_forward_gated_bf16": (c_int, [c_void_p] * 7 + [c_int] * 16 + [c_void_p]),
     "fi_conv3x3_forward_gated_bf16w": (c_int, [c_void_p] * 7 + [c_int] * 7 + [c_void_p]),
     "fi_conv1x1_forward_gated_bf16w": (c_int, [c_void_p] * 7 + [c_int] * 5 + [c_void_p]),

@@ -600,9 +600,10 @@ def _conv_backward(ctx_needs, x, w, dz, stride, padding, want_db=False, add_to_d
             side.wait_event(dz_ready)                      # dz (and x) were complete on the main stream there
             x.record_stream(side)
             dz.record_stream(side)
-        if flags and adopt and not bf16 and WGRAD_BATCH > 1 and hwc and same and Cin % 128 == 0 and \
+        if flags and adopt and WGRAD_BATCH > 1 and hwc and same and Cin % 128 == 0 and \
+                (not bf16 or (Cout % 64 == 0 and (R * S == 1 or (R, S, padding) == (3, 3, (1, 1))))) and \
                 N * dz.shape[2] * dz.shape[3] <= WGRAD_BATCH_MAX_PIXELS and _defer_wgrad(
-                    (N, Cin, H, W, Cout, R, S, padding, want_db and db is not None),
+                    (N, Cin, H, W, Cout, R, S, padding, want_db and db is not None, precision if bf16 else None),
                     x, dz, dw, db if want_db else None, after_wgrad, bool(hwc and R * S > 1), dz_ready,
                     torch.cuda.current_stream(x.device), side):
             side = None                    # queued: launched with the other layers of its geometry (_flush_wgrads)
@@ -729,7 +730,7 @@ def _flush_wgrads(key):
     if not e or not e["items"]:
         return
     items, side = e["items"], e["side"]
-    N, Cin, H, W, Cout, R, S, padding, has_db = key
+    N, Cin, H, W, Cout, R, S, padding, has_db, lowp = key
     n = len(items)
     L = _lib.load()
     arr = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])
@@ -739,8 +740,12 @@ def _flush_wgrads(key):
         for t in xs + dzs:
             t.record_stream(side)
     with torch.cuda.device(xs[0].device), (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
-        _log_flops("wgrad", Cout, R, S, 2.0 * n * N * H * W * Cout * Cin * R * S, N * H * W, Cin, batch=n)
-        _lib.check(L.fi_conv2d_weight_grad_batch(arr(xs), arr(dzs), arr(dws),
+        if lowp:
+            _log_flops("bf16_wgrad", Cout, R, S, 2.0 * n * N * H * W * Cout * Cin * R * S)
+        else:
+            _log_flops("wgrad", Cout, R, S, 2.0 * n * N * H * W * Cout * Cin * R * S, N * H * W, Cin, batch=n)
+        fn = _lowp_fn(L, "conv2d_weight_grad_batch", lowp) if lowp else L.fi_conv2d_weight_grad_batch
+        _lib.check(fn(arr(xs), arr(dzs), arr(dws),
                                                  arr([it[3] for it in items]) if has_db else None, n, N, Cin, H, W, Cout,
                                                  R, S, 1, 1, padding[0], padding[1], 1, _lib.OUTPUTS_ZEROED,
                                                  _lib.current_stream()), "fi_conv2d_weight_grad_batch")

@@ -1346,16 +1346,29 @@ __global__ __launch_bounds__(kThreads, 2) void conv_bf16_wgrad_kernel(const floa
 // divergent path that only wavefronts with a row end inside their tile take.  The pixel axis is the plain
 // (n, y, x) order (requires H*W % 4 == 0 so that a group never straddles two images), i.e. no padded pixels.
 // ------------------------------------------------------------------------------------------------
+// operand pointers of a batched launch (fi_conv2d_weight_grad_batch_{bf16,f16}; see csrc/conv_igemm.hip), by value
+struct WgradBatch16 {
+    int n;
+    const float *x[FI_WGRAD_BATCH_MAX];
+    const float *dy[FI_WGRAD_BATCH_MAX];
+    float *dw[FI_WGRAD_BATCH_MAX];
+    float *db[FI_WGRAD_BATCH_MAX];
+};
+
 constexpr int FK = 64;             // pixels per K-tile: 4 MFMA k-steps of 16
 constexpr int FLP = FK + 8;        // LDS row pitch in bf16 (144 B = 9 16-byte chunks: 16 rows cover all banks once)
 
 template <int BM, int BNC, bool K3>
-__global__ __launch_bounds__(kThreads, 2) void conv_bf16_wgrad_flat_kernel(const float *__restrict__ x,
-                                                                           const float *__restrict__ dy,
-                                                                           float *__restrict__ dw, Geom g, int cin_tiles,
+__global__ __launch_bounds__(kThreads, 2) void conv_bf16_wgrad_flat_kernel(const float *__restrict__ x_arg,
+                                                                           const float *__restrict__ dy_arg,
+                                                                           float *__restrict__ dw_arg, Geom g, int cin_tiles,
                                                                            int p_per_split, int mtiles, int splits,
-                                                                           float *__restrict__ dbias)
+                                                                           float *__restrict__ dbias_arg, WgradBatch16 wb)
 {
+    const float *__restrict__ x = x_arg;
+    const float *__restrict__ dy = dy_arg;
+    float *__restrict__ dw = dw_arg;
+    float *__restrict__ dbias = dbias_arg;
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     constexpr int MT = BM / 64, NT = BNC / 64;
     constexpr int AV = BM / 16, BV = BNC / 16;          // row passes of the loaders: thread = (group tid & 15, row tid >> 4)
@@ -1374,10 +1387,19 @@ __global__ __launch_bounds__(kThreads, 2) void conv_bf16_wgrad_flat_kernel(const
     // ranges, so a split is fetched into ONE L2 and re-read there (plain order: 36 tiles of a split on 8 XCDs,
     // 9.8 GB of operand reads per launch on the P2-level layers -- the kernel ran at the Infinity-Cache rate).
     const int tiles_per_split = mtiles * RS * cin_tiles;
-    const int nblk = tiles_per_split * splits;
+    const int nblk1 = tiles_per_split * splits;
+    const int nblk = wb.n ? nblk1 * wb.n : nblk1;
     const int per_xcd = (nblk + 7) >> 3;
-    const int idx = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    int idx = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
     if (idx >= nblk) return;
+    if (wb.n) {                                       // batched launch: (problem, split, tile) order
+        const int prob = idx / nblk1;
+        idx -= prob * nblk1;
+        x = wb.x[prob];
+        dy = wb.dy[prob];
+        dw = wb.dw[prob];
+        dbias = wb.db[prob];
+    }
     const int bz = idx / tiles_per_split;
     const int tl = idx - bz * tiles_per_split;
     const int by = tl / mtiles, bx = tl - by * mtiles;
@@ -1778,9 +1800,64 @@ int FI16(fi_conv2d_weight_grad, )(const float *x, const float *dy, float *dweigh
                                             pad_w, flags, stream);
 }
 
+static int wgrad16_impl(const float *x, const float *dy, float *dweight, float *dbias, int N, int Cin, int H,
+                        int W, int Cout, int R, int S, int stride_h, int stride_w, int pad_h, int pad_w,
+                        int flags, fi_stream_t stream, const WgradBatch16 *batch);
+
 int FI16(fi_conv2d_weight_grad_db, )(const float *x, const float *dy, float *dweight, float *dbias, int N, int Cin, int H,
                                   int W, int Cout, int R, int S, int stride_h, int stride_w, int pad_h, int pad_w,
                                   int flags, fi_stream_t stream)
+{
+    return wgrad16_impl(x, dy, dweight, dbias, N, Cin, H, W, Cout, R, S, stride_h, stride_w, pad_h, pad_w, flags, stream,
+                        nullptr);
+}
+
+// n weight gradients of one geometry in one launch (see fi_conv2d_weight_grad_batch); loops when the geometry is not
+// the flat kernel's or the outputs are not pre-zeroed
+int FI16(fi_conv2d_weight_grad_batch, )(const float *const *x, const float *const *dy, float *const *dweight,
+                                     float *const *dbias, int n, int N, int Cin, int H, int W, int Cout, int R, int S,
+                                     int stride_h, int stride_w, int pad_h, int pad_w, int weight_layout, int flags,
+                                     fi_stream_t stream)
+{
+    (void)weight_layout;                                  // the 16-bit kernels always write tap-major
+    FI_REQUIRE(n >= 1 && x && dy && dweight, "empty batch / null pointer table");
+    const bool k3 = R == 3 && S == 3 && pad_h == 1 && pad_w == 1, k1 = R == 1 && S == 1 && pad_h == 0 && pad_w == 0;
+    const int HWf = H * W;
+    bool ok = (k3 || k1) && stride_h == 1 && stride_w == 1 && HWf % 4 == 0 && HWf >= FK && W >= 4 && Cout % 64 == 0 &&
+              Cin % 64 == 0 && (flags & FI_OUTPUTS_ZEROED) && n > 1 && !getenv("FI_NO_BF16_FLAT");
+    bool any_db = false, all_db = true;
+    for (int i = 0; i < n; ++i) {
+        FI_REQUIRE(x[i] && dy[i] && dweight[i], "null pointer in the batch");
+        ok = ok && (uintptr_t)x[i] % 16 == 0 && (uintptr_t)dy[i] % 16 == 0;
+        const bool has = dbias && dbias[i];
+        any_db = any_db || has;
+        all_db = all_db && has;
+    }
+    if (!ok || (any_db && !all_db)) {
+        for (int i = 0; i < n; ++i) {
+            const int rc = wgrad16_impl(x[i], dy[i], dweight[i], dbias ? dbias[i] : nullptr, N, Cin, H, W, Cout, R, S,
+                                        stride_h, stride_w, pad_h, pad_w, flags, stream, nullptr);
+            if (rc != FI_OK) return rc;
+        }
+        return FI_OK;
+    }
+    for (int i0 = 0; i0 < n; i0 += FI_WGRAD_BATCH_MAX) {
+        WgradBatch16 wb;
+        wb.n = n - i0 < FI_WGRAD_BATCH_MAX ? n - i0 : FI_WGRAD_BATCH_MAX;
+        for (int i = 0; i < FI_WGRAD_BATCH_MAX; ++i) {
+            const int j = i0 + (i < wb.n ? i : 0);
+            wb.x[i] = x[j]; wb.dy[i] = dy[j]; wb.dw[i] = dweight[j]; wb.db[i] = all_db ? dbias[j] : nullptr;
+        }
+        const int rc = wgrad16_impl(wb.x[0], wb.dy[0], wb.dw[0], wb.db[0], N, Cin, H, W, Cout, R, S, stride_h, stride_w,
+                                    pad_h, pad_w, flags, stream, &wb);
+        if (rc != FI_OK) return rc;
+    }
+    return FI_OK;
+}
+
+static int wgrad16_impl(const float *x, const float *dy, float *dweight, float *dbias, int N, int Cin, int H,
+                        int W, int Cout, int R, int S, int stride_h, int stride_w, int pad_h, int pad_w,
+                        int flags, fi_stream_t stream, const WgradBatch16 *batch)
 {
     Geom g;
     int rc = make_geom(g, N, Cin, H, W, Cout, R, S, stride_h, stride_w, pad_h, pad_w, 0, 0);
@@ -1806,21 +1883,25 @@ int FI16(fi_conv2d_weight_grad_db, )(const float *x, const float *dy, float *dwe
             const long tiles = (long)mt * RS * cin_tiles;
             const int ptiles = fi::ceil_div(g.P, FK);
             // split the pixel range so that ~2048 workgroups exist, at least 8 K-tiles each
-            long z = 2048 / tiles;
+            const int nb = batch ? batch->n : 1;            // a batch fills the chip together: fewer, longer splits each
+            long z = 2048 / (tiles * nb);
             if (z < 1) z = 1;
             if (z > ptiles / 8) z = ptiles / 8 > 0 ? ptiles / 8 : 1;
             if (z > 65535) z = 65535;
             const int per = fi::ceil_div(ptiles, (int)z);
             z = fi::ceil_div(ptiles, per);
             FI_REQUIRE((long)RS * cin_tiles <= 65535, "too many (tap, ci) tiles");
-            const long nblk = tiles * z;
+            const long nblk = tiles * z * nb;
             FI_REQUIRE(nblk + 8 < 2147483647L, "too many workgroups");
             const dim3 grid((unsigned)(((nblk + 7) / 8) * 8));
             auto k = k3 ? (bm == 128 ? (bnc == 128 ? conv_bf16_wgrad_flat_kernel<128, 128, true> : conv_bf16_wgrad_flat_kernel<128, 64, true>)
                                      : (bnc == 128 ? conv_bf16_wgrad_flat_kernel<64, 128, true> : conv_bf16_wgrad_flat_kernel<64, 64, true>))
                         : (bm == 128 ? (bnc == 128 ? conv_bf16_wgrad_flat_kernel<128, 128, false> : conv_bf16_wgrad_flat_kernel<128, 64, false>)
                                      : (bnc == 128 ? conv_bf16_wgrad_flat_kernel<64, 128, false> : conv_bf16_wgrad_flat_kernel<64, 64, false>));
-            hipLaunchKernelGGL(k, grid, dim3(kThreads), 0, st, x, dy, dweight, g, cin_tiles, per * FK, mt, (int)z, dbias);
+            WgradBatch16 wb;
+            wb.n = 0;
+            if (batch) wb = *batch;
+            hipLaunchKernelGGL(k, grid, dim3(kThreads), 0, st, x, dy, dweight, g, cin_tiles, per * FK, mt, (int)z, dbias, wb);
             FI_HIP_CHECK(hipGetLastError());
             return FI_OK;
         }

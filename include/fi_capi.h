@@ -361,9 +361,18 @@ int fi_conv2d_weight_grad(const float *x, const float *dy, float *dweight, int N
  * fixed cost (prologue, atomic epilogue) is a third of its time; n layers together take fewer, longer pixel splits
  * per layer.  Same sums as n calls of fi_conv2d_weight_grad (fp32 atomics: the order of the partial sums differs).
  * One launch needs FI_OUTPUTS_ZEROED, tap-major / 1x1 weights with Cin % 128 == 0 and a same-size stride-1 layer;
- * otherwise the call loops over the problems.  At most FI_WGRAD_BATCH_MAX problems travel in one launch. */
+ * otherwise the call loops over the problems.  At most FI_WGRAD_BATCH_MAX problems travel in one launch.
+ * _bf16 / _f16: the same on the 16-bit-operand kernels (conv_bf16_wgrad_flat_kernel; weight_layout is ignored: tap-major). */
 #define FI_WGRAD_BATCH_MAX 24
 int fi_conv2d_weight_grad_batch(const float *const *x, const float *const *dy, float *const *dweight,
+                                float *const *dbias, int n, int N, int Cin, int H, int W, int Cout, int R, int S,
+                                int stride_h, int stride_w, int pad_h, int pad_w, int weight_layout, int flags,
+                                fi_stream_t stream);
+int fi_conv2d_weight_grad_batch_bf16(const float *const *x, const float *const *dy, float *const *dweight,
+                                float *const *dbias, int n, int N, int Cin, int H, int W, int Cout, int R, int S,
+                                int stride_h, int stride_w, int pad_h, int pad_w, int weight_layout, int flags,
+                                fi_stream_t stream);
+int fi_conv2d_weight_grad_batch_f16(const float *const *x, const float *const *dy, float *const *dweight,
                                 float *const *dbias, int n, int N, int Cin, int H, int W, int Cout, int R, int S,
                                 int stride_h, int stride_w, int pad_h, int pad_w, int weight_layout, int flags,
                                 fi_stream_t stream);

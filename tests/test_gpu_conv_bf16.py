@@ -312,3 +312,35 @@ def test_stage_gradients_on_the_16bit_kernels_track_fp32(precision):
         assert float((new - old).abs().max()) <= 0.4 * far * top, k
         ratio = float((new * ref).sum() / (ref * ref).sum().clamp(min=1e-30))
         assert abs(ratio - 1.0) < 3e-2, (k, ratio)
+
+
+@pytest.mark.parametrize("prec", ["bf16", "f16"])
+def test_weight_grad_batch_16bit_equals_separate_launches(prec):
+    """fi_conv2d_weight_grad_batch_{bf16,f16}: n problems of one geometry in one launch of the flat 16-bit weight-gradient
+    kernel against n separate launches (same operand rounding; the fp32 atomics add the pixel splits in another order) --
+    1x1 and 3x3, with the bias sums, more problems than FI_WGRAD_BATCH_MAX, and a geometry that falls back to the loop."""
+    import ctypes
+    from feature_intertwiner_amd import _lib
+    L = _lib.load()
+    torch.manual_seed(5)
+    single = getattr(L, "fi_conv2d_weight_grad_db_%s" % prec)
+    batch = getattr(L, "fi_conv2d_weight_grad_batch_%s" % prec)
+    for N, Cin, H, W, Cout, R, n, with_db in [(2, 256, 16, 16, 512, 1, 5, True), (2, 128, 16, 16, 128, 3, 4, True),
+                                              (1, 128, 8, 8, 64, 3, 26, False), (2, 128, 6, 6, 128, 3, 3, True)]:
+        pad = R // 2
+        xs = [torch.randn(N, Cin, H, W, device=DEV) for _ in range(n)]
+        dys = [torch.randn(N, Cout, H, W, device=DEV) for _ in range(n)]
+        got = [torch.zeros(Cout, R, R, Cin, device=DEV) for _ in range(n)]
+        gdb = [torch.zeros(Cout, device=DEV) for _ in range(n)]
+        arr = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])
+        _lib.check(batch(arr(xs), arr(dys), arr(got), arr(gdb) if with_db else None, n, N, Cin, H, W, Cout, R, R, 1, 1, pad,
+                         pad, 1, _lib.OUTPUTS_ZEROED, _lib.current_stream()), "batch")
+        for i in range(n):
+            one = torch.zeros(Cout, R, R, Cin, device=DEV)
+            odb = torch.zeros(Cout, device=DEV)
+            _lib.check(single(_lib.ptr(xs[i]), _lib.ptr(dys[i]), _lib.ptr(one), _lib.ptr(odb) if with_db else None, N, Cin,
+                              H, W, Cout, R, R, 1, 1, pad, pad, _lib.OUTPUTS_ZEROED, _lib.current_stream()), "single")
+            scale = float(one.abs().max())
+            assert float((got[i] - one).abs().max()) <= 2e-5 * (N * H * W) ** 0.5 * scale, (N, Cin, Cout, R, i)
+            if with_db:
+                assert float((gdb[i] - odb).abs().max()) <= 1e-3
