@@ -611,6 +611,9 @@ def _main():
     from feature_intertwiner_amd import model as fimodel
     dead_side = fimodel._DEAD_SIDE
     fimodel._DEAD_SIDE = False            # the mask head's unread batch back on the main stream, for the same reason
+    from feature_intertwiner_amd import sub_module as fisub, workflow as fiwork
+    keep_side = (fimodel._PROPOSAL_SIDE, fisub._BIG_SIDE, fiwork.META_SIDE_STREAM)
+    fimodel._PROPOSAL_SIDE = fisub._BIG_SIDE = fiwork.META_SIDE_STREAM = False     # (round 4's side-stream work as well)
     t1 = time.perf_counter()
     for _ in range(prof_steps):
         step()
@@ -618,6 +621,7 @@ def _main():
     prof_elapsed = time.perf_counter() - t1
     ficonv.WGRAD_SIDE_STREAM_MAX_PIXELS = side_pixels
     fimodel._DEAD_SIDE = dead_side
+    fimodel._PROPOSAL_SIDE, fisub._BIG_SIDE, fiwork.META_SIDE_STREAM = keep_side
     _lib.prof_enable(False)
     log = car.LAUNCH_LOG
     car.LAUNCH_LOG = None
