@@ -652,7 +652,8 @@ def _main():
                              "multi-reader gradients -- the same forward results and the same gradients as the default"}
     # ---- the default backward pass against its dense form on the SAME weights / inputs / draws (outside the timed region)
     backward_check = None
-    if world == 1 and not args.dense_backward and not args.no_dense_reference:
+    if world == 1 and sync is None and not args.dense_backward and not args.no_dense_reference:
+        # (not with the data-parallel engine attached: its autograd hooks expect begin() / sync() around a backward pass)
         from feature_intertwiner_amd.workflow import compare_backward_forms
         lowp = args.conv_precision != "fp32"
         r = compare_backward_forms(model, batch, skip=(lambda n: n.startswith("ot_loss") or
@@ -666,7 +667,7 @@ def _main():
         torch.cuda.synchronize()
     # ---- BASELINE configs[4], single-GPU slice, on the driver's record too (outside the timed region) -----------------
     cfg4_slice = None
-    if world == 1 and args.config == "cfg3" and not args.no_dense_reference and not args.dense_backward and \
+    if world == 1 and sync is None and args.config == "cfg3" and not args.no_dense_reference and not args.dense_backward and \
             args.conv_precision == "fp32":
         try:
             cfg4_slice = configs4_slice(dev)
@@ -833,7 +834,10 @@ def _main():
                 child.append("--mask-head-on-positive-slots")
             if args.dense_backward:
                 child.append("--dense-backward")
-            subs = [roof["kernel"].split("<")[0] + "<" + roof["kernel"].split("<")[1].rstrip(">")]
+            # kernel-name prefix the trace rows are matched on: "name<args" without the closing bracket for a template
+            # instantiation, the plain name otherwise (the 16-bit kernels' slots)
+            kn = roof["kernel"]
+            subs = [kn.split("<")[0] + "<" + kn.split("<")[1].rstrip(">") if "<" in kn else kn]
             if roof_roi is not None:
                 subs.append(roof_roi["kernel"].rstrip(">"))
             t_p = time.time()

@@ -145,7 +145,6 @@ __global__ __launch_bounds__(1024) void rpn_sample_kernel(const float *__restric
     __shared__ unsigned s_hist[2][4096];
     __shared__ int s_claim[kMaxGT];
     __shared__ int s_nclaim;
-    __shared__ int s_w[17];
     __shared__ int s_cnt[2];
     __shared__ unsigned s_sel[2][3];                   // per class: high bucket, quota inside it; then threshold key, ties to keep
     const int img = blockIdx.x;
@@ -251,46 +250,103 @@ __global__ __launch_bounds__(1024) void rpn_sample_kernel(const float *__restric
     const bool all_p = bk_p == 0xFFFFFFFFu, all_n = bk_n == 0xFFFFFFFFu;
     const unsigned thr_p = s_sel[0][1], thr_n = s_sel[1][1];
     const int ties_p = (int)s_sel[0][2], ties_n = (int)s_sel[1][2];
-    // pass 3, in anchor order: final match, refinements of the kept positives, compact (image, anchor) rows
-    int seen_tp = 0, seen_tn = 0, rows = 0;
-    const int chunks = (A + 1023) / 1024;
-    for (int c = 0; c < chunks; ++c) {
-        const int a = c * 1024 + tid;
-        const bool in = a < A;
+    // pass 3, in anchor order: final match, refinements of the kept positives, compact (image, anchor) rows.  Ties at a
+    // selection boundary and the row positions need ORDERED counts: every wavefront owns a contiguous range of anchors
+    // (walked 64 at a time, coalesced), counts its ties / kept anchors in a first sweep, the 16 counts are scanned once,
+    // and a second sweep assigns ranks with wavefront ballots only -- no barrier inside the loops.
+    __shared__ int s_wcnt[3][16];
+    const int lane = tid & 63, wave = tid >> 6;
+    const int per_wave = ((A + 15) / 16 + 63) / 64 * 64;
+    const int a_begin = wave * per_wave, a_end = min(A, a_begin + per_wave);
+    auto classify = [&](int a, bool in, bool &cand_p, bool &cand_n, bool &tie_p, bool &tie_n, bool &sure_p, bool &sure_n) {
         const float m = in ? mt[a] : 0.0f;
         const unsigned k_p = in ? key_of(kp[a]) : 0u;
         const unsigned k_n = in ? key_of(kn[a]) : 0u;
-        const bool cand_p = m > 0.0f, cand_n = m < 0.0f;
-        const bool tie_p = cand_p && !all_p && k_p == thr_p;
-        const bool tie_n = cand_n && !all_n && k_n == thr_n;
-        int tot_tp = 0, tot_tn = 0;
-        int pre_tp = 0, pre_tn = 0;
-        if (!all_p) pre_tp = block_prefix(tie_p, s_w, &tot_tp);       // (uniform conditions)
-        if (!all_n) pre_tn = block_prefix(tie_n, s_w, &tot_tn);
-        bool keep_p = cand_p && keep_pos > 0 && (all_p ? (keep_pos >= n_pc) : (k_p > thr_p || (tie_p && seen_tp + pre_tp < ties_p)));
-        bool keep_n = cand_n && keep_neg > 0 && (all_n ? (keep_neg >= n_nc) : (k_n > thr_n || (tie_n && seen_tn + pre_tn < ties_n)));
-        seen_tp += tot_tp;
-        seen_tn += tot_tn;
-        int tot_rows = 0;
-        const int pre_rows = block_prefix(keep_p || keep_n, s_w, &tot_rows);
-        if (in) {
-            mt[a] = keep_p ? 1.0f : (keep_n ? -1.0f : 0.0f);
-            float d[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-            if (keep_p) {
-                const int g = (int)(ar[a] & 0x7FFFFFFFu);
-                const float4 bx = *reinterpret_cast<const float4 *>(anchors + (size_t)a * 4);
-                const float b4[4] = {bx.x, bx.y, bx.z, bx.w};
-                const float *gt = gts + ((size_t)img * G + g) * 4;
-                const float g4[4] = {gt[0], gt[1], gt[2], gt[3]};
-                refine(b4, g4, std4.v, d);
-            }
-            *reinterpret_cast<float4 *>(deltas + ((size_t)img * A + a) * 4) = make_float4(d[0], d[1], d[2], d[3]);
-            if ((keep_p || keep_n) && row_image && rows + pre_rows < n_total) {
-                row_image[(size_t)img * n_total + rows + pre_rows] = img;
-                row_anchor[(size_t)img * n_total + rows + pre_rows] = a;
-            }
+        cand_p = m > 0.0f;
+        cand_n = m < 0.0f;
+        tie_p = cand_p && !all_p && k_p == thr_p;
+        tie_n = cand_n && !all_n && k_n == thr_n;
+        sure_p = cand_p && keep_pos > 0 && (all_p ? (keep_pos >= n_pc) : (k_p > thr_p));
+        sure_n = cand_n && keep_neg > 0 && (all_n ? (keep_neg >= n_nc) : (k_n > thr_n));
+    };
+    int c_tp = 0, c_tn = 0;
+    for (int a0 = a_begin; a0 < a_end; a0 += 64) {
+        const int a = a0 + lane;
+        bool cp, cn, tp, tn, sp, sn;
+        classify(a, a < a_end, cp, cn, tp, tn, sp, sn);
+        c_tp += __popcll(__ballot(tp));
+        c_tn += __popcll(__ballot(tn));
+    }
+    if (lane == 0) {
+        s_wcnt[0][wave] = c_tp;
+        s_wcnt[1][wave] = c_tn;
+    }
+    __syncthreads();
+    int seen_tp = 0, seen_tn = 0;
+    for (int w = 0; w < wave; ++w) {
+        seen_tp += s_wcnt[0][w];
+        seen_tn += s_wcnt[1][w];
+    }
+    // second sweep: the kept flags are now decidable; count the rows per wavefront first (third counter), then write
+    int c_rows = 0;
+    {
+        int tp_run = seen_tp, tn_run = seen_tn;
+        for (int a0 = a_begin; a0 < a_end; a0 += 64) {
+            const int a = a0 + lane;
+            bool cp, cn, tp, tn, sp, sn;
+            classify(a, a < a_end, cp, cn, tp, tn, sp, sn);
+            const unsigned long long mtp = __ballot(tp), mtn = __ballot(tn);
+            const unsigned long long below = (1ull << lane) - 1ull;
+            const bool keep_p = sp || (tp && keep_pos > 0 && tp_run + __popcll(mtp & below) < ties_p);
+            const bool keep_n = sn || (tn && keep_neg > 0 && tn_run + __popcll(mtn & below) < ties_n);
+            tp_run += __popcll(mtp);
+            tn_run += __popcll(mtn);
+            c_rows += __popcll(__ballot(keep_p || keep_n));
         }
-        rows += tot_rows;
+    }
+    if (lane == 0) s_wcnt[2][wave] = c_rows;
+    __syncthreads();
+    int rows = 0, row_base = 0;
+    for (int w = 0; w < 16; ++w) {
+        row_base += w < wave ? s_wcnt[2][w] : 0;
+        rows += s_wcnt[2][w];
+    }
+    {
+        int tp_run = seen_tp, tn_run = seen_tn, r_run = row_base;
+        for (int a0 = a_begin; a0 < a_end; a0 += 64) {
+            const int a = a0 + lane;
+            const bool in = a < a_end;
+            bool cp, cn, tp, tn, sp, sn;
+            classify(a, in, cp, cn, tp, tn, sp, sn);
+            const unsigned long long mtp = __ballot(tp), mtn = __ballot(tn);
+            const unsigned long long below = (1ull << lane) - 1ull;
+            const bool keep_p = sp || (tp && keep_pos > 0 && tp_run + __popcll(mtp & below) < ties_p);
+            const bool keep_n = sn || (tn && keep_neg > 0 && tn_run + __popcll(mtn & below) < ties_n);
+            tp_run += __popcll(mtp);
+            tn_run += __popcll(mtn);
+            const unsigned long long mk = __ballot(keep_p || keep_n);
+            if (in) {
+                float d[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                if (keep_p) {
+                    const int g = (int)(ar[a] & 0x7FFFFFFFu);
+                    const float4 bx = *reinterpret_cast<const float4 *>(anchors + (size_t)a * 4);
+                    const float b4[4] = {bx.x, bx.y, bx.z, bx.w};
+                    const float *gt = gts + ((size_t)img * G + g) * 4;
+                    const float g4[4] = {gt[0], gt[1], gt[2], gt[3]};
+                    refine(b4, g4, std4.v, d);
+                }
+                *reinterpret_cast<float4 *>(deltas + ((size_t)img * A + a) * 4) = make_float4(d[0], d[1], d[2], d[3]);
+                const int pos = r_run + __popcll(mk & below);
+                if ((keep_p || keep_n) && row_image && pos < n_total) {
+                    row_image[(size_t)img * n_total + pos] = img;
+                    row_anchor[(size_t)img * n_total + pos] = a;
+                }
+            }
+            r_run += __popcll(mk);
+            // (the final match replaces the candidate class LAST: classify() of this wavefront's later chunks and of no
+            // other wavefront reads this element)
+            if (in) mt[a] = keep_p ? 1.0f : (keep_n ? -1.0f : 0.0f);
+        }
     }
     if (row_image)
         for (int r = rows + tid; r < n_total; r += 1024) {

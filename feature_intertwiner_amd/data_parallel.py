@@ -184,9 +184,9 @@ class GradientBuckets(object):
         self._start()
         for bi in self.buckets_of[p]:
             if bi in self._launched:
-                raise RuntimeError("GradientBuckets: a gradient arrived for a parameter of bucket %d after the bucket was "
-                                   "issued -- the set of parameters that receive gradients changed without a new "
-                                   "begin(key)" % bi)
+                raise RuntimeError("GradientBuckets: a gradient arrived for a parameter (shape %s%s) of bucket %d after the "
+                                   "bucket was issued -- the set of parameters that receive gradients changed without a "
+                                   "new begin(key)" % (tuple(p.shape), ", no longer waited for" if p in self._skip else "", bi))
             if p not in self._skip:
                 self.pending[bi] -= 1
         self._launch_ready()

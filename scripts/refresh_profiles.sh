@@ -19,7 +19,7 @@ f=$(find /tmp/prof8 -name 'c_kernel_stats.csv' | head -1); grep -E "Name|crop_|r
 bash scripts/conv_prof.sh "FPN P2" > $O/${R}_pmc_conv_mfma.txt 2>&1
 timeout 200 python scripts/roipool_probe.py > $O/${R}_roipool_probe.txt 2>&1
 # BASELINE configs[4] single-GPU slice (bf16 MFMA convs, 2 x 1344^2, 1000 RoIs/img) and the headline workload on the bf16 kernels
-( cd /tmp && timeout 400 python $GRAFT_REPO_ROOT/bench.py --config cfg5 --no-cpu-baseline --no-pmc > $O/${R}_bench_cfg5_bf16.json 2>/dev/null )
+( cd /tmp && timeout 500 python $GRAFT_REPO_ROOT/bench.py --config cfg5 --no-cpu-baseline > $O/${R}_bench_cfg5_bf16.json 2>$O/${R}_bench_cfg5_bf16.err )      # with the PMC passes: roofline.traffic
 ( cd /tmp && timeout 400 python $GRAFT_REPO_ROOT/bench.py --conv-precision bf16 --no-cpu-baseline --no-pmc > $O/${R}_bench_cfg3_bf16.json 2>/dev/null )
 # per-layer view of the step's kernels (grid size = layer shape) from a kernel trace of the headline command
 rm -rf /tmp/prof9; ( cd /tmp && FI_WGRAD_SIDE_PIXELS=0 FI_DEAD_SIDE=0 timeout 400 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof9 -o kt -- python $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 2 --profile-steps 0 --no-cpu-baseline --no-pmc --no-dense-reference > /dev/null 2>&1 )
@@ -37,11 +37,8 @@ timeout 200 python scripts/conv_shapes.py --bf16 --cfg5 > $O/${R}_conv_shapes_cf
 ( cd /tmp && FI_DP_FORCE=1 timeout 400 python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-pmc > $O/${R}_bench_dp_force_1rank_rccl.json 2>/dev/null )
 # `python bench.py --gpus 2` WITHOUT a launcher (self-launch), two ranks sharing the GPU over gloo (test mode)
 ( cd /tmp && FI_BENCH_SHARE_GPU=1 timeout 600 python $GRAFT_REPO_ROOT/bench.py --gpus 2 --steps 6 --no-cpu-baseline --no-pmc > $O/${R}_bench_gpus2_selflaunch_shared_gpu.json 2>/dev/null )
-# RoIAlign NCHW: kernel variants and overhead probes at the north-star shape, and the TCP / TCC / SQ counters of the library kernel
-timeout 200 scripts/micro/bin/crop_var > $O/${R}_crop_nchw_variants.txt 2>&1
-bash scripts/micro/crop_pmc.sh library > /dev/null 2>&1; cp $O/crop_pmc/summary.txt $O/${R}_crop_nchw_pmc.txt
-ls -la $O | tail -30
-# conv + eval-BN backward: the older form (fi_bn_act_backward passes) against the unscaled-gradient form, same box, interleaved
-( cd $GRAFT_REPO_ROOT && bash scripts/ab_env.sh "FI_BN_BWD_OLD=1" "FI_BN_BWD_NEW=1" 2>&1 | grep -v amdgpu > $O/${R}_ab_bn_backward.txt; bash scripts/ab_env.sh "FI_BN_BWD_OLD=1" "FI_BN_BWD_NEW=1" --config cfg5 2>&1 | grep -v amdgpu >> $O/${R}_ab_bn_backward.txt; bash scripts/ab_dense.sh > $O/${R}_ab_dense_backward.txt 2>&1 )
 timeout 200 python scripts/host_time.py 2>&1 | grep -v amdgpu | tail -8 > $O/${R}_host_time.txt
+# round 4: the short-K 1x1 probe needs a probe build (FI_EXTRA_HIPCC_FLAGS=-DFI_PROBE_1X1) and is run separately (scripts/c4_probe.sh);
+# what a batched weight-gradient launch reaches
+timeout 200 python scripts/wg_batch_probe.py 2>&1 | grep "^{" > $O/${R}_wgrad_batch_probe.txt
 ls -la $O | tail -40
