@@ -651,7 +651,10 @@ def _conv_backward(ctx_needs, x, w, dz, stride, padding, want_db=False, add_to_d
 # fp32 step 157.9 -> 155.1 ms with every layer on the second stream (155.3 with only layers <= 65 536 pixels); the
 # 16-bit kernels are bound by operand traffic through L2, not by their tails -- there it costs 0.5-1 ms and stays off.
 import os as _os
-WGRAD_SIDE_STREAM_MAX_PIXELS = int(_os.environ.get("FI_WGRAD_SIDE_PIXELS", str(1 << 30)))   # largest layer (pixels) that takes the second stream; 0 disables
+# Round 4: OFF by default.  With the weight gradients of a stage's identical layers batched into few long launches
+# (WGRAD_BATCH below) their tails no longer need hiding, and two MFMA-bound kernels sharing the chip only slow each other:
+# same-box A/B 112.7 (second stream) vs 110.9 ms/step (main stream), profiles/r04_ab_wgrad_stream.txt.
+WGRAD_SIDE_STREAM_MAX_PIXELS = int(_os.environ.get("FI_WGRAD_SIDE_PIXELS", "0"))   # largest layer (pixels) that takes the second stream; 0 disables
 _WG_STREAM = {}
 def wgrad_stream(device):
     """The second stream weight gradients may run on (None before first use)."""
