@@ -110,6 +110,7 @@ SIGNATURES = {
     "fi_relu_mask": (c_int, [c_void_p, c_void_p, c_void_p, ctypes.c_long, c_void_p]),
     "fi_bn_fold_grad": (c_int, [c_void_p] * 6 + [ctypes.c_float] + [c_void_p] * 3 + [c_int] * 5 + [c_void_p]),
     "fi_bn_fold_batch": (c_int, [c_void_p, c_int, c_int, c_void_p]),
+    "fi_bn_fold_grad_batch": (c_int, [c_void_p] * 6 + [ctypes.c_float] + [c_void_p] * 3 + [c_int] * 6 + [c_void_p]),
     "fi_stride2_interleave": (c_int, [c_void_p] * 6 + [ctypes.c_long, c_int, c_int, c_void_p]),
     "fi_stride2_interleave_gated": (c_int, [c_void_p] * 7 + [ctypes.c_long, c_int, c_int, c_void_p]),
     "fi_sgd_chunks": (ctypes.c_long, [ctypes.c_long]),

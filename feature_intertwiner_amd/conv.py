@@ -752,9 +752,24 @@ def _flush_wgrads(key):
                                                  arr([it[3] for it in items]) if has_db else None, n, N, Cin, H, W, Cout,
                                                  R, S, 1, 1, padding[0], padding[1], 1, _lib.OUTPUTS_ZEROED,
                                                  _lib.current_stream()), "fi_conv2d_weight_grad_batch")
-        for x, dz, dw, db, after, tap_major, ev in items:
-            if after is not None:
-                after(dw, db, tap_major)
+        folds = [getattr(it[4], "fold", None) for it in items]
+        if n > 1 and all(f is not None for f in folds) and len({(f[4], f[5] is None, f[6] is None, f[7] is None,
+                                                                 f[0].is_contiguous()) for f in folds}) == 1:
+            # every layer of the batch is conv + eval-BatchNorm: their fi_bn_fold_grad passes as one launch too
+            f0 = folds[0]
+            w_tap_major = R * S > 1 and not f0[0].is_contiguous()
+            here = torch.cuda.current_stream(xs[0].device)
+            for f in folds:
+                f[8].record_stream(here)
+                f[1].record_stream(here)
+            col = lambda k: arr([f[k] for f in folds]) if f0[k] is not None else None
+            _lib.check(L.fi_bn_fold_grad_batch(arr(dws), col(0), arr([it[3] for it in items]), col(1), col(2), col(3), f0[4],
+                                               col(5), col(6), col(7), n, Cout, Cin, R * S, 1 if items[0][5] else 0,
+                                               1 if w_tap_major else 0, _lib.current_stream()), "fi_bn_fold_grad_batch")
+        else:
+            for x, dz, dw, db, after, tap_major, ev in items:
+                if after is not None:
+                    after(dw, db, tap_major)
 
 
 def flush_deferred_wgrads():
@@ -1099,6 +1114,9 @@ class _ConvBnActFn(torch.autograd.Function):
                                          _lib.ptr(sums[2 * C:]) if want_db else None, C, Cin, R * S,
                                          1 if tap_major else 0, 1 if w_tap_major else 0, _lib.current_stream()),
                        "fi_bn_fold_grad")
+        # what a batched flush needs to run the folds of n queued layers as ONE launch (_flush_wgrads)
+        finish.fold = (w, scale, mean, var, float(eps), b if has_bias else None, sums[C:2 * C] if want_gamma else None,
+                       sums[2 * C:] if want_db else None, sums)
         dx, dw, _ = _conv_backward(ctx.needs_input_grad, x, w, g, stride, padding, want_db=True, add_to_dx=add,
                                    precision=ctx.precision, give_compact=ctx.dx_give_to is not None,
                                    gate=x if ctx.dx_gate else None, w_scale=scale, db_into=sums[:C],

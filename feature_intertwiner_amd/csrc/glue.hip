@@ -525,6 +525,63 @@ __global__ __launch_bounds__(256) void bn_fold_grad_kernel(float *__restrict__ d
     }
 }
 
+// the same for up to FI_WGRAD_BATCH_MAX layers of one geometry (behind fi_conv2d_weight_grad_batch): operand pointers by
+// value in the kernel arguments, blockIdx.y = layer
+struct FoldGradBatch {
+    float *dw[FI_WGRAD_BATCH_MAX];
+    const float *w[FI_WGRAD_BATCH_MAX];
+    const float *s[FI_WGRAD_BATCH_MAX];
+    const float *scale[FI_WGRAD_BATCH_MAX];
+    const float *mean[FI_WGRAD_BATCH_MAX];
+    const float *var[FI_WGRAD_BATCH_MAX];
+    const float *conv_bias[FI_WGRAD_BATCH_MAX];
+    float *dgamma[FI_WGRAD_BATCH_MAX];
+    float *dbias[FI_WGRAD_BATCH_MAX];
+};
+
+__global__ __launch_bounds__(256) void bn_fold_grad_batch_kernel(FoldGradBatch b, float eps, int Cin, int taps, int vec,
+                                                                 int same_order, int dw_tap_major)
+{
+    __shared__ float part[4];
+    const int co = blockIdx.x, K = Cin * taps, l = blockIdx.y;
+    float *__restrict__ drow = b.dw[l] + (size_t)co * K;
+    const float *__restrict__ wrow = b.w[l] + (size_t)co * K;
+    const float sc = b.scale[l][co];
+    float dot = 0.0f;
+    if (vec) {
+        for (int k = threadIdx.x * 4; k < K; k += 1024) {
+            float4 d = *reinterpret_cast<float4 *>(drow + k);
+            const float4 v = *reinterpret_cast<const float4 *>(wrow + k);
+            dot += (d.x * v.x + d.y * v.y) + (d.z * v.z + d.w * v.w);
+            d.x *= sc; d.y *= sc; d.z *= sc; d.w *= sc;
+            *reinterpret_cast<float4 *>(drow + k) = d;
+        }
+    } else {
+        for (int k = threadIdx.x; k < K; k += 256) {
+            int kw = k;
+            if (!same_order) {
+                const int ci = dw_tap_major ? k % Cin : k / taps, tap = dw_tap_major ? k / Cin : k % taps;
+                kw = dw_tap_major ? ci * taps + tap : tap * Cin + ci;
+            }
+            const float d = drow[k];
+            dot += d * wrow[kw];
+            drow[k] = d * sc;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) dot += __shfl_xor(dot, off, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = dot;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float total = (part[0] + part[1]) + (part[2] + part[3]);
+        const float sv = b.s[l][co];
+        const float inv = rsqrtf(b.var[l][co] + eps);
+        const float cb = b.conv_bias[l] ? b.conv_bias[l][co] : 0.0f;
+        if (b.dgamma[l]) atomicAdd(b.dgamma[l] + co, inv * (total + (cb - b.mean[l][co]) * sv));
+        if (b.dbias[l]) atomicAdd(b.dbias[l] + co, sc * sv);
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -720,6 +777,34 @@ int fi_bn_fold_grad(float *dw, const float *w, const float *s, const float *scal
     const int vec = (same_order && ((long)Cin * taps) % 4 == 0 && (uintptr_t)dw % 16 == 0 && (uintptr_t)w % 16 == 0) ? 1 : 0;
     hipLaunchKernelGGL(bn_fold_grad_kernel, dim3((unsigned)Cout), dim3(256), 0, (hipStream_t)stream, dw, w, s, scale, mean,
                        var, eps, conv_bias, dgamma, dbias, Cin, taps, vec, same_order, dw_tap_major);
+    FI_HIP_CHECK(hipGetLastError());
+    return FI_OK;
+}
+
+int fi_bn_fold_grad_batch(float *const *dw, const float *const *w, const float *const *s, const float *const *scale,
+                          const float *const *mean, const float *const *var, float eps, const float *const *conv_bias,
+                          float *const *dgamma, float *const *dbias, int n, int Cout, int Cin, int taps, int dw_tap_major,
+                          int w_tap_major, fi_stream_t stream)
+{
+    FI_REQUIRE(n >= 1 && Cout > 0 && Cin > 0 && taps > 0, "bad sizes");
+    FI_REQUIRE(dw && w && s && scale && mean && var, "null pointer table");
+    const int same_order = (taps == 1 || (dw_tap_major != 0) == (w_tap_major != 0)) ? 1 : 0;
+    for (int i0 = 0; i0 < n; i0 += FI_WGRAD_BATCH_MAX) {
+        const int m = n - i0 < FI_WGRAD_BATCH_MAX ? n - i0 : FI_WGRAD_BATCH_MAX;
+        FoldGradBatch b;
+        int vec = (same_order && ((long)Cin * taps) % 4 == 0) ? 1 : 0;
+        for (int i = 0; i < FI_WGRAD_BATCH_MAX; ++i) {
+            const int j = i0 + (i < m ? i : 0);
+            FI_REQUIRE(dw[j] && w[j] && s[j] && scale[j] && mean[j] && var[j], "null pointer in the batch");
+            b.dw[i] = dw[j]; b.w[i] = w[j]; b.s[i] = s[j]; b.scale[i] = scale[j]; b.mean[i] = mean[j]; b.var[i] = var[j];
+            b.conv_bias[i] = conv_bias ? conv_bias[j] : nullptr;
+            b.dgamma[i] = dgamma ? dgamma[j] : nullptr;
+            b.dbias[i] = dbias ? dbias[j] : nullptr;
+            if ((uintptr_t)dw[j] % 16 != 0 || (uintptr_t)w[j] % 16 != 0) vec = 0;
+        }
+        hipLaunchKernelGGL(bn_fold_grad_batch_kernel, dim3((unsigned)Cout, (unsigned)m), dim3(256), 0, (hipStream_t)stream, b, eps,
+                           Cin, taps, vec, same_order, dw_tap_major);
+    }
     FI_HIP_CHECK(hipGetLastError());
     return FI_OK;
 }

@@ -337,6 +337,12 @@ int fi_relu_mask(const float *dy, const float *y, float *out, long n, fi_stream_
 int fi_bn_fold_grad(float *dw, const float *w, const float *s, const float *scale, const float *mean,
                     const float *var, float eps, const float *conv_bias, float *dgamma, float *dbias, int Cout,
                     int Cin, int taps, int dw_tap_major, int w_tap_major, fi_stream_t stream);
+/* ... for n layers of one geometry in one launch (behind fi_conv2d_weight_grad_batch): HOST arrays of device pointers;
+ * conv_bias / dgamma / dbias may be NULL tables or hold NULL entries. */
+int fi_bn_fold_grad_batch(float *const *dw, const float *const *w, const float *const *s, const float *const *scale,
+                          const float *const *mean, const float *const *var, float eps, const float *const *conv_bias,
+                          float *const *dgamma, float *const *dbias, int n, int Cout, int Cin, int taps, int dw_tap_major,
+                          int w_tap_major, fi_stream_t stream);
 /* Backward of that fused epilogue (eval-mode BatchNorm folded into scale/shift, optional ReLU):
  * g = dy * (y > 0 | 1); dz = g * scale[c]; dshift[c] = sum g; dgamma[c] = sum g*(y-beta[c])/gamma[c].
  * layout 1: dy and y are channels-last [N,HW,C] (dz is still written [N,C,HW]; no residual/g_out).
