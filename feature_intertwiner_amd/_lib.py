@@ -89,6 +89,8 @@ SIGNATURES = {
     "fi_conv1x1_forward_f16w": (c_int, [c_void_p] * 6 + [c_int] * 5 + [c_void_p]),
     "fi_gemm_nt_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "fi_gemm_nt": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "fi_gemm_nt_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "fi_conv2d_forward_live": (c_int, [c_void_p] * 7 + [c_int] * 16 + [c_void_p, c_void_p]),
     "fi_weight_transpose_batch": (c_int, [c_void_p, c_int, ctypes.c_long, c_void_p]),
     "fi_conv3x3_forward_bf16w": (c_int, [c_void_p] * 6 + [c_int] * 7 + [c_void_p]),
     "fi_conv1x1_forward_bf16w": (c_int, [c_void_p] * 6 + [c_int] * 5 + [c_void_p]),

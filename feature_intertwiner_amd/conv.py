@@ -82,7 +82,7 @@ def _dense(w):
 
 
 def _conv_fwd(x, w, b, stride, padding, relu=False, scale=None, residual=None, out_hw=None,
-              out_channels_last=False, w_tap_major=False, flip_taps=False, precision=None, gate=None):
+              out_channels_last=False, w_tap_major=False, flip_taps=False, precision=None, gate=None, live=None):
     """w is [Cout, Cin, R, S].  When Cin % 16 == 0 the kernel's tap-major fast path is used: the
     weight is handed over channels-last ([Cout, R, S, Cin]; a copy of at most a few MB).
     out_channels_last: y is returned in torch.channels_last memory format ([N,OH,OW,Cout] in
@@ -152,6 +152,15 @@ def _conv_fwd(x, w, b, stride, padding, relu=False, scale=None, residual=None, o
                            "fi_conv1x1_forward_bf16w")
             return y
     with torch.cuda.device(x.device):
+        if live is not None and not bf16:
+            # live [1] int32 on the device: only the first live[0] images are real (fi_conv2d_forward_live)
+            _lib.check(L.fi_conv2d_forward_live(_lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(scale), _lib.ptr(residual),
+                                                _lib.ptr(gate), _lib.ptr(y), N, Cin, H, W, Cout, R, S, stride[0], stride[1],
+                                                padding[0], padding[1], 1 if relu else 0, layout,
+                                                OH if out_hw is not None else 0, OW if out_hw is not None else 0,
+                                                1 if out_channels_last else 0, _lib.ptr(live), _lib.current_stream()),
+                       "fi_conv2d_forward_live")
+            return y
         _lib.check(fn(_lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(scale), _lib.ptr(residual), _lib.ptr(gate),
                                        _lib.ptr(y), N, Cin, H, W, Cout,
                                        R, S, stride[0], stride[1], padding[0], padding[1], 1 if relu else 0,
@@ -600,7 +609,12 @@ def _conv_backward(ctx_needs, x, w, dz, stride, padding, want_db=False, add_to_d
             side.wait_event(dz_ready)                      # dz (and x) were complete on the main stream there
             x.record_stream(side)
             dz.record_stream(side)
-        if flags and adopt and WGRAD_BATCH > 1 and hwc and same and Cin % 128 == 0 and \
+        if flags and not first and _WGQ["queues"]:
+            # a further use of a layer in this backward pass (two forward passes before one backward; the dense RPN on five
+            # levels): its first use may still be queued together with the pass that scales dW in place -- run the queue
+            # before this use adds to the slot, and do not queue this one
+            flush_deferred_wgrads()
+        if flags and first and adopt and WGRAD_BATCH > 1 and hwc and same and Cin % 128 == 0 and \
                 (not bf16 or (Cout % 64 == 0 and (R * S == 1 or (R, S, padding) == (3, 3, (1, 1))))) and \
                 N * dz.shape[2] * dz.shape[3] <= WGRAD_BATCH_MAX_PIXELS and _defer_wgrad(
                     (N, Cin, H, W, Cout, R, S, padding, want_db and db is not None, precision if bf16 else None),
@@ -1052,7 +1066,7 @@ class _ConvBnActFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, b, gamma, beta, mean, var, eps, residual, relu, stride, padding, out_cl=False,
-                fold=None, res_grad_to=None, dx_add_from=None, dx_give_to=None, dx_gate=False, out_gate=None):
+                fold=None, res_grad_to=None, dx_add_from=None, dx_give_to=None, dx_gate=False, out_gate=None, live=None):
         _lib.require_cuda(x, w)
         x = x.contiguous().float()
         w = _dense(w.float())
@@ -1066,7 +1080,7 @@ class _ConvBnActFn(torch.autograd.Function):
         res = residual.contiguous().float() if residual is not None else None
         _log_shape(x, w, stride, padding)
         y = _conv_fwd(x, w, shift.contiguous(), stride, padding, relu=relu, scale=scale.contiguous(), residual=res,
-                      out_channels_last=out_cl)
+                      out_channels_last=out_cl, live=live)
         ctx.out_cl = bool(out_cl)
         ctx.precision = _PRECISION
         ctx.res_grad_to, ctx.dx_add_from, ctx.dx_give_to = res_grad_to, dx_add_from, dx_give_to
@@ -1127,7 +1141,7 @@ class _ConvBnActFn(torch.autograd.Function):
             ctx.dx_give_to.value = dx               # picked up (and added) by the backward of the block's first conv
             dx = None
         return (dx, dw, sums[2 * C:] if want_db else None, sums[C:2 * C] if want_gamma else None,
-                dbeta if want_beta else None, None, None, None, g_res) + (None,) * 10
+                dbeta if want_beta else None, None, None, None, g_res) + (None,) * 11
 
     @staticmethod
     def backward(ctx, dy):
@@ -1172,7 +1186,7 @@ class _ConvBnActFn(torch.autograd.Function):
         dbeta = dshift if ctx.needs_input_grad[4] else None
         if not first:                 # a repeated use of the layer: accumulated into the slices autograd already holds
             db = dgamma = dbeta = None
-        return (dx, dw, db, dgamma, dbeta, None, None, None, g_res) + (None,) * 10
+        return (dx, dw, db, dgamma, dbeta, None, None, None, g_res) + (None,) * 11
 
 
 class _ConvBiasActFn(torch.autograd.Function):
@@ -1359,7 +1373,7 @@ def _invalidate_bn_folds(module=None):
 
 
 def conv_bn_act(x, conv, bn, relu=True, residual=None, channels_last_out=False, res_grad_to=None,
-                dx_add_from=None, dx_give_to=None, gate_dx=False):
+                dx_add_from=None, dx_give_to=None, gate_dx=False, live=None):
     """act(bn(conv(x)) [+ residual]) for an eval-mode BatchNorm2d (the reference always evaluates
     BN with running statistics, lib/model.py:265-267).  Falls back to separate ops for a BN in
     training mode or a full-window (GEMM) convolution.  channels_last_out: return the result in
@@ -1375,7 +1389,8 @@ def conv_bn_act(x, conv, bn, relu=True, residual=None, channels_last_out=False, 
         if gemm_path and not bn.training and bn.track_running_stats:
             # [N,C,1,1]: MIOpen's spatial inference BN takes ~0.4 ms on 8 MB here; the affine form is ~10 us
             scale = bn.weight * torch.rsqrt(bn.running_var + bn.eps)
-            y = conv(x) * scale.view(1, -1, 1, 1) + (bn.bias - bn.running_mean * scale).view(1, -1, 1, 1)
+            z = conv(x) if live is None else conv2d(x, conv.weight, conv.bias, conv.stride, conv.padding, live=live)
+            y = z * scale.view(1, -1, 1, 1) + (bn.bias - bn.running_mean * scale).view(1, -1, 1, 1)
         else:
             y = bn(conv(x))
         if residual is not None:
@@ -1389,7 +1404,7 @@ def conv_bn_act(x, conv, bn, relu=True, residual=None, channels_last_out=False, 
     out_gate = Gate() if (relu and track and not out_cl) else None
     y = _ConvBnActFn.apply(x, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                            bn.eps, residual, relu, tuple(conv.stride), tuple(conv.padding), out_cl,
-                           _cached_fold(conv, bn), res_grad_to, dx_add_from, dx_give_to, claimed, out_gate)
+                           _cached_fold(conv, bn), res_grad_to, dx_add_from, dx_give_to, claimed, out_gate, live)
     if out_gate is not None:
         y._fi_gate = out_gate
     return y.contiguous(memory_format=torch.channels_last) if (channels_last_out and not out_cl) else y
@@ -1419,7 +1434,7 @@ def _pad_rows(t, rows):
     return out
 
 
-def _gemm_nt(a, b, bias=None, relu=False, precision="fp32"):
+def _gemm_nt(a, b, bias=None, relu=False, precision="fp32", live=None):
     """act(a [M,K] . b[N,K]^T + bias) -> [M,N]; N % 128 == 0, K % 4 == 0.  fp32: fi_gemm_nt (deterministic split over
     K).  16-bit precisions: the 16-bit weight-gradient kernel (operands rounded on their way into LDS, fp32 atomics
     over the split) when M % 64 == 0, then bias / ReLU."""
@@ -1440,8 +1455,8 @@ def _gemm_nt(a, b, bias=None, relu=False, precision="fp32"):
     ws = torch.empty((int(L.fi_gemm_nt_workspace_bytes(M, N, K)) + 3) // 4, device=a.device, dtype=torch.float32)
     _log_flops("wgrad", M, 1, 1, 2.0 * M * N * K, K, N)
     with torch.cuda.device(a.device):
-        _lib.check(L.fi_gemm_nt(_lib.ptr(a), _lib.ptr(b), _lib.ptr(bias), _lib.ptr(y), M, N, K, 1 if relu else 0,
-                                _lib.ptr(ws), _lib.current_stream()), "fi_gemm_nt")
+        _lib.check(L.fi_gemm_nt_rows(_lib.ptr(a), _lib.ptr(b), _lib.ptr(bias), _lib.ptr(y), M, N, K, 1 if relu else 0,
+                                     _lib.ptr(ws), _lib.ptr(live), _lib.current_stream()), "fi_gemm_nt")
     return y
 
 
@@ -1454,7 +1469,7 @@ def _gemm_nn(a, b, precision="fp32"):
 
 class _LinearFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, b):
+    def forward(ctx, x, w, b, live=None):
         _lib.require_cuda(x, w)
         M, K = x.shape
         N = w.shape[0]
@@ -1464,7 +1479,7 @@ class _LinearFn(torch.autograd.Function):
         xp = _pad_rows(x.float(), Mp)
         wp = _pad_rows(w.float(), Np)
         bp = _pad_rows(b.float(), Np) if b is not None else None
-        y = _gemm_nt(xp, wp, bp, precision=prec)[:M, :N]      # bias added by the split reduction
+        y = _gemm_nt(xp, wp, bp, precision=prec, live=live)[:M, :N]      # bias added by the split reduction
         ctx.save_for_backward(xp, wp)
         ctx.dims = (M, N, K, b is not None)
         ctx.precision = prec
@@ -1484,18 +1499,19 @@ class _LinearFn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             dw = _gemm_nn(dyp.t().contiguous(), xp, ctx.precision)[:N]      # reduction over the padded M
         db = dy.sum(0) if (has_b and ctx.needs_input_grad[2]) else None
-        return dx, dw, db
+        return dx, dw, db, None
 
 
-def linear(x, weight, bias=None):
+def linear(x, weight, bias=None, live=None):
     """F.linear(x [M,K], weight [N,K], bias) on the library's MFMA kernels (see above).  Shapes the kernels do not
     take (K % 4 != 0, a CPU tensor) fall back to F.linear."""
     if x.dim() != 2 or not x.is_cuda or x.shape[1] % 4 != 0 or x.shape[0] == 0 or x.dtype != torch.float32:
         return F.linear(x, weight, bias)
-    return _LinearFn.apply(x, weight, bias)
+    # live [1] int32 (device): only the first live[0] rows of x are real -- the others' outputs are zeros (no graph)
+    return _LinearFn.apply(x, weight, bias, live)
 
 
-def conv2d(x, weight, bias=None, stride=(1, 1), padding=(0, 0), residual=None, gate_dx=False, dx_give_to=None):
+def conv2d(x, weight, bias=None, stride=(1, 1), padding=(0, 0), residual=None, gate_dx=False, dx_give_to=None, live=None):
     """Functional form: conv(x) + bias [+ residual, added in the kernel epilogue].  Full-window kernels are
     matrix products (linear() above).  gate_dx: as conv_bn_act's (True, or the Gate of the tensor x is a view of).
     dx_give_to: a GradBox whose taker flag is set -- the data gradient goes there instead of to autograd (the taker,
@@ -1504,7 +1520,7 @@ def conv2d(x, weight, bias=None, stride=(1, 1), padding=(0, 0), residual=None, g
     gemm = ((x.shape[2], x.shape[3]) == (R, S) and tuple(padding) == (0, 0) and R * S > 1) or \
         (x.shape[2] * x.shape[3] == 1 and R * S == 1)
     if gemm:
-        y = linear(x.reshape(x.shape[0], -1), weight.reshape(weight.shape[0], -1), bias)
+        y = linear(x.reshape(x.shape[0], -1), weight.reshape(weight.shape[0], -1), bias, live)
         y = y.view(x.shape[0], weight.shape[0], 1, 1)
         return y if residual is None else y + residual
     give = dx_give_to if (dx_give_to is not None and dx_give_to.taker and x.is_cuda and torch.is_grad_enabled()) else None

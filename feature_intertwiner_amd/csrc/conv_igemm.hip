@@ -75,6 +75,9 @@ struct ConvGeom {
     unsigned mul_ohw, sft_ohw, mul_ow, sft_ow;   // magic numbers: n / d == umulhi(n, mul) >> sft
     const float *zero;   // device address of g_zero_page (a kernel argument: no GOT load inside the K loop)
     int wg_gx, wg_gy, wg_splits;   // weight gradient with swz: logical grid (column tiles, Cout tiles, pixel splits) of a 1-D launch
+    const int *n_live;  // optional DEVICE count: forward kernels skip tiles whose pixels all belong to images >= *n_live, the
+                        // slab-mode weight gradient (fi_gemm_nt) tiles whose rows are all >= *n_live (a batch of static
+                        // capacity of which only the first *n_live images / rows are real: the Dev stage's big branch)
     long dw_slab; // weight gradient: 0 = all pixel splits add into ONE dW (atomics); > 0 = split s STORES its partial
                   // sums at dw + s * dw_slab (one writer per element: deterministic; the caller reduces the slabs)
 };
@@ -421,6 +424,7 @@ __global__ __launch_bounds__(kThreads, 4) void conv_fwd_kernel(const float *__re
     const int p0 = g.p_base + tile_x * BNT;
     const int OHW = g.OH * g.OW;
     const int HW = g.H * g.W;
+    if (g.n_live && p0 >= *g.n_live * OHW) return;       // every pixel of the tile lies in an image that is not there
 
     // ---- per-thread constants of the B (im2col) gather: one pixel column, 8 k rows ----
     const int bj = tid & (BNT - 1);
@@ -1444,6 +1448,7 @@ __global__ __launch_bounds__(kThreads, 4) void conv_wgrad_vec_kernel(const float
     }
     const int m0 = by * BM;
     const int k0 = bx * BN;                      // 128 columns = 128 input channels of ONE tap
+    if (g.n_live && m0 >= *g.n_live) return;     // fi_gemm_nt: rows past the live count (their slabs are not reduced either)
     const int HW = g.H * g.W;                    // == OH*OW
     const int p_begin = bz * p_per_split;
     const int p_end = min(g.P, p_begin + p_per_split);
@@ -1832,6 +1837,7 @@ int make_geom(ConvGeom &g, int N, int Cin, int H, int W, int Cout, int R, int S,
     g.flip = 0;
     g.swz = 0;
     g.dw_slab = 0;
+    g.n_live = nullptr;
     g.vec_out = 0;
     g.zero = nullptr;      // set by the entry points once the arguments are validated (needs the device)
     g.p_base = 0;
@@ -1912,7 +1918,9 @@ void launch_fwd(const ConvGeom &g_in, const float *x, const float *w, const Epil
     int nx = fi::ceil_div(g.P, BN);
     // XCD-aware order for large compute-bound grids; short-K 1x1 layers are bound by their output
     // stream and small grids by occupancy -- both measured faster in the plain order
-    if (nx >= 512 && (g.R * g.S > 1 || g.K >= 128)) {
+    // (not with a device-side live count: the live tiles are the FIRST ones, and a band per XCD would hand them all to one
+    // or two XCDs)
+    if (nx >= 512 && (g.R * g.S > 1 || g.K >= 128) && !g.n_live) {
         g.swz = 1;
         nx = fi::ceil_div(nx, 8) * 8;
     }
@@ -2264,6 +2272,16 @@ int fi_conv2d_forward_gated(const float *x, const float *weight, const float *bi
                             int Cout, int R, int S, int stride_h, int stride_w, int pad_h, int pad_w, int relu,
                             int weight_layout, int out_h, int out_w, int output_layout, fi_stream_t stream)
 {
+    return fi_conv2d_forward_live(x, weight, bias, scale, residual, gate, y, N, Cin, H, W, Cout, R, S, stride_h, stride_w,
+                                  pad_h, pad_w, relu, weight_layout, out_h, out_w, output_layout, nullptr, stream);
+}
+
+int fi_conv2d_forward_live(const float *x, const float *weight, const float *bias, const float *scale,
+                           const float *residual, const float *gate, float *y, int N, int Cin, int H, int W,
+                           int Cout, int R, int S, int stride_h, int stride_w, int pad_h, int pad_w, int relu,
+                           int weight_layout, int out_h, int out_w, int output_layout, const int32_t *n_live_dev,
+                           fi_stream_t stream)
+{
     ConvGeom g;
     int rc = make_geom(g, N, Cin, H, W, Cout, R, S, stride_h, stride_w, pad_h, pad_w, out_h, out_w);
     if (rc != FI_OK) return rc;
@@ -2284,6 +2302,7 @@ int fi_conv2d_forward_gated(const float *x, const float *weight, const float *bi
     g.flip = (weight_layout == 2) ? 1 : 0;
     g.zero = zero_page();
     FI_REQUIRE(g.zero != nullptr, "zero page lookup failed (no HIP device?)");
+    g.n_live = n_live_dev;        // honoured by conv_fwd_kernel (every instantiation); the patch / 1x1 kernels compute all
     hipStream_t st = (hipStream_t)stream;
 #ifdef FI_PROBE_1X1
     if (getenv("FI_DBG_1X1")) relu |= (int)strtol(getenv("FI_DBG_1X1"), nullptr, 0);
@@ -2523,9 +2542,16 @@ static int wgrad_impl(const float *x, const float *dy, float *dweight, int N, in
 // c[i] = act(sum_s slab_s[i] + bias[i % N]): the ordered reduction of fi_gemm_nt's split-K partial sums
 __global__ __launch_bounds__(256) void gemm_slab_reduce_kernel(const float *__restrict__ ws, int splits, long slab,
                                                                const float *__restrict__ bias, int N, int relu,
-                                                               float *__restrict__ c, long total4)
+                                                               float *__restrict__ c, long total4,
+                                                               const int *__restrict__ n_live, int bm)
 {
+    // rows past the live count (rounded up to the tile height): their tiles were never computed -- zeros, not the slabs
+    const long live4 = n_live ? (long)((*n_live + bm - 1) / bm) * bm * N / 4 : total4;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long)gridDim.x * 256) {
+        if (i >= live4) {
+            *reinterpret_cast<float4 *>(c + 4 * i) = make_float4(0.f, 0.f, 0.f, 0.f);
+            continue;
+        }
         float4 a = *reinterpret_cast<const float4 *>(ws + 4 * i);
         for (int sidx = 1; sidx < splits; ++sidx) {
             const float4 v = *reinterpret_cast<const float4 *>(ws + (size_t)sidx * slab + 4 * i);
@@ -2570,6 +2596,12 @@ size_t fi_gemm_nt_workspace_bytes(int M, int N, int K)
 int fi_gemm_nt(const float *a, const float *b, const float *bias, float *c, int M, int N, int K, int relu,
                float *workspace, fi_stream_t stream)
 {
+    return fi_gemm_nt_rows(a, b, bias, c, M, N, K, relu, workspace, nullptr, stream);
+}
+
+int fi_gemm_nt_rows(const float *a, const float *b, const float *bias, float *c, int M, int N, int K, int relu,
+                    float *workspace, const int32_t *m_live_dev, fi_stream_t stream)
+{
     FI_REQUIRE(a && b && c && workspace, "null pointer");
     FI_REQUIRE(M >= 1 && N >= 1 && K >= 4, "sizes must be positive");
     FI_REQUIRE(N % BN == 0 && K % 4 == 0, "fi_gemm_nt needs N % 128 == 0 and K % 4 == 0");
@@ -2585,6 +2617,7 @@ int fi_gemm_nt(const float *a, const float *b, const float *bias, float *c, int 
     int bm, splits, pps;
     gemm_nt_plan(M, N, K, &bm, &splits, &pps);
     g.dw_slab = (long)M * N;
+    g.n_live = m_live_dev;
     hipStream_t st = (hipStream_t)stream;
     {
         fi::ProfScope prof(FI_K_CONV_WGRAD + (bm == 64 ? 0 : 4) + window_class(1, 1), st);
@@ -2598,7 +2631,7 @@ int fi_gemm_nt(const float *a, const float *b, const float *bias, float *c, int 
     const long blocks = (total4 + 255) / 256;
     fi::ProfScope prof2(FI_K_GEMM_REDUCE, st);
     hipLaunchKernelGGL(gemm_slab_reduce_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, st, workspace,
-                       splits, g.dw_slab, bias, N, relu, c, total4);
+                       splits, g.dw_slab, bias, N, relu, c, total4, m_live_dev, bm);
     FI_HIP_CHECK(hipGetLastError());
     return FI_OK;
 }

@@ -148,6 +148,7 @@ __global__ __launch_bounds__(kThreads) void crop_fwd_kernel(
 
     BoxHeader h;
     if (!load_box(ls, boxes, box_ind, level, box, batch, h)) {
+        if (level && level[box] == -1) return;      // level -1: a row of static capacity that nobody reads -- not even written
         for (int i = tid; i < total; i += kThreads) out[i] = 0.0f;
         if (status && tid == 0 && chunk == 0) atomicOr(status, 1);
         return;
@@ -489,6 +490,7 @@ __global__ __launch_bounds__(kThreads) void crop_fwd_cl_kernel(
 
     BoxHeader h;
     if (!load_box(ls, boxes, box_ind, level, box, batch, h)) {
+        if (level && level[box] == -1) return;      // level -1: a row of static capacity that nobody reads -- not even written
         for (int i = tid; i < total; i += kThreads) out[i] = 0.0f;
         return;
     }

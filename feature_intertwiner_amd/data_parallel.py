@@ -231,10 +231,11 @@ class GradientBuckets(object):
             buf[b.flag_off:b.flag_off + len(had)].copy_(flags)
             piece = buf[b.start:b.end]
             if self.use_stream:
-                self.comm_stream.wait_stream(torch.cuda.current_stream(self.device))
                 from .conv import flush_deferred_wgrads
-                flush_deferred_wgrads()                    # queued (batched) weight gradients of this bucket's layers
-                wg = conv_wgrad_stream(self.device)        # weight gradients of small layers run on their own stream
+                flush_deferred_wgrads()                    # queued (batched) weight gradients of this bucket's layers:
+                                                           # BEFORE the communication stream takes its dependency
+                self.comm_stream.wait_stream(torch.cuda.current_stream(self.device))
+                wg = conv_wgrad_stream(self.device)        # weight gradients on their own stream (conv.WGRAD_SIDE_STREAM...)
                 if wg is not None:
                     self.comm_stream.wait_stream(wg)
                 with torch.cuda.stream(self.comm_stream):

@@ -184,8 +184,8 @@ def meta_loss(cfg, feature_buffer, ot_module, feat_input, reduce_fn=None):
             num, den = num.view(()), den.view(())
         loss = num / den.clamp(min=1)
     else:
-        s_cnt = s_cnt.clone()
-        s_cnt[0, 0] = 0                                                       # no background class
+        # no background class (a scalar assignment `s_cnt[0, 0] = 0` is a synchronising host-to-device copy)
+        s_cnt = s_cnt * _lib.const_tensor([0.0] + [1.0] * (s_cnt.size(1) - 1), s_cnt.device).view(1, -1)
         on = ((s_cnt > 0) & (buf_cnt > 0)).view(-1)[1:].float()               # foreground classes
         SMALL = s_feat[:, 1:].t()                                             # [K-1, F]
         BIG = final_big[:, 1:].t().detach()

@@ -25,7 +25,8 @@ from .roi_pooling.functions.roi_pool import RoIPoolFunction
 
 
 import os as _os
-_BIG_SIDE = _os.environ.get('FI_BIG_SIDE', '1') != '0'      # the graph-less big branch of the Dev stage on the third stream (A/B switch)
+_BIG_SIDE = _os.environ.get('FI_BIG_SIDE', '1') != '0'
+_STATIC_DEV = _os.environ.get('FI_STATIC_DEV', '1') != '0'   # the Dev stage without its host read (Dev.static_shapes; A/B switch)      # the graph-less big branch of the Dev stage on the third stream (A/B switch)
 
 class SamePad2d(nn.Module):
     """TensorFlow 'SAME' padding (lib/sub_module.py:9-33).  `folded=True` means the following
@@ -502,8 +503,23 @@ class Dev(nn.Module):
         level = roi_level(boxes, float(self.image_shape[0] * self.image_shape[1]), self.config.ROIS.ASSIGN_ANCHOR_BASE)
         lv = torch.arange(2, 6, device=level.device, dtype=level.dtype)
         per_level = (level.unsqueeze(0) == lv.unsqueeze(1)).sum(1)                 # [n2, n3, n4, n5]
+        if self.static_shapes(rois):
+            return level, per_level           # stays on the device: forward() never learns the counts (round 4)
         counts_ready = _lib.async_host_read(per_level) if level.is_cuda else (lambda: per_level)
         return level, counts_ready
+
+    def static_shapes(self, rois):
+        """True: the stage runs without its one host read (round 4).  The RoI counts per level size the feature
+        extractor's two batches in the reference (nonzero / .any() per level, lib/sub_module.py:456-541).  Here the small
+        branch takes ALL RoIs (the level-5 rows ride along and are masked: at most one batch tile more than before), and
+        the big branch a batch of static capacity 3 * RoIs -- every (RoI, lower level) pair there can be -- whose live
+        count n3 + 2 n4 + 3 n5 stays on the device: its kernels skip the tiles past it (fi_conv2d_forward_live,
+        fi_gemm_nt_rows), the filler rows are zero crops with class 0.  Needs the graph-less big branch (the defaults
+        DEV.BIG_FEAT_DETACH, no BIG_SUPERVISE), fp32 kernels and a RoI count that is a multiple of 64."""
+        cfg = self.config
+        return bool(_STATIC_DEV and rois.is_cuda and self.use_dev and not cfg.DEV.BASELINE and cfg.DEV.BIG_FEAT_DETACH and
+                    not cfg.DEV.BIG_SUPERVISE and self.roi_type == 'roi_align' and
+                    getattr(cfg.MODEL, "CONV_PRECISION", "fp32") == "fp32" and (rois.size(0) * rois.size(1)) % 64 == 0)
 
     _PERM = {}
 
@@ -547,7 +563,9 @@ class Dev(nn.Module):
         # make-up layer on every level (unless the caller already ran it), then ONE launch per crop size over all levels
         if up_maps is None:
             up_maps = self.make_up_maps(x)
-        n2, n3, n4, n5 = (int(v) for v in counts_ready().tolist())
+        static = torch.is_tensor(counts_ready)          # level_info(): static_shapes() -- the counts stay on the device
+        if not static:
+            n2, n3, n4, n5 = (int(v) for v in counts_ready().tolist())
         group = CropGradGroup()      # both crops' gradients accumulate in ONE set of buffers (no add pass per level)
         pooled = self._crop(up_maps, boxes, box_ind, level, self.pool_size, group)
         if front:
@@ -562,8 +580,11 @@ class Dev(nn.Module):
         # 'small' features of the RoIs on levels 2..4 (levels with meta loss, :434-435), written
         # level-major like the reference's small_output_all / small_gt_all (:583-598): a stable sort by
         # level puts them first, in (level, original index) order
-        n_small = n2 + n3 + n4
         total_box = bs * R
+        if static:
+            return self._forward_static(x, boxes, box_ind, level, counts_ready, roi_cls_gt, pooled, mask_and_feat, inv,
+                                        mask_grad_box, total_box)
+        n_small = n2 + n3 + n4
         # The feature extractor's fully connected stages are matrix products over the rows fed to it; their kernels
         # take row counts that are multiples of 64, so up to 63 further RoIs (the first level-5 ones in the sorted
         # order) ride along.  Their outputs are never read: every use below is restricted to the first n_small rows
@@ -667,6 +688,83 @@ class Dev(nn.Module):
         feat_out = [bf, bcnt,
                     torch.stack(small_feat).unsqueeze(0), torch.stack(small_cnt).unsqueeze(0),
                     bloss, small_output_all, small_gt_all]
+        return pooled, mask_and_feat, feat_out
+
+
+    def _feat_extract_live(self, v, live):
+        """_feat_extract on a batch of static capacity whose first live[0] rows are real (no graph)."""
+        fe = self.feat_extract
+        v = conv_bn_act(v, fe[0], fe[1], relu=True, live=live)
+        v = conv_bn_act(v, fe[3], fe[4], relu=True, live=live)
+        return conv_bn_act(v, fe[6], fe[7], relu=True, live=live)
+
+    def _forward_static(self, x, boxes, box_ind, level, per_level, roi_cls_gt, pooled, mask_and_feat, inv, mask_grad_box,
+                        total_box):
+        """The part of forward() behind the two crops with shapes that do not depend on the RoIs (see static_shapes)."""
+        cfg = self.config
+        K = self.num_classs
+        dev = level.device
+        train_phase = roi_cls_gt is not None
+        order = torch.sort(level, stable=True)[1]                       # level-major, original index inside a level
+        lvl_o = level[order]
+        small_on = lvl_o <= 4                                           # the rows the reference feeds (:583-598)
+        small_output = self._feat_extract(take_rows(mask_and_feat, order if inv is None else inv[order], mask_grad_box))
+        if cfg.DEV.LOSS_CHOICE != 'ot':
+            small_output = self.last_op(small_output)
+        small_output = small_output.view(total_box, -1)
+        small_output_all = torch.where(small_on.unsqueeze(1), small_output, torch.zeros_like(small_output))
+        if not train_phase:
+            return pooled, mask_and_feat, [small_output_all, small_on.float()]
+        gt = roi_cls_gt.reshape(-1).to(torch.int32)
+        gt_o = gt[order]
+        small_gt_all = torch.where(small_on, gt_o, torch.zeros_like(gt_o)).float()
+        small_feat, small_cnt = [], []
+        for lvl in (2, 3, 4):
+            f, c = class_mean(small_output, torch.where(lvl_o == lvl, gt_o, torch.zeros_like(gt_o)), K)
+            small_feat.append(f)
+            small_cnt.append(c)
+        has_small = per_level[:3] > 0                                   # [3] bool, device
+
+        def big_branch():
+            # every (RoI, lower level) pair in (level, RoI) order, compacted to the front of a 3 * RoIs batch
+            pairs = torch.stack([level > lvl for lvl in (2, 3, 4)])                              # [3, N]
+            flat = torch.nonzero_static(pairs.reshape(-1), size=3 * total_box, fill_value=-1).view(-1)
+            valid = flat >= 0
+            flat_c = flat.clamp(min=0)
+            big_idx = flat_c % total_box
+            # (level -1: a row past the live count -- the crop does not even write it, nothing downstream reads it)
+            big_level = torch.where(valid, 2 + flat_c // total_box, torch.full_like(flat_c, -1)).to(torch.int32)
+            live = pairs.sum().to(torch.int32).view(1)
+            with torch.no_grad():
+                big_pooled = self._crop(x, boxes[big_idx], box_ind[big_idx], big_level, self.feat_pool_size, None)
+                big_raw = self._feat_extract_live(big_pooled, live)
+                big_out = self.last_op(big_raw) if cfg.DEV.LOSS_CHOICE != 'ot' else big_raw
+                big_out = big_out.view(3 * total_box, -1)
+                big_gt = gt[big_idx]
+                big_feat, big_cnt = [], []
+                for i, lvl in enumerate((2, 3, 4)):
+                    # a level without small boxes contributes no big statistics either (:456-467)
+                    use = (big_level == lvl) & has_small[i]
+                    f, c = class_mean(big_out, torch.where(use, big_gt, torch.zeros_like(big_gt)), K)
+                    big_feat.append(f)
+                    big_cnt.append(c)
+                return (torch.stack(big_feat).unsqueeze(0).detach(), torch.stack(big_cnt).unsqueeze(0),
+                        small_output.new_zeros(1, 3, 1))
+
+        self.big_done = None
+        if _BIG_SIDE:
+            fork = torch.cuda.Event()
+            fork.record(torch.cuda.current_stream(dev))
+            side3 = _lib.side_stream3(dev)
+            for t in (boxes, box_ind, level, gt, per_level):
+                t.record_stream(side3)
+            ready = _lib.run_on_side_stream(big_branch, after=fork)
+            bf, bcnt, bloss = ready.out
+            self.big_done = ready.done
+        else:
+            bf, bcnt, bloss = big_branch()
+        feat_out = [bf, bcnt, torch.stack(small_feat).unsqueeze(0), torch.stack(small_cnt).unsqueeze(0), bloss,
+                    small_output_all, small_gt_all]
         return pooled, mask_and_feat, feat_out
 
 

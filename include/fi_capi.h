@@ -357,6 +357,16 @@ int fi_bn_act_backward(const float *dy, const float *y, const float *scale, cons
                        const float *beta, const float *residual, int N, int C, int HW, int relu,
                        float *dz, float *g_out, float *dshift, float *dgamma, float *dbias,
                        int layout, int flags, fi_stream_t stream);
+/* fi_conv2d_forward_gated for a batch of STATIC capacity N of which only the first *n_live_dev images are real (a DEVICE
+ * count; NULL = all): tiles whose pixels all lie in images >= *n_live_dev are skipped (their outputs are not written) by
+ * the general kernel (conv_fwd_kernel: the strided layers); the 3x3 / 1x1 stride-1 fast paths compute every image.  The
+ * Dev stage's big branch (lib/sub_module.py:498-535) has a data-dependent number of rows -- n3 + 2 n4 + 3 n5 of up to
+ * 3 * RoIs --, which the reference reads back to the host; here the host never learns it. */
+int fi_conv2d_forward_live(const float *x, const float *weight, const float *bias, const float *scale,
+                           const float *residual, const float *gate, float *y, int N, int Cin, int H, int W,
+                           int Cout, int R, int S, int stride_h, int stride_w, int pad_h, int pad_w, int relu,
+                           int weight_layout, int out_h, int out_w, int output_layout, const int32_t *n_live_dev,
+                           fi_stream_t stream);
 int fi_conv2d_weight_grad(const float *x, const float *dy, float *dweight, int N, int Cin,
                           int H, int W, int Cout, int R, int S, int stride_h, int stride_w,
                           int pad_h, int pad_w, int weight_layout, float *dbias, int flags,
@@ -394,6 +404,10 @@ int fi_conv2d_weight_grad_batch_f16(const float *const *x, const float *const *d
 size_t fi_gemm_nt_workspace_bytes(int M, int N, int K);
 int fi_gemm_nt(const float *a, const float *b, const float *bias, float *c, int M, int N, int K, int relu,
                float *workspace, fi_stream_t stream);
+/* ... with a DEVICE count of live rows (NULL = M): tiles of rows >= *m_live_dev are skipped and those rows of c (from the
+ * count rounded up to the tile height) are written as zeros. */
+int fi_gemm_nt_rows(const float *a, const float *b, const float *bias, float *c, int M, int N, int K, int relu,
+                    float *workspace, const int32_t *m_live_dev, fi_stream_t stream);
 
 /* All layers' W^T for the data-gradient kernel in one launch: for every descriptor, src is
  * [rows][taps][cols] (a weight stored [Cout][R][S][Cin]) and dst becomes [cols][taps][rows]
