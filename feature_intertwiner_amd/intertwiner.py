@@ -104,7 +104,10 @@ class FeatureBuffer(object):
         if active is not None:
             new_buf = torch.where(active, new_buf, self.buffer)
             new_cnt = torch.where(active, new_cnt, self.buffer_cnt)
-        self.buffer, self.buffer_cnt = new_buf, new_cnt
+        # in place: the tensors keep their addresses (a captured step -- hipGraph -- reads and writes the same buffers at
+        # every replay; rebinding would leave the replays on the first step's tensors)
+        self.buffer.copy_(new_buf)
+        self.buffer_cnt.copy_(new_cnt)
         if self.buffer.size(0) == 1:
             return self.buffer[0]
         return (self.buffer * self.buffer_cnt).sum(0) / (self.buffer_cnt.sum(0) + EPS)

@@ -83,15 +83,27 @@ def clip_and_step(optimizer, max_norm):
                         raise _lib.FiError("clip_and_step: gradient of a %s parameter does not share its memory layout"
                                            % (tuple(c["params"][i].shape),))
                     c["contig"][i] = live[i].is_contiguous()
-                host, desc, ev = c["ring"][c["turn"] % len(c["ring"])]
-                c["turn"] += 1
-                ev.synchronize()                 # its previous upload (len(ring) steps ago) has long completed
+                if torch.cuda.is_current_stream_capturing():
+                    # a step being captured into a hipGraph: its upload becomes a copy node that every replay repeats, so
+                    # the staging buffer must stay what it is now -- a buffer of its own, kept for the life of the cache
+                    # entry (and no event query: not permitted on events of a capturing stream)
+                    if not c["spare"]:
+                        raise _lib.FiError("clip_and_step: more graph captures of one optimiser than spare staging buffers")
+                    host = c["spare"].pop()          # (pinned memory cannot be allocated while a stream is capturing)
+                    desc = host.numpy().view(c["desc"].dtype)
+                    c.setdefault("captured", []).append(host)
+                    ev = None
+                else:
+                    host, desc, ev = c["ring"][c["turn"] % len(c["ring"])]
+                    c["turn"] += 1
+                    ev.synchronize()             # its previous upload (len(ring) steps ago) has long completed
                 desc[:] = c["desc"]
                 desc["grad"] = lsig
                 c["desc"] = desc
                 with torch.cuda.device(c["dev"]):
                     c["table"].copy_(host, non_blocking=True)
-                    ev.record()
+                    if ev is not None:
+                        ev.record()
                 c["gsig"], c["lsig"] = sig, lsig
             if [g.is_contiguous() for g in live] == c["contig"]:
                 out = _launch(L, c, max_norm)
@@ -136,6 +148,8 @@ def clip_and_step(optimizer, max_norm):
         table.copy_(ring[0][0], non_blocking=True)
         ring[0][2].record()
     c = _CACHE[optimizer] = {
+        "spare": [torch.empty(desc.nbytes, dtype=torch.uint8).pin_memory() for _ in range(2)]
+        if not torch.cuda.is_current_stream_capturing() else [],
         "dev": dev, "table": table, "ring": ring, "turn": 1, "desc": ring[0][1], "chunks": base, "n": len(entries),
         "state": optimizer.state, "hyper": _hyper(optimizer), "all": every, "absent": [p.grad is None for p in every],
         "params": [e[0] for e in entries], "bufs": [e[2] for e in entries if e[2] is not None],
