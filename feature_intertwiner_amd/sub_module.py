@@ -756,7 +756,11 @@ class Dev(nn.Module):
             fork = torch.cuda.Event()
             fork.record(torch.cuda.current_stream(dev))
             side3 = _lib.side_stream3(dev)
-            for t in (boxes, box_ind, level, gt, per_level):
+            # every tensor of THIS stream that the closure reads on the third one: without the mark the allocator may hand
+            # a freed block (has_small is a local of this method) to the next main-stream tensor while the third stream
+            # still reads it -- the class counts of a level went missing that way in the two-pass reference of
+            # tests/test_gpu_data_parallel.py
+            for t in (boxes, box_ind, level, gt, per_level, has_small):
                 t.record_stream(side3)
             ready = _lib.run_on_side_stream(big_branch, after=fork)
             bf, bcnt, bloss = ready.out
