@@ -41,4 +41,8 @@ timeout 200 python scripts/host_time.py 2>&1 | grep -v amdgpu | tail -8 > $O/${R
 # round 4: the short-K 1x1 probe needs a probe build (FI_EXTRA_HIPCC_FLAGS=-DFI_PROBE_1X1) and is run separately (scripts/c4_probe.sh);
 # what a batched weight-gradient launch reaches
 timeout 200 python scripts/wg_batch_probe.py 2>&1 | grep "^{" > $O/${R}_wgrad_batch_probe.txt
+# GPU idle time between kernels (union over streams) from a kernel trace of the default command; the whole step as one hipGraph
+rm -rf /tmp/px; ( cd /tmp && timeout 400 rocprofv3 --kernel-trace --output-format csv -d /tmp/px -o kt -- python $GRAFT_REPO_ROOT/bench.py --steps 6 --warmup 2 --profile-steps 0 --no-cpu-baseline --no-pmc --no-dense-reference > /dev/null 2>&1 )
+f=$(find /tmp/px -name 'kt_kernel_trace.csv' | head -1); python scripts/gpu_idle.py $f > $O/${R}_gpu_idle.txt 2>&1
+timeout 300 python scripts/graph_probe.py 2>&1 | grep -v amdgpu > $O/${R}_graph_probe.txt
 ls -la $O | tail -40
