@@ -89,6 +89,10 @@ SIGNATURES = {
     "fi_conv1x1_forward_f16w": (c_int, [c_void_p] * 6 + [c_int] * 5 + [c_void_p]),
     "fi_gemm_nt_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "fi_gemm_nt": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "fi_conv2d_forward_live_bf16": (c_int, [c_void_p] * 7 + [c_int] * 16 + [c_void_p, c_void_p]),
+    "fi_conv2d_forward_live_f16": (c_int, [c_void_p] * 7 + [c_int] * 16 + [c_void_p, c_void_p]),
+    "fi_conv2d_weight_grad_rows_bf16": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 12 + [c_void_p, c_void_p]),
+    "fi_conv2d_weight_grad_rows_f16": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 12 + [c_void_p, c_void_p]),
     "fi_gemm_nt_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "fi_conv2d_forward_live": (c_int, [c_void_p] * 7 + [c_int] * 16 + [c_void_p, c_void_p]),
     "fi_weight_transpose_batch": (c_int, [c_void_p, c_int, ctypes.c_long, c_void_p]),
@@ -315,14 +319,28 @@ def side_stream3(device=None):
     return side
 
 
-def run_on_side_stream(fn, *args, after=None):
+def _mark_stream(o, stream):
+    """record_stream on every CUDA tensor in o (nested tuples / lists): a tensor that a stream OTHER than the one it
+    was allocated on reads must be marked, or the caching allocator may hand its block to the next tensor of the
+    allocating stream the moment Python drops it -- while the reader's kernels are still queued."""
+    if torch.is_tensor(o):
+        if o.is_cuda:
+            o.record_stream(stream)
+    elif isinstance(o, (tuple, list)):
+        for e in o:
+            _mark_stream(e, stream)
+
+
+def run_on_side_stream(fn, *args, after=None, reads=()):
     """Run fn(*args) (network-independent small kernels, e.g. RPN target generation) on a second stream so that
     its launch-latency-bound kernels interleave with the convolutions of the current stream.  Returns a
     function that makes the current stream wait for the result and returns it (a tuple/list of tensors or a
     tensor).  Inputs must already be complete on the current stream when this is called -- or, with `after` (an
     event recorded on the current stream EARLIER), at that event: the work then starts there, next to whatever the
     current stream has queued behind the event (a third stream, so that it does not queue behind run_on_side_stream
-    work either)."""
+    work either).  Tensor arguments, and the tensors a closure reads (`reads`), are marked as used on the side stream:
+    autograd keeps some of them for the backward pass of the side stream's ops and frees them, at CPU time, when it
+    enqueues that op -- possibly before the side stream has run it."""
     dev = torch.cuda.current_device()
     cur = torch.cuda.current_stream(dev)
     pool = _SIDE2 if after is None else _SIDE3
@@ -333,6 +351,8 @@ def run_on_side_stream(fn, *args, after=None):
         side.wait_stream(cur)
     else:
         side.wait_event(after)
+    _mark_stream(args, side)
+    _mark_stream(reads, side)
     with torch.cuda.stream(side):
         out = fn(*args)
     done = torch.cuda.Event()
@@ -341,14 +361,7 @@ def run_on_side_stream(fn, *args, after=None):
     def wait():
         now = torch.cuda.current_stream(dev)
         now.wait_event(done)
-        def mark(o):
-            if torch.is_tensor(o):
-                if o.is_cuda:
-                    o.record_stream(now)  # allocated from the side stream's pool, consumed here
-            elif isinstance(o, (tuple, list)):
-                for e in o:
-                    mark(e)
-        mark(out)
+        _mark_stream(out, now)          # allocated from the side stream's pool, consumed here
         return out
     wait.out, wait.done = out, done          # for consumers on the SAME side stream (ordered there): no wait needed
     return wait

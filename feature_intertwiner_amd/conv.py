@@ -152,6 +152,13 @@ def _conv_fwd(x, w, b, stride, padding, relu=False, scale=None, residual=None, o
                            "fi_conv1x1_forward_bf16w")
             return y
     with torch.cuda.device(x.device):
+        if live is not None and bf16:
+            _lib.check(_lowp_fn(L, "conv2d_forward_live", prec)(
+                _lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(scale), _lib.ptr(residual), _lib.ptr(gate), _lib.ptr(y), N, Cin,
+                H, W, Cout, R, S, stride[0], stride[1], padding[0], padding[1], 1 if relu else 0, layout,
+                OH if out_hw is not None else 0, OW if out_hw is not None else 0, 1 if out_channels_last else 0,
+                _lib.ptr(live), _lib.current_stream()), "fi_conv2d_forward_live_16")
+            return y
         if live is not None and not bf16:
             # live [1] int32 on the device: only the first live[0] images are real (fi_conv2d_forward_live)
             _lib.check(L.fi_conv2d_forward_live(_lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(scale), _lib.ptr(residual),
@@ -1445,9 +1452,15 @@ def _gemm_nt(a, b, bias=None, relu=False, precision="fp32", live=None):
         y = torch.empty((M, N), device=a.device, dtype=torch.float32)
         _log_flops("bf16_wgrad", M, 1, 1, 2.0 * M * N * K)
         with torch.cuda.device(a.device):
-            _lib.check(_lowp_fn(L, "conv2d_weight_grad", precision)(_lib.ptr(b), _lib.ptr(a), _lib.ptr(y), 1, N, 1, K, M,
-                                                                    1, 1, 1, 1, 0, 0, 0, _lib.current_stream()),
-                       "fi_conv2d_weight_grad_16 (gemm)")
+            if live is not None:
+                _lib.check(_lowp_fn(L, "conv2d_weight_grad_rows", precision)(_lib.ptr(b), _lib.ptr(a), _lib.ptr(y), 1, N, 1, K,
+                                                                             M, 1, 1, 1, 1, 0, 0, 0, _lib.ptr(live),
+                                                                             _lib.current_stream()),
+                           "fi_conv2d_weight_grad_rows_16 (gemm)")
+            else:
+                _lib.check(_lowp_fn(L, "conv2d_weight_grad", precision)(_lib.ptr(b), _lib.ptr(a), _lib.ptr(y), 1, N, 1, K, M,
+                                                                        1, 1, 1, 1, 0, 0, 0, _lib.current_stream()),
+                           "fi_conv2d_weight_grad_16 (gemm)")
         if bias is not None:
             y = y + bias
         return torch.relu_(y) if relu else y

@@ -59,6 +59,8 @@ struct Geom {
     int P;          // N*OH*OW
     int flip;       // taps of the weight applied in reverse order (data gradient)
     int out_nhwc;
+    const int *n_live;   // optional DEVICE count of real images (forward) / rows (weight gradient used as a GEMM): tiles that
+                         // lie completely past it are skipped -- see fi_conv2d_forward_live in csrc/conv_igemm.hip
 };
 
 struct Epi {
@@ -156,6 +158,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_bf16_fwd_kernel(const float 
     if (pt >= ptiles) return;
     const int m0 = (seq % mtiles) * BM;
     const int p0 = pt * TN;
+    if (g.n_live && p0 >= *g.n_live * g.OH * ((g.OW + 3) >> 2) * 4) return;      // (virtual pixels: rows padded to quads)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -1404,6 +1407,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_bf16_wgrad_flat_kernel(const
     const int tl = idx - bz * tiles_per_split;
     const int by = tl / mtiles, bx = tl - by * mtiles;
     const int m0 = bx * BM;
+    if (g.n_live && m0 >= *g.n_live) return;             // the kernel as a GEMM (conv.linear): rows past the live count
     const int tap = by / cin_tiles;
     const int ci0 = (by - tap * cin_tiles) * BNC;
     const int dr = K3 ? tap / 3 - 1 : 0, ds = K3 ? tap - (tap / 3) * 3 - 1 : 0;
@@ -1654,6 +1658,17 @@ int FI16(fi_conv2d_forward_gated, )(const float *x, const float *weight, const f
                                  int Cout, int R, int S, int stride_h, int stride_w, int pad_h, int pad_w, int relu,
                                  int weight_layout, int out_h, int out_w, int output_layout, fi_stream_t stream)
 {
+    return FI16(fi_conv2d_forward_live, )(x, weight, bias, scale, residual, gate, y, N, Cin, H, W, Cout, R, S, stride_h,
+                                          stride_w, pad_h, pad_w, relu, weight_layout, out_h, out_w, output_layout, nullptr,
+                                          stream);
+}
+
+int FI16(fi_conv2d_forward_live, )(const float *x, const float *weight, const float *bias, const float *scale,
+                                const float *residual, const float *gate, float *y, int N, int Cin, int H, int W,
+                                int Cout, int R, int S, int stride_h, int stride_w, int pad_h, int pad_w, int relu,
+                                int weight_layout, int out_h, int out_w, int output_layout, const int32_t *n_live_dev,
+                                fi_stream_t stream)
+{
     Geom g;
     int rc = make_geom(g, N, Cin, H, W, Cout, R, S, stride_h, stride_w, pad_h, pad_w, out_h, out_w);
     if (rc != FI_OK) return rc;
@@ -1668,6 +1683,7 @@ int FI16(fi_conv2d_forward_gated, )(const float *x, const float *weight, const f
     FI_REQUIRE(((uintptr_t)weight % 16) == 0, "weights must be 16-byte aligned");
     g.flip = weight_layout == 2;
     g.out_nhwc = output_layout == 1;
+    g.n_live = n_live_dev;               // honoured by conv_bf16_fwd_kernel; the patch kernel computes every image
     const Epi ep = {bias, scale, residual, relu, gate};
     hipStream_t st = (hipStream_t)stream;
     // 3x3 / stride 1 / pad 1 on maps at least 16 columns wide (whole 4-column groups): input patch in LDS
@@ -1812,6 +1828,20 @@ int FI16(fi_conv2d_weight_grad_db, )(const float *x, const float *dy, float *dwe
                         nullptr);
 }
 
+// the weight gradient used as a GEMM (conv.linear on the 16-bit kernels: dweight [Cout = rows][Cin]) with a DEVICE count of
+// live rows: row tiles past it are skipped and stay at the zeros the call fills dweight with
+static const int32_t *g_rows_live = nullptr;      // (set around one launch by the entry point below; host-side only)
+int FI16(fi_conv2d_weight_grad_rows, )(const float *x, const float *dy, float *dweight, int N, int Cin, int H, int W,
+                                    int Cout, int R, int S, int stride_h, int stride_w, int pad_h, int pad_w, int flags,
+                                    const int32_t *rows_live_dev, fi_stream_t stream)
+{
+    g_rows_live = rows_live_dev;
+    const int rc = wgrad16_impl(x, dy, dweight, nullptr, N, Cin, H, W, Cout, R, S, stride_h, stride_w, pad_h, pad_w, flags,
+                                stream, nullptr);
+    g_rows_live = nullptr;
+    return rc;
+}
+
 // n weight gradients of one geometry in one launch (see fi_conv2d_weight_grad_batch); loops when the geometry is not
 // the flat kernel's or the outputs are not pre-zeroed
 int FI16(fi_conv2d_weight_grad_batch, )(const float *const *x, const float *const *dy, float *const *dweight,
@@ -1863,6 +1893,7 @@ static int wgrad16_impl(const float *x, const float *dy, float *dweight, float *
     int rc = make_geom(g, N, Cin, H, W, Cout, R, S, stride_h, stride_w, pad_h, pad_w, 0, 0);
     if (rc != FI_OK) return rc;
     FI_REQUIRE(x && dy && dweight, "null pointer");
+    g.n_live = g_rows_live;              // only the flat kernel reads it
     hipStream_t st = (hipStream_t)stream;
     const int RS = R * S;
     if (!(flags & FI_OUTPUTS_ZEROED)) {

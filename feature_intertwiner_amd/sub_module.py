@@ -514,12 +514,11 @@ class Dev(nn.Module):
         branch takes ALL RoIs (the level-5 rows ride along and are masked: at most one batch tile more than before), and
         the big branch a batch of static capacity 3 * RoIs -- every (RoI, lower level) pair there can be -- whose live
         count n3 + 2 n4 + 3 n5 stays on the device: its kernels skip the tiles past it (fi_conv2d_forward_live,
-        fi_gemm_nt_rows), the filler rows are zero crops with class 0.  Needs the graph-less big branch (the defaults
-        DEV.BIG_FEAT_DETACH, no BIG_SUPERVISE), fp32 kernels and a RoI count that is a multiple of 64."""
+        fi_gemm_nt_rows and their 16-bit twins), the filler rows are never written and carry class 0.  Needs the graph-less big
+        branch (the defaults DEV.BIG_FEAT_DETACH, no BIG_SUPERVISE) and a RoI count that is a multiple of 64."""
         cfg = self.config
         return bool(_STATIC_DEV and rois.is_cuda and self.use_dev and not cfg.DEV.BASELINE and cfg.DEV.BIG_FEAT_DETACH and
-                    not cfg.DEV.BIG_SUPERVISE and self.roi_type == 'roi_align' and
-                    getattr(cfg.MODEL, "CONV_PRECISION", "fp32") == "fp32" and (rois.size(0) * rois.size(1)) % 64 == 0)
+                    not cfg.DEV.BIG_SUPERVISE and self.roi_type == 'roi_align' and (rois.size(0) * rois.size(1)) % 64 == 0)
 
     _PERM = {}
 

@@ -48,11 +48,15 @@ def compute_loss(model, inputs, do_meta=True, world_size=1, reduce_fn=None):
             # backward of these ops on the stream their forward ran on, with the joins it needs).  Data parallel: the
             # statistics all-reduce is a rendezvous of all ranks and stays on the main stream.
             model._stats_ready = None
-            meta = _run_on_side_stream(lambda: model.meta_loss(feats, reduce_fn=None), after=fork)()
+            # (`reads`: the statistics were allocated on this stream; the side stream's ops keep some for their backward)
+            meta = _run_on_side_stream(lambda: model.meta_loss(feats, reduce_fn=None), after=fork, reads=feats)()
         else:
             big_done = getattr(getattr(model, "dev_roi", None), "big_done", None)
             if big_done is not None:          # the big branch ran on the third stream (Dev.forward)
-                torch.cuda.current_stream(big_feat.device).wait_event(big_done)
+                here = torch.cuda.current_stream(big_feat.device)
+                here.wait_event(big_done)
+                big_feat.record_stream(here)
+                big_cnt.record_stream(here)
             meta = model.meta_loss(feats, reduce_fn=reduce_fn)
         meta = torch.where(meta < 0, torch.zeros_like(meta), meta)       # workflow.py:196-200
         meta = meta * cfg.DEV.LOSS_FAC if do_meta else torch.zeros_like(meta)
@@ -97,7 +101,7 @@ def train_step(model, optimizer, inputs, do_meta=True, grad_sync=None, world_siz
     return terms
 
 
-def compare_backward_forms(model, inputs, do_meta=True, generator_seed=3, skip=None):
+def compare_backward_forms(model, inputs, do_meta=True, generator_seed=3, skip=None, detail=0, forms=("default", "dense")):
     """Differential check of the default backward pass against its DENSE form on the same weights, the same inputs and
     the same random draws (no optimiser step; the intertwiner history buffer is restored between the two passes).
 
@@ -110,7 +114,7 @@ def compare_backward_forms(model, inputs, do_meta=True, generator_seed=3, skip=N
     Returns {"loss": (default, dense), "loss_rel": |difference| / |dense|, "max_rel_dev": the largest, over parameters,
     of max|g_default - g_dense| / max|g_dense|, "worst": its parameter, "params": parameters compared,
     "none_sets_equal": the same parameters have no gradient in both forms}.  skip(name) -> True leaves a parameter out
-    of max_rel_dev."""
+    of max_rel_dev; detail=k adds "table": the k largest deviations as (name, deviation, max|g_default|, max|g_dense|)."""
     from . import conv as C
     keep = (C.GATES, C._UNSCALED_BACKWARD)
     fb = model.feature_buffer
@@ -123,7 +127,7 @@ def compare_backward_forms(model, inputs, do_meta=True, generator_seed=3, skip=N
     dev = next(model.parameters()).device
     out = {}
     try:
-        for form in ("default", "dense"):
+        for slot, form in zip(("default", "dense"), forms):     # (forms=("default", "default"): run-to-run repeatability)
             C.GATES = C._UNSCALED_BACKWARD = (form == "default")
             if model.feature_buffer is not None and saved_fb is not None:
                 model.feature_buffer.buffer, model.feature_buffer.buffer_cnt = saved_fb[0].clone(), saved_fb[1].clone()
@@ -142,7 +146,7 @@ def compare_backward_forms(model, inputs, do_meta=True, generator_seed=3, skip=N
                 join()
             if dev.type == "cuda":
                 torch.cuda.synchronize(dev)
-            out[form] = (float(loss.detach()),
+            out[slot] = (float(loss.detach()),
                          {n: (None if p.grad is None else p.grad.detach().clone()) for n, p in model.named_parameters()})
     finally:
         C.GATES, C._UNSCALED_BACKWARD = keep
@@ -152,15 +156,20 @@ def compare_backward_forms(model, inputs, do_meta=True, generator_seed=3, skip=N
         for p in model.parameters():
             p.grad = None
     (l_a, g_a), (l_b, g_b) = out["default"], out["dense"]
-    worst, worst_name, n = 0.0, None, 0
+    worst, worst_name, n, table = 0.0, None, 0, []
     for name, ref in g_b.items():
         got = g_a[name]
         if ref is None or got is None or (skip is not None and skip(name)):
             continue
         n += 1
         dev_rel = float((got - ref).abs().max()) / (float(ref.abs().max()) + 1e-30)
+        if detail:
+            table.append((name, dev_rel, float(got.abs().max()), float(ref.abs().max())))
         if dev_rel > worst:
             worst, worst_name = dev_rel, name
     none_equal = {k for k, v in g_a.items() if v is None} == {k for k, v in g_b.items() if v is None}
-    return {"loss": (l_a, l_b), "loss_rel": abs(l_a - l_b) / (abs(l_b) + 1e-30), "max_rel_dev": worst,
-            "worst": worst_name, "params": n, "none_sets_equal": none_equal}
+    res = {"loss": (l_a, l_b), "loss_rel": abs(l_a - l_b) / (abs(l_b) + 1e-30), "max_rel_dev": worst,
+           "worst": worst_name, "params": n, "none_sets_equal": none_equal}
+    if detail:
+        res["table"] = sorted(table, key=lambda r: -r[1])[:detail]
+    return res

@@ -467,6 +467,26 @@ int fi_stride2_interleave_gated(const float *c00, const float *c01, const float 
                                 const float *add, const float *gate, float *dx, long planes, int height, int width,
                                 fi_stream_t stream);
 
+/* The live-count entry points on the 16-bit kernels (see fi_conv2d_forward_live / fi_gemm_nt_rows): the forward of a
+ * static-capacity batch, and the weight-gradient kernel used as the GEMM of conv.linear (dweight [Cout = rows][Cin], zero
+ * filled by the call unless FI_OUTPUTS_ZEROED) with a device count of live rows. */
+int fi_conv2d_forward_live_bf16(const float *x, const float *weight, const float *bias, const float *scale,
+                                const float *residual, const float *gate, float *y, int N, int Cin, int H, int W,
+                                int Cout, int R, int S, int stride_h, int stride_w, int pad_h, int pad_w, int relu,
+                                int weight_layout, int out_h, int out_w, int output_layout, const int32_t *n_live_dev,
+                                fi_stream_t stream);
+int fi_conv2d_forward_live_f16(const float *x, const float *weight, const float *bias, const float *scale,
+                               const float *residual, const float *gate, float *y, int N, int Cin, int H, int W,
+                               int Cout, int R, int S, int stride_h, int stride_w, int pad_h, int pad_w, int relu,
+                               int weight_layout, int out_h, int out_w, int output_layout, const int32_t *n_live_dev,
+                               fi_stream_t stream);
+int fi_conv2d_weight_grad_rows_bf16(const float *x, const float *dy, float *dweight, int N, int Cin, int H, int W,
+                                    int Cout, int R, int S, int stride_h, int stride_w, int pad_h, int pad_w, int flags,
+                                    const int32_t *rows_live_dev, fi_stream_t stream);
+int fi_conv2d_weight_grad_rows_f16(const float *x, const float *dy, float *dweight, int N, int Cin, int H, int W,
+                                   int Cout, int R, int S, int stride_h, int stride_w, int pad_h, int pad_w, int flags,
+                                   const int32_t *rows_live_dev, fi_stream_t stream);
+
 /* ------------------------------------------------------------------------
  * Target generation of one training step.
  * fi_rpn_targets: lib/layers.py:439-604 (generate_target) for a whole minibatch -- IoU of every anchor with the image's

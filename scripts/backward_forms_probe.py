@@ -1,0 +1,45 @@
+"""Where do the default and the dense backward forms differ?  The headline model after K real train steps, the
+differential check of workflow.compare_backward_forms with its table of the largest deviations.
+    python scripts/backward_forms_probe.py [--steps 8] [--cfg5]"""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from feature_intertwiner_amd.config import make_config
+from feature_intertwiner_amd.model import MaskRCNN
+from feature_intertwiner_amd.synthetic import SyntheticProposals, synthetic_batch
+from feature_intertwiner_amd.workflow import compare_backward_forms, set_optimizer, train_step
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--steps", type=int, default=8)
+ap.add_argument("--cfg5", action="store_true")
+ap.add_argument("--repeat", type=int, default=2)
+ap.add_argument("--self", action="store_true", help="default form against itself (run-to-run repeatability)")
+a = ap.parse_args()
+dev = torch.device("cuda:0")
+torch.manual_seed(2000)
+if a.cfg5:
+    cfg = make_config("resnet101", 1344, 2, 1000, dev_switch=True, loss_choice="ot", ot_L=50, conv_precision="bf16")
+    size, bs = 1344, 2
+else:
+    cfg = make_config("resnet101", 1024, 4, 512, dev_switch=True, loss_choice="ot", ot_L=50)
+    size, bs = 1024, 4
+model = MaskRCNN(cfg).to(dev)
+opt = set_optimizer(model, cfg.TRAIN)
+batch = synthetic_batch(bs, size, device=dev, seed=2000)
+model.external_proposals = SyntheticProposals(batch[2], size, seed=7)
+model.generator = torch.Generator(device=dev).manual_seed(11)
+for k in range(a.steps):
+    train_step(model, opt, list(batch))
+for rep in range(a.repeat):
+    r = compare_backward_forms(model, batch, detail=60, forms=("default", "default") if a.self else ("default", "dense"))
+    print("pass", rep, "loss_rel %.3g" % r["loss_rel"], "max_rel_dev %.3g" % r["max_rel_dev"], r["worst"], flush=True)
+    print("   loss", "%.9g %.9g" % tuple(r["loss"]))
+    for row in r["table"]:
+        if row[1] < 1e-4 and not row[0].startswith("ot_loss"):
+            continue
+        print("   %-44s dev %.3g   |g| %.4g   |g_dense| %.4g" % row, flush=True)
+    train_step(model, opt, list(batch))
