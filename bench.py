@@ -654,15 +654,20 @@ def _main():
     backward_check = None
     if world == 1 and sync is None and not args.dense_backward and not args.no_dense_reference:
         # (not with the data-parallel engine attached: its autograd hooks expect begin() / sync() around a backward pass)
-        from feature_intertwiner_amd.workflow import compare_backward_forms
+        from feature_intertwiner_amd.workflow import check_backward_forms
         lowp = args.conv_precision != "fp32"
-        r = compare_backward_forms(model, batch, skip=(lambda n: n.startswith("ot_loss") or
-                                                       n.startswith("dev_roi.feat_extract")) if lowp else None)
+        r = check_backward_forms(model, batch, bar=6e-2 if lowp else 2e-5,
+                                 skip=(lambda n: n.startswith("ot_loss") or n.startswith("dev_roi.feat_extract")) if lowp else None)
         backward_check = {"max_rel_dev": float("%.3g" % r["max_rel_dev"]), "worst": r["worst"], "params": r["params"],
                           "loss_rel": float("%.3g" % r["loss_rel"]), "none_sets_equal": r["none_sets_equal"],
+                          "attempts": r["attempts"], "boundary_events": [float("%.3g" % v) for v in r["boundary_events"]],
                           "what": "one backward pass in the default form and one in the dense form "
-                                  "(workflow.compare_backward_forms) after the timed steps: max over parameters of "
-                                  "max|g - g_dense| / max|g_dense|"}
+                                  "(workflow.check_backward_forms) after the timed steps: max over parameters of "
+                                  "max|g - g_dense| / max|g_dense|; boundary_events: passes set aside because one "
+                                  "pre-activation of the RPN's shared convolution fell on the other side of its ReLU "
+                                  "(the default form evaluates it at the sampled anchors as a matrix product -- another "
+                                  "summation order), recognised by its footprint (single channels of rpn.conv_shared) and "
+                                  "repeated with other sampled anchors"}
         step()                                  # plans / W^T tables back in the default form
         torch.cuda.synchronize()
     # ---- BASELINE configs[4], single-GPU slice, on the driver's record too (outside the timed region) -----------------

@@ -101,7 +101,8 @@ def train_step(model, optimizer, inputs, do_meta=True, grad_sync=None, world_siz
     return terms
 
 
-def compare_backward_forms(model, inputs, do_meta=True, generator_seed=3, skip=None, detail=0, forms=("default", "dense")):
+def compare_backward_forms(model, inputs, do_meta=True, generator_seed=3, skip=None, detail=0, forms=("default", "dense"),
+                           keep_gradients=False):
     """Differential check of the default backward pass against its DENSE form on the same weights, the same inputs and
     the same random draws (no optimiser step; the intertwiner history buffer is restored between the two passes).
 
@@ -170,6 +171,33 @@ def compare_backward_forms(model, inputs, do_meta=True, generator_seed=3, skip=N
     none_equal = {k for k, v in g_a.items() if v is None} == {k for k, v in g_b.items() if v is None}
     res = {"loss": (l_a, l_b), "loss_rel": abs(l_a - l_b) / (abs(l_b) + 1e-30), "max_rel_dev": worst,
            "worst": worst_name, "params": n, "none_sets_equal": none_equal}
+    # The one legitimate discontinuity between the forms: the default form evaluates the RPN's shared 3 x 3 convolution
+    # at the sampled anchors as a matrix product (RPN.forward_rows: another summation order than the dense kernel), so a
+    # pre-activation within rounding of zero can fall on the other side of its ReLU.  One (anchor, channel) mask bit
+    # then differs: the whole gradient of that channel at that anchor -- 1e-3..1e-2 of the channel's bias gradient, and
+    # what it sends down the backbone.  Recognisable by its footprint: single channels of rpn.conv_shared.
+    for name, ref in g_b.items():
+        if name.endswith("rpn.conv_shared.bias") and ref is not None and g_a[name] is not None:
+            d = (g_a[name] - ref).abs() / (ref.abs().max() + 1e-30)
+            res["rpn_relu_boundary_channels"] = int((d > 1e-4).sum())
     if detail:
         res["table"] = sorted(table, key=lambda r: -r[1])[:detail]
+    if keep_gradients:
+        res["gradients"] = (g_a, g_b)
     return res
+
+
+def check_backward_forms(model, inputs, bar=2e-5, attempts=3, **kw):
+    """compare_backward_forms with the RPN's ReLU-boundary events (see there) taken out: when the comparison misses
+    `bar` and the footprint is that of an event (1-2 single channels of rpn.conv_shared), it is repeated with other
+    random draws (other sampled anchors), at most `attempts` times.  Returns the last result plus "attempts" and
+    "boundary_events" (the max_rel_dev of the passes that were set aside)."""
+    events = []
+    for k in range(attempts):
+        r = compare_backward_forms(model, inputs, generator_seed=3 + k, **kw)
+        if r["max_rel_dev"] <= bar or not (1 <= r.get("rpn_relu_boundary_channels", 0) <= 2):
+            break
+        events.append(r["max_rel_dev"])
+    r["attempts"] = len(events) + 1
+    r["boundary_events"] = events
+    return r

