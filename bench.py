@@ -915,7 +915,7 @@ def _main():
         }
         if world > 1 or force_dp:
             out["data_parallel"] = {
-                "engine": "one process per GPU; gradients live in one arena per rank and every ~25 MB bucket is a "
+                "engine": "one process per GPU; gradients live in one arena per rank and every ~64 MB bucket is a "
                           "contiguous slice of it, all-reduced IN PLACE on a side HIP stream from autograd hooks; one "
                           "~1 MB all-reduce of the intertwiner class statistics in forward",
                 "buckets": len(sync.buckets), "bucket_bytes": sync.bucket_bytes(),

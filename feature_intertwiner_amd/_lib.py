@@ -297,25 +297,85 @@ def async_host_read(t):
 
 _SIDE = {}
 _SIDE2 = {}
+_SIDE3 = {}
+
+# ---- streams that really run next to each other -----------------------------------------------------------------------
+# A process gets GPU_MAX_HW_QUEUES hardware queues (default 4); a HIP stream is bound to one of them at its first use,
+# the least referenced one once all exist, and kernels of two streams on ONE queue run one after the other -- worse, a
+# stream that mostly holds waits (the gradient buckets' communication stream) parks its barrier packets in front of
+# whatever shares its queue.  Which streams collide depends on how many streams the process group, RCCL and torch used
+# before (scripts/stream_queues.py prints the map): with the data-parallel engine attached the third stream used to land
+# on the communication stream's queue (+3 ms per step).  So a stream is PICKED: candidates are bound by a first launch,
+# then a short spin kernel on each stream already in use must be overtaken by a kernel on the candidate.
+PICK_STREAMS = os.environ.get("FI_PICK_STREAMS", "1") != "0"       # A/B switch
+_CANDIDATES = {}
+_IN_USE = {}
+
+
+def _overtakes(a, b, probe):
+    """True when a kernel on stream b finishes before a ~1 ms spin that was launched on stream a just before it."""
+    e0, ea, eb = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+    with torch.cuda.stream(a):
+        e0.record(a)
+        torch.cuda._sleep(600000)
+        ea.record(a)
+    with torch.cuda.stream(b):
+        probe.add_(1.0)
+        eb.record(b)
+    ea.synchronize()
+    eb.synchronize()
+    return e0.elapsed_time(eb) < 0.5 * e0.elapsed_time(ea)
+
+
+def pick_stream(device=None):
+    """A new stream that runs concurrently with the current stream and with every stream picked before (when the
+    process has a hardware queue left for it; the best candidate otherwise)."""
+    dev = torch.cuda.current_device() if device is None else torch.device(device).index
+    if not PICK_STREAMS or torch.cuda.is_current_stream_capturing():
+        return torch.cuda.Stream(device=dev)
+    with torch.cuda.device(dev):
+        torch.cuda.synchronize(dev)
+        probe = torch.zeros(64, device="cuda:%d" % dev)
+        cands = _CANDIDATES.get(dev)
+        if cands is None:
+            cands = _CANDIDATES[dev] = [torch.cuda.Stream(device=dev) for _ in range(8)]
+            for c in cands:                       # first use binds the stream to its hardware queue (and may create it)
+                with torch.cuda.stream(c):
+                    probe.add_(1.0)
+            torch.cuda.synchronize(dev)
+        used = _IN_USE.setdefault(dev, [])
+        busy = [torch.cuda.current_stream(dev)] + used
+        best, best_hits = None, -1
+        for c in cands:
+            if any(c is u for u in used):
+                continue
+            hits = sum(1 for a in busy if _overtakes(a, c, probe))
+            if hits > best_hits:
+                best, best_hits = c, hits
+            if hits == len(busy):
+                break
+        torch.cuda.synchronize(dev)
+        if best is None:
+            best = torch.cuda.Stream(device=dev)
+        used.append(best)
+        return best
+
 
 def side_stream(device=None):
-    """The second stream of run_on_side_stream (created on first use)."""
+    """The second stream of run_on_side_stream (picked on first use)."""
     dev = torch.cuda.current_device() if device is None else torch.device(device).index
     side = _SIDE2.get(dev)
     if side is None:
-        side = _SIDE2[dev] = torch.cuda.Stream(device=dev)
+        side = _SIDE2[dev] = pick_stream(dev)
     return side
 
 
-_SIDE3 = {}
-
-
 def side_stream3(device=None):
-    """The third stream (run_on_side_stream(after=...)), created on first use."""
+    """The third stream (run_on_side_stream(after=...)), picked on first use."""
     dev = torch.cuda.current_device() if device is None else torch.device(device).index
     side = _SIDE3.get(dev)
     if side is None:
-        side = _SIDE3[dev] = torch.cuda.Stream(device=dev)
+        side = _SIDE3[dev] = pick_stream(dev)
     return side
 
 
@@ -343,10 +403,7 @@ def run_on_side_stream(fn, *args, after=None, reads=()):
     enqueues that op -- possibly before the side stream has run it."""
     dev = torch.cuda.current_device()
     cur = torch.cuda.current_stream(dev)
-    pool = _SIDE2 if after is None else _SIDE3
-    side = pool.get(dev)
-    if side is None:
-        side = pool[dev] = torch.cuda.Stream(device=dev)
+    side = side_stream(dev) if after is None else side_stream3(dev)
     if after is None:
         side.wait_stream(cur)
     else:

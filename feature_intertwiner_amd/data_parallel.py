@@ -5,7 +5,7 @@ step, gathers all outputs to GPU 0 and runs the optimizer there.
 
 Here every rank owns a full replica and its shard of the minibatch (images are
 independent through the whole detector), so the only exchanges per step are
-  1. an all-reduce (mean) of the gradients, bucketed (~25 MB contiguous slices of the
+  1. an all-reduce (mean) of the gradients, bucketed (~64 MB contiguous slices of the
      model's gradient arena, laid out in the order autograd produces the gradients, reduced
      IN PLACE) and issued from a side HIP stream so that RCCL traffic over xGMI overlaps
      the rest of backward;
@@ -77,7 +77,7 @@ class GradientBuckets(object):
         sync()               # waits; p.grad (views of the arena) now hold the rank-mean gradients
 
     Every trainable parameter owns a slot of ONE persistent buffer (grad_arena.ArenaLayout), laid out in the
-    order autograd produces gradients; a bucket is a contiguous ~25 MB slice of it.  The weight-gradient and
+    order autograd produces gradients; a bucket is a contiguous ~64 MB slice of it (FI_DP_BUCKET_MB).  The weight-gradient and
     fused-BN-backward kernels accumulate straight into their slots, so for nearly all bytes there is nothing
     to pack: when the last gradient of a bucket has arrived, the few gradients autograd allocated elsewhere
     (library GEMMs of the head FCs, the OT module) are moved into their slots with one multi-tensor copy and
@@ -112,8 +112,9 @@ class GradientBuckets(object):
             for p in w:
                 self.buckets_of.setdefault(p, []).append(bi)
         self.device = params[0].device if params else torch.device("cpu")
-        self.use_stream = self.device.type == "cuda"
-        self.comm_stream = torch.cuda.Stream(device=self.device) if self.use_stream else None
+        import os
+        self.use_stream = self.device.type == "cuda" and os.environ.get("FI_DP_COMM_STREAM", "1") != "0"
+        self._comm_stream = None     # picked at the first bucket (_lib.pick_stream: next to the streams the step uses)
         self.stream_ordered = False  # RCCL: completion is a stream dependency; other backends: host wait in __call__
         self.launch_log = None       # set to [] to record when each bucket is issued (tests)
         self.profile = None          # set to [] to record HIP events around every collective (bench.py, RCCL only)
@@ -132,6 +133,14 @@ class GradientBuckets(object):
             self._flag_index = torch.tensor(idx, dtype=torch.long, device=self.device)
             for p in params:
                 p.register_post_accumulate_grad_hook(self._on_grad)
+
+    @property
+    def comm_stream(self):
+        if self._comm_stream is None and self.use_stream:
+            from . import _lib
+            with torch.cuda.device(self.device):
+                self._comm_stream = _lib.pick_stream(self.device)
+        return self._comm_stream
 
     def bucket_bytes(self):
         return [4 * (b.end - b.start) for b in self.layout.buckets]

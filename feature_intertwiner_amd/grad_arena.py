@@ -17,12 +17,13 @@ block fi_bn_act_backward writes.  Units start on 16-byte boundaries.  Consecutiv
 once they reach `bucket_bytes`; each bucket ends with one float per parameter (the "had a gradient"
 flags that ride through the all-reduce for the cross-rank consistency check).
 """
+import os as _os
 import weakref
 
 import torch
 import torch.nn as nn
 
-DEFAULT_BUCKET_BYTES = 25 * 1024 * 1024
+DEFAULT_BUCKET_BYTES = int(float(_os.environ.get("FI_DP_BUCKET_MB", "64")) * 1024 * 1024)
 
 
 def _align4(n):

@@ -11,6 +11,7 @@ from ._lib import const_tensor
 from ._lib import run_on_side_stream as _run_on_side_stream
 
 META_SIDE_STREAM = os.environ.get("FI_META_SIDE", "1") != "0"      # A/B switch (scripts/ab_env.sh)
+META_SIDE_WITH_REDUCE = os.environ.get("FI_META_SIDE_DP", "1") != "0"   # ... also with the statistics all-reduce in it
 
 
 def set_optimizer(net, opt):
@@ -42,14 +43,16 @@ def compute_loss(model, inputs, do_meta=True, world_size=1, reduce_fn=None):
             detailed = detailed - detailed.detach() * off
         feats = [big_feat, big_cnt, small_feat, small_cnt, small_output_all, small_gt_all]
         fork = getattr(model, "_stats_ready", None)
-        if fork is not None and META_SIDE_STREAM and reduce_fn is None and big_feat.is_cuda:
+        if fork is not None and META_SIDE_STREAM and (reduce_fn is None or META_SIDE_WITH_REDUCE) and big_feat.is_cuda:
             # latency-bound (~70 small kernels + one Sinkhorn launch) and independent of the box / mask heads the main
             # stream still has queued: evaluated from the point where the statistics were complete (autograd runs the
             # backward of these ops on the stream their forward ran on, with the joins it needs).  Data parallel: the
-            # statistics all-reduce is a rendezvous of all ranks and stays on the main stream.
+            # statistics all-reduce is issued from that stream too -- every rank issues its collectives in the same
+            # program order (this one in forward, the gradient buckets in backward), and the process group runs them
+            # in issue order whatever stream they were issued from.
             model._stats_ready = None
             # (`reads`: the statistics were allocated on this stream; the side stream's ops keep some for their backward)
-            meta = _run_on_side_stream(lambda: model.meta_loss(feats, reduce_fn=None), after=fork, reads=feats)()
+            meta = _run_on_side_stream(lambda: model.meta_loss(feats, reduce_fn=reduce_fn), after=fork, reads=feats)()
         else:
             big_done = getattr(getattr(model, "dev_roi", None), "big_done", None)
             if big_done is not None:          # the big branch ran on the third stream (Dev.forward)
