@@ -515,10 +515,10 @@ class Dev(nn.Module):
         the big branch a batch of static capacity 3 * RoIs -- every (RoI, lower level) pair there can be -- whose live
         count n3 + 2 n4 + 3 n5 stays on the device: its kernels skip the tiles past it (fi_conv2d_forward_live,
         fi_gemm_nt_rows and their 16-bit twins), the filler rows are never written and carry class 0.  Needs the graph-less big
-        branch (the defaults DEV.BIG_FEAT_DETACH, no BIG_SUPERVISE) and a RoI count that is a multiple of 64."""
+        branch (the defaults DEV.BIG_FEAT_DETACH, no BIG_SUPERVISE)."""
         cfg = self.config
         return bool(_STATIC_DEV and rois.is_cuda and self.use_dev and not cfg.DEV.BASELINE and cfg.DEV.BIG_FEAT_DETACH and
-                    not cfg.DEV.BIG_SUPERVISE and self.roi_type == 'roi_align' and (rois.size(0) * rois.size(1)) % 64 == 0)
+                    not cfg.DEV.BIG_SUPERVISE and self.roi_type == 'roi_align')
 
     _PERM = {}
 
@@ -727,7 +727,8 @@ class Dev(nn.Module):
         def big_branch():
             # every (RoI, lower level) pair in (level, RoI) order, compacted to the front of a 3 * RoIs batch
             pairs = torch.stack([level > lvl for lvl in (2, 3, 4)])                              # [3, N]
-            flat = torch.nonzero_static(pairs.reshape(-1), size=3 * total_box, fill_value=-1).view(-1)
+            cap = (3 * total_box + 63) // 64 * 64        # whole row tiles of the fully connected stages: no padding copy
+            flat = torch.nonzero_static(pairs.reshape(-1), size=cap, fill_value=-1).view(-1)
             valid = flat >= 0
             flat_c = flat.clamp(min=0)
             big_idx = flat_c % total_box
@@ -738,7 +739,7 @@ class Dev(nn.Module):
                 big_pooled = self._crop(x, boxes[big_idx], box_ind[big_idx], big_level, self.feat_pool_size, None)
                 big_raw = self._feat_extract_live(big_pooled, live)
                 big_out = self.last_op(big_raw) if cfg.DEV.LOSS_CHOICE != 'ot' else big_raw
-                big_out = big_out.view(3 * total_box, -1)
+                big_out = big_out.view(cap, -1)
                 big_gt = gt[big_idx]
                 big_feat, big_cnt = [], []
                 for i, lvl in enumerate((2, 3, 4)):
