@@ -94,6 +94,9 @@ SIGNATURES = {
     "fi_conv2d_weight_grad_rows_bf16": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 12 + [c_void_p, c_void_p]),
     "fi_conv2d_weight_grad_rows_f16": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 12 + [c_void_p, c_void_p]),
     "fi_gemm_nt_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "fi_gemm_nt_affine": (c_int, [c_void_p] * 5 + [c_int] * 4 + [c_void_p, c_void_p, c_void_p]),
+    "fi_rows_mask_scale": (c_int, [c_void_p] * 6 + [c_int] * 5 + [c_void_p]),
+    "fi_rows_affine_act": (c_int, [c_void_p] * 3 + [c_int] * 3 + [c_void_p]),
     "fi_conv2d_forward_live": (c_int, [c_void_p] * 7 + [c_int] * 16 + [c_void_p, c_void_p]),
     "fi_weight_transpose_batch": (c_int, [c_void_p, c_int, ctypes.c_long, c_void_p]),
     "fi_conv3x3_forward_bf16w": (c_int, [c_void_p] * 6 + [c_int] * 7 + [c_void_p]),

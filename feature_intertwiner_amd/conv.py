@@ -1379,6 +1379,9 @@ def _invalidate_bn_folds(module=None):
             m._fi_fold = None
 
 
+FUSED_FC = _os.environ.get("FI_FUSED_FC", "1") != "0"       # A/B switch: linear_bn_act vs conv, affine, ReLU as torch ops
+
+
 def conv_bn_act(x, conv, bn, relu=True, residual=None, channels_last_out=False, res_grad_to=None,
                 dx_add_from=None, dx_give_to=None, gate_dx=False, live=None):
     """act(bn(conv(x)) [+ residual]) for an eval-mode BatchNorm2d (the reference always evaluates
@@ -1393,6 +1396,11 @@ def conv_bn_act(x, conv, bn, relu=True, residual=None, channels_last_out=False, 
     if bn.training or gemm_path or not bn.track_running_stats:
         assert res_grad_to is None and dx_add_from is None and dx_give_to is None, \
             "gradient hand-off needs the fused conv+BN path"
+        if gemm_path and not bn.training and bn.track_running_stats and x.is_cuda and x.dtype == torch.float32 and \
+                residual is None and FUSED_FC and (x.shape[1] * R * S) % 4 == 0 and conv.weight.shape[0] % 4 == 0 and \
+                x.shape[0] > 0:
+            y = linear_bn_act(x, conv, bn, relu, live)
+            return y.contiguous(memory_format=torch.channels_last) if channels_last_out else y
         if gemm_path and not bn.training and bn.track_running_stats:
             # [N,C,1,1]: MIOpen's spatial inference BN takes ~0.4 ms on 8 MB here; the affine form is ~10 us
             scale = bn.weight * torch.rsqrt(bn.running_var + bn.eps)
@@ -1441,7 +1449,7 @@ def _pad_rows(t, rows):
     return out
 
 
-def _gemm_nt(a, b, bias=None, relu=False, precision="fp32", live=None):
+def _gemm_nt(a, b, bias=None, relu=False, precision="fp32", live=None, scale=None):
     """act(a [M,K] . b[N,K]^T + bias) -> [M,N]; N % 128 == 0, K % 4 == 0.  fp32: fi_gemm_nt (deterministic split over
     K).  16-bit precisions: the 16-bit weight-gradient kernel (operands rounded on their way into LDS, fp32 atomics
     over the split) when M % 64 == 0, then bias / ReLU."""
@@ -1461,6 +1469,11 @@ def _gemm_nt(a, b, bias=None, relu=False, precision="fp32", live=None):
                 _lib.check(_lowp_fn(L, "conv2d_weight_grad", precision)(_lib.ptr(b), _lib.ptr(a), _lib.ptr(y), 1, N, 1, K, M,
                                                                         1, 1, 1, 1, 0, 0, 0, _lib.current_stream()),
                            "fi_conv2d_weight_grad_16 (gemm)")
+        if scale is not None:         # (fully connected + eval BatchNorm + ReLU: one in-place pass behind the atomics)
+            with torch.cuda.device(a.device):
+                _lib.check(L.fi_rows_affine_act(_lib.ptr(y), _lib.ptr(scale), _lib.ptr(bias), M, N, 1 if relu else 0,
+                                                _lib.current_stream()), "fi_rows_affine_act")
+            return y
         if bias is not None:
             y = y + bias
         return torch.relu_(y) if relu else y
@@ -1468,8 +1481,8 @@ def _gemm_nt(a, b, bias=None, relu=False, precision="fp32", live=None):
     ws = torch.empty((int(L.fi_gemm_nt_workspace_bytes(M, N, K)) + 3) // 4, device=a.device, dtype=torch.float32)
     _log_flops("wgrad", M, 1, 1, 2.0 * M * N * K, K, N)
     with torch.cuda.device(a.device):
-        _lib.check(L.fi_gemm_nt_rows(_lib.ptr(a), _lib.ptr(b), _lib.ptr(bias), _lib.ptr(y), M, N, K, 1 if relu else 0,
-                                     _lib.ptr(ws), _lib.ptr(live), _lib.current_stream()), "fi_gemm_nt")
+        _lib.check(L.fi_gemm_nt_affine(_lib.ptr(a), _lib.ptr(b), _lib.ptr(scale), _lib.ptr(bias), _lib.ptr(y), M, N, K,
+                                       1 if relu else 0, _lib.ptr(ws), _lib.ptr(live), _lib.current_stream()), "fi_gemm_nt")
     return y
 
 
@@ -1513,6 +1526,81 @@ class _LinearFn(torch.autograd.Function):
             dw = _gemm_nn(dyp.t().contiguous(), xp, ctx.precision)[:N]      # reduction over the padded M
         db = dy.sum(0) if (has_b and ctx.needs_input_grad[2]) else None
         return dx, dw, db, None
+
+
+class _LinearBnActFn(torch.autograd.Function):
+    """act((x W^T + conv_bias - mean) * gamma / sqrt(var + eps) + beta): a fully connected layer with its eval-mode
+    BatchNorm and ReLU (the heads' full-window "fc" convolutions and their 1x1 convolutions on 1x1 maps:
+    nn.Conv2d + nn.BatchNorm2d + nn.ReLU in the reference, lib/sub_module.py:333-340, :707-716).  Forward: the affine
+    map and the ReLU ride in the GEMM's reduction pass (fi_gemm_nt_affine).  Backward, as for the convolutions
+    (_ConvBnActFn): ONE pass makes g = dy * (y > 0), g * scale and the column sums of g (fi_rows_mask_scale); the data
+    gradient is (g * scale) W, the weight gradient of the unscaled g gives dW, d gamma, d conv_bias through
+    fi_bn_fold_grad (sum_m g * (x W^T) = <W, dW'>), d beta is the column sums."""
+
+    @staticmethod
+    def forward(ctx, x, w, cb, gamma, beta, mean, var, eps, relu, fold, live):
+        _lib.require_cuda(x, w)
+        M, K = x.shape
+        N = w.shape[0]
+        prec = _PRECISION
+        rows = 64 if prec in _LOWP else 32
+        Mp, Np = (M + rows - 1) // rows * rows, (N + 127) // 128 * 128
+        if fold is not None:
+            scale, shift = fold
+        else:
+            scale = gamma * torch.rsqrt(var + eps)
+            shift = beta - mean * scale if cb is None else beta + (cb - mean) * scale
+        xp = _pad_rows(x.float(), Mp)
+        wp = _pad_rows(w.float(), Np)
+        # (zero scale and shift in the padding columns: they come out as zeros)
+        y = _gemm_nt(xp, wp, _pad_rows(shift.float(), Np), relu=relu, precision=prec, live=live,
+                     scale=_pad_rows(scale.float(), Np))[:M, :N].contiguous()
+        ctx.save_for_backward(xp, wp, y, scale, mean, var, cb)
+        ctx.dims = (M, N, K, float(eps), bool(relu))
+        ctx.precision = prec
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xp, wp, y, scale, mean, var, cb = ctx.saved_tensors
+        M, N, K, eps, relu = ctx.dims
+        Mp, Np = xp.shape[0], wp.shape[0]
+        L = _lib.load()
+        dy = dy.contiguous().float()
+        need = ctx.needs_input_grad
+        want_w = need[1] or need[2] or need[3]
+        padded = (Mp, Np) != (M, N)
+        new = dy.new_zeros if padded else dy.new_empty
+        g = new((Mp, Np)) if want_w else None
+        gs = new((Mp, Np)) if need[0] else None
+        s = dy.new_zeros(N)
+        with torch.cuda.device(dy.device):
+            _lib.check(L.fi_rows_mask_scale(_lib.ptr(dy), _lib.ptr(y), _lib.ptr(scale), _lib.ptr(g), _lib.ptr(gs), _lib.ptr(s),
+                                            M, N, Np, 1 if relu else 0, _lib.OUTPUTS_ZEROED, _lib.current_stream()),
+                       "fi_rows_mask_scale")
+        dx = _gemm_nn(gs, wp, ctx.precision)[:M] if need[0] else None
+        dw = dcb = dgamma = None
+        if want_w:
+            dw = _gemm_nn(g.t().contiguous(), xp, ctx.precision)[:N]        # dW' of the unscaled g; [N, K] contiguous
+            dgamma = dy.new_zeros(N) if need[3] else None
+            dcb = dy.new_zeros(N) if (cb is not None and need[2]) else None
+            with torch.cuda.device(dy.device):
+                _lib.check(L.fi_bn_fold_grad(_lib.ptr(dw), _lib.ptr(wp), _lib.ptr(s), _lib.ptr(scale), _lib.ptr(mean),
+                                             _lib.ptr(var), eps, _lib.ptr(cb), _lib.ptr(dgamma), _lib.ptr(dcb), N, K, 1, 0, 0,
+                                             _lib.current_stream()), "fi_bn_fold_grad")
+            if not need[1]:
+                dw = None
+        return dx, dw, dcb, dgamma, (s if need[4] else None), None, None, None, None, None, None
+
+
+def linear_bn_act(x, conv, bn, relu=True, live=None):
+    """conv_bn_act for a convolution that is a matrix product (full window, or a 1x1 layer on a 1x1 map) behind an
+    eval-mode BatchNorm: x [M, Cin, R, S] -> [M, Cout, 1, 1]."""
+    M, N = x.shape[0], conv.weight.shape[0]
+    _FOLD_PAIRS[bn] = conv
+    y = _LinearBnActFn.apply(x.reshape(M, -1), conv.weight.reshape(N, -1), conv.bias, bn.weight, bn.bias, bn.running_mean,
+                             bn.running_var, bn.eps, relu, _cached_fold(conv, bn), live)
+    return y.view(M, N, 1, 1)
 
 
 def linear(x, weight, bias=None, live=None):

@@ -2539,11 +2539,13 @@ static int wgrad_impl(const float *x, const float *dy, float *dweight, int N, in
     return FI_OK;
 }
 
-// c[i] = act(sum_s slab_s[i] + bias[i % N]): the ordered reduction of fi_gemm_nt's split-K partial sums
+// c[i] = act(sum_s slab_s[i] * scale[i % N] + bias[i % N]): the ordered reduction of fi_gemm_nt's split-K partial sums
+// (scale: the eval-mode BatchNorm behind a fully connected layer, fi_gemm_nt_affine)
 __global__ __launch_bounds__(256) void gemm_slab_reduce_kernel(const float *__restrict__ ws, int splits, long slab,
                                                                const float *__restrict__ bias, int N, int relu,
                                                                float *__restrict__ c, long total4,
-                                                               const int *__restrict__ n_live, int bm)
+                                                               const int *__restrict__ n_live, int bm,
+                                                               const float *__restrict__ scale)
 {
     // rows past the live count (rounded up to the tile height): their tiles were never computed -- zeros, not the slabs
     const long live4 = n_live ? (long)((*n_live + bm - 1) / bm) * bm * N / 4 : total4;
@@ -2556,6 +2558,10 @@ __global__ __launch_bounds__(256) void gemm_slab_reduce_kernel(const float *__re
         for (int sidx = 1; sidx < splits; ++sidx) {
             const float4 v = *reinterpret_cast<const float4 *>(ws + (size_t)sidx * slab + 4 * i);
             a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        }
+        if (scale) {
+            const float4 m = *reinterpret_cast<const float4 *>(scale + (4 * i) % N);
+            a.x *= m.x; a.y *= m.y; a.z *= m.z; a.w *= m.w;
         }
         if (bias) {
             const float4 b = *reinterpret_cast<const float4 *>(bias + (4 * i) % N);
@@ -2602,7 +2608,14 @@ int fi_gemm_nt(const float *a, const float *b, const float *bias, float *c, int 
 int fi_gemm_nt_rows(const float *a, const float *b, const float *bias, float *c, int M, int N, int K, int relu,
                     float *workspace, const int32_t *m_live_dev, fi_stream_t stream)
 {
+    return fi_gemm_nt_affine(a, b, nullptr, bias, c, M, N, K, relu, workspace, m_live_dev, stream);
+}
+
+int fi_gemm_nt_affine(const float *a, const float *b, const float *scale, const float *bias, float *c, int M, int N, int K,
+                      int relu, float *workspace, const int32_t *m_live_dev, fi_stream_t stream)
+{
     FI_REQUIRE(a && b && c && workspace, "null pointer");
+    FI_REQUIRE(((uintptr_t)scale & 15) == 0, "fi_gemm_nt needs 16-byte aligned operands");
     FI_REQUIRE(M >= 1 && N >= 1 && K >= 4, "sizes must be positive");
     FI_REQUIRE(N % BN == 0 && K % 4 == 0, "fi_gemm_nt needs N % 128 == 0 and K % 4 == 0");
     FI_REQUIRE((((uintptr_t)a | (uintptr_t)b | (uintptr_t)c | (uintptr_t)workspace | (uintptr_t)bias) & 15) == 0,
@@ -2631,7 +2644,7 @@ int fi_gemm_nt_rows(const float *a, const float *b, const float *bias, float *c,
     const long blocks = (total4 + 255) / 256;
     fi::ProfScope prof2(FI_K_GEMM_REDUCE, st);
     hipLaunchKernelGGL(gemm_slab_reduce_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, st, workspace,
-                       splits, g.dw_slab, bias, N, relu, c, total4, m_live_dev, bm);
+                       splits, g.dw_slab, bias, N, relu, c, total4, m_live_dev, bm, scale);
     FI_HIP_CHECK(hipGetLastError());
     return FI_OK;
 }

@@ -475,6 +475,75 @@ __global__ __launch_bounds__(256) void relu_mask_kernel(const float *__restrict_
     for (long i = n4 * 4 + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) out[i] = y[i] > 0.0f ? dy[i] : 0.0f;
 }
 
+// Backward of a fully connected layer + eval-mode BatchNorm + ReLU, first pass (fi_rows_mask_scale): rows [M][N], the
+// channel is the contiguous index.  g = dy * (y > 0) -> g_out, g * scale[n] -> gs_out (the operand of the data gradient),
+// colsum[n] += sum_m g (d beta; fi_bn_fold_grad turns it and the weight gradient of g into d gamma / d bias / dW).
+// A workgroup takes 256 columns x rows_per_block rows: 64 column quads x 4 row lanes.
+__global__ __launch_bounds__(256) void rows_mask_scale_kernel(const float *__restrict__ dy, const float *__restrict__ y,
+                                                              const float *__restrict__ scale, float *__restrict__ g_out,
+                                                              float *__restrict__ gs_out, float *__restrict__ colsum, int M,
+                                                              int N, int ld_out, int relu, int rows_per_block)
+{
+    __shared__ float4 s_part[4][64];
+    const int tid = threadIdx.x, lane = tid & 63, rl = tid >> 6;
+    const int c0 = (blockIdx.x * 64 + lane) * 4;
+    const int r0 = blockIdx.y * rows_per_block;
+    const int r1 = min(M, r0 + rows_per_block);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c0 < N) {
+        float4 sc = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (scale) sc = *reinterpret_cast<const float4 *>(scale + c0);
+        for (int r = r0 + rl; r < r1; r += 4) {
+            float4 d = *reinterpret_cast<const float4 *>(dy + (size_t)r * N + c0);
+            if (relu) {
+                const float4 v = *reinterpret_cast<const float4 *>(y + (size_t)r * N + c0);
+                d.x = v.x > 0.0f ? d.x : 0.0f; d.y = v.y > 0.0f ? d.y : 0.0f;
+                d.z = v.z > 0.0f ? d.z : 0.0f; d.w = v.w > 0.0f ? d.w : 0.0f;
+            }
+            acc.x += d.x; acc.y += d.y; acc.z += d.z; acc.w += d.w;
+            if (g_out) *reinterpret_cast<float4 *>(g_out + (size_t)r * ld_out + c0) = d;
+            if (gs_out)
+                *reinterpret_cast<float4 *>(gs_out + (size_t)r * ld_out + c0) =
+                    make_float4(d.x * sc.x, d.y * sc.y, d.z * sc.z, d.w * sc.w);
+        }
+    }
+    if (!colsum) return;
+    s_part[rl][lane] = acc;
+    __syncthreads();
+    if (rl == 0 && c0 < N) {
+        float4 t = s_part[0][lane];
+        for (int k = 1; k < 4; ++k) {
+            const float4 v = s_part[k][lane];
+            t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+        }
+        atomicAdd(colsum + c0, t.x); atomicAdd(colsum + c0 + 1, t.y);
+        atomicAdd(colsum + c0 + 2, t.z); atomicAdd(colsum + c0 + 3, t.w);
+    }
+}
+
+// y = act(y * scale[n] + bias[n]) in place, rows [M][N]: the epilogue of the 16-bit GEMM (fp32 atomics over its K split,
+// so it has no reduction pass to fold this into)
+__global__ __launch_bounds__(256) void rows_affine_act_kernel(float *__restrict__ y, const float *__restrict__ scale,
+                                                              const float *__restrict__ bias, long total4, int N, int relu)
+{
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long)gridDim.x * 256) {
+        float4 a = *reinterpret_cast<float4 *>(y + 4 * i);
+        const int c = (int)((4 * i) % N);
+        if (scale) {
+            const float4 m = *reinterpret_cast<const float4 *>(scale + c);
+            a.x *= m.x; a.y *= m.y; a.z *= m.z; a.w *= m.w;
+        }
+        if (bias) {
+            const float4 b = *reinterpret_cast<const float4 *>(bias + c);
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        }
+        if (relu) {
+            a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f);
+        }
+        *reinterpret_cast<float4 *>(y + 4 * i) = a;
+    }
+}
+
 // one workgroup per output channel: <W[co], dW'[co]> while dW'[co] is scaled in place (see fi_capi.h)
 __global__ __launch_bounds__(256) void bn_fold_grad_kernel(float *__restrict__ dw, const float *__restrict__ w,
                                                            const float *__restrict__ s, const float *__restrict__ scale,
@@ -762,6 +831,39 @@ int fi_relu_mask(const float *dy, const float *y, float *out, long n, fi_stream_
     const long n4 = vec ? n / 4 : 0;
     const long blocks = std::min<long>(std::max<long>((std::max<long>(n4, 1) + 511) / 512, 1), 256L * 16);
     hipLaunchKernelGGL(relu_mask_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dy, y, out, n4, n);
+    FI_HIP_CHECK(hipGetLastError());
+    return FI_OK;
+}
+
+int fi_rows_mask_scale(const float *dy, const float *y, const float *scale, float *g, float *gs, float *colsum, int M,
+                       int N, int ld_out, int relu, int flags, fi_stream_t stream)
+{
+    FI_REQUIRE(M >= 0 && N >= 4 && N % 4 == 0 && ld_out >= N && ld_out % 4 == 0, "N and ld_out must be multiples of 4");
+    if (M == 0) return FI_OK;
+    FI_REQUIRE(dy && (y || !relu) && (g || gs || colsum), "null pointer");
+    FI_REQUIRE((((uintptr_t)dy | (uintptr_t)y | (uintptr_t)scale | (uintptr_t)g | (uintptr_t)gs) & 15) == 0,
+               "fi_rows_mask_scale needs 16-byte aligned operands");
+    hipStream_t st = (hipStream_t)stream;
+    if (colsum && !(flags & FI_OUTPUTS_ZEROED)) FI_HIP_CHECK(hipMemsetAsync(colsum, 0, sizeof(float) * (size_t)N, st));
+    const int panels = (N + 255) / 256;
+    int rpb = 32;                                  // enough workgroups to fill the chip, few atomics per column
+    while (rpb < 256 && (long)panels * ((M + rpb - 1) / rpb) > 2048) rpb *= 2;
+    hipLaunchKernelGGL(rows_mask_scale_kernel, dim3((unsigned)panels, (unsigned)((M + rpb - 1) / rpb)), dim3(256), 0, st, dy, y,
+                       scale, g, gs, colsum, M, N, ld_out, relu ? 1 : 0, rpb);
+    FI_HIP_CHECK(hipGetLastError());
+    return FI_OK;
+}
+
+int fi_rows_affine_act(float *y, const float *scale, const float *bias, int M, int N, int relu, fi_stream_t stream)
+{
+    FI_REQUIRE(M >= 0 && N >= 4 && N % 4 == 0, "N must be a multiple of 4");
+    if (M == 0) return FI_OK;
+    FI_REQUIRE(y != nullptr, "null pointer");
+    FI_REQUIRE((((uintptr_t)y | (uintptr_t)scale | (uintptr_t)bias) & 15) == 0, "fi_rows_affine_act needs 16-byte aligned operands");
+    const long total4 = (long)M * N / 4;
+    const long blocks = (total4 + 255) / 256;
+    hipLaunchKernelGGL(rows_affine_act_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0,
+                       (hipStream_t)stream, y, scale, bias, total4, N, relu ? 1 : 0);
     FI_HIP_CHECK(hipGetLastError());
     return FI_OK;
 }

@@ -337,6 +337,20 @@ int fi_relu_mask(const float *dy, const float *y, float *out, long n, fi_stream_
 int fi_bn_fold_grad(float *dw, const float *w, const float *s, const float *scale, const float *mean,
                     const float *var, float eps, const float *conv_bias, float *dgamma, float *dbias, int Cout,
                     int Cin, int taps, int dw_tap_major, int w_tap_major, fi_stream_t stream);
+/* The same for a FULLY CONNECTED layer + eval-mode BatchNorm + ReLU (the heads' full-window 7x7 "fc" convolutions and
+ * their 1x1 convolutions on 1x1 maps, lib/sub_module.py:333-340, :707-716 -- nn.Conv2d + nn.BatchNorm2d + nn.ReLU, three
+ * kernels each way in the reference): rows [M][N], the channel contiguous.  First pass of the backward:
+ *     g = relu ? dy * (y > 0) : dy  -> g  [M][ld_out]   (operand of the weight gradient dW' = g^T x)
+ *     g * scale[n]                  -> gs [M][ld_out]   (operand of the data gradient dx = gs W; scale NULL = 1)
+ *     colsum[n] += sum_m g                              (= s of fi_bn_fold_grad; zero-filled by the call unless
+ *                                                         FI_OUTPUTS_ZEROED)
+ * g, gs, colsum may each be NULL; ld_out >= N lets the outputs land in zero-padded operands of the matrix products. */
+int fi_rows_mask_scale(const float *dy, const float *y, const float *scale, float *g, float *gs, float *colsum, int M,
+                       int N, int ld_out, int relu, int flags, fi_stream_t stream);
+/* y = act(y * scale[n] + bias[n]) in place on rows [M][N] (scale / bias NULL = none): the epilogue of the fully
+ * connected forward on the 16-bit kernels, whose K split accumulates with atomics (fi_gemm_nt_affine has it in its
+ * reduction pass). */
+int fi_rows_affine_act(float *y, const float *scale, const float *bias, int M, int N, int relu, fi_stream_t stream);
 /* ... for n layers of one geometry in one launch (behind fi_conv2d_weight_grad_batch): HOST arrays of device pointers;
  * conv_bias / dgamma / dbias may be NULL tables or hold NULL entries. */
 int fi_bn_fold_grad_batch(float *const *dw, const float *const *w, const float *const *s, const float *const *scale,
@@ -408,6 +422,11 @@ int fi_gemm_nt(const float *a, const float *b, const float *bias, float *c, int 
  * count rounded up to the tile height) are written as zeros. */
 int fi_gemm_nt_rows(const float *a, const float *b, const float *bias, float *c, int M, int N, int K, int relu,
                     float *workspace, const int32_t *m_live_dev, fi_stream_t stream);
+/* ... with a per-column scale in the reduction pass as well: c = act((a . b^T) * scale [N] + bias [N]) -- a fully
+ * connected layer with its eval-mode BatchNorm (scale = gamma / sqrt(var + eps), bias = beta + (conv_bias - mean) * scale)
+ * and ReLU in one pass (scale NULL = fi_gemm_nt_rows). */
+int fi_gemm_nt_affine(const float *a, const float *b, const float *scale, const float *bias, float *c, int M, int N, int K,
+                      int relu, float *workspace, const int32_t *m_live_dev, fi_stream_t stream);
 
 /* All layers' W^T for the data-gradient kernel in one launch: for every descriptor, src is
  * [rows][taps][cols] (a weight stored [Cout][R][S][Cin]) and dst becomes [cols][taps][rows]

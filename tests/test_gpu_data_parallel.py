@@ -227,7 +227,7 @@ def test_configs3_slice_two_ranks_full_size():
         res = [torch.load(os.path.join(outdir, "rank%d.pt" % r), weights_only=False) for r in range(WORLD)]
     assert res[0]["param_digest"] == res[1]["param_digest"]
     assert torch.equal(res[0]["buffer_cnt"], res[1]["buffer_cnt"]) and float(res[0]["buffer_cnt"].sum()) > 0
-    assert res[0]["buckets"] >= 8
+    assert res[0]["buckets"] >= 4            # ~64 MB slices of the 386 MB arena
     for step in range(2):
         assert res[0]["hist"][step]["meta"] == res[1]["hist"][step]["meta"]          # one meta term, evaluated on both
         for r in range(WORLD):
