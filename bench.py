@@ -163,7 +163,7 @@ def configs4_slice(dev, steps=6, warmup=3):
     model = MaskRCNN(cfg).to(dev)
     opt = set_optimizer(model, cfg.TRAIN)
     batch = synthetic_batch(2, 1344, device=dev, seed=2000)
-    model.external_proposals = SyntheticProposals(batch[2], 1344, seed=7)
+    model.external_proposals = SyntheticProposals(batch[2], 1344, seed=7, cycle=16)
     model.generator = torch.Generator(device=dev).manual_seed(11)
     for _ in range(warmup):
         terms = train_step(model, opt, list(batch))
@@ -552,7 +552,7 @@ def _main():
     sync = GradientBuckets(model) if (world > 1 or force_dp) else None
     reduce_fn = all_reduce_statistics if (world > 1 or force_dp) else None
     batch = synthetic_batch(args.batch_per_gpu, args.image_size, device=dev, seed=2000 + rank)
-    model.external_proposals = SyntheticProposals(batch[2], args.image_size, seed=7 + rank)
+    model.external_proposals = SyntheticProposals(batch[2], args.image_size, seed=7 + rank, cycle=16)
     model.generator = torch.Generator(device=dev).manual_seed(11 + rank)
 
     def step():
@@ -693,7 +693,7 @@ def _main():
         # region (2 warm-up + 6 timed steps, barrier + synchronize on both sides, MAX over ranks)
         batch2 = synthetic_batch(2, args.image_size, device=dev, seed=3000 + rank)
         keep_ext = model.external_proposals
-        model.external_proposals = SyntheticProposals(batch2[2], args.image_size, seed=17 + rank)
+        model.external_proposals = SyntheticProposals(batch2[2], args.image_size, seed=17 + rank, cycle=16)
 
         def step2():
             return train_step(model, opt, list(batch2), do_meta=True, grad_sync=sync, world_size=world, reduce_fn=reduce_fn)
@@ -881,7 +881,8 @@ def _main():
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32" if args.conv_precision == "fp32" else "%s (conv operands; fp32 accumulation, fp32 elsewhere)" % args.conv_precision,
             "data": "synthetic (seeded N(0,1)*64 images, 20 GT boxes/img, random-init weights, "
-                    "GT-jittered proposals planted among RPN candidates before NMS)",
+                    "GT-jittered proposals planted among RPN candidates before NMS -- 16 sets drawn before the timed "
+                    "region and handed out in turn, resident in HBM like the images)",
             "config": {"workload": ("BASELINE configs[2]" if args.config == "cfg3" else
                                     "single-GPU slice of BASELINE configs[4] (1333x800 padded to a /64 multiple, SURVEY Q8)") +
                                    ": %s-FPN, %dx%d, %d images/GPU, %d RoIs/image, OT intertwiner "

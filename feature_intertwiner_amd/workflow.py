@@ -126,7 +126,9 @@ def compare_backward_forms(model, inputs, do_meta=True, generator_seed=3, skip=N
     saved_gen = model.generator
     # a stateful external proposal source (synthetic.SyntheticProposals draws new jitter at every call) must hand both
     # passes the same rows
-    ext_gen = getattr(getattr(model, "external_proposals", None), "gen", None)
+    ext_gen = getattr(model, "external_proposals", None)
+    if ext_gen is not None and not hasattr(ext_gen, "get_state"):
+        ext_gen = getattr(ext_gen, "gen", None)
     ext_state = ext_gen.get_state() if ext_gen is not None else None
     dev = next(model.parameters()).device
     out = {}

@@ -52,7 +52,7 @@ cfg = make_config("resnet101", SIZE, BATCH, ROIS, dev_switch=True, loss_choice="
 model = model_mod.MaskRCNN(cfg).to(dev)
 opt = workflow.set_optimizer(model, cfg.TRAIN)
 batch = synthetic_batch(BATCH, SIZE, device=dev, seed=2000)
-model.external_proposals = SyntheticProposals(batch[2], SIZE, seed=7)
+model.external_proposals = SyntheticProposals(batch[2], SIZE, seed=7, cycle=16)   # as bench.py: drawn before the measured steps
 model.generator = torch.Generator(device=dev).manual_seed(11)
 for _ in range(3):
     workflow.train_step(model, opt, list(batch))
