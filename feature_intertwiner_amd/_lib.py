@@ -94,6 +94,7 @@ SIGNATURES = {
     "fi_conv2d_weight_grad_rows_bf16": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 12 + [c_void_p, c_void_p]),
     "fi_conv2d_weight_grad_rows_f16": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 12 + [c_void_p, c_void_p]),
     "fi_gemm_nt_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "fi_dev_stage_index": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int] + [c_void_p] * 9),
     "fi_gemm_nt_affine": (c_int, [c_void_p] * 5 + [c_int] * 4 + [c_void_p, c_void_p, c_void_p]),
     "fi_rows_mask_scale": (c_int, [c_void_p] * 6 + [c_int] * 5 + [c_void_p]),
     "fi_rows_affine_act": (c_int, [c_void_p] * 3 + [c_int] * 3 + [c_void_p]),

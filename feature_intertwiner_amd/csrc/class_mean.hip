@@ -17,7 +17,7 @@
 namespace {
 
 constexpr int kCols = 64;
-constexpr int kMaxClasses = 128;
+constexpr int kMaxClasses = 248;      // 3 levels x 81 classes in one launch (Dev._forward_static); 62 KB of LDS
 
 constexpr int kRowsPerChunk = 64;
 

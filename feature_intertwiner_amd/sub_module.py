@@ -26,6 +26,7 @@ from .roi_pooling.functions.roi_pool import RoIPoolFunction
 
 import os as _os
 _BIG_SIDE = _os.environ.get('FI_BIG_SIDE', '1') != '0'
+_INDEX_KERNEL = _os.environ.get('FI_INDEX_KERNEL', '1') != '0'      # fi_dev_stage_index vs its tensor formulation (A/B switch)
 _STATIC_DEV = _os.environ.get('FI_STATIC_DEV', '1') != '0'   # the Dev stage without its host read (Dev.static_shapes; A/B switch)      # the graph-less big branch of the Dev stage on the third stream (A/B switch)
 
 class SamePad2d(nn.Module):
@@ -697,16 +698,69 @@ class Dev(nn.Module):
         v = conv_bn_act(v, fe[3], fe[4], relu=True, live=live)
         return conv_bn_act(v, fe[6], fe[7], relu=True, live=live)
 
+    @staticmethod
+    def _static_index_tensors(level, gt, K, cap):
+        """The index side of _forward_static as tensor operations (the specification of fi_dev_stage_index; CPU path and
+        the tests' reference): see include/fi_capi.h for the outputs."""
+        N = level.numel()
+        order = torch.sort(level, stable=True)[1]                       # level-major, original index inside a level
+        lvl_o = level[order]
+        small_on = lvl_o <= 4                                           # the rows the reference feeds (:583-598)
+        gt = gt if gt is not None else torch.zeros_like(level)
+        gt_o = gt[order]
+        zero = torch.zeros_like(gt_o)
+        small_gt = torch.where(small_on, gt_o, zero).float()
+        small_cls = torch.where(small_on & (gt_o > 0), (lvl_o - 2) * K + gt_o, zero).to(torch.int32)
+        # every (RoI, lower level) pair in (level, RoI) order, compacted to the front of the big batch
+        pairs = torch.stack([level > lvl for lvl in (2, 3, 4)])                              # [3, N]
+        flat = torch.nonzero_static(pairs.reshape(-1), size=cap, fill_value=-1).view(-1)
+        valid = flat >= 0
+        flat_c = flat.clamp(min=0)
+        big_idx = flat_c % N
+        # (level -1: a row past the live count -- the crop does not even write it, nothing downstream reads it)
+        big_level = torch.where(valid, 2 + flat_c // N, torch.full_like(flat_c, -1)).to(torch.int32)
+        counts = torch.stack([(level == lvl).sum() for lvl in (2, 3, 4, 5)]).to(torch.int32)
+        has_small = counts[:3] > 0                                      # a level without small boxes contributes no big
+        big_gt = gt[big_idx]                                            # statistics either (:456-467)
+        lv = (big_level - 2).clamp(0, 2).long()
+        use = valid & has_small[lv] & (big_gt > 0)
+        big_cls = torch.where(use, lv.to(torch.int32) * K + big_gt.to(torch.int32), torch.zeros_like(big_level))
+        live = pairs.sum().to(torch.int32).view(1)
+        return order, small_cls, small_gt, small_on, big_idx, big_level, big_cls, live
+
+    def _static_index(self, level, gt, K, cap):
+        if not (_INDEX_KERNEL and level.is_cuda):
+            return self._static_index_tensors(level, gt, K, cap)
+        N, dev = level.numel(), level.device
+        level = level.contiguous()
+        order = torch.empty(N, dtype=torch.int64, device=dev)
+        small_cls = torch.empty(N, dtype=torch.int32, device=dev)
+        small_gt = torch.empty(N, dtype=torch.float32, device=dev)
+        small_on = torch.empty(N, dtype=torch.bool, device=dev)
+        big_idx = torch.empty(cap, dtype=torch.int64, device=dev)
+        big_level = torch.empty(cap, dtype=torch.int32, device=dev)
+        big_cls = torch.empty(cap, dtype=torch.int32, device=dev)
+        counts = torch.empty(5, dtype=torch.int32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.load().fi_dev_stage_index(_lib.ptr(level), _lib.ptr(gt.contiguous() if gt is not None else None), N, K,
+                                                      cap, _lib.ptr(order), _lib.ptr(small_cls), _lib.ptr(small_gt),
+                                                      _lib.ptr(small_on), _lib.ptr(big_idx), _lib.ptr(big_level),
+                                                      _lib.ptr(big_cls), _lib.ptr(counts), _lib.current_stream()),
+                       "fi_dev_stage_index")
+        return order, small_cls, small_gt, small_on, big_idx, big_level, big_cls, counts[4:5]
+
     def _forward_static(self, x, boxes, box_ind, level, per_level, roi_cls_gt, pooled, mask_and_feat, inv, mask_grad_box,
                         total_box):
-        """The part of forward() behind the two crops with shapes that do not depend on the RoIs (see static_shapes)."""
+        """The part of forward() behind the two crops with shapes that do not depend on the RoIs (see static_shapes).
+        One launch (fi_dev_stage_index) makes every index the stage needs; the class means of the three levels are ONE
+        launch over 3 K classes (class = (level - 2) K + gt: the same rows in the same order per class as three launches)."""
         cfg = self.config
         K = self.num_classs
         dev = level.device
         train_phase = roi_cls_gt is not None
-        order = torch.sort(level, stable=True)[1]                       # level-major, original index inside a level
-        lvl_o = level[order]
-        small_on = lvl_o <= 4                                           # the rows the reference feeds (:583-598)
+        gt = roi_cls_gt.reshape(-1).to(torch.int32) if train_phase else None
+        cap = (3 * total_box + 63) // 64 * 64            # whole row tiles of the fully connected stages: no padding copy
+        order, small_cls, small_gt_all, small_on, big_idx, big_level, big_cls, live = self._static_index(level, gt, K, cap)
         small_output = self._feat_extract(take_rows(mask_and_feat, order if inv is None else inv[order], mask_grad_box))
         if cfg.DEV.LOSS_CHOICE != 'ot':
             small_output = self.last_op(small_output)
@@ -714,61 +768,33 @@ class Dev(nn.Module):
         small_output_all = torch.where(small_on.unsqueeze(1), small_output, torch.zeros_like(small_output))
         if not train_phase:
             return pooled, mask_and_feat, [small_output_all, small_on.float()]
-        gt = roi_cls_gt.reshape(-1).to(torch.int32)
-        gt_o = gt[order]
-        small_gt_all = torch.where(small_on, gt_o, torch.zeros_like(gt_o)).float()
-        small_feat, small_cnt = [], []
-        for lvl in (2, 3, 4):
-            f, c = class_mean(small_output, torch.where(lvl_o == lvl, gt_o, torch.zeros_like(gt_o)), K)
-            small_feat.append(f)
-            small_cnt.append(c)
-        has_small = per_level[:3] > 0                                   # [3] bool, device
+        F_ = small_output.size(1)
+
+        def per_level_stats(feat, cnt):          # [F, 3K], [1, 3K] -> [1, 3, F, K], [1, 3, 1, K] (views)
+            return feat.view(F_, 3, K).permute(1, 0, 2).unsqueeze(0), cnt.view(1, 3, 1, K)
+
+        small_feat, small_cnt = per_level_stats(*class_mean(small_output, small_cls, 3 * K))
 
         def big_branch():
-            # every (RoI, lower level) pair in (level, RoI) order, compacted to the front of a 3 * RoIs batch
-            pairs = torch.stack([level > lvl for lvl in (2, 3, 4)])                              # [3, N]
-            cap = (3 * total_box + 63) // 64 * 64        # whole row tiles of the fully connected stages: no padding copy
-            flat = torch.nonzero_static(pairs.reshape(-1), size=cap, fill_value=-1).view(-1)
-            valid = flat >= 0
-            flat_c = flat.clamp(min=0)
-            big_idx = flat_c % total_box
-            # (level -1: a row past the live count -- the crop does not even write it, nothing downstream reads it)
-            big_level = torch.where(valid, 2 + flat_c // total_box, torch.full_like(flat_c, -1)).to(torch.int32)
-            live = pairs.sum().to(torch.int32).view(1)
             with torch.no_grad():
                 big_pooled = self._crop(x, boxes[big_idx], box_ind[big_idx], big_level, self.feat_pool_size, None)
                 big_raw = self._feat_extract_live(big_pooled, live)
                 big_out = self.last_op(big_raw) if cfg.DEV.LOSS_CHOICE != 'ot' else big_raw
-                big_out = big_out.view(cap, -1)
-                big_gt = gt[big_idx]
-                big_feat, big_cnt = [], []
-                for i, lvl in enumerate((2, 3, 4)):
-                    # a level without small boxes contributes no big statistics either (:456-467)
-                    use = (big_level == lvl) & has_small[i]
-                    f, c = class_mean(big_out, torch.where(use, big_gt, torch.zeros_like(big_gt)), K)
-                    big_feat.append(f)
-                    big_cnt.append(c)
-                return (torch.stack(big_feat).unsqueeze(0).detach(), torch.stack(big_cnt).unsqueeze(0),
-                        small_output.new_zeros(1, 3, 1))
+                bf, bcnt = per_level_stats(*class_mean(big_out.view(cap, -1), big_cls, 3 * K))
+                return bf.detach(), bcnt, small_output.new_zeros(1, 3, 1)
 
         self.big_done = None
-        if _BIG_SIDE:
+        if _BIG_SIDE and level.is_cuda:
             fork = torch.cuda.Event()
             fork.record(torch.cuda.current_stream(dev))
-            side3 = _lib.side_stream3(dev)
-            # every tensor of THIS stream that the closure reads on the third one: without the mark the allocator may hand
-            # a freed block (has_small is a local of this method) to the next main-stream tensor while the third stream
-            # still reads it -- the class counts of a level went missing that way in the two-pass reference of
-            # tests/test_gpu_data_parallel.py
-            for t in (boxes, box_ind, level, gt, per_level, has_small):
-                t.record_stream(side3)
-            ready = _lib.run_on_side_stream(big_branch, after=fork)
+            # (reads=: every tensor of THIS stream that the closure reads on the third one -- without the mark the allocator
+            # may hand a freed block to the next main-stream tensor while the third stream still reads it)
+            ready = _lib.run_on_side_stream(big_branch, after=fork, reads=(boxes, box_ind, big_idx, big_level, big_cls, live))
             bf, bcnt, bloss = ready.out
             self.big_done = ready.done
         else:
             bf, bcnt, bloss = big_branch()
-        feat_out = [bf, bcnt, torch.stack(small_feat).unsqueeze(0), torch.stack(small_cnt).unsqueeze(0), bloss,
-                    small_output_all, small_gt_all]
+        feat_out = [bf, bcnt, small_feat, small_cnt, bloss, small_output_all, small_gt_all]
         return pooled, mask_and_feat, feat_out
 
 

@@ -506,6 +506,22 @@ int fi_conv2d_weight_grad_rows_f16(const float *x, const float *dy, float *dweig
                                    int Cout, int R, int S, int stride_h, int stride_w, int pad_h, int pad_w, int flags,
                                    const int32_t *rows_live_dev, fi_stream_t stream);
 
+/* The index side of the intertwiner RoI stage with static shapes (lib/sub_module.py:437-598 sizes its batches by the
+ * RoIs' levels with one nonzero / .any() -- a host synchronisation -- per level): one launch turns level[N] (2..5) and the
+ * class ids gt[N] (NULL at inference) into
+ *   order[N]      the stable level-major permutation (torch.sort(level, stable=True)[1]);
+ *   in that order: small_cls[N] = (level - 2) * K + gt on levels 2..4 with gt > 0, else 0 (the class index of ONE
+ *                 fi_class_mean_forward over 3 K classes), small_gt[N] = gt on levels 2..4 else 0 (small_gt_all),
+ *                 small_on[N] = level <= 4;
+ *   the big batch (capacity >= 3 N rows): every (level l < 5, RoI of a level above l) pair in (l, RoI) order at the
+ *                 front -- big_idx = the RoI, big_level = l, big_cls = (l - 2) * K + gt if level l has small rows at all
+ *                 and gt > 0, else 0 -- and big_level = -1 behind the live count;
+ *   counts[5]     n2, n3, n4, n5, live = n3 + 2 n4 + 3 n5 (device integers; nothing is read back).
+ * small_*, big_* and counts may be NULL. */
+int fi_dev_stage_index(const int32_t *level, const int32_t *gt, int N, int num_classes, int capacity, int64_t *order,
+                       int32_t *small_cls, float *small_gt, uint8_t *small_on, int64_t *big_idx, int32_t *big_level,
+                       int32_t *big_cls, int32_t *counts, fi_stream_t stream);
+
 /* ------------------------------------------------------------------------
  * Target generation of one training step.
  * fi_rpn_targets: lib/layers.py:439-604 (generate_target) for a whole minibatch -- IoU of every anchor with the image's

@@ -66,3 +66,36 @@ def test_static_dev_stage_equals_the_stage_with_the_host_read(rois, choice, prec
         diff = float((ga[n] - ref).abs().max())
         bar = (6e-2 if lowp else 1e-4) * float(ref.abs().max()) + 1e-7 * gmax
         assert diff <= bar, (n, diff, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("N,probs", [(8, (1, 1, 1, 1)), (2048, (4, 3, 2, 1)), (2000, (1, 0, 2, 5)), (3000, (0, 0, 0, 1)),
+                                     (1024, (1, 0, 0, 0)), (5000, (3, 1, 0, 2))])
+def test_index_kernel_equals_its_tensor_formulation(N, probs):
+    """fi_dev_stage_index against Dev._static_index_tensors (torch.sort / nonzero_static / where): every output, bit for
+    bit -- levels that are absent, all rows on one level, row counts that are not multiples of the workgroup size."""
+    from feature_intertwiner_amd import sub_module as SM
+    g = torch.Generator().manual_seed(N)
+    level = (2 + torch.multinomial(torch.tensor(probs, dtype=torch.float), N, replacement=True, generator=g)).to(torch.int32).to(DEV)
+    gt = torch.randint(0, 81, (N,), generator=g).to(torch.int32).to(DEV)
+    gt[torch.rand(N, generator=g).to(DEV) < 0.3] = 0
+    cap = (3 * N + 63) // 64 * 64
+    dev_stage = SM.Dev.__new__(SM.Dev)          # the two methods under test use no module state
+    keep = SM._INDEX_KERNEL
+    try:
+        SM._INDEX_KERNEL = True
+        got = SM.Dev._static_index(dev_stage, level, gt, 81, cap)
+        got_inf = SM.Dev._static_index(dev_stage, level, None, 81, cap)
+    finally:
+        SM._INDEX_KERNEL = keep
+    ref = SM.Dev._static_index_tensors(level, gt, 81, cap)
+    ref_inf = SM.Dev._static_index_tensors(level, None, 81, cap)
+    torch.cuda.synchronize()
+    names = ["order", "small_cls", "small_gt", "small_on", "big_idx", "big_level", "big_cls", "live"]
+    for name, a, b in zip(names, got, ref):
+        if name == "big_idx":           # behind the live count the row index is a don't-care (level -1)
+            n_live = int(ref[7])
+            a, b = a[:n_live], b[:n_live]
+        assert a.dtype == b.dtype and torch.equal(a, b), name
+    for name, a, b in zip(names, got_inf, ref_inf):
+        if name in ("order", "small_on", "big_level", "live"):
+            assert torch.equal(a, b), name
