@@ -27,7 +27,9 @@ from .roi_pooling.functions.roi_pool import RoIPoolFunction
 import os as _os
 _BIG_SIDE = _os.environ.get('FI_BIG_SIDE', '1') != '0'
 _INDEX_KERNEL = _os.environ.get('FI_INDEX_KERNEL', '1') != '0'      # fi_dev_stage_index vs its tensor formulation (A/B switch)
-_STATIC_DEV = _os.environ.get('FI_STATIC_DEV', '1') != '0'   # the Dev stage without its host read (Dev.static_shapes; A/B switch)      # the graph-less big branch of the Dev stage on the third stream (A/B switch)
+# the Dev stage without its host read (Dev.static_shapes): True / False, or None = on the fp32 kernels only -- on the 16-bit
+# kernels the extra rows of the static batches cost more than the read (cfg5: 46.4 vs 45.6 ms/step, same box)
+_STATIC_DEV = {'1': True, '0': False}.get(_os.environ.get('FI_STATIC_DEV', ''), None)
 
 class SamePad2d(nn.Module):
     """TensorFlow 'SAME' padding (lib/sub_module.py:9-33).  `folded=True` means the following
@@ -518,7 +520,8 @@ class Dev(nn.Module):
         fi_gemm_nt_rows and their 16-bit twins), the filler rows are never written and carry class 0.  Needs the graph-less big
         branch (the defaults DEV.BIG_FEAT_DETACH, no BIG_SUPERVISE)."""
         cfg = self.config
-        return bool(_STATIC_DEV and rois.is_cuda and self.use_dev and not cfg.DEV.BASELINE and cfg.DEV.BIG_FEAT_DETACH and
+        on = _STATIC_DEV if _STATIC_DEV is not None else getattr(cfg.MODEL, "CONV_PRECISION", "fp32") == "fp32"
+        return bool(on and rois.is_cuda and self.use_dev and not cfg.DEV.BASELINE and cfg.DEV.BIG_FEAT_DETACH and
                     not cfg.DEV.BIG_SUPERVISE and self.roi_type == 'roi_align')
 
     _PERM = {}

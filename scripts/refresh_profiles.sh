@@ -45,7 +45,7 @@ timeout 200 python scripts/wg_batch_probe.py 2>&1 | grep "^{" > $O/${R}_wgrad_ba
 rm -rf /tmp/px; ( cd /tmp && timeout 400 rocprofv3 --kernel-trace --output-format csv -d /tmp/px -o kt -- python $GRAFT_REPO_ROOT/bench.py --steps 6 --warmup 2 --profile-steps 0 --no-cpu-baseline --no-pmc --no-dense-reference > /dev/null 2>&1 )
 f=$(find /tmp/px -name 'kt_kernel_trace.csv' | head -1); python scripts/gpu_idle.py $f > $O/${R}_gpu_idle.txt 2>&1
 timeout 300 python scripts/graph_probe.py 2>&1 | grep -v amdgpu > $O/${R}_graph_probe.txt
-timeout 300 python scripts/graph_probe.py --cfg5 2>&1 | grep -v amdgpu > $O/${R}_graph_probe_cfg5.txt
+FI_STATIC_DEV=1 timeout 300 python scripts/graph_probe.py --cfg5 2>&1 | grep -v amdgpu > $O/${R}_graph_probe_cfg5.txt
 # which streams share a hardware queue (plain, and with a 1-rank RCCL group in the process); the engine's own cost with the
 # streams picked / not picked; run-to-run repeatability of the default backward form
 (python scripts/stream_queues.py; python scripts/stream_queues.py --pg) 2>&1 | grep -v "amdgpu\|socket\|RCCL version\|HIP version\|ROCm version\|Hostname\|Librccl\|destroy_process" > $O/${R}_stream_queues.txt
