@@ -99,3 +99,18 @@ def test_index_kernel_equals_its_tensor_formulation(N, probs):
     for name, a, b in zip(names, got_inf, ref_inf):
         if name in ("order", "small_on", "big_level", "live"):
             assert torch.equal(a, b), name
+
+
+def test_picked_streams_run_next_to_each_other():
+    """_lib.pick_stream: HIP binds a process's streams to at most GPU_MAX_HW_QUEUES hardware queues,
+    and two streams on one queue run their kernels one after the other.  The streams the step uses are picked by
+    measurement; here the measurement is repeated on the picked ones: a kernel on each overtakes a spin kernel on the
+    current stream and on the other picked streams."""
+    from feature_intertwiner_amd import _lib
+    torch.cuda.synchronize()
+    a, b = _lib.side_stream(0), _lib.side_stream3(0)
+    main = torch.cuda.current_stream()
+    assert a is not b and a != main and b != main
+    probe = torch.zeros(64, device=DEV)
+    for x, y in ((main, a), (main, b), (a, b), (b, a)):
+        assert _lib._overtakes(x, y, probe), "two of the step's streams share a hardware queue"
