@@ -165,6 +165,12 @@ class _PyramidCrop(torch.autograd.Function):
             grads = [torch.empty(s, device=g.device, dtype=torch.float32, memory_format=fmt) for s in ctx.shapes]
             if group is not None:
                 group.grads = grads
+                # the sharing holds for ONE backward pass: a further pass through the same graph (retain_graph, a second
+                # loss) must start with fresh buffers and hand them to autograd again
+                try:
+                    torch.autograd.Variable._execution_engine.queue_callback(lambda g=group: setattr(g, "grads", None))
+                except RuntimeError:          # called outside a backward pass
+                    pass
         ptrs = (ctypes.c_void_p * nl)(*[t.data_ptr() for t in grads])
         hs = (ctypes.c_int * nl)(*[s[2] for s in ctx.shapes])
         ws = (ctypes.c_int * nl)(*[s[3] for s in ctx.shapes])

@@ -309,3 +309,41 @@ def test_roi_align_module_matches_oracle(oracle):
         # the box transform runs in torch fp32 on the GPU: division may differ by 1 ulp from
         # numpy, so compare values with a tolerance here (bin assignment itself is tested above)
         assert np.allclose(got, exp, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("channels_last", [False, True])
+def test_crop_grad_group_shares_buffers_within_one_backward_pass_only(channels_last):
+    """Two pyramid crops of the same maps in one CropGradGroup (the Dev stage's 7x7 and 14x14 crops,
+    lib/sub_module.py:549-577): their map gradients accumulate in ONE set of buffers -- equal to two independent crops --
+    and a SECOND backward pass through the same graph starts with fresh buffers (the gradients double; they are neither
+    dropped nor added into the first pass's tensors)."""
+    from feature_intertwiner_amd.roi_align.crop_and_resize import CropGradGroup, pyramid_crop_and_resize
+    rs = np.random.RandomState(5)
+    B, C, N = 2, 64, 96
+    fmt = torch.channels_last if channels_last else torch.contiguous_format
+    maps = [torch.from_numpy(rs.standard_normal((B, C, s, s)).astype(np.float32)).to(DEV).contiguous(memory_format=fmt)
+            for s in (64, 32, 16, 8)]
+    boxes = torch.from_numpy(adversarial_boxes(rs, N, 64, 64)).to(DEV)
+    ind = torch.from_numpy(rs.randint(0, B, N).astype(np.int32)).to(DEV)
+    level = torch.from_numpy(rs.randint(2, 6, N).astype(np.int32)).to(DEV)
+    g7 = torch.from_numpy(rs.standard_normal((N, C, 7, 7)).astype(np.float32)).to(DEV)
+    g14 = torch.from_numpy(rs.standard_normal((N, C, 14, 14)).astype(np.float32)).to(DEV)
+
+    def run(shared, passes):
+        tm = [m.clone().requires_grad_(True) for m in maps]
+        group = CropGradGroup() if shared else None
+        a = pyramid_crop_and_resize(tm, boxes, ind, level, 7, 7, grad_group=group)
+        b = pyramid_crop_and_resize(tm, boxes, ind, level, 14, 14, grad_group=CropGradGroup() if not shared else group)
+        loss = (a * g7).sum() + (b * g14).sum()
+        for _ in range(passes):
+            loss.backward(retain_graph=True)
+        torch.cuda.synchronize()
+        return [t.grad.clone() for t in tm]
+
+    ref = run(False, 1)
+    one = run(True, 1)
+    two = run(True, 2)
+    for r, a, b in zip(ref, one, two):
+        tol = 2e-5 * (r.abs().max().item() + 1e-6)           # fp32 atomics: the order of the additions differs
+        assert (a - r).abs().max().item() <= tol
+        assert (b - 2 * r).abs().max().item() <= 2 * tol
