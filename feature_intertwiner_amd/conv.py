@@ -842,7 +842,7 @@ def _cached_wt(w, scaled=False):
     return None
 
 
-def _arena_take(key, numel):
+def _arena_take(key, numel, partner=None):
     """(slot, first): the slot reserved for `key` in this step's arena (zeroed at the start of the step) and
     whether this is its first use in the step.  A layer applied several times per step (the RPN on 5 levels, the
     feature extractor on small and big boxes) ACCUMULATES all its gradient contributions in the one slot -- the
@@ -854,6 +854,8 @@ def _arena_take(key, numel):
     owner = slot[2]()
     if owner is None or owner.data_ptr() != key[1]:
         return None, False        # the model this arena belongs to is gone and its address was reused
+    if partner is not None and len(slot) > 3 and slot[3] != partner:
+        return None, False        # a BatchNorm block laid out for another convolution's bias: private buffers instead
     first = key not in _ARENA["used"]
     _ARENA["used"].add(key)
     return _ARENA["buf"][slot[0]:slot[0] + numel], first
@@ -934,7 +936,12 @@ def _prepare_step(model, grad_on):
                 slots[("db", m.bias.data_ptr())] = layout.slot[m.bias] + (weakref.ref(m.bias),)
         for bn in [m for m in model.modules() if isinstance(m, nn.BatchNorm2d)]:
             if bn in layout.bn_slot:
-                slots[("bn", bn.weight.data_ptr())] = (layout.bn_slot[bn], 3 * bn.num_features, weakref.ref(bn.weight))
+                # (4th entry: the address of the convolution bias the layout paired with this BatchNorm -- by adjacency
+                # among a module's children; a caller that combines the BatchNorm with ANOTHER convolution must not
+                # have that one's bias gradient adopted as a view of this block)
+                partner = layout.bn_partner.get(bn)
+                slots[("bn", bn.weight.data_ptr())] = (layout.bn_slot[bn], 3 * bn.num_features, weakref.ref(bn.weight),
+                                                       partner.data_ptr() if partner is not None else 0)
         plan = {"ptrs": tuple(p.data_ptr() for p in model.parameters()), "tr": tr, "wts": wts, "table": table,
                 "desc": desc, "tiles": base, "slots": slots, "layout": layout, "versions": None, "convs": convs,
                 "scales": None}
@@ -1104,7 +1111,7 @@ class _ConvBnActFn(torch.autograd.Function):
         N, C, OH, OW = y.shape
         if not ctx.needs_input_grad[1]:
             return None                          # frozen weights: no weight gradient to take the sums from
-        sums, first = _arena_take(("bn", gamma.data_ptr()), 3 * C)
+        sums, first = _arena_take(("bn", gamma.data_ptr()), 3 * C, partner=b.data_ptr() if has_bias else 0)
         if sums is not None and not first:
             return None                          # applied more than once this step: sums and dW accumulate
         L = _lib.load()
@@ -1156,7 +1163,7 @@ class _ConvBnActFn(torch.autograd.Function):
             r = _ConvBnActFn._backward_unscaled(ctx, dy)
             if r is not None:
                 return r
-        x, w, y, scale, gamma, beta, res, _b = ctx.saved_tensors
+        x, w, y, scale, gamma, beta, res, b = ctx.saved_tensors
         stride, padding, has_bias, relu, has_res, eps, mean, var = ctx.conf
         L = _lib.load()
         # channels-last output: the gradient comes back channels-last from the RoIAlign backward and is
@@ -1166,7 +1173,7 @@ class _ConvBnActFn(torch.autograd.Function):
         dz = torch.empty(y.shape, device=y.device, dtype=torch.float32)
         g_res = torch.empty_like(y) if (has_res and ctx.needs_input_grad[8]) else None
         # (d shift, d gamma, d conv-bias) adjacent: a slot of the step's zeroed arena, or ONE fill in the call
-        sums, first = _arena_take(("bn", gamma.data_ptr()), 3 * C)
+        sums, first = _arena_take(("bn", gamma.data_ptr()), 3 * C, partner=b.data_ptr() if has_bias else 0)
         flags = _lib.OUTPUTS_ZEROED if sums is not None else 0
         if sums is None:
             sums, first = torch.empty(3 * C, device=y.device, dtype=torch.float32), True

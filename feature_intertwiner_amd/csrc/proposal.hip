@@ -18,6 +18,8 @@
 // in the same selection; they rank before anchors at equal score.
 #include <stdint.h>
 
+#include <atomic>
+
 #include "fi_common.h"
 
 namespace {
@@ -258,11 +260,15 @@ int fi_proposal_candidates(const float *probs, int prob_stride, int prob_offset,
     a.std0 = bbox_std_host[0]; a.std1 = bbox_std_host[1]; a.std2 = bbox_std_host[2]; a.std3 = bbox_std_host[3];
     a.win_h = window_h; a.win_w = window_w;
     const size_t lds = sizeof(u64) * kSortCap;
-    static bool attr_set = false;
-    if (!attr_set) {
+    // the attribute belongs to the (function, device) pair: once per device of the process, from any thread
+    static std::atomic<unsigned long long> attr_set{0};
+    int dev = 0;
+    FI_HIP_CHECK(hipGetDevice(&dev));
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(attr_set.load(std::memory_order_acquire) & bit)) {
         FI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(proposal_select_kernel),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
+        attr_set.fetch_or(bit, std::memory_order_release);
     }
     fi::ProfScope prof(FI_K_PROPOSAL_SELECT, (hipStream_t)stream);
     hipLaunchKernelGGL(proposal_select_kernel, dim3(batch), dim3(kSelThreads), lds, (hipStream_t)stream, a);

@@ -65,6 +65,7 @@ class ArenaLayout(object):
                                 group_of[p] = g
         self.slot = {}              # parameter -> (offset, numel)
         self.bn_slot = {}           # BatchNorm2d module -> offset of its 3*C block
+        self.bn_partner = {}        # BatchNorm2d module -> the convolution bias whose gradient is the block's third part
         self.buckets = []
         off, start, cur, done = 0, 0, [], set()
 
@@ -102,6 +103,7 @@ class ArenaLayout(object):
                 bn, members = g
                 C = bn.num_features
                 self.bn_slot[bn] = off
+                self.bn_partner[bn] = members[2]
                 for i, q in enumerate(members):
                     if q is not None:
                         self.slot[q] = (off + i * C, C)
