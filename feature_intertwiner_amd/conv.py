@@ -72,6 +72,14 @@ def _log_flops(kind, cout, R, S, flops, pixels=None, cin=None, patch=0, batch=1)
         e[1] += flops
 
 
+def _live_share(live, capacity):
+    """Share of a static-capacity batch that is real, for the flop log only (a profiled pass may read the device count;
+    the timed step never does: FLOP_LOG is None there)."""
+    if FLOP_LOG is None or live is None or capacity <= 0:
+        return 1.0
+    return min(1.0, float(int(live.reshape(-1)[0].item())) / capacity)
+
+
 def _dense(w):
     """A weight as the kernels can read it: NCHW-contiguous or channels-last-contiguous, no copy if it
     already is one of the two (parameters with Cin % 16 == 0 are stored channels-last, see
@@ -107,8 +115,9 @@ def _conv_fwd(x, w, b, stride, padding, relu=False, scale=None, residual=None, o
     if out_hw is not None:
         OH, OW = out_hw
     prec = _PRECISION if precision is None else precision
+    share = _live_share(live, N)            # (algorithmic flops: the live images only)
     if not (prec in _LOWP and layout >= 1 and Cin % 32 == 0):
-        _log_flops("fwd", Cout, R, S, 2 * N * Cout * OH * OW * Cin * R * S, N * OH * OW,
+        _log_flops("fwd", Cout, R, S, share * 2 * N * Cout * OH * OW * Cin * R * S, N * OH * OW,
                    patch=(_lib.patch_mode(N, Cin, H, W, Cout, R, S, stride, padding, layout >= 1,
                                           (OH, OW) == (H, W), out_channels_last) or
                           (3 if _lib.reg1x1_mode(N, Cin, H, W, Cout, R, S, stride, padding, out_channels_last) else 0))
@@ -121,7 +130,7 @@ def _conv_fwd(x, w, b, stride, padding, relu=False, scale=None, residual=None, o
         assert not out_channels_last and gate.shape == y.shape and gate.is_contiguous()
     fn = _lowp_fn(L, "conv2d_forward_gated", prec) if bf16 else L.fi_conv2d_forward_gated
     if bf16:
-        _log_flops("bf16_fwd", Cout, R, S, 2 * N * Cout * OH * OW * Cin * R * S)
+        _log_flops("bf16_fwd", Cout, R, S, share * 2 * N * Cout * OH * OW * Cin * R * S)
         # 3x3 / stride 1 / pad 1 on maps whose width is a multiple of 16 (or 14-wide RoI maps): patch kernel with the
         # weights converted to bf16 once per step (cached like W^T) instead of inside every workgroup
         mt = (Cout + 127) // 128
@@ -1465,7 +1474,7 @@ def _gemm_nt(a, b, bias=None, relu=False, precision="fp32", live=None, scale=Non
     N = b.shape[0]
     if precision in _LOWP and M % 64 == 0 and K >= 64:
         y = torch.empty((M, N), device=a.device, dtype=torch.float32)
-        _log_flops("bf16_wgrad", M, 1, 1, 2.0 * M * N * K)
+        _log_flops("bf16_wgrad", M, 1, 1, _live_share(live, M) * 2.0 * M * N * K)
         with torch.cuda.device(a.device):
             if live is not None:
                 _lib.check(_lowp_fn(L, "conv2d_weight_grad_rows", precision)(_lib.ptr(b), _lib.ptr(a), _lib.ptr(y), 1, N, 1, K,
@@ -1486,7 +1495,7 @@ def _gemm_nt(a, b, bias=None, relu=False, precision="fp32", live=None, scale=Non
         return torch.relu_(y) if relu else y
     y = torch.empty((M, N), device=a.device, dtype=torch.float32)
     ws = torch.empty((int(L.fi_gemm_nt_workspace_bytes(M, N, K)) + 3) // 4, device=a.device, dtype=torch.float32)
-    _log_flops("wgrad", M, 1, 1, 2.0 * M * N * K, K, N)
+    _log_flops("wgrad", M, 1, 1, _live_share(live, M) * 2.0 * M * N * K, K, N)
     with torch.cuda.device(a.device):
         _lib.check(L.fi_gemm_nt_affine(_lib.ptr(a), _lib.ptr(b), _lib.ptr(scale), _lib.ptr(bias), _lib.ptr(y), M, N, K,
                                        1 if relu else 0, _lib.ptr(ws), _lib.ptr(live), _lib.current_stream()), "fi_gemm_nt")
