@@ -94,6 +94,10 @@ SIGNATURES = {
     "fi_conv2d_weight_grad_rows_bf16": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 12 + [c_void_p, c_void_p]),
     "fi_conv2d_weight_grad_rows_f16": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 12 + [c_void_p, c_void_p]),
     "fi_gemm_nt_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "fi_meta_stats_workspace_bytes": (ctypes.c_size_t, [c_int, c_int]),
+    "fi_meta_stats_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int,
+                                      c_int, c_int, c_int, c_int] + [c_void_p] * 9),
+    "fi_meta_stats_backward": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 7 + [c_void_p, c_void_p]),
     "fi_dev_stage_index": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int] + [c_void_p] * 9),
     "fi_gemm_nt_affine": (c_int, [c_void_p] * 5 + [c_int] * 4 + [c_void_p, c_void_p, c_void_p]),
     "fi_rows_mask_scale": (c_int, [c_void_p] * 6 + [c_int] * 5 + [c_void_p]),

@@ -829,9 +829,17 @@ class Classifier(nn.Module):
                 x = (1 - wgt) * x + wgt * small_feat_input.view(x.size(0), x.size(1), 1, 1)
         x = conv_bn_act(x, self.conv2, self.bn2, relu=True)
         x = x.view(-1, 1024)
-        logits = linear(x, self.linear_class.weight, self.linear_class.bias)
+        if x.is_cuda:
+            # the two heads read the same rows: ONE matrix product over the stacked weights (81 + 324 output columns,
+            # padded once to the kernel's 128-column tiles instead of 128 + 384), split afterwards
+            nc = self.linear_class.weight.shape[0]
+            heads = linear(x, torch.cat((self.linear_class.weight, self.linear_bbox.weight), 0),
+                           torch.cat((self.linear_class.bias, self.linear_bbox.bias), 0))
+            logits, bbox = heads[:, :nc].contiguous(), heads[:, nc:].contiguous()
+        else:
+            logits = linear(x, self.linear_class.weight, self.linear_class.bias)
+            bbox = linear(x, self.linear_bbox.weight, self.linear_bbox.bias)
         probs = self.softmax(logits)
-        bbox = linear(x, self.linear_bbox.weight, self.linear_bbox.bias)
         bbox = bbox.view(bbox.size(0), -1, 4)
         return [logits, probs, bbox]
 

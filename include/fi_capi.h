@@ -522,6 +522,24 @@ int fi_dev_stage_index(const int32_t *level, const int32_t *gt, int N, int num_c
                        int32_t *small_cls, float *small_gt, uint8_t *small_on, int64_t *big_idx, int32_t *big_level,
                        int32_t *big_cls, int32_t *counts, fi_stream_t stream);
 
+/* The statistics side of the meta loss (MaskRCNN.meta_loss, lib/model.py:143-210) on one rank with a history of one
+ * step: _merge_feat_vec (:217-224) of the big and the small class features over L levels, the history-buffer update
+ * (:150-166; `buffer` [F][K] and `buffer_cnt` [K] are updated IN PLACE, and left alone when the step has no small-object
+ * statistics, lib/workflow.py:190), the class selection (:176-181) and the transposed operands of the pair loss:
+ *   SMALL [K-1][F] (merged small features, foreground classes), BIG [K-1][F] (history after the update),
+ *   on [K-1] (1 = small count > 0 and history count > 0), active_f [1], s_cnt_out [K] (kept for the backward).
+ * feat[g][s][f][k] = base[g * lg + s * lk + f * ld + k] (G = the reference's nn.DataParallel ranks, S = levels; the sums
+ * run over g first, then over s, as `.sum(0).sum(0)` does); cnt[g][s][k] = base[(g * S + s) * K + k].  Three launches; the tensor formulation
+ * (feature_intertwiner_amd.intertwiner.meta_loss) is ~35.  workspace: fi_meta_stats_workspace_bytes(F, K).
+ * Backward: d small_feat[g][s][f][k] = d SMALL[k-1][f] / (s_cnt[k] + 1e-20) * small_cnt[g][s][k], 0 for k = 0. */
+size_t fi_meta_stats_workspace_bytes(int F, int K);
+int fi_meta_stats_forward(const float *big_feat, const float *big_cnt, int big_ld, int big_lk, int big_lg,
+                          const float *small_feat, const float *small_cnt, int small_ld, int small_lk, int small_lg, int G,
+                          int S, int F, int K, float *buffer, float *buffer_cnt, float *s_cnt_out, float *SMALL, float *BIG,
+                          float *on, float *active_f, float *workspace, fi_stream_t stream);
+int fi_meta_stats_backward(const float *dsmall, const float *s_cnt, const float *small_cnt, int G, int S, int F, int K,
+                           int out_ld, int out_lk, int out_lg, float *dfeat, fi_stream_t stream);
+
 /* ------------------------------------------------------------------------
  * Target generation of one training step.
  * fi_rpn_targets: lib/layers.py:439-604 (generate_target) for a whole minibatch -- IoU of every anchor with the image's

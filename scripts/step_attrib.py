@@ -62,6 +62,13 @@ with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
     torch.cuda.synchronize()
 
 LIB = ("(anonymous namespace)::", "_GLOBAL__N_", "fi_calib")
+# ... and every __global__ function of csrc/ by name: a kernel defined outside an anonymous namespace (the split-K
+# reduction of fi_gemm_nt) carries no such marker and used to be counted as a framework launch
+import glob, re
+LIB_KERNELS = set()
+for _f in glob.glob(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "feature_intertwiner_amd", "csrc", "*.h*")):
+    for _m in re.finditer(r"__global__[^;{]*?void\s+(\w+)\s*\(", open(_f).read(), re.S):
+        LIB_KERNELS.add(_m.group(1))
 
 
 def origin(ev):
@@ -94,7 +101,8 @@ for ev in prof.events():
         continue
     org, op = origin(ev)
     for k in ks:
-        lib = any(s in k.name for s in LIB) and "at::native" not in k.name and "rocprim" not in k.name
+        base = k.name.split("(")[0].split("<")[0].replace("void ", "").split("::")[-1].strip()
+        lib = (any(s in k.name for s in LIB) or base in LIB_KERNELS) and "at::native" not in k.name and "rocprim" not in k.name
         key = (org, "<library kernels>" if lib else (op or "?") + " -> " + k.name.split("(")[0].replace("void ", "")[:70])
         e = acc.setdefault(key, [0, 0.0])
         e[0] += 1

@@ -134,3 +134,44 @@ def test_model_meta_loss_over_consecutive_steps_vs_oracle(oracle, choice, buffer
         assert np.array_equal(model.feature_buffer.buffer_cnt.cpu().numpy(), ml.buffer_cnt)
         assert np.allclose(model.feature_buffer.buffer.cpu().numpy(), ml.buffer, rtol=1e-5, atol=1e-7)
     assert n_selected > 0          # the comparison was not vacuous
+
+
+@pytest.mark.parametrize("choice", ["l2", "kl", "ot"])
+@pytest.mark.parametrize("layout", ["stacked", "one_launch_view"])
+def test_statistics_kernels_equal_the_tensor_formulation(choice, layout):
+    """fi_meta_stats_forward / _backward (merge, history update, selection, transposes: three launches) against the
+    tensor formulation of intertwiner.meta_loss on the same inputs over three steps (the second without small-object
+    statistics: history untouched, loss 0): loss, history buffer and counts, and the gradient with respect to the small
+    class features.  Both memory layouts Dev.forward produces."""
+    from feature_intertwiner_amd import intertwiner as IT
+    G, S = (2, 3) if layout == "stacked" else (1, 3)
+    ot = _ot_module() if choice == "ot" else None
+    out = {}
+    keep = IT.STATS_KERNEL
+    try:
+        for on in (True, False):
+            IT.STATS_KERNEL = on
+            buf = IT.FeatureBuffer(1, F, K, DEV)
+            res = []
+            for step in (0, 2, 1):
+                bf, bc, sf, sc = [torch.from_numpy(a).to(DEV) for a in golden_meta_inputs(step, K, F, G=G, activation=ACT[choice])]
+                if layout == "one_launch_view":         # [F, S K] storage viewed as [1, S, F, K]
+                    as_view = lambda t: t[0].permute(1, 0, 2).reshape(F, S * K).contiguous().view(F, S, K).permute(1, 0, 2).unsqueeze(0)
+                    bf, sf = as_view(bf), as_view(sf)
+                    assert not sf.is_contiguous()
+                sf = sf.detach().requires_grad_(True)
+                loss = IT.meta_loss(_cfg(choice), buf, ot, [bf, bc, sf, sc, None, None])
+                loss.backward()
+                res.append((float(loss.detach()), sf.grad.clone(), buf.buffer.clone(), buf.buffer_cnt.clone()))
+            out[on] = res
+    finally:
+        IT.STATS_KERNEL = keep
+    for (la, ga, ba, ca), (lb, gb, bb, cb) in zip(out[True], out[False]):
+        assert torch.equal(ca, cb)
+        assert (ba - bb).abs().max().item() <= 1e-6 * bb.abs().max().item()
+        if choice == "ot":
+            assert abs(la - lb) <= OT_ABS
+        else:
+            assert abs(la - lb) <= 2e-6 * abs(lb) + 1e-12
+            assert (ga - gb).abs().max().item() <= 1e-5 * gb.abs().max().item() + 1e-12
+    assert out[True][1][0] == 0.0 and torch.equal(out[True][1][2], out[True][0][2])      # the step without statistics
