@@ -271,6 +271,34 @@ def roi_level(rois, image_area, base=224.0):
     return np.clip(lvl, 2, 5).astype(np.int32)
 
 
+def dev_stage_groups(level, gt=None):
+    """Which RoIs the intertwiner stage feeds where, per pyramid level, as the reference's loop over levels 2..5 builds it
+    (lib/sub_module.py:437-598, structure 'beta'): level ell's SMALL boxes are the RoIs with roi_level == ell, in RoI
+    order (small_ix, :440-454 with DEV.ASSIGN_BOX_ON_ALL_SCALE off); its BIG boxes are those of the levels above,
+    _find_big_box2 (:366-378: 2 -> {3,4,5}, 3 -> {4,5}, 4 -> {5}, 5 -> none), and they contribute statistics only when
+    the level has small boxes at all (:456-467).  Statistics exist for levels 2..4 (:434-435).  The small rows are
+    written level-major into small_output_all / small_gt_all (:583-598).
+    level [N] int (2..5), gt [N] class ids or None.  Returns dict(order = RoI indices in level-major order (levels 2..5),
+    small = {ell: indices}, big = {ell: indices} for ell in 2..4 (empty when the level has no small box),
+    small_gt_all [N] float (class id of the small rows of levels 2..4 in level-major order, 0 behind them))."""
+    level = np.asarray(level).astype(np.int64).reshape(-1)
+    N = level.size
+    gt = np.zeros(N, np.int64) if gt is None else np.asarray(gt).astype(np.int64).reshape(-1)
+    small, big, order = {}, {}, []
+    small_gt_all = np.zeros(N, np.float32)
+    pos = 0
+    for ell in (2, 3, 4, 5):
+        idx = np.nonzero(level == ell)[0]
+        order.append(idx)
+        if ell <= 4:
+            small[ell] = idx
+            above = np.nonzero(level > ell)[0]
+            big[ell] = above if idx.size else above[:0]
+            small_gt_all[pos:pos + idx.size] = gt[idx]
+            pos += idx.size
+    return {"order": np.concatenate(order), "small": small, "big": big, "small_gt_all": small_gt_all}
+
+
 # ----------------------------------------------------------------------------
 # Intertwiner meta loss + history buffer (lib/model.py:143-224, lib/workflow.py:190-203)
 # ----------------------------------------------------------------------------

@@ -3,6 +3,7 @@ branch of static capacity whose live count stays on the device) against the stag
 sized by the RoI counts per level, as lib/sub_module.py:437-540 of the reference sizes them with nonzero / .any()).  Same
 weights, inputs and random draws: the same RoIs reach the same layers, so losses and gradients agree up to the summation
 order of the fully connected stages (their K split depends on the row count)."""
+import numpy as np
 import pytest
 import torch
 
@@ -114,3 +115,41 @@ def test_picked_streams_run_next_to_each_other():
     probe = torch.zeros(64, device=DEV)
     for x, y in ((main, a), (main, b), (a, b), (b, a)):
         assert _lib._overtakes(x, y, probe), "two of the step's streams share a hardware queue"
+
+
+@pytest.mark.parametrize("N,probs", [(2048, (4, 3, 2, 1)), (2000, (1, 0, 2, 5)), (777, (0, 1, 1, 1)), (64, (1, 1, 1, 0))])
+def test_index_kernel_against_the_oracles_level_loop(oracle, N, probs):
+    """fi_dev_stage_index against oracle.dev_stage_groups (the reference's loop over the levels, lib/sub_module.py:437-598):
+    the level-major order, which rows are small rows of which level and class, and every level's big rows in RoI order
+    with their classes -- dropped (class index 0) when the level has no small box."""
+    from feature_intertwiner_amd import sub_module as SM
+    K = 81
+    g = torch.Generator().manual_seed(100 + N)
+    level = (2 + torch.multinomial(torch.tensor(probs, dtype=torch.float), N, replacement=True, generator=g)).to(torch.int32)
+    gt = torch.randint(0, K, (N,), generator=g).to(torch.int32)
+    ref = oracle.dev_stage_groups(level.numpy(), gt.numpy())
+    cap = (3 * N + 63) // 64 * 64
+    keep = SM._INDEX_KERNEL
+    try:
+        SM._INDEX_KERNEL = True
+        order, small_cls, small_gt, small_on, big_idx, big_level, big_cls, live = [
+            t.cpu().numpy() for t in SM.Dev._static_index(SM.Dev.__new__(SM.Dev), level.to(DEV), gt.to(DEV), K, cap)]
+    finally:
+        SM._INDEX_KERNEL = keep
+    assert (order == ref["order"]).all()
+    assert (small_gt == ref["small_gt_all"]).all()
+    n_small = sum(len(ref["small"][l]) for l in (2, 3, 4))
+    assert small_on[:n_small].all() and not small_on[n_small:].any()
+    pos, bpos = 0, 0
+    for l in (2, 3, 4):
+        idx = ref["small"][l]
+        want = np.where(gt.numpy()[idx] > 0, (l - 2) * K + gt.numpy()[idx], 0)
+        assert (small_cls[pos:pos + len(idx)] == want).all()
+        pos += len(idx)
+        above = np.nonzero(level.numpy() > l)[0]                 # the stage crops them whether or not they count
+        assert (big_idx[bpos:bpos + len(above)] == above).all() and (big_level[bpos:bpos + len(above)] == l).all()
+        counted = len(ref["big"][l]) > 0 or len(above) == 0
+        want = np.where(gt.numpy()[above] > 0, (l - 2) * K + gt.numpy()[above], 0) if counted else np.zeros(len(above), np.int64)
+        assert (big_cls[bpos:bpos + len(above)] == want).all()
+        bpos += len(above)
+    assert int(live[0]) == bpos and (big_level[bpos:] == -1).all() and (small_cls[pos:] == 0).all()

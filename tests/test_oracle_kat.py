@@ -195,3 +195,40 @@ def test_class_mean_and_level(oracle):
     s = np.array([224, 112, 448, 8, 1000], np.float32) / 1024
     rois = np.stack([np.zeros(5, np.float32), np.zeros(5, np.float32), s, s], 1)
     assert oracle.roi_level(rois, 1024 * 1024).tolist() == [4, 3, 5, 2, 5]
+
+
+def test_dev_stage_groups_known_answer(oracle):
+    """oracle.dev_stage_groups on a hand-worked case (lib/sub_module.py:366-378, 437-598): levels 5,2,3,3,4,2,5,4."""
+    r = oracle.dev_stage_groups([5, 2, 3, 3, 4, 2, 5, 4], [1, 0, 2, 3, 4, 5, 6, 0])
+    assert r["order"].tolist() == [1, 5, 2, 3, 4, 7, 0, 6]
+    assert r["small"][2].tolist() == [1, 5] and r["small"][3].tolist() == [2, 3] and r["small"][4].tolist() == [4, 7]
+    assert r["big"][2].tolist() == [0, 2, 3, 4, 6, 7] and r["big"][3].tolist() == [0, 4, 6, 7] and r["big"][4].tolist() == [0, 6]
+    assert r["small_gt_all"].tolist() == [0, 5, 2, 3, 4, 0, 0, 0]
+    # a level without small boxes has no big statistics either (:456-467)
+    r = oracle.dev_stage_groups([5, 3, 3, 5], None)
+    assert r["big"][2].tolist() == [] and r["big"][3].tolist() == [0, 3] and r["big"][4].tolist() == []
+
+
+def test_static_index_tensor_formulation_equals_the_oracle(oracle):
+    """Dev._static_index_tensors (the CPU / reference form of fi_dev_stage_index) against oracle.dev_stage_groups."""
+    import numpy as np
+    import torch
+    from feature_intertwiner_amd.sub_module import Dev
+    rs = np.random.RandomState(3)
+    for N in (8, 100, 513):
+        level = rs.randint(2, 6, N).astype(np.int32)
+        gt = rs.randint(0, 11, N).astype(np.int32)
+        ref = oracle.dev_stage_groups(level, gt)
+        cap = (3 * N + 63) // 64 * 64
+        order, small_cls, small_gt, small_on, big_idx, big_level, big_cls, live = [
+            t.numpy() for t in Dev._static_index_tensors(torch.from_numpy(level), torch.from_numpy(gt), 11, cap)]
+        assert (order == ref["order"]).all() and (small_gt == ref["small_gt_all"]).all()
+        bpos = 0
+        for l in (2, 3, 4):
+            above = np.nonzero(level > l)[0]
+            assert (big_idx[bpos:bpos + len(above)] == above).all()
+            counted = len(ref["big"][l]) > 0
+            want = np.where((gt[above] > 0) & counted, (l - 2) * 11 + gt[above], 0)
+            assert (big_cls[bpos:bpos + len(above)] == want).all()
+            bpos += len(above)
+        assert int(live[0]) == bpos
