@@ -1915,9 +1915,18 @@ static int wgrad16_impl(const float *x, const float *dy, float *dweight, float *
             const int ptiles = fi::ceil_div(g.P, FK);
             // split the pixel range so that ~2048 workgroups exist, at least 8 K-tiles each
             const int nb = batch ? batch->n : 1;            // a batch fills the chip together: fewer, longer splits each
-            long z = 2048 / (tiles * nb);
+            static const int target_wg = getenv("FI_WG16_TARGET") ? atoi(getenv("FI_WG16_TARGET")) : 2048;    // (tuning knob)
+            long z = target_wg / (tiles * nb);
             if (z < 1) z = 1;
             if (z > ptiles / 8) z = ptiles / 8 > 0 ? ptiles / 8 : 1;
+            if (N == 1 && H == 1 && !batch) {
+                // the kernel as a GEMM (conv.linear: one long reduction): every split ends with a 64 KB atomic epilogue, so
+                // a split should cover >= 3072 elements of the reduction as long as the chip still gets a workgroup per CU
+                // (scripts/gemm16_probe.py: 2048 x 1024 x 12544 163 -> 111 us, 1408 x 1024 x 25088 180 -> 150 us)
+                long zmax = g.P / 3072, zmin = fi::ceil_div(256, (int)tiles);
+                if (zmax < zmin) zmax = zmin;
+                if (z > zmax) z = zmax;
+            }
             if (z > 65535) z = 65535;
             const int per = fi::ceil_div(ptiles, (int)z);
             z = fi::ceil_div(ptiles, per);
