@@ -2583,7 +2583,8 @@ static void gemm_nt_plan(int M, int N, int K, int *bm, int *splits, int *pps)
     const long reach128 = tiles128 * (per < max_splits0 ? per : max_splits0);
     *bm = (M <= 64 || reach128 < 768) ? 64 : 128;
     const long tiles = (long)fi::ceil_div(N, BN) * fi::ceil_div(M, *bm);
-    long want = 1024 / tiles;
+    static const long target_wg = getenv("FI_GEMM_TARGET") ? atol(getenv("FI_GEMM_TARGET")) : 1024;      // (tuning knob)
+    long want = target_wg / tiles;
     long sp = want < 1 ? 1 : (want > max_splits0 ? max_splits0 : want);
     int p = fi::ceil_div(K, (int)sp);
     p = fi::ceil_div(p, BK) * BK;
