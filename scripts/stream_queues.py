@@ -72,3 +72,23 @@ if "--pg" in sys.argv:
             ew.record(side)
         torch.cuda.synchronize()
         print("collective vs spin on %-5s: %s" % (n, "concurrent" if e0.elapsed_time(ew) < 0.5 * e0.elapsed_time(ea) else "SERIAL"))
+if "--pg" in sys.argv:
+    # The other direction: is work on stream X held up by a collective that is itself waiting (here: for a spin kernel on
+    # the stream it was issued from)?  X = the default (null) stream and a non-null stream with a queue of its own.
+    import torch.distributed as dist
+    issue, other = pool[0], pool[1]          # s0, s1: different hardware queues (matrix above)
+    for label, xs in (("default (null) stream", main), ("non-null stream s1", other)):
+        torch.cuda.synchronize()
+        e0, e_x, e_spin = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        with torch.cuda.stream(issue):
+            e0.record(issue)
+            torch.cuda._sleep(SPIN)
+            e_spin.record(issue)
+            w = dist.all_reduce(x, async_op=True)        # the process group's stream now waits for the spin on `issue`
+        with torch.cuda.stream(xs):
+            y = torch.ones(16, device=dev) + 1           # noqa: F841  issued AFTER the collective, independent of it
+            e_x.record(xs)
+        w.wait()
+        torch.cuda.synchronize()
+        held = e0.elapsed_time(e_x) > 0.5 * e0.elapsed_time(e_spin)
+        print("a kernel on the %-22s issued behind a pending collective: %s" % (label, "HELD UP until the collective ran" if held else "runs at once"))
