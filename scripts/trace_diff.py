@@ -16,7 +16,8 @@ def load(path, steps):
     tot, cnt = defaultdict(float), defaultdict(int)
     for s, e, n in rows:
         if s >= lo and e <= hi:
-            k = n.split("(")[0][:70]
+            k = n.replace("void ", "").replace("(anonymous namespace)::", "")
+            k = k.split("(")[0][:70]
             tot[k] += (e - s) / 1e6 / steps
             cnt[k] += 1
     return tot, cnt, (hi - lo) / 1e6 / steps
