@@ -100,6 +100,43 @@ def bbox_overlaps(boxes1, boxes2):
 # --------------------------------------------------------------------------------------
 # proposal layer (lib/layers.py:71-139)
 # --------------------------------------------------------------------------------------
+PRE_NMS_KERNEL_LIMIT = 8192       # fi_proposal_candidates sorts its winners in 64 KB of LDS
+
+
+def _proposal_candidates_tensors(probs, deltas, anchors, extra_dets, pre_nms_limit, std, height, width):
+    """fi_proposal_candidates as tensor operations on the device, for a PRE_NMS_LIMIT the kernel's LDS sort does not hold
+    (> 8192; the reference's own full sort, lib/layers.py:99-127, has no such bound): the same candidates in the same
+    order (descending score, ties to the lower index, external rows ahead of anchors), the same float32 operation order
+    for deltas * BBOX_STD_DEV, apply_box_deltas and clip_boxes (tools/box_utils.py:7-60)."""
+    b, A = probs.size(0), probs.size(1)
+    scores = probs[:, :, 1]
+    E = 0 if extra_dets is None else extra_dets.size(1)
+    if E:
+        scores = torch.cat((extra_dets[:, :, 4], scores), 1)
+    val, order = torch.sort(scores, dim=1, descending=True, stable=True)
+    val, order = val[:, :pre_nms_limit], order[:, :pre_nms_limit]
+    a_idx = (order - E).clamp(min=0)
+    box = anchors[a_idx]                                                     # [b, K, 4]
+    d = torch.gather(deltas, 1, a_idx.unsqueeze(2).expand(-1, -1, 4)) * torch.tensor(list(std), device=probs.device).view(1, 1, 4)
+    h = box[..., 2] - box[..., 0]
+    w = box[..., 3] - box[..., 1]
+    cy = box[..., 0] + 0.5 * h
+    cx = box[..., 1] + 0.5 * w
+    cy = cy + d[..., 0] * h
+    cx = cx + d[..., 1] * w
+    h = h * torch.exp(d[..., 2])
+    w = w * torch.exp(d[..., 3])
+    y1 = cy - 0.5 * h
+    x1 = cx - 0.5 * w
+    rows = torch.stack((y1, x1, y1 + h, x1 + w), 2)
+    if E:
+        ext = torch.gather(extra_dets[:, :, :4], 1, order.clamp(max=E - 1).unsqueeze(2).expand(-1, -1, 4))
+        rows = torch.where((order < E).unsqueeze(2), ext, rows)
+    lim = torch.tensor([height, width, height, width], device=probs.device).view(1, 1, 4)
+    rows = torch.minimum(torch.maximum(rows, torch.zeros_like(rows)), lim)
+    return torch.cat((rows, val.unsqueeze(2)), 2).contiguous()
+
+
 def proposal_layer(inputs, proposal_count, nms_threshold, priors, config, extra_dets=None):
     """rpn_probs [b, A, 2], rpn_bbox [b, A, 4] -> normalised proposals [b, proposal_count, 4]
     (zero rows past each image's count) and the per-image counts [b] (int32, on the GPU).
@@ -128,12 +165,16 @@ def proposal_layer(inputs, proposal_count, nms_threshold, priors, config, extra_
         E = extra_dets.size(1)
     pre_nms_limit = min(config.RPN.PRE_NMS_LIMIT, A + E)
     height, width = float(config.DATA.IMAGE_SHAPE[0]), float(config.DATA.IMAGE_SHAPE[1])
-    dets = torch.empty((b, pre_nms_limit, 5), device=probs.device, dtype=torch.float32)
-    std = (ctypes.c_float * 4)(*[float(v) for v in config.DATA.BBOX_STD_DEV])
-    with torch.cuda.device(probs.device):
-        _lib.check(L.fi_proposal_candidates(_lib.ptr(probs), probs.size(2), 1, _lib.ptr(deltas), _lib.ptr(anchors),
-                                            _lib.ptr(extra_dets), b, A, E, pre_nms_limit, std, height, width,
-                                            _lib.ptr(dets), _lib.current_stream()), "fi_proposal_candidates")
+    if pre_nms_limit > PRE_NMS_KERNEL_LIMIT:
+        dets = _proposal_candidates_tensors(probs, deltas, anchors, extra_dets, pre_nms_limit,
+                                            [float(v) for v in config.DATA.BBOX_STD_DEV], height, width)
+    else:
+        dets = torch.empty((b, pre_nms_limit, 5), device=probs.device, dtype=torch.float32)
+        std = (ctypes.c_float * 4)(*[float(v) for v in config.DATA.BBOX_STD_DEV])
+        with torch.cuda.device(probs.device):
+            _lib.check(L.fi_proposal_candidates(_lib.ptr(probs), probs.size(2), 1, _lib.ptr(deltas), _lib.ptr(anchors),
+                                                _lib.ptr(extra_dets), b, A, E, pre_nms_limit, std, height, width,
+                                                _lib.ptr(dets), _lib.current_stream()), "fi_proposal_candidates")
     if _lib.TAP is not None:
         _lib.TAP("proposal_candidates", probs=probs, deltas=deltas, anchors=anchors, extra=extra_dets, dets=dets)
     keep, num = nms_sorted(dets, nms_threshold, max_keep=proposal_count)

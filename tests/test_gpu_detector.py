@@ -657,3 +657,45 @@ def test_rpn_row_form_equals_the_dense_rpn_at_the_selected_anchors():
         assert close(a, b)
     for n in dgp:
         assert close(rgp[n], dgp[n]), n
+
+
+@pytest.mark.parametrize("with_extra", [False, True])
+def test_proposal_layer_with_a_pre_nms_limit_above_the_kernels_sort_capacity(oracle, with_extra):
+    """RPN.PRE_NMS_LIMIT > 8192 (the reference's full sort has no bound, lib/layers.py:99-106): the candidates come from
+    the tensor path (layers._proposal_candidates_tensors) -- against the oracle like the kernel's, and equal to the kernel
+    where both apply (limit 6000 on the same inputs, tie rule included)."""
+    from feature_intertwiner_amd import _lib
+    from feature_intertwiner_amd import layers as L
+    cfg = _cfg(backbone="resnet50", image_size=512)
+    pri = _priors(cfg)
+    g = torch.Generator(device=DEV).manual_seed(4)
+    A = pri.size(0)
+    probs = (torch.rand(2, A, 2, device=DEV, generator=g) * 64).round() / 64        # many ties
+    bbox = torch.randn(2, A, 4, device=DEV, generator=g) * 0.5
+    extra = None
+    if with_extra:
+        extra = torch.rand(2, 300, 5, device=DEV, generator=g) * 400
+        extra[..., 2:4] += extra[..., 0:2]
+        extra[..., 4] = (torch.rand(2, 300, device=DEV, generator=g) * 64).round() / 64
+    out = {}
+    for limit in (6000, 12000):
+        cfg.RPN.PRE_NMS_LIMIT = limit
+        taps = {}
+        _lib.TAP = lambda name, **kw: taps.setdefault(name, kw)
+        try:
+            props, num = L.proposal_layer([probs, bbox], 1000, 0.7, pri, cfg, extra)
+        finally:
+            _lib.TAP = None
+        tap = taps["proposal_candidates"]
+        assert tap["dets"].shape == (2, limit, 5)
+        _check_candidates(oracle, tap, cfg, 512.0)
+        out[limit] = (tap["dets"], props, num)
+    # the first 6000 candidates of the tensor path ARE the kernel's (same scores in the same order; boxes to 2 ulp)
+    a, b = out[6000][0], out[12000][0][:, :6000]
+    assert torch.equal(a[..., 4], b[..., 4])
+    assert (a[..., :4] - b[..., :4]).abs().max().item() <= 3e-7 * 512 * 8
+    for limit in (6000, 12000):
+        dets, props, num = out[limit]
+        for i in range(2):
+            keep = oracle.pth_nms(dets[i].cpu().numpy(), 0.7)[:1000]
+            assert int(num[i]) == len(keep)
