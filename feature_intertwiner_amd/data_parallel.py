@@ -91,8 +91,12 @@ class GradientBuckets(object):
         decay nor momentum to it, exactly as on one GPU and in the reference.
       * Buckets are issued strictly in order, so a bucket holding such a parameter would stall every
         later bucket until the end of backward.  A parameter that had no gradient in ABSENT_STEPS consecutive
-        steps of a `key` is no longer waited for under that key.  A gradient that shows up for a parameter whose
-        bucket has already been issued raises: the graph must be data-independent per key.
+        steps of a `key` is no longer waited for under that key.  A gradient that shows up for such a parameter
+        after its bucket has been issued travels in a LATE extra collective at the end of backward (same sequence
+        on every rank: the graph has the same structure everywhere), `late_gradients` counts the event, a warning is
+        printed once, and the parameter is waited for again under that key from the next step on.  (Only a gradient
+        that a kernel accumulated straight into the arena slot WHILE the slot's collective was in flight cannot be
+        recovered; that still raises.)
       * Cross-rank consistency (a parameter with a gradient on one rank and none on another) cannot be
         acted on without a host synchronisation; one flag per parameter travels at the end of each bucket, a
         device-side counter accumulates disagreements, and `check()` (tests, end of a run) raises on it.
@@ -121,6 +125,8 @@ class GradientBuckets(object):
         self._absent_run = {}        # key -> {parameter: consecutive steps without a gradient}
         self._key = None
         self._violations = torch.zeros((), device=self.device)
+        self.late_gradients = 0      # gradients that arrived after their bucket had been issued (see the class docstring)
+        self._late_warned = False
         self._flag_cache = {}
         self._flag_index = None
         self._started = False
@@ -188,17 +194,42 @@ class GradientBuckets(object):
         self.inflight = []        # (bucket index, work handle, which params had a gradient)
         self._launched = set()
         self._started = False
+        self._late = []           # parameters whose gradient arrived after their bucket was issued, in arrival order
+        # streams (other than the issuing one) on which gradients of a bucket were produced: the meta loss / OT module
+        # runs on the third stream, and autograd calls a parameter's hook with the stream of its forward pass current
+        self._grad_streams = [set() for _ in self.waits]
 
     def _on_grad(self, p):
         self._start()
+        cur = torch.cuda.current_stream(self.device) if self.use_stream else None
+        late = False
         for bi in self.buckets_of[p]:
             if bi in self._launched:
-                raise RuntimeError("GradientBuckets: a gradient arrived for a parameter (shape %s%s) of bucket %d after the "
-                                   "bucket was issued -- the set of parameters that receive gradients changed without a "
-                                   "new begin(key)" % (tuple(p.shape), ", no longer waited for" if p in self._skip else "", bi))
+                late = True
+                continue
+            if cur is not None:
+                self._grad_streams[bi].add(cur)
             if p not in self._skip:
                 self.pending[bi] -= 1
+        if late:
+            self._late_gradient(p, cur)
         self._launch_ready()
+
+    def _late_gradient(self, p, cur):
+        if p.grad is not None and self.layout.holds(p, p.grad, self.arena):
+            raise RuntimeError("GradientBuckets: a kernel accumulated the gradient of a parameter (shape %s) into its arena "
+                               "slot after the slot's bucket had been issued -- the set of parameters that receive "
+                               "gradients changed without a new begin(key)" % (tuple(p.shape),))
+        if all(q is not p for q, _ in self._late):
+            self._late.append((p, cur))
+        self.late_gradients += 1
+        run = self._absent_run.setdefault(self._key, {})
+        run.pop(p, None)                      # waited for again from the next step on
+        if not self._late_warned:
+            self._late_warned = True
+            import warnings
+            warnings.warn("GradientBuckets: a gradient (parameter of shape %s) arrived after its bucket had been issued; "
+                          "it is reduced in a late extra collective (counter: late_gradients)" % (tuple(p.shape),))
 
     @torch.no_grad()
     def _launch_ready(self, force=False):
@@ -215,6 +246,11 @@ class GradientBuckets(object):
             # gradients that autograd allocated outside the arena move into their slots (one multi-tensor copy);
             # a parameter without a gradient leaves its slot zero.  (b.wait: a piece of a split parameter moves the
             # whole parameter in before the first piece leaves)
+            if self.use_stream:
+                cur = torch.cuda.current_stream(self.device)
+                for s in self._grad_streams[bi]:
+                    if s != cur:
+                        cur.wait_stream(s)        # the move below (and the flag write) run on `cur`
             dst, src, moved = [], [], []
             for p in b.wait:
                 h = p.grad is not None
@@ -244,6 +280,8 @@ class GradientBuckets(object):
                 flush_deferred_wgrads()                    # queued (batched) weight gradients of this bucket's layers:
                                                            # BEFORE the communication stream takes its dependency
                 self.comm_stream.wait_stream(torch.cuda.current_stream(self.device))
+                for s in self._grad_streams[bi]:           # gradients produced on other streams (see _reset)
+                    self.comm_stream.wait_stream(s)
                 wg = conv_wgrad_stream(self.device)        # weight gradients on their own stream (conv.WGRAD_SIDE_STREAM...)
                 if wg is not None:
                     self.comm_stream.wait_stream(wg)
@@ -273,6 +311,7 @@ class GradientBuckets(object):
             e.record(torch.cuda.current_stream(self.device))
             self.profile.append(("backward_end", e))
         self._launch_ready(force=True)        # whatever is left (first steps of a key; trailing bucket)
+        late_views = self._reduce_late()
         for bi, work, had in self.inflight:
             if work is not None:
                 work.wait()
@@ -289,9 +328,12 @@ class GradientBuckets(object):
         if self.world > 1:
             buf.mul_(1.0 / float(self.world))         # ONE pass over the arena: sums -> means, in place
         run = self._absent_run.setdefault(self._key, {})
+        late = {id(p) for p, _ in late_views}
+        for p, v in late_views:
+            p.grad = v                         # the slot now holds the rank sum (scaled with the rest above)
         for bi, work, had in self.inflight:
             for p, h in zip(self.buckets[bi], had):
-                if h:
+                if h or id(p) in late:
                     run.pop(p, None)
                 else:
                     # no gradient here: .grad stays None, exactly as on one GPU
@@ -300,6 +342,45 @@ class GradientBuckets(object):
                     run[p] = run.get(p, 0) + 1
         self.layout.fresh = False
         self._reset()
+
+    def _reduce_late(self):
+        """Gradients that arrived after their bucket had left (autograd-allocated, outside the arena): moved into their
+        slots -- which the issued bucket left holding the rank sum of zeros -- and all-reduced there, one collective per
+        parameter in arrival order (the same on every rank), before the 1/world scaling.  Returns [(param, slot view)]."""
+        out = []
+        if not self._late:
+            return out
+        lay, buf = self.layout, self.arena
+        for p, s in self._late:
+            if p.grad is None:
+                continue
+            v = lay.view(p, buf)
+            if v is None:
+                raise RuntimeError("GradientBuckets: parameter with unsupported strides %s" % (p.stride(),))
+            if self.use_stream:
+                cur = torch.cuda.current_stream(self.device)
+                if s is not None and s != cur:
+                    cur.wait_stream(s)                # the producer of the late gradient
+                cur.wait_stream(self.comm_stream)     # the slot's own bucket must have landed before the move
+                v.copy_(p.grad)
+                self.comm_stream.wait_stream(cur)
+                with torch.cuda.stream(self.comm_stream):
+                    work = dist.all_reduce(v, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                    if self.stream_ordered:
+                        work.wait()
+                        work = None
+            else:
+                # the slot's own bucket may still be in flight on a host-waited backend: finish everything first
+                for _, w, _ in self.inflight:
+                    if w is not None:
+                        w.wait()
+                self.inflight = [(bi, None, had) for bi, _, had in self.inflight]
+                v.copy_(p.grad)
+                work = dist.all_reduce(v, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            if work is not None:
+                work.wait()
+            out.append((p, v))
+        return out
 
     def check(self):
         """Host-synchronising: raises if any parameter ever had a gradient on some ranks only."""

@@ -109,7 +109,9 @@ class FeatureBuffer(object):
         self.buffer.copy_(new_buf)
         self.buffer_cnt.copy_(new_cnt)
         if self.buffer.size(0) == 1:
-            return self.buffer[0]
+            # a copy: the caller saves it for the pair loss's backward, and the next update writes the buffer in place
+            # (two forward passes before one backward are supported, conv.py)
+            return self.buffer[0].clone()
         return (self.buffer * self.buffer_cnt).sum(0) / (self.buffer_cnt.sum(0) + EPS)
 
 

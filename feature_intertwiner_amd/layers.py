@@ -489,6 +489,12 @@ def select_rpn_rows(target_rpn_match, rows_per_image):
     b = target_rpn_match.size(0)
     rows = getattr(target_rpn_match, "_fi_rows", None)
     if rows is not None and rows[0] == rows_per_image:          # fi_rpn_targets listed them (per image, -1 padded)
+        if rows[1].is_cuda:
+            # allocated on the stream the targets ran on (run_on_side_stream marks its OUTPUTS for the consumer's stream;
+            # these two ride on a python attribute): mark them for the stream that reads them from here on
+            cur = torch.cuda.current_stream(rows[1].device)
+            rows[1].record_stream(cur)
+            rows[2].record_stream(cur)
         return rows[1], rows[2], rows[1] >= 0
     sel = torch.nonzero_static(target_rpn_match != 0, size=b * rows_per_image, fill_value=-1)
     return sel[:, 0], sel[:, 1], sel[:, 0] >= 0

@@ -521,8 +521,9 @@ class Dev(nn.Module):
         branch (the defaults DEV.BIG_FEAT_DETACH, no BIG_SUPERVISE)."""
         cfg = self.config
         on = _STATIC_DEV if _STATIC_DEV is not None else getattr(cfg.MODEL, "CONV_PRECISION", "fp32") == "fp32"
+        # (the class means of the three levels are ONE launch over 3 K classes; fi_class_mean holds at most 248)
         return bool(on and rois.is_cuda and self.use_dev and not cfg.DEV.BASELINE and cfg.DEV.BIG_FEAT_DETACH and
-                    not cfg.DEV.BIG_SUPERVISE and self.roi_type == 'roi_align')
+                    not cfg.DEV.BIG_SUPERVISE and self.roi_type == 'roi_align' and 3 * cfg.DATASET.NUM_CLASSES <= 248)
 
     _PERM = {}
 

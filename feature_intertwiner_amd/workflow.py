@@ -185,6 +185,7 @@ def compare_backward_forms(model, inputs, do_meta=True, generator_seed=3, skip=N
         if name.endswith("rpn.conv_shared.bias") and ref is not None and g_a[name] is not None:
             d = (g_a[name] - ref).abs() / (ref.abs().max() + 1e-30)
             res["rpn_relu_boundary_channels"] = int((d > 1e-4).sum())
+            res["rpn_relu_boundary_which"] = [int(c) for c in torch.nonzero(d > 1e-4).flatten().tolist()[:8]]
     if detail:
         res["table"] = sorted(table, key=lambda r: -r[1])[:detail]
     if keep_gradients:
@@ -196,12 +197,21 @@ def check_backward_forms(model, inputs, bar=2e-5, attempts=3, **kw):
     """compare_backward_forms with the RPN's ReLU-boundary events (see there) taken out: when the comparison misses
     `bar` and the footprint is that of an event (1-2 single channels of rpn.conv_shared), it is repeated with other
     random draws (other sampled anchors), at most `attempts` times.  Returns the last result plus "attempts" and
-    "boundary_events" (the max_rel_dev of the passes that were set aside)."""
-    events = []
+    "boundary_events" (the max_rel_dev of the passes that were set aside).
+    A pass is set aside only while the hypothesis stays plausible: the deviation is of an event's size (<= 3e-2: one
+    anchor's share of a channel's gradient), and the channel is a NEW one -- an event lands on whichever channel has a
+    pre-activation at rounding distance from zero under that draw, a gradient bug in the row form lands on the same
+    channel under every draw ("boundary_same_channel": the comparison then stands as failed)."""
+    events, seen = [], set()
     for k in range(attempts):
         r = compare_backward_forms(model, inputs, generator_seed=3 + k, **kw)
         if r["max_rel_dev"] <= bar or not (1 <= r.get("rpn_relu_boundary_channels", 0) <= 2):
             break
+        which = set(r.get("rpn_relu_boundary_which", ()))
+        if r["max_rel_dev"] > 3e-2 or (which & seen):
+            r["boundary_same_channel"] = bool(which & seen)
+            break
+        seen |= which
         events.append(r["max_rel_dev"])
     r["attempts"] = len(events) + 1
     r["boundary_events"] = events

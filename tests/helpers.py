@@ -259,3 +259,38 @@ def keras_named_arrays(arch="resnet101", num_classes=81, seed=5, small=True):
     out["mrcnn_mask_deconv.bias:0"] = rs.standard_normal((f,)).astype(np.float32)
     conv("mrcnn_mask", 1, 1, f, num_classes)
     return out
+
+
+def golden_wrapper_inputs(seed=23):
+    """Seeded inputs of tests/golden/wrappers.npz (oracle/gen_golden_wrappers.py): pixel boxes for RoIAlign.forward's box
+    transform, score-carrying boxes for pth_nms / nms, and a small pyramid with normalised RoIs for pyramid_roi_align
+    (incl. RoIs exactly on a level boundary's far sides, tiny and whole-image ones).  Shared with the tests, so the
+    fixture holds the reference's outputs only."""
+    rs = np.random.RandomState(seed)
+    f = np.float32
+    out = {}
+    # (a) RoIAlign pixel boxes (x1, y1, x2, y2) on a 50 x 68 map, some outside / degenerate
+    x1y1 = rs.uniform(-4, 60, (96, 2))
+    wh = np.exp(rs.uniform(np.log(0.5), np.log(40), (96, 2)))
+    px = np.concatenate([x1y1, x1y1 + wh], 1).astype(f)
+    px[::13, 2:] = px[::13, :2]                      # zero-area
+    px[5] = [0, 0, 67, 49]                           # the whole map
+    out["roialign_boxes_px"] = px
+    out["roialign_box_ind"] = rs.randint(0, 2, 96).astype(np.int32)
+    # (b) NMS: 3 images x 400 clustered boxes (y1, x1, y2, x2, score), scores unique but NOT pre-sorted
+    dets = np.stack([clustered_dets(rs, 400, 256, n_clusters=6, pixel_round=(i == 1)) for i in range(3)])
+    for i in range(3):
+        dets[i] = dets[i][rs.permutation(400)]
+    out["nms_dets"] = dets.astype(f)
+    # (c) pyramid: 2 images, 4 channels, maps 64/32/16/8, 60 RoIs per image; the level formula reads the IMAGE shape
+    # only (1024 x 1024 here), the crops read the maps
+    maps = [rs.standard_normal((2, 4, s, s)).astype(f) for s in (64, 32, 16, 8)]
+    rois = training_rois(rs, 2, 60, n_gt=6)
+    side = np.array([8, 40, 56, 112, 224, 448, 1023]) / 1024.0   # spans every level incl. both clamps
+    for j, s in enumerate(side):
+        rois[0, j] = [0.0, 0.0, s, s]
+        rois[1, j] = np.clip([0.3, 0.2, 0.3 + s / 2, 0.2 + 2 * s], 0, 1)
+    out["pyr_maps"] = maps
+    out["pyr_rois"] = rois.astype(f)
+    out["pyr_image_shape"] = (1024, 1024, 3)
+    return out

@@ -295,3 +295,70 @@ def test_eight_ranks_some_without_objects():
             else:
                 assert a is not None and np.allclose(a, p.grad.numpy(), rtol=2e-5, atol=2e-6), (r, n)
                 assert np.array_equal(a, out[0]["grads"][n])
+
+
+def _late_worker(rank, world, port, out):
+    """`unused` has no gradient in the first three steps of key "k" (it is no longer waited for after two), then takes
+    part in the loss under the SAME key: its gradient arrives after its bucket has left."""
+    import warnings
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from feature_intertwiner_amd.data_parallel import GradientBuckets, broadcast_parameters
+    net = _Net()
+    broadcast_parameters(net)
+    sync = GradientBuckets(net, bucket_bytes=300)
+    g = torch.Generator().manual_seed(21)
+    x_all = torch.randn(world * 3, 6, generator=g)
+    x = x_all[rank * 3:(rank + 1) * 3]
+    res = {}
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        for it in range(6):
+            net.zero_grad(set_to_none=True)
+            sync.begin("k")
+            sync.launch_log = []
+            # built FIRST, so autograd reaches it LAST: its bucket (early in the arena) has long left by then
+            extra = (net.unused(x[:, :4]) ** 2).mean() * (rank + 1) if it >= 3 else 0.0
+            y = net.body(x)
+            loss = (y ** 2).mean() + extra
+            loss.backward()
+            in_backward = len(sync.launch_log)
+            sync()
+            res[it] = {"late": sync.late_gradients, "in_backward": in_backward,
+                       "grads": {n: (None if p.grad is None else p.grad.detach().numpy().copy())
+                                 for n, p in net.named_parameters()}}
+    res["warned"] = sum("late extra collective" in str(w.message) for w in caught)
+    sync.check()
+    out[rank] = res
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_a_gradient_after_its_bucket_left_travels_in_a_late_collective():
+    import numpy as np
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_late_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    net = _Net()
+    g = torch.Generator().manual_seed(21)
+    x_all = torch.randn(world * 3, 6, generator=g)
+    terms = []
+    for r in range(world):
+        xr = x_all[r * 3:(r + 1) * 3]
+        terms.append((net.body(xr) ** 2).mean() + (net.unused(xr[:, :4]) ** 2).mean() * (r + 1))
+    torch.stack(terms).mean().backward()
+    for r in range(world):
+        res = out[r]
+        assert res[2]["late"] == 0 and res[2]["grads"]["unused.weight"] is None
+        assert res[2]["in_backward"] > 0                       # buckets were leaving from the hooks by then
+        assert res[3]["late"] == 2 and res["warned"] == 1      # weight and bias of `unused`, one warning
+        assert res[5]["late"] == 2                             # waited for again from the next step on: never late again
+        for it in (3, 4, 5):
+            for n, p in net.named_parameters():
+                a = res[it]["grads"][n]
+                if p.grad is None:
+                    assert a is None, n
+                else:
+                    assert a is not None and np.allclose(a, p.grad.numpy(), rtol=1e-5, atol=1e-6), (it, n)

@@ -179,3 +179,94 @@ def test_detector_losses_kernel_matches_the_loss_functions(with_fg):
         assert float(a[0][2]) == 0.0 and float(a[0][3]) == 0.0 and float(a[0][4]) == 0.0
     for name, ga, gr in zip(("rpn logits", "rpn bbox", "class logits", "roi bbox", "mask logits"), a[1], r[1]):
         assert float((ga - gr).abs().max()) <= 1e-6 * float(gr.abs().max()) + 1e-12, name
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the chain closed ON the GPU: the kernels against the oracle's restatement of the reference and the reference-run goldens
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("crowd,pos_thres", [(False, 0.7), (True, 0.7), (False, 0.4)])
+def test_rpn_target_kernels_equal_the_reference_rules(oracle, crowd, pos_thres):
+    """prepare_rpn_target on the GPU with the kernels on (fi_rpn_targets), replayed through oracle.generate_rpn_target
+    (= lib/layers.py:439-604 line by line) with the build's own random choice: candidate sets, the balancing rules and
+    every derived value are the reference's.  The gpu twin of tests/test_targets.py::test_rpn_targets_equal_the_reference_rules."""
+    from test_targets import _candidates, _perm_dropping, _gt as _gt_np
+    from feature_intertwiner_amd import layers as L
+    assert L.TARGET_KERNELS
+    cfg = _cfg(backbone="resnet50", image_size=256)
+    cfg.RPN.TARGET_POS_THRES = pos_thres
+    anchors = L.generate_pyramid_priors(cfg.RPN.ANCHOR_SCALES, cfg.RPN.ANCHOR_RATIOS, cfg.MODEL.BACKBONE_SHAPES,
+                                        cfg.MODEL.BACKBONE_STRIDES, 1).astype(np.float32)
+    rs = np.random.RandomState(3)
+    cls, boxes = _gt_np(rs, 3, 12, 256, [12, 7, 0], crowd)
+    g = torch.Generator(device=DEV).manual_seed(5)
+    match, deltas = L.prepare_rpn_target(torch.from_numpy(anchors).to(DEV), torch.from_numpy(cls).to(DEV),
+                                         torch.from_numpy(boxes).to(DEV), cfg, g)
+    assert getattr(match, "_fi_rows", None) is not None                  # the kernel path really ran
+    n_rows, row_image, row_anchor = match._fi_rows
+    match, deltas = match.cpu().numpy(), deltas.cpu().numpy()
+    row_anchor = row_anchor.view(3, n_rows).cpu().numpy()
+    for i in range(3):
+        m0 = _candidates(oracle, anchors, cls[i], boxes[i], cfg)
+        pos_c, neg_c = np.nonzero(m0 == 1)[0], np.nonzero(m0 == -1)[0]
+        kept_pos, kept_neg = np.nonzero(match[i] == 1)[0], np.nonzero(match[i] == -1)[0]
+        assert set(kept_pos) <= set(pos_c) and set(kept_neg) <= set(neg_c)
+        if pos_thres < 0.5 and i == 0:
+            assert len(pos_c) > 128 and len(kept_pos) == 128
+        exp_match, exp_bbox = oracle.generate_rpn_target(anchors, cls[i], boxes[i], cfg,
+                                                         _perm_dropping(pos_c, kept_pos), _perm_dropping(neg_c, kept_neg))
+        assert np.array_equal(match[i], exp_match), i
+        n_pos = int((exp_match == 1).sum())
+        if i < 2:
+            assert n_pos > 0 and n_pos + int((exp_match == -1).sum()) == 256
+        got = deltas[i][exp_match == 1]
+        exp = exp_bbox[:n_pos] / np.asarray(cfg.DATA.BBOX_STD_DEV, np.float32)
+        assert np.allclose(got, exp, rtol=1e-5, atol=1e-6)
+        assert np.all(deltas[i][exp_match != 1] == 0)
+        nz = np.nonzero(exp_match)[0]                                     # the rows the losses read = the reference's
+        assert np.array_equal(row_anchor[i, :len(nz)], nz) and np.all(row_anchor[i, len(nz):] == -1)
+    assert np.all(match[2] != 1)
+
+
+def test_detector_losses_kernel_returns_the_reference_values(golden_dir):
+    """fi_detector_losses on the inputs of tests/golden/layers.npz: the five values the REFERENCE's loss functions
+    (lib/layers.py:808-934, run by oracle/gen_golden_layers.py) returned, to 2e-6.  The kernel reads the RPN outputs as
+    rows of the non-zero anchors and the mask head's target-class logits in the un-shuffled layout, so the golden
+    inputs are re-laid here (no arithmetic beyond logit(p) for the mask probabilities)."""
+    import os
+    from helpers import golden_loss_inputs
+    from feature_intertwiner_amd import layers as L
+    assert L.LOSS_KERNEL
+    gold = np.load(os.path.join(golden_dir, "layers.npz"))
+    li = golden_loss_inputs()
+    match = li["rpn_match"]
+    B, A = match.shape
+    n_total = 256
+    per_anchor = np.zeros((B, A, 4), np.float32)
+    r_img = np.full((B, n_total), -1, np.int64)
+    r_anchor = np.full((B, n_total), -1, np.int64)
+    row_logits = np.zeros((B, n_total, 2), np.float32)
+    row_bbox = np.zeros((B, n_total, 4), np.float32)
+    for b in range(B):
+        pos = np.nonzero(match[b] == 1)[0]
+        per_anchor[b, pos] = li["rpn_bbox_target"][b, :len(pos)]          # the reference packs them (lib/layers.py:845-852)
+        nz = np.nonzero(match[b])[0]
+        assert len(nz) <= n_total
+        r_img[b, :len(nz)], r_anchor[b, :len(nz)] = b, nz
+        row_logits[b, :len(nz)] = li["rpn_logits"][b, nz]
+        row_bbox[b, :len(nz)] = li["rpn_bbox_pred"][b, nz]
+    ids = li["cls_ids"]
+    R = ids.shape[1]
+    p = li["mask_pred"].astype(np.float64)                                # [B, R, NC, 28, 28] probabilities
+    sel = np.take_along_axis(p, ids.reshape(B, R, 1, 1, 1).astype(np.int64), 2)[:, :, 0]     # [B, R, 28, 28]
+    logit = np.log(sel) - np.log1p(-sel)
+    un = logit.reshape(B, R, 14, 2, 14, 2).transpose(0, 1, 3, 5, 2, 4).astype(np.float32)    # [.., a, b, y, x]
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    five = L.detector_losses(T(row_logits.reshape(-1, 2)), T(row_bbox.reshape(-1, 4)), T(r_img.reshape(-1)),
+                             T(r_anchor.reshape(-1)), T(match.astype(np.float32)), T(per_anchor), T(li["cls_logits"]),
+                             T(li["bbox_pred"]), T(ids.astype(np.int32)), T(li["bbox_target"]), T(un),
+                             T(ids.astype(np.int32)), T(li["mask_target"]))
+    assert five is not None
+    five = five.cpu().numpy()
+    names = ("loss_rpn_class", "loss_rpn_bbox", "loss_mrcnn_class", "loss_mrcnn_bbox", "loss_mrcnn_mask")
+    for v, k in zip(five, names):
+        assert abs(float(v) - float(gold[k])) <= 2e-6 * max(1.0, abs(float(gold[k]))), (k, float(v), float(gold[k]))
