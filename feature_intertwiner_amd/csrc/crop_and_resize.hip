@@ -61,22 +61,28 @@ struct LevelSetMut {
 // Sampling coordinate k of one axis.  Mirrors the operation order of the
 // reference exactly (each * / + rounded to fp32; the crop == 1 case goes through
 // double because of the 0.5 literal) -- oracle: orc_axis_taps().
-__device__ __forceinline__ Tap make_tap(float lo, float hi, int extent, int crop, int k)
+// c(k) = base + (float)k * step: the two numbers the coordinate of every bin of one axis is made of.  crop == 1: the
+// reference's double-precision midpoint as base and a zero step (base + 0 * 0 = base up to the sign of zero, which no
+// result depends on: the validity tests, floorf / ceilf and 1 - frac are the same for +0 and -0).
+__device__ __forceinline__ void axis_coeff(float lo, float hi, int extent, int crop, float *base, float *step)
 {
     const float span = (float)(extent - 1);
-    float c;
     if (crop > 1) {
         const float d = hi - lo;
         const float m = d * span;
-        const float step = m / (float)(crop - 1);
-        const float base = lo * span;
-        const float off = (float)k * step;
-        c = base + off;
+        *step = m / (float)(crop - 1);
+        *base = lo * span;
     } else {
         const float s = lo + hi;
         const double dc = 0.5 * (double)s * (double)(extent - 1);
-        c = (float)dc;
+        *base = (float)dc;
+        *step = 0.0f;
     }
+}
+
+__device__ __forceinline__ Tap tap_at(float c, int extent)
+{
+    const float span = (float)(extent - 1);
     Tap t;
     if (c < 0.0f || c > span) {
         t.valid = 0;
@@ -90,6 +96,17 @@ __device__ __forceinline__ Tap make_tap(float lo, float hi, int extent, int crop
         t.frac = c - (float)t.i0;  // via the int, as the reference: keeps -0.0 - 0 == -0.0
     }
     return t;
+}
+
+__device__ __forceinline__ Tap make_tap(float lo, float hi, int extent, int crop, int k)
+{
+    float base, step;
+    axis_coeff(lo, hi, extent, crop, &base, &step);
+    if (crop > 1) {
+        const float off = (float)k * step;
+        return tap_at(base + off, extent);
+    }
+    return tap_at(base, extent);
 }
 
 // Resolve the (uniform) per-workgroup box header.  Returns false when the box has
@@ -443,6 +460,204 @@ __global__ __launch_bounds__(kThreads) void crop_bwd_kernel(
         atomicAdd(p + r0 + tx.i1, tx.frac * gtop);
         atomicAdd(p + r1 + tx.i0, wx0 * gbot);
         atomicAdd(p + r1 + tx.i1, tx.frac * gbot);
+    }
+}
+
+// -------------------------------------------------------------------------------------
+// NCHW backward without global atomics and without a memset pass: TILE-OWNER form.
+// A workgroup owns one tile (kTileCells cells: 16 x 64, 32 x 32 or 64 x 16 by map width) of CG channel planes of one
+// image.  It walks the boxes in chunks of 256 -- every thread tests one box against the tile and works out which range
+// of its bins per axis can reach it (the sampling coordinate is monotone in the bin index; conservative, every listed
+// bin is filtered again tap by tap) -- and the listed boxes are accumulated into an LDS copy of the tile with
+// ds_add_f32: a wavefront takes one box, a lane one bin of its range, computes the two taps once and applies them to
+// the CG channels (CG loads in flight; the bins of a (box, channel) are contiguous).  At the end the tile is written with plain
+// row-contiguous stores -- which is also the zero fill of the cells nobody touched (the accumulate form reads the tile
+// first instead of clearing it).  Against the scatter kernel above: no global_atomic_add_f32 (25.7 M of them at
+// 512 x 256 x 7 x 7, executed memory side at ~54 G/s), no 134..268 MB memset, every output byte written once.
+// The LDS accumulators are fp64 (see the kernel): every contribution is the reference's fp32 product, their sum is
+// rounded once; the reference adds them serially in fp32, so the two differ by that rounding (tests: 2e-5).
+// Workgroup order: the channel group is the fast index, so that (block -> XCD = block % 8) the tiles of one channel
+// group -- which read the same gradient rows -- share an L2.
+// -------------------------------------------------------------------------------------
+constexpr int kTileCells = 1024;
+
+struct TileGrid {
+    int base[kMaxLevels + 1];   // first (image, tile) index of level l; base[n] = total
+    int th[kMaxLevels], tw[kMaxLevels];
+    int nty[kMaxLevels], ntx[kMaxLevels];
+};
+
+// One axis of one box against the tile span [t0, t0 + tn): the coefficients of c(k) = base + k * step and the range of
+// bins [k_lo, k_lo + k_n) outside of which no tap (floor / ceil of c) can be a tile cell.  Conservative: c is monotone
+// in k, the bounds carry a margin of one bin against the rounding of the division, and every listed bin is tested
+// again tap by tap.  false: no bin of the axis reaches the tile (or the map).
+__device__ __forceinline__ bool axis_range(float a, float b, int extent, int crop, int t0, int tn, float *base,
+                                           float *step, int *k_lo, int *k_n)
+{
+    axis_coeff(a, b, extent, crop, base, step);
+    const float span = (float)(extent - 1);
+    const float c0 = *base;
+    const float c1 = (crop > 1) ? *base + (float)(crop - 1) * *step : *base;
+    const float mn = fminf(c0, c1), mx = fmaxf(c0, c1);
+    if (!(mx >= 0.0f) || !(mn <= span)) return false;                      // (also rejects NaN coordinates)
+    const float lo_cell = (float)(t0 - 1), hi_cell = (float)(t0 + tn);    // taps of c reach cells floor(c), ceil(c)
+    if (!(mx >= lo_cell) || !(mn <= hi_cell)) return false;
+    int lo = 0, hi = crop - 1;
+    if (*step != 0.0f) {
+        const float t1 = (lo_cell - *base) / *step, t2 = (hi_cell - *base) / *step;
+        const float fl = floorf(fminf(t1, t2)) - 1.0f, fh = ceilf(fmaxf(t1, t2)) + 1.0f;
+        if (fl > (float)(crop - 1) || fh < 0.0f) return false;
+        if (fl > 0.0f) lo = (int)fl;                                       // NaN / -inf: stays 0
+        if (fh < (float)(crop - 1)) hi = (int)fh;                          // NaN / +inf: stays crop - 1
+    }
+    *k_lo = lo;
+    *k_n = hi - lo + 1;
+    return true;
+}
+
+template <int CH, int CW, int CG, bool ACC>
+__global__ __launch_bounds__(kThreads) void crop_bwd_tiles_kernel(
+    LevelSetMut ls, TileGrid tg, const float *__restrict__ grads, const float *__restrict__ boxes,
+    const int *__restrict__ box_ind, const int *__restrict__ level, int num_boxes, int batch,
+    int depth, int crop_h_rt, int crop_w_rt, int ncg)
+{
+    const int crop_h = CH ? CH : crop_h_rt;
+    const int crop_w = CW ? CW : crop_w_rt;
+    const int bins = crop_h * crop_w;
+    // fp64 accumulators: ds_add_f64 runs at 7.7 lane-operations per clock per CU on gfx950, ds_add_f32 at 0.33 (it costs
+    // ~3 clocks per ACTIVE LANE; scripts/micro/lds_atomic_rate.hip, profiles/r05_lds_atomic_rate.txt) -- and the sum of
+    // the fp32 contributions is rounded once, at the end
+    __shared__ double s_tile[CG * kTileCells];
+    __shared__ float s_box[kThreads][4];        // base_y, step_y, base_x, step_x
+    __shared__ int s_rng[kThreads];             // k_lo(y) | k_n(y) << 8 | k_lo(x) << 16 | k_n(x) << 24
+    __shared__ int s_id[kThreads];
+    __shared__ int s_wave_n[kThreads / 64];
+
+    const int tid = threadIdx.x;
+    const int cg = blockIdx.x % ncg;
+    int t = blockIdx.x / ncg;
+    int lvl = 0;
+    while (lvl + 1 < ls.n && t >= tg.base[lvl + 1]) ++lvl;
+    t -= tg.base[lvl];
+    const int H = ls.H[lvl], W = ls.W[lvl];
+    const int th = tg.th[lvl], tw = tg.tw[lvl];
+    const int tiles = tg.nty[lvl] * tg.ntx[lvl];
+    const int img = t / tiles;
+    const int tile = t - img * tiles;
+    const int row0 = (tile / tg.ntx[lvl]) * th;
+    const int col0 = (tile % tg.ntx[lvl]) * tw;
+    const int c_begin = cg * CG;
+    const int c_count = min(CG, depth - c_begin);
+    const size_t plane = (size_t)H * (size_t)W;
+    float *__restrict__ dst = ls.img[lvl] + ((size_t)img * depth + c_begin) * plane;
+
+    // ---- the tile starts as zeros (or as what the map holds: accumulate form)
+    if (!ACC) {
+        for (int i = tid * 2; i < CG * kTileCells; i += kThreads * 2)
+            *reinterpret_cast<double2 *>(s_tile + i) = make_double2(0.0, 0.0);
+    }
+    for (int i = tid; ACC && i < CG * kTileCells; i += kThreads) {
+        float v = 0.0f;
+        if (ACC) {
+            const int c = i / kTileCells;
+            const int rem = i - c * kTileCells;
+            const int r = rem / tw, col = rem - r * tw;
+            if (c < c_count && row0 + r < H && col0 + col < W)
+                v = dst[(size_t)c * plane + (size_t)(row0 + r) * W + (col0 + col)];
+        }
+        s_tile[i] = (double)v;
+    }
+
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int chunk = 0; chunk < num_boxes; chunk += kThreads) {
+        // ---- which boxes of this chunk reach the tile, and with which bins (list in box order: ballot compaction)
+        const int box = chunk + tid;
+        bool hit = false;
+        float by = 0, sy = 0, bx = 0, sx = 0;
+        int ky = 0, ny = 0, kx = 0, nx = 0;
+        if (box < num_boxes && box_ind[box] == img && (level ? (level[box] - 2) : 0) == lvl) {
+            const float *b = boxes + 4 * (size_t)box;
+            hit = axis_range(b[0], b[2], H, crop_h, row0, th, &by, &sy, &ky, &ny) &&
+                  axis_range(b[1], b[3], W, crop_w, col0, tw, &bx, &sx, &kx, &nx);
+        }
+        const unsigned long long m = __ballot(hit);
+        if (lane == 0) s_wave_n[wave] = __popcll(m);
+        __syncthreads();                      // (also: the tile is initialised / the previous chunk's list is consumed)
+        int off = 0, n = 0;
+#pragma unroll
+        for (int w = 0; w < kThreads / 64; ++w) {
+            const int k = s_wave_n[w];
+            if (w < wave) off += k;
+            n += k;
+        }
+        if (hit) {
+            const int slot = off + __popcll(m & ((1ull << lane) - 1ull));
+            s_box[slot][0] = by; s_box[slot][1] = sy; s_box[slot][2] = bx; s_box[slot][3] = sx;
+            s_rng[slot] = ky | (ny << 8) | (kx << 16) | (nx << 24);
+            s_id[slot] = box;
+        }
+        __syncthreads();
+        // ---- a wavefront = one listed box, a lane = one of its bins in range: two taps, then CG channels
+        for (int j = wave; j < n; j += kThreads / 64) {
+            const int rng = s_rng[j];
+            const int ky0 = rng & 255, nyj = (rng >> 8) & 255, kx0 = (rng >> 16) & 255, nxj = (rng >> 24) & 255;
+            const float byj = s_box[j][0], syj = s_box[j][1], bxj = s_box[j][2], sxj = s_box[j][3];
+            const float *__restrict__ gbox = grads + ((size_t)s_id[j] * depth + c_begin) * bins;
+            for (int e = lane; e < nyj * nxj; e += 64) {
+                const int yy = e / nxj;
+                const int y = ky0 + yy;
+                const int x = kx0 + (e - yy * nxj);
+                const Tap ty = tap_at(crop_h > 1 ? byj + (float)y * syj : byj, H);
+                const Tap tx = tap_at(crop_w > 1 ? bxj + (float)x * sxj : bxj, W);
+                if (!(ty.valid & tx.valid)) continue;
+                const unsigned r0 = (unsigned)(ty.i0 - row0), r1 = (unsigned)(ty.i1 - row0);
+                const unsigned c0 = (unsigned)(tx.i0 - col0), c1 = (unsigned)(tx.i1 - col0);
+                const bool in_r0 = r0 < (unsigned)th, in_r1 = r1 < (unsigned)th;
+                const bool in_c0 = c0 < (unsigned)tw, in_c1 = c1 < (unsigned)tw;
+                if (!((in_r0 | in_r1) & (in_c0 | in_c1))) continue;
+                const float *__restrict__ g = gbox + (y * crop_w + x);
+                float gv[CG];
+#pragma unroll
+                for (int c = 0; c < CG; ++c) gv[c] = (c < c_count) ? g[(size_t)c * bins] : 0.0f;
+                // reference order: dtop = (1-ly)*g; TL += (1-lx)*dtop; TR += lx*dtop; dbot = ly*g; BL, BR likewise
+                const float wy0 = 1.0f - ty.frac, wx0 = 1.0f - tx.frac;
+                const int a00 = (int)(r0 * tw + c0), a01 = (int)(r0 * tw + c1);
+                const int a10 = (int)(r1 * tw + c0), a11 = (int)(r1 * tw + c1);
+#pragma unroll
+                for (int c = 0; c < CG; ++c) {
+                    double *tl = s_tile + c * kTileCells;
+                    const float gtop = wy0 * gv[c];
+                    const float gbot = ty.frac * gv[c];
+                    if (in_r0 & in_c0) atomicAdd(tl + a00, (double)(wx0 * gtop));
+                    if (in_r0 & in_c1) atomicAdd(tl + a01, (double)(tx.frac * gtop));
+                    if (in_r1 & in_c0) atomicAdd(tl + a10, (double)(wx0 * gbot));
+                    if (in_r1 & in_c1) atomicAdd(tl + a11, (double)(tx.frac * gbot));
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // ---- the tile leaves with plain stores (rows of tw consecutive floats; 16 bytes per lane where the rows allow)
+    const int rows = min(th, H - row0), cols = min(tw, W - col0);
+    if ((W & 3) == 0 && (cols & 3) == 0 && ((uintptr_t)dst & 15) == 0) {
+        for (int i = tid * 4; i < c_count * kTileCells; i += kThreads * 4) {
+            const int c = i / kTileCells;
+            const int rem = i - c * kTileCells;
+            const int r = rem / tw, col = rem - r * tw;
+            if (r < rows && col < cols) {
+                const double2 a = *reinterpret_cast<const double2 *>(s_tile + i);
+                const double2 b = *reinterpret_cast<const double2 *>(s_tile + i + 2);
+                *reinterpret_cast<float4 *>(dst + (size_t)c * plane + (size_t)(row0 + r) * W + (col0 + col)) =
+                    make_float4((float)a.x, (float)a.y, (float)b.x, (float)b.y);
+            }
+        }
+        return;
+    }
+    for (int i = tid; i < c_count * kTileCells; i += kThreads) {
+        const int c = i / kTileCells;
+        const int rem = i - c * kTileCells;
+        const int r = rem / tw, col = rem - r * tw;
+        if (r < rows && col < cols) dst[(size_t)c * plane + (size_t)(row0 + r) * W + (col0 + col)] = (float)s_tile[i];
     }
 }
 
@@ -884,10 +1099,53 @@ int forward_impl(const LevelSet &ls, const float *boxes, const int32_t *box_ind,
                         chunks, crops, status);
 }
 
+template <int CG, bool ACC>
+int launch_bwd_tiles(int crop_h, int crop_w, dim3 grid, hipStream_t st, const LevelSetMut &ls, const TileGrid &tg,
+                     const float *grads, const float *boxes, const int32_t *box_ind, const int32_t *level,
+                     int num_boxes, int batch, int depth, int ncg)
+{
+    return launch_sized(crop_h, crop_w, crop_bwd_tiles_kernel<7, 7, CG, ACC>, crop_bwd_tiles_kernel<14, 14, CG, ACC>,
+                        crop_bwd_tiles_kernel<28, 28, CG, ACC>, crop_bwd_tiles_kernel<0, 0, CG, ACC>, grid, st, ls, tg,
+                        grads, boxes, box_ind, level, num_boxes, batch, depth, crop_h, crop_w, ncg);
+}
+
 int backward_impl(const LevelSetMut &ls, const float *grads, const float *boxes,
                   const int32_t *box_ind, const int32_t *level, int num_boxes, int batch, int depth,
                   int crop_h, int crop_w, hipStream_t st, bool clear = true)
 {
+    static const bool scatter = getenv("FI_CROP_BWD_SCATTER") != nullptr;      // A/B: the round-1..4 kernel
+    if (!scatter) {
+        // tile-owner form: every cell of every map is written by exactly one workgroup (no memset, no global atomics)
+        // channels per workgroup: 4 (32 KB of fp64 accumulators, 4 workgroups per CU) measured against 8 (64 KB, 2 per CU)
+        // at 512 x 256 on one 256^2 map: 7 x 7 95 vs 114 us, 14 x 14 160 vs 196 us (profiles/r05_crop_bwd_tiles.txt)
+        static const int CG = getenv("FI_CROP_TILE_CG") ? atoi(getenv("FI_CROP_TILE_CG")) : 4;
+        TileGrid tg = {};
+        long total = 0;
+        for (int l = 0; l < ls.n; ++l) {
+            const int W = ls.W[l];
+            tg.tw[l] = W > 32 ? 64 : (W > 16 ? 32 : 16);
+            tg.th[l] = kTileCells / tg.tw[l];
+            tg.nty[l] = fi::ceil_div(ls.H[l], tg.th[l]);
+            tg.ntx[l] = fi::ceil_div(W, tg.tw[l]);
+            tg.base[l] = (int)total;
+            total += (long)batch * tg.nty[l] * tg.ntx[l];
+        }
+        tg.base[ls.n] = (int)total;
+        const int ncg = fi::ceil_div(depth, CG);
+        FI_REQUIRE(total * ncg < 2147483647L, "grid too large");
+        if (num_boxes == 0 && !clear) return FI_OK;
+        fi::ProfScope prof(FI_K_CROP_BWD_7X7 + size_class(crop_h, crop_w), st);
+        const dim3 grid((unsigned)(total * ncg));
+        if (CG == 4)
+            return clear ? launch_bwd_tiles<4, false>(crop_h, crop_w, grid, st, ls, tg, grads, boxes, box_ind, level,
+                                                      num_boxes, batch, depth, ncg)
+                         : launch_bwd_tiles<4, true>(crop_h, crop_w, grid, st, ls, tg, grads, boxes, box_ind, level,
+                                                     num_boxes, batch, depth, ncg);
+        return clear ? launch_bwd_tiles<8, false>(crop_h, crop_w, grid, st, ls, tg, grads, boxes, box_ind, level,
+                                                  num_boxes, batch, depth, ncg)
+                     : launch_bwd_tiles<8, true>(crop_h, crop_w, grid, st, ls, tg, grads, boxes, box_ind, level,
+                                                 num_boxes, batch, depth, ncg);
+    }
     for (int l = 0; clear && l < ls.n; ++l) {
         const size_t bytes = sizeof(float) * (size_t)batch * depth * ls.H[l] * ls.W[l];
         FI_HIP_CHECK(hipMemsetAsync(ls.img[l], 0, bytes, st));

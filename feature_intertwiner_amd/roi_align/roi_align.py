@@ -6,23 +6,29 @@ The module only converts the boxes to the normalised (y1, x1, y2, x2) form of
 crop_and_resize and launches the HIP operator.  With `transform_fpcoor` the sampling grid is
 moved to bin centres (tensorpack's convention): for a crop of `c` bins over [a, b] the first
 sample sits at a + (b - a)/(2c) - 0.5 and the last one (c - 1) bins further.  The order of the
-floating-point operations below is part of the specification (oracle.roi_align_boxes pins it).
+floating-point operations below is part of the specification (oracle.roi_align_boxes pins it, and
+tests/golden/wrappers.npz holds what the reference's own RoIAlign.forward computed).  Every division is a true
+fp32 division: the divisors are device tensors, because `tensor / python_number` on the GPU is a multiplication
+by the rounded reciprocal -- 1 ulp away from the reference's CPU result for divisors like 7 or W - 1
+(found by tests/test_reference_wrappers.py on the MI355X).
 """
 import torch
 from torch import nn
 
+from .. import _lib
 from .crop_and_resize import CropAndResizeFunction
 
 
 def to_crop_boxes(boxes, map_h, map_w, crop_h, crop_w, bin_centres=True):
     """[M, 4] pixel (x1, y1, x2, y2) -> [M, 4] normalised (y1, x1, y2, x2) for crop_and_resize."""
     left, top, right, bottom = boxes.unbind(dim=1)
-    span_x, span_y = float(map_w - 1), float(map_h - 1)
+    k = _lib.const_tensor([float(map_w - 1), float(map_h - 1), float(crop_w), float(crop_h)], boxes.device, boxes.dtype)
+    span_x, span_y, n_x, n_y = k[0], k[1], k[2], k[3]
     if not bin_centres:
         return torch.stack((top / span_y, left / span_x, bottom / span_y, right / span_x), dim=1)
-    bin_w = (right - left) / float(crop_w)
-    bin_h = (bottom - top) / float(crop_h)
-    first_x = (left + bin_w / 2 - 0.5) / span_x
+    bin_w = (right - left) / n_x
+    bin_h = (bottom - top) / n_y
+    first_x = (left + bin_w / 2 - 0.5) / span_x           # (/ 2 is exact either way)
     first_y = (top + bin_h / 2 - 0.5) / span_y
     reach_x = bin_w * float(crop_w - 1) / span_x
     reach_y = bin_h * float(crop_h - 1) / span_y
