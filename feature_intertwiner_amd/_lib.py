@@ -98,6 +98,9 @@ SIGNATURES = {
     "fi_meta_stats_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int,
                                       c_int, c_int, c_int, c_int] + [c_void_p] * 9),
     "fi_meta_stats_backward": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 7 + [c_void_p, c_void_p]),
+    "fi_meta_stats_sums": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int,
+                                   c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "fi_meta_stats_from_sums": (c_int, [c_void_p, c_int, c_int] + [c_void_p] * 9),
     "fi_dev_stage_index": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int] + [c_void_p] * 9),
     "fi_gemm_nt_affine": (c_int, [c_void_p] * 5 + [c_int] * 4 + [c_void_p, c_void_p, c_void_p]),
     "fi_rows_mask_scale": (c_int, [c_void_p] * 6 + [c_int] * 5 + [c_void_p]),

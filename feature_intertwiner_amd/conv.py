@@ -25,6 +25,7 @@ from . import _lib, grad_arena
 # bench.py sets this to a dict to accumulate the algorithmic flops (2*N*Cout*OH*OW*Cin*R*S) of
 # every launch, keyed by the device kernel instance (see _lib.conv_kernel_key).
 FLOP_LOG = None
+LIVE_LOG = None
 # bench.py sets this to a list to record the (N, Cin, H, W, Cout, R, S, stride, padding) of every
 # forward convolution of a step (used to time the same stack on the host CPU for cpu_baseline).
 SHAPE_LOG = None
@@ -72,12 +73,15 @@ def _log_flops(kind, cout, R, S, flops, pixels=None, cin=None, patch=0, batch=1)
         e[1] += flops
 
 
-def _live_share(live, capacity):
+def _live_share(live, capacity, tag="gemm"):
     """Share of a static-capacity batch that is real, for the flop log only (a profiled pass may read the device count;
     the timed step never does: FLOP_LOG is None there)."""
     if FLOP_LOG is None or live is None or capacity <= 0:
         return 1.0
-    return min(1.0, float(int(live.reshape(-1)[0].item())) / capacity)
+    share = min(1.0, float(int(live.reshape(-1)[0].item())) / capacity)
+    if LIVE_LOG is not None:                 # scripts/conv_shapes.py: the share of every live-count launch, in order
+        LIVE_LOG.append((tag, share))
+    return share
 
 
 def _dense(w):
@@ -115,7 +119,7 @@ def _conv_fwd(x, w, b, stride, padding, relu=False, scale=None, residual=None, o
     if out_hw is not None:
         OH, OW = out_hw
     prec = _PRECISION if precision is None else precision
-    share = _live_share(live, N)            # (algorithmic flops: the live images only)
+    share = _live_share(live, N, "conv")    # (algorithmic flops: the live images only)
     if not (prec in _LOWP and layout >= 1 and Cin % 32 == 0):
         _log_flops("fwd", Cout, R, S, share * 2 * N * Cout * OH * OW * Cin * R * S, N * OH * OW,
                    patch=(_lib.patch_mode(N, Cin, H, W, Cout, R, S, stride, padding, layout >= 1,

@@ -63,6 +63,61 @@ __global__ __launch_bounds__(256) void meta_merge_kernel(StatsArgs a)
     if (__syncthreads_or(any ? 1 : 0) && threadIdx.x == 0) atomicOr(a.active, 1u);
 }
 
+// data-parallel form, phase 1a: the LOCAL count-weighted sums only -- sums[0 .. FK) big, [FK .. 2FK) small, then the big
+// and the small counts [K] each: one flat vector, all-reduced (sum) across the ranks before phase 1b
+__global__ __launch_bounds__(256) void meta_sums_kernel(StatsArgs a, float *__restrict__ sums)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const long n = (long)a.F * a.K;
+    if (i >= n) return;
+    const int f = (int)(i / a.K), k = (int)(i - (long)f * a.K);
+    float sb = 0.f, cb = 0.f, ss = 0.f, cs = 0.f;
+    for (int l = 0; l < a.S; ++l) {
+        float tb = 0.f, ub = 0.f, ts = 0.f, us = 0.f;
+        for (int g = 0; g < a.G; ++g) {
+            const float wb = a.big_cnt[(g * a.S + l) * a.K + k], ws = a.small_cnt[(g * a.S + l) * a.K + k];
+            const float pb = a.big_feat[(size_t)g * a.big_lg + (size_t)l * a.big_lk + (size_t)f * a.big_ld + k] * wb;
+            const float ps = a.small_feat[(size_t)g * a.small_lg + (size_t)l * a.small_lk + (size_t)f * a.small_ld + k] * ws;
+            tb = g ? tb + pb : pb;
+            ts = g ? ts + ps : ps;
+            ub = g ? ub + wb : wb;
+            us = g ? us + ws : ws;
+        }
+        sb = l ? sb + tb : tb;
+        ss = l ? ss + ts : ts;
+        cb = l ? cb + ub : ub;
+        cs = l ? cs + us : us;
+    }
+    sums[i] = sb;
+    sums[n + i] = ss;
+    if (f == 0) {
+        sums[2 * n + k] = cb;
+        sums[2 * n + a.K + k] = cs;
+    }
+}
+
+// phase 1b: the merged means from the (reduced) sums -- what meta_merge_kernel leaves for the phases below
+__global__ __launch_bounds__(256) void meta_means_kernel(const float *__restrict__ sums, int F, int K, float *__restrict__ b_feat,
+                                                         float *__restrict__ s_feat, float *__restrict__ b_cnt,
+                                                         float *__restrict__ s_cnt, unsigned int *__restrict__ active)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const long n = (long)F * K;
+    bool any = false;
+    if (i < n) {
+        const int k = (int)(i % K);
+        const float cb = sums[2 * n + k], cs = sums[2 * n + K + k], ss = sums[n + i];
+        b_feat[i] = sums[i] / (cb + kEps);
+        s_feat[i] = ss / (cs + kEps);
+        if (i < K) {
+            b_cnt[k] = cb;
+            s_cnt[k] = cs;
+        }
+        any = ss != 0.0f;
+    }
+    if (__syncthreads_or(any ? 1 : 0) && threadIdx.x == 0) atomicOr(active, 1u);
+}
+
 struct UpdateArgs {
     const float *b_feat, *s_feat, *b_cnt, *s_cnt;
     const unsigned int *active;
@@ -158,6 +213,39 @@ int fi_meta_stats_forward(const float *big_feat, const float *big_cnt, int big_l
                     b_feat, s_feat, b_cnt, s_cnt_out, flag};
     const long n = (long)F * K;
     hipLaunchKernelGGL(meta_merge_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, sa);
+    UpdateArgs ua = {b_feat, s_feat, b_cnt, s_cnt_out, flag, buffer, buffer_cnt, F, K, SMALL, BIG, on, active_f};
+    hipLaunchKernelGGL(meta_update_kernel, dim3((unsigned)((F + 31) / 32), (unsigned)((K + 31) / 32)), dim3(256), 0, st, ua);
+    hipLaunchKernelGGL(meta_finish_kernel, dim3(1), dim3(128), 0, st, ua);
+    FI_HIP_CHECK(hipGetLastError());
+    return FI_OK;
+}
+
+int fi_meta_stats_sums(const float *big_feat, const float *big_cnt, int big_ld, int big_lk, int big_lg, const float *small_feat,
+                       const float *small_cnt, int small_ld, int small_lk, int small_lg, int G, int S, int F, int K, float *sums,
+                       fi_stream_t stream)
+{
+    FI_REQUIRE(G >= 1 && S >= 1 && F >= 1 && K >= 2, "G, S, F >= 1, K >= 2");
+    FI_REQUIRE(big_feat && big_cnt && small_feat && small_cnt && sums, "null pointer");
+    StatsArgs sa = {big_feat, big_cnt, small_feat, small_cnt, G, S, F, K, big_ld, big_lk, big_lg, small_ld, small_lk, small_lg,
+                    nullptr, nullptr, nullptr, nullptr, nullptr};
+    const long n = (long)F * K;
+    hipLaunchKernelGGL(meta_sums_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, sa, sums);
+    FI_HIP_CHECK(hipGetLastError());
+    return FI_OK;
+}
+
+int fi_meta_stats_from_sums(const float *sums, int F, int K, float *buffer, float *buffer_cnt, float *s_cnt_out, float *SMALL,
+                            float *BIG, float *on, float *active_f, float *workspace, fi_stream_t stream)
+{
+    FI_REQUIRE(F >= 1 && K >= 2, "F >= 1, K >= 2");
+    FI_REQUIRE(sums && buffer && buffer_cnt && s_cnt_out && SMALL && BIG && on && active_f && workspace, "null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    float *b_feat = workspace, *s_feat = workspace + (size_t)F * K, *b_cnt = workspace + 2 * (size_t)F * K;
+    unsigned int *flag = reinterpret_cast<unsigned int *>(b_cnt + K);
+    FI_HIP_CHECK(hipMemsetAsync(flag, 0, sizeof(unsigned int), st));
+    const long n = (long)F * K;
+    hipLaunchKernelGGL(meta_means_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, sums, F, K, b_feat, s_feat, b_cnt,
+                       s_cnt_out, flag);
     UpdateArgs ua = {b_feat, s_feat, b_cnt, s_cnt_out, flag, buffer, buffer_cnt, F, K, SMALL, BIG, on, active_f};
     hipLaunchKernelGGL(meta_update_kernel, dim3((unsigned)((F + 31) / 32), (unsigned)((K + 31) / 32)), dim3(256), 0, st, ua);
     hipLaunchKernelGGL(meta_finish_kernel, dim3(1), dim3(128), 0, st, ua);

@@ -67,6 +67,21 @@ def all_reduce_statistics(feat_sum, cnt_sum, group=None):
     return flat[:n].view_as(feat_sum), flat[n:].view_as(cnt_sum)
 
 
+def all_reduce_flat_sum(flat, group=None):
+    """In place: flat <- sum over the ranks of flat (no autograd; the caller's backward applies the world-size factor,
+    see _AllReduceSumIdentityGrad).  Returns the world size.  The kernel form of the statistics exchange
+    (intertwiner._MetaStatsReducedFn) reduces its one flat vector of sums with this."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return 1
+    world = dist.get_world_size(group)
+    if world > 1 or _force_collectives():
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    return world
+
+
+all_reduce_statistics.flat_sum = all_reduce_flat_sum
+
+
 class GradientBuckets(object):
     """Bucketed, overlapped gradient all-reduce, IN PLACE on the model's gradient arena.
 

@@ -159,6 +159,60 @@ class _MetaStatsFn(torch.autograd.Function):
         return out, None, None, None, None, None
 
 
+class _MetaStatsReducedFn(torch.autograd.Function):
+    """_MetaStatsFn under data parallelism: this rank's count-weighted sums in one flat vector (fi_meta_stats_sums), ONE
+    all-reduce of it (`flat_sum`: in place, returns the world size), and the rest of the statistics side from the reduced
+    vector (fi_meta_stats_from_sums) -- 1 + 3 launches around the collective instead of the ~60 of the tensor formulation.
+    Backward: every rank back-propagates the same meta loss through its own contribution only and gradients are averaged
+    afterwards, so the path into the local statistics carries the world size (data_parallel._AllReduceSumIdentityGrad)."""
+
+    @staticmethod
+    def forward(ctx, small_feat, small_cnt, big_feat, big_cnt, buffer, buffer_cnt, flat_sum):
+        G, S, F_, K = small_feat.shape
+        lib = _lib.load()
+        dev = small_feat.device
+        sc = small_cnt.reshape(G * S, K).contiguous().float()
+        bc = big_cnt.reshape(G * S, K).contiguous().float()
+        sums = torch.empty(2 * F_ * K + 2 * K, device=dev, dtype=torch.float32)
+        with torch.cuda.device(dev):
+            _lib.check(lib.fi_meta_stats_sums(_lib.ptr(big_feat), _lib.ptr(bc), big_feat.stride(2), big_feat.stride(1),
+                                              big_feat.stride(0), _lib.ptr(small_feat), _lib.ptr(sc), small_feat.stride(2),
+                                              small_feat.stride(1), small_feat.stride(0), G, S, F_, K, _lib.ptr(sums),
+                                              _lib.current_stream()), "fi_meta_stats_sums")
+        world = flat_sum(sums)
+        SMALL = torch.empty((K - 1, F_), device=dev, dtype=torch.float32)
+        BIG = torch.empty((K - 1, F_), device=dev, dtype=torch.float32)
+        on = torch.empty(K - 1, device=dev, dtype=torch.float32)
+        s_cnt = torch.empty(K, device=dev, dtype=torch.float32)
+        active = torch.empty(1, device=dev, dtype=torch.float32)
+        ws = torch.empty(int(lib.fi_meta_stats_workspace_bytes(F_, K)) // 4 + 1, device=dev, dtype=torch.float32)
+        with torch.cuda.device(dev):
+            _lib.check(lib.fi_meta_stats_from_sums(_lib.ptr(sums), F_, K, _lib.ptr(buffer), _lib.ptr(buffer_cnt),
+                                                   _lib.ptr(s_cnt), _lib.ptr(SMALL), _lib.ptr(BIG), _lib.ptr(on),
+                                                   _lib.ptr(active), _lib.ptr(ws), _lib.current_stream()),
+                       "fi_meta_stats_from_sums")
+        ctx.save_for_backward(s_cnt, sc)
+        ctx.layout = (tuple(small_feat.shape), tuple(small_feat.stride()))
+        ctx.world = float(world)
+        ctx.mark_non_differentiable(BIG, on, active)
+        return SMALL, BIG, on, active
+
+    @staticmethod
+    def backward(ctx, d_small, _d_big, _d_on, _d_active):
+        s_cnt, sc = ctx.saved_tensors                      # the GLOBAL small counts, this rank's own counts
+        shape, stride = ctx.layout
+        G, S, F_, K = shape
+        g = d_small.contiguous().float()
+        if ctx.world != 1.0:
+            g = g * ctx.world
+        out = torch.empty_strided(shape, stride, device=g.device, dtype=torch.float32)
+        with torch.cuda.device(g.device):
+            _lib.check(_lib.load().fi_meta_stats_backward(_lib.ptr(g), _lib.ptr(s_cnt), _lib.ptr(sc), G, S, F_, K, stride[2],
+                                                          stride[1], stride[0], _lib.ptr(out), _lib.current_stream()),
+                       "fi_meta_stats_backward")
+        return out, None, None, None, None, None, None
+
+
 def _dense_levels(t):
     """[G, S, F, K] whose layout covers its storage exactly once with unit stride along K: the stacked (contiguous) tensor,
     or -- G = 1 -- the [F, S K] result of one class-mean launch viewed per level."""
@@ -218,13 +272,20 @@ def meta_loss(cfg, feature_buffer, ot_module, feat_input, reduce_fn=None):
       compared with the buffer column of their class.
     """
     big_feat, big_cnt, small_feat, small_cnt = feat_input[:4]
-    if STATS_KERNEL and reduce_fn is None and not cfg.DEV.INST_LOSS and small_feat.is_cuda and \
+    flat_sum = getattr(reduce_fn, "flat_sum", None)       # data_parallel.all_reduce_statistics carries one
+    if STATS_KERNEL and (reduce_fn is None or flat_sum is not None) and not cfg.DEV.INST_LOSS and small_feat.is_cuda and \
             feature_buffer.buffer.size(0) == 1 and small_feat.dtype == torch.float32 and big_feat.dtype == torch.float32 and \
             _dense_levels(small_feat) and _dense_levels(big_feat) and small_feat.shape == big_feat.shape and \
             feature_buffer.buffer.is_contiguous() and feature_buffer.buffer_cnt.is_contiguous():
-        # one rank, a history of one step (every shipped configuration): the statistics side as three launches
-        SMALL, BIG, on, active = _MetaStatsFn.apply(small_feat, small_cnt.detach(), big_feat.detach(), big_cnt.detach(),
-                                                    feature_buffer.buffer, feature_buffer.buffer_cnt)
+        # a history of one step (every shipped configuration): the statistics side as three launches on one rank, as
+        # 1 + 3 launches around ONE all-reduce under data parallelism
+        if reduce_fn is None:
+            SMALL, BIG, on, active = _MetaStatsFn.apply(small_feat, small_cnt.detach(), big_feat.detach(), big_cnt.detach(),
+                                                        feature_buffer.buffer, feature_buffer.buffer_cnt)
+        else:
+            SMALL, BIG, on, active = _MetaStatsReducedFn.apply(small_feat, small_cnt.detach(), big_feat.detach(),
+                                                               big_cnt.detach(), feature_buffer.buffer,
+                                                               feature_buffer.buffer_cnt, flat_sum)
         loss = _masked_mean(_pair_loss(cfg.DEV.LOSS_CHOICE, SMALL, BIG, on, ot_module), on)
         return torch.where(active[0] > 0, loss, torch.zeros_like(loss))
 

@@ -539,6 +539,19 @@ int fi_meta_stats_forward(const float *big_feat, const float *big_cnt, int big_l
                           float *on, float *active_f, float *workspace, fi_stream_t stream);
 int fi_meta_stats_backward(const float *dsmall, const float *s_cnt, const float *small_cnt, int G, int S, int F, int K,
                            int out_ld, int out_lk, int out_lg, float *dfeat, fi_stream_t stream);
+/* The same under data parallelism (one process per GPU; replaces the reference's gather to GPU 0 + _merge_feat_vec,
+ * lib/model.py:217-224): fi_meta_stats_sums leaves this rank's count-weighted sums in ONE flat vector
+ *   sums = [ sum big_feat*big_cnt (F K) | sum small_feat*small_cnt (F K) | sum big_cnt (K) | sum small_cnt (K) ]
+ * which the caller all-reduces (sum) across the ranks, and fi_meta_stats_from_sums continues from the reduced vector
+ * exactly as fi_meta_stats_forward continues from its own sums (means, history update, selection, operands): every rank
+ * ends with the same history and the same operands.  1 + 3 launches around the collective.  Backward: the caller scales
+ * d SMALL by the world size (gradients are averaged over the ranks afterwards) and calls fi_meta_stats_backward with
+ * the GLOBAL s_cnt and its LOCAL small_cnt. */
+int fi_meta_stats_sums(const float *big_feat, const float *big_cnt, int big_ld, int big_lk, int big_lg, const float *small_feat,
+                       const float *small_cnt, int small_ld, int small_lk, int small_lg, int G, int S, int F, int K, float *sums,
+                       fi_stream_t stream);
+int fi_meta_stats_from_sums(const float *sums, int F, int K, float *buffer, float *buffer_cnt, float *s_cnt_out, float *SMALL,
+                            float *BIG, float *on, float *active_f, float *workspace, fi_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * Target generation of one training step.

@@ -62,16 +62,25 @@ class Wrapped(object):
         return timed
 
 
+from feature_intertwiner_amd import conv as _conv  # noqa: E402
 _lib._lib = Wrapped(L)
+_conv.FLOP_LOG, _conv.LIVE_LOG = {}, []      # static-capacity batches: the live share of each launch is read back (in order)
 train_step(model, opt, list(batch))
 torch.cuda.synchronize()
 _lib._lib = L
+live_shares = [sh for tag, sh in _conv.LIVE_LOG if tag == "conv"]
+_conv.FLOP_LOG = _conv.LIVE_LOG = None
 
 
 def describe(name, a):
     v = [x for x in a if x is not None]
     gated = "_gated" in name
     name = name.replace("_gated", "")
+    if name.endswith("_live") or "_live_" in name:
+        # (same leading arguments as the plain entry point; flops = the live rows only, as the bench counts them)
+        share = live_shares.pop(0) if live_shares else 1.0
+        key, fl = describe(name.replace("_live", ""), a)
+        return key + " [static capacity, %.0f %% live]" % (100 * share), fl * share
     if name in ("fi_conv2d_forward", "fi_conv2d_forward_bf16", "fi_conv2d_forward_f16"):
         N, Cin, H, W, Cout, R, S, sh, sw, ph, pw, relu, layout, oh, ow, ocl = v[:16]
         OH = oh or (H + 2 * ph - R) // sh + 1
