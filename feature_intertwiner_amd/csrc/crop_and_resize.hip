@@ -834,6 +834,145 @@ __global__ __launch_bounds__(kThreads) void crop_bwd_cl_kernel(
     }
 }
 
+// -------------------------------------------------------------------------------------
+// Channels-last backward, TILE-OWNER form: no atomics of any kind, no memset, and the reference's summation order.
+// A workgroup owns a tile of kClTH x kClTW cells of one image's map for 256 channels: thread t owns channel t of every
+// cell (its private column of an LDS tile [cell][256]: plain read-add-write, no conflicts, nothing shared).  The boxes
+// that reach the tile are listed in box order (as crop_bwd_tiles_kernel does) and every thread walks the listed boxes
+// and their bins in (y, x) order, adding TL, TR, BL, BR -- exactly the order in which the reference's serial loop
+// (lib/roi_align/src/crop_and_resize.c:190-251) reaches a given (cell, channel), with the same fp32 products: the
+// result is BIT-IDENTICAL to the reference / the oracle, and the same from run to run (the atomic forms are not).
+// Opt-in (FI_CROP_BWD_CL_TILES=1, see backward_cl_impl): slower than the atomic kernels on crowded coarse levels.
+// The tile then leaves with 1 KB-contiguous stores (256 channels of a cell), which is also the zero fill; the
+// accumulate form skips tiles no box reaches and reads the others first.
+// (Zero-weight duplicates are skipped: when a coordinate is an integer, floor == ceil and the reference adds
+// frac * g = +-0 to the same cell a second time, which never changes a sum.)
+// -------------------------------------------------------------------------------------
+constexpr int kClTH = 4, kClTW = 8, kClCells = kClTH * kClTW, kClChan = 256;
+
+template <int CH, int CW, bool ACC>
+__global__ __launch_bounds__(kThreads) void crop_bwd_cl_tiles_kernel(
+    LevelSetMut ls, TileGrid tg, const float *__restrict__ grads, const float *__restrict__ boxes,
+    const int *__restrict__ box_ind, const int *__restrict__ level, int num_boxes, int batch,
+    int depth, int crop_h_rt, int crop_w_rt, int nchunk)
+{
+    const int crop_h = CH ? CH : crop_h_rt;
+    const int crop_w = CW ? CW : crop_w_rt;
+    const int bins = crop_h * crop_w;
+    __shared__ float s_tile[kClCells * kClChan];
+    __shared__ float s_box[kThreads][4];        // base_y, step_y, base_x, step_x
+    __shared__ int s_rng[kThreads];             // k_lo(y) | k_n(y) << 8 | k_lo(x) << 16 | k_n(x) << 24
+    __shared__ int s_id[kThreads];
+    __shared__ int s_wave_n[kThreads / 64];
+
+    const int tid = threadIdx.x;
+    const int chunk = blockIdx.x % nchunk;
+    int t = blockIdx.x / nchunk;
+    int lvl = 0;
+    while (lvl + 1 < ls.n && t >= tg.base[lvl + 1]) ++lvl;
+    t -= tg.base[lvl];
+    const int H = ls.H[lvl], W = ls.W[lvl];
+    const int tiles = tg.nty[lvl] * tg.ntx[lvl];
+    const int img = t / tiles;
+    const int tile = t - img * tiles;
+    const int row0 = (tile / tg.ntx[lvl]) * kClTH;
+    const int col0 = (tile % tg.ntx[lvl]) * kClTW;
+    const int c = chunk * kClChan + tid;
+    const bool c_ok = c < depth;
+    float *__restrict__ dst = ls.img[lvl] + (size_t)img * H * W * depth + (c_ok ? c : 0);
+    float *mine = s_tile + tid;                  // [cell] at stride kClChan
+
+    bool started = false;                        // the tile holds its starting values
+    auto start = [&]() {
+#pragma unroll
+        for (int cell = 0; cell < kClCells; ++cell) {
+            float v = 0.0f;
+            if (ACC) {
+                const int r = row0 + cell / kClTW, col = col0 + cell % kClTW;
+                if (c_ok && r < H && col < W) v = dst[((size_t)r * W + col) * depth];
+            }
+            mine[cell * kClChan] = v;
+        }
+        started = true;
+    };
+    if (!ACC) start();
+
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int chunk0 = 0; chunk0 < num_boxes; chunk0 += kThreads) {
+        const int box = chunk0 + tid;
+        bool hit = false;
+        float by = 0, sy = 0, bx = 0, sx = 0;
+        int ky = 0, ny = 0, kx = 0, nx = 0;
+        if (box < num_boxes && box_ind[box] == img && (level ? (level[box] - 2) : 0) == lvl) {
+            const float *b = boxes + 4 * (size_t)box;
+            hit = axis_range(b[0], b[2], H, crop_h, row0, kClTH, &by, &sy, &ky, &ny) &&
+                  axis_range(b[1], b[3], W, crop_w, col0, kClTW, &bx, &sx, &kx, &nx);
+        }
+        const unsigned long long m = __ballot(hit);
+        if (lane == 0) s_wave_n[wave] = __popcll(m);
+        __syncthreads();
+        int off = 0, n = 0;
+#pragma unroll
+        for (int w = 0; w < kThreads / 64; ++w) {
+            const int k = s_wave_n[w];
+            if (w < wave) off += k;
+            n += k;
+        }
+        if (hit) {
+            const int slot = off + __popcll(m & ((1ull << lane) - 1ull));
+            s_box[slot][0] = by; s_box[slot][1] = sy; s_box[slot][2] = bx; s_box[slot][3] = sx;
+            s_rng[slot] = ky | (ny << 8) | (kx << 16) | (nx << 24);
+            s_id[slot] = box;
+        }
+        __syncthreads();
+        if (n > 0 && !started) start();           // (uniform over the workgroup)
+        for (int j = 0; j < n; ++j) {             // box order; every thread: its own channel
+            const int rng = s_rng[j];
+            const int ky0 = rng & 255, nyj = (rng >> 8) & 255, kx0 = (rng >> 16) & 255, nxj = (rng >> 24) & 255;
+            const float byj = s_box[j][0], syj = s_box[j][1], bxj = s_box[j][2], sxj = s_box[j][3];
+            const float *__restrict__ gch = grads + ((size_t)s_id[j] * depth + (c_ok ? c : 0)) * bins;
+            for (int y = ky0; y < ky0 + nyj; ++y) {
+                const Tap ty = tap_at(crop_h > 1 ? byj + (float)y * syj : byj, H);
+                if (!ty.valid) continue;
+                const unsigned r0 = (unsigned)(ty.i0 - row0), r1 = (unsigned)(ty.i1 - row0);
+                const bool in_r0 = r0 < (unsigned)kClTH, in_r1 = (r1 < (unsigned)kClTH) && (ty.i1 != ty.i0);
+                if (!(in_r0 | in_r1)) continue;
+                const float wy0 = 1.0f - ty.frac;
+                const float *__restrict__ grow = gch + y * crop_w;
+                for (int xb = kx0; xb < kx0 + nxj; xb += 4) {
+                    float gv[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) gv[u] = (xb + u < kx0 + nxj) ? grow[xb + u] : 0.0f;   // 4 loads in flight
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int x = xb + u;
+                        if (x >= kx0 + nxj) break;
+                        const Tap tx = tap_at(crop_w > 1 ? bxj + (float)x * sxj : bxj, W);
+                        if (!tx.valid) continue;
+                        const unsigned c0 = (unsigned)(tx.i0 - col0), c1 = (unsigned)(tx.i1 - col0);
+                        const bool in_c0 = c0 < (unsigned)kClTW, in_c1 = (c1 < (unsigned)kClTW) && (tx.i1 != tx.i0);
+                        if (!(in_c0 | in_c1)) continue;
+                        // reference order: dtop = (1-ly)*g; TL += (1-lx)*dtop; TR += lx*dtop; dbot = ly*g; BL, BR
+                        const float wx0 = 1.0f - tx.frac;
+                        const float gtop = wy0 * gv[u], gbot = ty.frac * gv[u];
+                        if (in_r0 & in_c0) mine[(r0 * kClTW + c0) * kClChan] += wx0 * gtop;
+                        if (in_r0 & in_c1) mine[(r0 * kClTW + c1) * kClChan] += tx.frac * gtop;
+                        if (in_r1 & in_c0) mine[(r1 * kClTW + c0) * kClChan] += wx0 * gbot;
+                        if (in_r1 & in_c1) mine[(r1 * kClTW + c1) * kClChan] += tx.frac * gbot;
+                    }
+                }
+            }
+        }
+        __syncthreads();                          // the list is rebuilt by the next chunk
+    }
+    if (!started || !c_ok) return;                // accumulate form: nothing reached this tile
+#pragma unroll
+    for (int cell = 0; cell < kClCells; ++cell) {
+        const int r = row0 + cell / kClTW, col = col0 + cell % kClTW;
+        if (r < H && col < W) dst[((size_t)r * W + col) * depth] = mine[cell * kClChan];
+    }
+}
+
 // Channels-last backward for crops with more bins than source cells (14 x 14 crops of the mask branch: a box
 // of a pyramid level covers about 8..21 source rows/columns, so its 4 * 196 bilinear contributions per channel
 // land on 64..441 distinct cells).  GATHER form: the sample coordinates of an axis are monotone in the bin
@@ -1211,6 +1350,38 @@ int backward_cl_impl(const LevelSetMut &ls, const float *grads, const float *box
                      const int32_t *box_ind, const int32_t *level, int num_boxes, int batch, int depth,
                      int crop_h, int crop_w, hipStream_t st, bool clear = true)
 {
+    // FI_CROP_BWD_CL_TILES=1 (read at every call): the deterministic tile-owner form -- bit-identical to the reference's
+    // serial loop, no atomics, no memset -- instead of the atomic kernels below.  Not the default: a thread walks its
+    // tile's boxes one after the other and waits for every box's gradient values (one HBM round trip each), so the
+    // crowded tiles of the coarse levels set the time: pyramid 2048 x 256, 7 x 7 492 vs 346 (+130 memset) us,
+    // 14 x 14 1567 vs 410 (+90) us (profiles/r05_crop_bwd_tiles.txt).
+    const char *tiles_env = getenv("FI_CROP_BWD_CL_TILES");
+    if (tiles_env && tiles_env[0] == '1') {
+        // every cell of every map is written by exactly one workgroup
+        TileGrid tg = {};
+        long total = 0;
+        for (int l = 0; l < ls.n; ++l) {
+            tg.th[l] = kClTH;
+            tg.tw[l] = kClTW;
+            tg.nty[l] = fi::ceil_div(ls.H[l], kClTH);
+            tg.ntx[l] = fi::ceil_div(ls.W[l], kClTW);
+            tg.base[l] = (int)total;
+            total += (long)batch * tg.nty[l] * tg.ntx[l];
+        }
+        tg.base[ls.n] = (int)total;
+        const int nchunk = fi::ceil_div(depth, kClChan);
+        FI_REQUIRE(total * nchunk < 2147483647L, "grid too large");
+        if (num_boxes == 0 && !clear) return FI_OK;
+        fi::ProfScope prof(FI_K_CROP_BWD_NHWC_7X7 + cl_size_class(crop_h, crop_w), st);
+        const dim3 grid((unsigned)(total * nchunk));
+        if (clear)
+            return launch_sized(crop_h, crop_w, crop_bwd_cl_tiles_kernel<7, 7, false>, crop_bwd_cl_tiles_kernel<14, 14, false>,
+                                crop_bwd_cl_tiles_kernel<28, 28, false>, crop_bwd_cl_tiles_kernel<0, 0, false>, grid, st, ls,
+                                tg, grads, boxes, box_ind, level, num_boxes, batch, depth, crop_h, crop_w, nchunk);
+        return launch_sized(crop_h, crop_w, crop_bwd_cl_tiles_kernel<7, 7, true>, crop_bwd_cl_tiles_kernel<14, 14, true>,
+                            crop_bwd_cl_tiles_kernel<28, 28, true>, crop_bwd_cl_tiles_kernel<0, 0, true>, grid, st, ls, tg,
+                            grads, boxes, box_ind, level, num_boxes, batch, depth, crop_h, crop_w, nchunk);
+    }
     for (int l = 0; clear && l < ls.n; ++l) {
         const size_t bytes = sizeof(float) * (size_t)batch * depth * ls.H[l] * ls.W[l];
         FI_HIP_CHECK(hipMemsetAsync(ls.img[l], 0, bytes, st));

@@ -198,8 +198,11 @@ def test_pyramid_matches_per_level_oracle(oracle):
 @pytest.mark.parametrize("C,crops", [(16, (7, 14)), (256, (7, 14)), (200, (7, 5)), (64, (1, 12)), (40, (14, 10))])
 def test_pyramid_channels_last_matches_per_level_oracle(oracle, C, crops):
     """Maps in torch.channels_last memory format ([B,H,W,C]) take fi_pyramid_crop_*_nhwc: forward
-    BIT-EXACT vs the oracle (and hence vs the NCHW kernels), backward within the atomics tolerance,
+    BIT-EXACT vs the oracle (and hence vs the NCHW kernels), backward within the atomics tolerance -- and EQUAL to the
+    oracle in the deterministic tile-owner form (FI_CROP_BWD_CL_TILES=1: every cell's contributions are added in the
+    reference's serial order -- box, bin row, bin column, TL TR BL BR -- with the reference's fp32 products);
     gradients returned in channels_last."""
+    import os
     from feature_intertwiner_amd.roi_align.crop_and_resize import LAUNCH_LOG, pyramid_crop_and_resize
     import feature_intertwiner_amd.roi_align.crop_and_resize as mod
     rs = np.random.RandomState(32 + C)
@@ -228,15 +231,24 @@ def test_pyramid_channels_last_matches_per_level_oracle(oracle, C, crops):
                 exp[sel] = oracle.crop_and_resize_forward(maps[l - 2], boxes[sel], ind[sel], crop, crop, 0.0)
         assert np.array_equal(_bits(got), _bits(exp))
         G = rs.standard_normal(got.shape).astype(np.float32)
-        for t in tm:
-            t.grad = None
-        out.backward(torch.from_numpy(G).to(DEV))
-        for l in range(2, 6):
-            sel = np.nonzero((level == l) & good)[0]
-            e = oracle.crop_and_resize_backward(G[sel], boxes[sel], ind[sel], maps[l - 2].shape)
-            assert tm[l - 2].grad.is_contiguous(memory_format=torch.channels_last)
-            g = tm[l - 2].grad.cpu().numpy()
-            assert np.max(np.abs(g - e)) <= 2e-5 * (np.abs(e).max() + 1e-6)
+        for tiles in ("0", "1"):
+            for t in tm:
+                t.grad = None
+            os.environ["FI_CROP_BWD_CL_TILES"] = tiles
+            try:
+                out.backward(torch.from_numpy(G).to(DEV), retain_graph=True)
+                torch.cuda.synchronize()
+            finally:
+                del os.environ["FI_CROP_BWD_CL_TILES"]
+            for l in range(2, 6):
+                sel = np.nonzero((level == l) & good)[0]
+                e = oracle.crop_and_resize_backward(G[sel], boxes[sel], ind[sel], maps[l - 2].shape)
+                assert tm[l - 2].grad.is_contiguous(memory_format=torch.channels_last)
+                g = tm[l - 2].grad.cpu().numpy()
+                if tiles == "1":
+                    assert np.array_equal(g, e), (crop, l, float(np.max(np.abs(g - e))))
+                else:
+                    assert np.max(np.abs(g - e)) <= 2e-5 * (np.abs(e).max() + 1e-6)
 
 
 def test_channels_last_full_size_equals_nchw_bitwise():
