@@ -378,6 +378,7 @@ def side_stream(device=None):
     side = _SIDE2.get(dev)
     if side is None:
         side = _SIDE2[dev] = pick_stream(dev)
+        _ROLE[(dev, id(side))] = "second"
     return side
 
 
@@ -387,7 +388,68 @@ def side_stream3(device=None):
     side = _SIDE3.get(dev)
     if side is None:
         side = _SIDE3[dev] = pick_stream(dev)
+        _ROLE[(dev, id(side))] = "third"
     return side
+
+
+_ROLE = {}          # (device, id(stream)) -> "second" | "third" | "communication" | ...
+
+
+def name_stream(stream, role, device=None):
+    """Give a picked stream a name for stream_report (the gradient buckets call this for their communication stream)."""
+    dev = torch.cuda.current_device() if device is None else torch.device(device).index
+    _ROLE[(dev, id(stream))] = role
+
+
+def stream_report(device=None, repick=False):
+    """The measured concurrency of the streams this process picked on `device`, in pick order: for every stream, whether a
+    kernel on it overtakes a spin on the current stream and on every stream picked before it (the property pick_stream
+    selected it for).  A process group created later, RCCL's own streams at its first collective, or another library can
+    take hardware queues and change the map: with repick=True a stream that lost the property is REPLACED by a candidate
+    that has it (the second / third stream caches are updated; the returned "replaced" maps id(old) -> new stream, so an
+    owner like GradientBuckets can follow).  Host-synchronising (a handful of ~1 ms spins): for start-up and the first
+    step boundary after the first real collective, not for the step."""
+    dev = torch.cuda.current_device() if device is None else torch.device(device).index
+    out = {"GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES", "unset (runtime default 4)"), "pick_streams": PICK_STREAMS,
+           "streams": [], "replaced": {}}
+    used = _IN_USE.get(dev, [])
+    if not used or torch.cuda.is_current_stream_capturing():
+        return out
+    with torch.cuda.device(dev):
+        torch.cuda.synchronize(dev)
+        probe = torch.zeros(64, device="cuda:%d" % dev)
+        cur = torch.cuda.current_stream(dev)
+        for i in range(len(used)):
+            u = used[i]
+            busy = [cur] + used[:i]
+            ok = [bool(_overtakes(a, u, probe)) for a in busy]
+            role = _ROLE.get((dev, id(u)), "picked-%d" % i)
+            rec = {"role": role, "concurrent_with_earlier": all(ok), "detail": ok}
+            if repick and not all(ok) and PICK_STREAMS:
+                best, best_hits = None, sum(ok)
+                for c in _CANDIDATES.get(dev, []) + [torch.cuda.Stream(device=dev) for _ in range(4)]:
+                    if any(c is x for x in used):
+                        continue
+                    with torch.cuda.stream(c):
+                        probe.add_(1.0)                   # binds a fresh stream to its hardware queue
+                    hits = sum(1 for a in busy if _overtakes(a, c, probe))
+                    if hits > best_hits:
+                        best, best_hits = c, hits
+                    if hits == len(busy):
+                        break
+                if best is not None:
+                    out["replaced"][id(u)] = best
+                    used[i] = best
+                    _ROLE[(dev, id(best))] = role
+                    if _SIDE2.get(dev) is u:
+                        _SIDE2[dev] = best
+                    if _SIDE3.get(dev) is u:
+                        _SIDE3[dev] = best
+                    rec["repicked"] = True
+                    rec["concurrent_with_earlier"] = best_hits == len(busy)
+            out["streams"].append(rec)
+        torch.cuda.synchronize(dev)
+    return out
 
 
 def _mark_stream(o, stream):

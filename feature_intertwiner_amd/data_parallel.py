@@ -140,6 +140,7 @@ class GradientBuckets(object):
         self._absent_run = {}        # key -> {parameter: consecutive steps without a gradient}
         self._key = None
         self._violations = torch.zeros((), device=self.device)
+        self.stream_choice = None    # recheck_streams(): the measured concurrency of the picked streams
         self.late_gradients = 0      # gradients that arrived after their bucket had been issued (see the class docstring)
         self._late_warned = False
         self._flag_cache = {}
@@ -161,7 +162,25 @@ class GradientBuckets(object):
             from . import _lib
             with torch.cuda.device(self.device):
                 self._comm_stream = _lib.pick_stream(self.device)
+                _lib.name_stream(self._comm_stream, "communication", self.device)
         return self._comm_stream
+
+    def recheck_streams(self):
+        """Call at a step boundary AFTER the first step (i.e. after the first real collectives: RCCL has created its own
+        streams and channels by then): re-measures which of the process's picked streams still run next to each other and
+        replaces those that do not (_lib.stream_report(repick=True)); follows a replaced communication stream.  The
+        report is kept in `stream_choice` (bench.py prints it).  Host-synchronising, a few ms: once, not per step."""
+        if not (self.active and self.use_stream):
+            return None
+        from . import _lib
+        with torch.cuda.device(self.device):
+            rep = _lib.stream_report(self.device, repick=True)
+        new = rep["replaced"].get(id(self._comm_stream)) if self._comm_stream is not None else None
+        if new is not None:
+            self._comm_stream = new
+        self.stream_choice = {"GPU_MAX_HW_QUEUES": rep["GPU_MAX_HW_QUEUES"],
+                              "streams": [{k: v for k, v in r.items() if k != "detail"} for r in rep["streams"]]}
+        return self.stream_choice
 
     def bucket_bytes(self):
         return [4 * (b.end - b.start) for b in self.layout.buckets]

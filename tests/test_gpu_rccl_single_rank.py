@@ -53,6 +53,17 @@ def _run(use_dp, out):
     torch.cuda.synchronize()
     if sync is not None:
         sync.check()
+        # after the first real collectives: the measured concurrency of the picked streams (second, third, communication),
+        # a stream that lost it is replaced -- and the engine goes on working on whatever it ended up with
+        choice = sync.recheck_streams()
+        roles = [r["role"] for r in choice["streams"]]
+        assert "communication" in roles and "second" in roles, roles
+        assert all(isinstance(r["concurrent_with_earlier"], bool) for r in choice["streams"])
+        assert sum(1 for r in choice["streams"] if r["concurrent_with_earlier"]) >= 2, choice     # 4 hardware queues: main + 2 at least
+        t3 = train_step(model, opt, list(batch), grad_sync=sync, world_size=1, reduce_fn=reduce_fn)
+        assert all(torch.isfinite(v) for v in t3.values()) and sync.late_gradients == 0
+        torch.cuda.synchronize()
+        sync.check()
     torch.save({"terms": {k: float(v) for k, v in terms.items()}, "params": params}, out)
 
 
