@@ -35,7 +35,12 @@ def make_config(backbone="resnet101", image_size=1024, batch_size=4, train_rois_
                 ASSIGN_ANCHOR_BASE=224.0, METHOD=roi_method)
     c.TRAIN = NS(BATCH_SIZE=batch_size, INIT_LR=0.01, MOMENTUM=0.9, WEIGHT_DECAY=0.0001,
                  CLIP_GRAD=True, MAX_GRAD_NORM=5.0, BN_LEARN=False, FPN_OT_LOSS=False,
-                 FPN_OT_LOSS_FAC=1.0)
+                 FPN_OT_LOSS_FAC=1.0,
+                 # LOSS_SCALE (not in the reference, which has no 16-bit path): the loss is multiplied by it before
+                 # backward and the gradients divided by it afterwards (workflow.backward_scaled).  fp16 operands: the
+                 # mask head's gradients g = dy * (y > 0) fall below fp16's normal range (6e-5) unscaled -- the
+                 # BatchNorm-weight gradients of the default backward form were 15-30 % off the dense form's
+                 LOSS_SCALE=1024.0 if conv_precision == "fp16" else 1.0)
     c.DEV = NS(SWITCH=dev_switch, BUFFER_SIZE=buffer_size, EFFECT_AFER_EP_PERCENT=0.0,
                MULTI_UPSAMPLER=False, UPSAMPLE_FAC=1.0, LOSS_CHOICE=loss_choice,
                OT_ONE_DIM_FORM="conv", OT_L=ot_L, OT_EPSILON=1.0, LOSS_FAC=loss_fac, INST_LOSS=False,

@@ -77,6 +77,23 @@ def compute_loss(model, inputs, do_meta=True, world_size=1, reduce_fn=None):
     return loss, {k: v.detach() for k, v in terms.items()}
 
 
+def backward_scaled(model, loss):
+    """loss.backward() with the static loss scale of the 16-bit paths (cfg.TRAIN.LOSS_SCALE; 1 = plain backward).  Returns
+    the function that divides the scale out of the gradients again (one multi-tensor pass; call it after the gradient
+    exchange, before clipping)."""
+    s = float(getattr(model.config.TRAIN, "LOSS_SCALE", 1.0) or 1.0)
+    if s == 1.0:
+        loss.backward()
+        return lambda: None
+    (loss * s).backward()
+
+    def unscale():
+        grads = [p.grad for p in model.parameters() if p.grad is not None]
+        if grads:
+            torch._foreach_mul_(grads, 1.0 / s)
+    return unscale
+
+
 def train_step(model, optimizer, inputs, do_meta=True, grad_sync=None, world_size=1, reduce_fn=None):
     """zero_grad / backward / clip_grad_norm(MAX_GRAD_NORM) / step (lib/workflow.py:226-230).
     `grad_sync` (data parallel) is called after backward and must leave the rank-averaged
@@ -86,13 +103,14 @@ def train_step(model, optimizer, inputs, do_meta=True, grad_sync=None, world_siz
     loss, terms = compute_loss(model, inputs, do_meta, world_size, reduce_fn)
     if grad_sync is not None and hasattr(grad_sync, "begin"):
         grad_sync.begin(("do_meta", bool(do_meta)))     # the graph variant decides which parameters get gradients
-    loss.backward()
+    unscale = backward_scaled(model, loss)
     join = getattr(model, "_side_join", None)
     if join is not None:          # work of the forward pass that nothing reads (MaskRCNN.forward) ends before the weights move
         model._side_join = None
         join()
     if grad_sync is not None:
         grad_sync()
+    unscale()
     if optim.supported(optimizer):
         # clip_grad_norm_ + SGD step in three launches (csrc/sgd.hip) instead of ~8 passes over all parameters
         optim.clip_and_step(optimizer, cfg.TRAIN.MAX_GRAD_NORM if cfg.TRAIN.CLIP_GRAD else None)
@@ -145,11 +163,12 @@ def compare_backward_forms(model, inputs, do_meta=True, generator_seed=3, skip=N
             for p in model.parameters():
                 p.grad = None
             loss, _ = compute_loss(model, list(inputs), do_meta, 1, None)
-            loss.backward()
+            unscale = backward_scaled(model, loss)
             join = getattr(model, "_side_join", None)
             if join is not None:
                 model._side_join = None
                 join()
+            unscale()
             if dev.type == "cuda":
                 torch.cuda.synchronize(dev)
             out[slot] = (float(loss.detach()),
