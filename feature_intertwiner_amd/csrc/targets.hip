@@ -168,19 +168,37 @@ __global__ __launch_bounds__(1024) void rpn_sample_kernel(const float *__restric
 
     // pass 1: candidate class of every anchor (written to `match`), counts, histogram of the keys' high 12 bits
     int c_pos = 0, c_neg = 0;
-    for (int a = tid; a < A; a += 1024) {
-        const float v = im[a];
-        float m = (v < neg_thres && !(ar[a] & 0x80000000u)) ? -1.0f : 0.0f;
-        bool claimed = false;
-        for (int g = 0; g < nclaim; ++g) claimed = claimed || (s_claim[g] == a);
-        if (claimed || v >= pos_thres) m = 1.0f;
-        mt[a] = m;
-        if (m > 0.0f) {
-            ++c_pos;
-            atomicAdd(&s_hist[0][key_of(kp[a]) >> 12], 1u);
-        } else if (m < 0.0f) {
-            ++c_neg;
-            atomicAdd(&s_hist[1][key_of(kn[a]) >> 12], 1u);
+    // (4 anchors per thread and iteration, their loads issued together: the kernel is ONE workgroup per image walking
+    // 261 888 anchors five times -- its time is memory latency per iteration, round 4: 1.6-4.0 ms)
+    for (int a0 = tid; a0 < A; a0 += 4096) {
+        float v4[4], kp4[4], kn4[4];
+        unsigned ar4[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int a = a0 + 1024 * u;
+            const bool in = a < A;
+            v4[u] = in ? im[a] : 0.0f;
+            ar4[u] = in ? ar[a] : 0u;
+            kp4[u] = in ? kp[a] : 1.0f;
+            kn4[u] = in ? kn[a] : 1.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int a = a0 + 1024 * u;
+            if (a >= A) break;
+            const float v = v4[u];
+            float m = (v < neg_thres && !(ar4[u] & 0x80000000u)) ? -1.0f : 0.0f;
+            bool claimed = false;
+            for (int g = 0; g < nclaim; ++g) claimed = claimed || (s_claim[g] == a);
+            if (claimed || v >= pos_thres) m = 1.0f;
+            mt[a] = m;
+            if (m > 0.0f) {
+                ++c_pos;
+                atomicAdd(&s_hist[0][key_of(kp4[u]) >> 12], 1u);
+            } else if (m < 0.0f) {
+                ++c_neg;
+                atomicAdd(&s_hist[1][key_of(kn4[u]) >> 12], 1u);
+            }
         }
     }
     atomicAdd(&s_cnt[0], c_pos);
@@ -215,14 +233,26 @@ __global__ __launch_bounds__(1024) void rpn_sample_kernel(const float *__restric
     for (int i = tid; i < 2 * 4096; i += 1024) (&s_hist[0][0])[i] = 0u;
     __syncthreads();
     if (bk_p != 0xFFFFFFFFu || bk_n != 0xFFFFFFFFu) {
-        for (int a = tid; a < A; a += 1024) {
-            const float m = mt[a];
-            if (m > 0.0f && bk_p != 0xFFFFFFFFu) {
-                const unsigned k = key_of(kp[a]);
-                if ((k >> 12) == bk_p) atomicAdd(&s_hist[0][k & 4095u], 1u);
-            } else if (m < 0.0f && bk_n != 0xFFFFFFFFu) {
-                const unsigned k = key_of(kn[a]);
-                if ((k >> 12) == bk_n) atomicAdd(&s_hist[1][k & 4095u], 1u);
+        for (int a0 = tid; a0 < A; a0 += 4096) {
+            float m4[4], kp4[4], kn4[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int a = a0 + 1024 * u;
+                const bool in = a < A;
+                m4[u] = in ? mt[a] : 0.0f;
+                kp4[u] = in ? kp[a] : 1.0f;
+                kn4[u] = in ? kn[a] : 1.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float m = m4[u];
+                if (m > 0.0f && bk_p != 0xFFFFFFFFu) {
+                    const unsigned k = key_of(kp4[u]);
+                    if ((k >> 12) == bk_p) atomicAdd(&s_hist[0][k & 4095u], 1u);
+                } else if (m < 0.0f && bk_n != 0xFFFFFFFFu) {
+                    const unsigned k = key_of(kn4[u]);
+                    if ((k >> 12) == bk_n) atomicAdd(&s_hist[1][k & 4095u], 1u);
+                }
             }
         }
     }
@@ -258,10 +288,21 @@ __global__ __launch_bounds__(1024) void rpn_sample_kernel(const float *__restric
     const int lane = tid & 63, wave = tid >> 6;
     const int per_wave = ((A + 15) / 16 + 63) / 64 * 64;
     const int a_begin = wave * per_wave, a_end = min(A, a_begin + per_wave);
-    auto classify = [&](int a, bool in, bool &cand_p, bool &cand_n, bool &tie_p, bool &tie_n, bool &sure_p, bool &sure_n) {
-        const float m = in ? mt[a] : 0.0f;
-        const unsigned k_p = in ? key_of(kp[a]) : 0u;
-        const unsigned k_n = in ? key_of(kn[a]) : 0u;
+    struct Loaded { float m, kp, kn; };
+    auto load4 = [&](int a0, Loaded (&v)[4]) {               // the next four 64-anchor chunks of this wavefront: 12 loads in flight
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int a = a0 + 64 * u + lane;
+            const bool in = a < a_end;
+            v[u].m = in ? mt[a] : 0.0f;
+            v[u].kp = in ? kp[a] : 1.0f;
+            v[u].kn = in ? kn[a] : 1.0f;
+        }
+    };
+    auto classify = [&](const Loaded &v, bool in, bool &cand_p, bool &cand_n, bool &tie_p, bool &tie_n, bool &sure_p, bool &sure_n) {
+        const float m = in ? v.m : 0.0f;
+        const unsigned k_p = in ? key_of(v.kp) : 0u;
+        const unsigned k_n = in ? key_of(v.kn) : 0u;
         cand_p = m > 0.0f;
         cand_n = m < 0.0f;
         tie_p = cand_p && !all_p && k_p == thr_p;
@@ -270,12 +311,17 @@ __global__ __launch_bounds__(1024) void rpn_sample_kernel(const float *__restric
         sure_n = cand_n && keep_neg > 0 && (all_n ? (keep_neg >= n_nc) : (k_n > thr_n));
     };
     int c_tp = 0, c_tn = 0;
-    for (int a0 = a_begin; a0 < a_end; a0 += 64) {
-        const int a = a0 + lane;
-        bool cp, cn, tp, tn, sp, sn;
-        classify(a, a < a_end, cp, cn, tp, tn, sp, sn);
-        c_tp += __popcll(__ballot(tp));
-        c_tn += __popcll(__ballot(tn));
+    for (int a4 = a_begin; a4 < a_end; a4 += 256) {
+        Loaded ld[4];
+        load4(a4, ld);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int a = a4 + 64 * u + lane;
+            bool cp, cn, tp, tn, sp, sn;
+            classify(ld[u], a < a_end, cp, cn, tp, tn, sp, sn);
+            c_tp += __popcll(__ballot(tp));
+            c_tn += __popcll(__ballot(tn));
+        }
     }
     if (lane == 0) {
         s_wcnt[0][wave] = c_tp;
@@ -291,17 +337,22 @@ __global__ __launch_bounds__(1024) void rpn_sample_kernel(const float *__restric
     int c_rows = 0;
     {
         int tp_run = seen_tp, tn_run = seen_tn;
-        for (int a0 = a_begin; a0 < a_end; a0 += 64) {
-            const int a = a0 + lane;
-            bool cp, cn, tp, tn, sp, sn;
-            classify(a, a < a_end, cp, cn, tp, tn, sp, sn);
-            const unsigned long long mtp = __ballot(tp), mtn = __ballot(tn);
-            const unsigned long long below = (1ull << lane) - 1ull;
-            const bool keep_p = sp || (tp && keep_pos > 0 && tp_run + __popcll(mtp & below) < ties_p);
-            const bool keep_n = sn || (tn && keep_neg > 0 && tn_run + __popcll(mtn & below) < ties_n);
-            tp_run += __popcll(mtp);
-            tn_run += __popcll(mtn);
-            c_rows += __popcll(__ballot(keep_p || keep_n));
+        for (int a4 = a_begin; a4 < a_end; a4 += 256) {
+            Loaded ld[4];
+            load4(a4, ld);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int a = a4 + 64 * u + lane;
+                bool cp, cn, tp, tn, sp, sn;
+                classify(ld[u], a < a_end, cp, cn, tp, tn, sp, sn);
+                const unsigned long long mtp = __ballot(tp), mtn = __ballot(tn);
+                const unsigned long long below = (1ull << lane) - 1ull;
+                const bool keep_p = sp || (tp && keep_pos > 0 && tp_run + __popcll(mtp & below) < ties_p);
+                const bool keep_n = sn || (tn && keep_neg > 0 && tn_run + __popcll(mtn & below) < ties_n);
+                tp_run += __popcll(mtp);
+                tn_run += __popcll(mtn);
+                c_rows += __popcll(__ballot(keep_p || keep_n));
+            }
         }
     }
     if (lane == 0) s_wcnt[2][wave] = c_rows;
@@ -313,39 +364,50 @@ __global__ __launch_bounds__(1024) void rpn_sample_kernel(const float *__restric
     }
     {
         int tp_run = seen_tp, tn_run = seen_tn, r_run = row_base;
-        for (int a0 = a_begin; a0 < a_end; a0 += 64) {
-            const int a = a0 + lane;
-            const bool in = a < a_end;
-            bool cp, cn, tp, tn, sp, sn;
-            classify(a, in, cp, cn, tp, tn, sp, sn);
-            const unsigned long long mtp = __ballot(tp), mtn = __ballot(tn);
-            const unsigned long long below = (1ull << lane) - 1ull;
-            const bool keep_p = sp || (tp && keep_pos > 0 && tp_run + __popcll(mtp & below) < ties_p);
-            const bool keep_n = sn || (tn && keep_neg > 0 && tn_run + __popcll(mtn & below) < ties_n);
-            tp_run += __popcll(mtp);
-            tn_run += __popcll(mtn);
-            const unsigned long long mk = __ballot(keep_p || keep_n);
-            if (in) {
-                float d[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-                if (keep_p) {
-                    const int g = (int)(ar[a] & 0x7FFFFFFFu);
-                    const float4 bx = *reinterpret_cast<const float4 *>(anchors + (size_t)a * 4);
-                    const float b4[4] = {bx.x, bx.y, bx.z, bx.w};
-                    const float *gt = gts + ((size_t)img * G + g) * 4;
-                    const float g4[4] = {gt[0], gt[1], gt[2], gt[3]};
-                    refine(b4, g4, std4.v, d);
-                }
-                *reinterpret_cast<float4 *>(deltas + ((size_t)img * A + a) * 4) = make_float4(d[0], d[1], d[2], d[3]);
-                const int pos = r_run + __popcll(mk & below);
-                if ((keep_p || keep_n) && row_image && pos < n_total) {
-                    row_image[(size_t)img * n_total + pos] = img;
-                    row_anchor[(size_t)img * n_total + pos] = a;
-                }
+        for (int a4 = a_begin; a4 < a_end; a4 += 256) {
+            Loaded ld[4];
+            load4(a4, ld);               // (before any of the four chunks' match values is replaced below)
+            unsigned ar4[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int a = a4 + 64 * u + lane;
+                ar4[u] = a < a_end ? ar[a] : 0u;
             }
-            r_run += __popcll(mk);
-            // (the final match replaces the candidate class LAST: classify() of this wavefront's later chunks and of no
-            // other wavefront reads this element)
-            if (in) mt[a] = keep_p ? 1.0f : (keep_n ? -1.0f : 0.0f);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int a = a4 + 64 * u + lane;
+                const bool in = a < a_end;
+                bool cp, cn, tp, tn, sp, sn;
+                classify(ld[u], in, cp, cn, tp, tn, sp, sn);
+                const unsigned long long mtp = __ballot(tp), mtn = __ballot(tn);
+                const unsigned long long below = (1ull << lane) - 1ull;
+                const bool keep_p = sp || (tp && keep_pos > 0 && tp_run + __popcll(mtp & below) < ties_p);
+                const bool keep_n = sn || (tn && keep_neg > 0 && tn_run + __popcll(mtn & below) < ties_n);
+                tp_run += __popcll(mtp);
+                tn_run += __popcll(mtn);
+                const unsigned long long mk = __ballot(keep_p || keep_n);
+                if (in) {
+                    float d[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                    if (keep_p) {
+                        const int g = (int)(ar4[u] & 0x7FFFFFFFu);
+                        const float4 bx = *reinterpret_cast<const float4 *>(anchors + (size_t)a * 4);
+                        const float b4[4] = {bx.x, bx.y, bx.z, bx.w};
+                        const float *gt = gts + ((size_t)img * G + g) * 4;
+                        const float g4[4] = {gt[0], gt[1], gt[2], gt[3]};
+                        refine(b4, g4, std4.v, d);
+                    }
+                    *reinterpret_cast<float4 *>(deltas + ((size_t)img * A + a) * 4) = make_float4(d[0], d[1], d[2], d[3]);
+                    const int pos = r_run + __popcll(mk & below);
+                    if ((keep_p || keep_n) && row_image && pos < n_total) {
+                        row_image[(size_t)img * n_total + pos] = img;
+                        row_anchor[(size_t)img * n_total + pos] = a;
+                    }
+                }
+                r_run += __popcll(mk);
+                // (the final match replaces the candidate class LAST: it was read into ld[] for this and the following
+                // three chunks already, and no other wavefront reads this element)
+                if (in) mt[a] = keep_p ? 1.0f : (keep_n ? -1.0f : 0.0f);
+            }
         }
     }
     if (row_image)
