@@ -52,3 +52,14 @@ FI_STATIC_DEV=1 timeout 300 python scripts/graph_probe.py --cfg5 2>&1 | grep -v 
 bash scripts/ab_dp.sh 2 "X=1" "FI_PICK_STREAMS=0" "FI_DP_BUCKET_MB=25" 2>&1 | grep -v amdgpu > $O/${R}_ab_dp_final.txt
 REP=12 bash scripts/bfp_sweep.sh ${R}
 ls -la $O | tail -40
+# round 5: BASELINE configs[3]'s per-GPU shape (2 images per GPU) on the one GPU -- the step against its exclusive conv
+# time (are the one-workgroup latency kernels of the side streams still hidden at half the conv time?) -- and its idle gaps;
+# the data-parallel preflight; the target generation alone on the chip; NCHW pyramid crop backward; LDS atomic rates
+( cd /tmp && timeout 400 python $GRAFT_REPO_ROOT/bench.py --batch-per-gpu 2 --no-cpu-baseline --no-pmc --no-dense-reference > $O/${R}_bench_2img_per_gpu.json 2>/dev/null )
+rm -rf /tmp/py; ( cd /tmp && timeout 400 rocprofv3 --kernel-trace --output-format csv -d /tmp/py -o kt -- python $GRAFT_REPO_ROOT/bench.py --batch-per-gpu 2 --steps 6 --warmup 2 --profile-steps 0 --no-cpu-baseline --no-pmc --no-dense-reference > /dev/null 2>&1 )
+f=$(find /tmp/py -name 'kt_kernel_trace.csv' | head -1); python scripts/gpu_idle.py $f > $O/${R}_gpu_idle_2img_per_gpu.txt 2>&1
+( cd /tmp && FI_DP_FORCE=1 timeout 200 python $GRAFT_REPO_ROOT/bench.py --preflight > $O/${R}_preflight_1rank_rccl.json 2>/dev/null )
+timeout 100 python scripts/rpn_target_probe.py 2>&1 | grep prepare > $O/${R}_rpn_target_probe.txt
+(timeout 100 python scripts/pyr_bwd_probe.py; FI_CROP_BWD_SCATTER=1 timeout 100 python scripts/pyr_bwd_probe.py) 2>&1 | grep NCHW > $O/${R}_pyr_bwd_probe.txt
+scripts/micro/bin/lds_atomic_rate > $O/${R}_lds_atomic_rate.txt 2>&1
+ls -la $O | tail -50
