@@ -7,6 +7,9 @@ Python with the native extension call replaced by a recorder (TEST INFRASTRUCTUR
   * `pth_nms` + `nms` (lib/nms/pth_nms.py:5-19, lib/nms/nms_wrapper.py:14-34): `_ext.nms.cpu_nms` is replaced
     by a recorder that captures the `order` / `areas` prelude and completes the call with the oracle's
     restatement of the C kernel -> areas, order, and the wrapper's int32 [bs, min_keep] result;
+  * `conduct_nms` (lib/layers.py:664-718: the per-sample half of the detection layer -- per-class NMS through the `nms`
+    wrapper on that recorder, union, top DET_MAX_INSTANCES by score, output rows) -> detections [<=100, 6] and the
+    indices of the surviving RoIs;
   * `pyramid_roi_align` (lib/layers.py:143-218): `CropAndResizeFunction` is replaced by the oracle's crop ->
     which level every RoI is sent to (tools/utils.py:50-55 `log2` + the level formula :168-181, identical to
     lib/sub_module.py:405-410), the per-level box order, and the scatter back into RoI order.
@@ -82,6 +85,17 @@ def gen():
         out["pth_nms_keep_%d" % int(t * 10)] = single.numpy().astype(np.int64)
     out["nms_order"] = np.stack([r[0] for r in rec[:3]]).astype(np.int64)
     out["nms_areas"] = np.stack([r[1] for r in rec[:3]]).astype(np.float32)
+
+    # ---- conduct_nms (detection layer, one sample at a time)
+    from types import SimpleNamespace as NS
+    dcfg = NS(TEST=NS(DET_NMS_THRESHOLD=0.3, DET_MAX_INSTANCES=100, DET_MIN_CONFIDENCE=0.5))
+    for i, (cls, boxes, scores) in enumerate(gi["det_samples"]):
+        cls_t, box_t, sc_t = torch.from_numpy(cls), torch.from_numpy(boxes), torch.from_numpy(scores)
+        area = (box_t[:, 0] - box_t[:, 2]) * (box_t[:, 1] - box_t[:, 3])
+        keep = (cls_t > 0) & (sc_t >= dcfg.TEST.DET_MIN_CONFIDENCE) & (area > 0)          # lib/layers.py:768-769
+        det, final_index = RL.conduct_nms(cls_t, box_t, sc_t, keep, dcfg)
+        out["det_rows_%d" % i] = det.numpy().astype(np.float32)
+        out["det_index_%d" % i] = final_index.numpy().astype(np.int64)
 
     # ---- pyramid_roi_align: level routing + scatter back
     calls = []

@@ -290,6 +290,18 @@ def golden_wrapper_inputs(seed=23):
     for j, s in enumerate(side):
         rois[0, j] = [0.0, 0.0, s, s]
         rois[1, j] = np.clip([0.3, 0.2, 0.3 + s / 2, 0.2 + 2 * s], 0, 1)
+    # (d) detection layer, per sample: integer pixel boxes, top class and its score per RoI (conduct_nms's inputs)
+    det = []
+    for n_roi, n_cls, lo in ((400, 6, 0.2), (120, 8, 0.45)):           # > 100 survivors / fewer than 100 (every class keeps >= 2 boxes:
+                                                                        # the reference indexes a 1-element class as a scalar and fails)
+        cls = rs.randint(0, n_cls, n_roi).astype(np.int64)
+        y1x1 = rs.randint(0, 200, (n_roi, 2))
+        hw = rs.randint(1, 56, (n_roi, 2))
+        hw[::17] = 0                                                    # zero-area boxes (filtered)
+        boxes = np.concatenate([y1x1, y1x1 + hw], 1).astype(f)
+        scores = (lo + (1 - lo) * (rs.permutation(n_roi) + 0.5) / n_roi).astype(f)      # unique
+        det.append((cls, boxes, scores))
+    out["det_samples"] = det
     out["pyr_maps"] = maps
     out["pyr_rois"] = rois.astype(f)
     out["pyr_image_shape"] = (1024, 1024, 3)

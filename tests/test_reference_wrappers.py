@@ -131,3 +131,31 @@ def test_pyramid_crop_equals_the_reference_pyramid_roi_align(gold, gi, channels_
     for pool in (7, 14):
         got = pyramid_crop_and_resize(maps, rois.reshape(-1, 4), box_ind, level.reshape(-1), pool, pool).cpu().numpy()
         assert np.array_equal(_bits(got), _bits(gold["pyr_pooled_%d" % pool]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sample", [0, 1])
+def test_detection_layer_returns_what_the_reference_conduct_nms_returned(gold, gi, sample):
+    """detection_layer (one sorted NMS launch per image with class-offset boxes, no host synchronisation) against the
+    reference's per-sample conduct_nms (lib/layers.py:664-718: a python loop over the classes present, each through the
+    `nms` wrapper), run by oracle/gen_golden_wrappers.py: the same rows in the same order -- boxes, class ids, scores --
+    and, through `feature`, the same surviving RoI indices; zero padded to DET_MAX_INSTANCES."""
+    from types import SimpleNamespace as NS
+    from feature_intertwiner_amd.layers import detection_layer
+    cls, boxes, scores = gi["det_samples"][sample]
+    N, K, S = len(cls), 81, 256.0
+    probs = np.full((N, K), 0.001, np.float32)
+    probs[np.arange(N), cls] = scores                       # arg max = the class, max = the score
+    cfg = NS(TEST=NS(DET_NMS_THRESHOLD=0.3, DET_MAX_INSTANCES=100, DET_MIN_CONFIDENCE=0.5),
+             DATA=NS(IMAGE_SHAPE=np.array([256, 256, 3]), BBOX_STD_DEV=np.array([0.1, 0.1, 0.2, 0.2], np.float32)))
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    feat = np.arange(N, dtype=np.float32).reshape(N, 1) + 1.0           # row id + 1 (0 = padding)
+    det, out_feat = detection_layer(T((boxes / S).reshape(1, N, 4)), T(probs), T(np.zeros((N, K, 4), np.float32)),
+                                    T(np.array([[0, 0, S, S]], np.float32)), cfg, feature=T(feat))
+    det, out_feat = det.cpu().numpy()[0], out_feat.cpu().numpy()[0, :, 0]
+    exp, idx = gold["det_rows_%d" % sample], gold["det_index_%d" % sample]
+    n = exp.shape[0]
+    assert det.shape == (100, 6) and n <= 100
+    assert np.array_equal(det[:n], exp), np.abs(det[:n] - exp).max()
+    assert np.all(det[n:] == 0)
+    assert np.array_equal(out_feat[:n], idx.astype(np.float32) + 1.0) and np.all(out_feat[n:] == 0)
