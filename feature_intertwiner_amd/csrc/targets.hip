@@ -103,8 +103,12 @@ __global__ __launch_bounds__(256) void rpn_iou_kernel(const float *__restrict__ 
         arg[(size_t)img * A + a] = (unsigned)bi | (crowd < 0.001f ? 0u : 0x80000000u);
     }
     __syncthreads();
+    // one global atomic per (workgroup, GT) whose best key can still win: a key with zero IoU bits only competes on the
+    // anchor index, and the lowest anchor of the image sits in workgroup 0 (1023 workgroups x 20 GTs of 64-bit
+    // atomicMax on 20 addresses per image were most of this kernel's 236 us)
     for (int g = threadIdx.x; g < G; g += 256)
-        if (s_kind[g] == 1) atomicMax(&gt_best[(size_t)img * G + g], s_best[g]);
+        if (s_kind[g] == 1 && ((s_best[g] >> 32) != 0ull || blockIdx.x == 0))
+            atomicMax(&gt_best[(size_t)img * G + g], s_best[g]);
 }
 
 // block-wide exclusive prefix of a flag in thread order (1024 threads = 16 wavefronts); returns the prefix and, in
@@ -128,55 +132,81 @@ __device__ __forceinline__ int block_prefix(bool flag, int *s_w, int *total)
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// RPN targets, phase 2 (one 1024-thread workgroup per image): candidate classes, the two random sub-samples (exact
-// selection of the k largest 23-bit keys: two histogram passes + an ordered tie pass), match / deltas / compact rows
+// RPN targets, phase 2, as SEVEN small launches of kSampleWGs workgroups per image (round 5; rounds 2-4: one
+// 1024-thread workgroup per image walked the 261 888 anchors five times -- 1.4 ms, issue bound on ONE compute unit):
+// candidate classes, the two random sub-samples (exact selection of the k largest 23-bit keys: two histogram passes
+// + an ordered tie pass), match / deltas / compact rows.  The state between the launches lives in the workspace
+// (SampleState per image, cleared by the entry point): the histograms are accumulated in LDS per workgroup and added
+// to the image's with integer atomics, the ordered passes keep the per-WAVEFRONT counts (every wavefront of every
+// workgroup owns a contiguous range of anchors, in anchor order), so the results -- which anchors are kept, the row
+// order -- are what the one-workgroup kernel produced, bit for bit.
 // ------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void rpn_sample_kernel(const float *__restrict__ anchors, const long *__restrict__ ids,
-                                                          const float *__restrict__ gts,
-                                                          const float *__restrict__ key_pos,
-                                                          const float *__restrict__ key_neg, int A, int G, float neg_thres,
-                                                          float pos_thres, int n_total, Std4 std4,
-                                                          const float *__restrict__ iou_max,
-                                                          const unsigned *__restrict__ arg,
-                                                          const unsigned long long *__restrict__ gt_best,
-                                                          float *__restrict__ match, float *__restrict__ deltas,
-                                                          long *__restrict__ row_image, long *__restrict__ row_anchor)
+constexpr int kSampleWGs = 16;                       // workgroups per image
+constexpr int kSampleWaves = kSampleWGs * 16;        // wavefronts per image: the units of the ordered passes
+
+struct SampleState {
+    unsigned hist_hi[2][4096];
+    unsigned hist_lo[2][4096];
+    int cnt[2];                                      // candidates per class (positive, negative)
+    int keep[2];                                     // how many of them are kept
+    unsigned sel[2][3];                              // high bucket (0xFFFFFFFF: all / none), threshold key, ties to keep
+    int wcnt[3][kSampleWaves];                       // per wavefront: ties (pos), ties (neg), kept rows
+};
+
+struct SampleArgs {
+    const float *anchors;
+    const long *ids;
+    const float *gts, *key_pos, *key_neg;
+    int A, G;
+    float neg_thres, pos_thres;
+    int n_total;
+    Std4 std4;
+    const float *iou_max;
+    const unsigned *arg;
+    const unsigned long long *gt_best;
+    float *match, *deltas;
+    long *row_image, *row_anchor;
+    SampleState *state;
+};
+
+__device__ __forceinline__ int sample_per_wave(int A) { return ((A + kSampleWaves - 1) / kSampleWaves + 63) / 64 * 64; }
+
+// launch 1: candidate class of every anchor (written to `match`), counts, histogram of the keys' high 12 bits
+__global__ __launch_bounds__(1024) void rpn_cand_kernel(SampleArgs p)
 {
     __shared__ unsigned s_hist[2][4096];
     __shared__ int s_claim[kMaxGT];
     __shared__ int s_nclaim;
     __shared__ int s_cnt[2];
-    __shared__ unsigned s_sel[2][3];                   // per class: high bucket, quota inside it; then threshold key, ties to keep
-    const int img = blockIdx.x;
-    const int tid = threadIdx.x;
-    const float *__restrict__ im = iou_max + (size_t)img * A;
-    const unsigned *__restrict__ ar = arg + (size_t)img * A;
-    const float *__restrict__ kp = key_pos + (size_t)img * A;
-    const float *__restrict__ kn = key_neg + (size_t)img * A;
-    float *__restrict__ mt = match + (size_t)img * A;
-
+    const int img = blockIdx.y, tid = threadIdx.x;
+    const int A = p.A;
+    const float *__restrict__ im = p.iou_max + (size_t)img * A;
+    const unsigned *__restrict__ ar = p.arg + (size_t)img * A;
+    const float *__restrict__ kp = p.key_pos + (size_t)img * A;
+    const float *__restrict__ kn = p.key_neg + (size_t)img * A;
+    float *__restrict__ mt = p.match + (size_t)img * A;
+    SampleState *__restrict__ st = p.state + img;
     for (int i = tid; i < 2 * 4096; i += 1024) (&s_hist[0][0])[i] = 0u;
     if (tid == 0) {
         int n = 0;
-        for (int g = 0; g < G; ++g)
-            if (ids[(size_t)img * G + g] > 0) s_claim[n++] = (int)(0xFFFFFFFFu - (unsigned)(gt_best[(size_t)img * G + g] & 0xFFFFFFFFull));
+        for (int g = 0; g < p.G; ++g)
+            if (p.ids[(size_t)img * p.G + g] > 0)
+                s_claim[n++] = (int)(0xFFFFFFFFu - (unsigned)(p.gt_best[(size_t)img * p.G + g] & 0xFFFFFFFFull));
         s_nclaim = n;
         s_cnt[0] = s_cnt[1] = 0;
     }
     __syncthreads();
     const int nclaim = s_nclaim;
-
-    // pass 1: candidate class of every anchor (written to `match`), counts, histogram of the keys' high 12 bits
+    const int per_wg = sample_per_wave(A) * 16;
+    const int a_lo = blockIdx.x * per_wg, a_hi = min(A, a_lo + per_wg);
     int c_pos = 0, c_neg = 0;
-    // (4 anchors per thread and iteration, their loads issued together: the kernel is ONE workgroup per image walking
-    // 261 888 anchors five times -- its time is memory latency per iteration, round 4: 1.6-4.0 ms)
-    for (int a0 = tid; a0 < A; a0 += 4096) {
+    for (int a0 = a_lo + tid; a0 < a_hi; a0 += 4096) {
         float v4[4], kp4[4], kn4[4];
         unsigned ar4[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int a = a0 + 1024 * u;
-            const bool in = a < A;
+            const bool in = a < a_hi;
             v4[u] = in ? im[a] : 0.0f;
             ar4[u] = in ? ar[a] : 0u;
             kp4[u] = in ? kp[a] : 1.0f;
@@ -185,12 +215,12 @@ __global__ __launch_bounds__(1024) void rpn_sample_kernel(const float *__restric
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int a = a0 + 1024 * u;
-            if (a >= A) break;
+            if (a >= a_hi) break;
             const float v = v4[u];
-            float m = (v < neg_thres && !(ar4[u] & 0x80000000u)) ? -1.0f : 0.0f;
+            float m = (v < p.neg_thres && !(ar4[u] & 0x80000000u)) ? -1.0f : 0.0f;
             bool claimed = false;
             for (int g = 0; g < nclaim; ++g) claimed = claimed || (s_claim[g] == a);
-            if (claimed || v >= pos_thres) m = 1.0f;
+            if (claimed || v >= p.pos_thres) m = 1.0f;
             mt[a] = m;
             if (m > 0.0f) {
                 ++c_pos;
@@ -201,93 +231,153 @@ __global__ __launch_bounds__(1024) void rpn_sample_kernel(const float *__restric
             }
         }
     }
-    atomicAdd(&s_cnt[0], c_pos);
-    atomicAdd(&s_cnt[1], c_neg);
+    if (c_pos) atomicAdd(&s_cnt[0], c_pos);
+    if (c_neg) atomicAdd(&s_cnt[1], c_neg);
     __syncthreads();
-    const int n_pc = s_cnt[0], n_nc = s_cnt[1];
+    for (int i = tid; i < 2 * 4096; i += 1024) {
+        const unsigned c = (&s_hist[0][0])[i];
+        if (c) atomicAdd(&st->hist_hi[0][0] + i, c);
+    }
+    if (tid < 2 && s_cnt[tid]) atomicAdd(&st->cnt[tid], s_cnt[tid]);
+}
+
+// The bin (scanning from the top) that holds the quota-th largest entry of a 4096-bin histogram, and how many entries of
+// that bin are wanted: 64 threads sum 64 bins each, one thread walks the 64 sums and then the bin's 64 counts.
+__device__ __forceinline__ void pick_bin(const unsigned *__restrict__ hist, int quota, unsigned *s_part, int tid64,
+                                         unsigned *bin, unsigned *rest)
+{
+    unsigned sum = 0;
+    for (int i = 0; i < 64; ++i) sum += hist[4095 - (tid64 * 64 + i)];       // chunk tid64: bins 4095 - 64 t .. down
+    s_part[tid64] = sum;
+    __syncthreads();
+    if (tid64 == 0) {
+        int acc = 0, c = 0;
+        for (; c < 64; ++c) {
+            if (acc + (int)s_part[c] >= quota) break;
+            acc += (int)s_part[c];
+        }
+        unsigned b = 0, r = 0;
+        if (c < 64) {
+            for (int i = 0; i < 64; ++i) {
+                const int h = 4095 - (c * 64 + i);
+                const int n = (int)hist[h];
+                if (acc + n >= quota) {
+                    b = (unsigned)h;
+                    r = (unsigned)(quota - acc);
+                    break;
+                }
+                acc += n;
+            }
+        }
+        *bin = b;
+        *rest = r;
+    }
+    __syncthreads();
+}
+
+// launches 2 and 4 (one 128-thread workgroup per image; threads 0..63: positives, 64..127: negatives)
+template <bool LOW>
+__global__ __launch_bounds__(128) void rpn_pick_kernel(SampleState *__restrict__ state, int n_total)
+{
+    __shared__ unsigned s_part[2][64];
+    __shared__ unsigned s_out[2][2];
+    SampleState *__restrict__ st = state + blockIdx.x;
+    const int cls = threadIdx.x >> 6, t64 = threadIdx.x & 63;
+    const int n_pc = st->cnt[0], n_nc = st->cnt[1];
     const int keep_pos = min(n_pc, n_total / 2);
     const int keep_neg = min(n_nc, max(n_total - keep_pos, 0));
-    // the high bucket that holds the keep-th largest key (scanning from the top), per class
-    if (tid < 2) {
-        const int keep = tid == 0 ? keep_pos : keep_neg;
-        const int have = tid == 0 ? n_pc : n_nc;
-        unsigned bucket = 0xFFFFFFFFu, quota = 0;          // bucket 0xFFFFFFFF: everything is kept / nothing is
-        if (keep > 0 && keep < have) {
-            int acc = 0;
-            for (int h = 4095; h >= 0; --h) {
-                const int c = (int)s_hist[tid][h];
-                if (acc + c >= keep) {
-                    bucket = (unsigned)h;
-                    quota = (unsigned)(keep - acc);        // 1 .. c of this bucket's candidates are kept
-                    break;
-                }
-                acc += c;
-            }
+    const int keep = cls == 0 ? keep_pos : keep_neg, have = cls == 0 ? n_pc : n_nc;
+    if (!LOW) {
+        const bool scan = keep > 0 && keep < have;                       // otherwise everything is kept / nothing is
+        unsigned b = 0, r = 0;
+        // (both halves of the workgroup reach the barriers inside pick_bin: a quota of 1 << 30 finds no bin)
+        pick_bin(st->hist_hi[cls], scan ? keep : (1 << 30), s_part[cls], t64, &s_out[cls][0], &s_out[cls][1]);
+        if (t64 == 0) {
+            b = scan ? s_out[cls][0] : 0xFFFFFFFFu;
+            r = scan ? s_out[cls][1] : 0u;
+            st->sel[cls][0] = b;
+            st->sel[cls][1] = r;                                         // quota inside the bucket (launch 4 reads it)
+            st->keep[cls] = keep;
         }
-        s_sel[tid][0] = bucket;
-        s_sel[tid][1] = quota;
+    } else {
+        const unsigned bucket = st->sel[cls][0];
+        const int quota = (int)st->sel[cls][1];
+        pick_bin(st->hist_lo[cls], bucket != 0xFFFFFFFFu ? quota : (1 << 30), s_part[cls], t64, &s_out[cls][0], &s_out[cls][1]);
+        if (t64 == 0) {
+            st->sel[cls][1] = bucket != 0xFFFFFFFFu ? ((bucket << 12) | s_out[cls][0]) : 0u;      // threshold key
+            st->sel[cls][2] = bucket != 0xFFFFFFFFu ? s_out[cls][1] : 0u;                           // ties to keep
+        }
     }
-    __syncthreads();
-    const unsigned bk_p = s_sel[0][0], bk_n = s_sel[1][0];
-    // pass 2: histogram of the low 12 bits inside the threshold buckets
+}
+
+// launch 3: histogram of the low 12 bits inside the threshold buckets
+__global__ __launch_bounds__(1024) void rpn_hist_lo_kernel(SampleArgs p)
+{
+    __shared__ unsigned s_hist[2][4096];
+    const int img = blockIdx.y, tid = threadIdx.x;
+    const int A = p.A;
+    SampleState *__restrict__ st = p.state + img;
+    const unsigned bk_p = st->sel[0][0], bk_n = st->sel[1][0];
+    if (bk_p == 0xFFFFFFFFu && bk_n == 0xFFFFFFFFu) return;
+    const float *__restrict__ kp = p.key_pos + (size_t)img * A;
+    const float *__restrict__ kn = p.key_neg + (size_t)img * A;
+    const float *__restrict__ mt = p.match + (size_t)img * A;
     for (int i = tid; i < 2 * 4096; i += 1024) (&s_hist[0][0])[i] = 0u;
     __syncthreads();
-    if (bk_p != 0xFFFFFFFFu || bk_n != 0xFFFFFFFFu) {
-        for (int a0 = tid; a0 < A; a0 += 4096) {
-            float m4[4], kp4[4], kn4[4];
+    const int per_wg = sample_per_wave(A) * 16;
+    const int a_lo = blockIdx.x * per_wg, a_hi = min(A, a_lo + per_wg);
+    for (int a0 = a_lo + tid; a0 < a_hi; a0 += 4096) {
+        float m4[4], kp4[4], kn4[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int a = a0 + 1024 * u;
-                const bool in = a < A;
-                m4[u] = in ? mt[a] : 0.0f;
-                kp4[u] = in ? kp[a] : 1.0f;
-                kn4[u] = in ? kn[a] : 1.0f;
-            }
+        for (int u = 0; u < 4; ++u) {
+            const int a = a0 + 1024 * u;
+            const bool in = a < a_hi;
+            m4[u] = in ? mt[a] : 0.0f;
+            kp4[u] = in ? kp[a] : 1.0f;
+            kn4[u] = in ? kn[a] : 1.0f;
+        }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const float m = m4[u];
-                if (m > 0.0f && bk_p != 0xFFFFFFFFu) {
-                    const unsigned k = key_of(kp4[u]);
-                    if ((k >> 12) == bk_p) atomicAdd(&s_hist[0][k & 4095u], 1u);
-                } else if (m < 0.0f && bk_n != 0xFFFFFFFFu) {
-                    const unsigned k = key_of(kn4[u]);
-                    if ((k >> 12) == bk_n) atomicAdd(&s_hist[1][k & 4095u], 1u);
-                }
+        for (int u = 0; u < 4; ++u) {
+            const float m = m4[u];
+            if (m > 0.0f && bk_p != 0xFFFFFFFFu) {
+                const unsigned k = key_of(kp4[u]);
+                if ((k >> 12) == bk_p) atomicAdd(&s_hist[0][k & 4095u], 1u);
+            } else if (m < 0.0f && bk_n != 0xFFFFFFFFu) {
+                const unsigned k = key_of(kn4[u]);
+                if ((k >> 12) == bk_n) atomicAdd(&s_hist[1][k & 4095u], 1u);
             }
         }
     }
     __syncthreads();
-    if (tid < 2) {
-        const unsigned bucket = s_sel[tid][0];
-        unsigned thr = 0, ties = 0;                        // keep keys > thr, and the first `ties` keys == thr
-        if (bucket != 0xFFFFFFFFu) {
-            const int quota = (int)s_sel[tid][1];
-            int acc = 0;
-            for (int l = 4095; l >= 0; --l) {
-                const int c = (int)s_hist[tid][l];
-                if (acc + c >= quota) {
-                    thr = (bucket << 12) | (unsigned)l;
-                    ties = (unsigned)(quota - acc);
-                    break;
-                }
-                acc += c;
-            }
-        }
-        s_sel[tid][1] = thr;
-        s_sel[tid][2] = ties;
+    for (int i = tid; i < 2 * 4096; i += 1024) {
+        const unsigned c = (&s_hist[0][0])[i];
+        if (c) atomicAdd(&st->hist_lo[0][0] + i, c);
     }
-    __syncthreads();
-    const bool all_p = bk_p == 0xFFFFFFFFu, all_n = bk_n == 0xFFFFFFFFu;
-    const unsigned thr_p = s_sel[0][1], thr_n = s_sel[1][1];
-    const int ties_p = (int)s_sel[0][2], ties_n = (int)s_sel[1][2];
-    // pass 3, in anchor order: final match, refinements of the kept positives, compact (image, anchor) rows.  Ties at a
-    // selection boundary and the row positions need ORDERED counts: every wavefront owns a contiguous range of anchors
-    // (walked 64 at a time, coalesced), counts its ties / kept anchors in a first sweep, the 16 counts are scanned once,
-    // and a second sweep assigns ranks with wavefront ballots only -- no barrier inside the loops.
-    __shared__ int s_wcnt[3][16];
+}
+
+// launches 5-7, in anchor order: ties at a selection boundary and the row positions need ORDERED counts.  PASS 0 counts
+// every wavefront's ties, PASS 1 (knowing the ties in front of it) its kept rows, PASS 2 (knowing both) writes the final
+// match, the refinements of the kept positives and the compact (image, anchor) rows.
+template <int PASS>
+__global__ __launch_bounds__(1024) void rpn_order_kernel(SampleArgs p)
+{
+    const int img = blockIdx.y, tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    const int per_wave = ((A + 15) / 16 + 63) / 64 * 64;
-    const int a_begin = wave * per_wave, a_end = min(A, a_begin + per_wave);
+    const int gw = blockIdx.x * 16 + wave;                     // this wavefront among the image's kSampleWaves
+    const int A = p.A, n_total = p.n_total;
+    SampleState *__restrict__ st = p.state + img;
+    const float *__restrict__ kp = p.key_pos + (size_t)img * A;
+    const float *__restrict__ kn = p.key_neg + (size_t)img * A;
+    const unsigned *__restrict__ ar = p.arg + (size_t)img * A;
+    float *__restrict__ mt = p.match + (size_t)img * A;
+    const int n_pc = st->cnt[0], n_nc = st->cnt[1];
+    const int keep_pos = st->keep[0], keep_neg = st->keep[1];
+    const bool all_p = st->sel[0][0] == 0xFFFFFFFFu, all_n = st->sel[1][0] == 0xFFFFFFFFu;
+    const unsigned thr_p = st->sel[0][1], thr_n = st->sel[1][1];
+    const int ties_p = (int)st->sel[0][2], ties_n = (int)st->sel[1][2];
+    const int per_wave = sample_per_wave(A);
+    const int a_begin = min(A, gw * per_wave), a_end = min(A, a_begin + per_wave);
+
     struct Loaded { float m, kp, kn; };
     auto load4 = [&](int a0, Loaded (&v)[4]) {               // the next four 64-anchor chunks of this wavefront: 12 loads in flight
 #pragma unroll
@@ -299,121 +389,115 @@ __global__ __launch_bounds__(1024) void rpn_sample_kernel(const float *__restric
             v[u].kn = in ? kn[a] : 1.0f;
         }
     };
-    auto classify = [&](const Loaded &v, bool in, bool &cand_p, bool &cand_n, bool &tie_p, bool &tie_n, bool &sure_p, bool &sure_n) {
+    auto classify = [&](const Loaded &v, bool in, bool &tie_p, bool &tie_n, bool &sure_p, bool &sure_n) {
         const float m = in ? v.m : 0.0f;
         const unsigned k_p = in ? key_of(v.kp) : 0u;
         const unsigned k_n = in ? key_of(v.kn) : 0u;
-        cand_p = m > 0.0f;
-        cand_n = m < 0.0f;
+        const bool cand_p = m > 0.0f, cand_n = m < 0.0f;
         tie_p = cand_p && !all_p && k_p == thr_p;
         tie_n = cand_n && !all_n && k_n == thr_n;
         sure_p = cand_p && keep_pos > 0 && (all_p ? (keep_pos >= n_pc) : (k_p > thr_p));
         sure_n = cand_n && keep_neg > 0 && (all_n ? (keep_neg >= n_nc) : (k_n > thr_n));
     };
-    int c_tp = 0, c_tn = 0;
-    for (int a4 = a_begin; a4 < a_end; a4 += 256) {
-        Loaded ld[4];
-        load4(a4, ld);
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int a = a4 + 64 * u + lane;
-            bool cp, cn, tp, tn, sp, sn;
-            classify(ld[u], a < a_end, cp, cn, tp, tn, sp, sn);
-            c_tp += __popcll(__ballot(tp));
-            c_tn += __popcll(__ballot(tn));
-        }
-    }
-    if (lane == 0) {
-        s_wcnt[0][wave] = c_tp;
-        s_wcnt[1][wave] = c_tn;
-    }
-    __syncthreads();
-    int seen_tp = 0, seen_tn = 0;
-    for (int w = 0; w < wave; ++w) {
-        seen_tp += s_wcnt[0][w];
-        seen_tn += s_wcnt[1][w];
-    }
-    // second sweep: the kept flags are now decidable; count the rows per wavefront first (third counter), then write
-    int c_rows = 0;
-    {
-        int tp_run = seen_tp, tn_run = seen_tn;
+    if (PASS == 0) {
+        int c_tp = 0, c_tn = 0;
         for (int a4 = a_begin; a4 < a_end; a4 += 256) {
             Loaded ld[4];
             load4(a4, ld);
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int a = a4 + 64 * u + lane;
-                bool cp, cn, tp, tn, sp, sn;
-                classify(ld[u], a < a_end, cp, cn, tp, tn, sp, sn);
-                const unsigned long long mtp = __ballot(tp), mtn = __ballot(tn);
-                const unsigned long long below = (1ull << lane) - 1ull;
-                const bool keep_p = sp || (tp && keep_pos > 0 && tp_run + __popcll(mtp & below) < ties_p);
-                const bool keep_n = sn || (tn && keep_neg > 0 && tn_run + __popcll(mtn & below) < ties_n);
-                tp_run += __popcll(mtp);
-                tn_run += __popcll(mtn);
-                c_rows += __popcll(__ballot(keep_p || keep_n));
+                bool tp, tn, sp, sn;
+                classify(ld[u], a4 + 64 * u + lane < a_end, tp, tn, sp, sn);
+                c_tp += __popcll(__ballot(tp));
+                c_tn += __popcll(__ballot(tn));
             }
         }
+        if (lane == 0) {
+            st->wcnt[0][gw] = c_tp;
+            st->wcnt[1][gw] = c_tn;
+        }
+        return;
     }
-    if (lane == 0) s_wcnt[2][wave] = c_rows;
-    __syncthreads();
-    int rows = 0, row_base = 0;
-    for (int w = 0; w < 16; ++w) {
-        row_base += w < wave ? s_wcnt[2][w] : 0;
-        rows += s_wcnt[2][w];
+    // ties in front of this wavefront (and, PASS 2, rows in front of it / in total): lanes sum the per-wavefront counts
+    int seen_tp = 0, seen_tn = 0, row_base = 0, rows = 0;
+    for (int w = lane; w < kSampleWaves; w += 64) {
+        if (w < gw) {
+            seen_tp += st->wcnt[0][w];
+            seen_tn += st->wcnt[1][w];
+        }
+        if (PASS == 2) {
+            const int r = st->wcnt[2][w];
+            rows += r;
+            if (w < gw) row_base += r;
+        }
     }
-    {
-        int tp_run = seen_tp, tn_run = seen_tn, r_run = row_base;
-        for (int a4 = a_begin; a4 < a_end; a4 += 256) {
-            Loaded ld[4];
-            load4(a4, ld);               // (before any of the four chunks' match values is replaced below)
-            unsigned ar4[4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        seen_tp += __shfl_xor(seen_tp, o);
+        seen_tn += __shfl_xor(seen_tn, o);
+        row_base += __shfl_xor(row_base, o);
+        rows += __shfl_xor(rows, o);
+    }
+    int tp_run = seen_tp, tn_run = seen_tn, r_run = row_base, c_rows = 0;
+    for (int a4 = a_begin; a4 < a_end; a4 += 256) {
+        Loaded ld[4];
+        load4(a4, ld);               // (before any of the four chunks' match values is replaced below)
+        unsigned ar4[4];
+        if (PASS == 2) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int a = a4 + 64 * u + lane;
                 ar4[u] = a < a_end ? ar[a] : 0u;
             }
+        }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int a = a4 + 64 * u + lane;
-                const bool in = a < a_end;
-                bool cp, cn, tp, tn, sp, sn;
-                classify(ld[u], in, cp, cn, tp, tn, sp, sn);
-                const unsigned long long mtp = __ballot(tp), mtn = __ballot(tn);
-                const unsigned long long below = (1ull << lane) - 1ull;
-                const bool keep_p = sp || (tp && keep_pos > 0 && tp_run + __popcll(mtp & below) < ties_p);
-                const bool keep_n = sn || (tn && keep_neg > 0 && tn_run + __popcll(mtn & below) < ties_n);
-                tp_run += __popcll(mtp);
-                tn_run += __popcll(mtn);
-                const unsigned long long mk = __ballot(keep_p || keep_n);
-                if (in) {
-                    float d[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-                    if (keep_p) {
-                        const int g = (int)(ar4[u] & 0x7FFFFFFFu);
-                        const float4 bx = *reinterpret_cast<const float4 *>(anchors + (size_t)a * 4);
-                        const float b4[4] = {bx.x, bx.y, bx.z, bx.w};
-                        const float *gt = gts + ((size_t)img * G + g) * 4;
-                        const float g4[4] = {gt[0], gt[1], gt[2], gt[3]};
-                        refine(b4, g4, std4.v, d);
-                    }
-                    *reinterpret_cast<float4 *>(deltas + ((size_t)img * A + a) * 4) = make_float4(d[0], d[1], d[2], d[3]);
-                    const int pos = r_run + __popcll(mk & below);
-                    if ((keep_p || keep_n) && row_image && pos < n_total) {
-                        row_image[(size_t)img * n_total + pos] = img;
-                        row_anchor[(size_t)img * n_total + pos] = a;
-                    }
+        for (int u = 0; u < 4; ++u) {
+            const int a = a4 + 64 * u + lane;
+            const bool in = a < a_end;
+            bool tp, tn, sp, sn;
+            classify(ld[u], in, tp, tn, sp, sn);
+            const unsigned long long mtp = __ballot(tp), mtn = __ballot(tn);
+            const unsigned long long below = (1ull << lane) - 1ull;
+            const bool keep_p = sp || (tp && keep_pos > 0 && tp_run + __popcll(mtp & below) < ties_p);
+            const bool keep_n = sn || (tn && keep_neg > 0 && tn_run + __popcll(mtn & below) < ties_n);
+            tp_run += __popcll(mtp);
+            tn_run += __popcll(mtn);
+            const unsigned long long mk = __ballot(keep_p || keep_n);
+            if (PASS == 1) {
+                c_rows += __popcll(mk);
+                continue;
+            }
+            if (in) {
+                float d[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                if (keep_p) {
+                    const int g = (int)(ar4[u] & 0x7FFFFFFFu);
+                    const float4 bx = *reinterpret_cast<const float4 *>(p.anchors + (size_t)a * 4);
+                    const float b4[4] = {bx.x, bx.y, bx.z, bx.w};
+                    const float *gt = p.gts + ((size_t)img * p.G + g) * 4;
+                    const float g4[4] = {gt[0], gt[1], gt[2], gt[3]};
+                    refine(b4, g4, p.std4.v, d);
                 }
-                r_run += __popcll(mk);
+                *reinterpret_cast<float4 *>(p.deltas + ((size_t)img * A + a) * 4) = make_float4(d[0], d[1], d[2], d[3]);
+                const int pos = r_run + __popcll(mk & below);
+                if ((keep_p || keep_n) && p.row_image && pos < n_total) {
+                    p.row_image[(size_t)img * n_total + pos] = img;
+                    p.row_anchor[(size_t)img * n_total + pos] = a;
+                }
                 // (the final match replaces the candidate class LAST: it was read into ld[] for this and the following
                 // three chunks already, and no other wavefront reads this element)
-                if (in) mt[a] = keep_p ? 1.0f : (keep_n ? -1.0f : 0.0f);
+                mt[a] = keep_p ? 1.0f : (keep_n ? -1.0f : 0.0f);
             }
+            r_run += __popcll(mk);
         }
     }
-    if (row_image)
+    if (PASS == 1) {
+        if (lane == 0) st->wcnt[2][gw] = c_rows;
+        return;
+    }
+    if (p.row_image && blockIdx.x == 0)
         for (int r = rows + tid; r < n_total; r += 1024) {
-            row_image[(size_t)img * n_total + r] = -1;
-            row_anchor[(size_t)img * n_total + r] = -1;
+            p.row_image[(size_t)img * n_total + r] = -1;
+            p.row_anchor[(size_t)img * n_total + r] = -1;
         }
 }
 
@@ -551,7 +635,9 @@ extern "C" {
 
 size_t fi_rpn_targets_workspace_bytes(int batch, int anchors, int max_gt)
 {
-    return (size_t)batch * anchors * 8 + (size_t)batch * max_gt * 8 + 64;
+    // iou_max + arg per anchor, gt_best per GT, the sampling state per image (SampleState)
+    return (((size_t)batch * anchors * 8 + 15) / 16) * 16 + (((size_t)batch * max_gt * 8 + 15) / 16) * 16 +
+           (size_t)batch * sizeof(SampleState) + 64;
 }
 
 int fi_rpn_targets(const float *anchors, const int64_t *gt_class_ids, const float *gt_boxes, const float *key_pos,
@@ -576,10 +662,20 @@ int fi_rpn_targets(const float *anchors, const int64_t *gt_class_ids, const floa
     for (int k = 0; k < 4; ++k) s4.v[k] = bbox_std_dev[k];
     hipLaunchKernelGGL(rpn_iou_kernel, dim3(fi::ceil_div(n_anchors, 256), batch), dim3(256), 0, st, anchors,
                        reinterpret_cast<const long *>(gt_class_ids), gt_boxes, n_anchors, max_gt, iou_max, arg, gt_best);
-    hipLaunchKernelGGL(rpn_sample_kernel, dim3(batch), dim3(1024), 0, st, anchors,
-                       reinterpret_cast<const long *>(gt_class_ids), gt_boxes, key_pos, key_neg, n_anchors, max_gt, neg_thres,
-                       pos_thres, n_total, s4, iou_max, arg, gt_best, match, deltas, reinterpret_cast<long *>(row_image),
-                       reinterpret_cast<long *>(row_anchor));
+    SampleState *state = reinterpret_cast<SampleState *>(reinterpret_cast<char *>(gt_best) +
+                                                         (((size_t)batch * max_gt * 8 + 15) / 16) * 16);
+    FI_HIP_CHECK(hipMemsetAsync(state, 0, (size_t)batch * sizeof(SampleState), st));
+    SampleArgs sa = {anchors, reinterpret_cast<const long *>(gt_class_ids), gt_boxes, key_pos, key_neg, n_anchors, max_gt,
+                     neg_thres, pos_thres, n_total, s4, iou_max, arg, gt_best, match, deltas,
+                     reinterpret_cast<long *>(row_image), reinterpret_cast<long *>(row_anchor), state};
+    const dim3 grid(kSampleWGs, batch);
+    hipLaunchKernelGGL(rpn_cand_kernel, grid, dim3(1024), 0, st, sa);
+    hipLaunchKernelGGL(rpn_pick_kernel<false>, dim3(batch), dim3(128), 0, st, state, n_total);
+    hipLaunchKernelGGL(rpn_hist_lo_kernel, grid, dim3(1024), 0, st, sa);
+    hipLaunchKernelGGL(rpn_pick_kernel<true>, dim3(batch), dim3(128), 0, st, state, n_total);
+    hipLaunchKernelGGL(rpn_order_kernel<0>, grid, dim3(1024), 0, st, sa);
+    hipLaunchKernelGGL(rpn_order_kernel<1>, grid, dim3(1024), 0, st, sa);
+    hipLaunchKernelGGL(rpn_order_kernel<2>, grid, dim3(1024), 0, st, sa);
     FI_HIP_CHECK(hipGetLastError());
     return FI_OK;
 }
