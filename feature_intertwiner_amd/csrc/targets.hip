@@ -75,7 +75,10 @@ __global__ __launch_bounds__(256) void rpn_iou_kernel(const float *__restrict__ 
         const long c = ids[(size_t)img * G + g];
         s_kind[g] = c > 0 ? 1 : (c < 0 ? -1 : 0);
         for (int k = 0; k < 4; ++k) s_gt[g][k] = gts[((size_t)img * G + g) * 4 + k];
-        s_best[g] = 0ull;
+        // seeded with the key the workgroup's FIRST anchor has at IoU +0 (its real key is at least that): the anchors
+        // without overlap -- nearly all -- are then filtered by the plain read below instead of all 256 threads
+        // queueing a same-address 64-bit LDS atomic per GT (that queue was most of this kernel: 235 -> see profiles)
+        s_best[g] = (unsigned long long)(0xFFFFFFFFu - (unsigned)min(blockIdx.x * 256, (unsigned)(A - 1)));
     }
     __syncthreads();
     const int a = blockIdx.x * 256 + threadIdx.x;
