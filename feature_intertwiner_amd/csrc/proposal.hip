@@ -101,9 +101,21 @@ __global__ __launch_bounds__(kSelThreads) void proposal_select_kernel(SelectArgs
         const int nb = 1 << widths[p];
         for (int i = tid; i < kBins; i += kSelThreads) hist[i] = 0;
         __syncthreads();
-        for (int i = tid; i < total; i += kSelThreads) {
-            const unsigned k = sortable(score_of(a, img, i));
-            if ((k & prefix_mask) == prefix) atomicAdd(&hist[(k >> shifts[p]) & (nb - 1)], 1);
+        // (4 scores per thread and iteration, their loads in flight together: one workgroup walks 261 888 scores four
+        // times, its time is memory latency per iteration)
+        for (int i0 = tid; i0 < total; i0 += 4 * kSelThreads) {
+            float sc4[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * kSelThreads;
+                sc4[u] = i < total ? score_of(a, img, i) : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (i0 + u * kSelThreads >= total) break;
+                const unsigned k = sortable(sc4[u]);
+                if ((k & prefix_mask) == prefix) atomicAdd(&hist[(k >> shifts[p]) & (nb - 1)], 1);
+            }
         }
         __syncthreads();
         find_digit(hist, nb, want, s_wave, s_out);
@@ -122,14 +134,25 @@ __global__ __launch_bounds__(kSelThreads) void proposal_select_kernel(SelectArgs
     if (tid == 0) { s_cnt = 0; s_cnt_eq = 0; }
     __syncthreads();
     const bool all_ties = (count_eq == need_eq);         // every key equal to T is a winner: no order needed
-    for (int i = tid; i < total; i += kSelThreads) {
-        const unsigned k = sortable(score_of(a, img, i));
-        if (k > T) {
-            const int pos = atomicAdd(&s_cnt, 1);
-            s_keys[pos] = ((u64)(~k) << 32) | (unsigned)i;
-        } else if (k == T && all_ties) {
-            const int pos = atomicAdd(&s_cnt_eq, 1);
-            s_keys[(K - need_eq) + pos] = ((u64)(~k) << 32) | (unsigned)i;
+    for (int i0 = tid; i0 < total; i0 += 4 * kSelThreads) {
+        float sc4[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * kSelThreads;
+            sc4[u] = i < total ? score_of(a, img, i) : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * kSelThreads;
+            if (i >= total) break;
+            const unsigned k = sortable(sc4[u]);
+            if (k > T) {
+                const int pos = atomicAdd(&s_cnt, 1);
+                s_keys[pos] = ((u64)(~k) << 32) | (unsigned)i;
+            } else if (k == T && all_ties) {
+                const int pos = atomicAdd(&s_cnt_eq, 1);
+                s_keys[(K - need_eq) + pos] = ((u64)(~k) << 32) | (unsigned)i;
+            }
         }
     }
     __syncthreads();
