@@ -744,9 +744,32 @@ def _main():
         mine2 = torch.tensor([time.perf_counter() - t3], device=dev, dtype=torch.float64)
         dist.all_reduce(mine2, op=dist.ReduceOp.MAX)
         ms2 = float(mine2.item()) / 6 * 1e3
+        # how much of that step is NOT convolution time: 2 further steps with HIP events around every library kernel and
+        # everything on one stream (as the roofline pass above): the MFMA kernels' exclusive time per step, this rank.
+        # The difference to ms_per_step is what the latency kernels of the side streams, the RoI operators, the gradient
+        # exchange and the launch gaps add on the critical path at half the headline's conv time.
+        _lib.prof_reset()
+        _lib.prof_enable(True)
+        side_pixels2 = ficonv.WGRAD_SIDE_STREAM_MAX_PIXELS
+        ficonv.WGRAD_SIDE_STREAM_MAX_PIXELS = 0
+        for _ in range(2):
+            step2()
+        torch.cuda.synchronize()
+        ficonv.WGRAD_SIDE_STREAM_MAX_PIXELS = side_pixels2
+        _lib.prof_enable(False)
+        conv_ms = side_ms = 0.0
+        for k in _lib.KERNEL_IDS:
+            n, ms = _lib.prof_get(k)
+            if n and k.startswith("conv"):
+                conv_ms += ms / 2
+            elif n and (k.startswith("nms") or k.startswith("proposal") or k.startswith("sinkhorn")):
+                side_ms += ms / 2
         configs3 = {"workload": "BASELINE configs[3]: 2 images per GPU, otherwise as config.workload", "images_per_gpu": 2,
                     "global_batch": 2 * world, "steps": 6, "ms_per_step": round(ms2, 3),
-                    "value": round(2 * world * 1e3 / ms2, 4), "unit": "images/sec"}
+                    "value": round(2 * world * 1e3 / ms2, 4), "unit": "images/sec",
+                    "rank0_conv_kernels_ms_per_step": round(conv_ms, 3),
+                    "rank0_not_conv_ms_per_step": round(ms2 - conv_ms, 3),
+                    "rank0_nms_proposal_sinkhorn_kernels_ms_per_step": round(side_ms, 3)}
         model.external_proposals = keep_ext
         del batch2
     if world > 1:
