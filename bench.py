@@ -693,14 +693,17 @@ def _main():
                                  skip=(lambda n: n.startswith("ot_loss") or n.startswith("dev_roi.feat_extract")) if lowp else None)
         backward_check = {"max_rel_dev": float("%.3g" % r["max_rel_dev"]), "worst": r["worst"], "params": r["params"],
                           "loss_rel": float("%.3g" % r["loss_rel"]), "none_sets_equal": r["none_sets_equal"],
-                          "attempts": r["attempts"], "boundary_events": [float("%.3g" % v) for v in r["boundary_events"]],
+                          "attempts": r["attempts"], "boundary_events": [{"max_rel_dev": float("%.3g" % v["max_rel_dev"]),
+                                                                          "evidence": v["evidence"]} for v in r["boundary_events"]],
                           "what": "one backward pass in the default form and one in the dense form "
                                   "(workflow.check_backward_forms) after the timed steps: max over parameters of "
                                   "max|g - g_dense| / max|g_dense|; boundary_events: passes set aside because one "
                                   "pre-activation of the RPN's shared convolution fell on the other side of its ReLU "
                                   "(the default form evaluates it at the sampled anchors as a matrix product -- another "
-                                  "summation order), recognised by its footprint (single channels of rpn.conv_shared) and "
-                                  "repeated with other sampled anchors"}
+                                  "summation order), recognised by its footprint (single channels of rpn.conv_shared), VERIFIED "
+                                  "(evidence: at the differing channel the dense kernel and the row form disagree on the sign "
+                                  "of a sampled pre-activation whose float64 value is within 16 x 2^-24 of its summands' "
+                                  "magnitude) and repeated with other sampled anchors"}
         step()                                  # plans / W^T tables back in the default form
         torch.cuda.synchronize()
     # ---- BASELINE configs[4], single-GPU slice, on the driver's record too (outside the timed region) -----------------

@@ -132,6 +132,7 @@ SIGNATURES = {
     "fi_stride2_interleave_gated": (c_int, [c_void_p] * 7 + [ctypes.c_long, c_int, c_int, c_void_p]),
     "fi_sgd_chunks": (ctypes.c_long, [ctypes.c_long]),
     "fi_sgd_clip_step": (c_int, [c_void_p, c_int, ctypes.c_long, c_float, c_void_p, c_void_p, c_void_p]),
+    "fi_sgd_clip_step_guarded": (c_int, [c_void_p, c_int, ctypes.c_long, c_float, c_void_p, c_void_p, c_void_p]),
     "fi_calib_copy": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     "fi_prof_enable": (None, [c_int]),
     "fi_prof_reset": (None, []),
@@ -321,6 +322,9 @@ _SIDE3 = {}
 PICK_STREAMS = os.environ.get("FI_PICK_STREAMS", "1") != "0"       # A/B switch
 _CANDIDATES = {}
 _IN_USE = {}
+_RETIRED = {}       # device -> streams stream_report(repick=True) replaced: never handed out again (holders of the old
+                    # reference -- events, captured graphs -- may still use them), kept alive for the process
+_FRESH = {}         # device -> extra candidates created by a repick (created once, not four per failing entry per call)
 
 
 def _overtakes(a, b, probe):
@@ -357,8 +361,9 @@ def pick_stream(device=None):
         used = _IN_USE.setdefault(dev, [])
         busy = [torch.cuda.current_stream(dev)] + used
         best, best_hits = None, -1
-        for c in cands:
-            if any(c is u for u in used):
+        retired = _RETIRED.get(dev, [])
+        for c in cands + _FRESH.get(dev, []):
+            if any(c is u for u in used) or any(c is r for r in retired):
                 continue
             hits = sum(1 for a in busy if _overtakes(a, c, probe))
             if hits > best_hits:
@@ -408,7 +413,11 @@ def stream_report(device=None, repick=False):
     take hardware queues and change the map: with repick=True a stream that lost the property is REPLACED by a candidate
     that has it (the second / third stream caches are updated; the returned "replaced" maps id(old) -> new stream, so an
     owner like GradientBuckets can follow).  Host-synchronising (a handful of ~1 ms spins): for start-up and the first
-    step boundary after the first real collective, not for the step."""
+    step boundary after the first real collective, not for the step.
+    A replaced stream is RETIRED: it is never a candidate again (someone may still hold it), and blocks the caching
+    allocator handed out on it stay in its pool (a one-off cost of the few tensors of the first step).  Call this before
+    any graph capture and before caching a side stream or an event recorded on one (dev_roi.big_done, hipGraphs):
+    consumers that cached the old stream keep working on it, but no longer next to the others."""
     dev = torch.cuda.current_device() if device is None else torch.device(device).index
     out = {"GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES", "unset (runtime default 4)"), "pick_streams": PICK_STREAMS,
            "streams": [], "replaced": {}}
@@ -427,8 +436,12 @@ def stream_report(device=None, repick=False):
             rec = {"role": role, "concurrent_with_earlier": all(ok), "detail": ok}
             if repick and not all(ok) and PICK_STREAMS:
                 best, best_hits = None, sum(ok)
-                for c in _CANDIDATES.get(dev, []) + [torch.cuda.Stream(device=dev) for _ in range(4)]:
-                    if any(c is x for x in used):
+                fresh = _FRESH.get(dev)
+                if fresh is None:
+                    fresh = _FRESH[dev] = [torch.cuda.Stream(device=dev) for _ in range(4)]
+                retired = _RETIRED.setdefault(dev, [])
+                for c in _CANDIDATES.get(dev, []) + fresh:
+                    if any(c is x for x in used) or any(c is x for x in retired):
                         continue
                     with torch.cuda.stream(c):
                         probe.add_(1.0)                   # binds a fresh stream to its hardware queue
@@ -439,6 +452,7 @@ def stream_report(device=None, repick=False):
                         break
                 if best is not None:
                     out["replaced"][id(u)] = best
+                    retired.append(u)
                     used[i] = best
                     _ROLE[(dev, id(best))] = role
                     if _SIDE2.get(dev) is u:

@@ -1258,6 +1258,7 @@ int backward_impl(const LevelSetMut &ls, const float *grads, const float *boxes,
         // channels per workgroup: 4 (32 KB of fp64 accumulators, 4 workgroups per CU) measured against 8 (64 KB, 2 per CU)
         // at 512 x 256 on one 256^2 map: 7 x 7 95 vs 114 us, 14 x 14 160 vs 196 us (profiles/r05_crop_bwd_tiles.txt)
         static const int CG = getenv("FI_CROP_TILE_CG") ? atoi(getenv("FI_CROP_TILE_CG")) : 4;
+        FI_REQUIRE(CG == 4 || CG == 8, "FI_CROP_TILE_CG must be 4 or 8 (the two instantiated channel groups)");
         TileGrid tg = {};
         long total = 0;
         for (int l = 0; l < ls.n; ++l) {

@@ -63,9 +63,10 @@ __global__ __launch_bounds__(kThreads) void sgd_sumsq_kernel(const FiSgdDesc *__
     if (threadIdx.x == 0) partial[chunk] = s;
 }
 
-// out[0] = ||grad||_2, out[1] = clip factor
+// out[0] = ||grad||_2, out[1] = clip factor; guard: out[2] = 1 when the norm is not finite (the update kernel then
+// leaves parameters, momentum buffers and gradients untouched: the step is skipped), out[3] += 1 per skipped step
 __global__ __launch_bounds__(kThreads) void sgd_norm_kernel(const float *__restrict__ partial, long chunks,
-                                                            float max_norm, float *__restrict__ out)
+                                                            float max_norm, float *__restrict__ out, int guard)
 {
     __shared__ double s_d[kThreads];
     double acc = 0.0;
@@ -85,6 +86,11 @@ __global__ __launch_bounds__(kThreads) void sgd_norm_kernel(const float *__restr
             if (coef > 1.0f) coef = 1.0f;              // a NaN norm stays NaN, like torch.clamp(max=1)
         }
         out[1] = coef;
+        if (guard) {
+            const bool bad = !(norm <= 3.0e38f);        // inf or NaN (one fp16 overflow under the loss scale)
+            out[2] = bad ? 1.0f : 0.0f;
+            if (bad) out[3] += 1.0f;
+        }
     }
 }
 
@@ -102,8 +108,9 @@ __device__ __forceinline__ void update_one(float &p, float &g, float &b, float c
 }
 
 __global__ __launch_bounds__(kThreads) void sgd_update_kernel(const FiSgdDesc *__restrict__ descs, int n,
-                                                              const float *__restrict__ norm_coef)
+                                                              const float *__restrict__ norm_coef, int guard)
 {
+    if (guard && norm_coef[2] != 0.0f) return;          // non-finite gradient norm: skip the step (uniform branch)
     const long chunk = blockIdx.x;
     const FiSgdDesc d = descs[find_desc(descs, n, chunk)];
     const long begin = (chunk - d.chunk_base) * kChunk;
@@ -157,8 +164,8 @@ extern "C" {
 
 long fi_sgd_chunks(long numel) { return numel <= 0 ? 0 : (numel + kChunk - 1) / kChunk; }
 
-int fi_sgd_clip_step(const FiSgdDesc *descs_dev, int n, long total_chunks, float max_norm, float *partial_ws,
-                     float *norm_coef, fi_stream_t stream)
+static int sgd_clip_step(const FiSgdDesc *descs_dev, int n, long total_chunks, float max_norm, float *partial_ws,
+                         float *norm_coef, fi_stream_t stream, int guard)
 {
     FI_REQUIRE(n >= 0 && total_chunks >= 0, "negative count");
     FI_REQUIRE(total_chunks < 2147483647L, "too many chunks");
@@ -166,10 +173,24 @@ int fi_sgd_clip_step(const FiSgdDesc *descs_dev, int n, long total_chunks, float
     FI_REQUIRE(descs_dev && partial_ws && norm_coef, "null pointer");
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(sgd_sumsq_kernel, dim3((unsigned)total_chunks), dim3(kThreads), 0, st, descs_dev, n, partial_ws);
-    hipLaunchKernelGGL(sgd_norm_kernel, dim3(1), dim3(kThreads), 0, st, partial_ws, total_chunks, max_norm, norm_coef);
-    hipLaunchKernelGGL(sgd_update_kernel, dim3((unsigned)total_chunks), dim3(kThreads), 0, st, descs_dev, n, norm_coef);
+    hipLaunchKernelGGL(sgd_norm_kernel, dim3(1), dim3(kThreads), 0, st, partial_ws, total_chunks, max_norm, norm_coef,
+                       guard);
+    hipLaunchKernelGGL(sgd_update_kernel, dim3((unsigned)total_chunks), dim3(kThreads), 0, st, descs_dev, n, norm_coef,
+                       guard);
     FI_HIP_CHECK(hipGetLastError());
     return FI_OK;
+}
+
+int fi_sgd_clip_step(const FiSgdDesc *descs_dev, int n, long total_chunks, float max_norm, float *partial_ws,
+                     float *norm_coef, fi_stream_t stream)
+{
+    return sgd_clip_step(descs_dev, n, total_chunks, max_norm, partial_ws, norm_coef, stream, 0);
+}
+
+int fi_sgd_clip_step_guarded(const FiSgdDesc *descs_dev, int n, long total_chunks, float max_norm, float *partial_ws,
+                             float *norm_coef4, fi_stream_t stream)
+{
+    return sgd_clip_step(descs_dev, n, total_chunks, max_norm, partial_ws, norm_coef4, stream, 1);
 }
 
 }  // extern "C"

@@ -236,26 +236,26 @@ class GradientBuckets(object):
     def _on_grad(self, p):
         self._start()
         cur = torch.cuda.current_stream(self.device) if self.use_stream else None
-        late = False
+        late = []                 # this parameter's buckets that had already been issued when the gradient arrived
         for bi in self.buckets_of[p]:
             if bi in self._launched:
-                late = True
+                late.append(bi)
                 continue
             if cur is not None:
                 self._grad_streams[bi].add(cur)
             if p not in self._skip:
                 self.pending[bi] -= 1
         if late:
-            self._late_gradient(p, cur)
+            self._late_gradient(p, cur, late)
         self._launch_ready()
 
-    def _late_gradient(self, p, cur):
+    def _late_gradient(self, p, cur, late_buckets):
         if p.grad is not None and self.layout.holds(p, p.grad, self.arena):
             raise RuntimeError("GradientBuckets: a kernel accumulated the gradient of a parameter (shape %s) into its arena "
                                "slot after the slot's bucket had been issued -- the set of parameters that receive "
                                "gradients changed without a new begin(key)" % (tuple(p.shape),))
-        if all(q is not p for q, _ in self._late):
-            self._late.append((p, cur))
+        if all(q is not p for q, _, _ in self._late):
+            self._late.append((p, cur, tuple(late_buckets)))
         self.late_gradients += 1
         run = self._absent_run.setdefault(self._key, {})
         run.pop(p, None)                      # waited for again from the next step on
@@ -286,9 +286,19 @@ class GradientBuckets(object):
                     if s != cur:
                         cur.wait_stream(s)        # the move below (and the flag write) run on `cur`
             dst, src, moved = [], [], []
+            late_now = {id(q) for q, _, _ in self._late}
             for p in b.wait:
                 h = p.grad is not None
                 if h and not lay.holds(p, p.grad, buf):
+                    if id(p) in late_now and self.use_stream:
+                        # a split parameter whose EARLIER piece has already been issued: the whole gradient moves in
+                        # here, over a slice that piece's collective may still be writing
+                        torch.cuda.current_stream(self.device).wait_stream(self.comm_stream)
+                    elif id(p) in late_now:
+                        for _, w, _ in self.inflight:
+                            if w is not None:
+                                w.wait()
+                        self.inflight = [(i, None, hd) for i, _, hd in self.inflight]
                     v = lay.view(p, buf)
                     if v is None:
                         raise RuntimeError("GradientBuckets: parameter with unsupported strides %s" % (p.stride(),))
@@ -297,6 +307,12 @@ class GradientBuckets(object):
                     moved.append((p, v))
             if dst:
                 torch._foreach_copy_(dst, src)
+                if self.use_stream:
+                    # `p.grad = v` drops the last reference to the autograd-allocated gradient; it may have been
+                    # allocated on another stream (the OT module's on the third one) and would return to THAT stream's
+                    # pool with the copy on `cur` still queued: tell the allocator `cur` uses the block
+                    for g in src:
+                        g.record_stream(cur)
                 for p, v in moved:
                     p.grad = v
             # one flag per parameter rides along for the cross-rank consistency counter; the flag vector of a
@@ -385,33 +401,50 @@ class GradientBuckets(object):
         if not self._late:
             return out
         lay, buf = self.layout, self.arena
-        for p, s in self._late:
+        for p, s, late_buckets in self._late:
             if p.grad is None:
                 continue
             v = lay.view(p, buf)
             if v is None:
                 raise RuntimeError("GradientBuckets: parameter with unsupported strides %s" % (p.stride(),))
+            # only the slices whose buckets had left when the gradient arrived: a piece of a split parameter whose
+            # bucket was still to come has been reduced by that bucket (which also moved the whole gradient in)
+            off, n = lay.slot[p]
+            slices = []
+            for bi in late_buckets:
+                b = lay.buckets[bi]
+                lo, hi = max(off, b.start), min(off + n, b.end)
+                if hi > lo:
+                    slices.append(buf[lo:hi])
+            moved_in = lay.holds(p, p.grad, buf)
             if self.use_stream:
                 cur = torch.cuda.current_stream(self.device)
                 if s is not None and s != cur:
                     cur.wait_stream(s)                # the producer of the late gradient
                 cur.wait_stream(self.comm_stream)     # the slot's own bucket must have landed before the move
-                v.copy_(p.grad)
+                if not moved_in:
+                    v.copy_(p.grad)
+                    p.grad.record_stream(cur)         # allocated on the producer's stream, read here on `cur`
                 self.comm_stream.wait_stream(cur)
+                works = []
                 with torch.cuda.stream(self.comm_stream):
-                    work = dist.all_reduce(v, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-                    if self.stream_ordered:
-                        work.wait()
-                        work = None
+                    for piece in slices:
+                        work = dist.all_reduce(piece, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                        if self.stream_ordered:
+                            work.wait()
+                        else:
+                            works.append(work)
             else:
                 # the slot's own bucket may still be in flight on a host-waited backend: finish everything first
                 for _, w, _ in self.inflight:
                     if w is not None:
                         w.wait()
                 self.inflight = [(bi, None, had) for bi, _, had in self.inflight]
-                v.copy_(p.grad)
-                work = dist.all_reduce(v, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-            if work is not None:
+                if not moved_in:
+                    v.copy_(p.grad)
+                works = [dist.all_reduce(piece, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                         for piece in slices]
+            for work in works:
                 work.wait()
             out.append((p, v))
         return out

@@ -40,10 +40,11 @@ def supported(optimizer):
 
 
 def _launch(L, c, max_norm):
+    fn = L.fi_sgd_clip_step_guarded if c.get("guard") else L.fi_sgd_clip_step
     with torch.cuda.device(c["dev"]):
-        _lib.check(L.fi_sgd_clip_step(_lib.ptr(c["table"]), c["n"], c["chunks"],
-                                      float(max_norm) if max_norm else 0.0, _lib.ptr(c["partial"]), _lib.ptr(c["out"]),
-                                      _lib.current_stream()), "fi_sgd_clip_step")
+        _lib.check(fn(_lib.ptr(c["table"]), c["n"], c["chunks"],
+                      float(max_norm) if max_norm else 0.0, _lib.ptr(c["partial"]), _lib.ptr(c["out"]),
+                      _lib.current_stream()), "fi_sgd_clip_step")
     # the kernel wrote parameters, buffers and gradients behind autograd's back: bump their version counters
     # (the per-step caches of W^T and of the eval-BN folds are keyed on parameter versions)
     torch.autograd.graph.increment_version(c["params"])
@@ -57,8 +58,18 @@ def _hyper(optimizer):
                  for g in optimizer.param_groups)
 
 
-def clip_and_step(optimizer, max_norm):
+def skipped_steps(optimizer):
+    """Steps `clip_and_step(..., skip_nonfinite=True)` skipped so far because the gradient norm was inf / NaN
+    (host-synchronising; for logs and tests)."""
+    c = _CACHE.get(optimizer)
+    return 0 if c is None else int(c["out"][3].item())
+
+
+def clip_and_step(optimizer, max_norm, skip_nonfinite=False):
     """Returns the total gradient norm (0-d device tensor), like clip_grad_norm_.  max_norm None/<=0: no clip.
+    skip_nonfinite (the 16-bit paths, workflow.train_step under a loss scale): a step whose gradient norm is inf / NaN
+    leaves parameters and momentum buffers untouched (decided on the device, no host synchronisation);
+    `skipped_steps(optimizer)` counts them.
 
     The descriptor table is static across steps when the gradients live where they lived last step (the gradient
     arena, grad_arena.py): the per-step host work is then one pass collecting (parameter, gradient) addresses and
@@ -66,6 +77,8 @@ def clip_and_step(optimizer, max_norm):
     validation + table building, at a point of the step where the device has nothing queued)."""
     L = _lib.load()
     c = _CACHE.get(optimizer)
+    if c is not None:
+        c["guard"] = bool(skip_nonfinite)
     if c is not None and c["state"] is optimizer.state and c["hyper"] == _hyper(optimizer):
         grads = [p.grad for p in c["all"]]
         sig = [0 if g is None else g.data_ptr() for g in grads]
@@ -148,6 +161,7 @@ def clip_and_step(optimizer, max_norm):
         table.copy_(ring[0][0], non_blocking=True)
         ring[0][2].record()
     c = _CACHE[optimizer] = {
+        "guard": bool(skip_nonfinite),
         "spare": [torch.empty(desc.nbytes, dtype=torch.uint8).pin_memory() for _ in range(2)]
         if not torch.cuda.is_current_stream_capturing() else [],
         "dev": dev, "table": table, "ring": ring, "turn": 1, "desc": ring[0][1], "chunks": base, "n": len(entries),
@@ -160,7 +174,7 @@ def clip_and_step(optimizer, max_norm):
         c["partial"], c["out"] = old["partial"], old["out"]
     else:
         c["partial"] = torch.empty(max(base, 1), device=dev, dtype=torch.float32)
-        c["out"] = torch.empty(2, device=dev, dtype=torch.float32)
+        c["out"] = torch.zeros(4, device=dev, dtype=torch.float32)     # norm, clip factor, skipped now, skipped so far
     out = _launch(L, c, max_norm)
     torch.autograd.graph.increment_version([e[1] for e in entries])
     return out

@@ -329,6 +329,8 @@ class _PatchRowsFn(torch.autograd.Function):
 class RPN(nn.Module):
     """Returns [rpn_class_logits [b, anchors, 2], rpn_probs, rpn_bbox [b, anchors, 4]]."""
 
+    _probe = None       # a dict while workflow.compare_backward_forms records what decides the ReLU masks of the two forms
+
     def __init__(self, anchors_per_location, anchor_stride, input_ch):
         super(RPN, self).__init__()
         self.anchor_stride = anchor_stride
@@ -348,6 +350,8 @@ class RPN(nn.Module):
         xp = self.padding(x)
         x = conv_bias_relu(xp, c.weight, c.bias, c.stride, c.padding,
                            dx_add_from=grad_box if xp is x else None)                    # conv + bias + ReLU, one launch
+        if self._probe is not None:       # workflow.compare_backward_forms: the dense kernel's ReLU output per level
+            self._probe.setdefault("dense_y", []).append(x.detach())
         # the two 1x1 heads as ONE convolution over their stacked filters (every output channel is computed
         # exactly as before): the 512-channel map is read once instead of twice in forward, data gradient and
         # weight gradient, and autograd has no two data gradients to add
@@ -378,7 +382,11 @@ class RPN(nn.Module):
         a = anchor
         cs = self.conv_shared
         ws = cs.weight.permute(0, 2, 3, 1).reshape(cs.weight.shape[0], -1)           # [512, 9*256]: a view of the
-        y = torch.relu(linear(patches, ws, cs.bias))                                  # channels-last parameter
+        z = linear(patches, ws, cs.bias)                                              # channels-last parameter
+        if self._probe is not None:       # workflow.compare_backward_forms: the row form's pre-activations
+            self._probe.update(rows=(rows_image.detach(), anchor.detach(), valid.detach(), per_loc),
+                               patches=patches.detach(), z_rows=z.detach())
+        y = torch.relu(z)
         heads = linear(y, torch.cat((self.conv_class.weight, self.conv_bbox.weight), 0).flatten(1),
                        torch.cat((self.conv_class.bias, self.conv_bbox.bias), 0))     # [R, 2*per_loc + 4*per_loc]
         ncls = 2 * per_loc

@@ -80,7 +80,10 @@ def compute_loss(model, inputs, do_meta=True, world_size=1, reduce_fn=None):
 def backward_scaled(model, loss):
     """loss.backward() with the static loss scale of the 16-bit paths (cfg.TRAIN.LOSS_SCALE; 1 = plain backward).  Returns
     the function that divides the scale out of the gradients again (one multi-tensor pass; call it after the gradient
-    exchange, before clipping)."""
+    exchange, before clipping).  Custom training loops on the 16-bit paths must go through this function (a plain
+    `loss.backward()` silently loses the scale) and should pass `skip_nonfinite=True` to `optim.clip_and_step`, as
+    `train_step` does: a data gradient above 65504 / LOSS_SCALE gives an inf norm, and that step must not reach the
+    weights."""
     s = float(getattr(model.config.TRAIN, "LOSS_SCALE", 1.0) or 1.0)
     if s == 1.0:
         loss.backward()
@@ -113,7 +116,9 @@ def train_step(model, optimizer, inputs, do_meta=True, grad_sync=None, world_siz
     unscale()
     if optim.supported(optimizer):
         # clip_grad_norm_ + SGD step in three launches (csrc/sgd.hip) instead of ~8 passes over all parameters
-        optim.clip_and_step(optimizer, cfg.TRAIN.MAX_GRAD_NORM if cfg.TRAIN.CLIP_GRAD else None)
+        # under a loss scale (fp16 operands) a step whose gradient norm overflowed is skipped on the device
+        scaled = float(getattr(cfg.TRAIN, "LOSS_SCALE", 1.0) or 1.0) != 1.0
+        optim.clip_and_step(optimizer, cfg.TRAIN.MAX_GRAD_NORM if cfg.TRAIN.CLIP_GRAD else None, skip_nonfinite=scaled)
         return terms
     if cfg.TRAIN.CLIP_GRAD:
         torch.nn.utils.clip_grad_norm_([p for p in model.parameters() if p.grad is not None],
@@ -150,9 +155,12 @@ def compare_backward_forms(model, inputs, do_meta=True, generator_seed=3, skip=N
     ext_state = ext_gen.get_state() if ext_gen is not None else None
     dev = next(model.parameters()).device
     out = {}
+    rpn = getattr(model, "rpn", None)
     try:
         for slot, form in zip(("default", "dense"), forms):     # (forms=("default", "default"): run-to-run repeatability)
             C.GATES = C._UNSCALED_BACKWARD = (form == "default")
+            if rpn is not None:     # the default form's pass computes BOTH evaluations of the shared convolution (the dense
+                rpn._probe = {} if (slot == "default" and form == "default") else None       # kernel and the row form)
             if model.feature_buffer is not None and saved_fb is not None:
                 model.feature_buffer.buffer, model.feature_buffer.buffer_cnt = saved_fb[0].clone(), saved_fb[1].clone()
             elif saved_fb is None:
@@ -173,14 +181,19 @@ def compare_backward_forms(model, inputs, do_meta=True, generator_seed=3, skip=N
                 torch.cuda.synchronize(dev)
             out[slot] = (float(loss.detach()),
                          {n: (None if p.grad is None else p.grad.detach().clone()) for n, p in model.named_parameters()})
+            if slot == "default" and rpn is not None and rpn._probe and "z_rows" in rpn._probe:
+                out["probe"] = rpn._probe
     finally:
         C.GATES, C._UNSCALED_BACKWARD = keep
+        if rpn is not None:
+            rpn._probe = None
         model.generator = saved_gen
         if saved_fb is not None and model.feature_buffer is not None:
             model.feature_buffer.buffer, model.feature_buffer.buffer_cnt = saved_fb
         for p in model.parameters():
             p.grad = None
     (l_a, g_a), (l_b, g_b) = out["default"], out["dense"]
+    probe_default = out.get("probe")
     worst, worst_name, n, table = 0.0, None, 0, []
     for name, ref in g_b.items():
         got = g_a[name]
@@ -205,6 +218,9 @@ def compare_backward_forms(model, inputs, do_meta=True, generator_seed=3, skip=N
             d = (g_a[name] - ref).abs() / (ref.abs().max() + 1e-30)
             res["rpn_relu_boundary_channels"] = int((d > 1e-4).sum())
             res["rpn_relu_boundary_which"] = [int(c) for c in torch.nonzero(d > 1e-4).flatten().tolist()[:8]]
+            if res["rpn_relu_boundary_channels"] and probe_default is not None:
+                res["rpn_relu_boundary_evidence"] = _relu_boundary_evidence(
+                    probe_default, model.rpn, res["rpn_relu_boundary_which"])
     if detail:
         res["table"] = sorted(table, key=lambda r: -r[1])[:detail]
     if keep_gradients:
@@ -212,11 +228,53 @@ def compare_backward_forms(model, inputs, do_meta=True, generator_seed=3, skip=N
     return res
 
 
+def _relu_boundary_evidence(probe, rpn, channels, ulps=16.0):
+    """Is a differing channel of rpn.conv_shared really a ReLU-boundary event?  For every channel c in `channels`: the
+    sampled rows (image, anchor) at which the two evaluations of the shared 3 x 3 convolution -- the dense kernel
+    (`RPN.forward`, whose output the dense form's backward masks with) and the row form (`RPN.forward_rows`) --
+    DISAGREE on the sign of the pre-activation, and for each such row the float64 pre-activation z (from the row's own
+    3 x 3 patch) against the rounding scale of its summands, S = sum|patch . w| + |bias|.  An event requires
+    |z| <= ulps * 2^-24 * S: at that distance from zero two fp32 summation orders may land on different sides; a row
+    that disagrees with |z| far above it is a bug in one of the two evaluations.
+    Returns [{"channel", "rows_disagreeing", "max_abs_z_over_scale" (in units of 2^-24 * S), "within_rounding"}]."""
+    img, anchor, valid, per_loc = probe["rows"]
+    patches, z_rows, maps = probe["patches"], probe["z_rows"], probe.get("dense_y", [])
+    cs = rpn.conv_shared
+    ws = cs.weight.detach().permute(0, 2, 3, 1).reshape(cs.weight.shape[0], -1)
+    # dense output at the rows: anchors are level-major, per_loc per pixel (lib/layers.py:41-44)
+    a = anchor.clamp(min=0)
+    dense = torch.zeros_like(z_rows)
+    base = 0
+    for y in maps:
+        B, Cc, H, W = y.shape
+        n = H * W * per_loc
+        here = valid & (a >= base) & (a < base + n)
+        if bool(here.any()):
+            pix = (a[here] - base) // per_loc
+            dense[here] = y[img[here].clamp(min=0), :, pix // W, pix % W]
+        base += n
+    out = []
+    for c in channels:
+        dis = valid & ((z_rows[:, c] > 0) != (dense[:, c] > 0))
+        rec = {"channel": int(c), "rows_disagreeing": int(dis.sum()), "max_abs_z_over_scale": None,
+               "within_rounding": False}
+        if rec["rows_disagreeing"]:
+            pr = patches[dis].double()
+            w = ws[c].double()
+            z64 = pr @ w + float(cs.bias[c])
+            scale = pr.abs() @ w.abs() + abs(float(cs.bias[c]))
+            ratio = (z64.abs() / (scale * 2.0 ** -24 + 1e-300)).max()
+            rec["max_abs_z_over_scale"] = float(ratio)
+            rec["within_rounding"] = bool(ratio <= ulps)
+        out.append(rec)
+    return out
+
+
 def check_backward_forms(model, inputs, bar=2e-5, attempts=3, **kw):
     """compare_backward_forms with the RPN's ReLU-boundary events (see there) taken out: when the comparison misses
     `bar` and the footprint is that of an event (1-2 single channels of rpn.conv_shared), it is repeated with other
     random draws (other sampled anchors), at most `attempts` times.  Returns the last result plus "attempts" and
-    "boundary_events" (the max_rel_dev of the passes that were set aside).
+    "boundary_events" (max_rel_dev and the evidence -- `_relu_boundary_evidence` -- of the passes that were set aside).
     A pass is set aside only while the hypothesis stays plausible: the deviation is of an event's size (<= 3e-2: one
     anchor's share of a channel's gradient), and the channel is a NEW one -- an event lands on whichever channel has a
     pre-activation at rounding distance from zero under that draw, a gradient bug in the row form lands on the same
@@ -230,8 +288,14 @@ def check_backward_forms(model, inputs, bar=2e-5, attempts=3, **kw):
         if r["max_rel_dev"] > 3e-2 or (which & seen):
             r["boundary_same_channel"] = bool(which & seen)
             break
+        # ... and only when it is VERIFIED: at every differing channel the two evaluations of the shared convolution
+        # disagree on the sign of a sampled pre-activation whose float64 value is within rounding of zero
+        ev = r.get("rpn_relu_boundary_evidence")
+        if ev is not None and not all(e["rows_disagreeing"] >= 1 and e["within_rounding"] for e in ev):
+            r["boundary_unverified"] = True
+            break
         seen |= which
-        events.append(r["max_rel_dev"])
+        events.append({"max_rel_dev": r["max_rel_dev"], "evidence": ev})
     r["attempts"] = len(events) + 1
     r["boundary_events"] = events
     return r

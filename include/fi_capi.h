@@ -71,9 +71,15 @@ int fi_crop_and_resize_forward(const float *image, const float *boxes,
 /* Replaces: crop_and_resize_gpu_backward  lib/roi_align/src/crop_and_resize_gpu.c:40-69
  *           CropAndResizeBackpropImageLaucher  .../crop_and_resize_kernel.cu:196-221
  * grads [num_boxes, depth, crop_h, crop_w] -> grads_image [batch, depth, H, W].
- * grads_image is zero-filled by the call (crop_and_resize_gpu.c:57) and then
- * accumulated with hardware fp32 atomics (summation order is not deterministic,
- * as in the reference's atomicAdd kernel). */
+ * Every element of grads_image is WRITTEN by the call (the reference zero-fills it
+ * first, crop_and_resize_gpu.c:57; here the tile-owner kernel's plain stores are
+ * the zero fill -- no memset, no global atomics).  Deterministic: a workgroup owns
+ * a tile of the map, accumulates every contribution to a cell in fp64 in LDS and
+ * rounds once to fp32, so the result does not depend on scheduling (the
+ * reference's atomicAdd kernel sums in arrival order; the CPU reference sums in
+ * box order in fp32 -- both are within 2e-5 * max|grad| of this).  The round-4
+ * scatter kernel (zero fill + fp32 global atomics) stays behind
+ * FI_CROP_BWD_SCATTER=1. */
 int fi_crop_and_resize_backward(const float *grads, const float *boxes,
                                 const int32_t *box_ind, int num_boxes, int batch,
                                 int depth, int image_h, int image_w, int crop_h,
@@ -749,6 +755,13 @@ typedef struct {
 long fi_sgd_chunks(long numel);
 int fi_sgd_clip_step(const FiSgdDesc *descs_dev, int n, long total_chunks, float max_norm, float *partial_ws,
                      float *norm_coef, fi_stream_t stream);
+/* The same three launches with a non-finite guard for the 16-bit paths (static loss scale: one fp16 overflow in a
+ * data gradient gives an inf / NaN norm, and the plain form -- like clip_grad_norm_ + step in the reference's
+ * lib/workflow.py:226-230 -- would then write NaN into every weight).  norm_coef4: 4 floats, [2] is set to 1 when
+ * this step's norm is not finite, in which case parameters, momentum buffers and gradients are left untouched (the
+ * step is skipped); [3] counts skipped steps (zero it once).  No host synchronisation. */
+int fi_sgd_clip_step_guarded(const FiSgdDesc *descs_dev, int n, long total_chunks, float max_norm, float *partial_ws,
+                             float *norm_coef4, fi_stream_t stream);
 
 /* Streaming copy of n_floats floats (16 bytes per lane) with exactly known memory traffic: the
  * calibration point for rocprofv3's FETCH_SIZE / WRITE_SIZE (MI355X_MICROARCH.md, HBM section). */

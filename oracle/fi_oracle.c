@@ -17,14 +17,24 @@
  *   - orc_sinkhorn / OptTrans : pinned -- checked against golden vectors generated
  *     in the build container by importing the reference's lib/OT_module.py
  *     (oracle/gen_golden_ot.py, fixtures tests/golden/ot_*.npz).
- *   - orc_crop_*, orc_nms, orc_roi_pool_* : PARITY UNPINNED by reference
- *     execution.  The reference C sources need <TH/TH.h> (PyTorch 0.3 headers,
- *     absent from this image) and its .cu files need CUDA, so no reference build
+ *   - orc_crop_forward / orc_crop_taps (a1, the RoI bin assignment) : pinned by
+ *     the reference compiled here -- lines 2-112 of lib/roi_align/src/
+ *     crop_and_resize.c (`CropAndResizePerBox`, TH-free) are compiled UNMODIFIED
+ *     in a temporary directory outside the repository by oracle/gen_golden_crop.py
+ *     and run on 84 seeded cases (82 M elements, adversarial boxes, 8 crop sizes,
+ *     both extrapolation values, the north-star 512x256x7x7 / 14x14); fixture
+ *     tests/golden/crop_fwd.npz; tests/test_reference_crop_golden.py holds this
+ *     restatement to it bit for bit.
+ *   - orc_crop_backward, orc_nms, orc_roi_pool_* : PARITY UNPINNED by reference
+ *     execution.  Those reference functions take TH tensors (<TH/TH.h>, PyTorch
+ *     0.3 headers, absent from this image) or are CUDA, so no reference build
  *     exists here; the reference ships no tests or golden vectors.  These
  *     restatements are pinned only by hand-derived known-answer cases (written
  *     inline in tests/test_oracle_kat.py) and cross-checks against independent
- *     formulations (torch grid_sample, float64 brute-force NMS, max_pool2d for
- *     aligned RoIPool windows), which the tests state explicitly.
+ *     formulations (the adjoint identity against the pinned forward, float64
+ *     brute-force NMS, max_pool2d for aligned RoIPool windows), which the tests
+ *     state explicitly.  The Python on both sides of each is pinned by running
+ *     the reference's wrappers (oracle/gen_golden_wrappers.py).
  */
 #include <math.h>
 #include <float.h>

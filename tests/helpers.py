@@ -306,3 +306,38 @@ def golden_wrapper_inputs(seed=23):
     out["pyr_rois"] = rois.astype(f)
     out["pyr_image_shape"] = (1024, 1024, 3)
     return out
+
+
+def golden_crop_cases():
+    """Seeded inputs for tests/golden/crop_fwd.npz (oracle/gen_golden_crop.py runs the reference's own
+    `CropAndResizePerBox` on them; the tests regenerate the same inputs and compare bit for bit).
+    Yields (name, keep_full_output, image[B,C,H,W], boxes[N,4], box_ind[N], crop_h, crop_w, extrapolation)."""
+    small_crops = ((7, 7), (1, 1), (5, 3), (1, 9), (3, 11), (14, 14))
+    all_crops = small_crops + ((28, 28), (64, 64))
+    shapes = ((2, 4, 64, 64), (3, 5, 37, 91), (1, 6, 16, 16), (1, 3, 2, 2), (2, 3, 1, 5))
+    for si, shape in enumerate(shapes):
+        B, C, H, W = shape
+        for ci, (ch, cw) in enumerate(all_crops):
+            rs = np.random.RandomState(7000 + 31 * si + ci)
+            image = rs.standard_normal(shape).astype(np.float32)
+            for extrap in (0.0, -3.5):
+                keep = (ch, cw) in small_crops and extrap == 0.0
+                n = 48 if keep else 203
+                boxes = adversarial_boxes(rs, n, max(H, 9), max(W, 9))
+                ind = rs.randint(0, B, n).astype(np.int32)
+                yield ("s%d_c%dx%d_e%s" % (si, ch, cw, "0" if extrap == 0.0 else "m"), keep,
+                       image, boxes, ind, ch, cw, extrap)
+    # the shapes of tests/test_gpu_crop.py::test_forward_bit_exact_adversarial (70 channels: odd channel chunks)
+    rs = np.random.RandomState(7900)
+    image = rs.standard_normal((1, 70, 16, 16)).astype(np.float32)
+    boxes = adversarial_boxes(rs, 203, 16, 16)
+    yield ("c70_7x7", False, image, boxes, np.zeros(203, np.int32), 7, 7, 0.0)
+    # north star: 512 RoIs x 256 channels x 7x7 (and 14x14) from a [2,256,256,256] map
+    rs = np.random.RandomState(2000)
+    image = rs.standard_normal((2, 256, 256, 256)).astype(np.float32)
+    rois = training_rois(rs, 2, 256).reshape(-1, 4)
+    ind = np.repeat(np.arange(2, dtype=np.int32), 256)
+    for crop in (7, 14):
+        yield ("northstar_%dx%d" % (crop, crop), False, image, rois, ind, crop, crop, 0.0)
+    adv = adversarial_boxes(np.random.RandomState(2001), 512, 256, 256)
+    yield ("northstar_adversarial_7x7", False, image, adv, ind, 7, 7, 0.0)

@@ -223,3 +223,40 @@ def test_checkpoint_file_round_trip(tmp_path):
     # bare state dict == pretrain model
     torch.save(a.state_dict(), path)
     assert load_model(MaskRCNN(cfg), path)[:2] == (1, 1)
+
+
+def test_relu_boundary_evidence_tells_an_event_from_a_bug():
+    """workflow._relu_boundary_evidence (advisor: a deviating rpn.conv_shared channel was classified as a ReLU-boundary
+    event by footprint only): a sign disagreement between the dense kernel and the row form counts as an event only when
+    the float64 pre-activation is within rounding of zero."""
+    import types
+    import torch
+    from feature_intertwiner_amd.workflow import _relu_boundary_evidence
+    g = torch.Generator().manual_seed(5)
+    per_loc, H, W, Cin, Cout, R = 3, 4, 4, 2, 8, 6
+    weight = torch.randn(Cout, Cin, 3, 3, generator=g)
+    bias = torch.randn(Cout, generator=g)
+    ws = weight.permute(0, 2, 3, 1).reshape(Cout, -1)
+    patches = torch.randn(R, 9 * Cin, generator=g)
+    # row 2, channel 5: a pre-activation at rounding distance from zero
+    bias[5] = -float(patches[2].double() @ ws[5].double())
+    z = patches @ ws.t() + bias
+    anchor = torch.tensor([0, 7, 13, 20, 31, 47])             # pixel = anchor // per_loc
+    img = torch.zeros(R, dtype=torch.long)
+    valid = torch.ones(R, dtype=torch.bool)
+    dense = torch.zeros(1, Cout, H, W)
+    pix = anchor // per_loc
+    dense[0, :, pix // W, pix % W] = torch.relu(z).t()
+    rpn = types.SimpleNamespace(conv_shared=types.SimpleNamespace(weight=weight, bias=bias))
+    probe = {"rows": (img, anchor, valid, per_loc), "patches": patches, "z_rows": z.clone(), "dense_y": [dense.clone()]}
+    assert all(e["rows_disagreeing"] == 0 for e in _relu_boundary_evidence(probe, rpn, [5, 1]))
+    # the event: the row form lands just above zero, the dense kernel on zero
+    probe["z_rows"][2, 5] = 1e-9
+    probe["dense_y"][0][0, 5, pix[2] // W, pix[2] % W] = 0.0
+    ev = _relu_boundary_evidence(probe, rpn, [5])[0]
+    assert ev["rows_disagreeing"] == 1 and ev["within_rounding"] and ev["max_abs_z_over_scale"] <= 16
+    # a bug: the evaluations disagree where |z| is far from zero
+    r = int(torch.argmax(z[:, 1].abs()))
+    probe["z_rows"][r, 1] = -z[r, 1]
+    ev = _relu_boundary_evidence(probe, rpn, [1])[0]
+    assert ev["rows_disagreeing"] == 1 and not ev["within_rounding"]

@@ -182,3 +182,37 @@ def test_static_table_path_with_persistent_gradients():
     # same table for steps 0-1; rebuilt at 2 (lr), 3 (buffer), 4 (gradient dropped), 5 (it is back); patched in place at 6 (moved)
     assert tables[0] == tables[1] and tables[5] == tables[6]
     torch.cuda.synchronize()
+
+
+def test_a_step_with_a_non_finite_gradient_norm_is_skipped_under_the_guard():
+    """16-bit paths (static loss scale): one overflowed data gradient gives an inf norm; the guarded form leaves weights
+    and momentum buffers untouched and counts the event -- decided on the device."""
+    from feature_intertwiner_amd import optim
+    a, b = _params(4), _params(4)
+    oa, ob = _make(a), _make(b)
+    for step, bad in enumerate([None, float("inf"), float("nan"), None]):
+        _set_grads(a, 300 + step, 0.5)
+        _set_grads(b, 300 + step, 0.5)
+        if bad is not None:
+            a[5].grad.view(-1)[17] = bad
+        snap = [p.detach().clone() for p in a]
+        bufs = [oa.state[p]["momentum_buffer"].clone() for p in a] if step else None
+        optim.clip_and_step(oa, 5.0, skip_nonfinite=True)
+        torch.cuda.synchronize()
+        if bad is not None:
+            for p, s in zip(a, snap):
+                assert torch.equal(p.detach(), s)
+            for p, s in zip(a, bufs):
+                assert torch.equal(oa.state[p]["momentum_buffer"], s)
+        else:
+            torch.nn.utils.clip_grad_norm_(b, 5.0)
+            ob.step()
+            for p, q in zip(a, b):
+                assert torch.allclose(p.detach(), q.detach(), rtol=2e-6, atol=1e-7)
+    assert optim.skipped_steps(oa) == 2
+    # the plain form on the same gradient poisons the weights (what the guard is for)
+    _set_grads(a, 400, 0.5)
+    a[5].grad.view(-1)[3] = float("inf")
+    optim.clip_and_step(oa, 5.0)
+    torch.cuda.synchronize()
+    assert not torch.isfinite(a[0].detach()).all()
