@@ -697,13 +697,13 @@ def _main():
                                                                           "evidence": v["evidence"]} for v in r["boundary_events"]],
                           "what": "one backward pass in the default form and one in the dense form "
                                   "(workflow.check_backward_forms) after the timed steps: max over parameters of "
-                                  "max|g - g_dense| / max|g_dense|; boundary_events: passes set aside because one "
-                                  "pre-activation of the RPN's shared convolution fell on the other side of its ReLU "
-                                  "(the default form evaluates it at the sampled anchors as a matrix product -- another "
-                                  "summation order), recognised by its footprint (single channels of rpn.conv_shared), VERIFIED "
-                                  "(evidence: at the differing channel the dense kernel and the row form disagree on the sign "
-                                  "of a sampled pre-activation whose float64 value is within 16 x 2^-24 of its summands' "
-                                  "magnitude) and repeated with other sampled anchors"}
+                                  "max|g - g_dense| / max|g_dense|; boundary_events: a pass set aside because pre-activations of "
+                                  "the RPN's shared convolution fell on the other side of their ReLU (the default form evaluates "
+                                  "it at the sampled anchors as a matrix product -- another summation order): VERIFIED (evidence: "
+                                  "at every differing channel the dense kernel and the row form disagree on the sign of a sampled "
+                                  "pre-activation whose float64 value is within 16 x 2^-24 of its summands' magnitude) and then "
+                                  "REPLAYED on the same draws with the row form using the dense kernel's mask bits; max_rel_dev "
+                                  "is the replay's"}
         step()                                  # plans / W^T tables back in the default form
         torch.cuda.synchronize()
     # ---- BASELINE configs[4], single-GPU slice, on the driver's record too (outside the timed region) -----------------

@@ -363,6 +363,23 @@ class RPN(nn.Module):
         bbox = both[:, ncls:].permute(0, 2, 3, 1).contiguous().view(x.size(0), -1, 4)
         return [logits, probs, bbox]
 
+    @staticmethod
+    def dense_at_rows(dense_maps, image, anchor, valid, per_loc):
+        """[R, C]: the per-level maps `dense_maps` ([B, C, H_l, W_l], pyramid order) at rows (image[r], anchor[r]) of the
+        level-major anchor list with per_loc anchors per pixel (lib/layers.py:41-44); zeros where valid[r] is False."""
+        a = anchor.clamp(min=0)
+        out = dense_maps[0].new_zeros((a.numel(), dense_maps[0].shape[1]))
+        base = 0
+        for y in dense_maps:
+            H, W = y.shape[2], y.shape[3]
+            n = H * W * per_loc
+            here = valid & (a >= base) & (a < base + n)
+            pix = ((a - base) // per_loc).clamp(0, H * W - 1)
+            got = y[image.clamp(min=0), :, pix // W, pix % W]
+            out = torch.where(here.unsqueeze(1), got, out)
+            base += n
+        return out
+
     def forward_rows(self, maps, image, anchor, valid, grad_boxes=None):
         """The RPN's outputs at SELECTED anchors only: (logits [R, 2], bbox [R, 4]) for rows (image[r], anchor[r]) of the
         level-major anchor list (lib/layers.py:41-44), zeros where valid[r] is False.
@@ -386,7 +403,13 @@ class RPN(nn.Module):
         if self._probe is not None:       # workflow.compare_backward_forms: the row form's pre-activations
             self._probe.update(rows=(rows_image.detach(), anchor.detach(), valid.detach(), per_loc),
                                patches=patches.detach(), z_rows=z.detach())
-        y = torch.relu(z)
+        if self._probe is not None and self._probe.get("mask_from_dense"):
+            # check_backward_forms' replay of a verified ReLU-boundary event: the mask bits of the DENSE kernel (whose
+            # output the dense form's backward masks with) instead of the row form's own -- the two forms then differ
+            # by rounding only, whatever side of zero a pre-activation at rounding distance fell on
+            y = z * (self.dense_at_rows(self._probe["dense_y"], rows_image, anchor, valid, per_loc) > 0).to(z.dtype)
+        else:
+            y = torch.relu(z)
         heads = linear(y, torch.cat((self.conv_class.weight, self.conv_bbox.weight), 0).flatten(1),
                        torch.cat((self.conv_class.bias, self.conv_bbox.bias), 0))     # [R, 2*per_loc + 4*per_loc]
         ncls = 2 * per_loc
