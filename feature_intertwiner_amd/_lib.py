@@ -131,6 +131,7 @@ SIGNATURES = {
     "fi_stride2_interleave": (c_int, [c_void_p] * 6 + [ctypes.c_long, c_int, c_int, c_void_p]),
     "fi_stride2_interleave_gated": (c_int, [c_void_p] * 7 + [ctypes.c_long, c_int, c_int, c_void_p]),
     "fi_sgd_chunks": (ctypes.c_long, [ctypes.c_long]),
+    "fi_conv1x1_ring_eligible": (c_int, [c_int] * 12 + [c_void_p] * 4),
     "fi_sgd_clip_step": (c_int, [c_void_p, c_int, ctypes.c_long, c_float, c_void_p, c_void_p, c_void_p]),
     "fi_sgd_clip_step_guarded": (c_int, [c_void_p, c_int, ctypes.c_long, c_float, c_void_p, c_void_p, c_void_p]),
     "fi_calib_copy": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),

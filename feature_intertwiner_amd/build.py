@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(_HERE, "libfi_hip.so")
 SOURCES = ["fi_core.hip", "crop_and_resize.hip", "roi_pool.hip", "nms.hip", "sinkhorn.hip",
-           "class_mean.hip", "conv_igemm.hip", "conv_bf16.hip", "conv_f16.hip", "sgd.hip", "glue.hip", "proposal.hip", "targets.hip", "losses.hip", "dev_stage.hip", "meta_stats.hip"]
+           "class_mean.hip", "conv_igemm.hip", "conv1x1_ring.hip", "conv_bf16.hip", "conv_f16.hip", "sgd.hip", "glue.hip", "proposal.hip", "targets.hip", "losses.hip", "dev_stage.hip", "meta_stats.hip"]
 HEADERS = ["fi_common.h", os.path.join("..", "..", "include", "fi_capi.h")]
 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -24,6 +24,8 @@ FLAGS = [
     # hardware fp32 atomic add (global_atomic_add_f32) for the scatter kernels
     "-munsafe-fp-atomics",
     "-Wall", "-Wno-unused-function",
+    # the ring kernel's LDS-DMA asm names m0 as clobbered (a reserved register: clang warns per use)
+    "-Wno-inline-asm",
 ] + os.environ.get("FI_EXTRA_HIPCC_FLAGS", "").split()          # e.g. -DFI_PROBE_1X1 (scripts/c4_probe.sh)
 
 

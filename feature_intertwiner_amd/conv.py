@@ -164,6 +164,12 @@ def _conv_fwd(x, w, b, stride, padding, relu=False, scale=None, residual=None, o
                                                       1 if relu else 0, _lib.current_stream()),
                            "fi_conv1x1_forward_bf16w")
             return y
+    if not bf16 and layout >= 1 and R * S == 1 and live is None and out_hw is None and not out_channels_last and _WF:
+        e = _WF.get(w.data_ptr())
+        if e is not None and e[2] == (Cout, Cin) and (e[1] is None or e[1] == w._version) and \
+                L.fi_conv1x1_ring_eligible(N, Cin, H, W, Cout, 1, 1, stride[0], stride[1], padding[0], padding[1], 0,
+                                           _lib.ptr(x), _lib.ptr(y), _lib.ptr(residual), _lib.ptr(gate)) == 1:
+            w, layout = e[0], 3         # the persistent 1x1 kernel (csrc/conv1x1_ring.hip)
     with torch.cuda.device(x.device):
         if live is not None and bf16:
             _lib.check(_lowp_fn(L, "conv2d_forward_live", prec)(
@@ -825,6 +831,7 @@ def _finish_wgrads():
 
 # ---- per-step derived state: W^T for the data gradient, zeroed gradient arena ---------------------
 _WT = {}           # weight data_ptr -> (W^T [Cin,R,S,Cout], weight version it was made from)
+_WF = {}           # data_ptr of a 1x1 weight (or of its W^T) -> (fragment-major copy, version or None, (Cout, Cin) of the matrix)
 _ARENA = {"buf": None, "slots": {}, "used": set()}
 _PLAN = weakref.WeakKeyDictionary()      # model -> cached layer lists / descriptor table
 
@@ -881,6 +888,7 @@ _TR_DESC = _np.dtype([("src", "<u8"), ("dst", "<u8"), ("rows", "<i4"), ("cols", 
 
 def invalidate_step_state():
     _WT.clear()
+    _WF.clear()
     _WB.clear()
     _ARENA["buf"] = None
     _ARENA["slots"] = {}
@@ -937,7 +945,27 @@ def _prepare_step(model, grad_on):
             wts.append(wt)
             desc[i] = (m.weight.data_ptr(), wt.data_ptr(), co, ci, r * s_, 0, base, 0)
             base += r * s_ * ((co + 31) // 32) * ((ci + 31) // 32)
-        table = torch.from_numpy(desc.view(np.uint8).copy()).to(dev) if len(tr) else None
+        # fragment-major copies of the 1x1 / stride-1 weights for the persistent 1x1 kernel (conv1x1_ring_kernel,
+        # weight_layout 3): W itself for the forward pass, W^T (with the eval-BatchNorm scale, like the plain W^T) for the
+        # data gradient -- extra descriptors of the SAME launch (flag 1 = fragment-major, flag 2 = no transpose)
+        frag = []           # (module, "fwd" | "dgrad", tensor, index of the module in tr or -1)
+        tr_index = {m: i for i, m in enumerate(tr)}
+        for m in convs:
+            co, ci, r, s_ = m.weight.shape
+            if r * s_ != 1 or tuple(m.stride) != (1, 1) or tuple(m.padding) != (0, 0) or _PRECISION in _LOWP:
+                continue
+            if co % 128 == 0 and ci % 32 == 0 and ci >= 128:
+                frag.append((m, "fwd", torch.empty(co * ci, device=dev, dtype=torch.float32), -1))
+            if m in tr_index and ci % 128 == 0 and co % 32 == 0 and co >= 128:
+                frag.append((m, "dgrad", torch.empty(co * ci, device=dev, dtype=torch.float32), tr_index[m]))
+        if frag:
+            extra = np.zeros(len(frag), dtype=_TR_DESC)
+            for i, (m, kind, t, _) in enumerate(frag):
+                co, ci = m.weight.shape[0], m.weight.shape[1]
+                extra[i] = (m.weight.data_ptr(), t.data_ptr(), co, ci, 1, 3 if kind == "fwd" else 1, base, 0)
+                base += ((co + 31) // 32) * ((ci + 31) // 32)
+            desc = np.concatenate([desc, extra])
+        table = torch.from_numpy(desc.view(np.uint8).copy()).to(dev) if len(desc) else None
         # gradient slots: the model-wide arena layout (grad_arena.py) -- every trainable parameter has one, in
         # bucket order; the kernels' keys are the weight's / the BatchNorm gamma's address
         layout = grad_arena.get_layout(model)
@@ -955,7 +983,7 @@ def _prepare_step(model, grad_on):
                 partner = layout.bn_partner.get(bn)
                 slots[("bn", bn.weight.data_ptr())] = (layout.bn_slot[bn], 3 * bn.num_features, weakref.ref(bn.weight),
                                                        partner.data_ptr() if partner is not None else 0)
-        plan = {"ptrs": tuple(p.data_ptr() for p in model.parameters()), "tr": tr, "wts": wts, "table": table,
+        plan = {"ptrs": tuple(p.data_ptr() for p in model.parameters()), "tr": tr, "wts": wts, "table": table, "frag": frag,
                 "desc": desc, "tiles": base, "slots": slots, "layout": layout, "versions": None, "convs": convs,
                 "scales": None}
         _PLAN[model] = plan
@@ -970,6 +998,7 @@ def _prepare_step(model, grad_on):
             if b is not None and not b.training and getattr(b, "_fi_fold", None) is not None:
                 scales[i] = b
     sig = tuple(0 if b is None else b._fi_fold[0].data_ptr() for b in scales)
+    sig = sig + tuple(sig[ti] if ti >= 0 else 0 for _, _, _, ti in plan["frag"])
     if plan["table"] is not None and plan["scales"] != sig:
         desc = plan["desc"]
         desc["row_scale"] = sig
@@ -977,14 +1006,21 @@ def _prepare_step(model, grad_on):
         plan["scales"] = sig
         plan["versions"] = None
     versions = tuple(m.weight._version for m in plan["tr"]) + tuple(b._fi_fold[2] for b in scales if b is not None)
+    versions = versions + tuple(m.weight._version for m, _, _, ti in plan["frag"] if ti < 0)
     if plan["table"] is not None and (plan["versions"] != versions or not all(
             _cached_wt(m.weight, sig[0] != 0) is not None for m in plan["tr"][:1])):
         L = _lib.load()
         with torch.cuda.device(dev):
-            _lib.check(L.fi_weight_transpose_batch(_lib.ptr(plan["table"]), len(plan["tr"]), plan["tiles"],
+            _lib.check(L.fi_weight_transpose_batch(_lib.ptr(plan["table"]), len(plan["desc"]), plan["tiles"],
                                                    _lib.current_stream()), "fi_weight_transpose_batch")
         for m, wt, sp in zip(plan["tr"], plan["wts"], sig):
             _WT[m.weight.data_ptr()] = (wt, m.weight._version, sp != 0)
+        for m, kind, t, ti in plan["frag"]:
+            # forward: keyed by the parameter; data gradient: keyed by the W^T tensor _conv_fwd is handed
+            if kind == "fwd":
+                _WF[m.weight.data_ptr()] = (t, m.weight._version, tuple(m.weight.shape[:2]))
+            else:
+                _WF[plan["wts"][ti].data_ptr()] = (t, None, (m.weight.shape[1], m.weight.shape[0]))
         plan["versions"] = versions
         _WB.clear()          # the W^T tensors were rewritten in place (no version bump): drop their bf16 copies
     if _PRECISION in _LOWP:

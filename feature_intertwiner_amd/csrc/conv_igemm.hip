@@ -889,7 +889,11 @@ __global__ __launch_bounds__(kThreads, 3) void conv3x3_patch_kernel(const float 
                                                                     // without it every read group slides one sub-step back)
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
+#ifdef FI_EXP_NO_A
+            if (t < 8 && cb == 0) load_a(areg[(t + 1) % 3], t + 1, cb);      // timing experiment: weights loaded once (wrong results)
+#else
             if (t < 8) load_a(areg[(t + 1) % 3], t + 1, cb);
+#endif
             // the next patch is requested behind the weights of tap 2: the first wait that covers it is the one for
             // the weights of tap 3, two taps (64 MFMAs) later -- at the top of the block it would sit in front of the
             // wait for tap 0's weights
@@ -915,7 +919,9 @@ __global__ __launch_bounds__(kThreads, 3) void conv3x3_patch_kernel(const float 
             }
         }
         if (more) {
+#ifndef FI_EXP_NO_A
             load_a(areg[0], 0, cb + 1);
+#endif
             stage_store((cb + 1) & 1);
         }
         __syncthreads();
@@ -2229,6 +2235,36 @@ __global__ __launch_bounds__(256) void weight_transpose_kernel(const FiTranspose
         }
         const FiTransposeDesc d = descs[lo];
         const int tr = (d.rows + 31) >> 5, tc = (d.cols + 31) >> 5;
+        if (d.pad_ & 1) {
+            // fragment-major output for conv1x1_ring_kernel (taps == 1, rows and cols multiples of 32): the matrix D [M][K]
+            // (D = src^T * row_scale, or D = src with flag 2) stored per block of 32 rows x 16 columns as
+            // [2 halves of 4 k][64 lanes = (k / 8, row)][4 k]: a wavefront's A-operand load is 1 KB contiguous
+            const long local = t - d.tile_base;
+            const int r0 = (int)(local / tc) * 32, c0 = (int)(local % tc) * 32;
+            const float *__restrict__ rs = (const float *)d.row_scale;
+            const bool keep = (d.pad_ & 2) != 0;
+            const int K = keep ? d.cols : d.rows;
+            const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int r = r0 + ty + 8 * k, c = c0 + tx;
+                const float v = ((const float *)d.src)[(size_t)r * d.cols + c];
+                s_t[ty + 8 * k][tx] = (rs && !keep) ? v * rs[r] : v;
+            }
+            __syncthreads();
+            // element (m, kq) of the 32 x 32 tile of D, 4 consecutive k per thread: 256 threads x 4 = 1024
+            const int m = threadIdx.x & 31, kq = (threadIdx.x >> 5) * 4;      // kq = 0, 4, .., 28
+            float4 v;
+            if (keep) v = make_float4(s_t[m][kq], s_t[m][kq + 1], s_t[m][kq + 2], s_t[m][kq + 3]);
+            else v = make_float4(s_t[kq][m], s_t[kq + 1][m], s_t[kq + 2][m], s_t[kq + 3][m]);
+            const int Mrow = (keep ? r0 : c0) + m, Kcol = (keep ? c0 : r0) + kq;
+            const int kg = Kcol >> 4, kh = (Kcol & 15) >> 3, k8 = Kcol & 7;           // k8 = 0 or 4
+            float *__restrict__ dstf = (float *)d.dst + ((size_t)(Mrow >> 5) * (K >> 4) + kg) * 512 + (k8 >> 2) * 256 +
+                                       (kh * 32 + (Mrow & 31)) * 4;
+            *reinterpret_cast<float4 *>(dstf) = v;
+            continue;
+        }
         long local = t - d.tile_base;
         const int tap = (int)(local / ((long)tr * tc));
         local -= (long)tap * tr * tc;
@@ -2294,11 +2330,11 @@ int fi_conv2d_forward_live(const float *x, const float *weight, const float *bia
                    "channels-last output is implemented on the tap-major path (Cin % 16 == 0, weight_layout 1)");
         g.out_nhwc = 1;
     }
-    FI_REQUIRE(weight_layout >= 0 && weight_layout <= 2,
-               "weight_layout: 0 = [Cout][Cin][R][S], 1 = [Cout][R][S][Cin], 2 = 1 with the taps reversed");
+    FI_REQUIRE(weight_layout >= 0 && weight_layout <= 3,
+               "weight_layout: 0 = [Cout][Cin][R][S], 1 = [Cout][R][S][Cin], 2 = 1 with the taps reversed, 3 = fragment-major 1x1");
     // tap-major fast path: channels-last weights (any 1x1 weight is both layouts at once)
     const bool hwc = (Cin % BK == 0) && (R * S <= 64) && (weight_layout >= 1 || R * S == 1);
-    FI_REQUIRE(hwc || weight_layout == 0, "weight_layout 1/2 needs Cin % 16 == 0 and R*S <= 64");
+    FI_REQUIRE(hwc || weight_layout == 0, "weight_layout 1/2/3 needs Cin % 16 == 0 and R*S <= 64");
     g.flip = (weight_layout == 2) ? 1 : 0;
     g.zero = zero_page();
     FI_REQUIRE(g.zero != nullptr, "zero page lookup failed (no HIP device?)");
@@ -2319,6 +2355,17 @@ int fi_conv2d_forward_live(const float *x, const float *weight, const float *bia
                         pad_w == 0 && !g.out_nhwc && Cin % P1_CB == 0 && Cin >= 128 && Cout > 64 && (H * W) % 4 == 0 &&
                         (uintptr_t)x % 16 == 0 && (long)N * Cin * H * W < 2147483647L &&
                         (long)fi::ceil_div(N * H * W, 128) * fi::ceil_div(Cout, 128) >= 256;
+    // ... and with fragment-major weights (weight_layout 3, made by fi_weight_transpose_batch): the persistent ring form
+    if (weight_layout == 3) {
+        FI_REQUIRE(fi_conv1x1_ring_eligible(N, Cin, H, W, Cout, R, S, stride_h, stride_w, pad_h, pad_w, output_layout, x, y,
+                                            residual, gate) == 1,
+                   "weight_layout 3 (fragment-major 1x1 weights): shape or alignment not eligible for conv1x1_ring_kernel");
+        fi::ProfScope prof(FI_K_CONV1X1_REG, st);
+        const fi::RingArgs ra = {x, weight, bias, scale, residual, gate, y, g.zero, N, Cin, H * W, Cout, relu & 1};
+        fi::launch_conv1x1_ring(ra, st);
+        FI_HIP_CHECK(hipGetLastError());
+        return FI_OK;
+    }
     fi::ProfScope prof(patch_mode ? FI_K_CONV3X3_PATCH + (patch_mode - 1)
                        : reg1x1 ? FI_K_CONV1X1_REG
                                 : FI_K_CONV_FWD + (bm64 ? 0 : 4) + window_class(R, S), st);

@@ -13,7 +13,21 @@
 
 namespace fi {
 
+template <int V>
+struct Int {
+    static constexpr int value = V;      // a compile-time integer as a function argument (generic lambdas)
+};
+
 void set_error(const char *fmt, ...);
+
+// conv1x1_ring.hip (called from fi_conv2d_forward with weight_layout 3)
+struct RingArgs {
+    const float *x, *wF, *bias, *scale, *residual, *gate;
+    float *y;
+    const float *zero;
+    int N, Cin, HW, Cout, relu;
+};
+int launch_conv1x1_ring(const RingArgs &a, hipStream_t st);
 
 #define FI_HIP_CHECK(expr)                                                         \
     do {                                                                           \

@@ -262,6 +262,8 @@ int fi_class_mean_backward(const float *grad_feat, const int32_t *gt,
  * (tap-major / channels-last; needs Cin % 16 == 0) -- selects the fast gather path; 2: as 1,
  * but the taps are applied in reverse order (tap (r,s) of the window uses weight[R-1-r][S-1-s]) --
  * with weight = W^T stored [Cin,R,S,Cout] that is the data gradient without a flipped copy.
+ * 3: fragment-major 1x1 weights as written by fi_weight_transpose_batch (flag 1): the persistent form of the 1x1 / stride-1
+ * kernel (conv1x1_ring_kernel); only for calls for which fi_conv1x1_ring_eligible() returns 1 (FI_ERR otherwise).
  * output_layout 0: y is [N,Cout,OH,OW]; 1: y is [N,OH,OW,Cout] (channels-last; Cout % 4 == 0, no
  * residual) -- used for the maps that only the channels-last RoIAlign consumes.
  * The data gradient of a stride-1 convolution is this same call on dY with the flipped,
@@ -272,6 +274,12 @@ int fi_class_mean_backward(const float *grad_feat, const int32_t *gt,
  * Cin == 64 on a same-size stride-1 layer with H*W % 4 == 0 and 16-byte aligned x, dy).
  * dbias (optional, [Cout]) receives the bias gradient sum(dy) from the same pass over dy.
  * ---------------------------------------------------------------------- */
+/* 1 when fi_conv2d_forward(_gated) accepts weight_layout 3 for this call: 1x1 / stride 1 / no padding, NCHW output,
+ * Cin % 32 == 0 and >= 128, Cout % 128 == 0, H*W % 4 == 0, 16-byte aligned tensors, y below 4 GB, at least 256 tiles of
+ * 128 pixels x 128 channels.  Pointers are only inspected for alignment (NULL = absent). */
+int fi_conv1x1_ring_eligible(int N, int Cin, int H, int W, int Cout, int R, int S, int stride_h, int stride_w, int pad_h,
+                             int pad_w, int output_layout, const float *x, const float *y, const float *residual,
+                             const float *gate);
 int fi_conv2d_forward(const float *x, const float *weight, const float *bias,
                       const float *scale, const float *residual, float *y, int N, int Cin,
                       int H, int W, int Cout, int R, int S, int stride_h, int stride_w,
@@ -441,7 +449,11 @@ int fi_gemm_nt_affine(const float *a, const float *b, const float *scale, const 
 typedef struct {
     const void *src;
     void *dst;
-    int rows, cols, taps, pad_;
+    int rows, cols, taps;
+    int pad_;                /* flags.  1: dst is FRAGMENT-MAJOR for the 1x1 ring kernel (taps == 1, rows % 32 == 0, cols % 32 == 0):
+                              * the matrix D [M][K] = src^T (* row_scale) -- or D = src when flag 2 is also set -- stored per block
+                              * of 32 rows x 16 columns as [2 halves of 4 k][64 lanes = (k / 8, row)][4 k], blocks in [M/32][K/16]
+                              * order; M * K floats.  0: the plain transpose below. */
     long tile_base;
     const void *row_scale;   /* [rows] or NULL: dst[col][tap][row] = src[row][tap][col] * row_scale[row] -- the data
                               * gradient of conv + eval-BatchNorm reads W^T with the BatchNorm scale folded in */

@@ -13,6 +13,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("FI_DEAD_SIDE", "0")
 os.environ.setdefault("FI_WGRAD_SIDE_PIXELS", "0")      # weight gradients on the main stream: the events bracket the kernel
+# ... and so is every other side stream (round 5's file had three GEMMs of the OT module's backward at 0.1-0.9 TFLOP/s: 8
+# workgroups of the meta loss on the THIRD stream waiting for CU slots next to a main-stream convolution -- the events
+# bracketed the wait, not the kernel)
+os.environ.setdefault("FI_META_SIDE", "0")
+os.environ.setdefault("FI_BIG_SIDE", "0")
+os.environ.setdefault("FI_PROPOSAL_SIDE", "0")
 from feature_intertwiner_amd import _lib  # noqa: E402
 from feature_intertwiner_amd.config import make_config  # noqa: E402
 from feature_intertwiner_amd.model import MaskRCNN  # noqa: E402
