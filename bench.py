@@ -355,6 +355,104 @@ def cpu_baseline(model, batch, log_entries, shape_log=None):
             "detail_ms": {k: round(v, 1) for k, v in detail.items()}, "host_cpus": os.cpu_count()}
 
 
+def issue_profile(step, dev, ms_per_step_unprofiled, steps=2):
+    """What the HOST side of a step costs and how busy the GPU is (at 8 ranks x 2 images the device step halves and
+    the launch path is the first thing that can cap scaling).
+      host_issue_ms_per_step  wall time of step() when the device queue is EMPTY at its start (synchronise, then time the
+                              call): what the host needs to issue one step, never blocked on a full queue;
+      gpu_busy_ms_per_step    union over all streams of the kernel / copy intervals of `steps` traced steps (torch.profiler);
+      gpu_idle_ms_per_step    ms_per_step of the UN-profiled timed region minus that union (the tracer slows the host, so
+                              gaps measured inside a traced run over-state the idle time; kernel durations are not affected);
+      launches / framework_launches  device kernels per step, and those that are not this library's (torch glue)."""
+    from torch.profiler import ProfilerActivity, profile
+    host = []
+    for _ in range(steps):
+        torch.cuda.synchronize(dev)
+        t = time.perf_counter()
+        step()
+        host.append(time.perf_counter() - t)
+    torch.cuda.synchronize(dev)
+    with profile(activities=[ProfilerActivity.CUDA]) as prof:
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize(dev)
+    iv, launches, fw = [], 0, 0
+    for e in prof.events():
+        if e.device_type != torch.autograd.DeviceType.CUDA:
+            continue
+        iv.append((e.time_range.start, e.time_range.end))
+        name = e.name.lower()
+        if "memcpy" in name or "memset" in name:
+            continue
+        launches += 1
+        if "_global__n_1" not in name and not name.startswith("fi_") and "nccl" not in name and "rccl" not in name:
+            fw += 1
+    iv.sort()
+    busy, cs, ce = 0.0, None, None
+    for a, b in iv:
+        if ce is None:
+            cs, ce = a, b
+        elif a <= ce:
+            ce = max(ce, b)
+        else:
+            busy += ce - cs
+            cs, ce = a, b
+    if ce is not None:
+        busy += ce - cs
+    busy_ms = busy / steps / 1e3
+    return {"host_issue_ms_per_step": round(min(host) * 1e3, 2), "gpu_busy_ms_per_step": round(busy_ms, 2),
+            "gpu_idle_ms_per_step": round(max(ms_per_step_unprofiled - busy_ms, 0.0), 2),
+            "launches_per_step": launches // steps, "framework_launches_per_step": fw // steps,
+            "method": "host: step() timed from an empty device queue; busy: union of kernel intervals over all streams of %d "
+                      "traced steps (torch.profiler); idle = un-profiled ms_per_step - busy" % steps}
+
+
+def graph_ab_two_images(model, opt, dev, image_size, train_step, steps=8):
+    """BASELINE configs[3]'s per-GPU shape (2 images) on this GPU, eager against ONE hipGraph replay of the whole step
+    (possible because the step has no host synchronisation): ms/step and GPU idle time of both.  At 2 images the device step
+    is ~60 ms against ~25 ms of host issue time; the replay takes the host out of the picture entirely."""
+    from feature_intertwiner_amd.synthetic import SyntheticProposals, synthetic_batch
+    keep_ext, keep_gen = model.external_proposals, model.generator
+    batch2 = synthetic_batch(2, image_size, device=dev, seed=4000)
+    model.external_proposals = SyntheticProposals(batch2[2], image_size, seed=9, cycle=16)
+    model.generator = torch.Generator(device=dev).manual_seed(13)
+
+    def step2():
+        return train_step(model, opt, list(batch2), do_meta=True)
+
+    def timed(fn):
+        torch.cuda.synchronize(dev)
+        t = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize(dev)
+        return (time.perf_counter() - t) / steps * 1e3
+    out = {}
+    try:
+        s = torch.cuda.Stream(device=dev)
+        s.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(s):
+            for _ in range(3):
+                step2()
+        torch.cuda.current_stream(dev).wait_stream(s)
+        ms_e = timed(step2)
+        out["eager"] = dict(ms_per_step=round(ms_e, 3), **issue_profile(step2, dev, ms_e))
+        g = torch.cuda.CUDAGraph()
+        for gen in (model.generator, model.external_proposals.gen):
+            g.register_generator_state(gen)
+        with torch.cuda.graph(g, stream=s):
+            step2()
+        torch.cuda.synchronize(dev)
+        ms_g = timed(g.replay)
+        out["graph_replay"] = dict(ms_per_step=round(ms_g, 3), **issue_profile(g.replay, dev, ms_g))
+        del g
+    except Exception as ex:           # a capture failure must not take the headline line with it
+        out["error"] = repr(ex)
+    model.external_proposals, model.generator = keep_ext, keep_gen
+    out["what"] = "2 images per GPU (BASELINE configs[3]'s per-rank shape) on one GPU: eager launches vs one hipGraph replay"
+    return out
+
+
 def _self_launch(n):
     """Re-run this command line under `python -m torch.distributed.run --nnodes=1 --nproc-per-node n` and
     return the child job's JSON line."""
@@ -628,6 +726,12 @@ def _main():
     elapsed = time.perf_counter() - t0
     if sync is not None:
         sync.check()               # replicas stayed consistent (host sync, outside the timed region)
+    # ---- host issue time / GPU busy and idle time / launches per step, this rank (outside the timed region) ----------
+    issue = None
+    try:
+        issue = issue_profile(step, dev, elapsed / args.steps * 1e3)
+    except Exception as ex:
+        issue = {"error": repr(ex)}
     # ---- a separate profiled pass for the roofline objects (HIP events around every library kernel) --
     prof_steps = max(1, args.profile_steps)
     _lib.prof_reset()
@@ -714,6 +818,10 @@ def _main():
             cfg4_slice = configs4_slice(dev)
         except Exception as ex:          # never takes the headline down
             cfg4_slice = {"error": repr(ex)}
+    graph_ab = None
+    if world == 1 and sync is None and args.config == "cfg3" and not args.no_dense_reference and not args.dense_backward and \
+            args.conv_precision == "fp32" and args.batch_per_gpu != 2:
+        graph_ab = graph_ab_two_images(model, opt, dev, args.image_size, train_step)
     per_rank_ms, rccl_ranks, overlap = None, None, None
     if sync is not None and not share:
         # a further pass with HIP events around every bucket's collective: how much of the exchange hides in backward
@@ -767,7 +875,12 @@ def _main():
                 conv_ms += ms / 2
             elif n and (k.startswith("nms") or k.startswith("proposal") or k.startswith("sinkhorn")):
                 side_ms += ms / 2
+        try:
+            issue2 = issue_profile(step2, dev, ms2)
+        except Exception as ex:
+            issue2 = {"error": repr(ex)}
         configs3 = {"workload": "BASELINE configs[3]: 2 images per GPU, otherwise as config.workload", "images_per_gpu": 2,
+                    "rank0_issue": issue2,
                     "global_batch": 2 * world, "steps": 6, "ms_per_step": round(ms2, 3),
                     "value": round(2 * world * 1e3 / ms2, 4), "unit": "images/sec",
                     "rank0_conv_kernels_ms_per_step": round(conv_ms, 3),
@@ -965,6 +1078,7 @@ def _main():
             "dense_backward_reference": dense_ref,
             "backward_check": backward_check,
             "configs4_slice": cfg4_slice,
+            "issue": issue, "two_images_per_gpu_graph_ab": graph_ab,
             "roofline": roof, "roofline_roialign": roof_roi, "conv_stack": conv_stack, "nms": nms_obj, "sinkhorn": sk_obj,
             "timing": {"timed_region": "%d steps, no event recording / logging" % args.steps,
                        "profiled_pass": "%d further steps with HIP-event timing of every library kernel, weight gradients "

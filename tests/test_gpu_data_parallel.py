@@ -235,3 +235,60 @@ def test_configs3_slice_two_ranks_full_size():
         for r in range(WORLD):
             assert all(np.isfinite(v) for v in res[r]["hist"][step].values()), res[r]["hist"][step]
     assert res[0]["hist"][1]["total"] < res[0]["hist"][0]["total"]
+
+
+def _count_launches(fn, reps=2):
+    """Device kernels (no memcpy / memset) of fn(), counted by torch.profiler on the last of `reps` calls."""
+    from torch.profiler import ProfilerActivity, profile
+    n = 0
+    for _ in range(reps):
+        torch.cuda.synchronize()
+        with profile(activities=[ProfilerActivity.CUDA]) as prof:
+            fn()
+            torch.cuda.synchronize()
+        n = sum(1 for e in prof.events() if e.device_type == torch.autograd.DeviceType.CUDA
+                and "memcpy" not in e.name.lower() and "memset" not in e.name.lower())
+    return n
+
+
+def _worker_launches(rank, port, outdir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+    from feature_intertwiner_amd.data_parallel import GradientBuckets, all_reduce_statistics, broadcast_parameters
+    from feature_intertwiner_amd.workflow import set_optimizer, train_step
+    cfg, model, (batch, hook, gen) = _make(rank, "ot_l2cost", "small")
+    broadcast_parameters(model)
+    opt = set_optimizer(model, cfg.TRAIN)
+    sync = GradientBuckets(model, bucket_bytes=4 << 20)
+    model.external_proposals, model.generator = hook, gen
+
+    def step():
+        train_step(model, opt, list(batch), do_meta=True, grad_sync=sync, world_size=WORLD, reduce_fn=all_reduce_statistics)
+    for _ in range(sync.ABSENT_STEPS + 1):
+        step()
+    n = _count_launches(step)
+    if rank == 0:
+        torch.save({"launches": n, "buckets": len(sync.buckets)}, os.path.join(outdir, "launches.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_data_parallel_step_launches_what_the_single_rank_step_does():
+    """The host side is what caps scaling first at 2 images per GPU: the data-parallel step must not launch more
+    device kernels than the one-rank step plus the exchange's own (move-in copy, flag copy and collective staging per
+    bucket, one scaling pass, the consistency counter, the statistics sums)."""
+    from feature_intertwiner_amd.workflow import set_optimizer, train_step
+    with tempfile.TemporaryDirectory() as outdir:
+        mp.spawn(_worker_launches, args=(_free_port(), outdir), nprocs=WORLD, join=True)
+        dp = torch.load(os.path.join(outdir, "launches.pt"), weights_only=False)
+    cfg, model, (batch, hook, gen) = _make(0, "ot_l2cost", "small")
+    opt = set_optimizer(model, cfg.TRAIN)
+    model.external_proposals, model.generator = hook, gen
+    for _ in range(2):
+        train_step(model, opt, list(batch), do_meta=True)
+    single = _count_launches(lambda: train_step(model, opt, list(batch), do_meta=True))
+    assert dp["launches"] <= single + 16 + 4 * dp["buckets"], (single, dp)
+    print("device kernels per step: single rank %d, data parallel (2 ranks, rank 0) %d, %d buckets" % (
+        single, dp["launches"], dp["buckets"]))
