@@ -105,7 +105,7 @@ def crop_dedup_bytes(log_entry, batch):
     return 4 * N * C * crop * crop + 4 * C * uniq + 24 * N
 
 
-def north_star_roialign(dev):
+def north_star_roialign(dev, counters_only=False):
     """The north star's RoIAlign shape -- 512 RoIs x 256 channels x 7 x 7 on ONE map ([2, 256, 256, 256], jittered-GT +
     background RoIs of 4-128 pixels, seeded) -- through the reference-shaped operator on a channels-last map and on
     the reference's native NCHW map: kernel time from the in-library HIP events (50 launches each), priced with
@@ -127,6 +127,13 @@ def north_star_roialign(dev):
     b_min = crop_algorithmic_bytes(entry)
     fn = CropAndResizeFunction(crop, crop)
     out = {"shape": [N, C, crop, crop], "map": [B, C, S, S], "B_min_bytes": int(b_min), "peak": HBM_PEAK_GBPS, "unit": "GB/s"}
+    if counters_only:       # the rocprofv3 --pmc child: the same launches, nothing timed
+        with torch.no_grad():
+            for img in (image.contiguous(memory_format=torch.channels_last), image):
+                for _ in range(12):
+                    fn(img, rois, ind)
+        torch.cuda.synchronize()
+        return None
     with torch.no_grad():
         for name, img, key in (("channels_last", image.contiguous(memory_format=torch.channels_last), "crop_fwd_nhwc_7x7"),
                                ("nchw", image, "crop_fwd_7x7")):
@@ -185,7 +192,7 @@ def configs4_slice(dev, steps=6, warmup=3):
     return out
 
 
-def pmc_traffic(kernel_substrings, extra_args, timeout_s=170):
+def pmc_traffic(kernel_substrings, extra_args, timeout_s=170, child_flag="--pmc-child"):
     """HBM-side bytes per launch of the named kernels from rocprofv3's FETCH_SIZE / WRITE_SIZE, collected as
     MI355X_MICROARCH.md prescribes: each counter in its OWN `--pmc` pass (with --kernel-trace only), values in
     KB, and calibrated on a streaming copy of known size run in the same process (fi_calib_copy, 16 bytes
@@ -206,7 +213,7 @@ def pmc_traffic(kernel_substrings, extra_args, timeout_s=170):
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         d = tempfile.mkdtemp(prefix="fi_pmc_", dir=os.environ.get("TMPDIR", "/tmp"))
         cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "p", "--",
-               sys.executable, os.path.abspath(__file__), "--pmc-child"] + extra_args
+               sys.executable, os.path.abspath(__file__), child_flag] + extra_args
         try:
             subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s, check=False,
                            cwd=os.environ.get("TMPDIR", "/tmp"))
@@ -249,6 +256,27 @@ def pmc_traffic(kernel_substrings, extra_args, timeout_s=170):
     return out
 
 
+def _pin_to_physical_cores(limit=128):
+    """One hardware thread per physical core (at most `limit`): the CPU leg's OpenMP / oneDNN threads then never share a
+    core, which is what made its number differ by +-40 % between boxes.  Returns the previous affinity mask (or None)."""
+    try:
+        prev = os.sched_getaffinity(0)
+        seen, cpus = set(), []
+        for c in sorted(prev):
+            path = "/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list" % c
+            sib = open(path).read().strip() if os.path.exists(path) else str(c)
+            if sib not in seen:
+                seen.add(sib)
+                cpus.append(c)
+        cpus = cpus[:limit]
+        if cpus:
+            os.sched_setaffinity(0, cpus)
+            torch.set_num_threads(len(cpus))
+        return prev
+    except Exception:
+        return None
+
+
 def cpu_conv_stack_seconds(shape_log, top=5, budget_s=60.0):
     """The step's convolutions (forward + input/weight gradients) on the host CPU through torch /
     oneDNN -- which is how the reference runs them on its CPU path.  The `top` layer shapes that carry the most
@@ -288,7 +316,8 @@ def cpu_conv_stack_seconds(shape_log, top=5, budget_s=60.0):
     return total, n_timed, (timed_flops / max(timed_flops + rest_flops, 1.0))
 
 
-def cpu_baseline(model, batch, log_entries, shape_log=None):
+def cpu_baseline(model, batch, log_entries, shape_log=None, conv_top=5, conv_budget_s=60.0, nms_boxes=6000, image=1024,
+                 sinkhorn_problems=240):
     """ONE step's hot path on the host CPU.  Operators on the CPU oracle (all host cores for RoIAlign
     forward, one thread for backward / NMS / Sinkhorn, as the reference's C and Python do): the
     step's RoIAlign 7x7 and 14x14 forward on the real RoIs and feature-map sizes, their backward,
@@ -299,9 +328,11 @@ def cpu_baseline(model, batch, log_entries, shape_log=None):
     from oracle import oracle as O
     from helpers import clustered_dets
     O.build()
+    prev_aff = _pin_to_physical_cores()
     rs = np.random.RandomState(2000)
     t_total = 0.0
     detail = {}
+    frac = None
     bs = batch[0].size(0)
     for e in log_entries:
         crop, C = e["crop"], e["depth"]
@@ -323,26 +354,26 @@ def cpu_baseline(model, batch, log_entries, shape_log=None):
         detail["roialign_%dx%d_fwd_ms" % (crop, crop)] = t_f * 1e3
         detail["roialign_%dx%d_bwd_ms" % (crop, crop)] = t_b * 1e3
         t_total += t_f + t_b
-    dets = [clustered_dets(rs, 6000, 1024) for _ in range(bs)]
+    dets = [clustered_dets(rs, nms_boxes, image) for _ in range(bs)]
     t = time.time()
     for d in dets:
         O.pth_nms(d, 0.7)
     detail["nms_ms"] = (time.time() - t) * 1e3
     t_total += time.time() - t
-    x = np.maximum(rs.standard_normal((240, 256, 1)), 0).astype(np.float32)
-    y = np.maximum(rs.standard_normal((240, 256, 1)), 0).astype(np.float32)
+    x = np.maximum(rs.standard_normal((max(sinkhorn_problems, 1), 256, 1)), 0).astype(np.float32)
+    y = np.maximum(rs.standard_normal((max(sinkhorn_problems, 1), 256, 1)), 0).astype(np.float32)
     t = time.time()
-    for p in range(240):           # every problem of the step (~1 s; rounds 1-3 timed 24 and scaled)
+    for p in range(sinkhorn_problems):           # every problem of the step (~1 s; rounds 1-3 timed 24 and scaled)
         O.sinkhorn(x[p], y[p], 1.0, 50)
     sk = time.time() - t
-    detail["sinkhorn_240_ms"] = sk * 1e3
+    detail["sinkhorn_%d_ms" % sinkhorn_problems] = sk * 1e3
     t_total += sk
     sample = ("one step's operator work on the CPU oracle: RoIAlign 7x7+14x14 fwd (OpenMP, %d threads) "
-              "and bwd (serial) on the step's %d RoIs, NMS 4x6000 @0.7 (serial), Sinkhorn 240x256x256 "
-              "L=50 (serial, all 240 timed)" % (O.num_threads(), log_entries[0]["boxes"].size(0)))
+              "and bwd (serial) on the step's %d RoIs, NMS %dx%d @0.7 (serial), Sinkhorn %dx256x256 "
+              "L=50 (serial, all timed)" % (O.num_threads(), log_entries[0]["boxes"].size(0), bs, nms_boxes, sinkhorn_problems))
     unit = "images/sec (hot-path operators only, conv stack excluded)"
     if shape_log:
-        conv_s, n_shapes, frac = cpu_conv_stack_seconds(shape_log)
+        conv_s, n_shapes, frac = cpu_conv_stack_seconds(shape_log, top=conv_top, budget_s=conv_budget_s)
         detail["conv_stack_fwd_bwd_ms"] = conv_s * 1e3
         detail["operators_ms"] = t_total * 1e3
         t_total += conv_s
@@ -350,9 +381,54 @@ def cpu_baseline(model, batch, log_entries, shape_log=None):
         sample += ("; conv stack: the %d layer shapes with the most flops timed fwd+bwd at full batch with torch on %d "
                    "threads (second of two runs), = %.0f%% of the conv flops; the other shapes priced at the measured "
                    "seconds per flop" % (n_shapes, torch.get_num_threads(), 100 * frac))
+    used = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else O.num_threads()
+    if prev_aff is not None:
+        try:
+            os.sched_setaffinity(0, prev_aff)
+        except Exception:
+            pass
     return {"value": bs / t_total, "unit": unit,
-            "cores": O.num_threads(), "kind": "port", "sample": sample,
+            "cores": min(O.num_threads(), used), "kind": "port", "sample": sample,
+            "conv_flops_timed_share": None if frac is None else round(frac, 3),
+            "conv_flops_extrapolated_share": None if frac is None else round(1.0 - frac, 3),
+            "affinity": "one hardware thread per physical core (sched_setaffinity), %d CPUs" % used,
             "detail_ms": {k: round(v, 1) for k, v in detail.items()}, "host_cpus": os.cpu_count()}
+
+
+def cpu_baseline_configs0(dev):
+    """BASELINE configs[0] -- ResNet-50-FPN, 2 synthetic 512 x 512 images, 64 RoIs per image, OT off: the reference's own
+    CPU-runnable case -- as a CPU composite: one step of that model is run on the GPU once to log its RoIAlign launches and
+    convolution shapes, then the operators are timed on the CPU oracle and EVERY convolution shape (forward + backward)
+    on torch / oneDNN (the model is small enough that nothing is extrapolated)."""
+    from feature_intertwiner_amd import conv as ficonv
+    from feature_intertwiner_amd.config import make_config
+    from feature_intertwiner_amd.model import MaskRCNN
+    from feature_intertwiner_amd.roi_align import crop_and_resize as car
+    from feature_intertwiner_amd.synthetic import SyntheticProposals, synthetic_batch
+    from feature_intertwiner_amd.workflow import set_optimizer, train_step
+    torch.manual_seed(2000)
+    cfg = make_config("resnet50", 512, 2, 64, dev_switch=False, loss_choice="l2")
+    model = MaskRCNN(cfg).to(dev)
+    opt = set_optimizer(model, cfg.TRAIN)
+    batch = synthetic_batch(2, 512, device=dev, seed=2000)
+    model.external_proposals = SyntheticProposals(batch[2], 512, seed=7)
+    model.generator = torch.Generator(device=dev).manual_seed(11)
+    for _ in range(2):
+        train_step(model, opt, list(batch), do_meta=False)
+    car.LAUNCH_LOG, ficonv.SHAPE_LOG = [], []
+    train_step(model, opt, list(batch), do_meta=False)
+    torch.cuda.synchronize(dev)
+    log, shapes = car.LAUNCH_LOG, ficonv.SHAPE_LOG
+    car.LAUNCH_LOG = ficonv.SHAPE_LOG = None
+    entries = [e for e in log if e["crop"] in (7, 14) and e["boxes"].size(0) == 2 * 64][-2:]
+    if not entries:
+        entries = [e for e in log if e["crop"] in (7, 14)][-2:]
+    out = cpu_baseline(model, batch, entries, shapes, conv_top=10 ** 6, conv_budget_s=120.0, nms_boxes=6000, image=512,
+                       sinkhorn_problems=0)
+    out["workload"] = "BASELINE configs[0]: ResNet-50-FPN, 2 x 512^2, 64 RoIs/image, OT off (no Sinkhorn problems)"
+    del model, opt
+    torch.cuda.empty_cache()
+    return out
 
 
 def issue_profile(step, dev, ms_per_step_unprofiled, steps=2):
@@ -385,7 +461,10 @@ def issue_profile(step, dev, ms_per_step_unprofiled, steps=2):
         if "memcpy" in name or "memset" in name:
             continue
         launches += 1
-        if "_global__n_1" not in name and not name.startswith("fi_") and "nccl" not in name and "rccl" not in name:
+        # this library's kernels live in anonymous namespaces of csrc/*.hip (demangled "(anonymous namespace)::...") or are
+        # named fi_*; everything else on the device is torch glue (at::native::..., rocprim, copies as kernels) or RCCL
+        ours = ("(anonymous namespace)::" in e.name and "at::" not in e.name) or name.startswith("fi_") or "fi_calib" in name
+        if not ours and "nccl" not in name and "rccl" not in name:
             fw += 1
     iv.sort()
     busy, cs, ce = 0.0, None, None
@@ -595,6 +674,7 @@ def _main():
     ap.add_argument("--profile-steps", type=int, default=4,
                     help="extra steps AFTER the timed region, run with in-library HIP-event timing for the roofline objects")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--pmc-child-roi", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--mask-head-on-positive-slots", action="store_true",
                     help="NOT the headline configuration: run the mask head only on the RoI slots that can hold "
                          "positives (identical loss/gradients, see MaskRCNN.forward); recorded in config.variant")
@@ -687,6 +767,15 @@ def _main():
         if world > 1 or force_dp:
             dist.destroy_process_group()
         return json.dumps(info) if rank == 0 else None
+    if args.pmc_child_roi:
+        # profiled under `rocprofv3 --pmc <one counter>`: calibration copies, then the north star's RoIAlign launches
+        a = torch.empty(64 * 1024 * 1024, device=dev)
+        b = torch.empty_like(a)
+        for _ in range(4):
+            _lib.check(_lib.load().fi_calib_copy(_lib.ptr(a), _lib.ptr(b), a.numel(), _lib.current_stream()), "calib")
+        del a, b
+        north_star_roialign(dev, counters_only=True)
+        return None
     if args.pmc_child:
         # profiled under `rocprofv3 --pmc <one counter>`: calibration copies of known size, then the step
         a = torch.empty(64 * 1024 * 1024, device=dev)
@@ -1044,7 +1133,24 @@ def _main():
                                  ("frac_by_B_min", roof_roi["frac"])] + list(roof_roi.items()))
             if world == 1:
                 try:
-                    roof_roi["north_star_shape"] = north_star_roialign(dev)
+                    ns = roof_roi["north_star_shape"] = north_star_roialign(dev)
+                    if not args.no_pmc:
+                        # the memory side of the north star's own launches: FETCH_SIZE / WRITE_SIZE of the two kernels in a
+                        # child that runs only them (calibrated on the copy kernel in the same process, as above)
+                        names = {"channels_last": "crop_fwd_cl_kernel<7, 7", "nchw": "crop_fwd_flat_kernel<7, 7"}
+                        tr2 = pmc_traffic(list(names.values()), [], timeout_s=120, child_flag="--pmc-child-roi")
+                        for lay, sub in names.items():
+                            if lay in ns and sub in tr2:
+                                t_b = tr2[sub]["fetch"] + tr2[sub]["write"]
+                                gbps = t_b / (ns[lay]["avg_launch_us"] * 1e-6) / 1e9
+                                ns[lay].update(traffic=int(t_b), fetch_bytes=int(tr2[sub]["fetch"]), write_bytes=int(tr2[sub]["write"]),
+                                               launches_counted=tr2[sub]["launches"], traffic_GBps=round(gbps, 1),
+                                               frac_hbm_memory_side=round(gbps / HBM_PEAK_GBPS, 4),
+                                               frac_by_B_min=ns[lay]["frac"])
+                        if "error" in tr2:
+                            ns["traffic_error"] = tr2["error"]
+                        elif "calibration" in tr2:
+                            ns["calibration"] = tr2["calibration"]
                 except Exception as ex:
                     roof_roi["north_star_shape"] = {"error": repr(ex)}
         out = {
@@ -1103,6 +1209,11 @@ def _main():
                 out["cpu_baseline"] = cpu_baseline(model, batch, entries, shape_log)
             except Exception as ex:   # the baseline must never take the headline down
                 out["cpu_baseline"] = {"error": repr(ex)}
+            if args.config == "cfg3" and args.conv_precision == "fp32" and not args.dense_backward:
+                try:
+                    out["cpu_baseline_configs0"] = cpu_baseline_configs0(dev)
+                except Exception as ex:
+                    out["cpu_baseline_configs0"] = {"error": repr(ex)}
         result_line = json.dumps(out)
     if world > 1 or force_dp:
         dist.destroy_process_group()

@@ -100,10 +100,13 @@ def describe(name, a):
     if name in ("fi_conv1x1_forward_bf16w",):
         N, Cin, HW, Cout = v[:4]
         return "fwd_bf16w1x1 N%d HW%d Cin%d->Cout%d" % (N, HW, Cin, Cout), 2.0 * N * Cout * HW * Cin
-    if name == "fi_conv2d_weight_grad_batch":          # (x[], dy[], dw[], db[], n, N, Cin, H, W, Cout, R, S, 1, 1, ph, pw, ...)
+    if name in ("fi_conv2d_weight_grad_batch", "fi_conv2d_weight_grad_batch_bf16", "fi_conv2d_weight_grad_batch_f16"):
+        # (x[], dy[], dw[], db[], n, N, Cin, H, W, Cout, R, S, 1, 1, ph, pw, ...) -- the 16-bit entry points take the same
+        # arguments (round 5's cfg5 file had this row at 0.0 TFLOP/s: the script did not know the name)
         n, N, Cin, H, W, Cout, R, S, sh, sw, ph, pw = v[:12]
         fl = 2.0 * n * N * Cout * H * W * Cin * R * S
-        return "wgrad x%d (one launch) N%d %dx%d Cin%d->Cout%d k%dx%d s%d p%d" % (n, N, H, W, Cin, Cout, R, S, sh, ph), fl
+        return "wgrad%s x%d (one launch) N%d %dx%d Cin%d->Cout%d k%dx%d s%d p%d" % (
+            "_bf16" if ("bf16" in name or "f16" in name) else "", n, N, H, W, Cin, Cout, R, S, sh, ph), fl
     name = name.replace("_db_", "_")
     if name in ("fi_conv2d_weight_grad", "fi_conv2d_weight_grad_bf16"):
         N, Cin, H, W, Cout, R, S, sh, sw, ph, pw = v[:11]
