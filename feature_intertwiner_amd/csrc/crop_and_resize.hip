@@ -252,6 +252,51 @@ __global__ __launch_bounds__(kThreads) void crop_fwd_kernel(
 }
 
 // -------------------------------------------------------------------------------------
+// Single-channel maps (the mask-target crop of lib/layers.py:301-322: every positive RoI's 28 x 28 window of its GT
+// mini-mask, depth 1): a thread owns ONE bin of one RoI -- no table, no barrier, no per-workgroup header chain; the
+// RoI x channel-chunk workgroups of crop_fwd_kernel spend their time on the header and the barrier when there is one
+// plane (2048 workgroups of 784 outputs: 94 us alone on the chip, round 5).  Same make_tap, same lerp order:
+// bit-identical to crop_fwd_kernel.
+// -------------------------------------------------------------------------------------
+template <int CH, int CW>
+__global__ __launch_bounds__(kThreads) void crop_fwd_c1_kernel(LevelSet ls, const float *__restrict__ boxes,
+                                                               const int *__restrict__ box_ind, const int *__restrict__ level,
+                                                               int num_boxes, int batch, int crop_h_rt, int crop_w_rt,
+                                                               float extrap, float *__restrict__ crops, int *__restrict__ status)
+{
+    const int crop_h = CH ? CH : crop_h_rt;
+    const int crop_w = CW ? CW : crop_w_rt;
+    const int bins = crop_h * crop_w;
+    const long idx = (long)blockIdx.x * kThreads + threadIdx.x;
+    if (idx >= (long)num_boxes * bins) return;
+    const int box = (int)(idx / bins);
+    const int bin = (int)(idx - (long)box * bins);
+    const int y = bin / crop_w, x = bin - y * crop_w;
+    BoxHeader h;
+    if (!load_box(ls, boxes, box_ind, level, box, batch, h)) {
+        if (level && level[box] == -1) return;
+        crops[idx] = 0.0f;
+        if (status && bin == 0) atomicOr(status, 1);
+        return;
+    }
+    const Tap ty = make_tap(h.y1, h.y2, h.H, crop_h, y);
+    const Tap tx = make_tap(h.x1, h.x2, h.W, crop_w, x);
+    if (!(ty.valid & tx.valid)) {
+        crops[idx] = extrap;
+        return;
+    }
+    const float *__restrict__ p = ls.img[h.lvl] + (size_t)h.img * h.H * h.W;
+    const int r0 = ty.i0 * h.W, r1 = ty.i1 * h.W;
+    const float tl = p[r0 + tx.i0], tr = p[r0 + tx.i1], bl = p[r1 + tx.i0], br = p[r1 + tx.i1];
+    const float dt = tr - tl;
+    const float top = tl + dt * tx.frac;
+    const float db = br - bl;
+    const float bot = bl + db * tx.frac;
+    const float dv = bot - top;
+    crops[idx] = top + dv * ty.frac;
+}
+
+// -------------------------------------------------------------------------------------
 // Table-free forward for small crops (7 x 7): a thread owns ONE bin of one RoI for CG consecutive channels.
 // No LDS, no barrier, no per-workgroup header chain: the flat thread index runs over (channel group, RoI, bin),
 // the two sampling coordinates are computed per thread (two make_tap() -- ~70 VALU amortised over CG outputs), the
@@ -1226,6 +1271,15 @@ int forward_impl(const LevelSet &ls, const float *boxes, const int32_t *box_ind,
                            boxes, box_ind, level, num_boxes, batch, depth, extrap, groups_per_xcd, crops, status);
         FI_HIP_CHECK(hipGetLastError());
         return FI_OK;
+    }
+    if (depth == 1 && !getenv("FI_CROP_NO_C1")) {
+        // one plane per map (the GT-mask crop): a thread per bin
+        const long nb = ((long)num_boxes * crop_h * crop_w + kThreads - 1) / kThreads;
+        FI_REQUIRE(nb < 2147483647L, "grid too large");
+        fi::ProfScope prof(FI_K_CROP_FWD_7X7 + size_class(crop_h, crop_w), st);
+        return launch_sized(crop_h, crop_w, crop_fwd_c1_kernel<7, 7>, crop_fwd_c1_kernel<14, 14>, crop_fwd_c1_kernel<28, 28>,
+                            crop_fwd_c1_kernel<0, 0>, dim3((unsigned)nb), st, ls, boxes, box_ind, level, num_boxes, batch, crop_h,
+                            crop_w, extrap, crops, status);
     }
     int cpb, chunks;
     pick_fwd_chunks(depth, &cpb, &chunks);

@@ -359,3 +359,30 @@ def test_crop_grad_group_shares_buffers_within_one_backward_pass_only(channels_l
         tol = 2e-5 * (r.abs().max().item() + 1e-6)           # fp32 atomics: the order of the additions differs
         assert (a - r).abs().max().item() <= tol
         assert (b - 2 * r).abs().max().item() <= 2 * tol
+
+
+@pytest.mark.parametrize("crop", [(28, 28), (7, 7), (14, 14), (5, 3), (1, 1)])
+def test_single_channel_maps_bit_exact(oracle, crop):
+    """depth 1 (the mask-target crop, lib/layers.py:301-322) takes crop_fwd_c1_kernel (a thread per bin): bit-identical to the
+    oracle on adversarial boxes, both extrapolation values, bad box indices flagged and zero-filled."""
+    from feature_intertwiner_amd import _lib
+    rs = np.random.RandomState(77)
+    for (B, H, W) in ((5, 56, 56), (3, 37, 91), (2, 2, 2)):
+        image = rs.standard_normal((B, 1, H, W)).astype(np.float32)
+        boxes = adversarial_boxes(rs, 211, max(H, 9), max(W, 9))
+        ind = rs.randint(0, B, boxes.shape[0]).astype(np.int32)
+        for extrap in (0.0, 2.5):
+            exp = oracle.crop_and_resize_forward(image, boxes, ind, crop[0], crop[1], extrap)
+            got = _fwd(image, boxes, ind, crop[0], crop[1], extrap)
+            assert np.array_equal(_bits(got), _bits(exp)), (crop, H, W, extrap)
+    L = _lib.load()
+    image = torch.from_numpy(rs.standard_normal((2, 1, 16, 16)).astype(np.float32)).to(DEV)
+    boxes = torch.tensor([[0.1, 0.1, 0.5, 0.5]] * 3, device=DEV)
+    ind = torch.tensor([0, 7, -1], device=DEV, dtype=torch.int32)
+    crops = torch.full((3, 1, 28, 28), 9.0, device=DEV)
+    status = torch.zeros(1, device=DEV, dtype=torch.int32)
+    _lib.check(L.fi_crop_and_resize_forward(_lib.ptr(image), _lib.ptr(boxes), _lib.ptr(ind), 3, 2, 1, 16, 16, 28, 28, 0.0,
+                                            _lib.ptr(crops), _lib.ptr(status), _lib.current_stream()), "fwd")
+    torch.cuda.synchronize()
+    assert status.item() == 1 and crops[1].abs().max().item() == 0 and crops[2].abs().max().item() == 0
+    assert crops[0].abs().max().item() > 0
