@@ -28,6 +28,13 @@ constexpr int kDChunk = 16;   // feature columns staged per pass (D > 1)
 constexpr int kStride = 260;  // LDS row stride of the staged, transposed chunk
 #define FI_OT_EPS 1e-20f
 
+// v (DPP-moved) with zero where the control selects no source lane
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_mov(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, true));
+}
+
 struct Smem {
     float a[kMaxS];
     float b[kMaxS];
@@ -173,12 +180,20 @@ __global__ __launch_bounds__(kThreads) void sinkhorn_kernel(const float *__restr
                 for (int c = 0; c < kT; ++c) s = fmaf(K[r][c], bv[c], s);
                 part[r] = s;
             }
-            // reduce over the 32 lanes sharing this row tile (xor 1..16 stays in the half)
+            // reduce over the 32 lanes sharing this row tile: DPP row shifts inside the 16-lane rows, then row_bcast:15 folds
+            // row 0 into row 1 (and 2 into 3) -- the sum lands in lane 31 of each half.  (Round 5 used five rounds of
+            // __shfl_xor = 40 ds_bpermute per half-iteration through the LDS crossbar.)
 #pragma unroll
-            for (int off = 1; off < 32; off <<= 1)
-#pragma unroll
-                for (int r = 0; r < kT; ++r) part[r] += __shfl_xor(part[r], off, 64);
-            if (tj == 0) {
+            for (int r = 0; r < kT; ++r) {
+                float v = part[r];
+                v += dpp_mov<0x111, 0xF>(v);      // row_shr:1
+                v += dpp_mov<0x112, 0xF>(v);      // row_shr:2
+                v += dpp_mov<0x114, 0xF>(v);      // row_shr:4
+                v += dpp_mov<0x118, 0xF>(v);      // row_shr:8
+                v += dpp_mov<0x142, 0xA>(v);      // row_bcast:15 into rows 1 and 3
+                part[r] = v;
+            }
+            if (tj == 31) {
 #pragma unroll
                 for (int r = 0; r < kT; ++r) {
                     const int i = ti * kT + r;
@@ -201,7 +216,10 @@ __global__ __launch_bounds__(kThreads) void sinkhorn_kernel(const float *__restr
                 part[c] = s;
             }
 #pragma unroll
-            for (int c = 0; c < kT; ++c) part[c] += __shfl_xor(part[c], 32, 64);
+            for (int c = 0; c < kT; ++c) {          // lane l + lane l^32 in every lane (v_permlane32_swap: no LDS crossbar)
+                const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_int(part[c]), __float_as_int(part[c]), false, false);
+                part[c] = __int_as_float(sw[0]) + __int_as_float(sw[1]);
+            }
             if (lane < 32) {
 #pragma unroll
                 for (int c = 0; c < kT; ++c) sm.red[wave][tj * kT + c] = part[c];
