@@ -63,3 +63,13 @@ timeout 100 python scripts/rpn_target_probe.py 2>&1 | grep prepare > $O/${R}_rpn
 (timeout 100 python scripts/pyr_bwd_probe.py; FI_CROP_BWD_SCATTER=1 timeout 100 python scripts/pyr_bwd_probe.py) 2>&1 | grep NCHW > $O/${R}_pyr_bwd_probe.txt
 scripts/micro/bin/lds_atomic_rate > $O/${R}_lds_atomic_rate.txt 2>&1
 ls -la $O | tail -50
+# round 6: the 1x1 ring kernel's development harness (library kernel vs ring variants, decomposition experiments), the patch
+# kernel alone on the chip by tile count and by reduction length (fixed cost per launch), what sits on the main stream besides
+# the MFMA kernels, the ReLU-boundary events of the backward-form comparison with their evidence
+( export LD_LIBRARY_PATH=$GRAFT_REPO_ROOT/feature_intertwiner_amd; V2_ONLY=1 timeout 300 scripts/micro/bin/conv1x1_ring > $O/${R}_ring_harness.txt 2>&1 )
+timeout 200 python scripts/patch_probe.py 2>&1 | grep "^{" > $O/${R}_patch_probe.txt
+timeout 200 python scripts/patch_k_probe.py 2>&1 | grep "^{" >> $O/${R}_patch_probe.txt
+timeout 300 python scripts/main_stream_report.py 2>&1 | grep -v "Warning\|amdgpu\|_warn_once" > $O/${R}_main_stream.txt
+timeout 300 python scripts/main_stream_report.py --batch 2 2>&1 | grep -v "Warning\|amdgpu\|_warn_once" > $O/${R}_main_stream_2img_per_gpu.txt
+timeout 400 python scripts/relu_boundary_probe.py 8 --mask 2>&1 | grep "^{" > $O/${R}_relu_boundary_probe.txt
+ls -la $O | tail -20
