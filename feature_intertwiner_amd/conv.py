@@ -927,6 +927,9 @@ def _prepare_step(model, grad_on):
     plan = _PLAN.get(model)
     ptrs = tuple(p.data_ptr() for p in model.parameters())
     if plan is None or plan["ptrs"] != ptrs or plan["layout"].superseded:
+        if plan is not None:
+            for k in plan.get("wf_keys", ()):          # the replaced plan's fragment-major copies
+                _WF.pop(k, None)
         convs = [m for m in model.modules() if isinstance(m, Conv2d) and not m.full_window]
         for m in convs:
             w = m.weight
@@ -1015,12 +1018,16 @@ def _prepare_step(model, grad_on):
                                                    _lib.current_stream()), "fi_weight_transpose_batch")
         for m, wt, sp in zip(plan["tr"], plan["wts"], sig):
             _WT[m.weight.data_ptr()] = (wt, m.weight._version, sp != 0)
+        keys = []
         for m, kind, t, ti in plan["frag"]:
             # forward: keyed by the parameter; data gradient: keyed by the W^T tensor _conv_fwd is handed
             if kind == "fwd":
-                _WF[m.weight.data_ptr()] = (t, m.weight._version, tuple(m.weight.shape[:2]))
+                keys.append(m.weight.data_ptr())
+                _WF[keys[-1]] = (t, m.weight._version, tuple(m.weight.shape[:2]))
             else:
-                _WF[plan["wts"][ti].data_ptr()] = (t, None, (m.weight.shape[1], m.weight.shape[0]))
+                keys.append(plan["wts"][ti].data_ptr())
+                _WF[keys[-1]] = (t, None, (m.weight.shape[1], m.weight.shape[0]))
+        plan["wf_keys"] = keys
         plan["versions"] = versions
         _WB.clear()          # the W^T tensors were rewritten in place (no version bump): drop their bf16 copies
     if _PRECISION in _LOWP:
