@@ -508,22 +508,33 @@ def graph_ab_two_images(model, opt, dev, image_size, train_step, steps=8):
         return (time.perf_counter() - t) / steps * 1e3
     out = {}
     try:
+        for _ in range(3):                  # (the caching allocator's pools are per stream: warm the one that is timed)
+            step2()
+        ms_e = timed(step2)
+        out["eager"] = dict(ms_per_step=round(ms_e, 3), **issue_profile(step2, dev, ms_e))
         s = torch.cuda.Stream(device=dev)
         s.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(s):
             for _ in range(3):
                 step2()
         torch.cuda.current_stream(dev).wait_stream(s)
-        ms_e = timed(step2)
-        out["eager"] = dict(ms_per_step=round(ms_e, 3), **issue_profile(step2, dev, ms_e))
         g = torch.cuda.CUDAGraph()
         for gen in (model.generator, model.external_proposals.gen):
             g.register_generator_state(gen)
         with torch.cuda.graph(g, stream=s):
             step2()
         torch.cuda.synchronize(dev)
+        timed(g.replay)
         ms_g = timed(g.replay)
-        out["graph_replay"] = dict(ms_per_step=round(ms_g, 3), **issue_profile(g.replay, dev, ms_g))
+        host = []
+        for _ in range(3):
+            torch.cuda.synchronize(dev)
+            t = time.perf_counter()
+            g.replay()
+            host.append(time.perf_counter() - t)
+        torch.cuda.synchronize(dev)
+        # (no busy / idle figures for the replay: the tracer does not see every kernel node of a graph launch)
+        out["graph_replay"] = {"ms_per_step": round(ms_g, 3), "host_issue_ms_per_step": round(min(host) * 1e3, 2)}
         del g
     except Exception as ex:           # a capture failure must not take the headline line with it
         out["error"] = repr(ex)
@@ -673,6 +684,8 @@ def _main():
                          "schedule as one JSON line")
     ap.add_argument("--profile-steps", type=int, default=4,
                     help="extra steps AFTER the timed region, run with in-library HIP-event timing for the roofline objects")
+    ap.add_argument("--no-issue-profile", action="store_true",
+                    help="skip the host-issue / GPU-busy pass and the 2-image eager-vs-hipGraph A/B (runs traced from outside)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--pmc-child-roi", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--mask-head-on-positive-slots", action="store_true",
@@ -817,10 +830,11 @@ def _main():
         sync.check()               # replicas stayed consistent (host sync, outside the timed region)
     # ---- host issue time / GPU busy and idle time / launches per step, this rank (outside the timed region) ----------
     issue = None
-    try:
-        issue = issue_profile(step, dev, elapsed / args.steps * 1e3)
-    except Exception as ex:
-        issue = {"error": repr(ex)}
+    if not args.no_issue_profile:
+        try:
+            issue = issue_profile(step, dev, elapsed / args.steps * 1e3)
+        except Exception as ex:
+            issue = {"error": repr(ex)}
     # ---- a separate profiled pass for the roofline objects (HIP events around every library kernel) --
     prof_steps = max(1, args.profile_steps)
     _lib.prof_reset()
@@ -909,7 +923,7 @@ def _main():
             cfg4_slice = {"error": repr(ex)}
     graph_ab = None
     if world == 1 and sync is None and args.config == "cfg3" and not args.no_dense_reference and not args.dense_backward and \
-            args.conv_precision == "fp32" and args.batch_per_gpu != 2:
+            args.conv_precision == "fp32" and args.batch_per_gpu != 2 and not args.no_issue_profile:
         graph_ab = graph_ab_two_images(model, opt, dev, args.image_size, train_step)
     per_rank_ms, rccl_ranks, overlap = None, None, None
     if sync is not None and not share:

@@ -111,6 +111,10 @@ SIGNATURES = {
     "fi_conv1x1_forward_bf16w": (c_int, [c_void_p] * 6 + [c_int] * 5 + [c_void_p]),
     "fi_proposal_candidates": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                        ctypes.POINTER(c_float), c_float, c_float, c_void_p, c_void_p]),
+    "fi_proposal_workspace_bytes": (ctypes.c_size_t, [c_int]),
+    "fi_proposal_candidates_ws": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                          ctypes.POINTER(c_float), c_float, c_float, c_void_p, c_void_p, ctypes.c_size_t,
+                                          c_void_p]),
     "fi_proposal_gather": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_float, c_float,
                                    c_void_p, c_void_p]),
     "fi_conv2d_forward_gated": (c_int, [c_void_p] * 7 + [c_int] * 16 + [c_void_p]),

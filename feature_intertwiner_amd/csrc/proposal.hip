@@ -80,6 +80,50 @@ __device__ __forceinline__ void find_digit(int *hist, int nbins, int want, int *
     __syncthreads();
 }
 
+// decode + clip of the K sorted winners (tools/box_utils.py:7-60, each operation rounded separately)
+__device__ __forceinline__ void decode_rows(const SelectArgs &a, int img, const u64 *s_keys)
+{
+    const int tid = threadIdx.x;
+    const int K = a.K;
+    float *out = a.dets + (size_t)img * K * 5;
+    for (int r = tid; r < K; r += kSelThreads) {
+        const int i = (int)(unsigned)(s_keys[r] & 0xffffffffull);
+        float y1, x1, y2, x2, sc;
+        if (i < a.E) {
+            const float *e = a.extra + ((size_t)img * a.E + i) * 5;
+            y1 = e[0]; x1 = e[1]; y2 = e[2]; x2 = e[3]; sc = e[4];
+        } else {
+            const int an = i - a.E;
+            const float4 b = *reinterpret_cast<const float4 *>(a.anchors + 4 * (size_t)an);
+            const float4 d = *reinterpret_cast<const float4 *>(a.deltas + ((size_t)img * a.A + an) * 4);
+            sc = a.probs[((size_t)img * a.A + an) * a.prob_stride + a.prob_off];
+            const float d0 = d.x * a.std0, d1 = d.y * a.std1, d2 = d.z * a.std2, d3 = d.w * a.std3;
+            float height = b.z - b.x;
+            float width = b.w - b.y;
+            float cy = b.x + 0.5f * height;
+            float cx = b.y + 0.5f * width;
+            cy = cy + d0 * height;
+            cx = cx + d1 * width;
+            height = height * expf(d2);
+            width = width * expf(d3);
+            y1 = cy - 0.5f * height;
+            x1 = cx - 0.5f * width;
+            y2 = y1 + height;
+            x2 = x1 + width;
+        }
+        // clamp(min, max) = min(max(v, lo), hi), NaN propagates as in torch.clamp
+        y1 = fminf(fmaxf(y1, 0.0f), a.win_h);
+        x1 = fminf(fmaxf(x1, 0.0f), a.win_w);
+        y2 = fminf(fmaxf(y2, 0.0f), a.win_h);
+        x2 = fminf(fmaxf(x2, 0.0f), a.win_w);
+        out[r * 5 + 0] = y1;
+        out[r * 5 + 1] = x1;
+        out[r * 5 + 2] = y2;
+        out[r * 5 + 3] = x2;
+        out[r * 5 + 4] = sc;
+    }
+}
+
 __global__ __launch_bounds__(kSelThreads) void proposal_select_kernel(SelectArgs a)
 {
     extern __shared__ u64 s_keys[];                      // kSortCap keys; the histogram aliases its start
@@ -200,44 +244,203 @@ __global__ __launch_bounds__(kSelThreads) void proposal_select_kernel(SelectArgs
         }
     }
 
-    // ---- 4. decode + clip (tools/box_utils.py:7-60, each operation rounded separately) ------------------------
-    float *out = a.dets + (size_t)img * K * 5;
-    for (int r = tid; r < K; r += kSelThreads) {
-        const int i = (int)(unsigned)(s_keys[r] & 0xffffffffull);
-        float y1, x1, y2, x2, sc;
-        if (i < a.E) {
-            const float *e = a.extra + ((size_t)img * a.E + i) * 5;
-            y1 = e[0]; x1 = e[1]; y2 = e[2]; x2 = e[3]; sc = e[4];
-        } else {
-            const int an = i - a.E;
-            const float4 b = *reinterpret_cast<const float4 *>(a.anchors + 4 * (size_t)an);
-            const float4 d = *reinterpret_cast<const float4 *>(a.deltas + ((size_t)img * a.A + an) * 4);
-            sc = a.probs[((size_t)img * a.A + an) * a.prob_stride + a.prob_off];
-            const float d0 = d.x * a.std0, d1 = d.y * a.std1, d2 = d.z * a.std2, d3 = d.w * a.std3;
-            float height = b.z - b.x;
-            float width = b.w - b.y;
-            float cy = b.x + 0.5f * height;
-            float cx = b.y + 0.5f * width;
-            cy = cy + d0 * height;
-            cx = cx + d1 * width;
-            height = height * expf(d2);
-            width = width * expf(d3);
-            y1 = cy - 0.5f * height;
-            x1 = cx - 0.5f * width;
-            y2 = y1 + height;
-            x2 = x1 + width;
+    decode_rows(a, img, s_keys);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The same selection as proposal_select_kernel in EIGHT small launches (round 6, fi_proposal_candidates_ws): the single
+// kernel is one workgroup per image that walks the 261 888 scores four times -- 4 workgroups on 256 CUs, ~310 us, memory
+// latency per iteration on ONE CU each.  Here the three radix passes and the compaction run on kHistWgs workgroups per
+// image with the state in a caller-provided workspace; only the sort + decode stays one workgroup per image.  The result
+// is the same: the final order comes from the sort of (score, index) keys, not from the arrival order of the atomics.
+//   per image:  hist[2048] | state {prefix, mask, want, count_eq, n_cand, n_tie, T, need_eq} | cand[8192] | tie[8192]
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int kHistWgs = 32;              // workgroups per image of the multi-workgroup passes
+constexpr int kHistThreads = 256;
+struct SelState {
+    unsigned prefix, mask;
+    int want, count_eq, n_cand, n_tie;
+    unsigned T;
+    int need_eq;
+};
+constexpr size_t kWsHist = sizeof(int) * kBins;
+constexpr size_t kWsState = 64;           // >= sizeof(SelState), keeps the key arrays 16-byte aligned
+constexpr size_t kWsKeys = sizeof(u64) * kSortCap;
+constexpr size_t kWsPerImage = kWsHist + kWsState + 2 * kWsKeys;
+
+__device__ __forceinline__ int *ws_hist(char *ws, int img) { return reinterpret_cast<int *>(ws + (size_t)img * kWsPerImage); }
+__device__ __forceinline__ SelState *ws_state(char *ws, int img)
+{
+    return reinterpret_cast<SelState *>(ws + (size_t)img * kWsPerImage + kWsHist);
+}
+__device__ __forceinline__ u64 *ws_cand(char *ws, int img)
+{
+    return reinterpret_cast<u64 *>(ws + (size_t)img * kWsPerImage + kWsHist + kWsState);
+}
+__device__ __forceinline__ u64 *ws_tie(char *ws, int img) { return ws_cand(ws, img) + kSortCap; }
+
+// pass p of the radix select: histogram of digit p of the keys that match the prefix so far
+__global__ __launch_bounds__(kHistThreads) void proposal_hist_kernel(SelectArgs a, char *__restrict__ ws, int pass)
+{
+    __shared__ int s_hist[kBins];
+    const int img = blockIdx.y, tid = threadIdx.x;
+    const int total = a.A + a.E;
+    const int shifts[3] = {21, 10, 0};
+    const int widths[3] = {11, 11, 10};
+    const int nb = 1 << widths[pass], sh = shifts[pass];
+    const SelState st = *ws_state(ws, img);
+    const unsigned prefix = pass ? st.prefix : 0u, pmask = pass ? st.mask : 0u;
+    for (int i = tid; i < nb; i += kHistThreads) s_hist[i] = 0;
+    __syncthreads();
+    const int per = (total + kHistWgs - 1) / kHistWgs;
+    const int lo = blockIdx.x * per, hi = min(total, lo + per);
+    for (int i0 = lo + tid; i0 < hi; i0 += 4 * kHistThreads) {
+        float sc4[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * kHistThreads;
+            sc4[u] = i < hi ? score_of(a, img, i) : 0.0f;
         }
-        // clamp(min, max) = min(max(v, lo), hi), NaN propagates as in torch.clamp
-        y1 = fminf(fmaxf(y1, 0.0f), a.win_h);
-        x1 = fminf(fmaxf(x1, 0.0f), a.win_w);
-        y2 = fminf(fmaxf(y2, 0.0f), a.win_h);
-        x2 = fminf(fmaxf(x2, 0.0f), a.win_w);
-        out[r * 5 + 0] = y1;
-        out[r * 5 + 1] = x1;
-        out[r * 5 + 2] = y2;
-        out[r * 5 + 3] = x2;
-        out[r * 5 + 4] = sc;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (i0 + u * kHistThreads >= hi) break;
+            const unsigned k = sortable(sc4[u]);
+            if ((k & pmask) == prefix) atomicAdd(&s_hist[(k >> sh) & (nb - 1)], 1);
+        }
     }
+    __syncthreads();
+    int *g = ws_hist(ws, img);
+    for (int i = tid; i < nb; i += kHistThreads) {
+        const int c = s_hist[i];
+        if (c) atomicAdd(&g[i], c);
+    }
+}
+
+// after pass p: the digit that holds the K-th largest key; the state moves on; the histogram is cleared for the next pass
+__global__ __launch_bounds__(kSelThreads) void proposal_digit_kernel(SelectArgs a, char *__restrict__ ws, int pass)
+{
+    __shared__ int s_hist[kBins];
+    __shared__ int s_wave[kSelThreads / 64];
+    __shared__ int s_out[2];
+    const int img = blockIdx.x, tid = threadIdx.x;
+    const int shifts[3] = {21, 10, 0};
+    const int widths[3] = {11, 11, 10};
+    const int nb = 1 << widths[pass];
+    int *g = ws_hist(ws, img);
+    SelState *st = ws_state(ws, img);
+    for (int i = tid; i < kBins; i += kSelThreads) {
+        s_hist[i] = i < nb ? g[i] : 0;
+        g[i] = 0;
+    }
+    __syncthreads();
+    const int want = pass ? st->want : a.K;
+    find_digit(s_hist, nb, want, s_wave, s_out);
+    if (tid == 0) {
+        const int d = s_out[0];
+        const unsigned prefix = (pass ? st->prefix : 0u) | ((unsigned)d << shifts[pass]);
+        st->prefix = prefix;
+        st->mask = (pass ? st->mask : 0u) | ((unsigned)(nb - 1) << shifts[pass]);
+        st->want = want - s_out[1];
+        st->count_eq = s_hist[d];
+        if (pass == 2) {
+            st->T = prefix;
+            st->need_eq = want - s_out[1];
+        }
+    }
+}
+
+// keys above the threshold go to cand[], keys equal to it to tie[] (used when every tie is a winner)
+__global__ __launch_bounds__(kHistThreads) void proposal_compact_kernel(SelectArgs a, char *__restrict__ ws)
+{
+    const int img = blockIdx.y, tid = threadIdx.x;
+    const int total = a.A + a.E;
+    SelState *st = ws_state(ws, img);
+    const unsigned T = st->T;
+    u64 *cand = ws_cand(ws, img), *tie = ws_tie(ws, img);
+    const int per = (total + kHistWgs - 1) / kHistWgs;
+    const int lo = blockIdx.x * per, hi = min(total, lo + per);
+    for (int base = lo; base < hi; base += kHistThreads) {          // (uniform trip count: the ballots see whole wavefronts)
+        const int i = base + tid;
+        const bool in = i < hi;
+        const unsigned k = in ? sortable(score_of(a, img, i)) : 0u;
+        const bool above = in && k > T, eq = in && k == T;
+        const u64 b_above = __ballot(above), b_eq = __ballot(eq);
+        const int lane = tid & 63;
+        if (b_above) {
+            int base_pos = 0;
+            if (lane == 0) base_pos = atomicAdd(&st->n_cand, __popcll(b_above));
+            base_pos = __shfl(base_pos, 0, 64);
+            if (above) cand[base_pos + __popcll(b_above & ((1ull << lane) - 1ull))] = ((u64)(~k) << 32) | (unsigned)i;
+        }
+        if (b_eq) {
+            int base_pos = 0;
+            if (lane == 0) base_pos = atomicAdd(&st->n_tie, __popcll(b_eq));
+            base_pos = __shfl(base_pos, 0, 64);
+            const int pos = base_pos + __popcll(b_eq & ((1ull << lane) - 1ull));
+            if (eq && pos < kSortCap) tie[pos] = ((u64)(~k) << 32) | (unsigned)i;
+        }
+    }
+}
+
+// one workgroup per image: winners into LDS, ties, bitonic sort, decode + clip (as proposal_select_kernel's steps 2b-4)
+__global__ __launch_bounds__(kSelThreads) void proposal_sort_kernel(SelectArgs a, char *__restrict__ ws)
+{
+    extern __shared__ u64 s_keys[];
+    __shared__ int s_wave[kSelThreads / 64];
+    const int tid = threadIdx.x;
+    const int img = blockIdx.x;
+    const int total = a.A + a.E;
+    const int K = a.K;
+    const SelState st = *ws_state(ws, img);
+    const unsigned T = st.T;
+    const int need_eq = st.need_eq, n_above = K - need_eq;
+    const u64 *cand = ws_cand(ws, img), *tie = ws_tie(ws, img);
+    for (int i = tid; i < n_above; i += kSelThreads) s_keys[i] = cand[i];
+    const bool all_ties = (st.count_eq == need_eq);
+    if (all_ties) {
+        for (int i = tid; i < need_eq; i += kSelThreads) s_keys[n_above + i] = tie[i];
+    }
+    __syncthreads();
+    if (!all_ties) {
+        // more keys equal to T than places left: the lowest indices win (walk the indices in order, stop when filled)
+        int taken = 0;
+        for (int base = 0; base < total && taken < need_eq; base += kSelThreads) {
+            const int i = base + tid;
+            const bool is_eq = i < total && sortable(score_of(a, img, i)) == T;
+            const u64 ballot = __ballot(is_eq);
+            const int lane = tid & 63, wave = tid >> 6;
+            const int in_wave = __popcll(ballot & ((1ull << lane) - 1ull));
+            if (lane == 0) s_wave[wave] = __popcll(ballot);
+            __syncthreads();
+            int before = 0, chunk = 0;
+            for (int w = 0; w < kSelThreads / 64; ++w) {
+                const int c = s_wave[w];
+                if (w < wave) before += c;
+                chunk += c;
+            }
+            const int rank = taken + before + in_wave;
+            if (is_eq && rank < need_eq) s_keys[n_above + rank] = ((u64)(~T) << 32) | (unsigned)i;
+            taken += chunk;
+            __syncthreads();
+        }
+    }
+    int n2 = 1;
+    while (n2 < K) n2 <<= 1;
+    for (int i = K + tid; i < n2; i += kSelThreads) s_keys[i] = ~0ull;
+    __syncthreads();
+    for (int size = 2; size <= n2; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int t = tid; t < (n2 >> 1); t += kSelThreads) {
+                const int lo = ((t / stride) * stride * 2) + (t % stride);
+                const int hi = lo + stride;
+                const bool up = ((lo & size) == 0);
+                const u64 x = s_keys[lo], y = s_keys[hi];
+                if ((x > y) == up) { s_keys[lo] = y; s_keys[hi] = x; }
+            }
+            __syncthreads();
+        }
+    }
+    decode_rows(a, img, s_keys);
 }
 
 // proposals[b][j] = j < num[b] ? dets[b][keep[b][j]][0:4] / (h, w, h, w) : 0   (lib/layers.py:131-137)
@@ -295,6 +498,54 @@ int fi_proposal_candidates(const float *probs, int prob_stride, int prob_offset,
     }
     fi::ProfScope prof(FI_K_PROPOSAL_SELECT, (hipStream_t)stream);
     hipLaunchKernelGGL(proposal_select_kernel, dim3(batch), dim3(kSelThreads), lds, (hipStream_t)stream, a);
+    FI_HIP_CHECK(hipGetLastError());
+    return FI_OK;
+}
+
+size_t fi_proposal_workspace_bytes(int batch) { return batch <= 0 ? 0 : (size_t)batch * kWsPerImage; }
+
+int fi_proposal_candidates_ws(const float *probs, int prob_stride, int prob_offset, const float *deltas,
+                              const float *anchors, const float *extra, int batch, int num_anchors, int num_extra,
+                              int pre_nms, const float *bbox_std_host, float window_h, float window_w, float *dets,
+                              void *workspace, size_t workspace_bytes, fi_stream_t stream)
+{
+    FI_REQUIRE(batch >= 0 && num_anchors >= 0 && num_extra >= 0, "sizes must be non-negative");
+    FI_REQUIRE(pre_nms >= 1 && pre_nms <= kSortCap, "1 <= pre_nms <= 8192");
+    FI_REQUIRE((long)num_anchors + num_extra >= pre_nms, "fewer candidates than pre_nms");
+    FI_REQUIRE(prob_stride >= 1 && prob_offset >= 0 && prob_offset < prob_stride, "bad score stride / offset");
+    FI_REQUIRE(bbox_std_host && dets && (num_anchors == 0 || (probs && deltas && anchors)), "null pointer");
+    FI_REQUIRE(num_extra == 0 || extra, "null extra candidates");
+    FI_REQUIRE(((uintptr_t)anchors | (uintptr_t)deltas) % 16 == 0, "anchors / deltas must be 16-byte aligned");
+    if (batch == 0) return FI_OK;
+    FI_REQUIRE(workspace && (uintptr_t)workspace % 16 == 0 && workspace_bytes >= fi_proposal_workspace_bytes(batch),
+               "workspace: fi_proposal_workspace_bytes(batch) bytes, 16-byte aligned");
+    SelectArgs a;
+    a.probs = probs; a.deltas = deltas; a.anchors = anchors; a.extra = extra; a.dets = dets;
+    a.A = num_anchors; a.E = num_extra; a.K = pre_nms; a.prob_stride = prob_stride; a.prob_off = prob_offset;
+    a.std0 = bbox_std_host[0]; a.std1 = bbox_std_host[1]; a.std2 = bbox_std_host[2]; a.std3 = bbox_std_host[3];
+    a.win_h = window_h; a.win_w = window_w;
+    hipStream_t st = (hipStream_t)stream;
+    char *ws = static_cast<char *>(workspace);
+    const size_t lds = sizeof(u64) * kSortCap;
+    static std::atomic<unsigned long long> attr_set{0};
+    int dev = 0;
+    FI_HIP_CHECK(hipGetDevice(&dev));
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(attr_set.load(std::memory_order_acquire) & bit)) {
+        FI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(proposal_sort_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set.fetch_or(bit, std::memory_order_release);
+    }
+    fi::ProfScope prof(FI_K_PROPOSAL_SELECT, st);
+    // histogram + state of every image: one strided clear (the key arrays need none)
+    FI_HIP_CHECK(hipMemset2DAsync(ws, kWsPerImage, 0, kWsHist + kWsState, (size_t)batch, st));
+    const dim3 wide(kHistWgs, batch);
+    for (int pass = 0; pass < 3; ++pass) {
+        hipLaunchKernelGGL(proposal_hist_kernel, wide, dim3(kHistThreads), 0, st, a, ws, pass);
+        hipLaunchKernelGGL(proposal_digit_kernel, dim3(batch), dim3(kSelThreads), 0, st, a, ws, pass);
+    }
+    hipLaunchKernelGGL(proposal_compact_kernel, wide, dim3(kHistThreads), 0, st, a, ws);
+    hipLaunchKernelGGL(proposal_sort_kernel, dim3(batch), dim3(kSelThreads), lds, st, a, ws);
     FI_HIP_CHECK(hipGetLastError());
     return FI_OK;
 }

@@ -101,6 +101,9 @@ def bbox_overlaps(boxes1, boxes2):
 # proposal layer (lib/layers.py:71-139)
 # --------------------------------------------------------------------------------------
 PRE_NMS_KERNEL_LIMIT = 8192       # fi_proposal_candidates sorts its winners in 64 KB of LDS
+import os as _os
+PROPOSAL_MULTI_WG = _os.environ.get("FI_PROPOSAL_MULTI_WG", "1") != "0"      # A/B switch: fi_proposal_candidates_ws
+_PROPOSAL_WS = {}                 # device -> workspace of the multi-workgroup selection (one per device; stream-ordered use)
 
 
 def _proposal_candidates_tensors(probs, deltas, anchors, extra_dets, pre_nms_limit, std, height, width):
@@ -172,9 +175,22 @@ def proposal_layer(inputs, proposal_count, nms_threshold, priors, config, extra_
         dets = torch.empty((b, pre_nms_limit, 5), device=probs.device, dtype=torch.float32)
         std = (ctypes.c_float * 4)(*[float(v) for v in config.DATA.BBOX_STD_DEV])
         with torch.cuda.device(probs.device):
-            _lib.check(L.fi_proposal_candidates(_lib.ptr(probs), probs.size(2), 1, _lib.ptr(deltas), _lib.ptr(anchors),
-                                                _lib.ptr(extra_dets), b, A, E, pre_nms_limit, std, height, width,
-                                                _lib.ptr(dets), _lib.current_stream()), "fi_proposal_candidates")
+            if PROPOSAL_MULTI_WG:
+                # eight small launches with the state in a workspace (32 workgroups per image for the radix passes and the
+                # compaction) instead of one workgroup per image walking every score four times
+                need = int(L.fi_proposal_workspace_bytes(b))
+                ws = _PROPOSAL_WS.get(probs.device)
+                if ws is None or ws.numel() < need:
+                    ws = _PROPOSAL_WS[probs.device] = torch.empty(need, device=probs.device, dtype=torch.uint8)
+                ws.record_stream(torch.cuda.current_stream(probs.device))
+                _lib.check(L.fi_proposal_candidates_ws(_lib.ptr(probs), probs.size(2), 1, _lib.ptr(deltas), _lib.ptr(anchors),
+                                                       _lib.ptr(extra_dets), b, A, E, pre_nms_limit, std, height, width,
+                                                       _lib.ptr(dets), _lib.ptr(ws), need, _lib.current_stream()),
+                           "fi_proposal_candidates_ws")
+            else:
+                _lib.check(L.fi_proposal_candidates(_lib.ptr(probs), probs.size(2), 1, _lib.ptr(deltas), _lib.ptr(anchors),
+                                                    _lib.ptr(extra_dets), b, A, E, pre_nms_limit, std, height, width,
+                                                    _lib.ptr(dets), _lib.current_stream()), "fi_proposal_candidates")
     if _lib.TAP is not None:
         _lib.TAP("proposal_candidates", probs=probs, deltas=deltas, anchors=anchors, extra=extra_dets, dets=dets)
     keep, num = nms_sorted(dets, nms_threshold, max_keep=proposal_count)

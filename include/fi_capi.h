@@ -475,6 +475,15 @@ int fi_proposal_candidates(const float *probs, int prob_stride, int prob_offset,
                            const float *anchors, const float *extra, int batch, int num_anchors,
                            int num_extra, int pre_nms, const float *bbox_std_host, float window_h,
                            float window_w, float *dets, fi_stream_t stream);
+/* The same rows in eight small launches (round 6): the three radix passes and the compaction on 32 workgroups per image
+ * with their state in `workspace` (fi_proposal_workspace_bytes(batch) bytes, 16-byte aligned, contents need not be
+ * preserved or cleared between calls); sort + decode stay one workgroup per image.  fi_proposal_candidates is one
+ * workgroup per image walking every score four times (4 workgroups on 256 CUs). */
+size_t fi_proposal_workspace_bytes(int batch);
+int fi_proposal_candidates_ws(const float *probs, int prob_stride, int prob_offset, const float *deltas,
+                              const float *anchors, const float *extra, int batch, int num_anchors, int num_extra,
+                              int pre_nms, const float *bbox_std_host, float window_h, float window_w, float *dets,
+                              void *workspace, size_t workspace_bytes, fi_stream_t stream);
 /* proposals[b][j] = dets[b][keep[b][j]][0:4] / (norm_h, norm_w, norm_h, norm_w) for j < num[b], zero rows after
  * (lib/layers.py:131-137 without the host-side truncation to the shortest keep list). */
 int fi_proposal_gather(const float *dets, int pre_nms, int det_stride, const int64_t *keep, int keep_stride,

@@ -54,7 +54,7 @@ class Wrapped(object):
 
     def __getattr__(self, name):
         fn = getattr(self._real, name)
-        if not name.startswith("fi_conv"):
+        if not name.startswith("fi_conv") or name.endswith("_eligible"):       # (a host-side query, not a launch)
             return fn
 
         def timed(*a):

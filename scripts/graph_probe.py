@@ -9,11 +9,12 @@ from feature_intertwiner_amd.model import MaskRCNN
 from feature_intertwiner_amd.synthetic import SyntheticProposals, synthetic_batch
 dev = torch.device("cuda", 0)
 small = "--small" in sys.argv
+BATCH = int(sys.argv[sys.argv.index("--batch") + 1]) if "--batch" in sys.argv else 4      # 2 = BASELINE configs[3]'s per-GPU shape
 torch.manual_seed(2000)
 if "--cfg5" in sys.argv:          # the single-GPU slice of BASELINE configs[4] on the bf16 kernels
     cfg = make_config("resnet101", 1344, 2, 1000, dev_switch=True, loss_choice="ot", ot_L=50, conv_precision="bf16")
 else:
-    cfg = make_config("resnet50" if small else "resnet101", 512 if small else 1024, 2 if small else 4, 128 if small else 512,
+    cfg = make_config("resnet50" if small else "resnet101", 512 if small else 1024, 2 if small else BATCH, 128 if small else 512,
                       dev_switch=True, loss_choice="ot", ot_L=50)
 model = MaskRCNN(cfg).to(dev)
 opt = workflow.set_optimizer(model, cfg.TRAIN)
@@ -46,3 +47,9 @@ p0 = next(model.parameters()).detach().clone()
 ms, _ = timeit(g.replay)
 print("graph ms/step", round(ms, 2), {k: round(float(v), 4) for k, v in static_terms.items()}, flush=True)
 print("parameters moved:", float((next(model.parameters()).detach() - p0).abs().max()) > 0)
+
+if "--replay" in sys.argv:        # for an outside tracer (rocprofv3 --kernel-trace + scripts/gpu_idle.py): replays only
+    n = int(sys.argv[sys.argv.index("--replay") + 1])
+    for _ in range(n):
+        g.replay()
+    torch.cuda.synchronize()

@@ -8,7 +8,7 @@ O=$GRAFT_REPO_ROOT/gpurun_out
 # rocprofv3 per-kernel summary of the same command (headline flags, fewer steps; no nested PMC passes)
 # (FI_WGRAD_SIDE_PIXELS=0: weight gradients on the main stream, as in bench.py's profiled pass -- kernel durations are
 # exclusive; with the second stream two kernels share the chip and each row's average is longer than the kernel alone)
-rm -rf /tmp/prof7; ( cd /tmp && FI_WGRAD_SIDE_PIXELS=0 FI_DEAD_SIDE=0 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof7 -o b -- python $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 2 --profile-steps 1 --no-cpu-baseline --no-pmc --no-dense-reference > $O/${R}_bench_n1_under_rocprof.json 2>/dev/null )
+rm -rf /tmp/prof7; ( cd /tmp && FI_WGRAD_SIDE_PIXELS=0 FI_DEAD_SIDE=0 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof7 -o b -- python $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 2 --profile-steps 1 --no-cpu-baseline --no-pmc --no-dense-reference --no-issue-profile > $O/${R}_bench_n1_under_rocprof.json 2>/dev/null )
 f=$(find /tmp/prof7 -name 'b_kernel_stats.csv' | head -1)
 ( head -81 $f; grep -E "crop_|nms_|sinkhorn|roi_pool|class_mean|weight_transpose" $f ) | awk '!seen[$0]++' > $O/${R}_bench_n1_kernel_stats.csv
 # operator micro-benchmarks, and the rocprofv3 summary of the RoI operators in that run
@@ -22,7 +22,7 @@ timeout 200 python scripts/roipool_probe.py > $O/${R}_roipool_probe.txt 2>&1
 ( cd /tmp && timeout 500 python $GRAFT_REPO_ROOT/bench.py --config cfg5 --no-cpu-baseline > $O/${R}_bench_cfg5_bf16.json 2>$O/${R}_bench_cfg5_bf16.err )      # with the PMC passes: roofline.traffic
 ( cd /tmp && timeout 400 python $GRAFT_REPO_ROOT/bench.py --conv-precision bf16 --no-cpu-baseline --no-pmc > $O/${R}_bench_cfg3_bf16.json 2>/dev/null )
 # per-layer view of the step's kernels (grid size = layer shape) from a kernel trace of the headline command
-rm -rf /tmp/prof9; ( cd /tmp && FI_WGRAD_SIDE_PIXELS=0 FI_DEAD_SIDE=0 timeout 400 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof9 -o kt -- python $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 2 --profile-steps 0 --no-cpu-baseline --no-pmc --no-dense-reference > /dev/null 2>&1 )
+rm -rf /tmp/prof9; ( cd /tmp && FI_WGRAD_SIDE_PIXELS=0 FI_DEAD_SIDE=0 timeout 400 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof9 -o kt -- python $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 2 --profile-steps 0 --no-cpu-baseline --no-pmc --no-dense-reference --no-issue-profile > /dev/null 2>&1 )
 f=$(find /tmp/prof9 -name 'kt_kernel_trace.csv' | head -1)
 python scripts/trace_groups.py $f conv 7 | head -70 > $O/${R}_conv_layers.txt
 python scripts/trace_groups.py $f bn_act 7 > $O/${R}_bn_bwd_layers.txt
@@ -42,7 +42,7 @@ timeout 200 python scripts/host_time.py 2>&1 | grep -v amdgpu | tail -8 > $O/${R
 # what a batched weight-gradient launch reaches
 timeout 200 python scripts/wg_batch_probe.py 2>&1 | grep "^{" > $O/${R}_wgrad_batch_probe.txt
 # GPU idle time between kernels (union over streams) from a kernel trace of the default command; the whole step as one hipGraph
-rm -rf /tmp/px; ( cd /tmp && timeout 400 rocprofv3 --kernel-trace --output-format csv -d /tmp/px -o kt -- python $GRAFT_REPO_ROOT/bench.py --steps 6 --warmup 2 --profile-steps 0 --no-cpu-baseline --no-pmc --no-dense-reference > /dev/null 2>&1 )
+rm -rf /tmp/px; ( cd /tmp && timeout 400 rocprofv3 --kernel-trace --output-format csv -d /tmp/px -o kt -- python $GRAFT_REPO_ROOT/bench.py --steps 6 --warmup 2 --profile-steps 0 --no-cpu-baseline --no-pmc --no-dense-reference --no-issue-profile > /dev/null 2>&1 )
 f=$(find /tmp/px -name 'kt_kernel_trace.csv' | head -1); python scripts/gpu_idle.py $f > $O/${R}_gpu_idle.txt 2>&1
 timeout 300 python scripts/graph_probe.py 2>&1 | grep -v amdgpu > $O/${R}_graph_probe.txt
 FI_STATIC_DEV=1 timeout 300 python scripts/graph_probe.py --cfg5 2>&1 | grep -v amdgpu > $O/${R}_graph_probe_cfg5.txt
@@ -56,7 +56,7 @@ ls -la $O | tail -40
 # time (are the one-workgroup latency kernels of the side streams still hidden at half the conv time?) -- and its idle gaps;
 # the data-parallel preflight; the target generation alone on the chip; NCHW pyramid crop backward; LDS atomic rates
 ( cd /tmp && timeout 400 python $GRAFT_REPO_ROOT/bench.py --batch-per-gpu 2 --no-cpu-baseline --no-pmc --no-dense-reference > $O/${R}_bench_2img_per_gpu.json 2>/dev/null )
-rm -rf /tmp/py; ( cd /tmp && timeout 400 rocprofv3 --kernel-trace --output-format csv -d /tmp/py -o kt -- python $GRAFT_REPO_ROOT/bench.py --batch-per-gpu 2 --steps 6 --warmup 2 --profile-steps 0 --no-cpu-baseline --no-pmc --no-dense-reference > /dev/null 2>&1 )
+rm -rf /tmp/py; ( cd /tmp && timeout 400 rocprofv3 --kernel-trace --output-format csv -d /tmp/py -o kt -- python $GRAFT_REPO_ROOT/bench.py --batch-per-gpu 2 --steps 6 --warmup 2 --profile-steps 0 --no-cpu-baseline --no-pmc --no-dense-reference --no-issue-profile > /dev/null 2>&1 )
 f=$(find /tmp/py -name 'kt_kernel_trace.csv' | head -1); python scripts/gpu_idle.py $f > $O/${R}_gpu_idle_2img_per_gpu.txt 2>&1
 ( cd /tmp && FI_DP_FORCE=1 timeout 200 python $GRAFT_REPO_ROOT/bench.py --preflight > $O/${R}_preflight_1rank_rccl.json 2>/dev/null )
 timeout 100 python scripts/rpn_target_probe.py 2>&1 | grep prepare > $O/${R}_rpn_target_probe.txt
@@ -73,3 +73,7 @@ timeout 300 python scripts/main_stream_report.py 2>&1 | grep -v "Warning\|amdgpu
 timeout 300 python scripts/main_stream_report.py --batch 2 2>&1 | grep -v "Warning\|amdgpu\|_warn_once" > $O/${R}_main_stream_2img_per_gpu.txt
 timeout 400 python scripts/relu_boundary_probe.py 8 --mask 2>&1 | grep "^{" > $O/${R}_relu_boundary_probe.txt
 ls -la $O | tail -20
+# GPU idle at 2 images per GPU with the whole step replayed as ONE hipGraph (no host in the loop): kernel trace of replays only
+rm -rf /tmp/pz; ( cd /tmp && timeout 400 rocprofv3 --kernel-trace --output-format csv -d /tmp/pz -o kt -- python $GRAFT_REPO_ROOT/scripts/graph_probe.py --batch 2 --replay 8 > $O/${R}_graph_probe_2img_per_gpu.txt 2>&1 )
+f=$(find /tmp/pz -name 'kt_kernel_trace.csv' | head -1); python scripts/gpu_idle.py $f > $O/${R}_gpu_idle_2img_per_gpu_graph.txt 2>&1
+ls -la $O | tail -8

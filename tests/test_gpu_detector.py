@@ -84,11 +84,14 @@ def _check_candidates(oracle, tap, cfg, size):
     return True
 
 
-def test_proposal_layer_matches_oracle(oracle):
-    """proposal_layer = fi_proposal_candidates + fi_nms_sorted + fi_proposal_gather.  Candidates vs the oracle
-    (selection exact); keep list = the oracle's NMS on the kernel's own dets (exact); gathered proposals exact."""
+@pytest.mark.parametrize("multi_wg", [True, False])
+def test_proposal_layer_matches_oracle(oracle, multi_wg, monkeypatch):
+    """proposal_layer = fi_proposal_candidates(_ws) + fi_nms_sorted + fi_proposal_gather.  Candidates vs the oracle
+    (selection exact); keep list = the oracle's NMS on the kernel's own dets (exact); gathered proposals exact.
+    multi_wg: the eight-launch selection with its state in a workspace (round 6) / the single kernel."""
     from feature_intertwiner_amd import _lib
     from feature_intertwiner_amd import layers as L
+    monkeypatch.setattr(L, "PROPOSAL_MULTI_WG", multi_wg)
     cfg = _cfg(backbone="resnet50", image_size=256)
     pri = _priors(cfg)
     g = torch.Generator(device=DEV).manual_seed(2)
@@ -114,12 +117,14 @@ def test_proposal_layer_matches_oracle(oracle):
         assert torch.all(props[b, n:] == 0)
 
 
+@pytest.mark.parametrize("multi_wg", [True, False])
 @pytest.mark.parametrize("case", ["ties", "extra", "few", "all_equal", "negative_and_nan_free"])
-def test_proposal_candidates_edge_cases(oracle, case):
+def test_proposal_candidates_edge_cases(oracle, case, multi_wg, monkeypatch):
     """Tie rule (lower index first; more ties at the threshold than places), external candidates merged by score
     (before anchors at equal score), fewer candidates than PRE_NMS_LIMIT, constant scores, scores of both signs."""
     from feature_intertwiner_amd import _lib
     from feature_intertwiner_amd import layers as L
+    monkeypatch.setattr(L, "PROPOSAL_MULTI_WG", multi_wg)
     cfg = _cfg(backbone="resnet50", image_size=256)
     pri = _priors(cfg)
     A = pri.size(0)
