@@ -35,6 +35,7 @@ SHAPE_LOG = None
 # (operands rounded to the 16-bit type, fp32 accumulation, v_mfma_f32_32x32x16_{bf16,f16} -- BASELINE configs[4]'s reduced-
 # precision conv path).  Read when a forward pass runs; the backward of that pass uses the same setting.
 _PRECISION = "fp32"
+RING_1X1 = True        # A/B switch of the persistent 1x1 kernel (conv1x1_ring_kernel); FI_NO_RING1X1=1 does the same in C
 
 
 def set_conv_precision(mode):
@@ -164,9 +165,9 @@ def _conv_fwd(x, w, b, stride, padding, relu=False, scale=None, residual=None, o
                                                       1 if relu else 0, _lib.current_stream()),
                            "fi_conv1x1_forward_bf16w")
             return y
-    if not bf16 and layout >= 1 and R * S == 1 and live is None and out_hw is None and not out_channels_last and _WF:
+    if RING_1X1 and not bf16 and layout >= 1 and R * S == 1 and live is None and out_hw is None and not out_channels_last and _WF:
         e = _WF.get(w.data_ptr())
-        if e is not None and e[2] == (Cout, Cin) and (e[1] is None or e[1] == w._version) and \
+        if e is not None and e[3]() is not None and e[2] == (Cout, Cin) and (e[1] is None or e[1] == w._version) and \
                 L.fi_conv1x1_ring_eligible(N, Cin, H, W, Cout, 1, 1, stride[0], stride[1], padding[0], padding[1], 0,
                                            _lib.ptr(x), _lib.ptr(y), _lib.ptr(residual), _lib.ptr(gate)) == 1:
             w, layout = e[0], 3         # the persistent 1x1 kernel (csrc/conv1x1_ring.hip)
@@ -831,7 +832,10 @@ def _finish_wgrads():
 
 # ---- per-step derived state: W^T for the data gradient, zeroed gradient arena ---------------------
 _WT = {}           # weight data_ptr -> (W^T [Cin,R,S,Cout], weight version it was made from)
-_WF = {}           # data_ptr of a 1x1 weight (or of its W^T) -> (fragment-major copy, version or None, (Cout, Cin) of the matrix)
+_WF = {}           # data_ptr of a 1x1 weight (or of its W^T) -> (fragment-major copy, version or None, (Cout, Cin) of the matrix,
+                   # weak reference to the tensor that owns the address).  An entry is valid only while its owner lives: a
+                   # model that is garbage-collected leaves its entries behind (the plan is weakly keyed), and the allocator
+                   # hands the freed addresses to the next model's tensors -- same shape, same version counter
 _ARENA = {"buf": None, "slots": {}, "used": set()}
 _PLAN = weakref.WeakKeyDictionary()      # model -> cached layer lists / descriptor table
 
@@ -856,7 +860,7 @@ def _cached_wt(w, scaled=False):
     """This step's W^T [Cin][R][S][Cout] (prepare_step); scaled: the copy with the layer's eval-BatchNorm scale folded
     in (W^T[...][co] * scale[co]) -- a layer has one or the other."""
     e = _WT.get(w.data_ptr())
-    if e is not None and e[1] == w._version and e[2] == bool(scaled) and \
+    if e is not None and e[3]() is not None and e[1] == w._version and e[2] == bool(scaled) and \
             e[0].shape == (w.shape[1], w.shape[2], w.shape[3], w.shape[0]):
         return e[0]
     return None
@@ -930,6 +934,9 @@ def _prepare_step(model, grad_on):
         if plan is not None:
             for k in plan.get("wf_keys", ()):          # the replaced plan's fragment-major copies
                 _WF.pop(k, None)
+        for cache in (_WF, _WT):                       # entries of models that no longer exist
+            for k in [k for k, e in cache.items() if e[3]() is None]:
+                del cache[k]
         convs = [m for m in model.modules() if isinstance(m, Conv2d) and not m.full_window]
         for m in convs:
             w = m.weight
@@ -1017,16 +1024,16 @@ def _prepare_step(model, grad_on):
             _lib.check(L.fi_weight_transpose_batch(_lib.ptr(plan["table"]), len(plan["desc"]), plan["tiles"],
                                                    _lib.current_stream()), "fi_weight_transpose_batch")
         for m, wt, sp in zip(plan["tr"], plan["wts"], sig):
-            _WT[m.weight.data_ptr()] = (wt, m.weight._version, sp != 0)
+            _WT[m.weight.data_ptr()] = (wt, m.weight._version, sp != 0, weakref.ref(m.weight))
         keys = []
         for m, kind, t, ti in plan["frag"]:
             # forward: keyed by the parameter; data gradient: keyed by the W^T tensor _conv_fwd is handed
             if kind == "fwd":
                 keys.append(m.weight.data_ptr())
-                _WF[keys[-1]] = (t, m.weight._version, tuple(m.weight.shape[:2]))
+                _WF[keys[-1]] = (t, m.weight._version, tuple(m.weight.shape[:2]), weakref.ref(m.weight))
             else:
                 keys.append(plan["wts"][ti].data_ptr())
-                _WF[keys[-1]] = (t, None, (m.weight.shape[1], m.weight.shape[0]))
+                _WF[keys[-1]] = (t, None, (m.weight.shape[1], m.weight.shape[0]), weakref.ref(plan["wts"][ti]))
         plan["wf_keys"] = keys
         plan["versions"] = versions
         _WB.clear()          # the W^T tensors were rewritten in place (no version bump): drop their bf16 copies

@@ -148,3 +148,48 @@ def test_model_layers_take_the_ring_kernel_and_match_the_reg_kernel(monkeypatch)
     assert torch.equal(outs[0][1], outs[1][1])          # data gradient: bit-identical
     for a, b in zip(outs[0][2:], outs[1][2:]):          # weight gradients: the same kernel, fp32 atomics (order not fixed)
         assert torch.allclose(a, b, rtol=1e-4, atol=1e-4 * float(b.abs().max()))
+
+
+def test_a_collected_models_fragment_copies_are_not_used_for_the_next_model():
+    """The caches are keyed by address and the plan is weakly keyed by the model: when a model is garbage-collected its
+    entries stay, and the allocator hands the freed addresses to the next model's weights (same shape, same version
+    counter).  Seen as a 9 % gradient error in the two-rank `full` test whenever a smaller detector had run before it in
+    the same process.  Entries carry a weak reference to the tensor that owns their address and are void without it."""
+    import gc
+    import torch.nn as nn
+    from feature_intertwiner_amd import conv as C
+
+    class One(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.conv = C.Conv2d(256, 256, kernel_size=1)
+
+    C.invalidate_step_state()
+    x = torch.randn(4, 256, 64, 64, device=DEV)
+    a = One().to(DEV)
+    C.prepare_step(a)
+    torch.cuda.synchronize()
+    key = a.conv.weight.data_ptr()
+    assert key in C._WF
+    del a
+    gc.collect()
+    # a tensor of the same shape at the freed address, not a parameter of any planned model
+    w = None
+    for _ in range(64):
+        t = torch.randn(256, 256, 1, 1, device=DEV)
+        if t.data_ptr() == key:
+            w = t
+            break
+    if w is None:
+        pytest.skip("the allocator did not hand the freed block back")
+    assert C._WF[key][3]() is None                      # the owner is gone
+    while w._version < C._WF[key][1]:
+        w.add_(0)                                       # (a parameter's counter after its initialisation)
+    assert C._WF[key][1] == w._version                  # version / shape alone would have matched
+    y = C._conv_fwd(x, w, None, (1, 1), (0, 0))
+    ref = torch.nn.functional.conv2d(x.double(), w.double()).float()
+    assert torch.allclose(y, ref, rtol=1e-4, atol=1e-3)
+    b = One().to(DEV)
+    C.prepare_step(b)                                   # a new plan sweeps the dead entries
+    assert all(e[3]() is not None for e in C._WF.values())
+    C.invalidate_step_state()
