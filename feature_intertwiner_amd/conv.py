@@ -934,7 +934,8 @@ def _prepare_step(model, grad_on):
         if plan is not None:
             for k in plan.get("wf_keys", ()):          # the replaced plan's fragment-major copies
                 _WF.pop(k, None)
-        for cache in (_WF, _WT):                       # entries of models that no longer exist
+        for cache in (_WT, _WF):                       # entries of models that no longer exist (W^T first: it owns the
+                                                       # tensors the data-gradient entries of _WF are keyed by)
             for k in [k for k, e in cache.items() if e[3]() is None]:
                 del cache[k]
         convs = [m for m in model.modules() if isinstance(m, Conv2d) and not m.full_window]

@@ -77,3 +77,9 @@ ls -la $O | tail -20
 rm -rf /tmp/pz; ( cd /tmp && timeout 400 rocprofv3 --kernel-trace --output-format csv -d /tmp/pz -o kt -- python $GRAFT_REPO_ROOT/scripts/graph_probe.py --batch 2 --replay 8 > $O/${R}_graph_probe_2img_per_gpu.txt 2>&1 )
 f=$(find /tmp/pz -name 'kt_kernel_trace.csv' | head -1); python scripts/gpu_idle.py $f > $O/${R}_gpu_idle_2img_per_gpu_graph.txt 2>&1
 ls -la $O | tail -8
+# the mask-target crop and the NMS scan alone on the chip (new kernel vs A/B switch), the scan's take-apart builds, the
+# shader clock a one-workgroup kernel sees
+(timeout 100 python scripts/mask_crop_probe.py; FI_CROP_NO_C1=1 timeout 100 python scripts/mask_crop_probe.py) 2>&1 | grep "^{" > $O/${R}_mask_crop_probe.txt
+(timeout 100 python scripts/nms_scan_probe.py; FI_NMS_SCAN_NARROW=1 timeout 100 python scripts/nms_scan_probe.py) 2>&1 | grep "^{" > $O/${R}_nms_scan_probe.txt
+timeout 400 bash scripts/nms_exp.sh 2>&1 | grep "^EXP\|^{" >> $O/${R}_nms_scan_probe.txt
+hipcc --offload-arch=gfx950 -O3 -o /tmp/sclk_probe scripts/micro/sclk_probe.hip && /tmp/sclk_probe > $O/${R}_sclk_probe.txt 2>&1

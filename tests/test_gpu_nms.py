@@ -23,6 +23,18 @@ def test_pth_nms_matches_oracle(oracle, n, thresh):
             assert np.array_equal(got, exp), (n, thresh, pixel, strict, len(got), len(exp))
 
 
+@pytest.mark.parametrize("n", [7104, 7168, 7169, 9000, 14336, 14400])
+def test_scan_kernel_variants_by_size(oracle, n):
+    """nms_scan_wide_kernel<8> up to 112 column words (7168 boxes), <4> up to 224 (14336), the one-word-per-thread scan
+    above; the last block partly filled or full."""
+    from feature_intertwiner_amd.nms.pth_nms import pth_nms
+    rs = np.random.RandomState(n)
+    dets = clustered_dets(rs, n, 1024, n_clusters=40)
+    exp = oracle.pth_nms(dets, 0.7, False)
+    got = pth_nms(torch.from_numpy(dets).to(DEV), 0.7, strict=False).cpu().numpy()
+    assert np.array_equal(got, exp), (n, len(got), len(exp))
+
+
 def test_threshold_tie_ge_vs_gt(oracle):
     """IoU exactly equal to the threshold: `>=` (CPU spec) suppresses, `>` (CUDA) keeps."""
     from feature_intertwiner_amd.nms.pth_nms import pth_nms

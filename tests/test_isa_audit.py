@@ -74,3 +74,68 @@ def test_ring_kernel_asm_loads_are_not_touched_before_their_wait():
     for blk in re.findall(r";;#ASMSTART\n(.*?);;#ASMEND", text, re.S):
         if "global_" in blk:
             assert blk.strip().startswith("s_nop 4"), blk
+
+
+NMS_SRC = os.path.join(ROOT, "feature_intertwiner_amd", "csrc", "nms.hip")
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="no hipcc")
+def test_wide_nms_scan_asm_loads():
+    """csrc/nms.hip, nms_scan_wide_kernel: every global load is inline asm with a hand-counted wait.  Audited on the ISA:
+      * the compiler inserted no vmcnt wait of its own into the kernel (it sees no vector memory load there);
+      * between an asm load and the counted wait that covers it no compiler instruction touches the destination
+        registers (loads retire in order: `s_waitcnt vmcnt(N)` completes all but the youngest N);
+      * the scalar base of an asm load is never written by v_readlane / v_readfirstlane within 8 instructions before it
+        (VALU-written SGPR -> VMEM needs 5 wait states the compiler does not know to insert for asm);
+      * no scratch."""
+    with tempfile.TemporaryDirectory() as tmp:
+        out = os.path.join(tmp, "nms.s")
+        subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
+                               "-munsafe-fp-atomics", "-Wno-inline-asm", "-S", "--cuda-device-only",
+                               "-I", os.path.join(ROOT, "include"), NMS_SRC, "-o", out])
+        text = open(out).read()
+    kernels = re.findall(r"^(_ZN\S*nms_scan_wide_kernel\S*):[^\n]*\n(.*?)\n\.Lfunc_end", text, re.S | re.M)
+    assert len(kernels) == 2
+    for name, body in kernels:
+        pending = []            # asm loads in issue order: (set of vregs, line)
+        in_asm = False
+        n_loads = n_waits = 0
+        recent = []             # the last compiler instructions (for the SGPR hazard)
+        for ln, line in enumerate(body.split("\n")):
+            t = line.strip()
+            if t.startswith(";;#ASMSTART"):
+                in_asm = True
+                continue
+            if t.startswith(";;#ASMEND"):
+                in_asm = False
+                continue
+            if not t or t.startswith(";"):
+                continue
+            if t.startswith("."):
+                continue
+            if in_asm:
+                if t.startswith("global_load_dwordx"):
+                    ops = [o.strip() for o in t.split(None, 1)[1].split(",")]
+                    pending.append((_regs(ops[0]), ln))
+                    n_loads += 1
+                    m = re.fullmatch(r"s\[(\d+):(\d+)\]", ops[2])
+                    if m:
+                        base = {int(m.group(1)), int(m.group(2))}
+                        for prev in recent[-8:]:
+                            w = re.match(r"v_(?:readfirstlane|readlane)_b32 s(\d+)", prev)
+                            assert not (w and int(w.group(1)) in base), (name, prev, t)
+                elif t.startswith("s_waitcnt vmcnt"):
+                    n = int(re.search(r"vmcnt\((\d+)\)", t).group(1))
+                    pending = pending[len(pending) - n:] if n else []
+                    n_waits += 1
+                continue
+            assert "s_waitcnt vmcnt" not in t, "%s: a compiler-inserted vmcnt wait: %s" % (name, t)
+            if t.startswith("s_endpgm") or t.startswith("s_branch") or t.startswith("s_setpc"):
+                pending = []    # (linear listing: what follows is another path)
+            busy = set().union(*[r for r, _ in pending]) if pending else set()
+            touched = _all_vregs(t) & busy
+            assert not touched, "%s: compiler instruction touches in-flight asm load registers %s: %s" % (name, sorted(touched), t)
+            recent.append(t)
+        assert n_loads >= 20 and n_waits >= 8, (name, n_loads, n_waits)
+    for m in re.finditer(r"\.name:\s+(\S*nms_scan_wide_kernel\S*)(.*?)\.vgpr_spill_count:\s+(\d+)", text, re.S):
+        assert int(m.group(3)) == 0, m.group(1)
