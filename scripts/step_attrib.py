@@ -57,7 +57,8 @@ model.generator = torch.Generator(device=dev).manual_seed(11)
 for _ in range(3):
     workflow.train_step(model, opt, list(batch))
 torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+SHAPES = "--shapes" in sys.argv     # input shapes of the aten op behind every framework launch
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=SHAPES) as prof:
     workflow.train_step(model, opt, list(batch))
     torch.cuda.synchronize()
 
@@ -79,7 +80,7 @@ def origin(ev):
     while p is not None:
         n = p.name
         if n.startswith("aten::") and op is None:
-            op = n
+            op = n + ((" " + str([list(x) for x in p.input_shapes if x])[:90]) if SHAPES and p.input_shapes else "")
         if n.startswith("stage:"):
             stage = n[6:] if stage is None else stage
         if "evaluate_function: " in n:
