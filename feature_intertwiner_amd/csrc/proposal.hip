@@ -44,6 +44,7 @@ struct SelectArgs {
     float *dets;             // [batch, K, 5]
     int A, E, K, prob_stride, prob_off;
     float std0, std1, std2, std3, win_h, win_w;
+    int lds_sort;            // A/B (FI_PROPOSAL_LDS_SORT): the all-LDS bitonic sort in proposal_sort_kernel
 };
 
 __device__ __forceinline__ float score_of(const SelectArgs &a, int img, int i)
@@ -81,12 +82,12 @@ __device__ __forceinline__ void find_digit(int *hist, int nbins, int want, int *
 }
 
 // decode + clip of the K sorted winners (tools/box_utils.py:7-60, each operation rounded separately)
-__device__ __forceinline__ void decode_rows(const SelectArgs &a, int img, const u64 *s_keys)
+__device__ __forceinline__ void decode_rows(const SelectArgs &a, int img, const u64 *s_keys, int first = -1, int step = 0)
 {
-    const int tid = threadIdx.x;
     const int K = a.K;
     float *out = a.dets + (size_t)img * K * 5;
-    for (int r = tid; r < K; r += kSelThreads) {
+    if (first < 0) { first = threadIdx.x; step = kSelThreads; }
+    for (int r = first; r < K; r += step) {
         const int i = (int)(unsigned)(s_keys[r] & 0xffffffffull);
         float y1, x1, y2, x2, sc;
         if (i < a.E) {
@@ -248,7 +249,7 @@ __global__ __launch_bounds__(kSelThreads) void proposal_select_kernel(SelectArgs
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// The same selection as proposal_select_kernel in EIGHT small launches (round 6, fi_proposal_candidates_ws): the single
+// The same selection as proposal_select_kernel in NINE small launches (round 6, fi_proposal_candidates_ws): the single
 // kernel is one workgroup per image that walks the 261 888 scores four times -- 4 workgroups on 256 CUs, ~310 us, memory
 // latency per iteration on ONE CU each.  Here the three radix passes and the compaction run on kHistWgs workgroups per
 // image with the state in a caller-provided workspace; only the sort + decode stays one workgroup per image.  The result
@@ -257,6 +258,7 @@ __global__ __launch_bounds__(kSelThreads) void proposal_select_kernel(SelectArgs
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int kHistWgs = 32;              // workgroups per image of the multi-workgroup passes
 constexpr int kHistThreads = 256;
+constexpr int kCompactWgs = 128;          // workgroups per image of the compaction (8 iterations of 256 scores each at 261 888)
 struct SelState {
     unsigned prefix, mask;
     int want, count_eq, n_cand, n_tie;
@@ -349,37 +351,139 @@ __global__ __launch_bounds__(kSelThreads) void proposal_digit_kernel(SelectArgs 
     }
 }
 
-// keys above the threshold go to cand[], keys equal to it to tie[] (used when every tie is a winner)
+// keys above the threshold go to cand[], keys equal to it to tie[] (used when every tie is a winner).  A workgroup reserves
+// its two ranges with ONE pair of global atomics (one returning atomic per wavefront and iteration on two words per image
+// serialised at the memory side: 40 us of the selection); the places inside the range come from LDS counters.
+constexpr int kCompactPerThread = 16;     // scores per thread held in registers between the two phases
 __global__ __launch_bounds__(kHistThreads) void proposal_compact_kernel(SelectArgs a, char *__restrict__ ws)
 {
-    const int img = blockIdx.y, tid = threadIdx.x;
+    __shared__ int s_n[2], s_base[2];
+    const int img = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
     const int total = a.A + a.E;
     SelState *st = ws_state(ws, img);
     const unsigned T = st->T;
     u64 *cand = ws_cand(ws, img), *tie = ws_tie(ws, img);
-    const int per = (total + kHistWgs - 1) / kHistWgs;
+    const int per = (total + kCompactWgs - 1) / kCompactWgs;
     const int lo = blockIdx.x * per, hi = min(total, lo + per);
-    for (int base = lo; base < hi; base += kHistThreads) {          // (uniform trip count: the ballots see whole wavefronts)
-        const int i = base + tid;
-        const bool in = i < hi;
-        const unsigned k = in ? sortable(score_of(a, img, i)) : 0u;
-        const bool above = in && k > T, eq = in && k == T;
-        const u64 b_above = __ballot(above), b_eq = __ballot(eq);
-        const int lane = tid & 63;
-        if (b_above) {
-            int base_pos = 0;
-            if (lane == 0) base_pos = atomicAdd(&st->n_cand, __popcll(b_above));
-            base_pos = __shfl(base_pos, 0, 64);
-            if (above) cand[base_pos + __popcll(b_above & ((1ull << lane) - 1ull))] = ((u64)(~k) << 32) | (unsigned)i;
+    if (tid < 2) s_n[tid] = 0;
+    __syncthreads();
+    for (int base0 = lo; base0 < hi; base0 += kCompactPerThread * kHistThreads) {       // (one round unless per > 4096)
+        unsigned key[kCompactPerThread];
+        int pos[kCompactPerThread];                   // place inside the workgroup's range; bit 30: a tie; -1: neither
+#pragma unroll
+        for (int u = 0; u < kCompactPerThread; ++u) {                                  // all scores in flight together
+            const int i = base0 + u * kHistThreads + tid;
+            key[u] = i < hi ? sortable(score_of(a, img, i)) : 0u;
         }
-        if (b_eq) {
-            int base_pos = 0;
-            if (lane == 0) base_pos = atomicAdd(&st->n_tie, __popcll(b_eq));
-            base_pos = __shfl(base_pos, 0, 64);
-            const int pos = base_pos + __popcll(b_eq & ((1ull << lane) - 1ull));
-            if (eq && pos < kSortCap) tie[pos] = ((u64)(~k) << 32) | (unsigned)i;
+#pragma unroll
+        for (int u = 0; u < kCompactPerThread; ++u) {
+            const int i = base0 + u * kHistThreads + tid;
+            const bool in = i < hi;
+            const bool above = in && key[u] > T, eq = in && key[u] == T;
+            const u64 b_above = __ballot(above), b_eq = __ballot(eq);
+            pos[u] = -1;
+            if (b_above) {
+                int p0 = 0;
+                if (lane == 0) p0 = atomicAdd(&s_n[0], __popcll(b_above));
+                p0 = __shfl(p0, 0, 64);
+                if (above) pos[u] = p0 + __popcll(b_above & ((1ull << lane) - 1ull));
+            }
+            if (b_eq) {
+                int p0 = 0;
+                if (lane == 0) p0 = atomicAdd(&s_n[1], __popcll(b_eq));
+                p0 = __shfl(p0, 0, 64);
+                if (eq) pos[u] = (p0 + __popcll(b_eq & ((1ull << lane) - 1ull))) | (1 << 30);
+            }
+        }
+        __syncthreads();
+        if (tid < 2) {
+            const int n = s_n[tid];
+            s_base[tid] = n ? atomicAdd(tid == 0 ? &st->n_cand : &st->n_tie, n) : 0;
+            s_n[tid] = 0;
+        }
+        __syncthreads();
+        const int b0 = s_base[0], b1 = s_base[1];
+#pragma unroll
+        for (int u = 0; u < kCompactPerThread; ++u) {
+            if (pos[u] < 0) continue;
+            const int i = base0 + u * kHistThreads + tid;
+            const u64 k64 = ((u64)(~key[u]) << 32) | (unsigned)i;
+            if (pos[u] & (1 << 30)) {
+                const int p = b1 + (pos[u] & ~(1 << 30));
+                if (p < kSortCap) tie[p] = k64;
+            } else {
+                cand[b0 + pos[u]] = k64;
+            }
+        }
+        __syncthreads();                              // (s_base is rewritten by a further round)
+    }
+}
+
+// Bitonic sort of KPT * 1024 u64 keys, ascending, with the keys in REGISTERS (thread t holds keys t*KPT .. t*KPT+KPT-1):
+// compare-exchange distances below KPT stay inside a thread, distances up to 32 threads are lane exchanges inside the
+// wavefront (ds_bpermute, no barrier), and only the distances of 64 threads and more go through LDS -- 10 of the 91
+// stages of the 8192-key sort (the all-LDS form: one barrier and four LDS round trips per thread in every stage).
+template <int KPT>
+__device__ __forceinline__ void sort_keys_in_registers(u64 *s_keys, u64 *__restrict__ sorted_out, int n_out)
+{
+    constexpr int N2 = KPT * kSelThreads;
+    const int tid = threadIdx.x;
+    u64 key[KPT];
+    // (the input order is arbitrary: a conflict-free read)
+#pragma unroll
+    for (int e = 0; e < KPT; ++e) key[e] = s_keys[e * kSelThreads + tid];
+#pragma unroll
+    for (int size = 2; size <= N2; size <<= 1) {
+        const bool asc_thread = ((tid * KPT) & size) == 0;      // (for size >= 2 * KPT: the same for all keys of a thread)
+#pragma unroll
+        for (int stride = size / 2; stride >= 64 * KPT; stride >>= 1) {
+            // partner thread tid ^ (stride / KPT) is the same lane of another wavefront: keys through LDS, key-major
+            // ([e][thread]: consecutive lanes, consecutive words -- no bank conflicts), compared in registers
+            const int partner = tid ^ (stride / KPT);
+            const bool keep_min = (((tid * KPT) & stride) == 0) == asc_thread;
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < KPT; ++e) s_keys[e * kSelThreads + tid] = key[e];
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < KPT; ++e) {
+                const u64 other = s_keys[e * kSelThreads + partner];
+                const bool take = keep_min ? (other < key[e]) : (other > key[e]);
+                key[e] = take ? other : key[e];
+            }
+        }
+#pragma unroll
+        for (int stride = (size / 2 < 64 * KPT ? size / 2 : 32 * KPT); stride >= KPT; stride >>= 1) {
+            // lane exchange: the partner thread is tid ^ (stride / KPT), inside the wavefront
+            const int ld = stride / KPT;
+            const bool lower = ((tid * KPT) & stride) == 0;
+            const bool keep_min = lower == asc_thread;
+#pragma unroll
+            for (int e = 0; e < KPT; ++e) {
+                const unsigned olo = __shfl_xor((unsigned)(key[e] & 0xffffffffull), ld, 64);
+                const unsigned ohi = __shfl_xor((unsigned)(key[e] >> 32), ld, 64);
+                const u64 other = ((u64)ohi << 32) | olo;
+                const bool take = keep_min ? (other < key[e]) : (other > key[e]);
+                key[e] = take ? other : key[e];
+            }
+        }
+#pragma unroll
+        for (int stride = (size / 2 < KPT ? size / 2 : KPT / 2); stride >= 1; stride >>= 1) {
+#pragma unroll
+            for (int e = 0; e < KPT; ++e) {
+                if (e & stride) continue;
+                const bool up = (((tid * KPT + e) & size) == 0);
+                const u64 x = key[e], y = key[e + stride];
+                const bool sw = (x > y) == up;
+                key[e] = sw ? y : x;
+                key[e + stride] = sw ? x : y;
+            }
         }
     }
+    // thread t holds the sorted keys t*KPT .. t*KPT+KPT-1: straight to memory
+#pragma unroll
+    for (int e = 0; e < KPT; ++e)
+        if (tid * KPT + e < n_out) sorted_out[tid * KPT + e] = key[e];
 }
 
 // one workgroup per image: winners into LDS, ties, bitonic sort, decode + clip (as proposal_select_kernel's steps 2b-4)
@@ -394,8 +498,21 @@ __global__ __launch_bounds__(kSelThreads) void proposal_sort_kernel(SelectArgs a
     const SelState st = *ws_state(ws, img);
     const unsigned T = st.T;
     const int need_eq = st.need_eq, n_above = K - need_eq;
-    const u64 *cand = ws_cand(ws, img), *tie = ws_tie(ws, img);
-    for (int i = tid; i < n_above; i += kSelThreads) s_keys[i] = cand[i];
+    u64 *cand = ws_cand(ws, img);
+    const u64 *tie = ws_tie(ws, img);
+    {
+        u64 v[kSortCap / kSelThreads];                   // (all loads in flight together)
+#pragma unroll
+        for (int u = 0; u < kSortCap / kSelThreads; ++u) {
+            const int i = tid + u * kSelThreads;
+            v[u] = i < n_above ? cand[i] : 0ull;
+        }
+#pragma unroll
+        for (int u = 0; u < kSortCap / kSelThreads; ++u) {
+            const int i = tid + u * kSelThreads;
+            if (i < n_above) s_keys[i] = v[u];
+        }
+    }
     const bool all_ties = (st.count_eq == need_eq);
     if (all_ties) {
         for (int i = tid; i < need_eq; i += kSelThreads) s_keys[n_above + i] = tie[i];
@@ -428,6 +545,9 @@ __global__ __launch_bounds__(kSelThreads) void proposal_sort_kernel(SelectArgs a
     while (n2 < K) n2 <<= 1;
     for (int i = K + tid; i < n2; i += kSelThreads) s_keys[i] = ~0ull;
     __syncthreads();
+    // (sorted keys go back to the workspace -- the candidate array is done with: proposal_decode_kernel reads them)
+    if (n2 == 8 * kSelThreads && !a.lds_sort) { sort_keys_in_registers<8>(s_keys, cand, K); return; }
+    if (n2 == 4 * kSelThreads && !a.lds_sort) { sort_keys_in_registers<4>(s_keys, cand, K); return; }
     for (int size = 2; size <= n2; size <<= 1) {
         for (int stride = size >> 1; stride > 0; stride >>= 1) {
             for (int t = tid; t < (n2 >> 1); t += kSelThreads) {
@@ -440,7 +560,16 @@ __global__ __launch_bounds__(kSelThreads) void proposal_sort_kernel(SelectArgs a
             __syncthreads();
         }
     }
-    decode_rows(a, img, s_keys);
+    for (int i = tid; i < K; i += kSelThreads) cand[i] = s_keys[i];
+}
+
+// decode + clip of the sorted winners on kDecodeWgs workgroups per image (inside the sort kernel: one workgroup per image,
+// six rows per thread one after the other, each behind three dependent loads)
+constexpr int kDecodeThreads = 256;
+__global__ __launch_bounds__(kDecodeThreads) void proposal_decode_kernel(SelectArgs a, char *__restrict__ ws)
+{
+    const int img = blockIdx.y;
+    decode_rows(a, img, ws_cand(ws, img), blockIdx.x * kDecodeThreads + threadIdx.x, gridDim.x * kDecodeThreads);
 }
 
 // proposals[b][j] = j < num[b] ? dets[b][keep[b][j]][0:4] / (h, w, h, w) : 0   (lib/layers.py:131-137)
@@ -485,6 +614,8 @@ int fi_proposal_candidates(const float *probs, int prob_stride, int prob_offset,
     a.A = num_anchors; a.E = num_extra; a.K = pre_nms; a.prob_stride = prob_stride; a.prob_off = prob_offset;
     a.std0 = bbox_std_host[0]; a.std1 = bbox_std_host[1]; a.std2 = bbox_std_host[2]; a.std3 = bbox_std_host[3];
     a.win_h = window_h; a.win_w = window_w;
+    static const int lds_sort = getenv("FI_PROPOSAL_LDS_SORT") != nullptr;
+    a.lds_sort = lds_sort;
     const size_t lds = sizeof(u64) * kSortCap;
     // the attribute belongs to the (function, device) pair: once per device of the process, from any thread
     static std::atomic<unsigned long long> attr_set{0};
@@ -524,6 +655,8 @@ int fi_proposal_candidates_ws(const float *probs, int prob_stride, int prob_offs
     a.A = num_anchors; a.E = num_extra; a.K = pre_nms; a.prob_stride = prob_stride; a.prob_off = prob_offset;
     a.std0 = bbox_std_host[0]; a.std1 = bbox_std_host[1]; a.std2 = bbox_std_host[2]; a.std3 = bbox_std_host[3];
     a.win_h = window_h; a.win_w = window_w;
+    static const int lds_sort = getenv("FI_PROPOSAL_LDS_SORT") != nullptr;
+    a.lds_sort = lds_sort;
     hipStream_t st = (hipStream_t)stream;
     char *ws = static_cast<char *>(workspace);
     const size_t lds = sizeof(u64) * kSortCap;
@@ -544,8 +677,10 @@ int fi_proposal_candidates_ws(const float *probs, int prob_stride, int prob_offs
         hipLaunchKernelGGL(proposal_hist_kernel, wide, dim3(kHistThreads), 0, st, a, ws, pass);
         hipLaunchKernelGGL(proposal_digit_kernel, dim3(batch), dim3(kSelThreads), 0, st, a, ws, pass);
     }
-    hipLaunchKernelGGL(proposal_compact_kernel, wide, dim3(kHistThreads), 0, st, a, ws);
+    hipLaunchKernelGGL(proposal_compact_kernel, dim3(kCompactWgs, batch), dim3(kHistThreads), 0, st, a, ws);
     hipLaunchKernelGGL(proposal_sort_kernel, dim3(batch), dim3(kSelThreads), lds, st, a, ws);
+    hipLaunchKernelGGL(proposal_decode_kernel, dim3((pre_nms + kDecodeThreads - 1) / kDecodeThreads, batch),
+                       dim3(kDecodeThreads), 0, st, a, ws);
     FI_HIP_CHECK(hipGetLastError());
     return FI_OK;
 }

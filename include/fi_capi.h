@@ -475,10 +475,11 @@ int fi_proposal_candidates(const float *probs, int prob_stride, int prob_offset,
                            const float *anchors, const float *extra, int batch, int num_anchors,
                            int num_extra, int pre_nms, const float *bbox_std_host, float window_h,
                            float window_w, float *dets, fi_stream_t stream);
-/* The same rows in eight small launches (round 6): the three radix passes and the compaction on 32 workgroups per image
- * with their state in `workspace` (fi_proposal_workspace_bytes(batch) bytes, 16-byte aligned, contents need not be
- * preserved or cleared between calls); sort + decode stay one workgroup per image.  fi_proposal_candidates is one
- * workgroup per image walking every score four times (4 workgroups on 256 CUs). */
+/* The same rows in nine small launches (round 6): the three radix passes on 32 workgroups per image, the compaction on 128
+ * (one pair of global atomics per workgroup), the sort of the winners with the keys in registers (one workgroup per image),
+ * decode + clip on 24 -- with their state in `workspace` (fi_proposal_workspace_bytes(batch) bytes, 16-byte aligned,
+ * contents need not be preserved or cleared between calls).  fi_proposal_candidates is one workgroup per image walking every
+ * score four times (4 workgroups on 256 CUs): 322 vs 102 us at 4 x 261 888 anchors. */
 size_t fi_proposal_workspace_bytes(int batch);
 int fi_proposal_candidates_ws(const float *probs, int prob_stride, int prob_offset, const float *deltas,
                               const float *anchors, const float *extra, int batch, int num_anchors, int num_extra,
