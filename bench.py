@@ -486,7 +486,20 @@ def issue_profile(step, dev, ms_per_step_unprofiled, steps=2):
                       "traced steps (torch.profiler); idle = un-profiled ms_per_step - busy" % steps}
 
 
-def graph_ab_two_images(model, opt, dev, image_size, train_step, steps=8):
+def graph_ab_child():
+    """`python bench.py --batch-per-gpu 2 --graph-ab-child` in a process of its own; its JSON line."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--batch-per-gpu", "2", "--graph-ab-child", "--no-cpu-baseline",
+           "--no-pmc", "--no-dense-reference", "--steps", "8", "--warmup", "3"]
+    try:
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=400)
+        lines = [l for l in r.stdout.decode("utf-8", "replace").splitlines() if l.startswith("{")]
+        return json.loads(lines[-1]) if lines else {"error": "no output (exit code %d)" % r.returncode}
+    except Exception as ex:
+        return {"error": repr(ex)}
+
+
+def graph_ab_two_images(model, opt, dev, image_size, train_step, steps=8, own_model=False, eager=None):
     """BASELINE configs[3]'s per-GPU shape (2 images) on this GPU, eager against ONE hipGraph replay of the whole step
     (possible because the step has no host synchronisation): ms/step and GPU idle time of both.  At 2 images the device step
     is ~60 ms against ~25 ms of host issue time; the replay takes the host out of the picture entirely."""
@@ -508,10 +521,15 @@ def graph_ab_two_images(model, opt, dev, image_size, train_step, steps=8):
         return (time.perf_counter() - t) / steps * 1e3
     out = {}
     try:
-        for _ in range(3):                  # (the caching allocator's pools are per stream: warm the one that is timed)
-            step2()
-        ms_e = timed(step2)
-        out["eager"] = dict(ms_per_step=round(ms_e, 3), **issue_profile(step2, dev, ms_e))
+        if eager is not None:               # the caller's timed region IS the eager leg (a 2-image process)
+            out["eager"] = eager
+            for _ in range(2):
+                step2()
+        else:
+            for _ in range(3):              # (the caching allocator's pools are per stream: warm the one that is timed)
+                step2()
+            ms_e = timed(step2)
+            out["eager"] = dict(ms_per_step=round(ms_e, 3), **issue_profile(step2, dev, ms_e))
         s = torch.cuda.Stream(device=dev)
         s.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(s):
@@ -539,7 +557,8 @@ def graph_ab_two_images(model, opt, dev, image_size, train_step, steps=8):
     except Exception as ex:           # a capture failure must not take the headline line with it
         out["error"] = repr(ex)
     model.external_proposals, model.generator = keep_ext, keep_gen
-    out["what"] = "2 images per GPU (BASELINE configs[3]'s per-rank shape) on one GPU: eager launches vs one hipGraph replay"
+    out["what"] = ("2 images per GPU (BASELINE configs[3]'s per-rank shape) on one GPU, in a process of its own "
+                   "(python bench.py --batch-per-gpu 2 --graph-ab-child): eager launches vs one hipGraph replay of the whole step")
     return out
 
 
@@ -688,6 +707,7 @@ def _main():
                     help="skip the host-issue / GPU-busy pass and the 2-image eager-vs-hipGraph A/B (runs traced from outside)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--pmc-child-roi", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--graph-ab-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--mask-head-on-positive-slots", action="store_true",
                     help="NOT the headline configuration: run the mask head only on the RoI slots that can hold "
                          "positives (identical loss/gradients, see MaskRCNN.forward); recorded in config.variant")
@@ -835,6 +855,13 @@ def _main():
             issue = issue_profile(step, dev, elapsed / args.steps * 1e3)
         except Exception as ex:
             issue = {"error": repr(ex)}
+    if args.graph_ab_child:
+        # (a process of its own for the 2-image eager / hipGraph comparison: the same numbers inside the 4-image run came
+        # out 6-15 ms slower for the eager leg than the dedicated `--batch-per-gpu 2` run -- allocator state of the other
+        # workloads of that process)
+        out = graph_ab_two_images(model, opt, dev, args.image_size, train_step, own_model=True,
+                                  eager=dict(ms_per_step=round(elapsed / args.steps * 1e3, 3), **(issue or {})))
+        return json.dumps(out)
     # ---- a separate profiled pass for the roofline objects (HIP events around every library kernel) --
     prof_steps = max(1, args.profile_steps)
     _lib.prof_reset()
@@ -924,7 +951,7 @@ def _main():
     graph_ab = None
     if world == 1 and sync is None and args.config == "cfg3" and not args.no_dense_reference and not args.dense_backward and \
             args.conv_precision == "fp32" and args.batch_per_gpu != 2 and not args.no_issue_profile:
-        graph_ab = graph_ab_two_images(model, opt, dev, args.image_size, train_step)
+        graph_ab = graph_ab_child()
     per_rank_ms, rccl_ranks, overlap = None, None, None
     if sync is not None and not share:
         # a further pass with HIP events around every bucket's collective: how much of the exchange hides in backward

@@ -180,26 +180,41 @@ __global__ __launch_bounds__(kThreads) void sinkhorn_kernel(const float *__restr
                 for (int c = 0; c < kT; ++c) s = fmaf(K[r][c], bv[c], s);
                 part[r] = s;
             }
-            // reduce over the 32 lanes sharing this row tile: DPP row shifts inside the 16-lane rows, then row_bcast:15 folds
-            // row 0 into row 1 (and 2 into 3) -- the sum lands in lane 31 of each half.  (Round 5 used five rounds of
-            // __shfl_xor = 40 ds_bpermute per half-iteration through the LDS crossbar.)
+            // Reduce over the 32 lanes that share this row tile, HALVING the values a lane carries at every step: the pair
+            // (lane, partner) splits its rows -- the lower lane keeps the first half and is sent the partner's, the
+            // upper lane the second half -- so 8 values need 4 + 2 + 1 exchanges (quad_perm xor 1, xor 2, ds_swizzle xor 4: partners
+            // always carry the same rows), then the one value left is folded by row_ror:8 and ds_swizzle xor 16.
+            // Every lane ends with the FULL sum of one row, r = 4*bit0 + 2*bit1 + bit2 of its lane number, and does ONE
+            // division.  (Before: five DPP steps on all 8 values, the sums in lane 31 only, which then did 8 divisions
+            // one after the other -- under an exec mask, so at the full cost for the wavefront: 136 instructions, now ~40.)
+            float v4[4], v2[2], v;
+            {
+                const bool up = lane & 1;
 #pragma unroll
-            for (int r = 0; r < kT; ++r) {
-                float v = part[r];
-                v += dpp_mov<0x111, 0xF>(v);      // row_shr:1
-                v += dpp_mov<0x112, 0xF>(v);      // row_shr:2
-                v += dpp_mov<0x114, 0xF>(v);      // row_shr:4
-                v += dpp_mov<0x118, 0xF>(v);      // row_shr:8
-                v += dpp_mov<0x142, 0xA>(v);      // row_bcast:15 into rows 1 and 3
-                part[r] = v;
-            }
-            if (tj == 31) {
-#pragma unroll
-                for (int r = 0; r < kT; ++r) {
-                    const int i = ti * kT + r;
-                    if (i < S) sm.a[i] = u / (part[r] + FI_OT_EPS);
+                for (int k = 0; k < 4; ++k) {
+                    const float keep = up ? part[k + 4] : part[k], send = up ? part[k] : part[k + 4];
+                    v4[k] = keep + dpp_mov<0xB1, 0xF>(send);          // quad_perm [1,0,3,2]
                 }
             }
+            {
+                const bool up = lane & 2;
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const float keep = up ? v4[k + 2] : v4[k], send = up ? v4[k] : v4[k + 2];
+                    v2[k] = keep + dpp_mov<0x4E, 0xF>(send);          // quad_perm [2,3,0,1]
+                }
+            }
+            {
+                const bool up = lane & 4;
+                const float keep = up ? v2[1] : v2[0], send = up ? v2[0] : v2[1];
+                v = keep + __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(send), 0x101F));   // lane ^ 4
+            }
+            v += dpp_mov<0x128, 0xF>(v);                              // row_ror:8 = lane ^ 8
+            v += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x401F));   // lane ^ 16
+            const int r = ((lane & 1) << 2) | (lane & 2) | ((lane >> 2) & 1);
+            const int i = ti * kT + r;
+            const float ai = u / (v + FI_OT_EPS);
+            if ((tj & 24) == 0 && i < S) sm.a[i] = ai;
         }
         __syncthreads();
         // ---- b = u / (K^T a + eps) -------------------------------------------------
