@@ -1444,7 +1444,13 @@ int backward_cl_impl(const LevelSetMut &ls, const float *grads, const float *box
     if (num_boxes == 0) return FI_OK;
     const int bins = crop_h * crop_w;
     const int cls = cl_size_class(crop_h, crop_w);
-    if (bins >= 100 && bins <= 220) {
+    // 7 x 7 crops: as many atomics as touched cells when a box is 14 cells wide, up to 3x more when it is 7 -- and the
+    // step's pyramid call (2048 jittered-GT boxes crowding the coarse levels) is bound by same-cell atomics: the gather form
+    // is 345 -> 282 us there, but 94 -> 115 us for 512 boxes on one map (profiles/r06_crop_bwd_gather_small.txt).
+    // FI_CROP_BWD_GATHER_SMALL=0 / 1 forces the choice.
+    static const char *gs_env = getenv("FI_CROP_BWD_GATHER_SMALL");
+    const bool gather_small = gs_env ? atoi(gs_env) != 0 : (ls.n > 1 && num_boxes >= 1024);
+    if ((bins >= 100 || gather_small) && bins <= 220) {
         // more bins than source cells per box: gather form, one atomic per touched cell
         const int chunks = fi::ceil_div(depth, kGatherCpb);
         const long nblk = (long)num_boxes * chunks;
