@@ -45,6 +45,37 @@ def test_threshold_tie_ge_vs_gt(oracle):
     assert pth_nms(t, 0.5, strict=True).cpu().tolist() == [0, 1, 2] == oracle.pth_nms(dets, 0.5, True).tolist()
 
 
+def test_thresholds_at_and_next_to_attained_ious(oracle):
+    """nms_mask_kernel decides a pair from inter * rcp(union) unless that lies within 2^-20 of the threshold, where it
+    takes the IEEE division the reference makes: thresholds EQUAL to an IoU the boxes attain, and one float above / below."""
+    from feature_intertwiner_amd.nms.pth_nms import pth_nms
+    rs = np.random.RandomState(31)
+    checked = 0
+    for trial in range(12):
+        dets = clustered_dets(rs, 96, 256, n_clusters=6, pixel_round=bool(trial & 1))
+        order = np.argsort(-dets[:, 4], kind="stable")
+        d = dets[order]
+        x1, y1, x2, y2 = d[:, 0], d[:, 1], d[:, 2], d[:, 3]
+        area = (x2 - x1 + np.float32(1)) * (y2 - y1 + np.float32(1))
+        ious = []
+        for i in range(0, 40, 3):
+            for j in range(i + 1, min(i + 6, 96)):
+                w = max(np.float32(0), min(x2[i], x2[j]) - max(x1[i], x1[j]) + np.float32(1))
+                h = max(np.float32(0), min(y2[i], y2[j]) - max(y1[i], y1[j]) + np.float32(1))
+                inter = np.float32(w * h)
+                if inter > 0:
+                    ious.append(np.float32(inter / np.float32(np.float32(area[i] + area[j]) - inter)))
+        t = torch.from_numpy(dets).to(DEV)
+        for iou in ious[:6]:
+            for thr in (iou, np.nextafter(iou, np.float32(2)), np.nextafter(iou, np.float32(0))):
+                for strict in (False, True):
+                    exp = oracle.pth_nms(dets, float(thr), strict)
+                    got = pth_nms(t, float(thr), strict=strict).cpu().numpy()
+                    assert np.array_equal(got, exp), (trial, float(thr), strict)
+                    checked += 1
+    assert checked >= 200
+
+
 def test_unsorted_input_and_duplicates(oracle):
     from feature_intertwiner_amd.nms.pth_nms import pth_nms
     rs = np.random.RandomState(77)
