@@ -83,3 +83,11 @@ ls -la $O | tail -8
 (timeout 100 python scripts/nms_scan_probe.py; FI_NMS_SCAN_NARROW=1 timeout 100 python scripts/nms_scan_probe.py) 2>&1 | grep "^{" > $O/${R}_nms_scan_probe.txt
 timeout 400 bash scripts/nms_exp.sh 2>&1 | grep "^EXP\|^{" >> $O/${R}_nms_scan_probe.txt
 hipcc --offload-arch=gfx950 -O3 -o /tmp/sclk_probe scripts/micro/sclk_probe.hip && /tmp/sclk_probe > $O/${R}_sclk_probe.txt 2>&1
+# proposal selection alone on the chip (default / all-LDS sort / single kernel) with its rocprofv3 rows; Sinkhorn; the 7x7
+# channels-last crop backward in both forms; the round's kernels switched off one group at a time at step level
+(python scripts/proposal_probe.py; FI_PROPOSAL_LDS_SORT=1 python scripts/proposal_probe.py; FI_PROPOSAL_MULTI_WG=0 python scripts/proposal_probe.py) 2>&1 | grep "^{" > $O/${R}_proposal_probe.txt
+rm -rf /tmp/pp; ( cd /tmp && timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pp -o p -- python $GRAFT_REPO_ROOT/scripts/proposal_probe.py > /dev/null 2>&1 )
+f=$(find /tmp/pp -name 'p_kernel_stats.csv' | head -1); grep -E "Name|proposal_|fill" $f | cut -c1-130 > $O/${R}_proposal_kernel_stats.csv
+timeout 200 python scripts/op_bench.py --ops sinkhorn 2>&1 | grep "^{" > $O/${R}_sinkhorn_probe.txt
+( echo "FI_CROP_BWD_GATHER_SMALL=0 python scripts/op_bench.py --ops nhwc"; FI_CROP_BWD_GATHER_SMALL=0 timeout 200 python scripts/op_bench.py --ops nhwc 2>&1 | grep "bwd"; echo "FI_CROP_BWD_GATHER_SMALL=1 python scripts/op_bench.py --ops nhwc"; FI_CROP_BWD_GATHER_SMALL=1 timeout 200 python scripts/op_bench.py --ops nhwc 2>&1 | grep "bwd" ) > $O/${R}_crop_bwd_gather_small.txt
+( cd $GRAFT_REPO_ROOT && bash scripts/ab_multi.sh 3 "X=1" "FI_NO_RING1X1=1" "FI_NMS_SCAN_NARROW=1 FI_PROPOSAL_MULTI_WG=0 FI_CROP_NO_C1=1" "FI_CROP_BWD_GATHER_SMALL=0" 2>&1 | grep -v amdgpu > $O/${R}_ab_round_kernels.txt )
